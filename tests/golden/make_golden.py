@@ -1,0 +1,256 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures in tests/golden/ from the REAL reference.
+
+Runs only in the build container: needs oracle/_ref/ (compiled from /root/reference by
+`make -C oracle ref`). Every expected output below is produced by the reference binary itself
+(`MALLOC_PERTURB_=255`) and canonicalised (heap-pointer fields zeroed).
+The committed artefacts are data only: inputs (.fqb / hand-built .hash) and expected outputs.
+
+    python tests/golden/make_golden.py
+
+Fixtures:
+  kat.json            KAT-1 constants (glibc random() => factor1) and KAT-2 mosh lists printed by the
+                      reference's own -DTEST seqhash main (k=16, w=32) for fixed sequences
+  tiny.fqb            hand-built 16-record file with the quirks: duplicated read (min-read rule),
+                      a barcode without any mosh (bogus hash-0 entry), a poly-A read, a hash shared
+                      between barcodes on opposite strands, and the trailing barcode that is dropped
+  small.fqb.gz        seeded synthetic linked reads (gen_fqb) small enough to commit
+  *.hash.gz           canonical reference outputs for the command lines in manifest.json
+  abort255.in.hash.gz hand-written state that drives codeClusterFind past 255 raw clusters
+  manifest.json       command lines + sha256 of every artefact, and digest-only cases for larger
+                      seeded sets that tests regenerate with gen_fqb
+"""
+import gzip
+import json
+import os
+import shutil
+import subprocess
+import sys
+import tempfile
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(HERE))
+import orc  # noqa: E402
+
+
+def gz_write(path, data):
+    with open(path, "wb") as raw:
+        with gzip.GzipFile(filename="", mode="wb", fileobj=raw, mtime=0, compresslevel=9) as f:
+            f.write(data)
+
+
+def ref(args, cwd):
+    r = orc.run_ref(args, cwd)
+    if r.returncode != 0:
+        raise RuntimeError("reference failed: %s\n%s" % (args, r.stderr.decode()))
+    return r.stdout.decode(), r.stderr.decode()
+
+
+def rand_codes(rng, n):
+    return rng.integers(0, 4, size=n, dtype=np.uint8)
+
+
+def revcomp(c):
+    return (3 - np.asarray(c, dtype=np.uint8))[::-1].copy()
+
+
+def build_tiny(rng):
+    o = orc.Oracle(k=21, w=31, seed=17, B=20)
+
+    def n_mosh(tail, r2):
+        rec = orc.make_record(1, tail, r2)
+        s1 = np.zeros(160, np.uint8)
+        s2 = np.zeros(160, np.uint8)
+        orc.lib().orc_unpack160(rec[0:10].ctypes.data, s1.ctypes.data)
+        orc.lib().orc_unpack160(rec[15:25].ctypes.data, s2.ctypes.data)
+        return len(o.mosh(s1[23:150])[0]) + len(o.mosh(s2[0:150])[0])
+
+    # a read pair without any mosh; ~1 in 2000 random pairs
+    while True:
+        t, r = rand_codes(rng, 135), rand_codes(rng, 151)
+        if n_mosh(t, r) == 0:
+            nomosh = (t, r)
+            break
+    pA0, pA2 = (rand_codes(rng, 135), rand_codes(rng, 151)), (rand_codes(rng, 135), rand_codes(rng, 151))
+    polyA = np.zeros(151, np.uint8)
+    recs = []
+    bcA, bcB, bcC, bcD, bcE = 0x01234567, 0x1B2D3F41, 0x6789ABCD, 0xA0A0F0F0, 0xFEDCBA98
+    # barcode A: read 0, an exact copy of it (every hash duplicated: the lower read index must win), read 2
+    recs += [orc.make_record(bcA, *pA0), orc.make_record(bcA, *pA0), orc.make_record(bcA, *pA2)]
+    # barcode B: single pair with no mosh at all
+    recs += [orc.make_record(bcB, *nomosh)]
+    # barcode C: poly-A read 2 (canonical hash 0 of AAAA..), a pair sharing read 2 with A's pair 2, two random
+    recs += [orc.make_record(bcC, rand_codes(rng, 135), polyA), orc.make_record(bcC, rand_codes(rng, 135), pA2[1]),
+             orc.make_record(bcC, rand_codes(rng, 135), rand_codes(rng, 151)),
+             orc.make_record(bcC, rand_codes(rng, 135), rand_codes(rng, 151))]
+    # barcode D: read 2 = reverse complement of A's read-0 read 2 (same canonical k-mers), then the no-mosh pair
+    recs += [orc.make_record(bcD, rand_codes(rng, 135), revcomp(pA0[1])), orc.make_record(bcD, *nomosh)]
+    # barcode E: three pairs, trailing => never hashed
+    recs += [orc.make_record(bcE, rand_codes(rng, 135), rand_codes(rng, 151)) for _ in range(3)]
+    # barcode F..: a few more single-pair barcodes so that -N truncation cases differ
+    recs += [orc.make_record(0xFFFF0000 + i, rand_codes(rng, 135), pA0[1]) for i in range(3)]
+    return np.stack(recs).astype(np.uint32)
+
+
+def build_abort255():
+    """600 hashes in barcode 1; each consecutive pair is also held by five private helper
+    barcodes => every second good hash founds a new raw cluster => 300 > 255 => abort path."""
+    B = 20
+    nh = 600
+    hash_number = nh + 1
+    hash_value = np.zeros(hash_number, np.uint64)
+    hash_value[1:] = (np.arange(1, hash_number, dtype=np.uint64) * np.uint64(2654435761)) * np.uint64(31)
+    hash_index = np.zeros(1 << B, np.uint32)
+    mask = (1 << B) - 1
+    for ix in range(1, hash_number):
+        h = int(hash_value[ix])
+        s, d = h & mask, ((h >> B) & mask) | 1
+        while hash_index[s]:
+            s = (s + d) & mask
+        hash_index[s] = ix
+    n_helpers = 5 * (nh // 2)
+    n_blocks = 1 + 1 + n_helpers            # slot 0 unused
+    depth_dim = 1 << 20
+    depth = np.zeros(depth_dim, np.uint32)
+    depth[1:hash_number] = 6
+    blocks = np.zeros(n_blocks, orc.BLOCK)
+    blocks["nRead"][1] = nh
+    blocks["nHash"][1] = nh
+    blocks["nRead"][2:] = 1
+    blocks["nHash"][2:] = 2
+    ch = np.zeros(nh + 2 * n_helpers, orc.CLUSHASH)
+    ch["hash"][:nh] = np.arange(1, nh + 1)
+    ch["read"][:nh] = np.arange(nh)
+    for m in range(nh // 2):
+        for j in range(5):
+            k = nh + 2 * (5 * m + j)
+            ch["hash"][k] = 2 * m + 1
+            ch["hash"][k + 1] = 2 * m + 2
+    out = bytearray()
+    out += b"10XH" + (2).to_bytes(4, "little") + (8).to_bytes(2, "little") + (32).to_bytes(2, "little")
+    out += B.to_bytes(4, "little") + hash_index.tobytes() + hash_number.to_bytes(4, "little") + hash_value.tobytes()
+    hdr = np.zeros(1, dtype="<i4,<i4,<u8,<i4,<i4,<i4,<i4")
+    hdr[0] = (8918274, 0, 0, depth_dim, 4, hash_number, 0)
+    out += hdr.tobytes() + depth.tobytes()
+    hdr[0] = (8918274, 0, 0, n_blocks, 32, n_blocks, 0)
+    out += hdr.tobytes() + blocks.tobytes() + ch.tobytes()
+    return bytes(out)
+
+
+def main():
+    if not orc.have_ref():
+        sys.exit("oracle/_ref/hash10x missing: run `make -C oracle ref` in the build container")
+    man = {"note": "generated by tests/golden/make_golden.py from oracle/_ref (reference compiled -O3, "
+                   "MALLOC_PERTURB_=255, pointer fields zeroed)", "cases": [], "digest_cases": []}
+    tmp = tempfile.mkdtemp(prefix="h10x_golden_")
+    rng = np.random.default_rng(20181227)
+
+    # ---------------- KAT-1 / KAT-2
+    kat = {"seed17_factor1": "0x%016x" % orc.lib().orc_factor1_from_seed(17),
+           "k21": {"mask": "0x%x" % ((1 << 42) - 1), "shift1": 22,
+                   "patternRC": ["0x%x" % ((3 - i) << 40) for i in range(4)]}}
+    seqs = ["".join("ACGT"[c] for c in rand_codes(rng, n)) for n in (151, 64, 40, 16, 15, 300)]
+    seqs.append("A" * 60)
+    seqs.append("ACGT" * 30)
+    fa = "".join(">s%d\n%s\n" % (i, s) for i, s in enumerate(seqs))
+    r = subprocess.run([os.path.join(orc.REF_DIR, "seqhash_test")], input=fa.encode(), stdout=subprocess.PIPE, check=True)
+    cur, table = None, []
+    for line in r.stdout.decode().splitlines():
+        if line.startswith("read sequence"):
+            cur = {"id": line.split()[2], "len": int(line.split()[-1]), "moshes": []}
+            table.append(cur)
+        elif line.startswith("\t"):
+            h, p, f = line.split()
+            cur["moshes"].append([h, int(p), f])
+    kat["seqhash_test_k16_w32_default_seed"] = {"sequences": seqs, "out": table}
+    with open(os.path.join(HERE, "kat.json"), "w") as f:
+        json.dump(kat, f, indent=1)
+
+    def add_case(name, inp, args, out_name):
+        """Run the reference with args (input/output file names relative to tmp) and store canonical out."""
+        ref(args, tmp)
+        data = orc.canonical_hash_bytes(open(os.path.join(tmp, out_name), "rb").read())
+        gz_write(os.path.join(HERE, out_name + ".gz"), data)
+        man["cases"].append({"name": name, "input": inp, "args": [str(a) for a in args], "output": out_name + ".gz",
+                             "sha256": orc.sha256(data)})
+        return data
+
+    # ---------------- tiny
+    tiny = build_tiny(rng)
+    tiny.tofile(os.path.join(HERE, "tiny.fqb"))
+    shutil.copy(os.path.join(HERE, "tiny.fqb"), os.path.join(tmp, "tiny.fqb"))
+    add_case("tiny.readfqb", "tiny.fqb", ["-B", 20, "--readFQB", "tiny.fqb", "--writeHash", "tiny.hash"], "tiny.hash")
+    add_case("tiny.N9", "tiny.fqb", ["-B", 20, "-N", 9, "--readFQB", "tiny.fqb", "--writeHash", "tiny.N9.hash"], "tiny.N9.hash")
+    add_case("tiny.N15.c2", "tiny.fqb", ["-B", 20, "-N", 15, "-c", 5, "--readFQB", "tiny.fqb", "--writeHash", "tiny.N15.hash"], "tiny.N15.hash")
+    add_case("tiny.k16w5", "tiny.fqb", ["-k", 16, "-w", 5, "-r", 3, "-B", 21, "--readFQB", "tiny.fqb", "--writeHash", "tiny.k16.hash"], "tiny.k16.hash")
+    add_case("tiny.k31w64", "tiny.fqb", ["-k", 31, "-w", 64, "-B", 20, "--readFQB", "tiny.fqb", "--writeHash", "tiny.k31.hash"], "tiny.k31.hash")
+    add_case("tiny.cluster", "tiny.hash.gz", ["-B", 20, "-ct", 1, "--readHash", "tiny.hash", "--hashDepthRange", 1, 4,
+                                               "--cluster", 1, 0, "--writeHash", "tiny.c.hash"], "tiny.c.hash")
+
+    # ---------------- small (committed input)
+    small = orc.gen_fqb(os.path.join(tmp, "small.fqb"), pairs=4000, barcodes=40, genome=40000, err=0.004, seed=11, mol=3.0, mol_len=2500)
+    gz_write(os.path.join(HERE, "small.fqb.gz"), small.tobytes())
+    add_case("small.readfqb", "small.fqb.gz", ["-B", 20, "--readFQB", "small.fqb", "--writeHash", "small.hash"], "small.hash")
+    for lo, hi, ct in ((3, 14, 2), (3, 12, 3), (2, 14, 5)):
+        nm = "small.c_%d_%d_%d.hash" % (lo, hi, ct)
+        add_case("small.cluster_%d_%d_ct%d" % (lo, hi, ct), "small.hash.gz",
+                 ["-B", 20, "-ct", ct, "--readHash", "small.hash", "--hashDepthRange", lo, hi, "--cluster", 1, 0,
+                  "--writeHash", nm], nm)
+    # accumulating ranges + partial code range + re-clustering an already clustered file
+    add_case("small.cluster_accum", "small.hash.gz",
+             ["-B", 20, "-ct", 2, "--readHash", "small.hash", "--hashDepthRange", 3, 5, "--hashDepthRange", 8, 12, "--cluster", 2, 30,
+              "--writeHash", "small.accum.hash"], "small.accum.hash")
+    add_case("small.recluster", "small.c_3_14_2.hash.gz",
+             ["-B", 20, "-ct", 3, "--readHash", "small.c_3_14_2.hash", "--hashDepthRange", 3, 14, "--cluster", 1, 0,
+              "--writeHash", "small.recluster.hash"], "small.recluster.hash")
+    add_case("small.split", "small.c_3_14_2.hash.gz",
+             ["-B", 20, "--readHash", "small.c_3_14_2.hash", "--clusterSplit", "--writeHash", "small.split.hash"], "small.split.hash")
+    # end-to-end in one invocation (readFQB -> range -> cluster), as the README recipe chains commands
+    add_case("small.e2e", "small.fqb.gz",
+             ["-B", 20, "-ct", 2, "--readFQB", "small.fqb", "--hashDepthRange", 3, 14, "--cluster", 1, 0, "--writeHash", "small.e2e.hash"],
+             "small.e2e.hash")
+
+    # ---------------- > 255 raw clusters: abort path (hash10x.c:810-816)
+    ab = build_abort255()
+    gz_write(os.path.join(HERE, "abort255.in.hash.gz"), ab)
+    open(os.path.join(tmp, "abort255.in.hash"), "wb").write(ab)
+    add_case("abort255", "abort255.in.hash.gz",
+             ["-B", 20, "--readHash", "abort255.in.hash", "--hashDepthRange", 2, 100, "--cluster", 1, 2,
+              "--writeHash", "abort255.out.hash"], "abort255.out.hash")
+
+    # ---------------- digest-only cases: inputs regenerated by gen_fqb (seeded), outputs pinned by sha256
+    def digest_case(name, gen, B, extra):
+        p = os.path.join(tmp, name + ".fqb")
+        recs = orc.gen_fqb(p, **gen)
+        pre = [a for a in extra[:2]] if extra and extra[0] == "-ct" else []
+        args = ["-B", B] + pre + ["--readFQB", name + ".fqb"] + extra[len(pre):] + ["--writeHash", name + ".hash"]
+        ref(args, tmp)
+        data = orc.canonical_hash_bytes(open(os.path.join(tmp, name + ".hash"), "rb").read())
+        hf = orc.HashFile(data)
+        man["digest_cases"].append({
+            "name": name, "gen": gen, "B": B, "args": [str(a) for a in extra], "input_sha256": orc.sha256(recs.tobytes()),
+            "sha256": orc.sha256(data), "size": len(data), "hash_number": hf.hash_number, "blocks_max": hf.blocks_max,
+            "sum_nHash": int(hf.blocks["nHash"].sum()), "sum_nSubCluster": int(hf.blocks["nSubCluster"].sum()),
+            "sum_pointToMin_hex": float(hf.blocks["pointToMin"].sum()).hex()})
+        os.remove(os.path.join(tmp, name + ".hash"))
+
+    digest_case("mid", dict(pairs=20000, barcodes=40, genome=1000000, err=0.005, seed=7, mol=10.0), 20, [])
+    digest_case("mid.c", dict(pairs=20000, barcodes=40, genome=1000000, err=0.005, seed=7, mol=10.0), 20,
+                ["-ct", 2, "--hashDepthRange", 3, 9, "--cluster", 1, 0])
+    digest_case("dense.c", dict(pairs=60000, barcodes=200, genome=400000, err=0.002, seed=5, mol=4.0), 20,
+                ["--hashDepthRange", 8, 40, "--cluster", 1, 0])
+    # a barcode with > 65535 unique hashes is ignored by clustering (hash10x.c:748-753)
+    digest_case("big65k.c", dict(pairs=36000, barcodes=3, genome=3000000, err=0.01, seed=3, mol=12.0), 20,
+                ["--hashDepthRange", 1, 3, "--cluster", 1, 0])
+
+    with open(os.path.join(HERE, "manifest.json"), "w") as f:
+        json.dump(man, f, indent=1)
+    shutil.rmtree(tmp)
+    tot = sum(os.path.getsize(os.path.join(HERE, x)) for x in os.listdir(HERE))
+    print("golden fixtures written: %d cases, %d digest cases, %.1f KiB total" % (len(man["cases"]), len(man["digest_cases"]), tot / 1024))
+
+
+if __name__ == "__main__":
+    main()
