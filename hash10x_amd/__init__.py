@@ -1,0 +1,221 @@
+"""hash10x_amd — MI355X (gfx950) implementation of hash10x's mosh-construction + clustering path.
+
+This package is plumbing only: a ctypes binding of the C session layer (hash10x_amd/host/,
+`libh10x_host.so`) which drives the HIP kernels through the C ABI of include/h10x.h
+(`libh10x_hip.so`). There is no Python or CPU compute path: if the native libraries are missing or
+no gfx950 device is present, construction fails loudly.
+
+`Hash10x` mirrors the reference's command surface (hash10x.c:1200-1269):
+    --readFQB -> read_fqb / read_fqb_file      --readHash  -> read_hash
+    --writeHash -> write_hash                  --hashDepthRange -> depth_range
+    --cluster -> cluster                       --clusterSplit -> cluster_split
+with -k -w -r -B -N -c -ct as constructor / method arguments.
+"""
+import ctypes
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_HIP_SO = os.path.join(_HERE, "libh10x_hip.so")
+_HOST_SO = os.path.join(_HERE, "libh10x_host.so")
+
+
+class Hash10xError(RuntimeError):
+    """Raised with the reference's die() text where the reference would have died."""
+
+
+class _Counters(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_uint64) for n in (
+        "pairs", "kmers", "entries", "distinct", "clustered_codes", "sum_good", "sum_good_depth",
+        "sum_hash_clustered", "fallback_blocks")]
+
+
+class _Sizes(ctypes.Structure):
+    _fields_ = [("B", ctypes.c_int32), ("hashNumber", ctypes.c_uint32), ("nBlocks", ctypes.c_uint32),
+                ("reserved", ctypes.c_uint32), ("nClusHash", ctypes.c_uint64), ("nRecords", ctypes.c_uint64)]
+
+
+_libs = None
+
+
+def load_native():
+    """Load libh10x_hip.so + libh10x_host.so (built in-tree by __graft_entry__.build()). No fallback."""
+    global _libs
+    if _libs is not None:
+        return _libs
+    for p in (_HIP_SO, _HOST_SO):
+        if not os.path.exists(p):
+            raise Hash10xError("native library %s is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                               "(hash10x_amd has no CPU fallback)" % p)
+    hip = ctypes.CDLL(_HIP_SO, mode=ctypes.RTLD_GLOBAL)
+    host = ctypes.CDLL(_HOST_SO, mode=ctypes.RTLD_GLOBAL)
+    vp, ci, cu64, cs = ctypes.c_void_p, ctypes.c_int, ctypes.c_uint64, ctypes.c_char_p
+    host.h10x_session_new.restype = vp
+    host.h10x_session_free.argtypes = [vp]
+    host.h10x_session_set.argtypes = [vp, cs, ci]
+    host.h10x_session_get.argtypes = [vp, cs]
+    host.h10x_session_error.restype = cs
+    host.h10x_session_error.argtypes = [vp]
+    host.h10x_session_ctx.restype = vp
+    host.h10x_session_ctx.argtypes = [vp]
+    host.h10x_session_readFQB.argtypes = [vp, cs]
+    host.h10x_session_readFQB_mem.argtypes = [vp, vp, cu64]
+    host.h10x_session_readFQB_dev.argtypes = [vp, vp, cu64]
+    host.h10x_session_readHash.argtypes = [vp, cs]
+    host.h10x_session_writeHash.argtypes = [vp, cs]
+    host.h10x_session_hashDepthRange.argtypes = [vp, ci, ci]
+    host.h10x_session_cluster.argtypes = [vp, ci, ci]
+    host.h10x_session_clusterSplit.argtypes = [vp]
+    host.h10x_host_array_dim.argtypes = [ci, ci, ctypes.c_int64]
+    host.h10x_host_check_chunks.restype = ctypes.c_int64
+    host.h10x_host_check_chunks.argtypes = [vp, cu64, ci, ci, cs, ci]
+    hip.h10x_device_count.restype = ci
+    hip.h10x_abi_version.restype = ci
+    hip.h10x_factor1_from_seed.restype = cu64
+    hip.h10x_factor1_from_seed.argtypes = [ctypes.c_int32]
+    hip.h10x_timing_enable.argtypes = [vp, ci]
+    hip.h10x_timing_count.argtypes = [vp]
+    hip.h10x_timing_name.restype = cs
+    hip.h10x_timing_name.argtypes = [vp, ci]
+    hip.h10x_timing_get.argtypes = [vp, ci, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(cu64)]
+    hip.h10x_timing_reset.argtypes = [vp]
+    hip.h10x_get_counters.argtypes = [vp, ctypes.POINTER(_Counters)]
+    hip.h10x_get_sizes.argtypes = [vp, ctypes.POINTER(_Sizes)]
+    hip.h10x_set_option.argtypes = [vp, cs, ctypes.c_int64]
+    hip.h10x_last_error.restype = cs
+    hip.h10x_last_error.argtypes = [vp]
+    hip.h10x_export.argtypes = [vp, vp, vp, vp, vp, vp]
+    _libs = (hip, host)
+    return _libs
+
+
+def device_count():
+    return load_native()[0].h10x_device_count()
+
+
+class Hash10x:
+    """One hash10x session on one GPU (the reference's process-global state, hash10x.c:85-104)."""
+
+    def __init__(self, k=21, w=31, r=17, B=28, device=0):
+        self._hip, self._host = load_native()
+        self._s = self._host.h10x_session_new()
+        if not self._s:
+            raise Hash10xError("out of memory")
+        for n, v in (("k", k), ("w", w), ("r", r), ("B", B), ("device", device)):
+            self._host.h10x_session_set(self._s, n.encode(), int(v))
+        self._timing = False
+
+    def close(self):
+        if getattr(self, "_s", None):
+            self._host.h10x_session_free(self._s)
+            self._s = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, rc):
+        if rc != 0:
+            raise Hash10xError(self._host.h10x_session_error(self._s).decode())
+
+    def _ctx(self):
+        return self._host.h10x_session_ctx(self._s)
+
+    def _after_init(self):
+        ctx = self._ctx()
+        if ctx and self._timing:
+            self._hip.h10x_timing_enable(ctx, 1)
+
+    # ---- commands ------------------------------------------------------------------------------
+    def _pre(self, N, chunk):
+        self._host.h10x_session_set(self._s, b"N", int(N))
+        self._host.h10x_session_set(self._s, b"c", int(chunk))
+
+    def read_fqb(self, records, N=0, chunk=100000):
+        """--readFQB on an in-memory image of the sorted .fqb file (30 uint32 per read pair)."""
+        r = np.ascontiguousarray(records, dtype=np.uint32).reshape(-1)
+        if r.size % 30:
+            r = r[: r.size - r.size % 30]
+        self._pre(N, chunk)
+        self._chk(self._host.h10x_session_readFQB_mem(self._s, r.ctypes.data, r.size // 30))
+        self._after_init()
+
+    def read_fqb_file(self, path, N=0, chunk=100000):
+        self._pre(N, chunk)
+        self._chk(self._host.h10x_session_readFQB(self._s, os.fsencode(path)))
+        self._after_init()
+
+    def read_fqb_device(self, dev_ptr, n_records, N=0):
+        """--readFQB with the records already resident in HBM (dev_ptr = device address)."""
+        self._pre(N, 100000)
+        self._chk(self._host.h10x_session_readFQB_dev(self._s, ctypes.c_void_p(dev_ptr), int(n_records)))
+        self._after_init()
+
+    def read_hash(self, path):
+        self._chk(self._host.h10x_session_readHash(self._s, os.fsencode(path)))
+        self._after_init()
+
+    def write_hash(self, path):
+        self._chk(self._host.h10x_session_writeHash(self._s, os.fsencode(path)))
+
+    def depth_range(self, lo, hi):
+        self._chk(self._host.h10x_session_hashDepthRange(self._s, int(lo), int(hi)))
+
+    def cluster(self, code_min=1, code_max=0, threshold=5):
+        self._host.h10x_session_set(self._s, b"ct", int(threshold))
+        self._chk(self._host.h10x_session_cluster(self._s, int(code_min), int(code_max)))
+
+    def cluster_split(self):
+        self._chk(self._host.h10x_session_clusterSplit(self._s))
+
+    # ---- measurement / test hooks ---------------------------------------------------------------
+    def enable_timing(self, on=True):
+        self._timing = bool(on)
+        self._host.h10x_session_set(self._s, b"timing", 1 if on else 0)
+        if self._ctx():
+            self._hip.h10x_timing_enable(self._ctx(), 1 if on else 0)
+
+    def set_option(self, name, value):
+        """Test knobs (e.g. stage_a_max_slots) forwarded to the context of the next read_fqb/read_hash."""
+        if self._host.h10x_session_set(self._s, name.encode(), int(value)):
+            raise Hash10xError(self._host.h10x_session_error(self._s).decode())
+
+    def timings(self):
+        ctx = self._ctx()
+        out = {}
+        if not ctx:
+            return out
+        for i in range(self._hip.h10x_timing_count(ctx)):
+            ms, n = ctypes.c_double(), ctypes.c_uint64()
+            self._hip.h10x_timing_get(ctx, i, ctypes.byref(ms), ctypes.byref(n))
+            out[self._hip.h10x_timing_name(ctx, i).decode()] = (ms.value, n.value)
+        return out
+
+    def reset_timings(self):
+        if self._ctx():
+            self._hip.h10x_timing_reset(self._ctx())
+
+    def counters(self):
+        c = _Counters()
+        if self._ctx():
+            self._hip.h10x_get_counters(self._ctx(), ctypes.byref(c))
+        return {n: int(getattr(c, n)) for n, _ in _Counters._fields_}
+
+    def sizes(self):
+        z = _Sizes()
+        if not self._ctx() or self._hip.h10x_get_sizes(self._ctx(), ctypes.byref(z)):
+            raise Hash10xError("no hash state loaded")
+        return {n: int(getattr(z, n)) for n, _ in _Sizes._fields_ if n != "reserved"}
+
+    def export_blocks(self):
+        """nBlocks ClusterBlock records as a structured array (for tests/bench sanity checks)."""
+        z = self.sizes()
+        dt = np.dtype([("nRead", "<u4"), ("nHash", "<u4"), ("nSubCluster", "<u4"), ("clusterParent", "<u4"),
+                       ("ptr", "<u8"), ("pointToMin", "<f8")])
+        b = np.zeros(z["nBlocks"], dtype=dt)
+        if self._hip.h10x_export(self._ctx(), None, None, None, b.ctypes.data, None):
+            raise Hash10xError(self._hip.h10x_last_error(self._ctx()).decode())
+        return b

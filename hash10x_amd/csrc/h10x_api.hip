@@ -1,0 +1,207 @@
+// h10x_api.hip — the C ABI of include/h10x.h over the stage drivers. No torch, no CPU fallback.
+#include "common.hpp"
+#include <cstdlib>
+#include <new>
+
+using namespace h10x;
+
+struct h10x_ctx { Ctx c; };
+
+extern "C" {
+
+int h10x_abi_version(void) { return H10X_ABI_VERSION; }
+
+int h10x_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+uint64_t h10x_factor1_from_seed(int32_t seed) {
+  // hash10x.c:1101 srandom(r); seqhash.c:29 (random() << 32) | random() | 0x01 — first draw is the high word
+  srandom((unsigned)seed);
+  const uint64_t hi = (uint64_t)random();
+  const uint64_t lo = (uint64_t)random();
+  return (hi << 32) | lo | 1;
+}
+
+static int create_fail(char *err, int errlen, const char *fmt, ...) {
+  if (err && errlen > 0) { va_list ap; va_start(ap, fmt); vsnprintf(err, (size_t)errlen, fmt, ap); va_end(ap); }
+  return -1;
+}
+
+int h10x_create(h10x_ctx **out, const h10x_params *p, int device, void *stream, char *err, int errlen) {
+  if (!out || !p) return create_fail(err, errlen, "h10x_create: null argument");
+  *out = nullptr;
+  // the reference's die() conditions (hash10x.c:1103,1107-1108; seqhash.c:24-25)
+  if (p->k <= 0 || p->w <= 0) return create_fail(err, errlen, "k %d, w %d must be > 0; run without args for usage", p->k, p->w);
+  if (p->k >= 32) return create_fail(err, errlen, "seqhash k %d must be between 1 and 32\n", p->k);
+  if (p->B < 20 || p->B > 30) return create_fail(err, errlen, "hashTableBits %d out of range 20-30", p->B);
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n <= 0)
+    return create_fail(err, errlen, "no HIP device available: libh10x_hip has no CPU fallback");
+  if (device < 0 || device >= n) return create_fail(err, errlen, "HIP device %d out of range 0..%d", device, n - 1);
+  if (hipSetDevice(device) != hipSuccess) return create_fail(err, errlen, "hipSetDevice(%d) failed", device);
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, device) != hipSuccess) return create_fail(err, errlen, "hipGetDeviceProperties failed");
+  if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+    return create_fail(err, errlen, "device %d is %s: this library is built for gfx950 (MI355X) only", device, prop.gcnArchName);
+  h10x_ctx *h = new (std::nothrow) h10x_ctx();
+  if (!h) return create_fail(err, errlen, "out of host memory");
+  h->c.prm = *p; h->c.device = device; h->c.stream = (hipStream_t)stream; h->c.numCU = prop.multiProcessorCount;
+  *out = h;
+  return 0;
+}
+
+void h10x_destroy(h10x_ctx *h) {
+  if (!h) return;
+  (void)hipSetDevice(h->c.device);
+  (void)hipStreamSynchronize(h->c.stream);
+  for (auto &t : h->c.timers) { if (t.a) (void)hipEventDestroy(t.a); if (t.b) (void)hipEventDestroy(t.b); }
+  delete h;
+}
+
+const char *h10x_last_error(const h10x_ctx *h) { return h ? h->c.err.c_str() : "null context"; }
+
+static void reset_state(Ctx &c) {
+  c.haveState = false; c.haveRange = false; c.haveGood = false; c.rangeMin = c.rangeMax = 0;
+  c.within.release(); c.goodPos.release(); c.nGood.release();
+  c.hashNumber = 1; c.nBlocks = 0; c.nEntries = 0; c.nRecords = 0;
+  memset(&c.ctr, 0, sizeof c.ctr);
+}
+
+int h10x_read_fqb_device(h10x_ctx *h, const uint32_t *dRec, uint64_t n) {
+  if (!h) return -1;
+  Ctx &c = h->c;
+  H10X_HIP(&c, hipSetDevice(c.device));
+  if (n && !dRec) return c.fail("h10x_read_fqb_device: null records");
+  reset_state(c);
+  DevBuf<u64> entHash; DevBuf<u32> entCode, entRead;
+  H10X_TRY(stageA_run(&c, dRec, n, entHash, entCode, entRead));
+  H10X_TRY(stageB_run(&c, entHash, entCode, entRead));
+  return 0;
+}
+
+int h10x_read_fqb(h10x_ctx *h, const uint32_t *hostRec, uint64_t n) {
+  if (!h) return -1;
+  Ctx &c = h->c;
+  H10X_HIP(&c, hipSetDevice(c.device));
+  if (n && !hostRec) return c.fail("h10x_read_fqb: null records");
+  DevBuf<u32> d;
+  H10X_HIP(&c, d.alloc(n * 30));
+  if (n) H10X_HIP(&c, hipMemcpyAsync(d.p, hostRec, n * 120, hipMemcpyHostToDevice, c.stream));
+  H10X_HIP(&c, hipStreamSynchronize(c.stream));
+  return h10x_read_fqb_device(h, d.p, n);
+}
+
+__global__ void block_offsets_kernel(const h10x_block *__restrict__ blocks, u32 nBlocks, u32 *__restrict__ nHash) {
+  const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i <= nBlocks) nHash[i] = (i >= 1 && i < nBlocks) ? blocks[i].nHash : 0;   // block 0 owns no clusHash (hash10x.c:256)
+}
+
+}  // extern "C"
+
+#include "prim.hpp"
+
+extern "C" {
+
+int h10x_load_state(h10x_ctx *h, const uint32_t *hashIndex, uint32_t hashNumber, const uint64_t *hashValue,
+                    const uint32_t *hashDepth, const h10x_block *blocks, uint32_t nBlocks, const h10x_clushash *clusHash) {
+  if (!h) return -1;
+  Ctx &c = h->c;
+  H10X_HIP(&c, hipSetDevice(c.device));
+  if (!hashIndex || !hashValue || !hashDepth || !blocks || nBlocks < 1 || hashNumber < 1) return c.fail("h10x_load_state: bad argument");
+  reset_state(c);
+  hipStream_t st = c.stream;
+  const u64 tableSize = (u64)1 << c.prm.B;
+  u64 H = 0;
+  for (u32 i = 1; i < nBlocks; ++i) H += blocks[i].nHash;
+  if (H >= (1ULL << 32)) return c.fail("%llu (barcode,hash) entries exceed this build's 2^32 per-GPU limit", (u64)H);
+  if (H && !clusHash) return c.fail("h10x_load_state: null clusHash");
+  c.hashNumber = hashNumber; c.nBlocks = nBlocks; c.nEntries = H;
+  H10X_HIP(&c, c.hashIndex.alloc(tableSize)); H10X_HIP(&c, c.hashValue.alloc(hashNumber)); H10X_HIP(&c, c.hashDepth.alloc(hashNumber));
+  H10X_HIP(&c, c.blocks.alloc(nBlocks)); H10X_HIP(&c, c.clusHash.alloc(H)); H10X_HIP(&c, c.blockOff.alloc((size_t)nBlocks + 1));
+  H10X_HIP(&c, hipMemcpyAsync(c.hashIndex.p, hashIndex, tableSize * 4, hipMemcpyHostToDevice, st));
+  H10X_HIP(&c, hipMemcpyAsync(c.hashValue.p, hashValue, (size_t)hashNumber * 8, hipMemcpyHostToDevice, st));
+  H10X_HIP(&c, hipMemcpyAsync(c.hashDepth.p, hashDepth, (size_t)hashNumber * 4, hipMemcpyHostToDevice, st));
+  H10X_HIP(&c, hipMemcpyAsync(c.blocks.p, blocks, (size_t)nBlocks * sizeof(h10x_block), hipMemcpyHostToDevice, st));
+  if (H) H10X_HIP(&c, hipMemcpyAsync(c.clusHash.p, clusHash, H * sizeof(h10x_clushash), hipMemcpyHostToDevice, st));
+  PrimTemp pt; DevBuf<u32> nh; H10X_HIP(&c, nh.alloc((size_t)nBlocks + 1));
+  block_offsets_kernel<<<divUp((u64)nBlocks + 1, 256), 256, 0, st>>>(c.blocks.p, nBlocks, nh.p);
+  H10X_TRY(prim_exclusive_scan_u32_u64(&c, pt, nh.p, c.blockOff.p, (size_t)nBlocks + 1));
+  H10X_HIP(&c, hipStreamSynchronize(st));
+  H10X_TRY(stageB_buildCSR(&c));                              // fillHashTable (hash10x.c:1210)
+  c.ctr.entries = H; c.ctr.distinct = hashNumber - 1;
+  c.haveState = true;
+  return 0;
+}
+
+int h10x_depth_range(h10x_ctx *h, int32_t lo, int32_t hi) {
+  if (!h) return -1;
+  H10X_HIP(&h->c, hipSetDevice(h->c.device));
+  return stageC_depthRange(&h->c, lo, hi);
+}
+
+int h10x_cluster(h10x_ctx *h, int32_t codeMin, int32_t codeMax, int32_t threshold) {
+  if (!h) return -1;
+  H10X_HIP(&h->c, hipSetDevice(h->c.device));
+  return stageC_cluster(&h->c, codeMin, codeMax, threshold);
+}
+
+int h10x_cluster_split(h10x_ctx *h) {
+  if (!h) return -1;
+  H10X_HIP(&h->c, hipSetDevice(h->c.device));
+  return stageC_split(&h->c);
+}
+
+int h10x_get_sizes(h10x_ctx *h, h10x_sizes *out) {
+  if (!h || !out) return -1;
+  Ctx &c = h->c;
+  if (!c.haveState) return c.fail("no hash state loaded: use readFQB or readHash first");
+  out->B = c.prm.B; out->hashNumber = c.hashNumber; out->nBlocks = c.nBlocks; out->reserved = 0;
+  out->nClusHash = c.nEntries; out->nRecords = c.nRecords;
+  return 0;
+}
+
+int h10x_export(h10x_ctx *h, uint32_t *hashIndex, uint64_t *hashValue, uint32_t *hashDepth, h10x_block *blocks, h10x_clushash *clusHash) {
+  if (!h) return -1;
+  Ctx &c = h->c;
+  H10X_HIP(&c, hipSetDevice(c.device));
+  if (!c.haveState) return c.fail("no hash state loaded: use readFQB or readHash first");
+  hipStream_t st = c.stream;
+  if (hashIndex) H10X_HIP(&c, hipMemcpyAsync(hashIndex, c.hashIndex.p, ((size_t)1 << c.prm.B) * 4, hipMemcpyDeviceToHost, st));
+  if (hashValue) H10X_HIP(&c, hipMemcpyAsync(hashValue, c.hashValue.p, (size_t)c.hashNumber * 8, hipMemcpyDeviceToHost, st));
+  if (hashDepth) H10X_HIP(&c, hipMemcpyAsync(hashDepth, c.hashDepth.p, (size_t)c.hashNumber * 4, hipMemcpyDeviceToHost, st));
+  if (blocks) H10X_HIP(&c, hipMemcpyAsync(blocks, c.blocks.p, (size_t)c.nBlocks * sizeof(h10x_block), hipMemcpyDeviceToHost, st));
+  if (clusHash && c.nEntries) H10X_HIP(&c, hipMemcpyAsync(clusHash, c.clusHash.p, c.nEntries * sizeof(h10x_clushash), hipMemcpyDeviceToHost, st));
+  H10X_HIP(&c, hipStreamSynchronize(st));
+  return 0;
+}
+
+int h10x_timing_enable(h10x_ctx *h, int on) { if (!h) return -1; h->c.timing = on != 0; return 0; }
+int h10x_timing_count(const h10x_ctx *) { return T_COUNT; }
+const char *h10x_timing_name(const h10x_ctx *, int i) { return (i >= 0 && i < T_COUNT) ? kTimerNames[i] : ""; }
+int h10x_timing_get(h10x_ctx *h, int i, double *ms, uint64_t *launches) {
+  if (!h || i < 0 || i >= T_COUNT) return -1;
+  h->c.flush((TimerId)i);
+  if (ms) *ms = h->c.timers[i].ms;
+  if (launches) *launches = h->c.timers[i].launches;
+  return 0;
+}
+int h10x_timing_reset(h10x_ctx *h) {
+  if (!h) return -1;
+  for (int i = 0; i < T_COUNT; ++i) { h->c.flush((TimerId)i); h->c.timers[i].ms = 0; h->c.timers[i].launches = 0; }
+  return 0;
+}
+int h10x_get_counters(h10x_ctx *h, h10x_counters *out) { if (!h || !out) return -1; *out = h->c.ctr; return 0; }
+
+int h10x_set_option(h10x_ctx *h, const char *name, int64_t value) {
+  if (!h || !name) return -1;
+  if (!strcmp(name, "stage_a_max_slots")) {
+    if (value && (value < 256 || value > 16384 || (value & (value - 1)))) return h->c.fail("stage_a_max_slots must be a power of two in 256..16384 (or 0)");
+    h->c.optMaxSlots = value; return 0;
+  }
+  return h->c.fail("unknown option %s", name);
+}
+
+}  // extern "C"

@@ -1,0 +1,58 @@
+// prim.hip — rocPRIM instantiations (device-wide radix sort, segmented sort, scans, reductions).
+#include "prim.hpp"
+#include <rocprim/rocprim.hpp>
+
+namespace h10x {
+
+#define PRIM_TWO_PHASE(c, t, CALL)                                                               \
+  do { size_t bytes = 0; void *tmp = nullptr;                                                    \
+       hipError_t e = (CALL);                                                                    \
+       if (e != hipSuccess) return (c)->fail("rocPRIM size query failed: %s", hipGetErrorName(e)); \
+       if (bytes > (t).buf.n) { e = (t).buf.alloc(bytes + (bytes >> 2));                         \
+         if (e != hipSuccess) return (c)->fail("out of device memory for %zu bytes of sort/scan scratch", bytes); } \
+       tmp = (t).buf.p;                                                                          \
+       e = (CALL);                                                                               \
+       if (e != hipSuccess) return (c)->fail("rocPRIM call failed: %s", hipGetErrorName(e)); } while (0)
+
+int prim_exclusive_scan_u32(Ctx *c, PrimTemp &t, const u32 *in, u32 *out, size_t n) {
+  if (!n) return 0;
+  PRIM_TWO_PHASE(c, t, rocprim::exclusive_scan(tmp, bytes, in, out, (u32)0, n, rocprim::plus<u32>(), c->stream));
+  return 0;
+}
+int prim_exclusive_scan_u32_u64(Ctx *c, PrimTemp &t, const u32 *in, u64 *out, size_t n) {
+  if (!n) return 0;
+  auto in64 = rocprim::make_transform_iterator(in, [] __device__(u32 v) -> u64 { return (u64)v; });
+  PRIM_TWO_PHASE(c, t, rocprim::exclusive_scan(tmp, bytes, in64, out, (u64)0, n, rocprim::plus<u64>(), c->stream));
+  return 0;
+}
+int prim_inclusive_scan_u32(Ctx *c, PrimTemp &t, const u32 *in, u32 *out, size_t n) {
+  if (!n) return 0;
+  PRIM_TWO_PHASE(c, t, rocprim::inclusive_scan(tmp, bytes, in, out, n, rocprim::plus<u32>(), c->stream));
+  return 0;
+}
+int prim_sort_pairs_u64_u32(Ctx *c, PrimTemp &t, const u64 *kin, u64 *kout, const u32 *vin, u32 *vout, size_t n, int b0, int b1) {
+  if (!n) return 0;
+  PRIM_TWO_PHASE(c, t, rocprim::radix_sort_pairs(tmp, bytes, kin, kout, vin, vout, n, (unsigned)b0, (unsigned)b1, c->stream));
+  return 0;
+}
+int prim_sort_pairs_u32_u32(Ctx *c, PrimTemp &t, const u32 *kin, u32 *kout, const u32 *vin, u32 *vout, size_t n, int b0, int b1) {
+  if (!n) return 0;
+  PRIM_TWO_PHASE(c, t, rocprim::radix_sort_pairs(tmp, bytes, kin, kout, vin, vout, n, (unsigned)b0, (unsigned)b1, c->stream));
+  return 0;
+}
+int prim_seg_sort_keys_u64(Ctx *c, PrimTemp &t, const u64 *kin, u64 *kout, u32 n, u32 nSeg, const u32 *begin, const u32 *end, int b0, int b1) {
+  if (!n || !nSeg) return 0;
+  PRIM_TWO_PHASE(c, t, rocprim::segmented_radix_sort_keys(tmp, bytes, kin, kout, n, nSeg, begin, end, (unsigned)b0, (unsigned)b1, c->stream));
+  return 0;
+}
+int prim_reduce_max_u32(Ctx *c, PrimTemp &t, const u32 *in, u32 *out, size_t n) {
+  PRIM_TWO_PHASE(c, t, rocprim::reduce(tmp, bytes, in, out, (u32)0, n, rocprim::maximum<u32>(), c->stream));
+  return 0;
+}
+int prim_reduce_sum_u32_u64(Ctx *c, PrimTemp &t, const u32 *in, u64 *out, size_t n) {
+  auto in64 = rocprim::make_transform_iterator(in, [] __device__(u32 v) -> u64 { return (u64)v; });
+  PRIM_TWO_PHASE(c, t, rocprim::reduce(tmp, bytes, in64, out, (u64)0, n, rocprim::plus<u64>(), c->stream));
+  return 0;
+}
+
+}  // namespace h10x

@@ -1,0 +1,407 @@
+// stage_a.hip — .fqb records -> per-barcode unique (mosh hash, lowest read) sets.
+//
+// Replaces unpackFQB + seqAddHashes + moshRCiterator/moshRCnext + the sort/dedup half of
+// processBlock (hash10x.c:108-132, 154-172; seqhash.c:58-80, 154-195) and readFQB's barcode run
+// detection (hash10x.c:212-220).
+//
+// MI355X design: one workgroup per barcode block. Packed 2-bit records are streamed from HBM into an
+// LDS tile; each lane owns one k-mer start position of a read pair (107 + 130 = 237 positions at
+// k = 21), rebuilds the forward word with a 64-bit funnel shift straight from the packed dwords and
+// the reverse-complement word with v_bfrev, multiplies both by factor1 and keeps the canonical
+// hash if it is divisible by w (modulo sampling, SURVEY F1 — there is no window minimum to select).
+// Survivors go into an open-addressing hash set in LDS holding (hash << 16 | read), inserted with
+// ds 64-bit cmpswap/min atomics, so duplicates inside a barcode collapse on chip and the lowest
+// read index wins. Only the unique set (≈ 6-8 entries per pair) is written back to HBM.
+// Blocks that cannot use the LDS set (k > 24, > 65535 pairs, or more unique hashes than the table
+// holds) take a global-memory path: raw slots in read order + stable device radix sort + unique.
+#include "common.hpp"
+#include "prim.hpp"
+
+namespace h10x {
+
+constexpr u64 EMPTY64 = ~0ULL;
+constexpr u32 NHASH_OVERFLOW = 0xFFFFFFFFu;
+constexpr int MOSH_THREADS = 256;
+constexpr int REC_TILE = 16;            // records staged per LDS tile
+constexpr int SEQ_WORDS = 12;           // 10 packed words + 2 pad words per read
+
+struct MoshConst {
+  int k, w, shift1;      // shift1 = 64 - 2k
+  int n1, n2;            // k-mers per read 1 (127 bases from base 23) and read 2 (150 bases)
+  u64 factor1;
+};
+
+// ------------------------------------------------------------------------------------------ helpers
+// 2k-bit big-endian word of bases [p, p+k) from MSB-first packed dwords (fq2b.c:33-42 layout;
+// the un-justified tail word is consumed as-is, which reproduces the 'A' padding of SURVEY F6)
+__device__ __forceinline__ u64 kmer_window(const u32 *seq, int p, int k) {
+  const int wi = p >> 4, s = (p & 15) * 2;
+  const u64 hi = ((u64)seq[wi] << 32) | (u64)seq[wi + 1];
+  const u32 lo = seq[wi + 2];
+  const u64 x = s ? ((hi << s) | (u64)(lo >> (32 - s))) : hi;
+  return x >> (64 - 2 * k);
+}
+
+// reverse complement of a 2k-bit word == what advanceHashRC accumulates in hRC (seqhash.c:75)
+__device__ __forceinline__ u64 revcomp_word(u64 x, int k) {
+  u64 r = __brevll(~x);                                     // reverse all bits of the complement
+  r = ((r & 0xAAAAAAAAAAAAAAAAULL) >> 1) | ((r & 0x5555555555555555ULL) << 1);  // un-swap bit pairs
+  return r >> (64 - 2 * k);
+}
+
+template <bool W31>
+__device__ __forceinline__ bool divisible(u64 h, int w) {
+  if (W31) {                                                // 2^30 == 1 (mod 31): fold then 32-bit modulo
+    const u32 s = (u32)(h & 0x3FFFFFFFu) + (u32)((h >> 30) & 0x3FFFFFFFu) + (u32)(h >> 60);
+    return (s % 31u) == 0;
+  }
+  return (h % (u64)w) == 0;
+}
+
+// canonical hash of k-mer slot t of the record staged at seq (24 words: read 1, read 2)
+template <bool W31>
+__device__ __forceinline__ bool mosh_of_slot(const u32 *seq, int t, const MoshConst &mc, u64 &h) {
+  int p; const u32 *s;
+  if (t < mc.n1) { p = 23 + t; s = seq; }                   // hash10x.c:162  &s1[23], 127 bases
+  else { p = t - mc.n1; s = seq + SEQ_WORDS; }               // hash10x.c:163  s2, 150 bases
+  const u64 f = kmer_window(s, p, mc.k);
+  const u64 r = revcomp_word(f, mc.k);
+  const u64 hf = (f * mc.factor1) >> mc.shift1;              // seqhash.c:58-59
+  const u64 hr = (r * mc.factor1) >> mc.shift1;
+  h = hf < hr ? hf : hr;                                     // seqhash.c:67-68
+  return divisible<W31>(h, mc.w);
+}
+
+// stage the 20 sequence words of `cnt` records (qualities skipped) into LDS, padded to 24 per record
+__device__ __forceinline__ void stage_records(const u32 *__restrict__ rec, u64 firstRec, int cnt, u32 *tile) {
+  for (int t = threadIdx.x; t < cnt * 20; t += blockDim.x) {
+    const int rr = t / 20, wi = t - rr * 20;
+    const u32 v = rec[(firstRec + rr) * 30 + (wi < 10 ? wi : wi + 5)];
+    tile[rr * 2 * SEQ_WORDS + (wi < 10 ? wi : wi + 2)] = v;
+  }
+}
+
+// ------------------------------------------------------------------------------------------ block runs
+__global__ void head_flags_kernel(const u32 *__restrict__ rec, u64 n, u32 *__restrict__ flags) {
+  u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  const u64 stride = (u64)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) flags[i] = (i == 0 || rec[i * 30] != rec[(i - 1) * 30]) ? 1u : 0u;
+}
+
+// code[i] = inclusive scan of flags = 1-based block number of record i
+__global__ void block_starts_kernel(const u32 *__restrict__ flags, const u32 *__restrict__ code, u64 n,
+                                    u64 *__restrict__ startRec /* nBlocks+1 */) {
+  u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  const u64 stride = (u64)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) if (flags[i]) startRec[code[i]] = i;
+}
+
+// per block: nRead, the LDS table size it gets (0 = global path), and its class list
+__global__ void classify_kernel(const u64 *__restrict__ startRec, u32 nBlocks, h10x_block *__restrict__ blocks,
+                                u32 *__restrict__ slots, u32 maxSlots, int packedOK,
+                                u32 *__restrict__ listS, u32 *__restrict__ listM, u32 *__restrict__ listF,
+                                u32 *__restrict__ counts /* 3 */, u32 smallSlots) {
+  const u32 c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= nBlocks) return;
+  h10x_block b; memset(&b, 0, sizeof b);
+  if (c == 0) { blocks[0] = b; slots[0] = 0; return; }
+  const u64 nr = startRec[c + 1] - startRec[c];
+  b.nRead = (u32)nr;
+  blocks[c] = b;
+  u32 s = 0;
+  if (c + 1 < nBlocks) {                                     // the last block is never hashed
+    u64 want = 256; while (want < nr * 12) want <<= 1;      // expected load <= 0.63 at 7.6 unique / pair
+    if (packedOK && nr <= 65535 && want <= maxSlots) {
+      s = (u32)want;
+      if (s <= smallSlots) listS[atomicAdd(&counts[0], 1u)] = c; else listM[atomicAdd(&counts[1], 1u)] = c;
+    } else listF[atomicAdd(&counts[2], 1u)] = c;
+  }
+  slots[c] = s;
+}
+
+// ------------------------------------------------------------------------------------------ LDS path
+// packed entry: hash << 16 | read   (needs 2k + 16 <= 64 and read <= 65535)
+__device__ __forceinline__ bool lds_set_insert(u64 *table, u32 mask, u64 hash, u32 read) {
+  const u64 packed = (hash << 16) | (u64)read;
+  u32 slot = (u32)((hash * 0x9E3779B97F4A7C15ULL) >> 40) & mask;
+  for (u32 probe = 0; probe <= mask; ++probe) {
+    u64 cur = *(volatile u64 *)&table[slot];
+    if (cur == EMPTY64) {
+      cur = atomicCAS((u64 *)&table[slot], EMPTY64, packed);
+      if (cur == EMPTY64) return true;
+    }
+    if ((cur >> 16) == hash) { atomicMin((u64 *)&table[slot], packed); return true; }
+    slot = (slot + 1) & mask;
+  }
+  return false;                                              // table full
+}
+
+template <bool W31>
+__global__ __launch_bounds__(MOSH_THREADS)
+void mosh_lds_kernel(const u32 *__restrict__ rec, const u32 *__restrict__ list, u32 nList,
+                     const u64 *__restrict__ startRec, const u32 *__restrict__ slots, const u64 *__restrict__ capOff,
+                     MoshConst mc, u64 *__restrict__ stHash, u32 *__restrict__ stRead, u32 *__restrict__ nHashOut) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  if (blockIdx.x >= nList) return;
+  const u32 code = list[blockIdx.x];
+  const u32 S = slots[code], mask = S - 1;
+  u64 *table = (u64 *)smem;
+  u32 *tile = (u32 *)(table + S);
+  __shared__ u32 sOverflow, sCount;
+  const u64 rec0 = startRec[code];
+  const u32 nRead = (u32)(startRec[code + 1] - rec0);
+  const int nk = mc.n1 + mc.n2;
+
+  for (u32 i = threadIdx.x; i < S; i += blockDim.x) table[i] = EMPTY64;
+  for (u32 i = threadIdx.x; i < REC_TILE * 2 * SEQ_WORDS; i += blockDim.x) tile[i] = 0;   // pad words stay 0
+  if (threadIdx.x == 0) { sOverflow = 0; sCount = 0; }
+
+  for (u32 r0 = 0; r0 < nRead; r0 += REC_TILE) {
+    const int cnt = (int)min((u32)REC_TILE, nRead - r0);
+    __syncthreads();
+    stage_records(rec, rec0 + r0, cnt, tile);
+    __syncthreads();
+    for (int rr = 0; rr < cnt; ++rr)
+      for (int t = threadIdx.x; t < nk; t += blockDim.x) {
+        u64 h;
+        if (mosh_of_slot<W31>(tile + rr * 2 * SEQ_WORDS, t, mc, h))
+          if (!lds_set_insert(table, mask, h, r0 + rr)) sOverflow = 1;
+      }
+  }
+  __syncthreads();
+
+  // compact the set to this block's staging slice (order inside a block is irrelevant downstream)
+  const u64 out0 = capOff[code];
+  const u32 cap = S - (S >> 3);                              // > 87.5 % full => treat as overflow
+  for (u32 base = 0; base < S; base += blockDim.x) {
+    const u32 i = base + threadIdx.x;
+    const u64 v = i < S ? table[i] : EMPTY64;
+    const bool valid = v != EMPTY64;
+    const u64 bal = __ballot(valid);
+    const int lane = threadIdx.x & (WAVE - 1);
+    u32 wbase = 0;
+    if (lane == 0 && bal) wbase = atomicAdd(&sCount, (u32)__popcll(bal));
+    wbase = __shfl(wbase, 0);
+    if (valid) {
+      const u32 pos = wbase + (u32)__popcll(bal & ((1ULL << lane) - 1));
+      if (pos < cap) { stHash[out0 + pos] = v >> 16; stRead[out0 + pos] = (u32)(v & 0xFFFF); }
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    u32 n = sCount;
+    if (sOverflow || n > cap) n = NHASH_OVERFLOW;
+    else if (n == 0) { stHash[out0] = 0; stRead[out0] = 0; n = 1; }   // hash10x.c:167-174 quirk
+    nHashOut[code] = n;
+  }
+}
+
+// ------------------------------------------------------------------------------------------ global path
+// raw slot (read r, k-mer t) -> key = canonical hash if it is a mosh, else all-ones; slots are in read
+// order, so a stable sort by key leaves the lowest read first in every run of equal hashes
+template <bool W31>
+__global__ __launch_bounds__(MOSH_THREADS)
+void mosh_raw_kernel(const u32 *__restrict__ rec, u64 rec0, u32 nRead, MoshConst mc, u64 *__restrict__ rawKey, u32 *__restrict__ rawSlot) {
+  __shared__ u32 tile[REC_TILE * 2 * SEQ_WORDS];
+  const int nk = mc.n1 + mc.n2;
+  for (u32 i = threadIdx.x; i < REC_TILE * 2 * SEQ_WORDS; i += blockDim.x) tile[i] = 0;
+  for (u32 r0 = blockIdx.x * REC_TILE; r0 < nRead; r0 += gridDim.x * REC_TILE) {
+    const int cnt = (int)min((u32)REC_TILE, nRead - r0);
+    __syncthreads();
+    stage_records(rec, rec0 + r0, cnt, tile);
+    __syncthreads();
+    for (int rr = 0; rr < cnt; ++rr)
+      for (int t = threadIdx.x; t < nk; t += blockDim.x) {
+        u64 h; const bool ok = mosh_of_slot<W31>(tile + rr * 2 * SEQ_WORDS, t, mc, h);
+        const u64 slot = (u64)(r0 + rr) * nk + t;
+        rawKey[slot] = ok ? h : EMPTY64;
+        rawSlot[slot] = (u32)slot;
+      }
+  }
+}
+
+__global__ void unique_flags_kernel(const u64 *__restrict__ key, u64 n, u32 *__restrict__ flags) {
+  u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  const u64 stride = (u64)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) flags[i] = (key[i] != EMPTY64 && (i == 0 || key[i] != key[i - 1])) ? 1u : 0u;
+}
+__global__ void unique_scatter_kernel(const u64 *__restrict__ key, const u32 *__restrict__ slot, const u32 *__restrict__ flags,
+                                      const u32 *__restrict__ pos, u64 n, u32 nk, u64 *__restrict__ outHash, u32 *__restrict__ outRead) {
+  u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  const u64 stride = (u64)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) if (flags[i]) { outHash[pos[i]] = key[i]; outRead[pos[i]] = slot[i] / nk; }
+}
+
+// ------------------------------------------------------------------------------------------ gather
+__global__ void set_nhash_kernel(h10x_block *__restrict__ blocks, const u32 *__restrict__ nHash, u32 nBlocks) {
+  const u32 c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c < nBlocks) blocks[c].nHash = nHash[c];
+}
+
+struct SrcPtr { const u64 *hash; const u32 *read; };
+
+__global__ void compact_entries_kernel(const u64 *__restrict__ stHash, const u32 *__restrict__ stRead, const u64 *__restrict__ capOff,
+                                       const SrcPtr *__restrict__ fb /* per block, null hash = staging */,
+                                       const u32 *__restrict__ nHash, const u64 *__restrict__ blockOff, u32 nBlocks,
+                                       u64 *__restrict__ entHash, u32 *__restrict__ entCode, u32 *__restrict__ entRead) {
+  for (u32 c = blockIdx.x + 1; c < nBlocks; c += gridDim.x) {
+    const u32 n = nHash[c]; if (!n) continue;
+    const u64 *sh; const u32 *sr;
+    if (fb[c].hash) { sh = fb[c].hash; sr = fb[c].read; } else { sh = stHash + capOff[c]; sr = stRead + capOff[c]; }
+    const u64 o = blockOff[c];
+    for (u32 i = threadIdx.x; i < n; i += blockDim.x) { entHash[o + i] = sh[i]; entCode[o + i] = c; entRead[o + i] = sr[i]; }
+  }
+}
+
+// ------------------------------------------------------------------------------------------ driver
+int stageA_run(Ctx *c, const u32 *dRec, u64 nRec, DevBuf<u64> &entHash, DevBuf<u32> &entCode, DevBuf<u32> &entRead) {
+  hipStream_t st = c->stream;
+  PrimTemp pt;
+  const int k = c->prm.k;
+  MoshConst mc; mc.k = k; mc.w = c->prm.w; mc.shift1 = 64 - 2 * k; mc.factor1 = c->prm.factor1;
+  mc.n1 = 127 - k + 1 > 0 ? 127 - k + 1 : 0;               // len < k => no k-mer (seqhash.c:162)
+  mc.n2 = 150 - k + 1 > 0 ? 150 - k + 1 : 0;
+  const bool w31 = c->prm.w == 31;
+
+  // ---- barcode runs (hash10x.c:212-220)
+  c->tstart(T_RUNS);
+  u32 nBlocks = 2;                                           // empty input: block 1 with nRead 0 (hash10x.c:200-201)
+  DevBuf<u64> startRec;
+  if (nRec) {
+    DevBuf<u32> flags, code;
+    H10X_HIP(c, flags.alloc(nRec)); H10X_HIP(c, code.alloc(nRec));
+    const unsigned g = (unsigned)hmin<u64>(divUp(nRec, 256), 65535u * 4);
+    head_flags_kernel<<<g, 256, 0, st>>>(dRec, nRec, flags.p);
+    H10X_TRY(prim_inclusive_scan_u32(c, pt, flags.p, code.p, nRec));
+    u32 nRuns = 0;
+    H10X_HIP(c, hipMemcpyAsync(&nRuns, code.p + (nRec - 1), 4, hipMemcpyDeviceToHost, st));
+    H10X_HIP(c, hipStreamSynchronize(st));
+    nBlocks = nRuns + 1;
+    H10X_HIP(c, startRec.alloc((size_t)nBlocks + 1));
+    H10X_HIP(c, hipMemsetAsync(startRec.p, 0, 8, st));
+    block_starts_kernel<<<g, 256, 0, st>>>(flags.p, code.p, nRec, startRec.p);
+    H10X_HIP(c, hipMemcpyAsync(startRec.p + nBlocks, &nRec, 8, hipMemcpyHostToDevice, st));
+    H10X_HIP(c, hipStreamSynchronize(st));                   // flags/code are released below
+  } else {
+    H10X_HIP(c, startRec.alloc(3));
+    H10X_HIP(c, hipMemsetAsync(startRec.p, 0, 24, st));
+  }
+  c->nBlocks = nBlocks; c->nRecords = nRec;
+  H10X_HIP(c, c->blocks.alloc(nBlocks));
+
+  // ---- classes
+  const u32 smallSlots = 4096;                               // 32 KB tables: several workgroups per CU
+  u32 maxSlots = 16384;                                      // 128 KB tables: one workgroup per CU
+  if (c->optMaxSlots > 0) maxSlots = (u32)c->optMaxSlots;
+  const int packedOK = (2 * k + 16 <= 64) ? 1 : 0;
+  DevBuf<u32> slots, listS, listM, listF, counts, nHash;
+  H10X_HIP(c, slots.alloc(nBlocks)); H10X_HIP(c, listS.alloc(nBlocks)); H10X_HIP(c, listM.alloc(nBlocks));
+  H10X_HIP(c, listF.alloc(nBlocks)); H10X_HIP(c, counts.alloc(4)); H10X_HIP(c, nHash.alloc((size_t)nBlocks + 1));
+  H10X_HIP(c, hipMemsetAsync(counts.p, 0, 16, st));
+  H10X_HIP(c, hipMemsetAsync(nHash.p, 0, ((size_t)nBlocks + 1) * 4, st));
+  classify_kernel<<<divUp(nBlocks, 256), 256, 0, st>>>(startRec.p, nBlocks, c->blocks.p, slots.p, maxSlots, packedOK,
+                                                      listS.p, listM.p, listF.p, counts.p, smallSlots < maxSlots ? smallSlots : maxSlots);
+  DevBuf<u64> capOff; H10X_HIP(c, capOff.alloc((size_t)nBlocks + 1));
+  H10X_TRY(prim_exclusive_scan_u32_u64(c, pt, slots.p, capOff.p, nBlocks));
+  u32 hc[4]; u64 capTotal = 0; u32 lastSlots = 0;
+  H10X_HIP(c, hipMemcpyAsync(hc, counts.p, 16, hipMemcpyDeviceToHost, st));
+  H10X_HIP(c, hipMemcpyAsync(&capTotal, capOff.p + (nBlocks - 1), 8, hipMemcpyDeviceToHost, st));
+  H10X_HIP(c, hipMemcpyAsync(&lastSlots, slots.p + (nBlocks - 1), 4, hipMemcpyDeviceToHost, st));
+  H10X_HIP(c, hipStreamSynchronize(st));
+  capTotal += lastSlots;
+  c->tstop(T_RUNS);
+
+  // ---- LDS path
+  DevBuf<u64> stHash; DevBuf<u32> stRead;
+  H10X_HIP(c, stHash.alloc(capTotal)); H10X_HIP(c, stRead.alloc(capTotal));
+  c->tstart(T_MOSH);
+  const size_t tileBytes = REC_TILE * 2 * SEQ_WORDS * 4;
+  for (int cls = 0; cls < 2; ++cls) {
+    const u32 n = hc[cls]; if (!n) continue;
+    const u32 *list = cls ? listM.p : listS.p;
+    const size_t lds = (size_t)(cls ? maxSlots : (smallSlots < maxSlots ? smallSlots : maxSlots)) * 8 + tileBytes;
+    if (w31) {
+      if (lds > 48 * 1024) H10X_HIP(c, hipFuncSetAttribute((const void *)mosh_lds_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      mosh_lds_kernel<true><<<n, MOSH_THREADS, lds, st>>>(dRec, list, n, startRec.p, slots.p, capOff.p, mc, stHash.p, stRead.p, nHash.p);
+    } else {
+      if (lds > 48 * 1024) H10X_HIP(c, hipFuncSetAttribute((const void *)mosh_lds_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      mosh_lds_kernel<false><<<n, MOSH_THREADS, lds, st>>>(dRec, list, n, startRec.p, slots.p, capOff.p, mc, stHash.p, stRead.p, nHash.p);
+    }
+    H10X_HIP(c, hipGetLastError());
+  }
+  c->tstop(T_MOSH);
+
+  // ---- global path: class F plus any block whose LDS set overflowed
+  std::vector<u32> hNHash(nBlocks + 1), hListF(hc[2]);
+  std::vector<u64> hStart(nBlocks + 1);
+  H10X_HIP(c, hipMemcpyAsync(hNHash.data(), nHash.p, (size_t)nBlocks * 4, hipMemcpyDeviceToHost, st));
+  H10X_HIP(c, hipMemcpyAsync(hStart.data(), startRec.p, ((size_t)nBlocks + 1) * 8, hipMemcpyDeviceToHost, st));
+  if (hc[2]) H10X_HIP(c, hipMemcpyAsync(hListF.data(), listF.p, (size_t)hc[2] * 4, hipMemcpyDeviceToHost, st));
+  H10X_HIP(c, hipStreamSynchronize(st));
+  for (u32 b = 1; b + 1 < nBlocks; ++b) if (hNHash[b] == NHASH_OVERFLOW) hListF.push_back(b);
+  std::vector<SrcPtr> hFb(nBlocks, SrcPtr{nullptr, nullptr});
+  std::vector<DevBuf<u64> *> keepH; std::vector<DevBuf<u32> *> keepR;
+  c->ctr.fallback_blocks = hListF.size();
+  if (!hListF.empty()) {
+    c->tstart(T_FALLBACK);
+    const u32 nk = (u32)(mc.n1 + mc.n2);
+    for (u32 b : hListF) {
+      const u32 nr = (u32)(hStart[b + 1] - hStart[b]);
+      const u64 nSlot = (u64)nr * nk;
+      DevBuf<u64> *oh = new DevBuf<u64>(); DevBuf<u32> *orr = new DevBuf<u32>(); keepH.push_back(oh); keepR.push_back(orr);
+      u32 nUniq = 0;
+      if (nSlot >= (1ULL << 32)) return c->fail("barcode block %u too large for the global mosh path (%llu k-mer slots)", b, (u64)nSlot);
+      if (nSlot) {
+        DevBuf<u64> k0, k1; DevBuf<u32> v0, v1, fl, ps;
+        H10X_HIP(c, k0.alloc(nSlot)); H10X_HIP(c, k1.alloc(nSlot)); H10X_HIP(c, v0.alloc(nSlot)); H10X_HIP(c, v1.alloc(nSlot));
+        H10X_HIP(c, fl.alloc(nSlot + 1)); H10X_HIP(c, ps.alloc(nSlot + 1));
+        const unsigned g = (unsigned)hmin<u64>(divUp(nr, REC_TILE), 4096);
+        if (w31) mosh_raw_kernel<true><<<g, MOSH_THREADS, 0, st>>>(dRec, hStart[b], nr, mc, k0.p, v0.p);
+        else     mosh_raw_kernel<false><<<g, MOSH_THREADS, 0, st>>>(dRec, hStart[b], nr, mc, k0.p, v0.p);
+        H10X_TRY(prim_sort_pairs_u64_u32(c, pt, k0.p, k1.p, v0.p, v1.p, nSlot, 0, 64));
+        const unsigned g2 = (unsigned)hmin<u64>(divUp(nSlot, 256), 65535);
+        unique_flags_kernel<<<g2, 256, 0, st>>>(k1.p, nSlot, fl.p);
+        H10X_HIP(c, hipMemsetAsync(fl.p + nSlot, 0, 4, st));
+        H10X_TRY(prim_exclusive_scan_u32(c, pt, fl.p, ps.p, nSlot + 1));
+        H10X_HIP(c, hipMemcpyAsync(&nUniq, ps.p + nSlot, 4, hipMemcpyDeviceToHost, st));
+        H10X_HIP(c, hipStreamSynchronize(st));
+        H10X_HIP(c, oh->alloc(nUniq ? nUniq : 1)); H10X_HIP(c, orr->alloc(nUniq ? nUniq : 1));
+        if (nUniq) unique_scatter_kernel<<<g2, 256, 0, st>>>(k1.p, v1.p, fl.p, ps.p, nSlot, nk, oh->p, orr->p);
+        H10X_HIP(c, hipStreamSynchronize(st));
+      } else { H10X_HIP(c, oh->alloc(1)); H10X_HIP(c, orr->alloc(1)); }
+      if (!nUniq) {                                           // no mosh in the whole block: one {hash 0, read 0} entry
+        H10X_HIP(c, hipMemsetAsync(oh->p, 0, 8, st)); H10X_HIP(c, hipMemsetAsync(orr->p, 0, 4, st)); nUniq = 1;
+      }
+      hNHash[b] = nUniq; hFb[b] = SrcPtr{oh->p, orr->p};
+    }
+    H10X_HIP(c, hipMemcpyAsync(nHash.p, hNHash.data(), (size_t)nBlocks * 4, hipMemcpyHostToDevice, st));
+    c->tstop(T_FALLBACK);
+  }
+
+  // ---- gather into one (block-ordered) entry list
+  c->tstart(T_COMPACT);
+  DevBuf<SrcPtr> dFb; H10X_HIP(c, dFb.alloc(nBlocks));
+  H10X_HIP(c, hipMemcpyAsync(dFb.p, hFb.data(), (size_t)nBlocks * sizeof(SrcPtr), hipMemcpyHostToDevice, st));
+  H10X_HIP(c, c->blockOff.alloc((size_t)nBlocks + 1));
+  H10X_TRY(prim_exclusive_scan_u32_u64(c, pt, nHash.p, c->blockOff.p, (size_t)nBlocks + 1));
+  u64 H = 0;
+  H10X_HIP(c, hipMemcpyAsync(&H, c->blockOff.p + nBlocks, 8, hipMemcpyDeviceToHost, st));
+  H10X_HIP(c, hipStreamSynchronize(st));
+  if (H >= (1ULL << 32)) return c->fail("%llu (barcode,hash) entries exceed this build's 2^32 per-GPU limit", (u64)H);
+  c->nEntries = H;
+  set_nhash_kernel<<<divUp(nBlocks, 256), 256, 0, st>>>(c->blocks.p, nHash.p, nBlocks);
+  H10X_HIP(c, entHash.alloc(H)); H10X_HIP(c, entCode.alloc(H)); H10X_HIP(c, entRead.alloc(H));
+  if (H) compact_entries_kernel<<<hmin<u32>(nBlocks, 8192), 256, 0, st>>>(stHash.p, stRead.p, capOff.p, dFb.p, nHash.p, c->blockOff.p, nBlocks,
+                                                                        entHash.p, entCode.p, entRead.p);
+  H10X_HIP(c, hipGetLastError());
+  H10X_HIP(c, hipStreamSynchronize(st));
+  c->tstop(T_COMPACT);
+  for (auto *p : keepH) delete p;
+  for (auto *p : keepR) delete p;
+
+  u64 hashedPairs = nBlocks >= 2 ? hStart[nBlocks - 1] : 0;  // all blocks but the last
+  c->ctr.pairs = nRec; c->ctr.kmers = hashedPairs * (u64)(mc.n1 + mc.n2); c->ctr.entries = H;
+  return 0;
+}
+
+}  // namespace h10x

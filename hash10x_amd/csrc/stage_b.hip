@@ -1,0 +1,216 @@
+// stage_b.hip — global hash <-> barcode index.
+//
+// Replaces the order-dependent half of processBlock (hashIndexFind(…,TRUE), ++hashDepth, the sort of
+// clusHash by index; hash10x.c:139-152, 174-183) and fillHashTable (hash10x.c:317-347) with an
+// order-independent formulation:
+//   index(h)   = 1 + rank of (first barcode containing h, h)   — what hashNumber++ yields serially
+//   hashDepth  = number of barcodes containing h
+//   hashCodes  = those barcodes in ascending order               (one CSR instead of U mallocs)
+//   hashIndex  = the open-addressing table sequential insertion in index order would leave behind:
+//                key i sits in the first slot of its probe sequence not held by a smaller index, which
+//                a parallel atomicMin-and-evict insertion reaches in any order.
+// Device-wide radix sorts/scans come from rocPRIM (prim.hip); everything else is hand-written.
+#include "common.hpp"
+#include "prim.hpp"
+
+namespace h10x {
+
+constexpr u32 SLOT_EMPTY = 0xFFFFFFFFu;
+
+// ------------------------------------------------------------------------------------------ distinct hashes
+__global__ void seg_head_flags_kernel(const u64 *__restrict__ sHash, u64 n, u32 *__restrict__ flags) {
+  u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  const u64 stride = (u64)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) flags[i] = (i == 0 || sHash[i] != sHash[i - 1]) ? 1u : 0u;
+}
+
+__global__ void seg_scatter_kernel(const u64 *__restrict__ sHash, const u32 *__restrict__ sCode, const u32 *__restrict__ flags,
+                                   const u32 *__restrict__ ord, u64 n, u64 *__restrict__ dHash, u32 *__restrict__ dFirst,
+                                   u32 *__restrict__ segStart, u32 *__restrict__ iota) {
+  u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  const u64 stride = (u64)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) if (flags[i]) {
+    const u32 d = ord[i];
+    dHash[d] = sHash[i]; dFirst[d] = sCode[i]; segStart[d] = (u32)i; iota[d] = d;
+  }
+}
+
+// i-th distinct hash in (firstBarcode, hash) order gets index i + 1
+__global__ void assign_index_kernel(const u32 *__restrict__ order, const u64 *__restrict__ dHash, const u32 *__restrict__ segStart,
+                                    u32 U, u64 *__restrict__ hashValue, u32 *__restrict__ hashDepth, u64 *__restrict__ rowStart) {
+  const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i == 0) { hashValue[0] = 0; hashDepth[0] = 0; rowStart[0] = 0; }
+  if (i >= U) return;
+  const u32 d = order[i];
+  hashValue[i + 1] = dHash[d];
+  hashDepth[i + 1] = segStart[d + 1] - segStart[d];
+  rowStart[i + 1] = segStart[d];
+}
+
+// ------------------------------------------------------------------------------------------ probe table
+// hash10x.c:139-152 probe sequence: start hash & mask, odd stride ((hash >> B) & mask) | 1
+__global__ void probe_insert_kernel(const u64 *__restrict__ hashValue, u32 hashNumber, int B, u32 *__restrict__ table) {
+  const u32 first = blockIdx.x * blockDim.x + threadIdx.x + 1;
+  const u64 mask = ((u64)1 << B) - 1;
+  for (u32 start = first; start < hashNumber; start += gridDim.x * blockDim.x) {
+    u32 cur = start;
+    u64 h = hashValue[cur];
+    u64 slot = h & mask, step = ((h >> B) & mask) | 1;
+    for (;;) {
+      const u32 old = atomicMin(&table[slot], cur);
+      if (old == SLOT_EMPTY) break;                          // took a free slot
+      if (old > cur) {                                       // evicted a later index: it continues from here
+        cur = old; h = hashValue[cur]; step = ((h >> B) & mask) | 1;
+      }
+      slot = (slot + step) & mask;
+    }
+  }
+}
+__global__ void probe_finish_kernel(u32 *__restrict__ table, u64 n) {
+  u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  const u64 stride = (u64)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) if (table[i] == SLOT_EMPTY) table[i] = 0;
+}
+
+__device__ __forceinline__ u32 probe_find(const u32 *__restrict__ table, const u64 *__restrict__ hashValue, int B, u64 h) {
+  const u64 mask = ((u64)1 << B) - 1;
+  u64 slot = h & mask; const u64 step = ((h >> B) & mask) | 1;
+  u32 ix;
+  while ((ix = table[slot]) && hashValue[ix] != h) slot = (slot + step) & mask;
+  return ix;
+}
+
+// ------------------------------------------------------------------------------------------ clusHash
+__global__ void lookup_pack_kernel(const u64 *__restrict__ entHash, const u32 *__restrict__ entRead, u64 n,
+                                   const u32 *__restrict__ table, const u64 *__restrict__ hashValue, int B, u64 *__restrict__ key) {
+  u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  const u64 stride = (u64)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) {
+    const u32 ix = probe_find(table, hashValue, B, entHash[i]);
+    key[i] = ((u64)ix << 32) | (u64)(entRead[i] & 0xFFFFu);  // ClusterHash.read is U16 (hash10x.c:37,180)
+  }
+}
+__global__ void offsets32_kernel(const u64 *__restrict__ off, u32 n, u32 *__restrict__ out) {
+  const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = (u32)off[i];
+}
+__global__ void write_clushash_kernel(const u64 *__restrict__ key, u64 n, h10x_clushash *__restrict__ out) {
+  u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  const u64 stride = (u64)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) {
+    const u64 v = key[i];
+    h10x_clushash c; c.hash = (u32)(v >> 32); c.read = (u16)(v & 0xFFFF); c.subCluster = 0; c.flags = 0;   // zeroed: SURVEY F4
+    out[i] = c;
+  }
+}
+
+static int bitsFor(u64 maxValue) { int b = 1; while (b < 64 && (maxValue >> b)) ++b; return b; }
+
+int stageB_run(Ctx *c, DevBuf<u64> &entHash, DevBuf<u32> &entCode, DevBuf<u32> &entRead) {
+  hipStream_t st = c->stream; PrimTemp pt;
+  const u64 H = c->nEntries; const int B = c->prm.B; const u32 nBlocks = c->nBlocks;
+  const unsigned gH = (unsigned)hmin<u64>(divUp(H ? H : 1, 256), 65535u * 2);
+  const u64 tableSize = (u64)1 << B;
+
+  // ---- sort all (hash, barcode) entries by hash; stable => barcodes ascending inside a hash
+  c->tstart(T_SORT_HASH);
+  DevBuf<u64> sHash; DevBuf<u32> sCode;
+  H10X_HIP(c, sHash.alloc(H)); H10X_HIP(c, sCode.alloc(H));
+  H10X_TRY(prim_sort_pairs_u64_u32(c, pt, entHash.p, sHash.p, entCode.p, sCode.p, H, 0, 2 * c->prm.k));
+  c->tstop(T_SORT_HASH);
+
+  // ---- distinct hashes, first barcode, depth
+  c->tstart(T_RANK);
+  u32 U = 0;
+  DevBuf<u64> dHash; DevBuf<u32> dFirst, segStart, iota, order, dFirstSorted;
+  {
+    DevBuf<u32> flags, ord;
+    H10X_HIP(c, flags.alloc(H + 1)); H10X_HIP(c, ord.alloc(H + 1));
+    if (H) seg_head_flags_kernel<<<gH, 256, 0, st>>>(sHash.p, H, flags.p);
+    H10X_HIP(c, hipMemsetAsync(flags.p + H, 0, 4, st));
+    H10X_TRY(prim_exclusive_scan_u32(c, pt, flags.p, ord.p, H + 1));
+    H10X_HIP(c, hipMemcpyAsync(&U, ord.p + H, 4, hipMemcpyDeviceToHost, st));
+    H10X_HIP(c, hipStreamSynchronize(st));
+    // hash10x.c:149: die once hashNumber exceeds 2^(B-2) - 2; hashNumber ends at U + 1
+    if ((u64)U + 1 > (tableSize >> 2) - 2) return c->fail("hashTableSize is too small");
+    H10X_HIP(c, dHash.alloc(U)); H10X_HIP(c, dFirst.alloc(U)); H10X_HIP(c, segStart.alloc((size_t)U + 1));
+    H10X_HIP(c, iota.alloc(U)); H10X_HIP(c, order.alloc(U)); H10X_HIP(c, dFirstSorted.alloc(U));
+    if (H) seg_scatter_kernel<<<gH, 256, 0, st>>>(sHash.p, sCode.p, flags.p, ord.p, H, dHash.p, dFirst.p, segStart.p, iota.p);
+    const u32 H32 = (u32)H;
+    H10X_HIP(c, hipMemcpyAsync(segStart.p + U, &H32, 4, hipMemcpyHostToDevice, st));
+    H10X_HIP(c, hipStreamSynchronize(st));
+  }
+  // distinct hashes are in ascending hash order; a stable sort by first barcode gives (first, hash) order
+  H10X_TRY(prim_sort_pairs_u32_u32(c, pt, dFirst.p, dFirstSorted.p, iota.p, order.p, U, 0, bitsFor(nBlocks)));
+  c->hashNumber = U + 1;
+  H10X_HIP(c, c->hashValue.alloc((size_t)U + 1)); H10X_HIP(c, c->hashDepth.alloc((size_t)U + 1));
+  H10X_HIP(c, c->rowStart.alloc((size_t)U + 2));
+  assign_index_kernel<<<divUp((u64)U + 1, 256), 256, 0, st>>>(order.p, dHash.p, segStart.p, U, c->hashValue.p, c->hashDepth.p, c->rowStart.p);
+  c->rows.swap(sCode);                                       // barcode lists, grouped by hash (ascending barcodes)
+  c->tstop(T_RANK);
+  sHash.release(); dHash.release(); dFirst.release(); iota.release(); dFirstSorted.release();
+
+  // ---- probe table
+  c->tstart(T_PROBE);
+  H10X_HIP(c, c->hashIndex.alloc(tableSize));
+  H10X_HIP(c, hipMemsetAsync(c->hashIndex.p, 0xFF, tableSize * 4, st));
+  if (U) probe_insert_kernel<<<hmin<u32>(divUp(U, 256), 16384), 256, 0, st>>>(c->hashValue.p, U + 1, B, c->hashIndex.p);
+  probe_finish_kernel<<<(unsigned)hmin<u64>(divUp(tableSize, 256), 65535u * 2), 256, 0, st>>>(c->hashIndex.p, tableSize);
+  c->tstop(T_PROBE);
+
+  // ---- clusHash: look every entry up, order each block by index (hash10x.c:177-183)
+  c->tstart(T_CLUSHASH);
+  H10X_HIP(c, c->clusHash.alloc(H));
+  if (H) {
+    DevBuf<u64> key, keyS; DevBuf<u32> off32;
+    H10X_HIP(c, key.alloc(H)); H10X_HIP(c, keyS.alloc(H)); H10X_HIP(c, off32.alloc((size_t)nBlocks + 1));
+    lookup_pack_kernel<<<gH, 256, 0, st>>>(entHash.p, entRead.p, H, c->hashIndex.p, c->hashValue.p, B, key.p);
+    offsets32_kernel<<<divUp((u64)nBlocks + 1, 256), 256, 0, st>>>(c->blockOff.p, nBlocks + 1, off32.p);
+    H10X_TRY(prim_seg_sort_keys_u64(c, pt, key.p, keyS.p, (u32)H, nBlocks, off32.p, off32.p + 1, 32, 32 + bitsFor(U + 1)));
+    write_clushash_kernel<<<gH, 256, 0, st>>>(keyS.p, H, c->clusHash.p);
+    H10X_HIP(c, hipGetLastError());
+    H10X_HIP(c, hipStreamSynchronize(st));
+  }
+  c->tstop(T_CLUSHASH);
+  c->ctr.distinct = U;
+  c->haveState = true;
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------ fillHashTable from clusHash
+__global__ void entry_code_kernel(const h10x_clushash *__restrict__ ch, const u64 *__restrict__ blockOff, u32 nBlocks,
+                                  u32 *__restrict__ keyIdx, u32 *__restrict__ valCode) {
+  for (u32 c = blockIdx.x + 1; c < nBlocks; c += gridDim.x) {
+    const u64 o = blockOff[c], n = blockOff[c + 1] - o;
+    for (u64 i = threadIdx.x; i < n; i += blockDim.x) { keyIdx[o + i] = ch[o + i].hash; valCode[o + i] = c; }
+  }
+}
+
+// hashCodes for the current clusHash + hashDepth (hash10x.c:317-347): stable sort of (index, barcode)
+int stageB_buildCSR(Ctx *c) {
+  hipStream_t st = c->stream; PrimTemp pt;
+  const u64 H = c->nEntries; const u32 U1 = c->hashNumber;
+  c->tstart(T_CSR);
+  H10X_HIP(c, c->rowStart.alloc((size_t)U1 + 1));
+  H10X_TRY(prim_exclusive_scan_u32_u64(c, pt, c->hashDepth.p, c->rowStart.p, U1));
+  u64 lastOff = 0; u32 lastDepth = 0;
+  if (U1) {
+    H10X_HIP(c, hipMemcpyAsync(&lastOff, c->rowStart.p + (U1 - 1), 8, hipMemcpyDeviceToHost, st));
+    H10X_HIP(c, hipMemcpyAsync(&lastDepth, c->hashDepth.p + (U1 - 1), 4, hipMemcpyDeviceToHost, st));
+    H10X_HIP(c, hipStreamSynchronize(st));
+  }
+  if (lastOff + lastDepth != H)
+    return c->fail("inconsistent hash state: sum of hashDepth %llu != %llu (barcode,hash) entries", (u64)(lastOff + lastDepth), (u64)H);
+  H10X_HIP(c, c->rows.alloc(H));
+  if (H) {
+    DevBuf<u32> k0, k1, v0;
+    H10X_HIP(c, k0.alloc(H)); H10X_HIP(c, k1.alloc(H)); H10X_HIP(c, v0.alloc(H));
+    entry_code_kernel<<<hmin<u32>(c->nBlocks, 8192), 256, 0, st>>>(c->clusHash.p, c->blockOff.p, c->nBlocks, k0.p, v0.p);
+    H10X_TRY(prim_sort_pairs_u32_u32(c, pt, k0.p, k1.p, v0.p, c->rows.p, H, 0, bitsFor(U1)));
+    H10X_HIP(c, hipStreamSynchronize(st));
+  }
+  c->tstop(T_CSR);
+  return 0;
+}
+
+}  // namespace h10x

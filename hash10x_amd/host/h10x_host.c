@@ -1,0 +1,255 @@
+/* h10x_host.c — see h10x_host.h. Plain C; links libh10x_hip.so. */
+#define _GNU_SOURCE
+#include "h10x_host.h"
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <stdarg.h>
+
+#define ARRAY_MAGIC 8918274                            /* array.h:56 */
+typedef struct { int32_t magic, pad0; uint64_t base; int32_t dim, size, max, pad1; } array_hdr;   /* array.h:41-50 */
+
+struct h10x_session {
+  int k, w, r, B, N, chunk, ct, device;                /* params (hash10x.c:25-33) */
+  int timing;                                          /* measurement hook: enable hipEvent timers on every new context */
+  int maxSlots;                                        /* test knob forwarded to h10x_set_option("stage_a_max_slots") */
+  h10x_ctx *ctx;
+  /* Array bookkeeping of the reference for the two arrays that are dumped raw into .hash */
+  int depthDim, depthMax, blocksDim, blocksMax;
+  uint32_t *depthTail; int depthTailFrom;              /* entries [hashNumber, dim) as read from a file (normally zero) */
+  char err[1024];
+};
+
+static int fail(h10x_session *s, const char *fmt, ...) {
+  va_list ap; va_start(ap, fmt); vsnprintf(s->err, sizeof s->err, fmt, ap); va_end(ap);
+  return -1;
+}
+static int fail_ctx(h10x_session *s) { snprintf(s->err, sizeof s->err, "%s", h10x_last_error(s->ctx)); return -1; }
+
+h10x_session *h10x_session_new(void) {
+  h10x_session *s = (h10x_session *)calloc(1, sizeof *s);
+  if (!s) return 0;
+  s->k = 21; s->w = 31; s->r = 17; s->B = 28; s->N = 0; s->chunk = 100000; s->ct = 5; s->device = 0;
+  s->blocksDim = 1200;                                 /* arrayCreate(1200, ClusterBlock), hash10x.c:1151 */
+  return s;
+}
+void h10x_session_free(h10x_session *s) {
+  if (!s) return;
+  if (s->ctx) h10x_destroy(s->ctx);
+  free(s->depthTail); free(s);
+}
+const char *h10x_session_error(const h10x_session *s) { return s->err; }
+h10x_ctx *h10x_session_ctx(h10x_session *s) { return s->ctx; }
+
+static int *param_slot(h10x_session *s, const char *n) {
+  if (!strcmp(n, "k")) return &s->k;
+  if (!strcmp(n, "w")) return &s->w;
+  if (!strcmp(n, "r")) return &s->r;
+  if (!strcmp(n, "B")) return &s->B;
+  if (!strcmp(n, "N")) return &s->N;
+  if (!strcmp(n, "c")) return &s->chunk;
+  if (!strcmp(n, "ct")) return &s->ct;
+  if (!strcmp(n, "device")) return &s->device;
+  if (!strcmp(n, "stage_a_max_slots")) return &s->maxSlots;
+  if (!strcmp(n, "timing")) return &s->timing;
+  return 0;
+}
+int h10x_session_set(h10x_session *s, const char *name, int value) {
+  int *p = param_slot(s, name); if (!p) return fail(s, "unknown parameter %s", name);
+  *p = value; return 0;
+}
+int h10x_session_get(const h10x_session *s, const char *name) {
+  int *p = param_slot((h10x_session *)s, name); return p ? *p : 0;
+}
+
+int h10x_host_array_dim(int dim, int size, int64_t last) {
+  while (last >= dim) {                                /* arrayExtend is entered with n == dim when touching in order */
+    if (dim * size < (1 << 23)) dim *= 2; else dim += 1024 + ((1 << 23) / size);
+  }
+  return dim;
+}
+
+int64_t h10x_host_check_chunks(const uint32_t *rec, uint64_t total, int N, int chunk, char *err, int errlen) {
+  int64_t nReads = 0; uint64_t pos = 0; uint32_t barcode = 0; int64_t curRead = 0;
+  while (!N || nReads < N) {
+    int64_t thisChunk = (int64_t)chunk - curRead;
+    if (thisChunk <= 0) { if (err) snprintf(err, errlen, "chunkSize too small"); return -1; }   /* hash10x.c:206 */
+    if (N && nReads + thisChunk > N) thisChunk = N - nReads;
+    uint64_t avail = total - pos;
+    int64_t nRec = avail < (uint64_t)thisChunk ? (int64_t)avail : thisChunk;
+    if (!nRec) break;
+    const uint32_t *u = rec + 30 * pos;
+    if (!barcode) barcode = u[0];
+    for (int64_t i = 0; i < nRec; ++i) {
+      if (u[30 * i] == barcode) ++curRead; else { curRead = 1; barcode = u[30 * i]; }
+    }
+    nReads += nRec; pos += (uint64_t)nRec;
+  }
+  return nReads;
+}
+
+/* initialise() (hash10x.c:1099-1118): a fresh context with the currently latched parameters */
+static int session_init(h10x_session *s) {
+  if (s->ctx) { h10x_destroy(s->ctx); s->ctx = 0; }
+  h10x_params p; memset(&p, 0, sizeof p);
+  p.k = s->k; p.w = s->w; p.B = s->B;
+  if (s->k > 0 && s->w > 0) p.factor1 = h10x_factor1_from_seed(s->r);
+  if (h10x_create(&s->ctx, &p, s->device, 0, s->err, (int)sizeof s->err)) return -1;
+  if (s->timing) h10x_timing_enable(s->ctx, 1);
+  if (s->maxSlots && h10x_set_option(s->ctx, "stage_a_max_slots", s->maxSlots)) return fail_ctx(s);
+  s->depthDim = 1 << 20; s->depthMax = 0;             /* arrayCreate(1 << 20, U32), hash10x.c:1114 */
+  free(s->depthTail); s->depthTail = 0;
+  return 0;
+}
+
+static void after_readFQB(h10x_session *s) {
+  h10x_sizes z; h10x_get_sizes(s->ctx, &z);
+  /* hashDepth: touched at indices 1 .. hashNumber-1 in ascending order of first touch (hash10x.c:178) */
+  if (z.hashNumber > 1) { s->depthDim = h10x_host_array_dim(1 << 20, 4, (int64_t)z.hashNumber - 1); s->depthMax = (int)z.hashNumber; }
+  else { s->depthDim = 1 << 20; s->depthMax = 0; }
+  /* clusterBlocks: arrayp(…,1) then one more per barcode (hash10x.c:200,218); main() creates it once */
+  s->blocksDim = h10x_host_array_dim(s->blocksDim > 0 ? s->blocksDim : 1200, 32, (int64_t)z.nBlocks - 1);
+  s->blocksMax = (int)z.nBlocks;
+}
+
+int h10x_session_readFQB_mem(h10x_session *s, const uint32_t *rec, uint64_t n) {
+  if (session_init(s)) return -1;
+  int64_t use = h10x_host_check_chunks(rec, n, s->N, s->chunk, s->err, (int)sizeof s->err);
+  if (use < 0) return -1;
+  if (h10x_read_fqb(s->ctx, rec, (uint64_t)use)) return fail_ctx(s);
+  after_readFQB(s);
+  return 0;
+}
+
+int h10x_session_readFQB_dev(h10x_session *s, const uint32_t *devRec, uint64_t n) {
+  if (session_init(s)) return -1;
+  if (s->N && (uint64_t)s->N < n) n = (uint64_t)s->N;
+  if (h10x_read_fqb_device(s->ctx, devRec, n)) return fail_ctx(s);
+  after_readFQB(s);
+  return 0;
+}
+
+int h10x_session_readFQB(h10x_session *s, const char *path) {
+  FILE *f = fopen(path, "rb");
+  if (!f) return fail(s, "failed to open fqb file %s", path);                      /* hash10x.c:1201 */
+  fseek(f, 0, SEEK_END); long long sz = ftell(f); fseek(f, 0, SEEK_SET);
+  uint64_t n = (uint64_t)sz / 120;                                                 /* fread(u,120,…) ignores a partial tail */
+  if (s->N && (uint64_t)s->N < n) n = (uint64_t)s->N;
+  uint32_t *rec = (uint32_t *)malloc(n ? n * 120 : 120);
+  if (!rec) { fclose(f); return fail(s, "myalloc failure requesting %lld bytes", sz); }
+  if (n && fread(rec, 120, n, f) != n) { fclose(f); free(rec); return fail(s, "file read problem"); }   /* hash10x.c:209 */
+  fclose(f);
+  int rc = h10x_session_readFQB_mem(s, rec, n);
+  free(rec);
+  return rc;
+}
+
+int h10x_session_hashDepthRange(h10x_session *s, int min, int max) {
+  if (!s->ctx) return fail(s, "no hash state loaded: use readFQB or readHash first");
+  return h10x_depth_range(s->ctx, min, max) ? fail_ctx(s) : 0;
+}
+int h10x_session_cluster(h10x_session *s, int codeMin, int codeMax) {
+  if (!s->ctx) return fail(s, "!! you must set hashDepthRange before cluster");
+  return h10x_cluster(s->ctx, codeMin, codeMax, s->ct) ? fail_ctx(s) : 0;
+}
+int h10x_session_clusterSplit(h10x_session *s) {
+  if (!s->ctx) return fail(s, "no hash state loaded: use readFQB or readHash first");
+  if (h10x_cluster_split(s->ctx)) return fail_ctx(s);
+  h10x_sizes z; h10x_get_sizes(s->ctx, &z);
+  s->blocksDim = s->blocksMax = (int)z.nBlocks;                                    /* arrayCreate(n) + arrayMax = n, hash10x.c:961-962 */
+  return 0;
+}
+
+/* writeHashFile (hash10x.c:244-267) + arrayWrite (array.c:213-218); heap-pointer fields are written as 0 */
+int h10x_session_writeHash(h10x_session *s, const char *path) {
+  if (!s->ctx) return fail(s, "no hash state loaded: use readFQB or readHash first");
+  h10x_sizes z; if (h10x_get_sizes(s->ctx, &z)) return fail_ctx(s);
+  const uint64_t T = (uint64_t)1 << z.B;
+  uint32_t *hashIndex = (uint32_t *)malloc(T * 4);
+  uint64_t *hashValue = (uint64_t *)malloc((size_t)z.hashNumber * 8);
+  uint32_t *depth = (uint32_t *)calloc((size_t)s->depthDim > z.hashNumber ? (size_t)s->depthDim : z.hashNumber, 4);
+  h10x_block *blocks = (h10x_block *)calloc((size_t)s->blocksDim > z.nBlocks ? (size_t)s->blocksDim : z.nBlocks, sizeof(h10x_block));
+  h10x_clushash *ch = (h10x_clushash *)malloc(z.nClusHash ? z.nClusHash * 8 : 8);
+  int rc = 0; FILE *f = 0;
+  if (!hashIndex || !hashValue || !depth || !blocks || !ch) { rc = fail(s, "out of host memory for .hash export"); goto done; }
+  if (h10x_export(s->ctx, hashIndex, hashValue, depth, blocks, ch)) { rc = fail_ctx(s); goto done; }
+  if (s->depthTail)                                                                 /* bytes beyond max travel unchanged from --readHash */
+    for (int i = s->depthTailFrom; i < s->depthDim; ++i) depth[i] = s->depthTail[i - s->depthTailFrom];
+  for (uint32_t i = 0; i < z.nBlocks; ++i) blocks[i].clusHash = 0;
+  if (!(f = fopen(path, "wb"))) { rc = fail(s, "failed to open hash file %s", path); goto done; }
+  {
+    uint32_t version = 2; uint16_t chs = 8, cbs = 32; int32_t B = z.B;
+    if (fwrite("10XH", 4, 1, f) != 1 || fwrite(&version, 4, 1, f) != 1 || fwrite(&chs, 2, 1, f) != 1 ||
+        fwrite(&cbs, 2, 1, f) != 1 || fwrite(&B, 4, 1, f) != 1) { rc = fail(s, "write fail 1"); goto done; }
+    if (fwrite(hashIndex, 4, T, f) != T) { rc = fail(s, "write fail 2"); goto done; }
+    if (fwrite(&z.hashNumber, 4, 1, f) != 1) { rc = fail(s, "failed to write hashNumber"); goto done; }
+    if (fwrite(hashValue, 8, z.hashNumber, f) != z.hashNumber) { rc = fail(s, "failed to write hashValue"); goto done; }
+    array_hdr h = {ARRAY_MAGIC, 0, 0, s->depthDim, 4, s->depthMax, 0};
+    if (fwrite(&h, 32, 1, f) != 1 || fwrite(depth, 4, (size_t)s->depthDim, f) != (size_t)s->depthDim) { rc = fail(s, "failed to write hashDepth array"); goto done; }
+    array_hdr hb = {ARRAY_MAGIC, 0, 0, s->blocksDim, 32, s->blocksMax, 0};
+    if (fwrite(&hb, 32, 1, f) != 1 || fwrite(blocks, 32, (size_t)s->blocksDim, f) != (size_t)s->blocksDim) { rc = fail(s, "failed to write clusterBlocks array"); goto done; }
+    if (z.nClusHash && fwrite(ch, 8, z.nClusHash, f) != z.nClusHash) { rc = fail(s, "write fail 3"); goto done; }
+  }
+done:
+  if (f) fclose(f);
+  free(hashIndex); free(hashValue); free(depth); free(blocks); free(ch);
+  return rc;
+}
+
+/* readHashFile (hash10x.c:269-315) + arrayRead (array.c:220-238), then the upload that replaces
+   fillHashTable's input state */
+int h10x_session_readHash(h10x_session *s, const char *path) {
+  FILE *f = fopen(path, "rb");
+  if (!f) return fail(s, "failed to open hash file %s", path);
+  if (session_init(s)) { fclose(f); return -1; }
+  int rc = 0;
+  char name[5] = {0}; uint32_t version = 0; uint16_t chs = 0, cbs = 0; int32_t B = 0;
+  uint32_t *hashIndex = 0, *depth = 0; uint64_t *hashValue = 0; h10x_block *blocks = 0; h10x_clushash *ch = 0;
+  uint32_t hashNumber = 0; array_hdr h, hb;
+  const uint64_t T = (uint64_t)1 << s->B;
+  if (fread(name, 4, 1, f) != 1 || fread(&version, 4, 1, f) != 1 || fread(&chs, 2, 1, f) != 1 || fread(&cbs, 2, 1, f) != 1) { rc = fail(s, "read fail 0"); goto done; }
+  if (strcmp(name, "10XH")) { rc = fail(s, "not a 10X hash file"); goto done; }
+  if (version > 2) { rc = fail(s, "hash file version mismatch: file %d > code %d", version, 2); goto done; }
+  if (chs != 8) { rc = fail(s, "ClusterHash structure size mismatch: file %d != code %d", chs, 8); goto done; }
+  if (cbs != 32) { rc = fail(s, "ClusterBlock structure size mismatch: file %d != code %d", cbs, 32); goto done; }
+  if (fread(&B, 4, 1, f) != 1) { rc = fail(s, "read fail 1"); goto done; }
+  if (B != s->B) { rc = fail(s, "incompatible hash table size: rerun with -B %d", B); goto done; }
+  hashIndex = (uint32_t *)malloc(T * 4);
+  if (!hashIndex || fread(hashIndex, 4, T, f) != T) { rc = fail(s, "read fail 2"); goto done; }
+  if (version == 1) {                                                               /* hashValue stored as an Array */
+    if (fread(&h, 32, 1, f) != 1 || h.dim < h.max || h.max < 0) { rc = fail(s, "failed to read hashValue array"); goto done; }
+    hashValue = (uint64_t *)malloc((size_t)h.dim * 8 + 8);
+    if (!hashValue || fread(hashValue, 8, (size_t)h.dim, f) != (size_t)h.dim) { rc = fail(s, "failed to read hashValue array"); goto done; }
+    hashNumber = (uint32_t)h.max;
+  } else {
+    if (fread(&hashNumber, 4, 1, f) != 1) { rc = fail(s, "failed to read hashNumber"); goto done; }
+    if (hashNumber > (T >> 2)) { rc = fail(s, "failed to read hashValue"); goto done; }
+    hashValue = (uint64_t *)malloc((size_t)hashNumber * 8 + 8);
+    if (!hashValue || fread(hashValue, 8, hashNumber, f) != hashNumber) { rc = fail(s, "failed to read hashValue"); goto done; }
+  }
+  if (fread(&h, 32, 1, f) != 1 || h.size != 4 || h.dim < 0) { rc = fail(s, "failed to read hashDepth array"); goto done; }
+  depth = (uint32_t *)calloc((size_t)(h.dim > (int)hashNumber ? h.dim : (int)hashNumber) + 1, 4);
+  if (!depth || fread(depth, 4, (size_t)h.dim, f) != (size_t)h.dim) { rc = fail(s, "failed to read hashDepth array"); goto done; }
+  if (fread(&hb, 32, 1, f) != 1 || hb.size != 32 || hb.dim < hb.max || hb.max < 1) { rc = fail(s, "failed to read clusterBlocks array"); goto done; }
+  blocks = (h10x_block *)calloc((size_t)hb.dim + 1, 32);
+  if (!blocks || fread(blocks, 32, (size_t)hb.dim, f) != (size_t)hb.dim) { rc = fail(s, "failed to read clusterBlocks array"); goto done; }
+  {
+    uint64_t nCh = 0;
+    for (int i = 1; i < hb.max; ++i) nCh += blocks[i].nHash;
+    ch = (h10x_clushash *)malloc(nCh ? nCh * 8 : 8);
+    if (!ch || (nCh && fread(ch, 8, nCh, f) != nCh)) { rc = fail(s, "read fail 3"); goto done; }
+    if (hashNumber < 1) hashNumber = 1;
+    if (h10x_load_state(s->ctx, hashIndex, hashNumber, hashValue, depth, blocks, (uint32_t)hb.max, ch)) { rc = fail_ctx(s); goto done; }
+  }
+  s->depthDim = h.dim; s->depthMax = h.max; s->blocksDim = hb.dim; s->blocksMax = hb.max;
+  free(s->depthTail); s->depthTail = 0;
+  if (h.dim > (int)hashNumber) {                                                    /* keep the bytes the file carries beyond hashNumber */
+    s->depthTailFrom = (int)hashNumber;
+    s->depthTail = (uint32_t *)malloc((size_t)(h.dim - (int)hashNumber) * 4);
+    memcpy(s->depthTail, depth + hashNumber, (size_t)(h.dim - (int)hashNumber) * 4);
+  }
+done:
+  fclose(f);
+  free(hashIndex); free(hashValue); free(depth); free(blocks); free(ch);
+  return rc;
+}

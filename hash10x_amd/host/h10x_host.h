@@ -1,0 +1,48 @@
+/* h10x_host.h — host side of the hash10x command surface, in C, above the C ABI of include/h10x.h.
+ *
+ * A session holds what the reference keeps in globals (hash10x.c:25-33, 85-104): the latched
+ * parameters, the device context, and the Array bookkeeping (dim/max of hashDepth and
+ * clusterBlocks, array.c:144-170) that decides bytes of the .hash file. Each function is one
+ * command of the reference's argv loop (hash10x.c:1200-1269); hash10x_main.c is that loop.
+ * All compute goes through libh10x_hip.so — there is no CPU path here.
+ */
+#ifndef H10X_HOST_H
+#define H10X_HOST_H
+#include <stdint.h>
+#include "../../include/h10x.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct h10x_session h10x_session;
+
+h10x_session *h10x_session_new(void);                 /* defaults of hash10x.c:1131-1137 */
+void h10x_session_free(h10x_session *s);
+/* -k -w -r -B -N -c -ct (hash10x.c:1174-1179,1239) plus "device" (HIP ordinal); latched until the
+   next readFQB/readHash like the reference */
+int  h10x_session_set(h10x_session *s, const char *name, int value);
+int  h10x_session_get(const h10x_session *s, const char *name);
+const char *h10x_session_error(const h10x_session *s);
+h10x_ctx *h10x_session_ctx(h10x_session *s);
+
+int  h10x_session_readFQB(h10x_session *s, const char *path);                         /* hash10x.c:1200-1205 */
+int  h10x_session_readFQB_mem(h10x_session *s, const uint32_t *records, uint64_t nRecords);
+int  h10x_session_readFQB_dev(h10x_session *s, const uint32_t *devRecords, uint64_t nRecords);  /* records already in HBM */
+int  h10x_session_readHash(h10x_session *s, const char *path);                        /* hash10x.c:1206-1211 */
+int  h10x_session_writeHash(h10x_session *s, const char *path);                       /* hash10x.c:1212-1215 */
+int  h10x_session_hashDepthRange(h10x_session *s, int min, int max);                  /* hash10x.c:1216-1219 */
+int  h10x_session_cluster(h10x_session *s, int codeMin, int codeMax);                 /* hash10x.c:1241-1261 */
+int  h10x_session_clusterSplit(h10x_session *s);                                      /* hash10x.c:1267 */
+
+/* dimension the reference's Array reaches when elements are first touched in ascending order up to
+   lastIndex, starting from initialDim (array.c:144-185) */
+int  h10x_host_array_dim(int initialDim, int elemSize, int64_t lastIndex);
+/* readFQB's chunk loop (hash10x.c:202-223) replayed on the barcode column: returns the number of
+   records it would consume (honours -N), or -1 with "chunkSize too small" in err */
+int64_t h10x_host_check_chunks(const uint32_t *records, uint64_t nRecords, int N, int chunkSize, char *err, int errlen);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

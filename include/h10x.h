@@ -1,0 +1,141 @@
+/* h10x.h — C ABI of libh10x_hip.so: the MI355X (gfx950) implementation of hash10x's
+ * mosh-construction + per-barcode clustering path.
+ *
+ * The reference (richarddurbin/hash10x) has no library/FFI boundary: its seams are global-state C
+ * functions called from main()'s argv loop (hash10x.c:1158-1279). Each entry point below replaces
+ * one of those seams and cites it. A maintainer of the reference would call these from the same
+ * places in hash10x.c (see INTEGRATION.md for the exact stub); our own C host program
+ * (hash10x_amd/host/hash10x_main.c) does exactly that behind the reference's command surface.
+ *
+ * Conventions: every function returns 0 on success, non-zero on failure; h10x_last_error() then
+ * returns the message — the reference's own die() text (utils.c:18-29) where the reference would
+ * have died (e.g. "hashTableSize is too small"). Plain pointers and sizes only; host pointers are
+ * caller-owned; device memory is owned by the context. One host thread per context (the reference
+ * is single-threaded at this boundary; its OMP loop lives inside --cluster, as our kernels do).
+ * There is NO CPU fallback: without a HIP device h10x_create() fails.
+ */
+#ifndef H10X_H
+#define H10X_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define H10X_ABI_VERSION 1
+
+typedef struct h10x_ctx h10x_ctx;
+
+/* hasher + table parameters latched by -k -w -r -B (hash10x.c:1131-1134, 1174-1177) */
+typedef struct {
+  int32_t  k;          /* k-mer length, 1..31                      (seqhash.c:24)            */
+  int32_t  w;          /* mosh modulus, >= 1                       (seqhash.c:25) */
+  int32_t  B;          /* hash index table bits, 20..30            (hash10x.c:1107-1108)     */
+  int32_t  reserved;
+  uint64_t factor1;    /* multiplier of hashFunc (seqhash.c:29,58-59): h10x_factor1_from_seed(r) */
+} h10x_params;
+
+/* == ClusterBlock (hash10x.c:62-70), 32 bytes; clusHash is a heap pointer in the reference and is
+   always written as 0 by this library (canonical form) */
+typedef struct {
+  uint32_t nRead, nHash, nSubCluster, clusterParent;
+  uint64_t clusHash;
+  double   pointToMin;
+} h10x_block;
+
+/* == ClusterHash (hash10x.c:35-43), 8 bytes */
+typedef struct {
+  uint32_t hash;        /* hash INDEX (1-based, first-appearance order) */
+  uint16_t read;
+  uint8_t  subCluster;
+  uint8_t  flags;       /* isHet:1 isHom:1 isErr:1 isSure:1 — never set on this path */
+} h10x_clushash;
+
+typedef struct {
+  int32_t  B;
+  uint32_t hashNumber;  /* number of distinct hashes + 1 (index 0 unused)   (hash10x.c:90)  */
+  uint32_t nBlocks;     /* arrayMax(clusterBlocks) = barcodes + 1           (hash10x.c:96)  */
+  uint32_t reserved;
+  uint64_t nClusHash;   /* sum of nHash over blocks                                          */
+  uint64_t nRecords;    /* read pairs consumed by the last read_fqb                          */
+} h10x_sizes;
+
+/* srandom(seed); (random() << 32) | random() | 1 — glibc, as seqhashCreate draws it after
+   initialise() seeds the generator (hash10x.c:1101, seqhash.c:29). Host-side helper. */
+uint64_t h10x_factor1_from_seed(int32_t seed);
+
+int  h10x_abi_version(void);
+/* number of HIP devices visible (0 if none / no driver); never initialises a context */
+int  h10x_device_count(void);
+
+/* replaces initialise() (hash10x.c:1099-1118). device = HIP ordinal; stream = hipStream_t to launch
+   on, or NULL for the device's default stream. Fails (no fallback) if the device is unusable or the
+   parameters would make the reference die. err/errlen receive the message when *ctx stays NULL. */
+int  h10x_create(h10x_ctx **ctx, const h10x_params *p, int device, void *stream, char *err, int errlen);
+void h10x_destroy(h10x_ctx *ctx);
+const char *h10x_last_error(const h10x_ctx *ctx);
+
+/* replaces readFQB() + fillHashTable() (hash10x.c:188-236, 317-347) for a whole sorted .fqb image:
+   n_records records of 30 uint32 (fq2b.c:142-160). Barcode blocks are runs of equal word 0; the
+   block still open at the end is kept with nHash = 0 (hash10x.c:209). The caller applies
+   -N (pass only the first N records) and the reference's chunkSize check (h10x_host_check_chunks).
+   _device: records already resident in device memory (HBM). */
+int  h10x_read_fqb(h10x_ctx *ctx, const uint32_t *host_records, uint64_t n_records);
+int  h10x_read_fqb_device(h10x_ctx *ctx, const uint32_t *dev_records, uint64_t n_records);
+
+/* replaces the state that readHashFile() + fillHashTable() leave behind (hash10x.c:269-315,
+   317-347): uploads the tables of a parsed .hash file and rebuilds the hash->barcode lists.
+   hashDepth has hashNumber entries, blocks has nBlocks entries (entry 0 unused), clusHash is the
+   concatenation of blocks 1..nBlocks-1. */
+int  h10x_load_state(h10x_ctx *ctx, const uint32_t *hashIndex, uint32_t hashNumber,
+                     const uint64_t *hashValue, const uint32_t *hashDepth,
+                     const h10x_block *blocks, uint32_t nBlocks, const h10x_clushash *clusHash);
+
+/* replaces hashWithinRangeBuild() + goodHashesBuild() (hash10x.c:528-539, 738-766); ranges
+   accumulate over calls exactly as in the reference */
+int  h10x_depth_range(h10x_ctx *ctx, int32_t min, int32_t max);
+
+/* replaces the --cluster loop: codeClusterFind() + codeClusterReadMerge() for code in
+   [codeMin, codeMax) (hash10x.c:1241-1261, 770-868); 0,0 => 1..nBlocks. Fails with the reference's
+   "!! you must set hashDepthRange before cluster" if no range was set. */
+int  h10x_cluster(h10x_ctx *ctx, int32_t codeMin, int32_t codeMax, int32_t clusterThreshold);
+
+/* replaces clusterSplitCodes() (hash10x.c:956-1013) */
+int  h10x_cluster_split(h10x_ctx *ctx);
+
+/* what writeHashFile() needs (hash10x.c:244-267): sizes, then a copy-out of any subset of the
+   tables (NULL = skip). hashIndex: 2^B, hashValue/hashDepth: hashNumber, blocks: nBlocks,
+   clusHash: nClusHash entries. */
+int  h10x_get_sizes(h10x_ctx *ctx, h10x_sizes *out);
+int  h10x_export(h10x_ctx *ctx, uint32_t *hashIndex, uint64_t *hashValue, uint32_t *hashDepth,
+                 h10x_block *blocks, h10x_clushash *clusHash);
+
+/* ---- measurement hooks (not part of the reference surface) ----
+   Per-kernel device timings collected with hipEvents on the context's stream when enabled.
+   names: "mosh_extract", "index_build", "good_hashes", "cluster" ... (h10x_timing_name(i)). */
+int  h10x_timing_enable(h10x_ctx *ctx, int on);
+int  h10x_timing_count(const h10x_ctx *ctx);
+const char *h10x_timing_name(const h10x_ctx *ctx, int i);
+int  h10x_timing_get(h10x_ctx *ctx, int i, double *total_ms, uint64_t *launches);
+int  h10x_timing_reset(h10x_ctx *ctx);
+/* algorithmic work counters of the last commands: see DESIGN.md */
+typedef struct {
+  uint64_t pairs;            /* read pairs hashed                                   */
+  uint64_t kmers;            /* k-mers hashed (237 per pair at k=21)                */
+  uint64_t entries;          /* H = sum nHash                                       */
+  uint64_t distinct;         /* U = hashNumber - 1                                  */
+  uint64_t clustered_codes;  /* barcodes visited by the last h10x_cluster           */
+  uint64_t sum_good;         /* sum of good hashes over those barcodes              */
+  uint64_t sum_good_depth;   /* sum over good hashes of depth (gathered row entries)*/
+  uint64_t sum_hash_clustered; /* sum nHash over barcodes with good hashes          */
+  uint64_t fallback_blocks;  /* barcodes that took the global-memory path in stage A */
+} h10x_counters;
+int  h10x_get_counters(h10x_ctx *ctx, h10x_counters *out);
+/* testing knob: cap the LDS hash-set slots per barcode in stage A (0 = default) so that the
+   global-memory fallback can be exercised on small inputs */
+int  h10x_set_option(h10x_ctx *ctx, const char *name, int64_t value);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* H10X_H */

@@ -1,0 +1,134 @@
+"""Parity of the HIP path (through the C ABI / C session layer) against the reference's golden
+vectors and against the CPU oracle on seeded inputs. Needs a real MI355X: `pytest -m gpu`.
+
+Bar: bit-exact canonical .hash (integer/byte work; the one floating-point field, pointToMin, is an
+ordered IEEE double sum and is compared bit-for-bit too)."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import orc
+from driver import run_commands
+
+pytestmark = pytest.mark.gpu
+
+with open(os.path.join(orc.GOLDEN, "manifest.json")) as _f:
+    MAN = json.load(_f)
+
+
+def _factory(**opts):
+    import hash10x_amd
+
+    def make(k, w, r, B):
+        h = hash10x_amd.Hash10x(k=k, w=w, r=r, B=B)
+        for n, v in opts.items():
+            h.set_option(n, v)
+        return h
+    return make
+
+
+def test_native_library_is_the_path():
+    import hash10x_amd
+    hip, host = hash10x_amd.load_native()
+    assert hip.h10x_abi_version() == 1
+    assert hash10x_amd.device_count() >= 1
+    assert hip.h10x_factor1_from_seed(17) == 0x49308BB9003CB3AD
+
+
+@pytest.mark.parametrize("case", MAN["cases"], ids=[c["name"] for c in MAN["cases"]])
+def test_hip_matches_reference_golden(case, workdir):
+    if "--clusterSplit" in case["args"]:
+        pytest.skip("clusterSplit: next-row, not on the device path yet")
+    workdir.need(case["input"])
+    args = list(case["args"])
+    run_commands(_factory(), args, workdir.path)
+    got = open(workdir.file(args[-1]), "rb").read()
+    exp = orc.read_maybe_gz(os.path.join(orc.GOLDEN, case["output"]))
+    assert got == exp, orc.describe_diff(got, exp)
+
+
+@pytest.mark.parametrize("case", MAN["digest_cases"], ids=[c["name"] for c in MAN["digest_cases"]])
+def test_hip_matches_reference_digests(case, workdir):
+    recs = orc.gen_fqb(workdir.file(case["name"] + ".fqb"), **case["gen"])
+    assert orc.sha256(recs.tobytes()) == case["input_sha256"]
+    extra = list(case["args"])
+    pre = extra[:2] if extra and extra[0] == "-ct" else []
+    args = ["-B", case["B"]] + pre + ["--readFQB", case["name"] + ".fqb"] + extra[len(pre):] + ["--writeHash", "out.hash"]
+    run_commands(_factory(), args, workdir.path)
+    got = open(workdir.file("out.hash"), "rb").read()
+    if orc.sha256(got) != case["sha256"]:
+        # recompute the expectation with the oracle to say where it differs
+        run_commands(lambda k, w, r, B: orc.Oracle(k, w, r, B), args[:-1] + ["exp.hash"], workdir.path)
+        exp = open(workdir.file("exp.hash"), "rb").read()
+        assert got == exp, orc.describe_diff(got, exp)
+        raise AssertionError("digest mismatch but oracle agrees?!")
+
+
+def _against_oracle(workdir, recs_name, args_tail, k=21, w=31, r=17, B=20, **opts):
+    base = ["-k", k, "-w", w, "-r", r, "-B", B] + args_tail
+    run_commands(_factory(**opts), base + ["--writeHash", "hip.hash"], workdir.path)
+    run_commands(lambda k_, w_, r_, B_: orc.Oracle(k_, w_, r_, B_), base + ["--writeHash", "orc.hash"], workdir.path)
+    got = open(workdir.file("hip.hash"), "rb").read()
+    exp = open(workdir.file("orc.hash"), "rb").read()
+    assert got == exp, orc.describe_diff(got, exp)
+    return orc.HashFile(got)
+
+
+def test_global_mosh_path_forced(workdir):
+    """Every barcode through the global-memory mosh path (LDS table capped below what any block needs)."""
+    workdir.need("small.fqb.gz")
+    hf = _against_oracle(workdir, "small.fqb", ["--readFQB", "small.fqb", "--hashDepthRange", 3, 14, "-ct", 2, "--cluster", 1, 0],
+                         stage_a_max_slots=256)
+    assert hf.blocks["nSubCluster"].sum() > 0
+
+
+@pytest.mark.parametrize("k,w,r", [(21, 31, 17), (16, 5, 3), (24, 31, 5), (25, 31, 17), (31, 7, 1), (11, 32, 9)])
+def test_other_hashers(workdir, k, w, r):
+    """k > 24 cannot pack (hash, read) into 64 bits and takes the global path; w != 31 the generic modulo."""
+    orc.gen_fqb(workdir.file("x.fqb"), 3000, 20, 40000, 0.004, 100 + k, 3.0, 150, 2500)
+    _against_oracle(workdir, "x.fqb", ["--readFQB", "x.fqb"], k=k, w=w, r=r, B=21)
+
+
+@pytest.mark.parametrize("seed,pairs,barcodes,genome,mol,mol_len,lo,hi,ct", [
+    (41, 30000, 150, 300000, 4.0, 6000, 4, 30, 3),
+    (42, 50000, 60, 150000, 3.0, 5000, 6, 60, 5),
+    (43, 20000, 400, 100000, 2.0, 3000, 3, 40, 2),
+])
+def test_random_sets_end_to_end(workdir, seed, pairs, barcodes, genome, mol, mol_len, lo, hi, ct):
+    orc.gen_fqb(workdir.file("x.fqb"), pairs, barcodes, genome, 0.003, seed, mol, 150, mol_len)
+    hf = _against_oracle(workdir, "x.fqb", ["-ct", ct, "--readFQB", "x.fqb", "--hashDepthRange", lo, hi, "--cluster", 1, 0])
+    assert hf.blocks["nSubCluster"].sum() > 0
+
+
+def test_big_barcode_uses_medium_lds_class_and_wide_lists(workdir):
+    """~1200 pairs per barcode (128 KB LDS class) and depths > 64/128 (multi-chunk register lists)."""
+    orc.gen_fqb(workdir.file("x.fqb"), 60000, 50, 20000, 0.002, 77, 2.0, 150, 4000)
+    hf = _against_oracle(workdir, "x.fqb", ["-ct", 5, "--readFQB", "x.fqb", "--hashDepthRange", 10, 400, "--cluster", 1, 0])
+    assert hf.blocks["nSubCluster"].sum() > 0
+
+
+def test_empty_and_single_barcode_inputs(workdir):
+    np.zeros(0, np.uint32).tofile(workdir.file("empty.fqb"))
+    _against_oracle(workdir, "empty.fqb", ["--readFQB", "empty.fqb"])
+    recs = np.fromfile(workdir.need("tiny.fqb"), dtype=np.uint32).reshape(-1, 30)
+    recs[:3].tofile(workdir.file("one.fqb"))            # a single barcode: it is the trailing one => nothing hashed
+    _against_oracle(workdir, "one.fqb", ["--readFQB", "one.fqb"])
+
+
+def test_die_conditions_match_reference_text(workdir):
+    import hash10x_amd
+    recs = np.fromfile(workdir.need("tiny.fqb"), dtype=np.uint32)
+    with pytest.raises(hash10x_amd.Hash10xError, match="out of range 20-30"):
+        hash10x_amd.Hash10x(B=19).read_fqb(recs)
+    with pytest.raises(hash10x_amd.Hash10xError, match="chunkSize too small"):
+        hash10x_amd.Hash10x(B=20).read_fqb(recs, 0, 3)
+    h = hash10x_amd.Hash10x(B=20)
+    h.read_fqb(recs)
+    with pytest.raises(hash10x_amd.Hash10xError, match="you must set hashDepthRange before cluster"):
+        h.cluster(1, 0, 5)
+    orc.gen_fqb(workdir.file("x.fqb"), 200000, 100, 3000000, 0.02, 5, 10.0, 150, 50000)
+    big = np.fromfile(workdir.file("x.fqb"), dtype=np.uint32)
+    with pytest.raises(hash10x_amd.Hash10xError, match="hashTableSize is too small"):
+        hash10x_amd.Hash10x(B=20).read_fqb(big)       # > 2^18 - 2 distinct hashes (hash10x.c:149)
