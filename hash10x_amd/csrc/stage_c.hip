@@ -431,7 +431,9 @@ int stageC_cluster(Ctx *c, int codeMin, int codeMax, int threshold) {
     a.list = listL.p; a.nList = hc[0]; a.workCounter = counts.p + 2; a.scratch = nullptr; a.scratchStride = 0;
     H10X_HIP(c, hipFuncSetAttribute((const void *)cluster_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsBudget));
     const u32 grid = hmin<u32>(hc[0], (u32)c->numCU * 2);
+    c->tstart(T_CLUSTER_K);
     cluster_kernel<true><<<grid, CL_THREADS, ldsBudget, st>>>(a);
+    c->tstop(T_CLUSTER_K);
     H10X_HIP(c, hipGetLastError());
   }
   DevBuf<unsigned char> scratch;
