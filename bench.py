@@ -143,18 +143,19 @@ def main():
     wl = WORKLOADS[args.workload]
     recs = generate(wl, seed=1 + rank)                      # rank r: its own sample (seed 1 + r)
     pairs = recs.size // 30
-    d_recs = torch.from_numpy(recs.view(np.int32)).cuda()   # resident in HBM before the timed region
-    torch.cuda.synchronize()
+    d_recs = hash10x_amd.DeviceRecords(recs, device=local_rank)   # resident in HBM before the timed region
+    hash10x_amd.synchronize(local_rank)
 
     h = hash10x_amd.Hash10x(B=wl["B"], device=local_rank)
     h.enable_timing(True)
 
     def step():
-        h.read_fqb_device(d_recs.data_ptr(), pairs)
+        h.read_fqb_device(d_recs.ptr, pairs)
         h.depth_range(wl["lo"], wl["hi"])
         h.cluster(1, 0, wl["ct"])
 
     def barrier():
+        hash10x_amd.synchronize(local_rank)      # the library's HIP runtime (every command also syncs before returning)
         torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()

@@ -70,6 +70,12 @@ def load_native():
     host.h10x_host_array_dim.argtypes = [ci, ci, ctypes.c_int64]
     host.h10x_host_check_chunks.restype = ctypes.c_int64
     host.h10x_host_check_chunks.argtypes = [vp, cu64, ci, ci, cs, ci]
+    host.h10x_host_partition.argtypes = [vp, cu64, ci, vp]
+    hip.h10x_device_malloc.restype = vp
+    hip.h10x_device_malloc.argtypes = [ci, cu64]
+    hip.h10x_device_free.argtypes = [ci, vp]
+    hip.h10x_device_upload.argtypes = [ci, vp, vp, cu64]
+    hip.h10x_device_synchronize.argtypes = [ci]
     hip.h10x_device_count.restype = ci
     hip.h10x_abi_version.restype = ci
     hip.h10x_factor1_from_seed.restype = cu64
@@ -92,6 +98,35 @@ def load_native():
 
 def device_count():
     return load_native()[0].h10x_device_count()
+
+
+class DeviceRecords:
+    """A sorted .fqb image resident in HBM (hipMalloc through the library, no torch involved)."""
+
+    def __init__(self, records, device=0):
+        hip = load_native()[0]
+        r = np.ascontiguousarray(records, dtype=np.uint32).reshape(-1)
+        self.n_records, self.device, self._hip = r.size // 30, device, hip
+        self.ptr = hip.h10x_device_malloc(device, r.nbytes)
+        if not self.ptr:
+            raise Hash10xError("hipMalloc of %d bytes failed on device %d" % (r.nbytes, device))
+        if hip.h10x_device_upload(device, self.ptr, r.ctypes.data, r.nbytes):
+            raise Hash10xError("upload to device %d failed" % device)
+
+    def free(self):
+        if getattr(self, "ptr", None):
+            self._hip.h10x_device_free(self.device, self.ptr)
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+def synchronize(device=0):
+    load_native()[0].h10x_device_synchronize(device)
 
 
 class Hash10x:

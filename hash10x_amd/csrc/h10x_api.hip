@@ -178,6 +178,18 @@ int h10x_export(h10x_ctx *h, uint32_t *hashIndex, uint64_t *hashValue, uint32_t 
   return 0;
 }
 
+void *h10x_device_malloc(int device, uint64_t bytes) {
+  void *p = nullptr;
+  if (hipSetDevice(device) != hipSuccess) return nullptr;
+  if (hipMalloc(&p, bytes ? bytes : 1) != hipSuccess) return nullptr;
+  return p;
+}
+int h10x_device_free(int device, void *ptr) { return (hipSetDevice(device) == hipSuccess && hipFree(ptr) == hipSuccess) ? 0 : -1; }
+int h10x_device_upload(int device, void *dst, const void *src, uint64_t bytes) {
+  return (hipSetDevice(device) == hipSuccess && hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice) == hipSuccess) ? 0 : -1;
+}
+int h10x_device_synchronize(int device) { return (hipSetDevice(device) == hipSuccess && hipDeviceSynchronize() == hipSuccess) ? 0 : -1; }
+
 int h10x_timing_enable(h10x_ctx *h, int on) { if (!h) return -1; h->c.timing = on != 0; return 0; }
 int h10x_timing_count(const h10x_ctx *) { return T_COUNT; }
 const char *h10x_timing_name(const h10x_ctx *, int i) { return (i >= 0 && i < T_COUNT) ? kTimerNames[i] : ""; }

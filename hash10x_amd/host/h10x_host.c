@@ -88,6 +88,18 @@ int64_t h10x_host_check_chunks(const uint32_t *rec, uint64_t total, int N, int c
   return nReads;
 }
 
+int h10x_host_partition(const uint32_t *rec, uint64_t n, int nParts, uint64_t *cut) {
+  if (nParts < 1 || !cut) return -1;
+  cut[0] = 0; cut[nParts] = n;
+  for (int g = 1; g < nParts; ++g) {
+    uint64_t p = (uint64_t)(((__uint128_t)n * (unsigned)g) / (unsigned)nParts);
+    if (p < cut[g - 1]) p = cut[g - 1];
+    while (p > 0 && p < n && rec[30 * p] == rec[30 * (p - 1)]) ++p;     /* move forward to the next run boundary */
+    cut[g] = p;
+  }
+  return 0;
+}
+
 /* initialise() (hash10x.c:1099-1118): a fresh context with the currently latched parameters */
 static int session_init(h10x_session *s) {
   if (s->ctx) { h10x_destroy(s->ctx); s->ctx = 0; }

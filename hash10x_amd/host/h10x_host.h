@@ -42,6 +42,10 @@ int  h10x_host_array_dim(int initialDim, int elemSize, int64_t lastIndex);
    records it would consume (honours -N), or -1 with "chunkSize too small" in err */
 int64_t h10x_host_check_chunks(const uint32_t *records, uint64_t nRecords, int N, int chunkSize, char *err, int errlen);
 
+/* contiguous barcode-range shards for nParts GPUs: cut[g] = first record of shard g, always on a
+   barcode-run boundary, balanced by record count; cut[nParts] = nRecords. Returns 0. */
+int  h10x_host_partition(const uint32_t *records, uint64_t nRecords, int nParts, uint64_t *cut);
+
 #ifdef __cplusplus
 }
 #endif

@@ -110,6 +110,13 @@ int  h10x_get_sizes(h10x_ctx *ctx, h10x_sizes *out);
 int  h10x_export(h10x_ctx *ctx, uint32_t *hashIndex, uint64_t *hashValue, uint32_t *hashDepth,
                  h10x_block *blocks, h10x_clushash *clusHash);
 
+/* ---- device memory plumbing for callers that keep the input resident in HBM (bench, pipelines) ----
+   plain hipMalloc / hipMemcpy / hipDeviceSynchronize on `device`; return NULL / non-zero on failure */
+void *h10x_device_malloc(int device, uint64_t bytes);
+int   h10x_device_free(int device, void *ptr);
+int   h10x_device_upload(int device, void *dst, const void *src, uint64_t bytes);
+int   h10x_device_synchronize(int device);
+
 /* ---- measurement hooks (not part of the reference surface) ----
    Per-kernel device timings collected with hipEvents on the context's stream when enabled.
    names: "mosh_extract", "index_build", "good_hashes", "cluster" ... (h10x_timing_name(i)). */

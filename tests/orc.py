@@ -97,11 +97,15 @@ class Oracle:
         self.k, self.w, self.seed, self.B = k, w, seed, B
 
     def close(self):
-        if self.h:
-            lib().orc_destroy(self.h)
-            self.h = None
+        if getattr(self, "h", None) and _lib is not None:
+            _lib.orc_destroy(self.h)
+        self.h = None
 
-    __del__ = close
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
     def _chk(self, rc):
         if rc != 0:

@@ -1,0 +1,64 @@
+"""world_size-2 gloo test of the multi-process plumbing bench.py relies on at N > 1 (one process per
+GPU, barrier + max-over-ranks timing, per-rank seeded samples) and of the barcode-range partition the
+sharded path will use. CPU only; the compute in it is the oracle (test infrastructure)."""
+import os
+import socket
+import subprocess
+import sys
+
+import orc
+
+WORKER = r'''
+import ctypes, os, sys, json
+import numpy as np
+import torch, torch.distributed as dist
+sys.path.insert(0, os.environ["H10X_REPO"]); sys.path.insert(0, os.path.join(os.environ["H10X_REPO"], "tests"))
+import orc, hash10x_amd
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+recs = np.frombuffer(orc.read_maybe_gz(os.path.join(orc.GOLDEN, "small.fqb.gz")), dtype=np.uint32).copy()
+n = recs.size // 30
+host = hash10x_amd.load_native()[1]
+cut = (ctypes.c_uint64 * (world + 1))()
+assert host.h10x_host_partition(recs.ctypes.data, n, world, cut) == 0
+lo, hi = cut[rank], cut[rank + 1]
+# every rank hashes its own contiguous barcode range (+ the first record of the next shard, which
+# plays the "next barcode" that closes the last block: hash10x.c:213-220)
+end = hi + 1 if rank + 1 < world else hi
+o = orc.Oracle(B=20); o.read_fqb(recs[30 * lo: 30 * end])
+b, _, mx = o.blocks()
+nblk = mx - 1 - (1 if rank + 1 < world else 0)          # blocks this rank owns (the extra closing block is not ours)
+own = torch.tensor([int(nblk), int(b["nHash"][1:1 + nblk].sum()), int(hi - lo)], dtype=torch.int64)
+allv = [torch.zeros(3, dtype=torch.int64) for _ in range(world)]
+dist.all_gather(allv, own)
+t = torch.tensor([0.5 + rank], dtype=torch.float64); dist.all_reduce(t, op=dist.ReduceOp.MAX)
+dist.barrier()
+if rank == 0:
+    full = orc.Oracle(B=20); full.read_fqb(recs)
+    fb, _, fmx = full.blocks()
+    print(json.dumps({"blocks": int(sum(int(v[0]) for v in allv)), "full_blocks": int(fmx - 1),
+                      "entries": int(sum(int(v[1]) for v in allv)), "full_entries": int(fb["nHash"].sum()),
+                      "records": int(sum(int(v[2]) for v in allv)), "n": int(n), "tmax": float(t.item())}))
+dist.destroy_process_group()
+'''
+
+
+def test_two_rank_gloo_shards_cover_the_file(tmp_path):
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    wf = tmp_path / "worker.py"
+    wf.write_text(WORKER)
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   H10X_REPO=orc.REPO, OMP_NUM_THREADS="1")
+        procs.append(subprocess.Popen([sys.executable, str(wf)], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE))
+    outs = [p.communicate(timeout=300) for p in procs]
+    for p, (so, se) in zip(procs, outs):
+        assert p.returncode == 0, se.decode()[-2000:]
+    import json
+    res = json.loads(outs[0][0].decode().strip().splitlines()[-1])
+    assert res["records"] == res["n"]
+    assert res["blocks"] == res["full_blocks"]                 # shards own disjoint, complete barcode ranges
+    # per-barcode unique hash sets are shard-local, so entry counts add up (the file's last barcode is unhashed in both)
+    assert res["entries"] == res["full_entries"]
+    assert res["tmax"] == 1.5

@@ -1,0 +1,110 @@
+"""CPU-only checks of the product's host side: the C-ABI library loads and exports every symbol that
+include/h10x.h declares, fails loudly without a GPU (no fallback), and the C host helpers (Array dim
+rules, readFQB chunk replay, shard partition) behave like the reference. No compute calls here."""
+import ctypes
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+import orc
+
+REPO = orc.REPO
+
+
+@pytest.fixture(scope="module")
+def native():
+    import hash10x_amd
+    try:
+        return hash10x_amd.load_native()
+    except hash10x_amd.Hash10xError:
+        import __graft_entry__
+        __graft_entry__.build()
+        return hash10x_amd.load_native()
+
+
+def _declared(header):
+    txt = open(os.path.join(REPO, header)).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(h10x_[a-z0-9_A-Z]+)\s*\(", txt)))
+
+
+def test_c_abi_exports_every_declared_symbol(native):
+    hip, host = native
+    names = _declared("include/h10x.h")
+    assert len(names) >= 20
+    for n in names:
+        assert hasattr(hip, n), "libh10x_hip.so does not export %s" % n
+    for n in _declared("hash10x_amd/host/h10x_host.h"):
+        assert hasattr(host, n), "libh10x_host.so does not export %s" % n
+    assert hip.h10x_abi_version() == 1
+
+
+def test_no_cpu_fallback(native):
+    import hash10x_amd
+    if hash10x_amd.device_count() > 0:
+        pytest.skip("a GPU is present")
+    with pytest.raises(hash10x_amd.Hash10xError, match="no HIP device available"):
+        hash10x_amd.Hash10x(B=20).read_fqb(np.zeros(60, np.uint32))
+    r = subprocess.run([os.path.join(REPO, "bin", "hash10x-amd"), "-B", "20", "--readFQB", os.path.join(orc.GOLDEN, "tiny.fqb")],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert r.returncode == 255 and b"FATAL ERROR: no HIP device available" in r.stderr      # die(): exit(-1)
+
+
+def test_factor1_matches_glibc_random_kat(native):
+    assert native[0].h10x_factor1_from_seed(17) == 0x49308BB9003CB3AD       # SURVEY KAT-1
+    assert native[0].h10x_factor1_from_seed(17) == orc.lib().orc_factor1_from_seed(17)
+    assert native[0].h10x_factor1_from_seed(1) == orc.lib().orc_factor1_from_seed(1)
+
+
+def test_array_dim_rules(native):
+    dim = native[1].h10x_host_array_dim
+    # hashDepth: arrayCreate(1<<20, U32)
+    assert dim(1 << 20, 4, (1 << 20) - 1) == 1 << 20
+    assert dim(1 << 20, 4, 1 << 20) == 1 << 21
+    assert dim(1 << 20, 4, (1 << 21)) == (1 << 21) + 2098176
+    assert dim(1 << 20, 4, (1 << 21) + 2098176) == (1 << 21) + 2 * 2098176
+    # clusterBlocks: arrayCreate(1200, ClusterBlock): doubles to 307200, then +263168 per step
+    assert dim(1200, 32, 1199) == 1200 and dim(1200, 32, 1200) == 2400 and dim(1200, 32, 10000) == 19200
+    assert dim(1200, 32, 307199) == 307200 and dim(1200, 32, 307200) == 307200 + 263168
+    # and against what the oracle (pinned to the reference) reports for real data
+    for name in ("small.hash.gz", "tiny.hash.gz"):
+        hf = orc.HashFile(orc.read_maybe_gz(os.path.join(orc.GOLDEN, name)))
+        assert dim(1 << 20, 4, hf.hash_number - 1) == hf.depth_dim
+        assert dim(1200, 32, hf.blocks_max - 1) == hf.blocks_dim
+
+
+def test_chunk_replay_matches_reference_rule(native):
+    chk = native[1].h10x_host_check_chunks
+    recs = np.fromfile(os.path.join(orc.GOLDEN, "tiny.fqb"), dtype=np.uint32)
+    n = recs.size // 30
+    err = ctypes.create_string_buffer(256)
+    assert chk(recs.ctypes.data, n, 0, 100000, err, 256) == n
+    assert chk(recs.ctypes.data, n, 9, 100000, err, 256) == 9
+    assert chk(recs.ctypes.data, n, 0, 3, err, 256) == -1 and err.value == b"chunkSize too small"   # barcode C holds 4 pairs
+    assert chk(recs.ctypes.data, n, 0, 5, err, 256) == n
+    for chunk in (3, 4, 5, 7):                          # same verdict as the oracle's replay of hash10x.c:202-223
+        o = orc.Oracle(B=20)
+        try:
+            o.read_fqb(recs, 0, chunk)
+            ok = True
+        except orc.OracleError:
+            ok = False
+        assert (chk(recs.ctypes.data, n, 0, chunk, err, 256) >= 0) == ok
+
+
+def test_partition_cuts_on_barcode_boundaries(native):
+    part = native[1].h10x_host_partition
+    recs = np.frombuffer(orc.read_maybe_gz(os.path.join(orc.GOLDEN, "small.fqb.gz")), dtype=np.uint32).reshape(-1, 30)
+    n = recs.shape[0]
+    flat = np.ascontiguousarray(recs).reshape(-1)
+    for parts in (1, 2, 3, 8):
+        cut = (ctypes.c_uint64 * (parts + 1))()
+        assert part(flat.ctypes.data, n, parts, cut) == 0
+        c = list(cut)
+        assert c[0] == 0 and c[-1] == n and c == sorted(c)
+        for x in c[1:-1]:
+            assert x == n or recs[x, 0] != recs[x - 1, 0]
+        assert max(np.diff(c)) <= n / parts + 400       # balanced up to one barcode
