@@ -78,6 +78,8 @@ struct Ctx {
 
   // options / measurement
   int64_t optMaxSlots = 0;    // testing knob: cap stage-A LDS table
+  int64_t optClusterLds = 0;  // testing knob: LDS budget of cluster_kernel (forces the HBM-scratch path when small)
+  int64_t optStamps = 0;      // diagnostic: per-phase wall-clock stamps in cluster_kernel
   bool timing = false;
   Timer timers[T_COUNT];
   h10x_counters ctr{};

@@ -213,6 +213,8 @@ int h10x_set_option(h10x_ctx *h, const char *name, int64_t value) {
     if (value && (value < 256 || value > 16384 || (value & (value - 1)))) return h->c.fail("stage_a_max_slots must be a power of two in 256..16384 (or 0)");
     h->c.optMaxSlots = value; return 0;
   }
+  if (!strcmp(name, "cluster_lds_budget")) { h->c.optClusterLds = value; return 0; }
+  if (!strcmp(name, "cluster_stamps")) { h->c.optStamps = value; return 0; }
   return h->c.fail("unknown option %s", name);
 }
 

@@ -25,8 +25,8 @@
 
 namespace h10x {
 
-constexpr int CL_THREADS = 512;
-constexpr int CL_WAVES = CL_THREADS / WAVE;
+constexpr int CL_THREADS_SMALL = 512;                      // 64 KB working sets, two workgroups per CU
+constexpr int CL_THREADS_BIG = 1024;                       // up to the whole LDS of a CU, one workgroup per CU
 constexpr u16 NONE16 = 0xFFFF;
 constexpr int RCHUNK = 4;                                   // register chunks: lists up to 256 entries
 
@@ -130,6 +130,7 @@ struct ClusterArgs {
   size_t mergeOffset;                                       // global mode: read-merge tables live behind the rank arrays
   u32 maxGood;
   u64 *stats;                                               // [0] sum good, [1] sum good depth, [2] sum nHash, [3] codes
+  u64 *phase;                                               // diagnostic per-phase ticks (null = off)
 };
 
 struct PairCT { u32 cnt, tot; };                            // overwritten by the double quotient in phase (d)
@@ -137,28 +138,34 @@ struct PairCT { u32 cnt, tot; };                            // overwritten by th
 // working set layout inside a region (LDS or HBM scratch)
 struct Work {
   u16 *first;        // nBlocks entries, NONE16 = unseen
-  u32 *gx;           // hash index of each good rank
   PairCT *ct;        // msMax / msTot per rank, later the quotient (as double)
+  u32 *rs;           // offset of the rank's barcode list in rows[] (prefetched once)
+  u32 *dd;           // its length (hashDepth)
   u16 *best;         // msBest per rank
   u16 *qj;           // founding rank of the cluster the rank joins (NONE16 = no term)
   u8  *lab;          // label per rank
+  u32 *hist;         // CL_WAVES private byte-histograms over ranks (4 counters per word), all zero between lists
+  u32 histWords;     // words per wave
 };
-__host__ __device__ inline size_t workBytes(u32 nBlocks, u32 n) {
+__host__ __device__ inline size_t workBytes(u32 nBlocks, u32 n, u32 nWaves) {
   size_t b = (((size_t)nBlocks * 2 + 15) & ~(size_t)15);
   b += (size_t)n * 8;                                       // ct (8-byte aligned first)
-  b += (size_t)n * 4;                                       // gx
+  b += (size_t)n * 4 * 2;                                   // rs, dd
   b += (size_t)n * 2 * 2;                                   // best, qj
   b += ((size_t)n + 15) & ~(size_t)15;                      // lab
+  b += (size_t)nWaves * (((size_t)n + 3) / 4) * 4;          // hist
   return b + 16;
 }
 __device__ inline Work carve(unsigned char *base, u32 nBlocks, u32 n) {
   Work w; size_t o = 0;
   w.first = (u16 *)(base + o); o += (((size_t)nBlocks * 2 + 15) & ~(size_t)15);
   w.ct = (PairCT *)(base + o); o += (size_t)n * 8;
-  w.gx = (u32 *)(base + o); o += (size_t)n * 4;
+  w.rs = (u32 *)(base + o); o += (size_t)n * 4;
+  w.dd = (u32 *)(base + o); o += (size_t)n * 4;
   w.best = (u16 *)(base + o); o += (size_t)n * 2;
   w.qj = (u16 *)(base + o); o += (size_t)n * 2;
-  w.lab = (u8 *)(base + o);
+  w.lab = (u8 *)(base + o); o += ((size_t)n + 15) & ~(size_t)15;
+  w.hist = (u32 *)(base + o); w.histWords = (n + 3) / 4;
   return w;
 }
 // read-merge working set: readRep[min(nRead,65536)] bytes, adj[256][8] u32, comp[256] u32, newLab[256] u32
@@ -180,32 +187,46 @@ __device__ __forceinline__ void min_u16(u16 *arr, u32 idx, u32 val) {
   }
 }
 
-// msBest / msMax / msTot of one barcode list for rank i, one wavefront, list entries in registers
-__device__ __forceinline__ void row_mode_regs(const u32 *__restrict__ row, u32 d, u32 code, u32 i, const u16 *first,
+__device__ __forceinline__ u32 wave_max_u32(u32 v) {
+#pragma unroll
+  for (int s = 32; s; s >>= 1) { const u32 o = (u32)__shfl_xor((int)v, s); v = o > v ? o : v; }
+  return v;
+}
+
+// msBest / msMax / msTot of one barcode list (< 256 entries) for rank i, one wavefront: the gathered
+// first[] values are counted in this wave's private byte histogram with ds atomics, every lane reads back
+// the count of its own value, and a wave max over (count, lowest rank) picks the mode.
+__device__ __forceinline__ void row_mode_hist(const u32 *__restrict__ row, u32 d, u32 code, u32 i, const u16 *first, u32 *hist,
                                               u32 &best, u32 &bcnt, u32 &tot) {
   const int lane = threadIdx.x & (WAVE - 1);
-  u32 f[RCHUNK]; u64 rem[RCHUNK];
+  u32 f[RCHUNK]; bool ok[RCHUNK];
   tot = 0;
 #pragma unroll
   for (int r = 0; r < RCHUNK; ++r) {
-    const u32 j = r * WAVE + lane; bool valid = false; u32 v = NONE16;
-    if (j < d) { const u32 cj = row[j]; if (cj != code) { v = first[cj]; valid = v < i; } }
-    f[r] = v; rem[r] = __ballot(valid); tot += (u32)__popcll(rem[r]);
-  }
-  best = NONE16; bcnt = 0;
-#pragma unroll
-  for (int r = 0; r < RCHUNK; ++r) {
-    while (rem[r]) {
-      const int src = __ffsll((long long)rem[r]) - 1;
-      const u32 v = (u32)__builtin_amdgcn_readlane((int)f[r], src);
-      u32 cnt = 0;
-#pragma unroll
-      for (int q = 0; q < RCHUNK; ++q) if (q >= r) { const u64 m = __ballot(f[q] == v) & rem[q]; cnt += (u32)__popcll(m); rem[q] &= ~m; }
-      if (cnt > bcnt || (cnt == bcnt && v < best)) { bcnt = cnt; best = v; }
+    f[r] = NONE16; ok[r] = false;
+    if ((u32)(r * WAVE) < d) {
+      const u32 j = r * WAVE + lane;
+      if (j < d) { const u32 cj = row[j]; if (cj != code) { f[r] = first[cj]; ok[r] = f[r] < i; } }
+      tot += (u32)__popcll(__ballot(ok[r]));
+      if (ok[r]) atomicAdd(&hist[f[r] >> 2], 1u << ((f[r] & 3) * 8));
     }
   }
+  u32 key = 0;
+#pragma unroll
+  for (int r = 0; r < RCHUNK; ++r)
+    if ((u32)(r * WAVE) < d && ok[r]) {
+      const u32 c = (*(volatile u32 *)&hist[f[r] >> 2] >> ((f[r] & 3) * 8)) & 0xFFu;
+      const u32 k = (c << 16) | (0xFFFFu - f[r]);
+      key = k > key ? k : key;
+    }
+  key = wave_max_u32(key);
+#pragma unroll
+  for (int r = 0; r < RCHUNK; ++r)
+    if ((u32)(r * WAVE) < d && ok[r]) hist[f[r] >> 2] = 0;
+  bcnt = key >> 16;
+  best = key ? 0xFFFFu - (key & 0xFFFFu) : NONE16;
 }
-// same for lists longer than the register budget: re-gather per candidate (rare: depth >= 256)
+// lists of 256 entries and more (exotic depth ranges): re-gather per candidate
 __device__ void row_mode_long(const u32 *__restrict__ row, u32 d, u32 code, u32 i, const u16 *first, u32 &best, u32 &bcnt, u32 &tot) {
   const int lane = threadIdx.x & (WAVE - 1);
   best = NONE16; bcnt = 0; tot = 0;
@@ -240,8 +261,11 @@ __device__ __forceinline__ u32 row_count(const u32 *__restrict__ row, u32 d, u32
   return cnt;
 }
 
-template <bool IN_LDS>
+#define STAMP(k) do { if (a.phase && threadIdx.x == 0) { const u64 t__ = wall_clock64(); atomicAdd((u64 *)&a.phase[k], t__ - tPrev); tPrev = t__; } } while (0)
+
+template <bool IN_LDS, int CL_THREADS>
 __device__ void cluster_one_block(const ClusterArgs &a, u32 code, unsigned char *region, u32 *sh /* small shared ints */) {
+  constexpr int CL_WAVES = CL_THREADS / WAVE;
   const int tid = threadIdx.x, lane = tid & (WAVE - 1), wave = tid / WAVE;
   const u32 n = a.nGood[code];
   if (n == 0) return;                                        // hash10x.c:780: block left untouched
@@ -250,51 +274,100 @@ __device__ void cluster_one_block(const ClusterArgs &a, u32 code, unsigned char 
   Work w = carve(region, a.nBlocks, n);
   h10x_clushash *ch = a.clusHash + o; const u16 *g = a.goodPos + o;
 
-  // ---- init
+  u64 tPrev = a.phase ? wall_clock64() : 0;
+  // ---- init: prefetch every rank's list offset/length once
   if (IN_LDS) for (u32 i = tid; i < (a.nBlocks + 1) / 2; i += CL_THREADS) ((u32 *)w.first)[i] = 0xFFFFFFFFu;
+  for (u32 i = tid; i < CL_WAVES * w.histWords; i += CL_THREADS) w.hist[i] = 0;
   u64 myDepth = 0;
   for (u32 i = tid; i < n; i += CL_THREADS) {
-    const u32 x = ch[g[i]].hash; w.gx[i] = x; w.lab[i] = 0; w.qj[i] = NONE16; w.best[i] = NONE16;
-    w.ct[i].cnt = 0; w.ct[i].tot = 0; myDepth += a.hashDepth[x];
+    const u32 x = ch[g[i]].hash; const u32 d = a.hashDepth[x];
+    w.rs[i] = (u32)a.rowStart[x]; w.dd[i] = d; w.lab[i] = 0; w.qj[i] = NONE16; w.best[i] = NONE16;
+    w.ct[i].cnt = 0; w.ct[i].tot = 0; myDepth += d;
   }
   __syncthreads();
+  STAMP(0);
 
   // ---- (a) first[]: lowest rank >= 1 sharing each other barcode (hash10x.c:794-799, minShare)
   for (u32 i = 1 + wave; i < n; i += CL_WAVES) {
-    const u32 x = w.gx[i]; const u32 d = a.hashDepth[x]; const u32 *row = a.rows + a.rowStart[x];
+    const u32 d = w.dd[i]; const u32 *row = a.rows + w.rs[i];
     for (u32 j = lane; j < d; j += WAVE) { const u32 cj = row[j]; if (cj != code) min_u16(w.first, cj, i); }
   }
   __syncthreads();
+  STAMP(1);
 
   // ---- (b) msBest / msMax / msTot per rank (hash10x.c:801-806)
   for (u32 i = 1 + wave; i < n; i += CL_WAVES) {
-    const u32 x = w.gx[i]; const u32 d = a.hashDepth[x]; const u32 *row = a.rows + a.rowStart[x];
+    const u32 d = w.dd[i]; const u32 *row = a.rows + w.rs[i];
     u32 best, bcnt, tot;
-    if (d <= RCHUNK * WAVE) row_mode_regs(row, d, code, i, w.first, best, bcnt, tot);
+    if (d < RCHUNK * WAVE) row_mode_hist(row, d, code, i, w.first, w.hist + wave * w.histWords, best, bcnt, tot);
     else row_mode_long(row, d, code, i, w.first, best, bcnt, tot);
     if (lane == 0) { w.best[i] = (u16)best; w.ct[i].cnt = bcnt; w.ct[i].tot = tot; }
   }
   __syncthreads();
+  STAMP(2);
 
-  // ---- (c) order-dependent replay (hash10x.c:807-822)
-  if (tid == 0) {
-    u32 nSub = 0, stop = n; u16 *cmin = (u16 *)(sh + 4);       // founding rank of each cluster (clusterMin, hash10x.c:818)
-    for (u32 i = 1; i < n; ++i) {
-      if ((int)w.ct[i].cnt < a.threshold) continue;
-      const u32 b = w.best[i]; u32 L = w.lab[b];
-      if (!L) {
-        if (++nSub > 255) {                                  // hash10x.c:810-816: abandon; partial pointToMin is kept
-          nSub = 0; for (u32 j = 0; j < i; ++j) w.lab[j] = 0;
-          stop = i; break;
-        }
-        L = nSub; w.lab[b] = (u8)L; cmin[L] = (u16)b;
-      }
-      w.lab[i] = (u8)L; w.qj[i] = cmin[L];
+  // ---- (c) the order-dependent part of hash10x.c:807-822, restated without a serial walk.
+  // Call rank i "active" if msMax >= threshold. An active rank always ends up labelled at its own turn, and
+  // msBest < i, so: the cluster of an active rank is the one of the first INACTIVE rank on its msBest chain
+  // (its root = clusterMin of that cluster); an inactive rank founds a cluster at the first turn i' of an
+  // active rank pointing at it directly; clusters are numbered in founding order; the 256th founding turn is
+  // where the reference gives up. => roots by pointer jumping, founding turns by CAS-min, numbers by a scan.
+  {
+    u16 *ptr = w.qj;                                         // becomes root(i) = clusterMin[label(i)] for active ranks
+    u16 *ft = (u16 *)w.hist;                                 // founding turn of each inactive rank (NONE16 = never)
+    u16 *fl = ft + ((n + 2) & ~1u);                          // 1 at founding turns -> inclusive scan = cluster number
+    for (u32 i = tid; i < n; i += CL_THREADS) {
+      const bool act = i >= 1 && (int)w.ct[i].cnt >= a.threshold;
+      ptr[i] = act ? w.best[i] : (u16)i; ft[i] = NONE16; fl[i] = 0;
     }
-    sh[0] = nSub; sh[1] = stop;
+    __syncthreads();
+    for (u32 i = tid; i < n; i += CL_THREADS)
+      if (i >= 1 && (int)w.ct[i].cnt >= a.threshold) {
+        const u32 b = w.best[i];
+        if (!(b >= 1 && (int)w.ct[b].cnt >= a.threshold)) min_u16(ft, b, i);
+      }
+    u32 rounds = 1; while ((1u << rounds) < n) ++rounds;
+    for (u32 r = 0; r <= rounds; ++r) {                      // chains only run downwards: in-place jumping converges
+      __syncthreads();
+      for (u32 i = tid; i < n; i += CL_THREADS) { const u32 p = ptr[i]; const u32 pp = *(volatile u16 *)&ptr[p]; if (pp != p) ptr[i] = (u16)pp; }
+    }
+    __syncthreads();
+    for (u32 i = tid; i < n; i += CL_THREADS) { const u32 t = ft[i]; if (t != NONE16) fl[t] = 1; }   // founding turns are distinct
+    __syncthreads();
+    // block-wide inclusive scan of fl[0..n)
+    const u32 ipt = (n + CL_THREADS - 1) / CL_THREADS, s0 = tid * ipt, s1 = s0 + ipt < n ? s0 + ipt : n;
+    u32 mine = 0;
+    for (u32 i = s0; i < s1; ++i) mine += fl[i];
+    u32 inc = mine;
+#pragma unroll
+    for (int d = 1; d < WAVE; d <<= 1) { const u32 o = (u32)__shfl_up((int)inc, d); if (lane >= d) inc += o; }
+    if (lane == WAVE - 1) sh[4 + wave] = inc;
+    __syncthreads();
+    u32 run = inc - mine;
+    for (int q = 0; q < wave; ++q) run += sh[4 + q];
+    for (u32 i = s0; i < s1; ++i) { run += fl[i]; fl[i] = (u16)run; }
+    __syncthreads();
+    const u32 nRoots = fl[n - 1];
+    if (nRoots > 255) {                                      // hash10x.c:810-816: abandon at the 256th founding turn
+      for (u32 i = tid; i < n; i += CL_THREADS) {
+        if (fl[i] == 256 && (i == 0 || fl[i - 1] == 255)) { sh[0] = 0; sh[1] = i; }
+        w.lab[i] = 0;
+        if (!(i >= 1 && (int)w.ct[i].cnt >= a.threshold)) ptr[i] = NONE16;
+      }
+    } else {
+      if (tid == 0) { sh[0] = nRoots; sh[1] = n; }
+      for (u32 i = tid; i < n; i += CL_THREADS) {
+        const bool act = i >= 1 && (int)w.ct[i].cnt >= a.threshold;
+        u32 L = 0;
+        if (act) L = fl[ft[ptr[i]]];
+        else { const u32 t = ft[i]; if (t != NONE16) L = fl[t]; ptr[i] = NONE16; }
+        w.lab[i] = (u8)L;
+      }
+    }
   }
   __syncthreads();
   const u32 nSub = sh[0], stop = sh[1];
+  STAMP(3);
 
   // ---- (d) minShareCount[clusterMin[label]] / (double) msTot per rank (hash10x.c:821)
   for (u32 i = 1 + wave; i < stop; i += CL_WAVES) {
@@ -302,16 +375,29 @@ __device__ void cluster_one_block(const ClusterArgs &a, u32 code, unsigned char 
     if (qj == NONE16) continue;
     u32 q;
     if (qj == w.best[i]) q = w.ct[i].cnt;
-    else { const u32 x = w.gx[i]; q = row_count(a.rows + a.rowStart[x], a.hashDepth[x], code, qj, w.first); }
+    else q = row_count(a.rows + w.rs[i], w.dd[i], code, qj, w.first);
     if (lane == 0) { const double t = (double)(int)q / (double)(int)w.ct[i].tot; *(double *)&w.ct[i] = t; }
   }
   __syncthreads();
+  STAMP(4);
 
-  // ---- (e) ordered fp64 sum, labels out
-  if (tid == 0) {
+  // ---- (e) ordered fp64 sum (wavefront 0: 64 quotients per LDS read, added in rank order via readlane), labels out
+  if (wave == 0) {
     double p = 0.0;
-    for (u32 i = 1; i < stop; ++i) if (w.qj[i] != NONE16) p += *(const double *)&w.ct[i];
-    a.blocks[code].pointToMin = p; a.blocks[code].nSubCluster = nSub;
+    for (u32 base = 0; base < stop; base += WAVE) {
+      const u32 il = base + lane;
+      const bool has = il >= 1 && il < stop && w.qj[il] != NONE16;
+      const double t = has ? *(const double *)&w.ct[il] : 0.0;
+      const int tlo = (int)(u32)__double_as_longlong(t), thi = (int)(u32)((u64)__double_as_longlong(t) >> 32);
+      if (__ballot(has)) {
+#pragma unroll
+        for (int j = 0; j < WAVE; ++j) {                     // + 0.0 for ranks without a term is exact (p >= +0)
+          const u64 bits = ((u64)(u32)__builtin_amdgcn_readlane(thi, j) << 32) | (u64)(u32)__builtin_amdgcn_readlane(tlo, j);
+          p += __longlong_as_double((long long)bits);
+        }
+      }
+    }
+    if (lane == 0) { a.blocks[code].pointToMin = p; a.blocks[code].nSubCluster = nSub; }
   }
   for (u32 i = tid; i < n; i += CL_THREADS) ch[g[i]].subCluster = w.lab[i];     // includes the wipe of hash10x.c:783
   // wave-reduce the per-thread depth sums for the work counters
@@ -321,11 +407,12 @@ __device__ void cluster_one_block(const ClusterArgs &a, u32 code, unsigned char 
   if (!IN_LDS) {                                             // leave first[] clean for the next barcode of this workgroup
     __syncthreads();
     for (u32 i = 1 + wave; i < n; i += CL_WAVES) {
-      const u32 x = w.gx[i]; const u32 d = a.hashDepth[x]; const u32 *row = a.rows + a.rowStart[x];
+      const u32 d = w.dd[i]; const u32 *row = a.rows + w.rs[i];
       for (u32 j = lane; j < d; j += WAVE) w.first[row[j]] = NONE16;
     }
   }
   __syncthreads();
+  STAMP(5);
   if (!nSub) return;                                         // hash10x.c:840
 
   // ---- (f) codeClusterReadMerge (hash10x.c:837-868): components of labels that share a read
@@ -376,9 +463,10 @@ __device__ void cluster_one_block(const ClusterArgs &a, u32 code, unsigned char 
     if (L && L <= nSub) ch[p].subCluster = (u8)comp[L];
   }
   __syncthreads();
+  STAMP(6);
 }
 
-template <bool IN_LDS>
+template <bool IN_LDS, int CL_THREADS>
 __global__ __launch_bounds__(CL_THREADS)
 void cluster_kernel(ClusterArgs a) {
   extern __shared__ __align__(16) unsigned char smem[];
@@ -390,19 +478,23 @@ void cluster_kernel(ClusterArgs a) {
     __syncthreads();
     const u32 wi = sh[3];
     if (wi >= a.nList) break;                                // every wave of the workgroup leaves together
-    cluster_one_block<IN_LDS>(a, a.list[wi], region, sh);
+    cluster_one_block<IN_LDS, CL_THREADS>(a, a.list[wi], region, sh);
   }
 }
 
-// which barcodes fit the LDS budget; heaviest-first would be better for the tail, this keeps file order
+// three launch classes by working-set size: 0 = small LDS (two workgroups per CU), 1 = big LDS (one 1024-lane
+// workgroup per CU), 2 = HBM scratch
 __global__ void cluster_classify_kernel(const h10x_block *__restrict__ blocks, const u32 *__restrict__ nGood, u32 codeMin, u32 codeMax,
-                                        u32 nBlocks, size_t ldsBudget, u32 *__restrict__ listL, u32 *__restrict__ listG, u32 *__restrict__ counts) {
+                                        u32 nBlocks, size_t budgetSmall, size_t budgetBig,
+                                        u32 *__restrict__ list0, u32 *__restrict__ list1, u32 *__restrict__ list2, u32 *__restrict__ counts) {
   const u32 c = codeMin + blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= codeMax) return;
   const u32 n = nGood[c];
   if (!n) return;
-  const size_t need = max(workBytes(nBlocks, n), mergeBytes(blocks[c].nRead));
-  if (need <= ldsBudget) listL[atomicAdd(&counts[0], 1u)] = c; else listG[atomicAdd(&counts[1], 1u)] = c;
+  const size_t mb = mergeBytes(blocks[c].nRead);
+  if (max(workBytes(nBlocks, n, CL_THREADS_SMALL / WAVE), mb) <= budgetSmall) list0[atomicAdd(&counts[0], 1u)] = c;
+  else if (max(workBytes(nBlocks, n, CL_THREADS_BIG / WAVE), mb) <= budgetBig) list1[atomicAdd(&counts[1], 1u)] = c;
+  else list2[atomicAdd(&counts[2], 1u)] = c;
 }
 
 int stageC_cluster(Ctx *c, int codeMin, int codeMax, int threshold) {
@@ -415,11 +507,14 @@ int stageC_cluster(Ctx *c, int codeMin, int codeMax, int threshold) {
   if (codeMax <= codeMin) return 0;
   c->tstart(T_CLUSTER);
   const u32 span = (u32)(codeMax - codeMin);
-  DevBuf<u32> listL, listG, counts; DevBuf<u64> stats;
-  H10X_HIP(c, listL.alloc(span)); H10X_HIP(c, listG.alloc(span)); H10X_HIP(c, counts.alloc(4)); H10X_HIP(c, stats.alloc(4));
-  H10X_HIP(c, hipMemsetAsync(counts.p, 0, 16, st)); H10X_HIP(c, hipMemsetAsync(stats.p, 0, 32, st));
-  const size_t ldsBudget = 64 * 1024 - 1024;
-  cluster_classify_kernel<<<divUp(span, 256), 256, 0, st>>>(c->blocks.p, c->nGood.p, (u32)codeMin, (u32)codeMax, c->nBlocks, ldsBudget, listL.p, listG.p, counts.p);
+  DevBuf<u32> list0, list1, list2, counts; DevBuf<u64> stats;
+  H10X_HIP(c, list0.alloc(span)); H10X_HIP(c, list1.alloc(span)); H10X_HIP(c, list2.alloc(span));
+  H10X_HIP(c, counts.alloc(8)); H10X_HIP(c, stats.alloc(4));
+  H10X_HIP(c, hipMemsetAsync(counts.p, 0, 32, st)); H10X_HIP(c, hipMemsetAsync(stats.p, 0, 32, st));
+  const size_t budgetSmall = c->optClusterLds > 0 ? (size_t)c->optClusterLds : 64 * 1024 - 1024;
+  const size_t budgetBig = c->optClusterLds > 0 ? (size_t)c->optClusterLds : 160 * 1024 - 1024;
+  cluster_classify_kernel<<<divUp(span, 256), 256, 0, st>>>(c->blocks.p, c->nGood.p, (u32)codeMin, (u32)codeMax, c->nBlocks, budgetSmall, budgetBig,
+                                                          list0.p, list1.p, list2.p, counts.p);
   u32 hc[4];
   H10X_HIP(c, hipMemcpyAsync(hc, counts.p, 16, hipMemcpyDeviceToHost, st));
   H10X_HIP(c, hipStreamSynchronize(st));
@@ -427,33 +522,42 @@ int stageC_cluster(Ctx *c, int codeMin, int codeMax, int threshold) {
   a.blocks = c->blocks.p; a.blockOff = c->blockOff.p; a.clusHash = c->clusHash.p; a.goodPos = c->goodPos.p; a.nGood = c->nGood.p;
   a.hashDepth = c->hashDepth.p; a.rowStart = c->rowStart.p; a.rows = c->rows.p; a.nBlocks = c->nBlocks; a.threshold = threshold;
   a.maxGood = c->maxGood; a.stats = stats.p;
+  DevBuf<u64> phase;
+  if (c->optStamps) { H10X_HIP(c, phase.alloc(8)); H10X_HIP(c, hipMemsetAsync(phase.p, 0, 64, st)); a.phase = phase.p; }
+  c->tstart(T_CLUSTER_K);
+  if (hc[1]) {                                               // biggest working sets first
+    a.list = list1.p; a.nList = hc[1]; a.workCounter = counts.p + 5; a.scratch = nullptr; a.scratchStride = 0;
+    H10X_HIP(c, hipFuncSetAttribute((const void *)cluster_kernel<true, CL_THREADS_BIG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)budgetBig));
+    cluster_kernel<true, CL_THREADS_BIG><<<hmin<u32>(hc[1], (u32)c->numCU), CL_THREADS_BIG, budgetBig, st>>>(a);
+    H10X_HIP(c, hipGetLastError());
+  }
   if (hc[0]) {
-    a.list = listL.p; a.nList = hc[0]; a.workCounter = counts.p + 2; a.scratch = nullptr; a.scratchStride = 0;
-    H10X_HIP(c, hipFuncSetAttribute((const void *)cluster_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsBudget));
-    const u32 grid = hmin<u32>(hc[0], (u32)c->numCU * 2);
-    c->tstart(T_CLUSTER_K);
-    cluster_kernel<true><<<grid, CL_THREADS, ldsBudget, st>>>(a);
-    c->tstop(T_CLUSTER_K);
+    a.list = list0.p; a.nList = hc[0]; a.workCounter = counts.p + 4; a.scratch = nullptr; a.scratchStride = 0;
+    H10X_HIP(c, hipFuncSetAttribute((const void *)cluster_kernel<true, CL_THREADS_SMALL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)budgetSmall));
+    cluster_kernel<true, CL_THREADS_SMALL><<<hmin<u32>(hc[0], (u32)c->numCU * 2), CL_THREADS_SMALL, budgetSmall, st>>>(a);
     H10X_HIP(c, hipGetLastError());
   }
   DevBuf<unsigned char> scratch;
-  if (hc[1]) {
+  if (hc[2]) {
     // HBM working set per workgroup: first[] + per-rank arrays + read-merge tables for the largest barcode
-    const size_t mergeOff = (workBytes(c->nBlocks, c->maxGood) + 255) & ~(size_t)255;
+    const size_t mergeOff = (workBytes(c->nBlocks, c->maxGood, CL_THREADS_SMALL / WAVE) + 255) & ~(size_t)255;
     const size_t stride = mergeOff + ((mergeBytes(65536) + 255) & ~(size_t)255);
     a.mergeOffset = mergeOff;
-    const u32 grid = hmin<u32>(hc[1], (u32)c->numCU);
+    const u32 grid = hmin<u32>(hc[2], (u32)c->numCU);
     H10X_HIP(c, scratch.alloc(stride * grid));
     H10X_HIP(c, hipMemsetAsync(scratch.p, 0xFF, stride * grid, st));    // first[] = unseen everywhere
-    a.list = listG.p; a.nList = hc[1]; a.workCounter = counts.p + 3; a.scratch = scratch.p; a.scratchStride = stride;
-    cluster_kernel<false><<<grid, CL_THREADS, 0, st>>>(a);
+    a.list = list2.p; a.nList = hc[2]; a.workCounter = counts.p + 6; a.scratch = scratch.p; a.scratchStride = stride;
+    cluster_kernel<false, CL_THREADS_SMALL><<<grid, CL_THREADS_SMALL, 0, st>>>(a);
     H10X_HIP(c, hipGetLastError());
   }
+  c->tstop(T_CLUSTER_K);
   u64 hs[4];
   H10X_HIP(c, hipMemcpyAsync(hs, stats.p, 32, hipMemcpyDeviceToHost, st));
   H10X_HIP(c, hipStreamSynchronize(st));
   c->tstop(T_CLUSTER);
+  if (c->optStamps) { H10X_HIP(c, hipMemcpy(c->ctr.cluster_phase_ticks, phase.p, 64, hipMemcpyDeviceToHost)); }
   c->ctr.sum_good = hs[0]; c->ctr.sum_good_depth = hs[1]; c->ctr.sum_hash_clustered = hs[2]; c->ctr.clustered_codes = span;
+  c->ctr.cluster_class_counts[0] = hc[0]; c->ctr.cluster_class_counts[1] = hc[1]; c->ctr.cluster_class_counts[2] = hc[2];
   return 0;
 }
 

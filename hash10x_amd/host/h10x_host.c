@@ -12,6 +12,8 @@ typedef struct { int32_t magic, pad0; uint64_t base; int32_t dim, size, max, pad
 struct h10x_session {
   int k, w, r, B, N, chunk, ct, device;                /* params (hash10x.c:25-33) */
   int timing;                                          /* measurement hook: enable hipEvent timers on every new context */
+  int clusterLds;                                      /* test knob forwarded to h10x_set_option("cluster_lds_budget") */
+  int stamps;                                          /* diagnostic knob forwarded to h10x_set_option("cluster_stamps") */
   int maxSlots;                                        /* test knob forwarded to h10x_set_option("stage_a_max_slots") */
   h10x_ctx *ctx;
   /* Array bookkeeping of the reference for the two arrays that are dumped raw into .hash */
@@ -52,6 +54,8 @@ static int *param_slot(h10x_session *s, const char *n) {
   if (!strcmp(n, "device")) return &s->device;
   if (!strcmp(n, "stage_a_max_slots")) return &s->maxSlots;
   if (!strcmp(n, "timing")) return &s->timing;
+  if (!strcmp(n, "cluster_stamps")) return &s->stamps;
+  if (!strcmp(n, "cluster_lds_budget")) return &s->clusterLds;
   return 0;
 }
 int h10x_session_set(h10x_session *s, const char *name, int value) {
@@ -108,6 +112,8 @@ static int session_init(h10x_session *s) {
   if (s->k > 0 && s->w > 0) p.factor1 = h10x_factor1_from_seed(s->r);
   if (h10x_create(&s->ctx, &p, s->device, 0, s->err, (int)sizeof s->err)) return -1;
   if (s->timing) h10x_timing_enable(s->ctx, 1);
+  if (s->stamps) h10x_set_option(s->ctx, "cluster_stamps", 1);
+  if (s->clusterLds) h10x_set_option(s->ctx, "cluster_lds_budget", s->clusterLds);
   if (s->maxSlots && h10x_set_option(s->ctx, "stage_a_max_slots", s->maxSlots)) return fail_ctx(s);
   s->depthDim = 1 << 20; s->depthMax = 0;             /* arrayCreate(1 << 20, U32), hash10x.c:1114 */
   free(s->depthTail); s->depthTail = 0;

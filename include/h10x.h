@@ -136,6 +136,9 @@ typedef struct {
   uint64_t sum_good_depth;   /* sum over good hashes of depth (gathered row entries)*/
   uint64_t sum_hash_clustered; /* sum nHash over barcodes with good hashes          */
   uint64_t fallback_blocks;  /* barcodes that took the global-memory path in stage A */
+  uint64_t cluster_class_counts[3]; /* barcodes clustered in: 64 KB LDS, full-CU LDS, HBM scratch */
+  uint64_t cluster_phase_ticks[8]; /* diagnostic (option "cluster_stamps"): 100 MHz ticks per phase summed over workgroups:
+                                      init, first[], mode, replay, quotient, sum+labels, read merge, idle/queue */
 } h10x_counters;
 int  h10x_get_counters(h10x_ctx *ctx, h10x_counters *out);
 /* testing knob: cap the LDS hash-set slots per barcode in stage A (0 = default) so that the

@@ -84,6 +84,16 @@ def test_global_mosh_path_forced(workdir):
     assert hf.blocks["nSubCluster"].sum() > 0
 
 
+@pytest.mark.parametrize("budget", [2048, 24 * 1024])
+def test_cluster_hbm_scratch_and_big_lds_paths(workdir, budget):
+    """cluster_kernel on the per-workgroup HBM scratch (LDS budget too small for any barcode) and with a
+    budget that splits barcodes between the LDS classes."""
+    orc.gen_fqb(workdir.file("x.fqb"), 30000, 150, 300000, 0.003, 41, 4.0, 150, 6000)
+    hf = _against_oracle(workdir, "x.fqb", ["-ct", 3, "--readFQB", "x.fqb", "--hashDepthRange", 4, 30, "--cluster", 1, 0],
+                         cluster_lds_budget=budget)
+    assert hf.blocks["nSubCluster"].sum() > 0
+
+
 @pytest.mark.parametrize("k,w,r", [(21, 31, 17), (16, 5, 3), (24, 31, 5), (25, 31, 17), (31, 7, 1), (11, 32, 9)])
 def test_other_hashers(workdir, k, w, r):
     """k > 24 cannot pack (hash, read) into 64 bits and takes the global path; w != 31 the generic modulo."""
