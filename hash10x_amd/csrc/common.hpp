@@ -6,8 +6,10 @@
 #include <cstdio>
 #include <cstdarg>
 #include <cstring>
+#include <cstdlib>
 #include <string>
 #include <vector>
+#include <map>
 #include "../../include/h10x.h"
 
 namespace h10x {
@@ -22,20 +24,46 @@ static_assert(sizeof(h10x_block) == 32, "ClusterBlock layout (hash10x.c:62-70)")
 static_assert(sizeof(h10x_clushash) == 8, "ClusterHash layout (hash10x.c:35-43)");
 
 // ---- device buffer with explicit ownership ------------------------------------------------------
+// Allocations are stream-ordered (hipMallocAsync on the calling context's stream, pool kept warm), so the
+// dozens of temporaries of a command cost no driver round trips or implicit device syncs after warm-up.
+struct AllocScope {                                       // set by every C-ABI entry point for its thread
+  static hipStream_t &stream() { static thread_local hipStream_t s = nullptr; return s; }
+  static bool &async() { static thread_local bool a = false; return a; }
+  static int poison() { static int p = -1; if (p < 0) { const char *e = getenv("H10X_POISON"); p = e ? atoi(e) : 0; } return p; }   // debug: fill fresh buffers
+};
+// debug (H10X_ALLOC_CHECK=1): registry of live allocations, reports overlapping ranges handed out by the allocator
+struct AllocRegistry {
+  static std::map<uintptr_t, size_t> &live() { static std::map<uintptr_t, size_t> m; return m; }
+  static bool on() { static int v = -1; if (v < 0) { const char *e = getenv("H10X_ALLOC_CHECK"); v = e ? atoi(e) : 0; } return v != 0; }
+  static void add(void *p, size_t bytes) {
+    if (!on()) return;
+    const uintptr_t a = (uintptr_t)p;
+    for (auto &kv : live()) if (a < kv.first + kv.second && kv.first < a + bytes)
+      fprintf(stderr, "H10X_ALLOC_CHECK: new [%p,+%zu) overlaps live [%p,+%zu)\n", p, bytes, (void *)kv.first, kv.second);
+    live()[a] = bytes;
+  }
+  static void del(void *p) { if (on()) live().erase((uintptr_t)p); }
+};
 template <typename T> struct DevBuf {
-  T *p = nullptr; size_t n = 0;
+  T *p = nullptr; size_t n = 0; bool viaPool = false; hipStream_t st = nullptr;
   DevBuf() = default;
   DevBuf(const DevBuf &) = delete; DevBuf &operator=(const DevBuf &) = delete;
   ~DevBuf() { release(); }
-  void release() { if (p) (void)hipFree(p); p = nullptr; n = 0; }
+  void release() {
+    if (p) { AllocRegistry::del(p); if (viaPool) (void)hipFreeAsync(p, st); else (void)hipFree(p); }
+    p = nullptr; n = 0;
+  }
   hipError_t alloc(size_t count) {                       // contents undefined
     release();
     if (!count) count = 1;
-    hipError_t e = hipMalloc((void **)&p, count * sizeof(T));
-    if (e == hipSuccess) n = count; else p = nullptr;
+    hipError_t e;
+    if (AllocScope::async()) { st = AllocScope::stream(); viaPool = true; e = hipMallocAsync((void **)&p, count * sizeof(T), st); }
+    else { viaPool = false; e = hipMalloc((void **)&p, count * sizeof(T)); }
+    if (e == hipSuccess) { n = count; AllocRegistry::add(p, count * sizeof(T)); } else p = nullptr;
+    if (e == hipSuccess && AllocScope::poison()) (void)hipMemsetAsync(p, 0xA5, count * sizeof(T), AllocScope::stream());
     return e;
   }
-  void swap(DevBuf &o) { std::swap(p, o.p); std::swap(n, o.n); }
+  void swap(DevBuf &o) { std::swap(p, o.p); std::swap(n, o.n); std::swap(viaPool, o.viaPool); std::swap(st, o.st); }
   size_t bytes() const { return n * sizeof(T); }
 };
 
@@ -54,6 +82,8 @@ struct Ctx {
   int device = 0;
   hipStream_t stream = nullptr;
   int numCU = 256;
+  bool ownStream = false;     // stream created (and destroyed) by the context
+  bool poolOK = false;        // stream-ordered allocator usable on this device
   std::string err;
 
   // persistent state == the reference's globals (hash10x.c:85-96), device resident

@@ -5,6 +5,14 @@
 
 using namespace h10x;
 
+// every entry point: select the device and make DevBuf allocations stream-ordered on the context's stream
+static int enter(Ctx &c) {
+  if (hipSetDevice(c.device) != hipSuccess) return c.fail("hipSetDevice(%d) failed", c.device);
+  static const bool noPool = getenv("H10X_NOPOOL") != nullptr;      // debug: plain hipMalloc/hipFree
+  AllocScope::stream() = c.stream; AllocScope::async() = c.poolOK && !noPool;
+  return 0;
+}
+
 struct h10x_ctx { Ctx c; };
 
 extern "C" {
@@ -49,16 +57,32 @@ int h10x_create(h10x_ctx **out, const h10x_params *p, int device, void *stream, 
   h10x_ctx *h = new (std::nothrow) h10x_ctx();
   if (!h) return create_fail(err, errlen, "out of host memory");
   h->c.prm = *p; h->c.device = device; h->c.stream = (hipStream_t)stream; h->c.numCU = prop.multiProcessorCount;
+  if (!stream) {
+    // Never run on the legacy NULL stream: the stream-ordered allocator (hipMallocAsync/hipFreeAsync) reused blocks
+    // that kernels launched on the NULL stream were still using (ROCm 7.2; caught by the HBM-scratch parity test).
+    if (hipStreamCreateWithFlags(&h->c.stream, hipStreamNonBlocking) != hipSuccess) { delete h; return create_fail(err, errlen, "hipStreamCreate failed"); }
+    h->c.ownStream = true;
+  }
+  {                                                          // keep freed blocks in the device's default pool instead of returning them to the OS
+    int supported = 0; hipMemPool_t pool = nullptr;
+    if (hipDeviceGetAttribute(&supported, hipDeviceAttributeMemoryPoolsSupported, device) == hipSuccess && supported &&
+        hipDeviceGetDefaultMemPool(&pool, device) == hipSuccess) {
+      uint64_t keep = ~0ULL;
+      h->c.poolOK = hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &keep) == hipSuccess;
+    }
+  }
   *out = h;
   return 0;
 }
 
 void h10x_destroy(h10x_ctx *h) {
   if (!h) return;
-  (void)hipSetDevice(h->c.device);
+  (void)enter(h->c);
   (void)hipStreamSynchronize(h->c.stream);
   for (auto &t : h->c.timers) { if (t.a) (void)hipEventDestroy(t.a); if (t.b) (void)hipEventDestroy(t.b); }
+  hipStream_t own = h->c.ownStream ? h->c.stream : nullptr;
   delete h;
+  if (own) { (void)hipStreamSynchronize(own); (void)hipStreamDestroy(own); }
 }
 
 const char *h10x_last_error(const h10x_ctx *h) { return h ? h->c.err.c_str() : "null context"; }
@@ -73,7 +97,7 @@ static void reset_state(Ctx &c) {
 int h10x_read_fqb_device(h10x_ctx *h, const uint32_t *dRec, uint64_t n) {
   if (!h) return -1;
   Ctx &c = h->c;
-  H10X_HIP(&c, hipSetDevice(c.device));
+  H10X_TRY(enter(c));
   if (n && !dRec) return c.fail("h10x_read_fqb_device: null records");
   reset_state(c);
   DevBuf<u64> entHash; DevBuf<u32> entCode, entRead;
@@ -85,7 +109,7 @@ int h10x_read_fqb_device(h10x_ctx *h, const uint32_t *dRec, uint64_t n) {
 int h10x_read_fqb(h10x_ctx *h, const uint32_t *hostRec, uint64_t n) {
   if (!h) return -1;
   Ctx &c = h->c;
-  H10X_HIP(&c, hipSetDevice(c.device));
+  H10X_TRY(enter(c));
   if (n && !hostRec) return c.fail("h10x_read_fqb: null records");
   DevBuf<u32> d;
   H10X_HIP(&c, d.alloc(n * 30));
@@ -109,7 +133,7 @@ int h10x_load_state(h10x_ctx *h, const uint32_t *hashIndex, uint32_t hashNumber,
                     const uint32_t *hashDepth, const h10x_block *blocks, uint32_t nBlocks, const h10x_clushash *clusHash) {
   if (!h) return -1;
   Ctx &c = h->c;
-  H10X_HIP(&c, hipSetDevice(c.device));
+  H10X_TRY(enter(c));
   if (!hashIndex || !hashValue || !hashDepth || !blocks || nBlocks < 1 || hashNumber < 1) return c.fail("h10x_load_state: bad argument");
   reset_state(c);
   hipStream_t st = c.stream;
@@ -138,19 +162,19 @@ int h10x_load_state(h10x_ctx *h, const uint32_t *hashIndex, uint32_t hashNumber,
 
 int h10x_depth_range(h10x_ctx *h, int32_t lo, int32_t hi) {
   if (!h) return -1;
-  H10X_HIP(&h->c, hipSetDevice(h->c.device));
+  H10X_TRY(enter(h->c));
   return stageC_depthRange(&h->c, lo, hi);
 }
 
 int h10x_cluster(h10x_ctx *h, int32_t codeMin, int32_t codeMax, int32_t threshold) {
   if (!h) return -1;
-  H10X_HIP(&h->c, hipSetDevice(h->c.device));
+  H10X_TRY(enter(h->c));
   return stageC_cluster(&h->c, codeMin, codeMax, threshold);
 }
 
 int h10x_cluster_split(h10x_ctx *h) {
   if (!h) return -1;
-  H10X_HIP(&h->c, hipSetDevice(h->c.device));
+  H10X_TRY(enter(h->c));
   return stageC_split(&h->c);
 }
 
@@ -166,7 +190,7 @@ int h10x_get_sizes(h10x_ctx *h, h10x_sizes *out) {
 int h10x_export(h10x_ctx *h, uint32_t *hashIndex, uint64_t *hashValue, uint32_t *hashDepth, h10x_block *blocks, h10x_clushash *clusHash) {
   if (!h) return -1;
   Ctx &c = h->c;
-  H10X_HIP(&c, hipSetDevice(c.device));
+  H10X_TRY(enter(c));
   if (!c.haveState) return c.fail("no hash state loaded: use readFQB or readHash first");
   hipStream_t st = c.stream;
   if (hashIndex) H10X_HIP(&c, hipMemcpyAsync(hashIndex, c.hashIndex.p, ((size_t)1 << c.prm.B) * 4, hipMemcpyDeviceToHost, st));

@@ -25,9 +25,10 @@
 
 namespace h10x {
 
-constexpr int CL_THREADS_SMALL = 512;                      // 64 KB working sets, two workgroups per CU
+constexpr int CL_THREADS_SMALL = 1024;                     // 64 KB working sets, two workgroups per CU
 constexpr int CL_THREADS_BIG = 1024;                       // up to the whole LDS of a CU, one workgroup per CU
 constexpr u16 NONE16 = 0xFFFF;
+constexpr int ROWS_IN_FLIGHT = 4;                          // barcode lists a wavefront keeps in flight
 constexpr int RCHUNK = 4;                                   // register chunks: lists up to 256 entries
 
 // ------------------------------------------------------------------------------------------ depth range
@@ -168,16 +169,26 @@ __device__ inline Work carve(unsigned char *base, u32 nBlocks, u32 n) {
   w.hist = (u32 *)(base + o); w.histWords = (n + 3) / 4;
   return w;
 }
-// read-merge working set: readRep[min(nRead,65536)] bytes, adj[256][8] u32, comp[256] u32, newLab[256] u32
+// read-merge working set: readRep[min(nRead,65536)] bytes, adj[256][8] u32, comp[256] u32, newLab[512] u32
 __host__ __device__ inline size_t mergeBytes(u32 nRead) {
   const size_t r = nRead < 65536u ? nRead : 65536u;
-  return ((r + 15) & ~(size_t)15) + 256 * 8 * 4 + 256 * 4 + 256 * 4 + 16;
+  return ((r + 15) & ~(size_t)15) + 256 * 8 * 4 + 256 * 4 + 512 * 4 + 16;
+}
+
+// Loads of words that other waves of the workgroup modify with ATOMICS. Atomics on global memory execute in
+// L2 and leave this CU's vector L1 untouched, so in the HBM-scratch instantiation a plain load may return a
+// stale L1 line (left there by an earlier barcode of the same workgroup); agent-scope loads bypass L1.
+// In the LDS instantiation they are ordinary ds_reads.
+template <bool IN_LDS, typename T> __device__ __forceinline__ T ld_shared(const T *p) {
+  if (IN_LDS) return *p;
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // CAS-min on a u16 living in a u32 word (LDS or global)
+template <bool IN_LDS>
 __device__ __forceinline__ void min_u16(u16 *arr, u32 idx, u32 val) {
   u32 *w = (u32 *)arr + (idx >> 1); const int sh = (idx & 1) * 16;
-  u32 old = *(volatile u32 *)w;
+  u32 old = ld_shared<IN_LDS>(w);
   for (;;) {
     if (((old >> sh) & 0xFFFFu) <= val) return;
     const u32 nw = (old & ~(0xFFFFu << sh)) | (val << sh);
@@ -187,17 +198,28 @@ __device__ __forceinline__ void min_u16(u16 *arr, u32 idx, u32 val) {
   }
 }
 
+// wave64 max in registers: DPP row shifts (1,2,4,8) then row broadcasts 15/31 (gfx9 DPP), result in lane 63.
+// Identity 0 (keys are unsigned); no LDS round trips unlike ds_bpermute-based shuffles.
 __device__ __forceinline__ u32 wave_max_u32(u32 v) {
-#pragma unroll
-  for (int s = 32; s; s >>= 1) { const u32 o = (u32)__shfl_xor((int)v, s); v = o > v ? o : v; }
-  return v;
+#define H10X_DPP_MAX(ctrl, rowmask) { const u32 o = (u32)__builtin_amdgcn_update_dpp(0, (int)v, ctrl, rowmask, 0xf, false); v = o > v ? o : v; }
+  H10X_DPP_MAX(0x111, 0xf)      // row_shr:1
+  H10X_DPP_MAX(0x112, 0xf)      // row_shr:2
+  H10X_DPP_MAX(0x114, 0xf)      // row_shr:4
+  H10X_DPP_MAX(0x118, 0xf)      // row_shr:8
+  H10X_DPP_MAX(0x142, 0xa)      // row_bcast:15 into rows 1 and 3
+  H10X_DPP_MAX(0x143, 0xc)      // row_bcast:31 into rows 2 and 3
+#undef H10X_DPP_MAX
+  return (u32)__builtin_amdgcn_readlane((int)v, 63);
 }
 
-// msBest / msMax / msTot of one barcode list (< 256 entries) for rank i, one wavefront: the gathered
-// first[] values are counted in this wave's private byte histogram with ds atomics, every lane reads back
-// the count of its own value, and a wave max over (count, lowest rank) picks the mode.
-__device__ __forceinline__ void row_mode_hist(const u32 *__restrict__ row, u32 d, u32 code, u32 i, const u16 *first, u32 *hist,
-                                              u32 &best, u32 &bcnt, u32 &tot) {
+// msBest / msMax / msTot of one barcode list (< 256 entries) for rank i, one wavefront. The gathered first[]
+// values are counted in this wave's private byte histogram with RETURNING ds atomics: the lane that arrives
+// last at a value sees its full count, so a DPP wave max over (arrival count, lowest rank) is the mode —
+// one LDS round trip for the gather, one for the atomics. Lists with fewer usable entries than the
+// threshold are skipped (only "msMax < threshold" matters to the caller then).
+template <bool IN_LDS, int RCHUNK>
+__device__ __forceinline__ void row_mode_hist(const u32 *__restrict__ row, u32 cj0, u32 d, u32 code, u32 i, const u16 *first, u32 *hist,
+                                              u32 thr, u32 &best, u32 &bcnt, u32 &tot) {
   const int lane = threadIdx.x & (WAVE - 1);
   u32 f[RCHUNK]; bool ok[RCHUNK];
   tot = 0;
@@ -206,33 +228,39 @@ __device__ __forceinline__ void row_mode_hist(const u32 *__restrict__ row, u32 d
     f[r] = NONE16; ok[r] = false;
     if ((u32)(r * WAVE) < d) {
       const u32 j = r * WAVE + lane;
-      if (j < d) { const u32 cj = row[j]; if (cj != code) { f[r] = first[cj]; ok[r] = f[r] < i; } }
+      if (j < d) { const u32 cj = r == 0 ? cj0 : row[j]; if (cj != code) { f[r] = ld_shared<IN_LDS>(&first[cj]); ok[r] = f[r] < i; } }
       tot += (u32)__popcll(__ballot(ok[r]));
-      if (ok[r]) atomicAdd(&hist[f[r] >> 2], 1u << ((f[r] & 3) * 8));
     }
   }
+  best = NONE16; bcnt = 0;
+  if (tot < thr) return;
   u32 key = 0;
 #pragma unroll
   for (int r = 0; r < RCHUNK; ++r)
     if ((u32)(r * WAVE) < d && ok[r]) {
-      const u32 c = (*(volatile u32 *)&hist[f[r] >> 2] >> ((f[r] & 3) * 8)) & 0xFFu;
+      const int sh8 = (f[r] & 3) * 8;
+      const u32 c = ((atomicAdd(&hist[f[r] >> 2], 1u << sh8) >> sh8) & 0xFFu) + 1;
       const u32 k = (c << 16) | (0xFFFFu - f[r]);
       key = k > key ? k : key;
     }
   key = wave_max_u32(key);
 #pragma unroll
   for (int r = 0; r < RCHUNK; ++r)
-    if ((u32)(r * WAVE) < d && ok[r]) hist[f[r] >> 2] = 0;
+    if ((u32)(r * WAVE) < d && ok[r]) {
+      if (IN_LDS) hist[f[r] >> 2] = 0;                       // ds ops of a wave stay in order
+      else atomicAnd(&hist[f[r] >> 2], 0u);                  // HBM scratch: a plain store could be overtaken by the next list's atomics
+    }
   bcnt = key >> 16;
   best = key ? 0xFFFFu - (key & 0xFFFFu) : NONE16;
 }
 // lists of 256 entries and more (exotic depth ranges): re-gather per candidate
+template <bool IN_LDS>
 __device__ void row_mode_long(const u32 *__restrict__ row, u32 d, u32 code, u32 i, const u16 *first, u32 &best, u32 &bcnt, u32 &tot) {
   const int lane = threadIdx.x & (WAVE - 1);
   best = NONE16; bcnt = 0; tot = 0;
   for (u32 a0 = 0; a0 < d; a0 += WAVE) {
     u32 fa = NONE16; bool va = false;
-    if (a0 + lane < d) { const u32 cj = row[a0 + lane]; if (cj != code) { fa = first[cj]; va = fa < i; } }
+    if (a0 + lane < d) { const u32 cj = row[a0 + lane]; if (cj != code) { fa = ld_shared<IN_LDS>(&first[cj]); va = fa < i; } }
     u64 rem = __ballot(va); tot += (u32)__popcll(rem);
     while (rem) {
       const int src = __ffsll((long long)rem) - 1;
@@ -241,7 +269,7 @@ __device__ void row_mode_long(const u32 *__restrict__ row, u32 d, u32 code, u32 
       u32 cnt = 0; bool seenBefore = false;
       for (u32 b0 = 0; b0 < d; b0 += WAVE) {
         u32 fb = NONE16;
-        if (b0 + lane < d) { const u32 cj = row[b0 + lane]; if (cj != code) fb = first[cj]; }
+        if (b0 + lane < d) { const u32 cj = row[b0 + lane]; if (cj != code) fb = ld_shared<IN_LDS>(&first[cj]); }
         const u32 m = (u32)__popcll(__ballot(fb == v));
         if (b0 < a0 && m) { seenBefore = true; break; }
         cnt += m;
@@ -250,18 +278,12 @@ __device__ void row_mode_long(const u32 *__restrict__ row, u32 d, u32 code, u32 
     }
   }
 }
-__device__ __forceinline__ u32 row_count(const u32 *__restrict__ row, u32 d, u32 code, u32 target, const u16 *first) {
-  const int lane = threadIdx.x & (WAVE - 1);
-  u32 cnt = 0;
-  for (u32 b0 = 0; b0 < d; b0 += WAVE) {
-    bool m = false;
-    if (b0 + lane < d) { const u32 cj = row[b0 + lane]; if (cj != code) m = first[cj] == target; }
-    cnt += (u32)__popcll(__ballot(m));
-  }
-  return cnt;
-}
-
 #define STAMP(k) do { if (a.phase && threadIdx.x == 0) { const u64 t__ = wall_clock64(); atomicAdd((u64 *)&a.phase[k], t__ - tPrev); tPrev = t__; } } while (0)
+
+// Workgroup barrier. In the HBM-scratch instantiation the working set lives in global memory and is re-used
+// by successive phases: drop this CU's vector-L1 copies after every barrier (buffer_inv sc1) so that no phase
+// reads a line cached before another wave rewrote it.
+#define SYNC() do { __syncthreads(); if (!IN_LDS) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); } while (0)
 
 template <bool IN_LDS, int CL_THREADS>
 __device__ void cluster_one_block(const ClusterArgs &a, u32 code, unsigned char *region, u32 *sh /* small shared ints */) {
@@ -284,26 +306,50 @@ __device__ void cluster_one_block(const ClusterArgs &a, u32 code, unsigned char 
     w.rs[i] = (u32)a.rowStart[x]; w.dd[i] = d; w.lab[i] = 0; w.qj[i] = NONE16; w.best[i] = NONE16;
     w.ct[i].cnt = 0; w.ct[i].tot = 0; myDepth += d;
   }
-  __syncthreads();
+  SYNC();
   STAMP(0);
 
-  // ---- (a) first[]: lowest rank >= 1 sharing each other barcode (hash10x.c:794-799, minShare)
-  for (u32 i = 1 + wave; i < n; i += CL_WAVES) {
-    const u32 d = w.dd[i]; const u32 *row = a.rows + w.rs[i];
-    for (u32 j = lane; j < d; j += WAVE) { const u32 cj = row[j]; if (cj != code) min_u16(w.first, cj, i); }
+  // ---- (a) first[]: lowest rank >= 1 sharing each other barcode (hash10x.c:794-799, minShare).
+  // Each wavefront takes ranks in groups of ROWS_IN_FLIGHT so that several list reads are outstanding at once.
+  for (u32 i0 = 1 + wave * ROWS_IN_FLIGHT; i0 < n; i0 += CL_WAVES * ROWS_IN_FLIGHT) {
+    u32 cj[ROWS_IN_FLIGHT], dl[ROWS_IN_FLIGHT];
+#pragma unroll
+    for (int t = 0; t < ROWS_IN_FLIGHT; ++t) {
+      const u32 i = i0 + t; dl[t] = i < n ? w.dd[i] : 0;
+      cj[t] = (u32)lane < dl[t] ? a.rows[w.rs[i] + lane] : code;
+    }
+#pragma unroll
+    for (int t = 0; t < ROWS_IN_FLIGHT; ++t) {
+      const u32 i = i0 + t;
+      if (cj[t] != code) min_u16<IN_LDS>(w.first, cj[t], i);
+      if (dl[t] > WAVE) { const u32 *row = a.rows + w.rs[i]; for (u32 j = WAVE + lane; j < dl[t]; j += WAVE) { const u32 c2 = row[j]; if (c2 != code) min_u16<IN_LDS>(w.first, c2, i); } }
+    }
   }
-  __syncthreads();
+  SYNC();
   STAMP(1);
 
   // ---- (b) msBest / msMax / msTot per rank (hash10x.c:801-806)
-  for (u32 i = 1 + wave; i < n; i += CL_WAVES) {
-    const u32 d = w.dd[i]; const u32 *row = a.rows + w.rs[i];
-    u32 best, bcnt, tot;
-    if (d < RCHUNK * WAVE) row_mode_hist(row, d, code, i, w.first, w.hist + wave * w.histWords, best, bcnt, tot);
-    else row_mode_long(row, d, code, i, w.first, best, bcnt, tot);
-    if (lane == 0) { w.best[i] = (u16)best; w.ct[i].cnt = bcnt; w.ct[i].tot = tot; }
+  for (u32 i0 = 1 + wave * ROWS_IN_FLIGHT; i0 < n; i0 += CL_WAVES * ROWS_IN_FLIGHT) {
+    u32 cj[ROWS_IN_FLIGHT], dl[ROWS_IN_FLIGHT];
+#pragma unroll
+    for (int t = 0; t < ROWS_IN_FLIGHT; ++t) {
+      const u32 i = i0 + t; dl[t] = i < n ? w.dd[i] : 0;
+      cj[t] = (u32)lane < dl[t] ? a.rows[w.rs[i] + lane] : code;
+    }
+#pragma unroll
+    for (int t = 0; t < ROWS_IN_FLIGHT; ++t) {
+      const u32 i = i0 + t;
+      if (i < n) {
+        const u32 d = dl[t]; const u32 *row = a.rows + w.rs[i];
+        u32 best, bcnt, tot;
+        if (d <= WAVE) row_mode_hist<IN_LDS, 1>(row, cj[t], d, code, i, w.first, w.hist + wave * w.histWords, (u32)a.threshold, best, bcnt, tot);
+        else if (d < RCHUNK * WAVE) row_mode_hist<IN_LDS, RCHUNK>(row, cj[t], d, code, i, w.first, w.hist + wave * w.histWords, (u32)a.threshold, best, bcnt, tot);
+        else row_mode_long<IN_LDS>(row, d, code, i, w.first, best, bcnt, tot);
+        if (lane == 0) { w.best[i] = (u16)best; w.ct[i].cnt = bcnt; w.ct[i].tot = tot; }
+      }
+    }
   }
-  __syncthreads();
+  SYNC();
   STAMP(2);
 
   // ---- (c) the order-dependent part of hash10x.c:807-822, restated without a serial walk.
@@ -320,20 +366,20 @@ __device__ void cluster_one_block(const ClusterArgs &a, u32 code, unsigned char 
       const bool act = i >= 1 && (int)w.ct[i].cnt >= a.threshold;
       ptr[i] = act ? w.best[i] : (u16)i; ft[i] = NONE16; fl[i] = 0;
     }
-    __syncthreads();
+    SYNC();
     for (u32 i = tid; i < n; i += CL_THREADS)
       if (i >= 1 && (int)w.ct[i].cnt >= a.threshold) {
         const u32 b = w.best[i];
-        if (!(b >= 1 && (int)w.ct[b].cnt >= a.threshold)) min_u16(ft, b, i);
+        if (!(b >= 1 && (int)w.ct[b].cnt >= a.threshold)) min_u16<IN_LDS>(ft, b, i);
       }
     u32 rounds = 1; while ((1u << rounds) < n) ++rounds;
     for (u32 r = 0; r <= rounds; ++r) {                      // chains only run downwards: in-place jumping converges
-      __syncthreads();
+      SYNC();
       for (u32 i = tid; i < n; i += CL_THREADS) { const u32 p = ptr[i]; const u32 pp = *(volatile u16 *)&ptr[p]; if (pp != p) ptr[i] = (u16)pp; }
     }
-    __syncthreads();
-    for (u32 i = tid; i < n; i += CL_THREADS) { const u32 t = ft[i]; if (t != NONE16) fl[t] = 1; }   // founding turns are distinct
-    __syncthreads();
+    SYNC();
+    for (u32 i = tid; i < n; i += CL_THREADS) { const u32 t = ld_shared<IN_LDS>(&ft[i]); if (t != NONE16) fl[t] = 1; }   // founding turns are distinct
+    SYNC();
     // block-wide inclusive scan of fl[0..n)
     const u32 ipt = (n + CL_THREADS - 1) / CL_THREADS, s0 = tid * ipt, s1 = s0 + ipt < n ? s0 + ipt : n;
     u32 mine = 0;
@@ -342,11 +388,11 @@ __device__ void cluster_one_block(const ClusterArgs &a, u32 code, unsigned char 
 #pragma unroll
     for (int d = 1; d < WAVE; d <<= 1) { const u32 o = (u32)__shfl_up((int)inc, d); if (lane >= d) inc += o; }
     if (lane == WAVE - 1) sh[4 + wave] = inc;
-    __syncthreads();
+    SYNC();
     u32 run = inc - mine;
     for (int q = 0; q < wave; ++q) run += sh[4 + q];
     for (u32 i = s0; i < s1; ++i) { run += fl[i]; fl[i] = (u16)run; }
-    __syncthreads();
+    SYNC();
     const u32 nRoots = fl[n - 1];
     if (nRoots > 255) {                                      // hash10x.c:810-816: abandon at the 256th founding turn
       for (u32 i = tid; i < n; i += CL_THREADS) {
@@ -359,26 +405,41 @@ __device__ void cluster_one_block(const ClusterArgs &a, u32 code, unsigned char 
       for (u32 i = tid; i < n; i += CL_THREADS) {
         const bool act = i >= 1 && (int)w.ct[i].cnt >= a.threshold;
         u32 L = 0;
-        if (act) L = fl[ft[ptr[i]]];
-        else { const u32 t = ft[i]; if (t != NONE16) L = fl[t]; ptr[i] = NONE16; }
+        if (act) L = fl[ld_shared<IN_LDS>(&ft[ptr[i]])];
+        else { const u32 t = ld_shared<IN_LDS>(&ft[i]); if (t != NONE16) L = fl[t]; ptr[i] = NONE16; }
         w.lab[i] = (u8)L;
       }
     }
   }
-  __syncthreads();
+  SYNC();
   const u32 nSub = sh[0], stop = sh[1];
   STAMP(3);
 
-  // ---- (d) minShareCount[clusterMin[label]] / (double) msTot per rank (hash10x.c:821)
-  for (u32 i = 1 + wave; i < stop; i += CL_WAVES) {
-    const u32 qj = w.qj[i];
-    if (qj == NONE16) continue;
-    u32 q;
-    if (qj == w.best[i]) q = w.ct[i].cnt;
-    else q = row_count(a.rows + w.rs[i], w.dd[i], code, qj, w.first);
-    if (lane == 0) { const double t = (double)(int)q / (double)(int)w.ct[i].tot; *(double *)&w.ct[i] = t; }
+  // ---- (d) minShareCount[clusterMin[label]] / (double) msTot per rank (hash10x.c:821); the list is re-read only
+  // when the cluster's founder is not msBest, ROWS_IN_FLIGHT lists at a time
+  for (u32 i0 = 1 + wave * ROWS_IN_FLIGHT; i0 < stop; i0 += CL_WAVES * ROWS_IN_FLIGHT) {
+    u32 cj[ROWS_IN_FLIGHT], dl[ROWS_IN_FLIGHT], qv[ROWS_IN_FLIGHT];
+#pragma unroll
+    for (int t = 0; t < ROWS_IN_FLIGHT; ++t) {
+      const u32 i = i0 + t; qv[t] = i < stop ? (u32)w.qj[i] : NONE16;
+      const bool need = qv[t] != NONE16 && qv[t] != w.best[i];
+      dl[t] = need ? w.dd[i] : 0;
+      cj[t] = (u32)lane < dl[t] ? a.rows[w.rs[i] + lane] : code;
+    }
+#pragma unroll
+    for (int t = 0; t < ROWS_IN_FLIGHT; ++t) {
+      const u32 i = i0 + t;
+      if (qv[t] == NONE16) continue;
+      u32 q;
+      if (dl[t] == 0) q = w.ct[i].cnt;
+      else {
+        q = (u32)__popcll(__ballot(cj[t] != code && ld_shared<IN_LDS>(&w.first[cj[t]]) == qv[t]));
+        if (dl[t] > WAVE) { const u32 *row = a.rows + w.rs[i]; for (u32 b0 = WAVE; b0 < dl[t]; b0 += WAVE) { bool m = false; if (b0 + lane < dl[t]) { const u32 c2 = row[b0 + lane]; m = c2 != code && ld_shared<IN_LDS>(&w.first[c2]) == qv[t]; } q += (u32)__popcll(__ballot(m)); } }
+      }
+      if (lane == 0) { const double tq = (double)(int)q / (double)(int)w.ct[i].tot; *(double *)&w.ct[i] = tq; }
+    }
   }
-  __syncthreads();
+  SYNC();
   STAMP(4);
 
   // ---- (e) ordered fp64 sum (wavefront 0: 64 quotients per LDS read, added in rank order via readlane), labels out
@@ -405,13 +466,13 @@ __device__ void cluster_one_block(const ClusterArgs &a, u32 code, unsigned char 
   if (lane == 0) atomicAdd((u64 *)&a.stats[1], (u64)myDepth);
   if (tid == 0) { atomicAdd((u64 *)&a.stats[0], (u64)n); atomicAdd((u64 *)&a.stats[2], (u64)nHash); atomicAdd((u64 *)&a.stats[3], 1ULL); }
   if (!IN_LDS) {                                             // leave first[] clean for the next barcode of this workgroup
-    __syncthreads();
+    SYNC();
     for (u32 i = 1 + wave; i < n; i += CL_WAVES) {
       const u32 d = w.dd[i]; const u32 *row = a.rows + w.rs[i];
       for (u32 j = lane; j < d; j += WAVE) w.first[row[j]] = NONE16;
     }
   }
-  __syncthreads();
+  SYNC();
   STAMP(5);
   if (!nSub) return;                                         // hash10x.c:840
 
@@ -425,12 +486,12 @@ __device__ void cluster_one_block(const ClusterArgs &a, u32 code, unsigned char 
   for (u32 i = tid; i < 256 * 8; i += CL_THREADS) adj[i] = 0;
   if (tid < 256) comp[tid] = tid;
   __threadfence_block();
-  __syncthreads();
+  SYNC();
   for (u32 p = tid; p < nHash; p += CL_THREADS) {            // any one label of each read is its representative
     const h10x_clushash e = ch[p];
     if (e.subCluster && e.subCluster <= nSub && e.read < nRep) readRep[e.read] = e.subCluster;
   }
-  __syncthreads();
+  SYNC();
   for (u32 p = tid; p < nHash; p += CL_THREADS) {
     const h10x_clushash e = ch[p];
     if (e.subCluster && e.subCluster <= nSub && e.read < nRep) {
@@ -438,33 +499,35 @@ __device__ void cluster_one_block(const ClusterArgs &a, u32 code, unsigned char 
       if (R != L) { atomicOr(&adj[L * 8 + (R >> 5)], 1u << (R & 31)); atomicOr(&adj[R * 8 + (L >> 5)], 1u << (L & 31)); }
     }
   }
-  __syncthreads();
+  SYNC();
   for (int iter = 0; iter < 256; ++iter) {                   // min-label propagation; <= 255 rounds
     if (tid == 0) sh[2] = 0;
-    __syncthreads();
+    SYNC();
     if (tid >= 1 && tid <= (int)nSub) {
-      u32 m = comp[tid];
-      for (int wd = 0; wd < 8; ++wd) { u32 bits = adj[tid * 8 + wd]; while (bits) { const int b = __ffs((int)bits) - 1; bits &= bits - 1; const u32 cR = comp[wd * 32 + b]; m = cR < m ? cR : m; } }
-      if (m < comp[tid]) { atomicMin(&comp[tid], m); sh[2] = 1; }
+      const u32 mine = ld_shared<IN_LDS>(&comp[tid]); u32 m = mine;
+      for (int wd = 0; wd < 8; ++wd) { u32 bits = ld_shared<IN_LDS>(&adj[tid * 8 + wd]); while (bits) { const int b = __ffs((int)bits) - 1; bits &= bits - 1; const u32 cR = ld_shared<IN_LDS>(&comp[wd * 32 + b]); m = cR < m ? cR : m; } }
+      if (m < mine) { atomicMin(&comp[tid], m); sh[2] = 1; }
     }
-    __syncthreads();
+    SYNC();
     if (!sh[2]) break;
-    __syncthreads();
+    SYNC();
   }
   if (tid == 0) {                                            // renumber components by ascending minimum label
     u32 alive = 0; newLab[0] = 0;
-    for (u32 L = 1; L <= nSub; ++L) { if (comp[L] == L) ++alive; newLab[L] = alive; }   // rank of L if it is a minimum
-    for (u32 L = 1; L <= nSub; ++L) comp[L] = newLab[comp[L]];                          // label -> rank of its minimum
+    for (u32 L = 1; L <= nSub; ++L) { if (ld_shared<IN_LDS>(&comp[L]) == L) ++alive; newLab[L] = alive; }   // rank of L if it is a minimum
+    for (u32 L = 1; L <= nSub; ++L) newLab[256 + L] = newLab[ld_shared<IN_LDS>(&comp[L])];                 // label -> rank of its minimum
     a.blocks[code].nSubCluster = alive;
   }
-  __syncthreads();
+  SYNC();
   for (u32 p = tid; p < nHash; p += CL_THREADS) {
     const u32 L = ch[p].subCluster;
-    if (L && L <= nSub) ch[p].subCluster = (u8)comp[L];
+    if (L && L <= nSub) ch[p].subCluster = (u8)newLab[256 + L];
   }
-  __syncthreads();
+  SYNC();
   STAMP(6);
 }
+
+#undef SYNC
 
 template <bool IN_LDS, int CL_THREADS>
 __global__ __launch_bounds__(CL_THREADS)
@@ -511,7 +574,7 @@ int stageC_cluster(Ctx *c, int codeMin, int codeMax, int threshold) {
   H10X_HIP(c, list0.alloc(span)); H10X_HIP(c, list1.alloc(span)); H10X_HIP(c, list2.alloc(span));
   H10X_HIP(c, counts.alloc(8)); H10X_HIP(c, stats.alloc(4));
   H10X_HIP(c, hipMemsetAsync(counts.p, 0, 32, st)); H10X_HIP(c, hipMemsetAsync(stats.p, 0, 32, st));
-  const size_t budgetSmall = c->optClusterLds > 0 ? (size_t)c->optClusterLds : 64 * 1024 - 1024;
+  const size_t budgetSmall = c->optClusterLds > 0 ? (size_t)c->optClusterLds : 80 * 1024 - 1024;
   const size_t budgetBig = c->optClusterLds > 0 ? (size_t)c->optClusterLds : 160 * 1024 - 1024;
   cluster_classify_kernel<<<divUp(span, 256), 256, 0, st>>>(c->blocks.p, c->nGood.p, (u32)codeMin, (u32)codeMax, c->nBlocks, budgetSmall, budgetBig,
                                                           list0.p, list1.p, list2.p, counts.p);
