@@ -1,6 +1,7 @@
 // h10x_api.hip — the C ABI of include/h10x.h over the stage drivers. No torch, no CPU fallback.
 #include "common.hpp"
 #include <cstdlib>
+#include <ctime>
 #include <new>
 
 using namespace h10x;
@@ -50,8 +51,13 @@ int h10x_create(h10x_ctx **out, const h10x_params *p, int device, void *stream, 
     return create_fail(err, errlen, "no HIP device available: libh10x_hip has no CPU fallback");
   if (device < 0 || device >= n) return create_fail(err, errlen, "HIP device %d out of range 0..%d", device, n - 1);
   if (hipSetDevice(device) != hipSuccess) return create_fail(err, errlen, "hipSetDevice(%d) failed", device);
-  hipDeviceProp_t prop;
-  if (hipGetDeviceProperties(&prop, device) != hipSuccess) return create_fail(err, errlen, "hipGetDeviceProperties failed");
+  static hipDeviceProp_t propCache[64]; static bool propOK[64];          // hipGetDeviceProperties costs milliseconds
+  if (device >= 64) return create_fail(err, errlen, "HIP device %d out of range", device);
+  if (!propOK[device]) {
+    if (hipGetDeviceProperties(&propCache[device], device) != hipSuccess) return create_fail(err, errlen, "hipGetDeviceProperties failed");
+    propOK[device] = true;
+  }
+  const hipDeviceProp_t &prop = propCache[device];
   if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
     return create_fail(err, errlen, "device %d is %s: this library is built for gfx950 (MI355X) only", device, prop.gcnArchName);
   h10x_ctx *h = new (std::nothrow) h10x_ctx();
@@ -100,9 +106,15 @@ int h10x_read_fqb_device(h10x_ctx *h, const uint32_t *dRec, uint64_t n) {
   H10X_TRY(enter(c));
   if (n && !dRec) return c.fail("h10x_read_fqb_device: null records");
   reset_state(c);
+  static const bool prof = getenv("H10X_HOSTPROF") != nullptr;
+  timespec t0, t1, t2; clock_gettime(CLOCK_MONOTONIC, &t0);
   DevBuf<u64> entHash; DevBuf<u32> entCode, entRead;
   H10X_TRY(stageA_run(&c, dRec, n, entHash, entCode, entRead));
+  clock_gettime(CLOCK_MONOTONIC, &t1);
   H10X_TRY(stageB_run(&c, entHash, entCode, entRead));
+  clock_gettime(CLOCK_MONOTONIC, &t2);
+  if (prof) fprintf(stderr, "hostprof: stageA %.3f ms, stageB %.3f ms (wall)\n", 1e3 * (t1.tv_sec - t0.tv_sec) + 1e-6 * (t1.tv_nsec - t0.tv_nsec),
+                    1e3 * (t2.tv_sec - t1.tv_sec) + 1e-6 * (t2.tv_nsec - t1.tv_nsec));
   return 0;
 }
 

@@ -99,8 +99,8 @@ __global__ void block_starts_kernel(const u32 *__restrict__ flags, const u32 *__
 // per block: nRead, the LDS table size it gets (0 = global path), and its class list
 __global__ void classify_kernel(const u64 *__restrict__ startRec, u32 nBlocks, h10x_block *__restrict__ blocks,
                                 u32 *__restrict__ slots, u32 maxSlots, int packedOK,
-                                u32 *__restrict__ listS, u32 *__restrict__ listM, u32 *__restrict__ listF,
-                                u32 *__restrict__ counts /* 3 */, u32 smallSlots) {
+                                u32 *__restrict__ list0, u32 *__restrict__ list1, u32 *__restrict__ list2, u32 *__restrict__ listF,
+                                u32 *__restrict__ counts /* 4: <=4096, 8192, 16384 slots, global path */) {
   const u32 c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= nBlocks) return;
   h10x_block b; memset(&b, 0, sizeof b);
@@ -110,11 +110,13 @@ __global__ void classify_kernel(const u64 *__restrict__ startRec, u32 nBlocks, h
   blocks[c] = b;
   u32 s = 0;
   if (c + 1 < nBlocks) {                                     // the last block is never hashed
-    u64 want = 256; while (want < nr * 12) want <<= 1;      // expected load <= 0.63 at 7.6 unique / pair
+    u64 want = 256; while (want < nr * 10) want <<= 1;      // expected load <= 0.76 at 7.6 unique / pair (overflow at 0.875 => global path)
     if (packedOK && nr <= 65535 && want <= maxSlots) {
       s = (u32)want;
-      if (s <= smallSlots) listS[atomicAdd(&counts[0], 1u)] = c; else listM[atomicAdd(&counts[1], 1u)] = c;
-    } else listF[atomicAdd(&counts[2], 1u)] = c;
+      if (s <= 4096) list0[atomicAdd(&counts[0], 1u)] = c;
+      else if (s <= 8192) list1[atomicAdd(&counts[1], 1u)] = c;
+      else list2[atomicAdd(&counts[2], 1u)] = c;
+    } else listF[atomicAdd(&counts[3], 1u)] = c;
   }
   slots[c] = s;
 }
@@ -161,12 +163,18 @@ void mosh_lds_kernel(const u32 *__restrict__ rec, const u32 *__restrict__ list, 
     __syncthreads();
     stage_records(rec, rec0 + r0, cnt, tile);
     __syncthreads();
+    // survivors are rare (1 in w): park one per lane and insert them together once per tile, so the insert
+    // loop runs with many lanes active instead of ~2 per wavefront per record
+    u64 pendH = EMPTY64; u32 pendR = 0;
     for (int rr = 0; rr < cnt; ++rr)
       for (int t = threadIdx.x; t < nk; t += blockDim.x) {
         u64 h;
-        if (mosh_of_slot<W31>(tile + rr * 2 * SEQ_WORDS, t, mc, h))
-          if (!lds_set_insert(table, mask, h, r0 + rr)) sOverflow = 1;
+        if (mosh_of_slot<W31>(tile + rr * 2 * SEQ_WORDS, t, mc, h)) {
+          if (pendH != EMPTY64 && !lds_set_insert(table, mask, pendH, pendR)) sOverflow = 1;
+          pendH = h; pendR = r0 + rr;
+        }
       }
+    if (pendH != EMPTY64 && !lds_set_insert(table, mask, pendH, pendR)) sOverflow = 1;
   }
   __syncthreads();
 
@@ -290,17 +298,16 @@ int stageA_run(Ctx *c, const u32 *dRec, u64 nRec, DevBuf<u64> &entHash, DevBuf<u
   H10X_HIP(c, c->blocks.alloc(nBlocks));
 
   // ---- classes
-  const u32 smallSlots = 4096;                               // 32 KB tables: several workgroups per CU
-  u32 maxSlots = 16384;                                      // 128 KB tables: one workgroup per CU
+  u32 maxSlots = 16384;                                      // LDS table classes: 4096 / 8192 / 16384 slots = 32 / 64 / 128 KB
   if (c->optMaxSlots > 0) maxSlots = (u32)c->optMaxSlots;
   const int packedOK = (2 * k + 16 <= 64) ? 1 : 0;
-  DevBuf<u32> slots, listS, listM, listF, counts, nHash;
-  H10X_HIP(c, slots.alloc(nBlocks)); H10X_HIP(c, listS.alloc(nBlocks)); H10X_HIP(c, listM.alloc(nBlocks));
+  DevBuf<u32> slots, list0, list1, list2, listF, counts, nHash;
+  H10X_HIP(c, slots.alloc(nBlocks)); H10X_HIP(c, list0.alloc(nBlocks)); H10X_HIP(c, list1.alloc(nBlocks)); H10X_HIP(c, list2.alloc(nBlocks));
   H10X_HIP(c, listF.alloc(nBlocks)); H10X_HIP(c, counts.alloc(4)); H10X_HIP(c, nHash.alloc((size_t)nBlocks + 1));
   H10X_HIP(c, hipMemsetAsync(counts.p, 0, 16, st));
   H10X_HIP(c, hipMemsetAsync(nHash.p, 0, ((size_t)nBlocks + 1) * 4, st));
   classify_kernel<<<divUp(nBlocks, 256), 256, 0, st>>>(startRec.p, nBlocks, c->blocks.p, slots.p, maxSlots, packedOK,
-                                                      listS.p, listM.p, listF.p, counts.p, smallSlots < maxSlots ? smallSlots : maxSlots);
+                                                      list0.p, list1.p, list2.p, listF.p, counts.p);
   DevBuf<u64> capOff; H10X_HIP(c, capOff.alloc((size_t)nBlocks + 1));
   H10X_TRY(prim_exclusive_scan_u32_u64(c, pt, slots.p, capOff.p, nBlocks));
   u32 hc[4]; u64 capTotal = 0; u32 lastSlots = 0;
@@ -316,10 +323,10 @@ int stageA_run(Ctx *c, const u32 *dRec, u64 nRec, DevBuf<u64> &entHash, DevBuf<u
   H10X_HIP(c, stHash.alloc(capTotal)); H10X_HIP(c, stRead.alloc(capTotal));
   c->tstart(T_MOSH);
   const size_t tileBytes = REC_TILE * 2 * SEQ_WORDS * 4;
-  for (int cls = 0; cls < 2; ++cls) {
+  for (int cls = 2; cls >= 0; --cls) {                       // biggest tables first
     const u32 n = hc[cls]; if (!n) continue;
-    const u32 *list = cls ? listM.p : listS.p;
-    const size_t lds = (size_t)(cls ? maxSlots : (smallSlots < maxSlots ? smallSlots : maxSlots)) * 8 + tileBytes;
+    const u32 *list = cls == 0 ? list0.p : cls == 1 ? list1.p : list2.p;
+    const size_t lds = (size_t)hmin<u32>(4096u << cls, maxSlots) * 8 + tileBytes;
     if (w31) {
       if (lds > 48 * 1024) H10X_HIP(c, hipFuncSetAttribute((const void *)mosh_lds_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
       mosh_lds_kernel<true><<<n, MOSH_THREADS, lds, st>>>(dRec, list, n, startRec.p, slots.p, capOff.p, mc, stHash.p, stRead.p, nHash.p);
@@ -332,11 +339,11 @@ int stageA_run(Ctx *c, const u32 *dRec, u64 nRec, DevBuf<u64> &entHash, DevBuf<u
   c->tstop(T_MOSH);
 
   // ---- global path: class F plus any block whose LDS set overflowed
-  std::vector<u32> hNHash(nBlocks + 1), hListF(hc[2]);
+  std::vector<u32> hNHash(nBlocks + 1), hListF(hc[3]);
   std::vector<u64> hStart(nBlocks + 1);
   H10X_HIP(c, hipMemcpyAsync(hNHash.data(), nHash.p, (size_t)nBlocks * 4, hipMemcpyDeviceToHost, st));
   H10X_HIP(c, hipMemcpyAsync(hStart.data(), startRec.p, ((size_t)nBlocks + 1) * 8, hipMemcpyDeviceToHost, st));
-  if (hc[2]) H10X_HIP(c, hipMemcpyAsync(hListF.data(), listF.p, (size_t)hc[2] * 4, hipMemcpyDeviceToHost, st));
+  if (hc[3]) H10X_HIP(c, hipMemcpyAsync(hListF.data(), listF.p, (size_t)hc[3] * 4, hipMemcpyDeviceToHost, st));
   H10X_HIP(c, hipStreamSynchronize(st));
   for (u32 b = 1; b + 1 < nBlocks; ++b) if (hNHash[b] == NHASH_OVERFLOW) hListF.push_back(b);
   std::vector<SrcPtr> hFb(nBlocks, SrcPtr{nullptr, nullptr});
