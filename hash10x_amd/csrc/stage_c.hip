@@ -309,9 +309,13 @@ __device__ void cluster_one_block(const ClusterArgs &a, u32 code, unsigned char 
   SYNC();
   STAMP(0);
 
-  // ---- (a) first[]: lowest rank >= 1 sharing each other barcode (hash10x.c:794-799, minShare).
-  // Each wavefront takes ranks in groups of ROWS_IN_FLIGHT so that several list reads are outstanding at once.
-  for (u32 i0 = 1 + wave * ROWS_IN_FLIGHT; i0 < n; i0 += CL_WAVES * ROWS_IN_FLIGHT) {
+  // ---- (a)+(b) in one pass over the lists, in rank order, CL_WAVES * ROWS_IN_FLIGHT ranks per round:
+  //   (a) first[cj] = lowest rank >= 1 sharing barcode cj (hash10x.c:794-799, minShare) by CAS-min,
+  //   (b) msBest / msMax / msTot of the same ranks (hash10x.c:801-806) from the list entries still in registers.
+  // first[cj] for a barcode of list i is final once every list <= i has been merged (later lists can only
+  // offer larger ranks), so one barrier per round is enough.
+  for (u32 r0 = 1; r0 < n; r0 += CL_WAVES * ROWS_IN_FLIGHT) {
+    const u32 i0 = r0 + wave * ROWS_IN_FLIGHT;
     u32 cj[ROWS_IN_FLIGHT], dl[ROWS_IN_FLIGHT];
 #pragma unroll
     for (int t = 0; t < ROWS_IN_FLIGHT; ++t) {
@@ -324,18 +328,7 @@ __device__ void cluster_one_block(const ClusterArgs &a, u32 code, unsigned char 
       if (cj[t] != code) min_u16<IN_LDS>(w.first, cj[t], i);
       if (dl[t] > WAVE) { const u32 *row = a.rows + w.rs[i]; for (u32 j = WAVE + lane; j < dl[t]; j += WAVE) { const u32 c2 = row[j]; if (c2 != code) min_u16<IN_LDS>(w.first, c2, i); } }
     }
-  }
-  SYNC();
-  STAMP(1);
-
-  // ---- (b) msBest / msMax / msTot per rank (hash10x.c:801-806)
-  for (u32 i0 = 1 + wave * ROWS_IN_FLIGHT; i0 < n; i0 += CL_WAVES * ROWS_IN_FLIGHT) {
-    u32 cj[ROWS_IN_FLIGHT], dl[ROWS_IN_FLIGHT];
-#pragma unroll
-    for (int t = 0; t < ROWS_IN_FLIGHT; ++t) {
-      const u32 i = i0 + t; dl[t] = i < n ? w.dd[i] : 0;
-      cj[t] = (u32)lane < dl[t] ? a.rows[w.rs[i] + lane] : code;
-    }
+    SYNC();
 #pragma unroll
     for (int t = 0; t < ROWS_IN_FLIGHT; ++t) {
       const u32 i = i0 + t;
@@ -349,6 +342,7 @@ __device__ void cluster_one_block(const ClusterArgs &a, u32 code, unsigned char 
       }
     }
   }
+  STAMP(1);
   SYNC();
   STAMP(2);
 

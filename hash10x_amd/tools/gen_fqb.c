@@ -20,7 +20,6 @@
 #include <stdlib.h>
 #include <stdint.h>
 #include <string.h>
-#include <math.h>
 
 typedef struct { uint64_t s[4]; } rng_t;
 static uint64_t splitmix64(uint64_t *x) {
@@ -38,15 +37,31 @@ static inline uint64_t rng_next(rng_t *r) {           /* xoshiro256** */
 }
 static inline double rng_unif(rng_t *r) { return (rng_next(r) >> 11) * (1.0 / 9007199254740992.0); }
 static inline uint64_t rng_below(rng_t *r, uint64_t n) { return (uint64_t)(rng_unif(r) * (double)n); }
-static double rng_normal(rng_t *r) {
-  double u1 = rng_unif(r), u2 = rng_unif(r);
-  if (u1 < 1e-300) u1 = 1e-300;
-  return sqrt(-2.0 * log(u1)) * cos(6.283185307179586 * u2);
+/* No libm on the random path: glibc picks FMA / non-FMA variants of log/exp/cos per CPU, whose last-ulp
+   differences would make the "seeded" data set depend on the host. Everything below is plain IEEE
+   + - * / (compile with -ffp-contract=off), so a seed gives the same bytes everywhere. */
+static double det_log(double x) {                           /* ln x for x in (0, 1], ~1e-15 relative */
+  int e = 0;
+  while (x < 1.0) { x *= 2.0; --e; }
+  while (x >= 2.0) { x *= 0.5; ++e; }                        /* x in [1, 2) */
+  const double s = (x - 1.0) / (x + 1.0), s2 = s * s;
+  double term = s, sum = 0.0;
+  for (int k = 1; k < 60; k += 2) { sum += term / (double)k; term *= s2; }
+  return 2.0 * sum + (double)e * 0.6931471805599453;
 }
-static int rng_poisson(rng_t *r, double lambda) {
-  double L = exp(-lambda), p = 1.0; int k = 0;
-  do { ++k; p *= rng_unif(r); } while (p > L);
-  return k - 1;
+static double rng_exp1(rng_t *r) {                          /* Exp(1) */
+  double u = 1.0 - rng_unif(r);                             /* (0, 1] */
+  return -det_log(u);
+}
+static double rng_normal(rng_t *r) {                        /* Irwin-Hall: 12 uniforms - 6 */
+  double s = 0.0;
+  for (int i = 0; i < 12; ++i) s += rng_unif(r);
+  return s - 6.0;
+}
+static int rng_poisson(rng_t *r, double lambda) {           /* arrivals of a unit-rate process before time lambda */
+  int k = 0; double t = rng_exp1(r);
+  while (t < lambda) { ++k; t += rng_exp1(r); }
+  return k;
 }
 
 typedef struct {
@@ -139,7 +154,7 @@ static uint64_t generate(const h10x_gen_params *p, uint32_t *out, FILE *f) {
     blen[b] = 0;
     for (int j = 0; j < m; ++j) {
       if (nMol == molCap) { molCap *= 2; mols = (mol_t *)realloc(mols, sizeof(mol_t) * molCap); }
-      double L = -p->mean_len * log(1.0 - rng_unif(&r));
+      double L = p->mean_len * rng_exp1(&r);
       if (L < p->mean_len * 0.1) L = p->mean_len * 0.1;
       if (L < 400.0) L = 400.0;
       if (L > p->mean_len * 5.0) L = p->mean_len * 5.0;
