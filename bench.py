@@ -12,8 +12,8 @@ generator of hash10x_amd/tools/gen_fqb.c stands in.
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
 
 N > 1: one process per GPU, each rank runs the path on its own seeded set of the same size (weak
-scaling, independent samples, no data-path collective yet — see DESIGN.md "Multi-GPU"). torch is
-used for device memory, barriers and max-over-ranks only.
+scaling, independent samples, no data-path collective yet — see DESIGN.md "Multi-GPU"). torch.distributed
+(gloo) is used for the barrier and the max-over-ranks of the elapsed time only.
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` for the dominant
 kernel and `cpu_baseline` (the reference binary from oracle/_ref, or the oracle port, timed on the
@@ -123,7 +123,6 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
-    import torch
     import hash10x_amd
 
     rank = int(os.environ.get("RANK", "0"))
@@ -133,12 +132,15 @@ def main():
         raise SystemExit("WORLD_SIZE %d != --gpus %d" % (world, args.gpus))
     if args.gpus > 1 and world == 1:
         raise SystemExit("--gpus %d needs torch.distributed.run with one rank per GPU" % args.gpus)
-    dist = None
+    dist = torch = None
     if world > 1:
+        # control plane only (barrier + max of the elapsed time): the path has no data-path collective yet, so the
+        # process group runs on gloo and torch never initialises a second HIP runtime next to libh10x_hip's
+        # (two runtimes in one process cost ~3 ms of extra launch/sync latency per step, measured at N = 1).
+        import torch
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
-    torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="gloo", rank=rank, world_size=world)
 
     wl = WORKLOADS[args.workload]
     recs = generate(wl, seed=1 + rank)                      # rank r: its own sample (seed 1 + r)
@@ -149,17 +151,25 @@ def main():
     h = hash10x_amd.Hash10x(B=wl["B"], device=local_rank)
     h.enable_timing(True)
 
+    wall = {"readFQB": 0.0, "hashDepthRange": 0.0, "cluster": 0.0}
+
     def step():
+        t0 = time.perf_counter()
         h.read_fqb_device(d_recs.ptr, pairs)
+        t1 = time.perf_counter()
         h.depth_range(wl["lo"], wl["hi"])
+        t2 = time.perf_counter()
         h.cluster(1, 0, wl["ct"])
+        t3 = time.perf_counter()
+        wall["readFQB"] += t1 - t0
+        wall["hashDepthRange"] += t2 - t1
+        wall["cluster"] += t3 - t2
 
     def barrier():
-        hash10x_amd.synchronize(local_rank)      # the library's HIP runtime (every command also syncs before returning)
-        torch.cuda.synchronize()
+        hash10x_amd.synchronize(local_rank)      # hipDeviceSynchronize (every command also syncs before returning)
         if dist is not None:
             dist.barrier()
-        torch.cuda.synchronize()
+        hash10x_amd.synchronize(local_rank)
 
     for _ in range(args.warmup):
         step()
@@ -172,6 +182,8 @@ def main():
             a[0] += ms
             a[1] += n
 
+    for k in wall:
+        wall[k] = 0.0
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -180,7 +192,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -217,6 +229,7 @@ def main():
         "read_pairs_per_s_hashed": pairs / (hash_ms * 1e-3) if hash_ms else None,
         "barcodes_per_s_clustered": wl["barcodes"] / (clu_ms * 1e-3) if clu_ms else None,
         "device_ms_per_step": stage_ms,
+        "host_wall_ms_per_step": {k: round(1e3 * v / steps, 3) for k, v in wall.items()},
         "entries_H": H, "distinct_U": U, "hashNumber": sizes["hashNumber"], "fallback_blocks": ctr["fallback_blocks"],
         "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": None,

@@ -10,6 +10,7 @@
 #include <string>
 #include <vector>
 #include <map>
+#include <mutex>
 #include "../../include/h10x.h"
 
 namespace h10x {
@@ -24,46 +25,57 @@ static_assert(sizeof(h10x_block) == 32, "ClusterBlock layout (hash10x.c:62-70)")
 static_assert(sizeof(h10x_clushash) == 8, "ClusterHash layout (hash10x.c:35-43)");
 
 // ---- device buffer with explicit ownership ------------------------------------------------------
-// Allocations are stream-ordered (hipMallocAsync on the calling context's stream, pool kept warm), so the
-// dozens of temporaries of a command cost no driver round trips or implicit device syncs after warm-up.
+// A command allocates dozens of temporaries; hipMalloc/hipFree cost driver round trips and implicit device
+// syncs. Blocks are therefore recycled through a per-device cache: release() parks the block, alloc() takes
+// the smallest parked block that fits (within 2x). This is safe without events because every context issues
+// all of its work on ONE stream: a block is only ever handed to work enqueued after the work that used it.
+// (hipMallocAsync/hipFreeAsync were tried first and dropped: on ROCm 7.2 recycled blocks were handed out while
+// still in use — nondeterministic results on the second --readFQB of a process.)
+// Debug knobs: H10X_NOPOOL=1 (plain hipMalloc/hipFree), H10X_POISON=1 (fill every block handed out with 0xA5).
+struct DevCache {
+  std::multimap<size_t, void *> parked; size_t parkedBytes = 0; std::mutex mu;
+  static DevCache &of(int device) { static DevCache c[64]; return c[device & 63]; }
+  static bool disabled() { static int v = -1; if (v < 0) v = getenv("H10X_NOPOOL") != nullptr; return v != 0; }
+  static int poison() { static int p = -1; if (p < 0) { const char *e = getenv("H10X_POISON"); p = e ? atoi(e) : 0; } return p; }
+  void *take(size_t bytes, size_t &got) {
+    std::lock_guard<std::mutex> g(mu);
+    auto it = parked.lower_bound(bytes);
+    if (it == parked.end() || it->first > 2 * bytes + (1u << 20)) return nullptr;
+    void *p = it->second; got = it->first; parkedBytes -= got; parked.erase(it);
+    return p;
+  }
+  void park(void *p, size_t bytes) { std::lock_guard<std::mutex> g(mu); parked.emplace(bytes, p); parkedBytes += bytes; }
+  void trim() { std::lock_guard<std::mutex> g(mu); for (auto &kv : parked) (void)hipFree(kv.second); parked.clear(); parkedBytes = 0; }
+};
 struct AllocScope {                                       // set by every C-ABI entry point for its thread
   static hipStream_t &stream() { static thread_local hipStream_t s = nullptr; return s; }
-  static bool &async() { static thread_local bool a = false; return a; }
-  static int poison() { static int p = -1; if (p < 0) { const char *e = getenv("H10X_POISON"); p = e ? atoi(e) : 0; } return p; }   // debug: fill fresh buffers
-};
-// debug (H10X_ALLOC_CHECK=1): registry of live allocations, reports overlapping ranges handed out by the allocator
-struct AllocRegistry {
-  static std::map<uintptr_t, size_t> &live() { static std::map<uintptr_t, size_t> m; return m; }
-  static bool on() { static int v = -1; if (v < 0) { const char *e = getenv("H10X_ALLOC_CHECK"); v = e ? atoi(e) : 0; } return v != 0; }
-  static void add(void *p, size_t bytes) {
-    if (!on()) return;
-    const uintptr_t a = (uintptr_t)p;
-    for (auto &kv : live()) if (a < kv.first + kv.second && kv.first < a + bytes)
-      fprintf(stderr, "H10X_ALLOC_CHECK: new [%p,+%zu) overlaps live [%p,+%zu)\n", p, bytes, (void *)kv.first, kv.second);
-    live()[a] = bytes;
-  }
-  static void del(void *p) { if (on()) live().erase((uintptr_t)p); }
+  static int &device() { static thread_local int d = 0; return d; }
 };
 template <typename T> struct DevBuf {
-  T *p = nullptr; size_t n = 0; bool viaPool = false; hipStream_t st = nullptr;
+  T *p = nullptr; size_t n = 0; size_t cap = 0; int dev = 0;
   DevBuf() = default;
   DevBuf(const DevBuf &) = delete; DevBuf &operator=(const DevBuf &) = delete;
   ~DevBuf() { release(); }
   void release() {
-    if (p) { AllocRegistry::del(p); if (viaPool) (void)hipFreeAsync(p, st); else (void)hipFree(p); }
-    p = nullptr; n = 0;
+    if (p) { if (DevCache::disabled()) (void)hipFree(p); else DevCache::of(dev).park(p, cap); }
+    p = nullptr; n = 0; cap = 0;
   }
   hipError_t alloc(size_t count) {                       // contents undefined
     release();
     if (!count) count = 1;
-    hipError_t e;
-    if (AllocScope::async()) { st = AllocScope::stream(); viaPool = true; e = hipMallocAsync((void **)&p, count * sizeof(T), st); }
-    else { viaPool = false; e = hipMalloc((void **)&p, count * sizeof(T)); }
-    if (e == hipSuccess) { n = count; AllocRegistry::add(p, count * sizeof(T)); } else p = nullptr;
-    if (e == hipSuccess && AllocScope::poison()) (void)hipMemsetAsync(p, 0xA5, count * sizeof(T), AllocScope::stream());
+    size_t bytes = (count * sizeof(T) + 255) & ~(size_t)255;
+    dev = AllocScope::device();
+    hipError_t e = hipSuccess;
+    void *q = DevCache::disabled() ? nullptr : DevCache::of(dev).take(bytes, cap);
+    if (!q) {
+      cap = bytes; e = hipMalloc(&q, bytes);
+      if (e != hipSuccess && !DevCache::disabled()) { DevCache::of(dev).trim(); e = hipMalloc(&q, bytes); }   // give parked blocks back and retry
+    }
+    if (e == hipSuccess) { p = (T *)q; n = count; } else { p = nullptr; cap = 0; }
+    if (e == hipSuccess && DevCache::poison()) (void)hipMemsetAsync(p, 0xA5, bytes, AllocScope::stream());
     return e;
   }
-  void swap(DevBuf &o) { std::swap(p, o.p); std::swap(n, o.n); std::swap(viaPool, o.viaPool); std::swap(st, o.st); }
+  void swap(DevBuf &o) { std::swap(p, o.p); std::swap(n, o.n); std::swap(cap, o.cap); std::swap(dev, o.dev); }
   size_t bytes() const { return n * sizeof(T); }
 };
 
@@ -83,7 +95,6 @@ struct Ctx {
   hipStream_t stream = nullptr;
   int numCU = 256;
   bool ownStream = false;     // stream created (and destroyed) by the context
-  bool poolOK = false;        // stream-ordered allocator usable on this device
   std::string err;
 
   // persistent state == the reference's globals (hash10x.c:85-96), device resident

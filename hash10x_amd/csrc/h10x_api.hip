@@ -6,11 +6,10 @@
 
 using namespace h10x;
 
-// every entry point: select the device and make DevBuf allocations stream-ordered on the context's stream
+// every entry point: select the device and route DevBuf allocations to this device's block cache
 static int enter(Ctx &c) {
   if (hipSetDevice(c.device) != hipSuccess) return c.fail("hipSetDevice(%d) failed", c.device);
-  static const bool noPool = getenv("H10X_NOPOOL") != nullptr;      // debug: plain hipMalloc/hipFree
-  AllocScope::stream() = c.stream; AllocScope::async() = c.poolOK && !noPool;
+  AllocScope::stream() = c.stream; AllocScope::device() = c.device;
   return 0;
 }
 
@@ -64,18 +63,10 @@ int h10x_create(h10x_ctx **out, const h10x_params *p, int device, void *stream, 
   if (!h) return create_fail(err, errlen, "out of host memory");
   h->c.prm = *p; h->c.device = device; h->c.stream = (hipStream_t)stream; h->c.numCU = prop.multiProcessorCount;
   if (!stream) {
-    // Never run on the legacy NULL stream: the stream-ordered allocator (hipMallocAsync/hipFreeAsync) reused blocks
-    // that kernels launched on the NULL stream were still using (ROCm 7.2; caught by the HBM-scratch parity test).
+    // never the legacy NULL stream (no implicit syncs with other streams); the block cache of common.hpp relies
+    // on all work of a context being issued on this one stream
     if (hipStreamCreateWithFlags(&h->c.stream, hipStreamNonBlocking) != hipSuccess) { delete h; return create_fail(err, errlen, "hipStreamCreate failed"); }
     h->c.ownStream = true;
-  }
-  {                                                          // keep freed blocks in the device's default pool instead of returning them to the OS
-    int supported = 0; hipMemPool_t pool = nullptr;
-    if (hipDeviceGetAttribute(&supported, hipDeviceAttributeMemoryPoolsSupported, device) == hipSuccess && supported &&
-        hipDeviceGetDefaultMemPool(&pool, device) == hipSuccess) {
-      uint64_t keep = ~0ULL;
-      h->c.poolOK = hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &keep) == hipSuccess;
-    }
   }
   *out = h;
   return 0;

@@ -142,3 +142,26 @@ def test_die_conditions_match_reference_text(workdir):
     big = np.fromfile(workdir.file("x.fqb"), dtype=np.uint32)
     with pytest.raises(hash10x_amd.Hash10xError, match="hashTableSize is too small"):
         hash10x_amd.Hash10x(B=20).read_fqb(big)       # > 2^18 - 2 distinct hashes (hash10x.c:149)
+
+
+def test_context_reuse_is_deterministic(workdir):
+    """The C session keeps one device context (stream + recycled device blocks) across --readFQB calls with
+    unchanged parameters; every pass must give the same bytes as the first and as the oracle. (A stream-ordered
+    hipMallocAsync pool failed exactly this on ROCm 7.2 at this size.)"""
+    import hash10x_amd
+    recs = orc.gen_fqb(workdir.file("x.fqb"), 300000, 1500, 2000000, 0.004, 9, 8.0, 150, 30000)
+    o = orc.Oracle(B=22)
+    o.read_fqb(recs)
+    o.depth_range(6, 60)
+    o.cluster(1, 0, 3)
+    o.write_hash(workdir.file("orc.hash"))
+    exp = open(workdir.file("orc.hash"), "rb").read()
+    h = hash10x_amd.Hash10x(B=22)
+    for it in range(4):
+        h.read_fqb(recs)
+        h.depth_range(6, 60)
+        h.cluster(1, 0, 3)
+        h.write_hash(workdir.file("hip.hash"))
+        got = open(workdir.file("hip.hash"), "rb").read()
+        assert got == exp, "pass %d: %s" % (it, orc.describe_diff(got, exp))
+    assert orc.HashFile(exp).blocks["nSubCluster"].sum() > 0
