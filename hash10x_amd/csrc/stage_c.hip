@@ -618,6 +618,102 @@ int stageC_cluster(Ctx *c, int codeMin, int codeMax, int threshold) {
   return 0;
 }
 
-int stageC_split(Ctx *c) { return c->fail("clusterSplit is not implemented on the device path yet"); }
+// ------------------------------------------------------------------------------------------ clusterSplit
+// clusterSplitCodes (hash10x.c:956-1013): every sub-cluster becomes a barcode block of its own, appended after the
+// original blocks (cluster j of the s-th clustered parent lands at nCodes - 1 + (sub-clusters before it) + j),
+// reads renumbered in order of first appearance, labels cleared; the parent keeps its unclustered hashes.
+// Not a hot path: one wavefront per parent block, lane 0 replays the reference's single pass over the block.
+__global__ void split_count_kernel(const h10x_block *__restrict__ oldB, const u64 *__restrict__ oldOff, const h10x_clushash *__restrict__ ch,
+                                   u32 nCodes, const u32 *__restrict__ subBefore /* exclusive scan of nSubCluster */,
+                                   h10x_block *__restrict__ newB, u32 *__restrict__ newNHash) {
+  const u32 i = blockIdx.x; if (i >= nCodes) return;
+  const h10x_block ob = oldB[i];
+  __shared__ u32 cnt[256];
+  for (u32 t = threadIdx.x; t < 256; t += blockDim.x) cnt[t] = 0;
+  __syncthreads();
+  if (!ob.nSubCluster) {
+    if (threadIdx.x == 0) { h10x_block b = ob; b.clusHash = 0; newB[i] = b; newNHash[i] = (i >= 1) ? ob.nHash : 0; }
+    return;
+  }
+  const h10x_clushash *e = ch + oldOff[i];
+  for (u32 p = threadIdx.x; p < ob.nHash; p += blockDim.x) atomicAdd(&cnt[e[p].subCluster], 1u);
+  __syncthreads();
+  const u32 ext = nCodes - 1 + subBefore[i];
+  for (u32 j = threadIdx.x; j <= ob.nSubCluster && j < 256; j += blockDim.x) {
+    h10x_block b; memset(&b, 0, sizeof b);
+    if (j == 0) { b.nRead = ob.nRead; b.nHash = cnt[0]; newB[i] = b; newNHash[i] = cnt[0]; }      // hash10x.c:990: nRead kept, rest calloc'd
+    else { b.nHash = cnt[j]; b.clusterParent = i + 1; newB[ext + j] = b; newNHash[ext + j] = cnt[j]; }   // nRead filled by the move pass
+  }
+}
+
+__global__ void split_move_kernel(const h10x_block *__restrict__ oldB, const u64 *__restrict__ oldOff, const h10x_clushash *__restrict__ ch,
+                                  u32 nCodes, const u32 *__restrict__ subBefore, const u64 *__restrict__ readOff /* scan of nRead+1 */,
+                                  u32 *__restrict__ readMap /* zeroed */, h10x_block *__restrict__ newB, const u64 *__restrict__ newOff,
+                                  h10x_clushash *__restrict__ out) {
+  const u32 i = blockIdx.x; if (i >= nCodes) return;
+  const h10x_block ob = oldB[i];
+  const h10x_clushash *e = ch + oldOff[i];
+  if (!ob.nSubCluster) {                                     // *new1++ = *old (hash10x.c:996)
+    if (i >= 1) for (u32 p = threadIdx.x; p < ob.nHash; p += blockDim.x) out[newOff[i] + p] = e[p];
+    return;
+  }
+  if (threadIdx.x != 0) return;
+  __shared__ u32 cursor[256], nReadNew[256];
+  for (u32 j = 0; j <= ob.nSubCluster && j < 256; ++j) { cursor[j] = 0; nReadNew[j] = 0; }
+  const u32 ext = nCodes - 1 + subBefore[i];
+  u32 *rm = readMap + readOff[i];
+  for (u32 p = 0; p < ob.nHash; ++p) {                       // hash10x.c:980-989
+    h10x_clushash c = e[p]; const u32 cl = c.subCluster; c.subCluster = 0;
+    if (cl && cl <= ob.nSubCluster) {
+      if (!rm[c.read]) rm[c.read] = ++nReadNew[cl];
+      c.read = (u16)(rm[c.read] - 1);
+      out[newOff[ext + cl] + cursor[cl]++] = c;
+    } else out[newOff[i] + cursor[0]++] = c;
+  }
+  for (u32 j = 1; j <= ob.nSubCluster && j < 256; ++j) newB[ext + j].nRead = nReadNew[j];
+}
+
+__global__ void split_aux_kernel(const h10x_block *__restrict__ b, u32 n, u32 *__restrict__ nSub, u32 *__restrict__ nReadP1) {
+  const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) { nSub[i] = b[i].nSubCluster; nReadP1[i] = b[i].nSubCluster ? (b[i].nRead > 65535u ? 65536u : b[i].nRead) + 1 : 0; }
+}
+
+int stageC_split(Ctx *c) {
+  hipStream_t st = c->stream; PrimTemp pt;
+  if (!c->haveState) return c->fail("no hash state loaded: use readFQB or readHash first");
+  c->tstart(T_SPLIT);
+  const u32 nCodes = c->nBlocks;
+  DevBuf<u32> nSub, subBefore, nReadP1; DevBuf<u64> readOff;
+  H10X_HIP(c, nSub.alloc((size_t)nCodes + 1)); H10X_HIP(c, subBefore.alloc((size_t)nCodes + 1));
+  H10X_HIP(c, nReadP1.alloc((size_t)nCodes + 1)); H10X_HIP(c, readOff.alloc((size_t)nCodes + 1));
+  H10X_HIP(c, hipMemsetAsync(nSub.p + nCodes, 0, 4, st)); H10X_HIP(c, hipMemsetAsync(nReadP1.p + nCodes, 0, 4, st));
+  split_aux_kernel<<<divUp(nCodes, 256), 256, 0, st>>>(c->blocks.p, nCodes, nSub.p, nReadP1.p);
+  H10X_TRY(prim_exclusive_scan_u32(c, pt, nSub.p, subBefore.p, (size_t)nCodes + 1));
+  H10X_TRY(prim_exclusive_scan_u32_u64(c, pt, nReadP1.p, readOff.p, (size_t)nCodes + 1));
+  u32 totalSub = 0; u64 totalRead = 0;
+  H10X_HIP(c, hipMemcpyAsync(&totalSub, subBefore.p + nCodes, 4, hipMemcpyDeviceToHost, st));
+  H10X_HIP(c, hipMemcpyAsync(&totalRead, readOff.p + nCodes, 8, hipMemcpyDeviceToHost, st));
+  H10X_HIP(c, hipStreamSynchronize(st));
+  const u64 nNew64 = (u64)nCodes + totalSub;
+  if (nNew64 >= (1ULL << 31)) return c->fail("clusterSplit would create %llu barcode blocks", (u64)nNew64);
+  const u32 nNew = (u32)nNew64;
+  DevBuf<h10x_block> newB; DevBuf<u32> newNHash, readMap; DevBuf<u64> newOff; DevBuf<h10x_clushash> out;
+  H10X_HIP(c, newB.alloc(nNew)); H10X_HIP(c, newNHash.alloc((size_t)nNew + 1)); H10X_HIP(c, newOff.alloc((size_t)nNew + 1));
+  H10X_HIP(c, readMap.alloc(totalRead + 1)); H10X_HIP(c, out.alloc(c->nEntries));
+  H10X_HIP(c, hipMemsetAsync(newB.p, 0, (size_t)nNew * sizeof(h10x_block), st));
+  H10X_HIP(c, hipMemsetAsync(newNHash.p, 0, ((size_t)nNew + 1) * 4, st));
+  H10X_HIP(c, hipMemsetAsync(readMap.p, 0, (totalRead + 1) * 4, st));
+  split_count_kernel<<<nCodes, 256, 0, st>>>(c->blocks.p, c->blockOff.p, c->clusHash.p, nCodes, subBefore.p, newB.p, newNHash.p);
+  H10X_TRY(prim_exclusive_scan_u32_u64(c, pt, newNHash.p, newOff.p, (size_t)nNew + 1));
+  split_move_kernel<<<nCodes, 64, 0, st>>>(c->blocks.p, c->blockOff.p, c->clusHash.p, nCodes, subBefore.p, readOff.p, readMap.p, newB.p, newOff.p, out.p);
+  H10X_HIP(c, hipGetLastError());
+  H10X_HIP(c, hipStreamSynchronize(st));
+  c->blocks.swap(newB); c->blockOff.swap(newOff); c->clusHash.swap(out);
+  c->nBlocks = nNew;
+  c->haveGood = false; c->goodPos.release(); c->nGood.release();      // lists refer to the old blocks: a new --hashDepthRange is required
+  H10X_TRY(stageB_buildCSR(c));                              // hash10x.c:1008-1012: hashCodes rebuilt, hashDepth unchanged
+  c->tstop(T_SPLIT);
+  return 0;
+}
 
 }  // namespace h10x

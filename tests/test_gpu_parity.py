@@ -39,8 +39,6 @@ def test_native_library_is_the_path():
 
 @pytest.mark.parametrize("case", MAN["cases"], ids=[c["name"] for c in MAN["cases"]])
 def test_hip_matches_reference_golden(case, workdir):
-    if "--clusterSplit" in case["args"]:
-        pytest.skip("clusterSplit: next-row, not on the device path yet")
     workdir.need(case["input"])
     args = list(case["args"])
     run_commands(_factory(), args, workdir.path)
@@ -110,6 +108,10 @@ def test_random_sets_end_to_end(workdir, seed, pairs, barcodes, genome, mol, mol
     orc.gen_fqb(workdir.file("x.fqb"), pairs, barcodes, genome, 0.003, seed, mol, 150, mol_len)
     hf = _against_oracle(workdir, "x.fqb", ["-ct", ct, "--readFQB", "x.fqb", "--hashDepthRange", lo, hi, "--cluster", 1, 0])
     assert hf.blocks["nSubCluster"].sum() > 0
+    # --clusterSplit, then cluster the split barcodes again (hashCodes rebuilt for the new block numbering)
+    hf2 = _against_oracle(workdir, "x.fqb", ["-ct", ct, "--readFQB", "x.fqb", "--hashDepthRange", lo, hi, "--cluster", 1, 0, "--clusterSplit",
+                                             "--hashDepthRange", lo, hi, "--cluster", 1, 0])
+    assert hf2.blocks_max > hf.blocks_max
 
 
 def test_big_barcode_uses_medium_lds_class_and_wide_lists(workdir):
