@@ -284,6 +284,9 @@ __device__ void row_mode_long(const u32 *__restrict__ row, u32 d, u32 code, u32 
 // by successive phases: drop this CU's vector-L1 copies after every barrier (buffer_inv sc1) so that no phase
 // reads a line cached before another wave rewrote it.
 #define SYNC() do { __syncthreads(); if (!IN_LDS) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); } while (0)
+// LDS-only rendezvous for the list loop: waits for this wave's LDS traffic but leaves its prefetched global loads in
+// flight (a full __syncthreads() drains vmcnt too). The HBM-scratch instantiation keeps the full barrier + L1 drop.
+#define SYNC_LDS() do { if (IN_LDS) { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); } else SYNC(); } while (0)
 
 template <bool IN_LDS, int CL_THREADS>
 __device__ void cluster_one_block(const ClusterArgs &a, u32 code, unsigned char *region, u32 *sh /* small shared ints */) {
@@ -314,13 +317,23 @@ __device__ void cluster_one_block(const ClusterArgs &a, u32 code, unsigned char 
   //   (b) msBest / msMax / msTot of the same ranks (hash10x.c:801-806) from the list entries still in registers.
   // first[cj] for a barcode of list i is final once every list <= i has been merged (later lists can only
   // offer larger ranks), so one barrier per round is enough.
+  // The lists of round r+1 are requested before round r is processed, so their HBM latency hides behind the
+  // CAS-min / barrier / mode work of round r.
+  u32 cjN[ROWS_IN_FLIGHT], dlN[ROWS_IN_FLIGHT];
+#pragma unroll
+  for (int t = 0; t < ROWS_IN_FLIGHT; ++t) {
+    const u32 i = 1 + wave * ROWS_IN_FLIGHT + t; dlN[t] = i < n ? w.dd[i] : 0;
+    cjN[t] = (u32)lane < dlN[t] ? a.rows[w.rs[i] + lane] : code;
+  }
   for (u32 r0 = 1; r0 < n; r0 += CL_WAVES * ROWS_IN_FLIGHT) {
     const u32 i0 = r0 + wave * ROWS_IN_FLIGHT;
     u32 cj[ROWS_IN_FLIGHT], dl[ROWS_IN_FLIGHT];
 #pragma unroll
+    for (int t = 0; t < ROWS_IN_FLIGHT; ++t) { cj[t] = cjN[t]; dl[t] = dlN[t]; }
+#pragma unroll
     for (int t = 0; t < ROWS_IN_FLIGHT; ++t) {
-      const u32 i = i0 + t; dl[t] = i < n ? w.dd[i] : 0;
-      cj[t] = (u32)lane < dl[t] ? a.rows[w.rs[i] + lane] : code;
+      const u32 i = i0 + CL_WAVES * ROWS_IN_FLIGHT + t; dlN[t] = i < n ? w.dd[i] : 0;
+      cjN[t] = (u32)lane < dlN[t] ? a.rows[w.rs[i] + lane] : code;
     }
 #pragma unroll
     for (int t = 0; t < ROWS_IN_FLIGHT; ++t) {
@@ -328,7 +341,7 @@ __device__ void cluster_one_block(const ClusterArgs &a, u32 code, unsigned char 
       if (cj[t] != code) min_u16<IN_LDS>(w.first, cj[t], i);
       if (dl[t] > WAVE) { const u32 *row = a.rows + w.rs[i]; for (u32 j = WAVE + lane; j < dl[t]; j += WAVE) { const u32 c2 = row[j]; if (c2 != code) min_u16<IN_LDS>(w.first, c2, i); } }
     }
-    SYNC();
+    SYNC_LDS();
 #pragma unroll
     for (int t = 0; t < ROWS_IN_FLIGHT; ++t) {
       const u32 i = i0 + t;
@@ -522,6 +535,7 @@ __device__ void cluster_one_block(const ClusterArgs &a, u32 code, unsigned char 
 }
 
 #undef SYNC
+#undef SYNC_LDS
 
 template <bool IN_LDS, int CL_THREADS>
 __global__ __launch_bounds__(CL_THREADS)

@@ -1,0 +1,11 @@
+import sys, os
+R = os.environ.get("GRAFT_REPO_ROOT", "/root/repo")
+sys.path.insert(0, R)
+import bench, hash10x_amd
+wl = bench.WORKLOADS["yeast-like-2.5M"]
+recs = bench.generate(wl, 1)
+d = hash10x_amd.DeviceRecords(recs)
+h = hash10x_amd.Hash10x(B=wl["B"])
+for it in range(2):
+    h.read_fqb_device(d.ptr, d.n_records); h.depth_range(wl["lo"], wl["hi"]); h.cluster(1, 0, wl["ct"])
+print("done", h.sizes())
