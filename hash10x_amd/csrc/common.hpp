@@ -93,6 +93,8 @@ struct Ctx {
   h10x_params prm{};
   int device = 0;
   hipStream_t stream = nullptr;
+  hipStream_t aux[3] = {nullptr, nullptr, nullptr};   // side streams for independent launches (fork/join around them)
+  hipEvent_t evFork = nullptr, evJoin[3] = {nullptr, nullptr, nullptr};
   int numCU = 256;
   bool ownStream = false;     // stream created (and destroyed) by the context
   std::string err;
@@ -128,6 +130,25 @@ struct Ctx {
   int fail(const char *fmt, ...) {
     char buf[1024]; va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof buf, fmt, ap); va_end(ap);
     err = buf; return -1;
+  }
+  int forkStreams(int n) {                               // side streams wait for everything issued on the main stream so far
+    if (!evFork) {
+      if (hipEventCreateWithFlags(&evFork, hipEventDisableTiming) != hipSuccess) return fail("hipEventCreate failed");
+      for (int i = 0; i < 3; ++i) {
+        if (hipStreamCreateWithFlags(&aux[i], hipStreamNonBlocking) != hipSuccess) return fail("hipStreamCreate failed");
+        if (hipEventCreateWithFlags(&evJoin[i], hipEventDisableTiming) != hipSuccess) return fail("hipEventCreate failed");
+      }
+    }
+    if (hipEventRecord(evFork, stream) != hipSuccess) return fail("hipEventRecord failed");
+    for (int i = 0; i < n; ++i) if (hipStreamWaitEvent(aux[i], evFork, 0) != hipSuccess) return fail("hipStreamWaitEvent failed");
+    return 0;
+  }
+  int joinStreams(int n) {                               // the main stream waits for the side streams
+    for (int i = 0; i < n; ++i) {
+      if (hipEventRecord(evJoin[i], aux[i]) != hipSuccess) return fail("hipEventRecord failed");
+      if (hipStreamWaitEvent(stream, evJoin[i], 0) != hipSuccess) return fail("hipStreamWaitEvent failed");
+    }
+    return 0;
   }
   void tstart(TimerId t) {
     if (!timing) return;

@@ -77,6 +77,8 @@ void h10x_destroy(h10x_ctx *h) {
   (void)enter(h->c);
   (void)hipStreamSynchronize(h->c.stream);
   for (auto &t : h->c.timers) { if (t.a) (void)hipEventDestroy(t.a); if (t.b) (void)hipEventDestroy(t.b); }
+  for (int i = 0; i < 3; ++i) { if (h->c.aux[i]) { (void)hipStreamSynchronize(h->c.aux[i]); (void)hipStreamDestroy(h->c.aux[i]); } if (h->c.evJoin[i]) (void)hipEventDestroy(h->c.evJoin[i]); }
+  if (h->c.evFork) (void)hipEventDestroy(h->c.evFork);
   hipStream_t own = h->c.ownStream ? h->c.stream : nullptr;
   delete h;
   if (own) { (void)hipStreamSynchronize(own); (void)hipStreamDestroy(own); }

@@ -27,6 +27,7 @@ namespace h10x {
 
 constexpr int CL_THREADS_SMALL = 1024;                     // 64 KB working sets, two workgroups per CU
 constexpr int CL_THREADS_BIG = 1024;                       // up to the whole LDS of a CU, one workgroup per CU
+constexpr int CL_THREADS_HUGE = 512;                       // same LDS with half the waves: per-wave histograms cost 8 instead of 16 B per rank
 constexpr u16 NONE16 = 0xFFFF;
 constexpr int ROWS_IN_FLIGHT = 4;                          // barcode lists a wavefront keeps in flight
 constexpr int RCHUNK = 4;                                   // register chunks: lists up to 256 entries
@@ -553,11 +554,13 @@ void cluster_kernel(ClusterArgs a) {
   }
 }
 
-// three launch classes by working-set size: 0 = small LDS (two workgroups per CU), 1 = big LDS (one 1024-lane
-// workgroup per CU), 2 = HBM scratch
+// launch classes by working-set size: 0 = small LDS (two 1024-lane workgroups per CU), 1 = the whole LDS of a CU
+// (one 1024-lane workgroup), 2 = the whole LDS with 512 lanes (fewer per-wave histograms => more ranks fit),
+// 3 = HBM scratch
 __global__ void cluster_classify_kernel(const h10x_block *__restrict__ blocks, const u32 *__restrict__ nGood, u32 codeMin, u32 codeMax,
                                         u32 nBlocks, size_t budgetSmall, size_t budgetBig,
-                                        u32 *__restrict__ list0, u32 *__restrict__ list1, u32 *__restrict__ list2, u32 *__restrict__ counts) {
+                                        u32 *__restrict__ list0, u32 *__restrict__ list1, u32 *__restrict__ list2, u32 *__restrict__ list3,
+                                        u32 *__restrict__ counts) {
   const u32 c = codeMin + blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= codeMax) return;
   const u32 n = nGood[c];
@@ -565,7 +568,8 @@ __global__ void cluster_classify_kernel(const h10x_block *__restrict__ blocks, c
   const size_t mb = mergeBytes(blocks[c].nRead);
   if (max(workBytes(nBlocks, n, CL_THREADS_SMALL / WAVE), mb) <= budgetSmall) list0[atomicAdd(&counts[0], 1u)] = c;
   else if (max(workBytes(nBlocks, n, CL_THREADS_BIG / WAVE), mb) <= budgetBig) list1[atomicAdd(&counts[1], 1u)] = c;
-  else list2[atomicAdd(&counts[2], 1u)] = c;
+  else if (max(workBytes(nBlocks, n, CL_THREADS_HUGE / WAVE), mb) <= budgetBig) list2[atomicAdd(&counts[2], 1u)] = c;
+  else list3[atomicAdd(&counts[3], 1u)] = c;
 }
 
 int stageC_cluster(Ctx *c, int codeMin, int codeMax, int threshold) {
@@ -578,14 +582,14 @@ int stageC_cluster(Ctx *c, int codeMin, int codeMax, int threshold) {
   if (codeMax <= codeMin) return 0;
   c->tstart(T_CLUSTER);
   const u32 span = (u32)(codeMax - codeMin);
-  DevBuf<u32> list0, list1, list2, counts; DevBuf<u64> stats;
-  H10X_HIP(c, list0.alloc(span)); H10X_HIP(c, list1.alloc(span)); H10X_HIP(c, list2.alloc(span));
+  DevBuf<u32> list0, list1, list2, list3, counts; DevBuf<u64> stats;
+  H10X_HIP(c, list0.alloc(span)); H10X_HIP(c, list1.alloc(span)); H10X_HIP(c, list2.alloc(span)); H10X_HIP(c, list3.alloc(span));
   H10X_HIP(c, counts.alloc(8)); H10X_HIP(c, stats.alloc(4));
   H10X_HIP(c, hipMemsetAsync(counts.p, 0, 32, st)); H10X_HIP(c, hipMemsetAsync(stats.p, 0, 32, st));
   const size_t budgetSmall = c->optClusterLds > 0 ? (size_t)c->optClusterLds : 80 * 1024 - 1024;
   const size_t budgetBig = c->optClusterLds > 0 ? (size_t)c->optClusterLds : 160 * 1024 - 1024;
   cluster_classify_kernel<<<divUp(span, 256), 256, 0, st>>>(c->blocks.p, c->nGood.p, (u32)codeMin, (u32)codeMax, c->nBlocks, budgetSmall, budgetBig,
-                                                          list0.p, list1.p, list2.p, counts.p);
+                                                          list0.p, list1.p, list2.p, list3.p, counts.p);
   u32 hc[4];
   H10X_HIP(c, hipMemcpyAsync(hc, counts.p, 16, hipMemcpyDeviceToHost, st));
   H10X_HIP(c, hipStreamSynchronize(st));
@@ -595,32 +599,43 @@ int stageC_cluster(Ctx *c, int codeMin, int codeMax, int threshold) {
   a.maxGood = c->maxGood; a.stats = stats.p;
   DevBuf<u64> phase;
   if (c->optStamps) { H10X_HIP(c, phase.alloc(8)); H10X_HIP(c, hipMemsetAsync(phase.p, 0, 64, st)); a.phase = phase.p; }
+  // HBM working set per workgroup (class 3): first[] + per-rank arrays + read-merge tables for the largest barcode
+  DevBuf<unsigned char> scratch;
+  size_t stride = 0; u32 grid3 = 0;
+  if (hc[3]) {
+    const size_t mergeOff = (workBytes(c->nBlocks, c->maxGood, CL_THREADS_SMALL / WAVE) + 255) & ~(size_t)255;
+    stride = mergeOff + ((mergeBytes(65536) + 255) & ~(size_t)255);
+    a.mergeOffset = mergeOff;
+    grid3 = hmin<u32>(hc[3], (u32)c->numCU);
+    H10X_HIP(c, scratch.alloc(stride * grid3));
+    H10X_HIP(c, hipMemsetAsync(scratch.p, 0xFF, stride * grid3, st));    // first[] = unseen everywhere
+  }
+  // The four classes are independent: fork them onto side streams so that the few largest barcodes (long, low
+  // parallelism) run beside the many small ones instead of in front of them. Every buffer they touch was
+  // allocated before the fork and is released after the join, which is what the block cache requires.
   c->tstart(T_CLUSTER_K);
-  if (hc[1]) {                                               // biggest working sets first
-    a.list = list1.p; a.nList = hc[1]; a.workCounter = counts.p + 5; a.scratch = nullptr; a.scratchStride = 0;
+  H10X_TRY(c->forkStreams(3));
+  if (hc[3]) {
+    ClusterArgs g = a; g.list = list3.p; g.nList = hc[3]; g.workCounter = counts.p + 7; g.scratch = scratch.p; g.scratchStride = stride;
+    cluster_kernel<false, CL_THREADS_SMALL><<<grid3, CL_THREADS_SMALL, 0, c->aux[0]>>>(g);
+  }
+  if (hc[2]) {
+    ClusterArgs g = a; g.list = list2.p; g.nList = hc[2]; g.workCounter = counts.p + 6;
+    H10X_HIP(c, hipFuncSetAttribute((const void *)cluster_kernel<true, CL_THREADS_HUGE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)budgetBig));
+    cluster_kernel<true, CL_THREADS_HUGE><<<hmin<u32>(hc[2], (u32)c->numCU), CL_THREADS_HUGE, budgetBig, c->aux[1]>>>(g);
+  }
+  if (hc[1]) {
+    ClusterArgs g = a; g.list = list1.p; g.nList = hc[1]; g.workCounter = counts.p + 5;
     H10X_HIP(c, hipFuncSetAttribute((const void *)cluster_kernel<true, CL_THREADS_BIG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)budgetBig));
-    cluster_kernel<true, CL_THREADS_BIG><<<hmin<u32>(hc[1], (u32)c->numCU), CL_THREADS_BIG, budgetBig, st>>>(a);
-    H10X_HIP(c, hipGetLastError());
+    cluster_kernel<true, CL_THREADS_BIG><<<hmin<u32>(hc[1], (u32)c->numCU), CL_THREADS_BIG, budgetBig, c->aux[2]>>>(g);
   }
   if (hc[0]) {
-    a.list = list0.p; a.nList = hc[0]; a.workCounter = counts.p + 4; a.scratch = nullptr; a.scratchStride = 0;
+    ClusterArgs g = a; g.list = list0.p; g.nList = hc[0]; g.workCounter = counts.p + 4;
     H10X_HIP(c, hipFuncSetAttribute((const void *)cluster_kernel<true, CL_THREADS_SMALL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)budgetSmall));
-    cluster_kernel<true, CL_THREADS_SMALL><<<hmin<u32>(hc[0], (u32)c->numCU * 2), CL_THREADS_SMALL, budgetSmall, st>>>(a);
-    H10X_HIP(c, hipGetLastError());
+    cluster_kernel<true, CL_THREADS_SMALL><<<hmin<u32>(hc[0], (u32)c->numCU * 2), CL_THREADS_SMALL, budgetSmall, st>>>(g);
   }
-  DevBuf<unsigned char> scratch;
-  if (hc[2]) {
-    // HBM working set per workgroup: first[] + per-rank arrays + read-merge tables for the largest barcode
-    const size_t mergeOff = (workBytes(c->nBlocks, c->maxGood, CL_THREADS_SMALL / WAVE) + 255) & ~(size_t)255;
-    const size_t stride = mergeOff + ((mergeBytes(65536) + 255) & ~(size_t)255);
-    a.mergeOffset = mergeOff;
-    const u32 grid = hmin<u32>(hc[2], (u32)c->numCU);
-    H10X_HIP(c, scratch.alloc(stride * grid));
-    H10X_HIP(c, hipMemsetAsync(scratch.p, 0xFF, stride * grid, st));    // first[] = unseen everywhere
-    a.list = list2.p; a.nList = hc[2]; a.workCounter = counts.p + 6; a.scratch = scratch.p; a.scratchStride = stride;
-    cluster_kernel<false, CL_THREADS_SMALL><<<grid, CL_THREADS_SMALL, 0, st>>>(a);
-    H10X_HIP(c, hipGetLastError());
-  }
+  H10X_HIP(c, hipGetLastError());
+  H10X_TRY(c->joinStreams(3));
   c->tstop(T_CLUSTER_K);
   u64 hs[4];
   H10X_HIP(c, hipMemcpyAsync(hs, stats.p, 32, hipMemcpyDeviceToHost, st));
@@ -628,7 +643,7 @@ int stageC_cluster(Ctx *c, int codeMin, int codeMax, int threshold) {
   c->tstop(T_CLUSTER);
   if (c->optStamps) { H10X_HIP(c, hipMemcpy(c->ctr.cluster_phase_ticks, phase.p, 64, hipMemcpyDeviceToHost)); }
   c->ctr.sum_good = hs[0]; c->ctr.sum_good_depth = hs[1]; c->ctr.sum_hash_clustered = hs[2]; c->ctr.clustered_codes = span;
-  c->ctr.cluster_class_counts[0] = hc[0]; c->ctr.cluster_class_counts[1] = hc[1]; c->ctr.cluster_class_counts[2] = hc[2];
+  c->ctr.cluster_class_counts[0] = hc[0]; c->ctr.cluster_class_counts[1] = hc[1]; c->ctr.cluster_class_counts[2] = hc[2]; c->ctr.cluster_class_counts[3] = hc[3];
   return 0;
 }
 
