@@ -71,6 +71,15 @@ def load_native():
     host.h10x_host_check_chunks.restype = ctypes.c_int64
     host.h10x_host_check_chunks.argtypes = [vp, cu64, ci, ci, cs, ci]
     host.h10x_host_partition.argtypes = [vp, cu64, ci, vp]
+    host.h10x_session_shardReadFQB_mem.argtypes = [vp, vp, vp, cu64]
+    host.h10x_session_shardReadFQB_dev.argtypes = [vp, vp, vp, cu64]
+    host.h10x_session_shardGather.argtypes = [vp]
+    hip.h10x_comm_unique_id.argtypes = [vp]
+    hip.h10x_comm_create_rccl.argtypes = [ctypes.POINTER(vp), ci, ci, vp, ci, cs, ci]
+    hip.h10x_comm_create_local.argtypes = [ctypes.POINTER(vp), ci]
+    hip.h10x_comm_destroy.argtypes = [vp]
+    hip.h10x_shard_barrier.argtypes = [vp]
+    hip.h10x_shard_allreduce_max.argtypes = [vp, ctypes.POINTER(ctypes.c_double)]
     hip.h10x_device_malloc.restype = vp
     hip.h10x_device_malloc.argtypes = [ci, cu64]
     hip.h10x_device_free.argtypes = [ci, vp]
@@ -127,6 +136,48 @@ class DeviceRecords:
 
 def synchronize(device=0):
     load_native()[0].h10x_device_synchronize(device)
+
+
+class Comm:
+    """Communicator of the sharded path: RCCL (one process per GPU) or in-process (N ranks = N threads)."""
+
+    def __init__(self, handle, rank, size):
+        self.handle, self.rank, self.size = handle, rank, size
+
+    @staticmethod
+    def unique_id():
+        buf = ctypes.create_string_buffer(128)
+        if load_native()[0].h10x_comm_unique_id(buf):
+            raise Hash10xError("ncclGetUniqueId failed")
+        return buf.raw
+
+    @staticmethod
+    def rccl(rank, size, unique_id, device):
+        h = ctypes.c_void_p()
+        err = ctypes.create_string_buffer(512)
+        if load_native()[0].h10x_comm_create_rccl(ctypes.byref(h), rank, size, unique_id, device, err, 512):
+            raise Hash10xError(err.value.decode())
+        return Comm(h, rank, size)
+
+    @staticmethod
+    def local(size):
+        arr = (ctypes.c_void_p * size)()
+        load_native()[0].h10x_comm_create_local(arr, size)
+        return [Comm(ctypes.c_void_p(arr[i]), i, size) for i in range(size)]
+
+    def destroy(self):
+        if self.handle:
+            load_native()[0].h10x_comm_destroy(self.handle)
+            self.handle = None
+
+
+def partition(records, parts):
+    """Record index cuts of contiguous barcode-range shards (h10x_host_partition)."""
+    r = np.ascontiguousarray(records, dtype=np.uint32).reshape(-1)
+    cut = (ctypes.c_uint64 * (parts + 1))()
+    if load_native()[1].h10x_host_partition(r.ctypes.data, r.size // 30, parts, cut):
+        raise Hash10xError("partition failed")
+    return [int(x) for x in cut]
 
 
 class Hash10x:
@@ -188,6 +239,28 @@ class Hash10x:
         self._pre(N, 100000)
         self._chk(self._host.h10x_session_readFQB_dev(self._s, ctypes.c_void_p(dev_ptr), int(n_records)))
         self._after_init()
+
+    def shard_read_fqb(self, comm, shard_records):
+        """Sharded --readFQB: this rank's barcode range (host image); collective over comm."""
+        r = np.ascontiguousarray(shard_records, dtype=np.uint32).reshape(-1)
+        self._chk(self._host.h10x_session_shardReadFQB_mem(self._s, comm.handle, r.ctypes.data, r.size // 30))
+        self._after_init()
+
+    def shard_read_fqb_device(self, comm, dev_ptr, n_records):
+        self._chk(self._host.h10x_session_shardReadFQB_dev(self._s, comm.handle, ctypes.c_void_p(dev_ptr), int(n_records)))
+        self._after_init()
+
+    def shard_gather(self):
+        """Collective: rank 0 ends up with the whole state (then write_hash there)."""
+        self._chk(self._host.h10x_session_shardGather(self._s))
+
+    def shard_barrier(self):
+        self._hip.h10x_shard_barrier(self._ctx())
+
+    def shard_allreduce_max(self, value):
+        v = ctypes.c_double(value)
+        self._hip.h10x_shard_allreduce_max(self._ctx(), ctypes.byref(v))
+        return v.value
 
     def read_hash(self, path):
         self._chk(self._host.h10x_session_readHash(self._s, os.fsencode(path)))

@@ -28,54 +28,78 @@ static_assert(sizeof(h10x_clushash) == 8, "ClusterHash layout (hash10x.c:35-43)"
 // A command allocates dozens of temporaries; hipMalloc/hipFree cost driver round trips and implicit device
 // syncs. Blocks are therefore recycled through a per-device cache: release() parks the block, alloc() takes
 // the smallest parked block that fits (within 2x). This is safe without events because every context issues
-// all of its work on ONE stream: a block is only ever handed to work enqueued after the work that used it.
+// all of its work on ONE stream and blocks are cached per stream: a block is only ever handed to work enqueued
+// after the work that used it.
 // (hipMallocAsync/hipFreeAsync were tried first and dropped: on ROCm 7.2 recycled blocks were handed out while
 // still in use — nondeterministic results on the second --readFQB of a process.)
 // Debug knobs: H10X_NOPOOL=1 (plain hipMalloc/hipFree), H10X_POISON=1 (fill every block handed out with 0xA5).
 struct DevCache {
-  std::multimap<size_t, void *> parked; size_t parkedBytes = 0; std::mutex mu;
-  static DevCache &of(int device) { static DevCache c[64]; return c[device & 63]; }
+  std::multimap<size_t, void *> parked; size_t parkedBytes = 0;
+  static std::mutex &mu() { static std::mutex m; return m; }
+  // one cache per (device, stream): a parked block may only go back to work issued on the stream that last used it;
+  // (device, nullptr) holds blocks whose stream has been synchronised (context destroyed): anyone may take those
+  static DevCache &of(int device, hipStream_t st) { static std::map<std::pair<int, hipStream_t>, DevCache> m; return m[{device, st}]; }
   static bool disabled() { static int v = -1; if (v < 0) v = getenv("H10X_NOPOOL") != nullptr; return v != 0; }
   static int poison() { static int p = -1; if (p < 0) { const char *e = getenv("H10X_POISON"); p = e ? atoi(e) : 0; } return p; }
-  void *take(size_t bytes, size_t &got) {
-    std::lock_guard<std::mutex> g(mu);
+  void *takeLocked(size_t bytes, size_t &got) {
     auto it = parked.lower_bound(bytes);
     if (it == parked.end() || it->first > 2 * bytes + (1u << 20)) return nullptr;
     void *p = it->second; got = it->first; parkedBytes -= got; parked.erase(it);
     return p;
   }
-  void park(void *p, size_t bytes) { std::lock_guard<std::mutex> g(mu); parked.emplace(bytes, p); parkedBytes += bytes; }
-  void trim() { std::lock_guard<std::mutex> g(mu); for (auto &kv : parked) (void)hipFree(kv.second); parked.clear(); parkedBytes = 0; }
+  static void *take(int device, hipStream_t st, size_t bytes, size_t &got) {
+    std::lock_guard<std::mutex> g(mu());
+    void *p = of(device, st).takeLocked(bytes, got);
+    if (!p && st) p = of(device, nullptr).takeLocked(bytes, got);
+    return p;
+  }
+  static void park(int device, hipStream_t st, void *p, size_t bytes) {
+    std::lock_guard<std::mutex> g(mu()); DevCache &c = of(device, st); c.parked.emplace(bytes, p); c.parkedBytes += bytes;
+  }
+  static void retireStream(int device, hipStream_t st) {     // call after the stream has been synchronised
+    std::lock_guard<std::mutex> g(mu());
+    DevCache &c = of(device, st), &idle = of(device, nullptr);
+    for (auto &kv : c.parked) { idle.parked.emplace(kv.first, kv.second); idle.parkedBytes += kv.first; }
+    c.parked.clear(); c.parkedBytes = 0;
+  }
+  static void trim(int device) {                             // give every parked block of the device back to the driver
+    std::lock_guard<std::mutex> g(mu());
+    (void)hipDeviceSynchronize();
+    static std::map<std::pair<int, hipStream_t>, DevCache> *dummy = nullptr; (void)dummy;
+    for (hipStream_t st : streamsOf(device)) { DevCache &c = of(device, st); for (auto &kv : c.parked) (void)hipFree(kv.second); c.parked.clear(); c.parkedBytes = 0; }
+  }
+  static std::vector<hipStream_t> &streamsOf(int device) { static std::map<int, std::vector<hipStream_t>> m; auto &v = m[device]; if (v.empty()) v.push_back(nullptr); return v; }
+  static void noteStream(int device, hipStream_t st) { std::lock_guard<std::mutex> g(mu()); auto &v = streamsOf(device); for (auto x : v) if (x == st) return; v.push_back(st); }
 };
 struct AllocScope {                                       // set by every C-ABI entry point for its thread
   static hipStream_t &stream() { static thread_local hipStream_t s = nullptr; return s; }
   static int &device() { static thread_local int d = 0; return d; }
 };
 template <typename T> struct DevBuf {
-  T *p = nullptr; size_t n = 0; size_t cap = 0; int dev = 0;
+  T *p = nullptr; size_t n = 0; size_t cap = 0; int dev = 0; hipStream_t st = nullptr;
   DevBuf() = default;
   DevBuf(const DevBuf &) = delete; DevBuf &operator=(const DevBuf &) = delete;
   ~DevBuf() { release(); }
   void release() {
-    if (p) { if (DevCache::disabled()) (void)hipFree(p); else DevCache::of(dev).park(p, cap); }
+    if (p) { if (DevCache::disabled()) (void)hipFree(p); else DevCache::park(dev, st, p, cap); }
     p = nullptr; n = 0; cap = 0;
   }
   hipError_t alloc(size_t count) {                       // contents undefined
     release();
     if (!count) count = 1;
     size_t bytes = (count * sizeof(T) + 255) & ~(size_t)255;
-    dev = AllocScope::device();
+    dev = AllocScope::device(); st = AllocScope::stream();
     hipError_t e = hipSuccess;
-    void *q = DevCache::disabled() ? nullptr : DevCache::of(dev).take(bytes, cap);
+    void *q = DevCache::disabled() ? nullptr : DevCache::take(dev, st, bytes, cap);
     if (!q) {
       cap = bytes; e = hipMalloc(&q, bytes);
-      if (e != hipSuccess && !DevCache::disabled()) { DevCache::of(dev).trim(); e = hipMalloc(&q, bytes); }   // give parked blocks back and retry
+      if (e != hipSuccess && !DevCache::disabled()) { DevCache::trim(dev); e = hipMalloc(&q, bytes); }   // give parked blocks back and retry
     }
     if (e == hipSuccess) { p = (T *)q; n = count; } else { p = nullptr; cap = 0; }
     if (e == hipSuccess && DevCache::poison()) (void)hipMemsetAsync(p, 0xA5, bytes, AllocScope::stream());
     return e;
   }
-  void swap(DevBuf &o) { std::swap(p, o.p); std::swap(n, o.n); std::swap(cap, o.cap); std::swap(dev, o.dev); }
+  void swap(DevBuf &o) { std::swap(p, o.p); std::swap(n, o.n); std::swap(cap, o.cap); std::swap(dev, o.dev); std::swap(st, o.st); }
   size_t bytes() const { return n * sizeof(T); }
 };
 
@@ -118,6 +142,12 @@ struct Ctx {
   DevBuf<u32> nGood;          // nBlocks
   bool haveRange = false, haveGood = false; int rangeMin = 0, rangeMax = 0;
   u32 maxGoodDepth = 0, maxGood = 0;
+
+  // sharded (multi-GPU) operation: this context owns barcodes codeBase+1 .. codeBase+nBlocks-1 of nBlocksGlobal-1 and,
+  // as hash owner, the barcode lists of the hashes in its hash range (shard.hip)
+  struct Comm *comm = nullptr; bool sharded = false;
+  u32 codeBase = 0, nBlocksGlobal = 0;
+  DevBuf<u32> oRows, oSegStart, oIndex; u32 oU = 0; u64 oM = 0;
 
   // options / measurement
   int64_t optMaxSlots = 0;    // testing knob: cap stage-A LDS table
@@ -180,11 +210,14 @@ template <typename T> static inline T hmax(T a, T b) { return a > b ? a : b; }
 
 // stage entry points (one per translation unit)
 int stageA_run(Ctx *c, const u32 *dRecords, u64 nRecords,
-               DevBuf<u64> &entHash, DevBuf<u32> &entCode, DevBuf<u32> &entRead);
+               DevBuf<u64> &entHash, DevBuf<u32> &entCode, DevBuf<u32> &entRead, bool hashLast = false);
 int stageB_run(Ctx *c, DevBuf<u64> &entHash, DevBuf<u32> &entCode, DevBuf<u32> &entRead);
 int stageB_buildCSR(Ctx *c);                   // rows/rowStart from clusHash + hashDepth (fillHashTable)
+int stageB_finishClusHash(Ctx *c, DevBuf<u64> &key);   // key[e] = index << 32 | read16 in block order -> clusHash sorted per block
+int stageB_buildProbeTable(Ctx *c);            // hashIndex[] from hashValue[1..hashNumber)
 int stageC_depthRange(Ctx *c, int min, int max);
 int stageC_cluster(Ctx *c, int codeMin, int codeMax, int threshold);
 int stageC_split(Ctx *c);
+int shard_exchangeRows(Ctx *c);                 // sharded --hashDepthRange: allgather the in-range barcode lists
 
 }  // namespace h10x

@@ -10,6 +10,7 @@ using namespace h10x;
 static int enter(Ctx &c) {
   if (hipSetDevice(c.device) != hipSuccess) return c.fail("hipSetDevice(%d) failed", c.device);
   AllocScope::stream() = c.stream; AllocScope::device() = c.device;
+  DevCache::noteStream(c.device, c.stream);
   return 0;
 }
 
@@ -79,9 +80,11 @@ void h10x_destroy(h10x_ctx *h) {
   for (auto &t : h->c.timers) { if (t.a) (void)hipEventDestroy(t.a); if (t.b) (void)hipEventDestroy(t.b); }
   for (int i = 0; i < 3; ++i) { if (h->c.aux[i]) { (void)hipStreamSynchronize(h->c.aux[i]); (void)hipStreamDestroy(h->c.aux[i]); } if (h->c.evJoin[i]) (void)hipEventDestroy(h->c.evJoin[i]); }
   if (h->c.evFork) (void)hipEventDestroy(h->c.evFork);
-  hipStream_t own = h->c.ownStream ? h->c.stream : nullptr;
-  delete h;
-  if (own) { (void)hipStreamSynchronize(own); (void)hipStreamDestroy(own); }
+  hipStream_t own = h->c.ownStream ? h->c.stream : nullptr; const hipStream_t used = h->c.stream; const int dev = h->c.device;
+  delete h;                                                  // parks every buffer of the context
+  (void)hipStreamSynchronize(used);
+  DevCache::retireStream(dev, used);                         // synchronised: its blocks may now serve any stream
+  if (own) (void)hipStreamDestroy(own);
 }
 
 const char *h10x_last_error(const h10x_ctx *h) { return h ? h->c.err.c_str() : "null context"; }
@@ -90,6 +93,7 @@ static void reset_state(Ctx &c) {
   c.haveState = false; c.haveRange = false; c.haveGood = false; c.rangeMin = c.rangeMax = 0;
   c.within.release(); c.goodPos.release(); c.nGood.release();
   c.hashNumber = 1; c.nBlocks = 0; c.nEntries = 0; c.nRecords = 0;
+  c.sharded = false; c.codeBase = 0; c.nBlocksGlobal = 0; c.oRows.release(); c.oSegStart.release(); c.oIndex.release(); c.oU = 0; c.oM = 0;
   memset(&c.ctr, 0, sizeof c.ctr);
 }
 
@@ -197,6 +201,7 @@ int h10x_export(h10x_ctx *h, uint32_t *hashIndex, uint64_t *hashValue, uint32_t 
   Ctx &c = h->c;
   H10X_TRY(enter(c));
   if (!c.haveState) return c.fail("no hash state loaded: use readFQB or readHash first");
+  if (c.sharded) return c.fail("this context holds one shard: call h10x_shard_gather and export on rank 0");
   hipStream_t st = c.stream;
   if (hashIndex) H10X_HIP(&c, hipMemcpyAsync(hashIndex, c.hashIndex.p, ((size_t)1 << c.prm.B) * 4, hipMemcpyDeviceToHost, st));
   if (hashValue) H10X_HIP(&c, hipMemcpyAsync(hashValue, c.hashValue.p, (size_t)c.hashNumber * 8, hipMemcpyDeviceToHost, st));
@@ -218,6 +223,41 @@ int h10x_device_upload(int device, void *dst, const void *src, uint64_t bytes) {
   return (hipSetDevice(device) == hipSuccess && hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice) == hipSuccess) ? 0 : -1;
 }
 int h10x_device_synchronize(int device) { return (hipSetDevice(device) == hipSuccess && hipDeviceSynchronize() == hipSuccess) ? 0 : -1; }
+
+}  // extern "C"
+#include "comm.hpp"
+namespace h10x { Comm *comm_impl(h10x_comm *c); int shard_readFqb(Ctx *c, Comm *cm, const u32 *dRec, u64 nRec); int shard_gather(Ctx *c); }
+extern "C" {
+
+int h10x_shard_attach(h10x_ctx *h, h10x_comm *comm) {
+  if (!h || !comm) return -1;
+  h->c.comm = comm_impl(comm);
+  return 0;
+}
+int h10x_shard_read_fqb_device(h10x_ctx *h, const uint32_t *dRec, uint64_t n) {
+  if (!h) return -1;
+  Ctx &c = h->c;
+  H10X_TRY(enter(c));
+  if (!c.comm) return c.fail("h10x_shard_read_fqb: no communicator attached");
+  if (n && !dRec) return c.fail("h10x_shard_read_fqb_device: null records");
+  Comm *cm = c.comm;
+  reset_state(c);
+  c.comm = cm;
+  return shard_readFqb(&c, cm, dRec, n);
+}
+int h10x_shard_read_fqb(h10x_ctx *h, const uint32_t *hostRec, uint64_t n) {
+  if (!h) return -1;
+  Ctx &c = h->c;
+  H10X_TRY(enter(c));
+  DevBuf<u32> d;
+  H10X_HIP(&c, d.alloc(n * 30));
+  if (n) H10X_HIP(&c, hipMemcpyAsync(d.p, hostRec, n * 120, hipMemcpyHostToDevice, c.stream));
+  H10X_HIP(&c, hipStreamSynchronize(c.stream));
+  return h10x_shard_read_fqb_device(h, d.p, n);
+}
+int h10x_shard_gather(h10x_ctx *h) { if (!h) return -1; H10X_TRY(enter(h->c)); if (!h->c.comm) return h->c.fail("no communicator attached"); return shard_gather(&h->c); }
+int h10x_shard_barrier(h10x_ctx *h) { if (!h) return -1; H10X_TRY(enter(h->c)); if (!h->c.comm) return 0; return h->c.comm->barrier(&h->c); }
+int h10x_shard_allreduce_max(h10x_ctx *h, double *v) { if (!h || !v) return -1; H10X_TRY(enter(h->c)); if (!h->c.comm) return 0; return h->c.comm->allreduceMaxHost(&h->c, v); }
 
 int h10x_timing_enable(h10x_ctx *h, int on) { if (!h) return -1; h->c.timing = on != 0; return 0; }
 int h10x_timing_count(const h10x_ctx *) { return T_COUNT; }

@@ -1,0 +1,316 @@
+// shard.hip — the multi-GPU form of --readFQB / --hashDepthRange / --writeHash.
+//
+// Barcodes are sharded by contiguous ranges of the sorted .fqb (rank r owns barcodes codeBase_r+1 ..); hashes are
+// owned by value range (owner(h) = floor(h * N / 4^k)), so the distinct hashes of owner o all precede those of o+1.
+//   1. every rank: mosh extraction of its records (stage A, unchanged)                                  — no traffic
+//   2. all-to-all: each (hash, global barcode) entry goes to the hash's owner                           — 12 B per entry
+//   3. owner: stable sort by hash => distinct hashes, first barcode, depth, barcode lists (ascending)
+//   4. allgather of the per-barcode counts of "first seen here" hashes; with hash ownership monotone this is all
+//      an owner needs to number its hashes exactly as the serial hashNumber++ would (rank of (first barcode, hash))
+//   5. all-to-all back: the index of every entry, in the order the entries were sent                     — 4 B per entry
+//   6. allgather of (index, hash, depth) so that every rank holds hashValue[] / hashDepth[] (and rank 0 can write
+//      hashIndex[]); barcode lists travel later, and only for hashes inside the depth range (--hashDepthRange),
+//      by an allgather of the filtered lists — clustering then needs no communication at all.
+// The result is byte-identical to the single-GPU path (tests: N ranks as threads on one GPU; bench: RCCL).
+#include "common.hpp"
+#include "prim.hpp"
+#include "comm.hpp"
+
+namespace h10x {
+
+__global__ void iota_kernel(u32 *__restrict__ p, u64 n) {
+  u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; const u64 stride = (u64)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) p[i] = (u32)i;
+}
+__global__ void gather_code_kernel(const u32 *__restrict__ entCode, const u32 *__restrict__ perm, u64 n, u32 codeBase, u32 *__restrict__ out) {
+  u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; const u64 stride = (u64)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) out[i] = entCode[perm[i]] + codeBase;
+}
+// first position in the ascending array whose hash belongs to owner >= o, for o = 0..N
+__global__ void owner_bounds_kernel(const u64 *__restrict__ sHash, u64 n, const u64 *__restrict__ lowHash /* N+1 */, int N, u64 *__restrict__ bound) {
+  const int o = blockIdx.x * blockDim.x + threadIdx.x;
+  if (o > N) return;
+  if (o == N) { bound[o] = n; return; }
+  u64 lo = 0, hi = n; const u64 key = lowHash[o];
+  while (lo < hi) { const u64 mid = (lo + hi) >> 1; if (sHash[mid] < key) lo = mid + 1; else hi = mid; }
+  bound[o] = lo;
+}
+__global__ void gather_u32_kernel(const u32 *__restrict__ src, const u32 *__restrict__ idx, u64 n, u32 *__restrict__ out) {
+  u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; const u64 stride = (u64)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) out[i] = src[idx[i]];
+}
+__global__ void heads_kernel(const u64 *__restrict__ sHash, u64 n, u32 *__restrict__ flags) {
+  u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; const u64 stride = (u64)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) flags[i] = (i == 0 || sHash[i] != sHash[i - 1]) ? 1u : 0u;
+}
+__global__ void owner_distinct_kernel(const u64 *__restrict__ sHash, const u32 *__restrict__ rows, const u32 *__restrict__ flags, const u32 *__restrict__ ord,
+                                      u64 n, u64 *__restrict__ dHash, u32 *__restrict__ dFirst, u32 *__restrict__ segStart, u32 *__restrict__ iota,
+                                      u32 *__restrict__ cntFirst) {
+  u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; const u64 stride = (u64)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) if (flags[i]) {
+    const u32 d = ord[i];
+    dHash[d] = sHash[i]; dFirst[d] = rows[i]; segStart[d] = (u32)i; iota[d] = d;
+    atomicAdd(&cntFirst[rows[i]], 1u);                      // stable sort => rows[i] is the lowest barcode of the hash
+  }
+}
+// per barcode c: how many new hashes it introduces in total and on owners before me
+__global__ void first_totals_kernel(const u32 *__restrict__ all /* N x nB */, int N, int me, u32 nB, u32 *__restrict__ total, u32 *__restrict__ before) {
+  const u32 c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= nB) return;
+  u32 t = 0, b = 0;
+  for (int o = 0; o < N; ++o) { const u32 v = all[(size_t)o * nB + c]; if (o < me) b += v; t += v; }
+  total[c] = t; before[c] = b;
+}
+// i-th of my distinct hashes in (first barcode, hash) order
+__global__ void owner_index_kernel(const u32 *__restrict__ order, const u32 *__restrict__ dFirstSorted, u32 U, const u32 *__restrict__ base /* excl. scan of total */,
+                                   const u32 *__restrict__ before, const u32 *__restrict__ myStart /* excl. scan of my cntFirst */, u32 *__restrict__ dIndex) {
+  const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= U) return;
+  const u32 f = dFirstSorted[i];
+  dIndex[order[i]] = 1 + base[f] + before[f] + (i - myStart[f]);
+}
+__global__ void reply_kernel(const u32 *__restrict__ ord /* distinct ordinal per sorted position (exclusive scan of heads) */, const u32 *__restrict__ flags,
+                             const u32 *__restrict__ q, u64 n, const u32 *__restrict__ dIndex, u32 *__restrict__ reply) {
+  u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; const u64 stride = (u64)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) reply[q[i]] = dIndex[ord[i] + flags[i] - 1];
+}
+__global__ void scatter_key_kernel(const u32 *__restrict__ rIdx, const u32 *__restrict__ perm, const u32 *__restrict__ entRead, u64 n, u64 *__restrict__ key) {
+  u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; const u64 stride = (u64)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) { const u32 e = perm[i]; key[e] = ((u64)rIdx[i] << 32) | (u64)(entRead[e] & 0xFFFFu); }
+}
+__global__ void depth_of_kernel(const u32 *__restrict__ segStart, u32 U, u32 *__restrict__ depth) {
+  const u32 d = blockIdx.x * blockDim.x + threadIdx.x;
+  if (d < U) depth[d] = segStart[d + 1] - segStart[d];
+}
+__global__ void scatter_tables_kernel(const u32 *__restrict__ idx, const u64 *__restrict__ hash, const u32 *__restrict__ depth, u64 n,
+                                      u64 *__restrict__ hashValue, u32 *__restrict__ hashDepth) {
+  u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; const u64 stride = (u64)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) { hashValue[idx[i]] = hash[i]; hashDepth[idx[i]] = depth[i]; }
+}
+
+static int bitsForS(u64 v) { int b = 1; while (b < 64 && (v >> b)) ++b; return b; }
+static unsigned gridFor(u64 n) { return (unsigned)hmin<u64>(divUp(n ? n : 1, 256), 65535u * 2); }
+
+struct ShardInfo { u64 barcodes, entries, records; };
+
+int shard_readFqb(Ctx *c, Comm *cm, const u32 *dRec, u64 nRec) {
+  hipStream_t st = c->stream; PrimTemp pt;
+  const int N = cm->n, me = cm->rank; const int k = c->prm.k;
+  // ---- 1. local mosh extraction; only the last shard's last barcode is the file's unhashed trailing block
+  DevBuf<u64> entHash; DevBuf<u32> entCode, entRead;
+  H10X_TRY(stageA_run(c, dRec, nRec, entHash, entCode, entRead, me != N - 1));
+  const u64 H = c->nEntries;
+  ShardInfo mine{(u64)c->nBlocks - 1, H, nRec}; std::vector<ShardInfo> all((size_t)N);
+  H10X_TRY(cm->allgatherHost(c, &mine, all.data(), sizeof mine));
+  u64 codeBase = 0, totalBarcodes = 0;
+  for (int r = 0; r < N; ++r) { if (r < me) codeBase += all[r].barcodes; totalBarcodes += all[r].barcodes; }
+  if (totalBarcodes + 1 >= (1ULL << 32)) return c->fail("too many barcodes for this build");
+  c->codeBase = (u32)codeBase; c->nBlocksGlobal = (u32)totalBarcodes + 1;
+  const u32 nB = c->nBlocksGlobal;
+
+  // ---- 2. my entries by hash owner
+  c->tstart(T_SORT_HASH);
+  DevBuf<u64> sHash; DevBuf<u32> perm, sCodeG, io;
+  H10X_HIP(c, sHash.alloc(H)); H10X_HIP(c, perm.alloc(H)); H10X_HIP(c, sCodeG.alloc(H)); H10X_HIP(c, io.alloc(H));
+  if (H) iota_kernel<<<gridFor(H), 256, 0, st>>>(io.p, H);
+  H10X_TRY(prim_sort_pairs_u64_u32(c, pt, entHash.p, sHash.p, io.p, perm.p, H, 0, 2 * k));
+  if (H) gather_code_kernel<<<gridFor(H), 256, 0, st>>>(entCode.p, perm.p, H, c->codeBase, sCodeG.p);
+  std::vector<u64> lowHash((size_t)N + 1), bound((size_t)N + 1);
+  for (int o = 0; o <= N; ++o) lowHash[o] = (u64)((((unsigned __int128)o << (2 * k)) + (unsigned)N - 1) / (unsigned)N);   // ceil(o * 4^k / N)
+  DevBuf<u64> dLow, dBound; H10X_HIP(c, dLow.alloc((size_t)N + 1)); H10X_HIP(c, dBound.alloc((size_t)N + 1));
+  H10X_HIP(c, hipMemcpyAsync(dLow.p, lowHash.data(), ((size_t)N + 1) * 8, hipMemcpyHostToDevice, st));
+  owner_bounds_kernel<<<1, 64 * ((N + 64) / 64), 0, st>>>(sHash.p, H, dLow.p, N, dBound.p);
+  H10X_HIP(c, hipMemcpyAsync(bound.data(), dBound.p, ((size_t)N + 1) * 8, hipMemcpyDeviceToHost, st));
+  H10X_HIP(c, hipStreamSynchronize(st));
+  std::vector<u64> sendCnt((size_t)N), sendOff((size_t)N), matrix((size_t)N * N), recvCnt((size_t)N), recvOff((size_t)N);
+  for (int o = 0; o < N; ++o) { sendOff[o] = bound[o]; sendCnt[o] = bound[o + 1] - bound[o]; }
+  H10X_TRY(cm->allgatherHost(c, sendCnt.data(), matrix.data(), (size_t)N * 8));
+  u64 M = 0;
+  for (int r = 0; r < N; ++r) { recvCnt[r] = matrix[(size_t)r * N + me]; recvOff[r] = M; M += recvCnt[r]; }
+  if (M >= (1ULL << 32)) return c->fail("%llu entries land on hash owner %d: over this build's 2^32 limit", (u64)M, me);
+  DevBuf<u64> rHash; DevBuf<u32> rCode;
+  H10X_HIP(c, rHash.alloc(M)); H10X_HIP(c, rCode.alloc(M));
+  H10X_TRY(cm->alltoallv(c, sHash.p, sendCnt.data(), sendOff.data(), rHash.p, recvCnt.data(), recvOff.data(), 8));
+  H10X_TRY(cm->alltoallv(c, sCodeG.p, sendCnt.data(), sendOff.data(), rCode.p, recvCnt.data(), recvOff.data(), 4));
+  sHash.release(); sCodeG.release();
+
+  // ---- 3. owner side: received runs are in rank (= barcode) order, a stable sort by hash keeps barcodes ascending
+  DevBuf<u64> oHash; DevBuf<u32> oQ; H10X_HIP(c, oHash.alloc(M)); H10X_HIP(c, oQ.alloc(M));
+  { DevBuf<u32> qio; H10X_HIP(c, qio.alloc(M)); if (M) iota_kernel<<<gridFor(M), 256, 0, st>>>(qio.p, M);
+    H10X_TRY(prim_sort_pairs_u64_u32(c, pt, rHash.p, oHash.p, qio.p, oQ.p, M, 0, 2 * k)); H10X_HIP(c, hipStreamSynchronize(st)); }
+  H10X_HIP(c, c->oRows.alloc(M));
+  if (M) gather_u32_kernel<<<gridFor(M), 256, 0, st>>>(rCode.p, oQ.p, M, c->oRows.p);
+  c->tstop(T_SORT_HASH);
+  c->tstart(T_RANK);
+  DevBuf<u32> flags, ord; H10X_HIP(c, flags.alloc(M + 1)); H10X_HIP(c, ord.alloc(M + 1));
+  if (M) heads_kernel<<<gridFor(M), 256, 0, st>>>(oHash.p, M, flags.p);
+  H10X_HIP(c, hipMemsetAsync(flags.p + M, 0, 4, st));
+  H10X_TRY(prim_exclusive_scan_u32(c, pt, flags.p, ord.p, M + 1));
+  u32 Uo = 0;
+  H10X_HIP(c, hipMemcpyAsync(&Uo, ord.p + M, 4, hipMemcpyDeviceToHost, st));
+  H10X_HIP(c, hipStreamSynchronize(st));
+  DevBuf<u64> dHash; DevBuf<u32> dFirst, dio, cntFirst;
+  H10X_HIP(c, dHash.alloc(Uo)); H10X_HIP(c, dFirst.alloc(Uo)); H10X_HIP(c, c->oSegStart.alloc((size_t)Uo + 1)); H10X_HIP(c, dio.alloc(Uo));
+  H10X_HIP(c, cntFirst.alloc(nB)); H10X_HIP(c, hipMemsetAsync(cntFirst.p, 0, (size_t)nB * 4, st));
+  if (M) owner_distinct_kernel<<<gridFor(M), 256, 0, st>>>(oHash.p, c->oRows.p, flags.p, ord.p, M, dHash.p, dFirst.p, c->oSegStart.p, dio.p, cntFirst.p);
+  const u32 M32 = (u32)M;
+  H10X_HIP(c, hipMemcpyAsync(c->oSegStart.p + Uo, &M32, 4, hipMemcpyHostToDevice, st));
+  H10X_HIP(c, hipStreamSynchronize(st));
+
+  // ---- 4. numbering: index = 1 + #(hashes first seen in an earlier barcode) + #(same barcode, smaller hash);
+  //         hashes of owners before me are smaller, those after me larger
+  DevBuf<u32> allFirst, total, before, base, myStart;
+  H10X_HIP(c, allFirst.alloc((size_t)N * nB)); H10X_HIP(c, total.alloc((size_t)nB + 1)); H10X_HIP(c, before.alloc(nB));
+  H10X_HIP(c, base.alloc((size_t)nB + 1)); H10X_HIP(c, myStart.alloc(nB));
+  { std::vector<u64> sc((size_t)N, nB), so((size_t)N, 0), rc((size_t)N, nB), ro((size_t)N);
+    for (int r = 0; r < N; ++r) ro[r] = (u64)r * nB;
+    H10X_TRY(cm->alltoallv(c, cntFirst.p, sc.data(), so.data(), allFirst.p, rc.data(), ro.data(), 4)); }   // allgather
+  first_totals_kernel<<<divUp(nB, 256), 256, 0, st>>>(allFirst.p, N, me, nB, total.p, before.p);
+  H10X_HIP(c, hipMemsetAsync(total.p + nB, 0, 4, st));
+  H10X_TRY(prim_exclusive_scan_u32(c, pt, total.p, base.p, (size_t)nB + 1));
+  H10X_TRY(prim_exclusive_scan_u32(c, pt, cntFirst.p, myStart.p, nB));
+  u32 U = 0;
+  H10X_HIP(c, hipMemcpyAsync(&U, base.p + nB, 4, hipMemcpyDeviceToHost, st));
+  H10X_HIP(c, hipStreamSynchronize(st));
+  if ((u64)U + 1 > (((u64)1 << c->prm.B) >> 2) - 2) return c->fail("hashTableSize is too small");     // hash10x.c:149, same verdict on every rank
+  DevBuf<u32> order, dFirstSorted; H10X_HIP(c, order.alloc(Uo)); H10X_HIP(c, dFirstSorted.alloc(Uo)); H10X_HIP(c, c->oIndex.alloc(Uo));
+  H10X_TRY(prim_sort_pairs_u32_u32(c, pt, dFirst.p, dFirstSorted.p, dio.p, order.p, Uo, 0, bitsForS(nB)));
+  if (Uo) owner_index_kernel<<<divUp(Uo, 256), 256, 0, st>>>(order.p, dFirstSorted.p, Uo, base.p, before.p, myStart.p, c->oIndex.p);
+  c->oU = Uo; c->oM = M;
+
+  // ---- 5. the index of every entry goes back to the rank that sent it, in the order it was sent
+  DevBuf<u32> reply, rIdx; H10X_HIP(c, reply.alloc(M)); H10X_HIP(c, rIdx.alloc(H));
+  if (M) reply_kernel<<<gridFor(M), 256, 0, st>>>(ord.p, flags.p, oQ.p, M, c->oIndex.p, reply.p);
+  H10X_TRY(cm->alltoallv(c, reply.p, recvCnt.data(), recvOff.data(), rIdx.p, sendCnt.data(), sendOff.data(), 4));
+  c->hashNumber = U + 1;
+  c->tstop(T_RANK);
+  c->tstart(T_CLUSHASH);
+  { DevBuf<u64> key; H10X_HIP(c, key.alloc(H));
+    if (H) scatter_key_kernel<<<gridFor(H), 256, 0, st>>>(rIdx.p, perm.p, entRead.p, H, key.p);
+    H10X_TRY(stageB_finishClusHash(c, key)); }
+  c->tstop(T_CLUSHASH);
+
+  // ---- 6. everyone gets hashValue[] / hashDepth[] (the .hash tables and the depth filter need them in full)
+  c->tstart(T_PROBE);
+  std::vector<u64> uo((size_t)N); { u64 u = Uo; H10X_TRY(cm->allgatherHost(c, &u, uo.data(), 8)); }
+  std::vector<u64> sc((size_t)N, Uo), so((size_t)N, 0), rc((size_t)N), ro((size_t)N); u64 Utot = 0;
+  for (int r = 0; r < N; ++r) { rc[r] = uo[r]; ro[r] = Utot; Utot += uo[r]; }
+  if (Utot != U) return c->fail("sharded index: %llu distinct hashes gathered, %u numbered", (u64)Utot, U);
+  DevBuf<u32> dDepth, gIdx, gDepth; DevBuf<u64> gHash;
+  H10X_HIP(c, dDepth.alloc(Uo)); H10X_HIP(c, gIdx.alloc(U)); H10X_HIP(c, gDepth.alloc(U)); H10X_HIP(c, gHash.alloc(U));
+  if (Uo) depth_of_kernel<<<divUp(Uo, 256), 256, 0, st>>>(c->oSegStart.p, Uo, dDepth.p);
+  H10X_TRY(cm->alltoallv(c, c->oIndex.p, sc.data(), so.data(), gIdx.p, rc.data(), ro.data(), 4));
+  H10X_TRY(cm->alltoallv(c, dDepth.p, sc.data(), so.data(), gDepth.p, rc.data(), ro.data(), 4));
+  H10X_TRY(cm->alltoallv(c, dHash.p, sc.data(), so.data(), gHash.p, rc.data(), ro.data(), 8));
+  H10X_HIP(c, c->hashValue.alloc((size_t)U + 1)); H10X_HIP(c, c->hashDepth.alloc((size_t)U + 1));
+  H10X_HIP(c, hipMemsetAsync(c->hashValue.p, 0, 8, st)); H10X_HIP(c, hipMemsetAsync(c->hashDepth.p, 0, 4, st));
+  if (U) scatter_tables_kernel<<<gridFor(U), 256, 0, st>>>(gIdx.p, gHash.p, gDepth.p, U, c->hashValue.p, c->hashDepth.p);
+  c->tstop(T_PROBE);
+  H10X_TRY(stageB_buildProbeTable(c));
+  H10X_HIP(c, hipStreamSynchronize(st));
+  c->rows.release(); c->rowStart.release();                  // barcode lists arrive with --hashDepthRange
+  c->ctr.distinct = U;
+  c->comm = cm; c->sharded = true; c->haveState = true;
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------- lists of in-range hashes
+__global__ void good_len_kernel(const u32 *__restrict__ oIndex, const u32 *__restrict__ segStart, const u8 *__restrict__ within, u32 U,
+                                u32 *__restrict__ isGood, u32 *__restrict__ len) {
+  const u32 d = blockIdx.x * blockDim.x + threadIdx.x;
+  if (d > U) return;
+  const bool g = d < U && within[oIndex[d]] != 0;
+  isGood[d] = g ? 1u : 0u; len[d] = g ? segStart[d + 1] - segStart[d] : 0u;
+}
+__global__ void good_pack_kernel(const u32 *__restrict__ oIndex, const u32 *__restrict__ segStart, const u32 *__restrict__ oRows, const u32 *__restrict__ isGood,
+                                 const u32 *__restrict__ pos, const u32 *__restrict__ off, u32 U, u32 *__restrict__ gIdx, u32 *__restrict__ gLen, u32 *__restrict__ gRows) {
+  for (u32 d = blockIdx.x; d < U; d += gridDim.x) {
+    if (!isGood[d]) continue;
+    const u32 s = segStart[d], n = segStart[d + 1] - s, o = off[d];
+    if (threadIdx.x == 0) { gIdx[pos[d]] = oIndex[d]; gLen[pos[d]] = n; }
+    for (u32 j = threadIdx.x; j < n; j += blockDim.x) gRows[o + j] = oRows[s + j];
+  }
+}
+__global__ void row_start_kernel(const u32 *__restrict__ gIdx, const u64 *__restrict__ gOff, u64 n, u64 *__restrict__ rowStart) {
+  u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; const u64 stride = (u64)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) rowStart[gIdx[i]] = gOff[i];
+}
+
+// after hashWithinRangeBuild: every rank receives the barcode lists of all in-range hashes (allgather of the filtered lists)
+int shard_exchangeRows(Ctx *c) {
+  hipStream_t st = c->stream; PrimTemp pt; Comm *cm = c->comm;
+  const int N = cm->n; const u32 Uo = c->oU;
+  c->tstart(T_CSR);
+  DevBuf<u32> isGood, len, pos, off;
+  H10X_HIP(c, isGood.alloc((size_t)Uo + 1)); H10X_HIP(c, len.alloc((size_t)Uo + 1)); H10X_HIP(c, pos.alloc((size_t)Uo + 1)); H10X_HIP(c, off.alloc((size_t)Uo + 1));
+  good_len_kernel<<<divUp((u64)Uo + 1, 256), 256, 0, st>>>(c->oIndex.p, c->oSegStart.p, c->within.p, Uo, isGood.p, len.p);
+  H10X_TRY(prim_exclusive_scan_u32(c, pt, isGood.p, pos.p, (size_t)Uo + 1));
+  H10X_TRY(prim_exclusive_scan_u32(c, pt, len.p, off.p, (size_t)Uo + 1));
+  u32 tail[2];
+  H10X_HIP(c, hipMemcpyAsync(&tail[0], pos.p + Uo, 4, hipMemcpyDeviceToHost, st));
+  H10X_HIP(c, hipMemcpyAsync(&tail[1], off.p + Uo, 4, hipMemcpyDeviceToHost, st));
+  H10X_HIP(c, hipStreamSynchronize(st));
+  u64 mine[2] = {tail[0], tail[1]}; std::vector<u64> all((size_t)2 * N);
+  H10X_TRY(cm->allgatherHost(c, mine, all.data(), 16));
+  DevBuf<u32> gIdx, gLen, gRows;
+  H10X_HIP(c, gIdx.alloc(mine[0])); H10X_HIP(c, gLen.alloc(mine[0])); H10X_HIP(c, gRows.alloc(mine[1]));
+  if (Uo) good_pack_kernel<<<hmin<u32>(Uo, 16384), 64, 0, st>>>(c->oIndex.p, c->oSegStart.p, c->oRows.p, isGood.p, pos.p, off.p, Uo, gIdx.p, gLen.p, gRows.p);
+  std::vector<u64> sc((size_t)N), so((size_t)N, 0), rc((size_t)N), ro((size_t)N); u64 nG = 0, nR = 0;
+  for (int r = 0; r < N; ++r) { sc[r] = mine[0]; rc[r] = all[2 * r]; ro[r] = nG; nG += rc[r]; }
+  DevBuf<u32> aIdx, aLen; H10X_HIP(c, aIdx.alloc(nG)); H10X_HIP(c, aLen.alloc(nG + 1));
+  H10X_TRY(cm->alltoallv(c, gIdx.p, sc.data(), so.data(), aIdx.p, rc.data(), ro.data(), 4));
+  H10X_TRY(cm->alltoallv(c, gLen.p, sc.data(), so.data(), aLen.p, rc.data(), ro.data(), 4));
+  for (int r = 0; r < N; ++r) { sc[r] = mine[1]; rc[r] = all[2 * r + 1]; ro[r] = nR; nR += rc[r]; }
+  if (nR >= (1ULL << 32)) return c->fail("%llu barcode-list entries in the depth range exceed this build's 2^32 limit", (u64)nR);
+  H10X_HIP(c, c->rows.alloc(nR));
+  H10X_TRY(cm->alltoallv(c, gRows.p, sc.data(), so.data(), c->rows.p, rc.data(), ro.data(), 4));
+  DevBuf<u64> aOff; H10X_HIP(c, aOff.alloc(nG + 1));
+  H10X_HIP(c, hipMemsetAsync(aLen.p + nG, 0, 4, st));
+  H10X_TRY(prim_exclusive_scan_u32_u64(c, pt, aLen.p, aOff.p, nG + 1));
+  H10X_HIP(c, c->rowStart.alloc((size_t)c->hashNumber + 1));
+  H10X_HIP(c, hipMemsetAsync(c->rowStart.p, 0, ((size_t)c->hashNumber + 1) * 8, st));
+  if (nG) row_start_kernel<<<gridFor(nG), 256, 0, st>>>(aIdx.p, aOff.p, nG, c->rowStart.p);
+  H10X_HIP(c, hipStreamSynchronize(st));
+  c->tstop(T_CSR);
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------- gather for --writeHash
+__global__ void blocks_nhash_kernel(const h10x_block *__restrict__ blocks, u32 nBlocks, u32 *__restrict__ nHash) {
+  const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i <= nBlocks) nHash[i] = (i >= 1 && i < nBlocks) ? blocks[i].nHash : 0;
+}
+
+// collective; afterwards rank 0 holds blocks[] and clusHash[] of the whole data set (and behaves like an unsharded context)
+int shard_gather(Ctx *c) {
+  hipStream_t st = c->stream; PrimTemp pt; Comm *cm = c->comm;
+  if (!c->sharded) return 0;
+  const int N = cm->n, me = cm->rank;
+  ShardInfo mine{(u64)c->nBlocks - 1, c->nEntries, c->nRecords}; std::vector<ShardInfo> all((size_t)N);
+  H10X_TRY(cm->allgatherHost(c, &mine, all.data(), sizeof mine));
+  std::vector<u64> sc((size_t)N, 0), so((size_t)N, 1), rc((size_t)N, 0), ro((size_t)N, 0);
+  u64 totB = 0, totH = 0, totR = 0;
+  for (int r = 0; r < N; ++r) { if (me == 0) { rc[r] = all[r].barcodes; ro[r] = 1 + totB; } totB += all[r].barcodes; totH += all[r].entries; totR += all[r].records; }
+  sc[0] = mine.barcodes;                                       // everyone sends blocks[1..] to rank 0 only
+  DevBuf<h10x_block> gBlocks; DevBuf<h10x_clushash> gClus;
+  if (me == 0) { H10X_HIP(c, gBlocks.alloc(totB + 1)); H10X_HIP(c, hipMemsetAsync(gBlocks.p, 0, sizeof(h10x_block), st)); H10X_HIP(c, gClus.alloc(totH)); }
+  H10X_TRY(cm->alltoallv(c, c->blocks.p, sc.data(), so.data(), gBlocks.p, rc.data(), ro.data(), sizeof(h10x_block)));
+  u64 acc = 0;
+  for (int r = 0; r < N; ++r) { so[r] = 0; sc[r] = 0; if (me == 0) { rc[r] = all[r].entries; ro[r] = acc; } acc += all[r].entries; }
+  sc[0] = mine.entries;
+  H10X_TRY(cm->alltoallv(c, c->clusHash.p, sc.data(), so.data(), gClus.p, rc.data(), ro.data(), sizeof(h10x_clushash)));
+  if (me == 0) {
+    if (totH >= (1ULL << 32)) return c->fail("%llu entries exceed this build's 2^32 limit on the gathering rank", (u64)totH);
+    c->blocks.swap(gBlocks); c->clusHash.swap(gClus);
+    c->nBlocks = (u32)totB + 1; c->nEntries = totH; c->nRecords = totR;
+    DevBuf<u32> nh; H10X_HIP(c, nh.alloc((size_t)c->nBlocks + 1)); H10X_HIP(c, c->blockOff.alloc((size_t)c->nBlocks + 1));
+    blocks_nhash_kernel<<<divUp((u64)c->nBlocks + 1, 256), 256, 0, st>>>(c->blocks.p, c->nBlocks, nh.p);
+    H10X_TRY(prim_exclusive_scan_u32_u64(c, pt, nh.p, c->blockOff.p, (size_t)c->nBlocks + 1));
+    H10X_HIP(c, hipStreamSynchronize(st));
+    c->sharded = false; c->codeBase = 0; c->haveGood = false;  // a full, unsharded state from here on (good lists were per shard)
+  }
+  H10X_TRY(cm->barrier(c));
+  return 0;
+}
+
+}  // namespace h10x

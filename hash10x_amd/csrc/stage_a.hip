@@ -100,7 +100,7 @@ __global__ void block_starts_kernel(const u32 *__restrict__ flags, const u32 *__
 __global__ void classify_kernel(const u64 *__restrict__ startRec, u32 nBlocks, h10x_block *__restrict__ blocks,
                                 u32 *__restrict__ slots, u32 maxSlots, int packedOK,
                                 u32 *__restrict__ list0, u32 *__restrict__ list1, u32 *__restrict__ list2, u32 *__restrict__ listF,
-                                u32 *__restrict__ counts /* 4: <=4096, 8192, 16384 slots, global path */) {
+                                u32 *__restrict__ counts /* 4: <=4096, 8192, 16384 slots, global path */, int hashLast) {
   const u32 c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= nBlocks) return;
   h10x_block b; memset(&b, 0, sizeof b);
@@ -109,7 +109,7 @@ __global__ void classify_kernel(const u64 *__restrict__ startRec, u32 nBlocks, h
   b.nRead = (u32)nr;
   blocks[c] = b;
   u32 s = 0;
-  if (c + 1 < nBlocks) {                                     // the last block is never hashed
+  if (c + 1 < nBlocks || hashLast) {                         // the file's last block is never hashed; a shard's last block is
     u64 want = 256; while (want < nr * 10) want <<= 1;      // expected load <= 0.76 at 7.6 unique / pair (overflow at 0.875 => global path)
     if (packedOK && nr <= 65535 && want <= maxSlots) {
       s = (u32)want;
@@ -262,7 +262,7 @@ __global__ void compact_entries_kernel(const u64 *__restrict__ stHash, const u32
 }
 
 // ------------------------------------------------------------------------------------------ driver
-int stageA_run(Ctx *c, const u32 *dRec, u64 nRec, DevBuf<u64> &entHash, DevBuf<u32> &entCode, DevBuf<u32> &entRead) {
+int stageA_run(Ctx *c, const u32 *dRec, u64 nRec, DevBuf<u64> &entHash, DevBuf<u32> &entCode, DevBuf<u32> &entRead, bool hashLast) {
   hipStream_t st = c->stream;
   PrimTemp pt;
   const int k = c->prm.k;
@@ -307,7 +307,7 @@ int stageA_run(Ctx *c, const u32 *dRec, u64 nRec, DevBuf<u64> &entHash, DevBuf<u
   H10X_HIP(c, hipMemsetAsync(counts.p, 0, 16, st));
   H10X_HIP(c, hipMemsetAsync(nHash.p, 0, ((size_t)nBlocks + 1) * 4, st));
   classify_kernel<<<divUp(nBlocks, 256), 256, 0, st>>>(startRec.p, nBlocks, c->blocks.p, slots.p, maxSlots, packedOK,
-                                                      list0.p, list1.p, list2.p, listF.p, counts.p);
+                                                      list0.p, list1.p, list2.p, listF.p, counts.p, hashLast ? 1 : 0);
   DevBuf<u64> capOff; H10X_HIP(c, capOff.alloc((size_t)nBlocks + 1));
   H10X_TRY(prim_exclusive_scan_u32_u64(c, pt, slots.p, capOff.p, nBlocks));
   u32 hc[4]; u64 capTotal = 0; u32 lastSlots = 0;
@@ -345,7 +345,7 @@ int stageA_run(Ctx *c, const u32 *dRec, u64 nRec, DevBuf<u64> &entHash, DevBuf<u
   H10X_HIP(c, hipMemcpyAsync(hStart.data(), startRec.p, ((size_t)nBlocks + 1) * 8, hipMemcpyDeviceToHost, st));
   if (hc[3]) H10X_HIP(c, hipMemcpyAsync(hListF.data(), listF.p, (size_t)hc[3] * 4, hipMemcpyDeviceToHost, st));
   H10X_HIP(c, hipStreamSynchronize(st));
-  for (u32 b = 1; b + 1 < nBlocks; ++b) if (hNHash[b] == NHASH_OVERFLOW) hListF.push_back(b);
+  for (u32 b = 1; b + (hashLast ? 0 : 1) < nBlocks; ++b) if (hNHash[b] == NHASH_OVERFLOW) hListF.push_back(b);
   std::vector<SrcPtr> hFb(nBlocks, SrcPtr{nullptr, nullptr});
   std::vector<DevBuf<u64> *> keepH; std::vector<DevBuf<u32> *> keepR;
   c->ctr.fallback_blocks = hListF.size();
@@ -406,7 +406,7 @@ int stageA_run(Ctx *c, const u32 *dRec, u64 nRec, DevBuf<u64> &entHash, DevBuf<u
   for (auto *p : keepH) delete p;
   for (auto *p : keepR) delete p;
 
-  u64 hashedPairs = nBlocks >= 2 ? hStart[nBlocks - 1] : 0;  // all blocks but the last
+  u64 hashedPairs = hashLast ? nRec : (nBlocks >= 2 ? hStart[nBlocks - 1] : 0);  // all blocks but the file's last
   c->ctr.pairs = nRec; c->ctr.kmers = hashedPairs * (u64)(mc.n1 + mc.n2); c->ctr.entries = H;
   return 0;
 }

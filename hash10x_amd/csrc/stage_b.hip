@@ -16,6 +16,7 @@
 namespace h10x {
 
 constexpr u32 SLOT_EMPTY = 0xFFFFFFFFu;
+static int bitsFor(u64 maxValue) { int b = 1; while (b < 64 && (maxValue >> b)) ++b; return b; }
 
 // ------------------------------------------------------------------------------------------ distinct hashes
 __global__ void seg_head_flags_kernel(const u64 *__restrict__ sHash, u64 n, u32 *__restrict__ flags) {
@@ -104,7 +105,6 @@ __global__ void write_clushash_kernel(const u64 *__restrict__ key, u64 n, h10x_c
   }
 }
 
-static int bitsFor(u64 maxValue) { int b = 1; while (b < 64 && (maxValue >> b)) ++b; return b; }
 
 int stageB_run(Ctx *c, DevBuf<u64> &entHash, DevBuf<u32> &entCode, DevBuf<u32> &entRead) {
   hipStream_t st = c->stream; PrimTemp pt;
@@ -150,30 +150,45 @@ int stageB_run(Ctx *c, DevBuf<u64> &entHash, DevBuf<u32> &entCode, DevBuf<u32> &
   c->tstop(T_RANK);
   sHash.release(); dHash.release(); dFirst.release(); iota.release(); dFirstSorted.release();
 
-  // ---- probe table
+  H10X_TRY(stageB_buildProbeTable(c));
+
+  // ---- clusHash: look every entry up, order each block by index (hash10x.c:177-183)
+  c->tstart(T_CLUSHASH);
+  if (H) {
+    DevBuf<u64> key; H10X_HIP(c, key.alloc(H));
+    lookup_pack_kernel<<<gH, 256, 0, st>>>(entHash.p, entRead.p, H, c->hashIndex.p, c->hashValue.p, B, key.p);
+    H10X_TRY(stageB_finishClusHash(c, key));
+  } else H10X_HIP(c, c->clusHash.alloc(0));
+  c->tstop(T_CLUSHASH);
+  c->ctr.distinct = U;
+  c->haveState = true;
+  return 0;
+}
+
+int stageB_buildProbeTable(Ctx *c) {
+  hipStream_t st = c->stream; const int B = c->prm.B; const u64 tableSize = (u64)1 << B; const u32 U = c->hashNumber - 1;
   c->tstart(T_PROBE);
   H10X_HIP(c, c->hashIndex.alloc(tableSize));
   H10X_HIP(c, hipMemsetAsync(c->hashIndex.p, 0xFF, tableSize * 4, st));
   if (U) probe_insert_kernel<<<hmin<u32>(divUp(U, 256), 16384), 256, 0, st>>>(c->hashValue.p, U + 1, B, c->hashIndex.p);
   probe_finish_kernel<<<(unsigned)hmin<u64>(divUp(tableSize, 256), 65535u * 2), 256, 0, st>>>(c->hashIndex.p, tableSize);
   c->tstop(T_PROBE);
+  return 0;
+}
 
-  // ---- clusHash: look every entry up, order each block by index (hash10x.c:177-183)
-  c->tstart(T_CLUSHASH);
+// key[e] = hash index << 32 | read (U16), entries in block order: sort every block by index, emit ClusterHash
+int stageB_finishClusHash(Ctx *c, DevBuf<u64> &key) {
+  hipStream_t st = c->stream; PrimTemp pt; const u64 H = c->nEntries; const u32 nBlocks = c->nBlocks;
+  const unsigned gH = (unsigned)hmin<u64>(divUp(H ? H : 1, 256), 65535u * 2);
   H10X_HIP(c, c->clusHash.alloc(H));
-  if (H) {
-    DevBuf<u64> key, keyS; DevBuf<u32> off32;
-    H10X_HIP(c, key.alloc(H)); H10X_HIP(c, keyS.alloc(H)); H10X_HIP(c, off32.alloc((size_t)nBlocks + 1));
-    lookup_pack_kernel<<<gH, 256, 0, st>>>(entHash.p, entRead.p, H, c->hashIndex.p, c->hashValue.p, B, key.p);
-    offsets32_kernel<<<divUp((u64)nBlocks + 1, 256), 256, 0, st>>>(c->blockOff.p, nBlocks + 1, off32.p);
-    H10X_TRY(prim_seg_sort_keys_u64(c, pt, key.p, keyS.p, (u32)H, nBlocks, off32.p, off32.p + 1, 32, 32 + bitsFor(U + 1)));
-    write_clushash_kernel<<<gH, 256, 0, st>>>(keyS.p, H, c->clusHash.p);
-    H10X_HIP(c, hipGetLastError());
-    H10X_HIP(c, hipStreamSynchronize(st));
-  }
-  c->tstop(T_CLUSHASH);
-  c->ctr.distinct = U;
-  c->haveState = true;
+  if (!H) return 0;
+  DevBuf<u64> keyS; DevBuf<u32> off32;
+  H10X_HIP(c, keyS.alloc(H)); H10X_HIP(c, off32.alloc((size_t)nBlocks + 1));
+  offsets32_kernel<<<divUp((u64)nBlocks + 1, 256), 256, 0, st>>>(c->blockOff.p, nBlocks + 1, off32.p);
+  H10X_TRY(prim_seg_sort_keys_u64(c, pt, key.p, keyS.p, (u32)H, nBlocks, off32.p, off32.p + 1, 32, 32 + bitsFor(c->hashNumber)));
+  write_clushash_kernel<<<gH, 256, 0, st>>>(keyS.p, H, c->clusHash.p);
+  H10X_HIP(c, hipGetLastError());
+  H10X_HIP(c, hipStreamSynchronize(st));
   return 0;
 }
 

@@ -118,6 +118,7 @@ int stageC_depthRange(Ctx *c, int lo, int hi) {
   H10X_HIP(c, hipStreamSynchronize(st));
   c->haveGood = true;
   c->tstop(T_GOOD);
+  if (c->sharded) H10X_TRY(shard_exchangeRows(c));           // barcode lists of the in-range hashes, from their owners
   return 0;
 }
 
@@ -128,6 +129,8 @@ struct ClusterArgs {
   const u32 *hashDepth; const u64 *rowStart; const u32 *rows;
   const u32 *list; u32 nList; u32 *workCounter;
   u32 nBlocks; int threshold;
+  u32 codeBase;                                             // sharded runs: global barcode number = codeBase + local block number
+  u32 nBlocksFirst;                                         // size of first[]: barcodes of the whole data set + 1
   unsigned char *scratch; size_t scratchStride;             // global-mode working set per workgroup
   size_t mergeOffset;                                       // global mode: read-merge tables live behind the rank arrays
   u32 maxGood;
@@ -290,19 +293,20 @@ __device__ void row_mode_long(const u32 *__restrict__ row, u32 d, u32 code, u32 
 #define SYNC_LDS() do { if (IN_LDS) { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); } else SYNC(); } while (0)
 
 template <bool IN_LDS, int CL_THREADS>
-__device__ void cluster_one_block(const ClusterArgs &a, u32 code, unsigned char *region, u32 *sh /* small shared ints */) {
+__device__ void cluster_one_block(const ClusterArgs &a, u32 code, unsigned char *region, u32 *sh /* small shared ints */) {   // code: local block number
   constexpr int CL_WAVES = CL_THREADS / WAVE;
   const int tid = threadIdx.x, lane = tid & (WAVE - 1), wave = tid / WAVE;
   const u32 n = a.nGood[code];
   if (n == 0) return;                                        // hash10x.c:780: block left untouched
   const u64 o = a.blockOff[code];
   const u32 nHash = a.blocks[code].nHash, nRead = a.blocks[code].nRead;
-  Work w = carve(region, a.nBlocks, n);
+  Work w = carve(region, a.nBlocksFirst, n);
+  const u32 lcode = code; code += a.codeBase;                // from here on `code` is the global barcode number (what the lists hold)
   h10x_clushash *ch = a.clusHash + o; const u16 *g = a.goodPos + o;
 
   u64 tPrev = a.phase ? wall_clock64() : 0;
   // ---- init: prefetch every rank's list offset/length once
-  if (IN_LDS) for (u32 i = tid; i < (a.nBlocks + 1) / 2; i += CL_THREADS) ((u32 *)w.first)[i] = 0xFFFFFFFFu;
+  if (IN_LDS) for (u32 i = tid; i < (a.nBlocksFirst + 1) / 2; i += CL_THREADS) ((u32 *)w.first)[i] = 0xFFFFFFFFu;
   for (u32 i = tid; i < CL_WAVES * w.histWords; i += CL_THREADS) w.hist[i] = 0;
   u64 myDepth = 0;
   for (u32 i = tid; i < n; i += CL_THREADS) {
@@ -466,7 +470,7 @@ __device__ void cluster_one_block(const ClusterArgs &a, u32 code, unsigned char 
         }
       }
     }
-    if (lane == 0) { a.blocks[code].pointToMin = p; a.blocks[code].nSubCluster = nSub; }
+    if (lane == 0) { a.blocks[lcode].pointToMin = p; a.blocks[lcode].nSubCluster = nSub; }
   }
   for (u32 i = tid; i < n; i += CL_THREADS) ch[g[i]].subCluster = w.lab[i];     // includes the wipe of hash10x.c:783
   // wave-reduce the per-thread depth sums for the work counters
@@ -524,7 +528,7 @@ __device__ void cluster_one_block(const ClusterArgs &a, u32 code, unsigned char 
     u32 alive = 0; newLab[0] = 0;
     for (u32 L = 1; L <= nSub; ++L) { if (ld_shared<IN_LDS>(&comp[L]) == L) ++alive; newLab[L] = alive; }   // rank of L if it is a minimum
     for (u32 L = 1; L <= nSub; ++L) newLab[256 + L] = newLab[ld_shared<IN_LDS>(&comp[L])];                 // label -> rank of its minimum
-    a.blocks[code].nSubCluster = alive;
+    a.blocks[lcode].nSubCluster = alive;
   }
   SYNC();
   for (u32 p = tid; p < nHash; p += CL_THREADS) {
@@ -558,7 +562,7 @@ void cluster_kernel(ClusterArgs a) {
 // (one 1024-lane workgroup), 2 = the whole LDS with 512 lanes (fewer per-wave histograms => more ranks fit),
 // 3 = HBM scratch
 __global__ void cluster_classify_kernel(const h10x_block *__restrict__ blocks, const u32 *__restrict__ nGood, u32 codeMin, u32 codeMax,
-                                        u32 nBlocks, size_t budgetSmall, size_t budgetBig,
+                                        u32 nBlocks /* size of first[] */, size_t budgetSmall, size_t budgetBig,
                                         u32 *__restrict__ list0, u32 *__restrict__ list1, u32 *__restrict__ list2, u32 *__restrict__ list3,
                                         u32 *__restrict__ counts) {
   const u32 c = codeMin + blockIdx.x * blockDim.x + threadIdx.x;
@@ -576,10 +580,15 @@ int stageC_cluster(Ctx *c, int codeMin, int codeMax, int threshold) {
   hipStream_t st = c->stream;
   if (!c->haveGood) return c->fail("!! you must set hashDepthRange before cluster");          // hash10x.c:1258
   if (threshold < 1) return c->fail("clusterThreshold %d must be >= 1 (the reference reads an uninitialised msBest otherwise)", threshold);
+  const u32 nGlobal = c->sharded ? c->nBlocksGlobal : c->nBlocks;
   if (!codeMin) codeMin = 1;                                                                    // hash10x.c:1243-1244
-  if (!codeMax) codeMax = (int)c->nBlocks;
-  if (codeMin < 0 || codeMax > (int)c->nBlocks) return c->fail("cluster code range %d..%d outside 1..%u", codeMin, codeMax, c->nBlocks);
-  if (codeMax <= codeMin) return 0;
+  if (!codeMax) codeMax = (int)nGlobal;
+  if (codeMin < 0 || codeMax > (int)nGlobal) return c->fail("cluster code range %d..%d outside 1..%u", codeMin, codeMax, nGlobal);
+  if (c->sharded) {                                          // keep this shard's part of the (global) range, as local block numbers
+    const long lo = (long)codeMin - (long)c->codeBase, hi = (long)codeMax - (long)c->codeBase;
+    codeMin = (int)(lo < 1 ? 1 : lo); codeMax = (int)(hi > (long)c->nBlocks ? (long)c->nBlocks : hi);
+  }
+  if (codeMax <= codeMin) { memset(c->ctr.cluster_class_counts, 0, sizeof c->ctr.cluster_class_counts); c->ctr.sum_good = c->ctr.sum_good_depth = c->ctr.sum_hash_clustered = c->ctr.clustered_codes = 0; return 0; }
   c->tstart(T_CLUSTER);
   const u32 span = (u32)(codeMax - codeMin);
   DevBuf<u32> list0, list1, list2, list3, counts; DevBuf<u64> stats;
@@ -588,7 +597,7 @@ int stageC_cluster(Ctx *c, int codeMin, int codeMax, int threshold) {
   H10X_HIP(c, hipMemsetAsync(counts.p, 0, 32, st)); H10X_HIP(c, hipMemsetAsync(stats.p, 0, 32, st));
   const size_t budgetSmall = c->optClusterLds > 0 ? (size_t)c->optClusterLds : 80 * 1024 - 1024;
   const size_t budgetBig = c->optClusterLds > 0 ? (size_t)c->optClusterLds : 160 * 1024 - 1024;
-  cluster_classify_kernel<<<divUp(span, 256), 256, 0, st>>>(c->blocks.p, c->nGood.p, (u32)codeMin, (u32)codeMax, c->nBlocks, budgetSmall, budgetBig,
+  cluster_classify_kernel<<<divUp(span, 256), 256, 0, st>>>(c->blocks.p, c->nGood.p, (u32)codeMin, (u32)codeMax, nGlobal, budgetSmall, budgetBig,
                                                           list0.p, list1.p, list2.p, list3.p, counts.p);
   u32 hc[4];
   H10X_HIP(c, hipMemcpyAsync(hc, counts.p, 16, hipMemcpyDeviceToHost, st));
@@ -596,6 +605,7 @@ int stageC_cluster(Ctx *c, int codeMin, int codeMax, int threshold) {
   ClusterArgs a{};
   a.blocks = c->blocks.p; a.blockOff = c->blockOff.p; a.clusHash = c->clusHash.p; a.goodPos = c->goodPos.p; a.nGood = c->nGood.p;
   a.hashDepth = c->hashDepth.p; a.rowStart = c->rowStart.p; a.rows = c->rows.p; a.nBlocks = c->nBlocks; a.threshold = threshold;
+  a.codeBase = c->sharded ? c->codeBase : 0; a.nBlocksFirst = nGlobal;
   a.maxGood = c->maxGood; a.stats = stats.p;
   DevBuf<u64> phase;
   if (c->optStamps) { H10X_HIP(c, phase.alloc(8)); H10X_HIP(c, hipMemsetAsync(phase.p, 0, 64, st)); a.phase = phase.p; }
@@ -603,7 +613,7 @@ int stageC_cluster(Ctx *c, int codeMin, int codeMax, int threshold) {
   DevBuf<unsigned char> scratch;
   size_t stride = 0; u32 grid3 = 0;
   if (hc[3]) {
-    const size_t mergeOff = (workBytes(c->nBlocks, c->maxGood, CL_THREADS_SMALL / WAVE) + 255) & ~(size_t)255;
+    const size_t mergeOff = (workBytes(nGlobal, c->maxGood, CL_THREADS_SMALL / WAVE) + 255) & ~(size_t)255;
     stride = mergeOff + ((mergeBytes(65536) + 255) & ~(size_t)255);
     a.mergeOffset = mergeOff;
     grid3 = hmin<u32>(hc[3], (u32)c->numCU);
@@ -709,6 +719,7 @@ __global__ void split_aux_kernel(const h10x_block *__restrict__ b, u32 n, u32 *_
 
 int stageC_split(Ctx *c) {
   hipStream_t st = c->stream; PrimTemp pt;
+  if (c->sharded) return c->fail("clusterSplit on a sharded context: gather first (h10x_shard_gather) and split on rank 0");
   if (!c->haveState) return c->fail("no hash state loaded: use readFQB or readHash first");
   c->tstart(T_SPLIT);
   const u32 nCodes = c->nBlocks;

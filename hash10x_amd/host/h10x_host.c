@@ -172,6 +172,26 @@ int h10x_session_readFQB_dev(h10x_session *s, const uint32_t *devRec, uint64_t n
   return 0;
 }
 
+int h10x_session_shardReadFQB_mem(h10x_session *s, h10x_comm *comm, const uint32_t *rec, uint64_t n) {
+  if (session_init(s)) return -1;
+  if (h10x_shard_attach(s->ctx, comm)) return fail(s, "h10x_shard_attach failed");
+  if (h10x_shard_read_fqb(s->ctx, rec, n)) return fail_ctx(s);
+  return 0;
+}
+int h10x_session_shardReadFQB_dev(h10x_session *s, h10x_comm *comm, const uint32_t *devRec, uint64_t n) {
+  if (session_init(s)) return -1;
+  if (h10x_shard_attach(s->ctx, comm)) return fail(s, "h10x_shard_attach failed");
+  if (h10x_shard_read_fqb_device(s->ctx, devRec, n)) return fail_ctx(s);
+  return 0;
+}
+int h10x_session_shardGather(h10x_session *s) {
+  if (!s->ctx) return fail(s, "no hash state loaded: use readFQB or readHash first");
+  if (h10x_shard_gather(s->ctx)) return fail_ctx(s);
+  h10x_sizes z;
+  if (!h10x_get_sizes(s->ctx, &z) && z.nBlocks) after_readFQB(s);   /* Array dims as one --readFQB of the whole file would leave them */
+  return 0;
+}
+
 int h10x_session_readFQB(h10x_session *s, const char *path) {
   FILE *f = fopen(path, "rb");
   if (!f) return fail(s, "failed to open fqb file %s", path);                      /* hash10x.c:1201 */

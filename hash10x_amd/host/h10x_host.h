@@ -35,6 +35,13 @@ int  h10x_session_hashDepthRange(h10x_session *s, int min, int max);            
 int  h10x_session_cluster(h10x_session *s, int codeMin, int codeMax);                 /* hash10x.c:1241-1261 */
 int  h10x_session_clusterSplit(h10x_session *s);                                      /* hash10x.c:1267 */
 
+/* multi-GPU (include/h10x.h "multi-GPU"): this rank's contiguous barcode range of the sorted file, cut with
+   h10x_host_partition; -N and the chunkSize check are the launcher's business here. After shardGather rank 0's
+   session holds the whole state and --writeHash works as usual. */
+int  h10x_session_shardReadFQB_mem(h10x_session *s, h10x_comm *comm, const uint32_t *shardRecords, uint64_t nRecords);
+int  h10x_session_shardReadFQB_dev(h10x_session *s, h10x_comm *comm, const uint32_t *devShardRecords, uint64_t nRecords);
+int  h10x_session_shardGather(h10x_session *s);
+
 /* dimension the reference's Array reaches when elements are first touched in ascending order up to
    lastIndex, starting from initialDim (array.c:144-185) */
 int  h10x_host_array_dim(int initialDim, int elemSize, int64_t lastIndex);

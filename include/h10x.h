@@ -110,6 +110,33 @@ int  h10x_get_sizes(h10x_ctx *ctx, h10x_sizes *out);
 int  h10x_export(h10x_ctx *ctx, uint32_t *hashIndex, uint64_t *hashValue, uint32_t *hashDepth,
                  h10x_block *blocks, h10x_clushash *clusHash);
 
+/* ---- multi-GPU: barcodes sharded over N ranks, hashes owned by value range (csrc/shard.hip) ----
+   The reference has no counterpart (its only parallelism is the OMP loop inside --cluster); the invariant is
+   that N ranks produce exactly the bytes one rank produces. A communicator is either RCCL (one process per GPU:
+   rank 0 calls h10x_comm_unique_id, ships the 128 bytes to the others by any means, every rank calls
+   h10x_comm_create_rccl) or in-process (h10x_comm_create_local: N ranks driven by N threads of one process,
+   used by the tests and by single-process multi-GPU hosts). */
+typedef struct h10x_comm h10x_comm;
+int  h10x_comm_unique_id(void *id128);
+int  h10x_comm_create_rccl(h10x_comm **comm, int rank, int nranks, const void *id128, int device, char *err, int errlen);
+int  h10x_comm_create_local(h10x_comm **comms /* nranks outputs */, int nranks);
+void h10x_comm_destroy(h10x_comm *comm);
+int  h10x_comm_rank(const h10x_comm *comm);
+int  h10x_comm_size(const h10x_comm *comm);
+/* bind a communicator to a context (collective calls below are made by every rank in the same order) */
+int  h10x_shard_attach(h10x_ctx *ctx, h10x_comm *comm);
+/* --readFQB on this rank's contiguous barcode range of the sorted file (cut with h10x_host_partition): stage A
+   locally, then the hash-owner exchange; afterwards every rank holds hashValue/hashDepth/hashIndex of the whole data
+   set and blocks/clusHash of its own barcodes. h10x_depth_range / h10x_cluster work as usual (global barcode
+   numbers; --hashDepthRange also allgathers the barcode lists of the in-range hashes). */
+int  h10x_shard_read_fqb(h10x_ctx *ctx, const uint32_t *host_records, uint64_t n_records);
+int  h10x_shard_read_fqb_device(h10x_ctx *ctx, const uint32_t *dev_records, uint64_t n_records);
+/* collective: rank 0 receives every rank's blocks and clusHash and from then on exports like a single-GPU context */
+int  h10x_shard_gather(h10x_ctx *ctx);
+/* collective plumbing for launchers: barrier, and max over ranks of a host double (timing) */
+int  h10x_shard_barrier(h10x_ctx *ctx);
+int  h10x_shard_allreduce_max(h10x_ctx *ctx, double *value);
+
 /* ---- device memory plumbing for callers that keep the input resident in HBM (bench, pipelines) ----
    plain hipMalloc / hipMemcpy / hipDeviceSynchronize on `device`; return NULL / non-zero on failure */
 void *h10x_device_malloc(int device, uint64_t bytes);

@@ -167,3 +167,80 @@ def test_context_reuse_is_deterministic(workdir):
         got = open(workdir.file("hip.hash"), "rb").read()
         assert got == exp, "pass %d: %s" % (it, orc.describe_diff(got, exp))
     assert orc.HashFile(exp).blocks["nSubCluster"].sum() > 0
+
+
+def _run_sharded(recs, nranks, B, lo, hi, ct, out_path, split_after=False):
+    """N ranks as N threads on one GPU (in-process communicator): the whole sharded pipeline incl. gather."""
+    import threading
+    import hash10x_amd
+    cut = hash10x_amd.partition(recs, nranks)
+    comms = hash10x_amd.Comm.local(nranks)
+    flat = np.ascontiguousarray(recs, dtype=np.uint32).reshape(-1)
+    errs = [None] * nranks
+
+    def work(r):
+        try:
+            h = hash10x_amd.Hash10x(B=B)
+            h.shard_read_fqb(comms[r], flat[30 * cut[r]: 30 * cut[r + 1]])
+            h.depth_range(lo, hi)
+            h.cluster(1, 0, ct)
+            h.shard_gather()
+            if r == 0:
+                h.write_hash(out_path)
+            h.close()
+        except Exception as e:              # noqa: BLE001
+            errs[r] = e
+    th = [threading.Thread(target=work, args=(r,)) for r in range(nranks)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(600)
+    for c in comms:
+        c.destroy()
+    for e in errs:
+        if e is not None:
+            raise e
+
+
+@pytest.mark.parametrize("nranks", [1, 2, 3, 4, 8])
+def test_sharded_equals_single_gpu_and_oracle(workdir, nranks):
+    """SURVEY §8e invariant: N-rank canonical .hash == 1-GPU == oracle (hash-owner all-to-all, index numbering by
+    allgathered first-barcode counts, allgather of in-range barcode lists, gather to rank 0)."""
+    recs = orc.gen_fqb(workdir.file("x.fqb"), 40000, 180, 300000, 0.003, 61, 4.0, 150, 6000)
+    o = orc.Oracle(B=20)
+    o.read_fqb(recs)
+    o.depth_range(4, 30)
+    o.cluster(1, 0, 3)
+    o.write_hash(workdir.file("orc.hash"))
+    exp = open(workdir.file("orc.hash"), "rb").read()
+    _run_sharded(recs, nranks, 20, 4, 30, 3, workdir.file("hip.hash"))
+    got = open(workdir.file("hip.hash"), "rb").read()
+    assert got == exp, orc.describe_diff(got, exp)
+    assert orc.HashFile(exp).blocks["nSubCluster"].sum() > 0
+
+
+def test_sharded_golden_small(workdir):
+    recs = np.frombuffer(orc.read_maybe_gz(os.path.join(orc.GOLDEN, "small.fqb.gz")), dtype=np.uint32)
+    _run_sharded(recs, 4, 20, 3, 14, 2, workdir.file("hip.hash"))
+    got = open(workdir.file("hip.hash"), "rb").read()
+    exp = orc.read_maybe_gz(os.path.join(orc.GOLDEN, "small.e2e.hash.gz"))
+    assert got == exp, orc.describe_diff(got, exp)
+
+
+def test_rccl_communicator_single_rank(workdir):
+    """The RCCL backend with one rank (all a 1-GPU box can run): init, the self-copy path of alltoallv, teardown."""
+    import hash10x_amd
+    recs = np.frombuffer(orc.read_maybe_gz(os.path.join(orc.GOLDEN, "small.fqb.gz")), dtype=np.uint32)
+    comm = hash10x_amd.Comm.rccl(0, 1, hash10x_amd.Comm.unique_id(), 0)
+    h = hash10x_amd.Hash10x(B=20)
+    h.shard_read_fqb(comm, recs)
+    h.depth_range(3, 14)
+    h.cluster(1, 0, 2)
+    assert h.shard_allreduce_max(1.5) == 1.5
+    h.shard_gather()
+    h.write_hash(workdir.file("hip.hash"))
+    h.close()
+    comm.destroy()
+    got = open(workdir.file("hip.hash"), "rb").read()
+    exp = orc.read_maybe_gz(os.path.join(orc.GOLDEN, "small.e2e.hash.gz"))
+    assert got == exp, orc.describe_diff(got, exp)
