@@ -11,9 +11,10 @@ generator of hash10x_amd/tools/gen_fqb.c stands in.
     python bench.py [--gpus N] [--steps K] [--warmup W]
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
 
-N > 1: one process per GPU, each rank runs the path on its own seeded set of the same size (weak
-scaling, independent samples, no data-path collective yet — see DESIGN.md "Multi-GPU"). torch.distributed
-(gloo) is used for the barrier and the max-over-ranks of the elapsed time only.
+N > 1: one process per GPU; the workload is N times the yeast-scale set (weak scaling), its barcodes
+sharded over the ranks and the global hash<->barcode index built by RCCL all-to-all over xGMI
+(csrc/shard.hip, DESIGN.md "Multi-GPU"). RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* are read from the
+environment as torch.distributed.run sets them; torch itself is not imported (see rendezvous_unique_id).
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` for the dominant
 kernel and `cpu_baseline` (the reference binary from oracle/_ref, or the oracle port, timed on the
@@ -63,6 +64,65 @@ def generate(wl, seed):
     g.h10x_gen_free()
     assert n == wl["pairs"]
     return out
+
+
+def rendezvous_unique_id(rank, world, hash10x_amd):
+    """RCCL bootstrap without torch in the process (torch ships its own HIP/RCCL runtimes; a second runtime next to
+    libh10x_hip's cost ~3 ms per step at N = 1): rank 0 draws the ncclUniqueId and serves "H10X" + its 128 bytes on
+    the first free port of MASTER_PORT + 29 .. + 44 at MASTER_ADDR; the other ranks walk the same ports until one
+    answers with the magic."""
+    import socket
+    if world == 1:
+        return hash10x_amd.Comm.unique_id()
+    addr = os.environ.get("MASTER_ADDR", "127.0.0.1")
+    if addr == "localhost":
+        addr = "127.0.0.1"
+    ports = [int(os.environ.get("MASTER_PORT", "29500")) + 29 + i for i in range(16)]
+    if rank == 0:
+        uid = hash10x_amd.Comm.unique_id()
+        srv = None
+        for port in ports:
+            try:
+                srv = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
+                srv.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
+                srv.bind((addr, port))
+                break
+            except OSError:
+                srv.close()
+                srv = None
+        if srv is None:
+            raise RuntimeError("rendezvous: no free port in %r" % ports)
+        srv.listen(world)
+        srv.settimeout(900)
+        for _ in range(world - 1):
+            c, _a = srv.accept()
+            c.sendall(b"H10X" + uid)
+            c.close()
+        srv.close()
+        return uid
+    deadline = time.time() + 900
+    while time.time() < deadline:
+        for port in ports:
+            try:
+                c = socket.create_connection((addr, port), timeout=5)
+            except OSError:
+                continue
+            try:
+                c.settimeout(20)
+                buf = b""
+                while len(buf) < 132:
+                    chunk = c.recv(132 - len(buf))
+                    if not chunk:
+                        break
+                    buf += chunk
+            except OSError:
+                buf = b""
+            finally:
+                c.close()
+            if len(buf) == 132 and buf[:4] == b"H10X":
+                return buf[4:]
+        time.sleep(0.2)
+    raise RuntimeError("rendezvous: rank 0 did not answer on %s:%r" % (addr, ports))
 
 
 def cpu_baseline(wl, recs, workdir, gpu_hash_path):
@@ -121,7 +181,14 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="yeast-like-2.5M", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--sharded", action="store_true", help="use the multi-GPU code path (RCCL communicator, shard exchange) even with one rank")
     args = ap.parse_args()
+
+    # the contract is ONE JSON line on stdout: native libraries (RCCL prints a version banner) must not write there,
+    # so fd 1 is pointed at stderr for the life of the process and the JSON line goes to the saved descriptor
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
 
     import hash10x_amd
 
@@ -131,19 +198,23 @@ def main():
     if world != args.gpus and world > 1:
         raise SystemExit("WORLD_SIZE %d != --gpus %d" % (world, args.gpus))
     if args.gpus > 1 and world == 1:
-        raise SystemExit("--gpus %d needs torch.distributed.run with one rank per GPU" % args.gpus)
-    dist = torch = None
-    if world > 1:
-        # control plane only (barrier + max of the elapsed time): the path has no data-path collective yet, so the
-        # process group runs on gloo and torch never initialises a second HIP runtime next to libh10x_hip's
-        # (two runtimes in one process cost ~3 ms of extra launch/sync latency per step, measured at N = 1).
-        import torch
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+        raise SystemExit("--gpus %d needs torch.distributed.run (or any launcher that sets RANK/LOCAL_RANK/WORLD_SIZE/MASTER_*), one rank per GPU" % args.gpus)
 
-    wl = WORKLOADS[args.workload]
-    recs = generate(wl, seed=1 + rank)                      # rank r: its own sample (seed 1 + r)
+    wl = dict(WORKLOADS[args.workload])
+    comm = None
+    if world > 1 or args.sharded:
+        # weak scaling: N times the yeast-scale set (N x pairs, barcodes and genome; table bits grow with log2 N),
+        # barcodes sharded over the ranks, hash index exchanged by RCCL all-to-all (csrc/shard.hip)
+        wl["pairs"] *= world
+        wl["barcodes"] *= world
+        wl["genome"] *= world
+        wl["B"] += (world - 1).bit_length()
+        comm = hash10x_amd.Comm.rccl(rank, world, rendezvous_unique_id(rank, world, hash10x_amd), local_rank)
+    recs = generate(wl, seed=1)                              # every rank builds the same seeded set and keeps its shard
+    total_pairs = recs.size // 30
+    if comm is not None:
+        cut = hash10x_amd.partition(recs, world)
+        recs = recs[30 * cut[rank]: 30 * cut[rank + 1]].copy()
     pairs = recs.size // 30
     d_recs = hash10x_amd.DeviceRecords(recs, device=local_rank)   # resident in HBM before the timed region
     hash10x_amd.synchronize(local_rank)
@@ -155,7 +226,10 @@ def main():
 
     def step():
         t0 = time.perf_counter()
-        h.read_fqb_device(d_recs.ptr, pairs)
+        if comm is None:
+            h.read_fqb_device(d_recs.ptr, pairs)
+        else:
+            h.shard_read_fqb_device(comm, d_recs.ptr, pairs)
         t1 = time.perf_counter()
         h.depth_range(wl["lo"], wl["hi"])
         t2 = time.perf_counter()
@@ -167,8 +241,8 @@ def main():
 
     def barrier():
         hash10x_amd.synchronize(local_rank)      # hipDeviceSynchronize (every command also syncs before returning)
-        if dist is not None:
-            dist.barrier()
+        if comm is not None:
+            h.shard_barrier()                    # RCCL allreduce
         hash10x_amd.synchronize(local_rank)
 
     for _ in range(args.warmup):
@@ -191,16 +265,14 @@ def main():
         harvest()          # reads finished hipEvents of this step's context (contexts are per-readFQB)
     barrier()
     elapsed = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    if comm is not None:
+        elapsed = h.shard_allreduce_max(elapsed)
 
     ctr = h.counters()
     sizes = h.sizes()
     steps = args.steps
     ms_per_step = 1e3 * elapsed / steps
-    value = world * pairs * steps / elapsed
+    value = total_pairs * steps / elapsed
 
     per = {k: (v[0] / max(v[1], 1), v[1] // steps if steps else 0, v[0] / steps) for k, v in acc.items()}   # avg ms/launch, launches/step, ms/step
     H, U = ctr["entries"], ctr["distinct"]
@@ -223,9 +295,9 @@ def main():
         "value": value, "unit": "read-pairs/s", "n_gpus": world, "steps": steps, "warmup": args.warmup,
         "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "u64", "data": "synthetic",
-        "config": {"workload": args.workload, "read_pairs": pairs, "barcodes": wl["barcodes"], "B": wl["B"], "k": 21, "w": 31,
+        "config": {"workload": args.workload + (" x%d" % world if world > 1 else ""), "read_pairs": total_pairs, "barcodes": wl["barcodes"], "B": wl["B"], "k": 21, "w": 31,
                    "hashDepthRange": [wl["lo"], wl["hi"]], "clusterThreshold": wl["ct"],
-                   "parallelism": "1 sample per GPU (independent, seeds 1..N)" if world > 1 else "single GPU"},
+                   "parallelism": ("barcodes sharded over %d GPUs, hash index by RCCL all-to-all" % world) if world > 1 else "single GPU"},
         "read_pairs_per_s_hashed": pairs / (hash_ms * 1e-3) if hash_ms else None,
         "barcodes_per_s_clustered": wl["barcodes"] / (clu_ms * 1e-3) if clu_ms else None,
         "device_ms_per_step": stage_ms,
@@ -249,9 +321,10 @@ def main():
             except Exception as e:                       # the baseline is reporting only; never lose the GPU number
                 out["cpu_baseline"] = {"value": None, "unit": "read-pairs/s", "cores": 1, "kind": "error", "sample": str(e)[:300]}
     if rank == 0:
-        print(json.dumps(out))
-    if dist is not None:
-        dist.destroy_process_group()
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
+    h.close()
+    if comm is not None:
+        comm.destroy()
 
 
 if __name__ == "__main__":

@@ -62,3 +62,34 @@ def test_two_rank_gloo_shards_cover_the_file(tmp_path):
     # per-barcode unique hash sets are shard-local, so entry counts add up (the file's last barcode is unhashed in both)
     assert res["entries"] == res["full_entries"]
     assert res["tmax"] == 1.5
+
+
+RDV = r'''
+import os, sys
+sys.path.insert(0, os.environ["H10X_REPO"])
+import bench
+class Fake:                      # stands in for hash10x_amd.Comm.unique_id() on a box without RCCL devices
+    class Comm:
+        @staticmethod
+        def unique_id():
+            return bytes(range(128))
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+uid = bench.rendezvous_unique_id(rank, world, Fake)
+assert uid == bytes(range(128)), uid
+print("ok", rank)
+'''
+
+
+def test_rccl_unique_id_rendezvous_three_ranks(tmp_path):
+    """bench.py's torch-free bootstrap: rank 0 serves the 128-byte ncclUniqueId to the other ranks over TCP."""
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    wf = tmp_path / "rdv.py"
+    wf.write_text(RDV)
+    procs = []
+    for r in (2, 1, 0):                               # clients first: they must wait for the server
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE="3", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), H10X_REPO=orc.REPO)
+        procs.append(subprocess.Popen([sys.executable, str(wf)], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE))
+    for p in procs:
+        so, se = p.communicate(timeout=120)
+        assert p.returncode == 0, se.decode()[-1500:]
+        assert so.decode().startswith("ok")
