@@ -290,6 +290,20 @@ def main():
                                                       "index_rank", "probe_table", "clushash_build"))
     clu_ms = per.get("cluster", (0, 0, 0))[2]
 
+    # HBM traffic of the dominant kernel: PMC counters cannot be read from inside this process; the figure is the
+    # one measured by the committed rocprofv3 --pmc passes (profiles/*_pmc_traffic.json), per step, raw counters
+    traffic = traffic_src = None
+    try:
+        import glob
+        cands = sorted(glob.glob(os.path.join(REPO, "profiles", "*_pmc_traffic.json")))
+        if cands and args.workload == "yeast-like-2.5M" and world == 1:
+            pm = json.load(open(cands[-1]))
+            tb = sum(sum(c["bytes_per_step"] for c in v.values()) for k, v in pm["kernels"].items() if dom.split("_")[0] in k)
+            if tb:
+                traffic, traffic_src = tb, os.path.basename(cands[-1])
+    except Exception:
+        traffic = None
+
     out = {
         "metric": "read-pairs/s through --readFQB + --hashDepthRange + --cluster (mosh construction + per-barcode clustering)",
         "value": value, "unit": "read-pairs/s", "n_gpus": world, "steps": steps, "warmup": args.warmup,
@@ -304,7 +318,7 @@ def main():
         "host_wall_ms_per_step": {k: round(1e3 * v / steps, 3) for k, v in wall.items()},
         "entries_H": H, "distinct_U": U, "hashNumber": sizes["hashNumber"], "fallback_blocks": ctr["fallback_blocks"],
         "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                      "algorithmic_bytes_per_launch": alg[dom], "avg_launch_ms": dom_ms,
                      "other_kernels": {k: {"GB/s": alg[k] / (per[k][2] * 1e-3) / 1e9, "ms_per_step": per[k][2]} for k in alg if k in per and per[k][2] > 0}},
     }
