@@ -221,7 +221,7 @@ __device__ __forceinline__ u32 wave_max_u32(u32 v) {
 // last at a value sees its full count, so a DPP wave max over (arrival count, lowest rank) is the mode —
 // one LDS round trip for the gather, one for the atomics. Lists with fewer usable entries than the
 // threshold are skipped (only "msMax < threshold" matters to the caller then).
-template <bool IN_LDS, int RCHUNK>
+template <bool IN_LDS, bool FIRST_LDS, int RCHUNK>
 __device__ __forceinline__ void row_mode_hist(const u32 *__restrict__ row, u32 cj0, u32 d, u32 code, u32 i, const u16 *first, u32 *hist,
                                               u32 thr, u32 &best, u32 &bcnt, u32 &tot) {
   const int lane = threadIdx.x & (WAVE - 1);
@@ -232,7 +232,7 @@ __device__ __forceinline__ void row_mode_hist(const u32 *__restrict__ row, u32 c
     f[r] = NONE16; ok[r] = false;
     if ((u32)(r * WAVE) < d) {
       const u32 j = r * WAVE + lane;
-      if (j < d) { const u32 cj = r == 0 ? cj0 : row[j]; if (cj != code) { f[r] = ld_shared<IN_LDS>(&first[cj]); ok[r] = f[r] < i; } }
+      if (j < d) { const u32 cj = r == 0 ? cj0 : row[j]; if (cj != code) { f[r] = ld_shared<FIRST_LDS>(&first[cj]); ok[r] = f[r] < i; } }
       tot += (u32)__popcll(__ballot(ok[r]));
     }
   }
@@ -292,21 +292,22 @@ __device__ void row_mode_long(const u32 *__restrict__ row, u32 d, u32 code, u32 
 // flight (a full __syncthreads() drains vmcnt too). The HBM-scratch instantiation keeps the full barrier + L1 drop.
 #define SYNC_LDS() do { if (IN_LDS) { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); } else SYNC(); } while (0)
 
-template <bool IN_LDS, int CL_THREADS>
-__device__ void cluster_one_block(const ClusterArgs &a, u32 code, unsigned char *region, u32 *sh /* small shared ints */) {   // code: local block number
+template <bool IN_LDS, bool FIRST_LDS, int CL_THREADS>
+__device__ void cluster_one_block(const ClusterArgs &a, u32 code, unsigned char *region, u16 *firstGlobal, u32 *sh /* small shared ints */) {   // code: local block number
   constexpr int CL_WAVES = CL_THREADS / WAVE;
   const int tid = threadIdx.x, lane = tid & (WAVE - 1), wave = tid / WAVE;
   const u32 n = a.nGood[code];
   if (n == 0) return;                                        // hash10x.c:780: block left untouched
   const u64 o = a.blockOff[code];
   const u32 nHash = a.blocks[code].nHash, nRead = a.blocks[code].nRead;
-  Work w = carve(region, a.nBlocksFirst, n);
+  Work w = carve(region, FIRST_LDS || !IN_LDS ? a.nBlocksFirst : 0, n);
+  if (IN_LDS && !FIRST_LDS) w.first = firstGlobal;           // hybrid: first[] on this workgroup's HBM slot, the rest in LDS
   const u32 lcode = code; code += a.codeBase;                // from here on `code` is the global barcode number (what the lists hold)
   h10x_clushash *ch = a.clusHash + o; const u16 *g = a.goodPos + o;
 
   u64 tPrev = a.phase ? wall_clock64() : 0;
   // ---- init: prefetch every rank's list offset/length once
-  if (IN_LDS) for (u32 i = tid; i < (a.nBlocksFirst + 1) / 2; i += CL_THREADS) ((u32 *)w.first)[i] = 0xFFFFFFFFu;
+  if (FIRST_LDS) for (u32 i = tid; i < (a.nBlocksFirst + 1) / 2; i += CL_THREADS) ((u32 *)w.first)[i] = 0xFFFFFFFFu;
   for (u32 i = tid; i < CL_WAVES * w.histWords; i += CL_THREADS) w.hist[i] = 0;
   u64 myDepth = 0;
   for (u32 i = tid; i < n; i += CL_THREADS) {
@@ -343,8 +344,8 @@ __device__ void cluster_one_block(const ClusterArgs &a, u32 code, unsigned char 
 #pragma unroll
     for (int t = 0; t < ROWS_IN_FLIGHT; ++t) {
       const u32 i = i0 + t;
-      if (cj[t] != code) min_u16<IN_LDS>(w.first, cj[t], i);
-      if (dl[t] > WAVE) { const u32 *row = a.rows + w.rs[i]; for (u32 j = WAVE + lane; j < dl[t]; j += WAVE) { const u32 c2 = row[j]; if (c2 != code) min_u16<IN_LDS>(w.first, c2, i); } }
+      if (cj[t] != code) min_u16<FIRST_LDS>(w.first, cj[t], i);
+      if (dl[t] > WAVE) { const u32 *row = a.rows + w.rs[i]; for (u32 j = WAVE + lane; j < dl[t]; j += WAVE) { const u32 c2 = row[j]; if (c2 != code) min_u16<FIRST_LDS>(w.first, c2, i); } }
     }
     SYNC_LDS();
 #pragma unroll
@@ -353,9 +354,9 @@ __device__ void cluster_one_block(const ClusterArgs &a, u32 code, unsigned char 
       if (i < n) {
         const u32 d = dl[t]; const u32 *row = a.rows + w.rs[i];
         u32 best, bcnt, tot;
-        if (d <= WAVE) row_mode_hist<IN_LDS, 1>(row, cj[t], d, code, i, w.first, w.hist + wave * w.histWords, (u32)a.threshold, best, bcnt, tot);
-        else if (d < RCHUNK * WAVE) row_mode_hist<IN_LDS, RCHUNK>(row, cj[t], d, code, i, w.first, w.hist + wave * w.histWords, (u32)a.threshold, best, bcnt, tot);
-        else row_mode_long<IN_LDS>(row, d, code, i, w.first, best, bcnt, tot);
+        if (d <= WAVE) row_mode_hist<IN_LDS, FIRST_LDS, 1>(row, cj[t], d, code, i, w.first, w.hist + wave * w.histWords, (u32)a.threshold, best, bcnt, tot);
+        else if (d < RCHUNK * WAVE) row_mode_hist<IN_LDS, FIRST_LDS, RCHUNK>(row, cj[t], d, code, i, w.first, w.hist + wave * w.histWords, (u32)a.threshold, best, bcnt, tot);
+        else row_mode_long<FIRST_LDS>(row, d, code, i, w.first, best, bcnt, tot);
         if (lane == 0) { w.best[i] = (u16)best; w.ct[i].cnt = bcnt; w.ct[i].tot = tot; }
       }
     }
@@ -445,8 +446,8 @@ __device__ void cluster_one_block(const ClusterArgs &a, u32 code, unsigned char 
       u32 q;
       if (dl[t] == 0) q = w.ct[i].cnt;
       else {
-        q = (u32)__popcll(__ballot(cj[t] != code && ld_shared<IN_LDS>(&w.first[cj[t]]) == qv[t]));
-        if (dl[t] > WAVE) { const u32 *row = a.rows + w.rs[i]; for (u32 b0 = WAVE; b0 < dl[t]; b0 += WAVE) { bool m = false; if (b0 + lane < dl[t]) { const u32 c2 = row[b0 + lane]; m = c2 != code && ld_shared<IN_LDS>(&w.first[c2]) == qv[t]; } q += (u32)__popcll(__ballot(m)); } }
+        q = (u32)__popcll(__ballot(cj[t] != code && ld_shared<FIRST_LDS>(&w.first[cj[t]]) == qv[t]));
+        if (dl[t] > WAVE) { const u32 *row = a.rows + w.rs[i]; for (u32 b0 = WAVE; b0 < dl[t]; b0 += WAVE) { bool m = false; if (b0 + lane < dl[t]) { const u32 c2 = row[b0 + lane]; m = c2 != code && ld_shared<FIRST_LDS>(&w.first[c2]) == qv[t]; } q += (u32)__popcll(__ballot(m)); } }
       }
       if (lane == 0) { const double tq = (double)(int)q / (double)(int)w.ct[i].tot; *(double *)&w.ct[i] = tq; }
     }
@@ -477,7 +478,7 @@ __device__ void cluster_one_block(const ClusterArgs &a, u32 code, unsigned char 
   for (int s = 32; s; s >>= 1) myDepth += __shfl_down(myDepth, s);
   if (lane == 0) atomicAdd((u64 *)&a.stats[1], (u64)myDepth);
   if (tid == 0) { atomicAdd((u64 *)&a.stats[0], (u64)n); atomicAdd((u64 *)&a.stats[2], (u64)nHash); atomicAdd((u64 *)&a.stats[3], 1ULL); }
-  if (!IN_LDS) {                                             // leave first[] clean for the next barcode of this workgroup
+  if (!FIRST_LDS) {                                          // leave first[] clean for the next barcode of this workgroup
     SYNC();
     for (u32 i = 1 + wave; i < n; i += CL_WAVES) {
       const u32 d = w.dd[i]; const u32 *row = a.rows + w.rs[i];
@@ -542,19 +543,20 @@ __device__ void cluster_one_block(const ClusterArgs &a, u32 code, unsigned char 
 #undef SYNC
 #undef SYNC_LDS
 
-template <bool IN_LDS, int CL_THREADS>
+template <bool IN_LDS, bool FIRST_LDS, int CL_THREADS>
 __global__ __launch_bounds__(CL_THREADS)
 void cluster_kernel(ClusterArgs a) {
   extern __shared__ __align__(16) unsigned char smem[];
   __shared__ u32 sh[4 + 128];                               // [0..3] scalars, then clusterMin[256] as u16
   unsigned char *region = IN_LDS ? smem : a.scratch + (size_t)blockIdx.x * a.scratchStride;
+  u16 *firstGlobal = (IN_LDS && !FIRST_LDS) ? (u16 *)(a.scratch + (size_t)blockIdx.x * a.scratchStride) : nullptr;
   for (;;) {
     __syncthreads();
     if (threadIdx.x == 0) sh[3] = atomicAdd(a.workCounter, 1u);
     __syncthreads();
     const u32 wi = sh[3];
     if (wi >= a.nList) break;                                // every wave of the workgroup leaves together
-    cluster_one_block<IN_LDS, CL_THREADS>(a, a.list[wi], region, sh);
+    cluster_one_block<IN_LDS, FIRST_LDS, CL_THREADS>(a, a.list[wi], region, firstGlobal, sh);
   }
 }
 
@@ -597,7 +599,11 @@ int stageC_cluster(Ctx *c, int codeMin, int codeMax, int threshold) {
   H10X_HIP(c, hipMemsetAsync(counts.p, 0, 32, st)); H10X_HIP(c, hipMemsetAsync(stats.p, 0, 32, st));
   const size_t budgetSmall = c->optClusterLds > 0 ? (size_t)c->optClusterLds : 80 * 1024 - 1024;
   const size_t budgetBig = c->optClusterLds > 0 ? (size_t)c->optClusterLds : 160 * 1024 - 1024;
-  cluster_classify_kernel<<<divUp(span, 256), 256, 0, st>>>(c->blocks.p, c->nGood.p, (u32)codeMin, (u32)codeMax, nGlobal, budgetSmall, budgetBig,
+  // first[] (2 B per barcode of the data set) stays in LDS while it is small; past that each workgroup keeps it on an
+  // HBM slot of its own (L2/MALL resident, atomics + L1-bypassing loads) and only the per-rank arrays live in LDS
+  const bool firstLds = c->optFirstGlobal ? false : (size_t)nGlobal * 2 <= 48 * 1024;
+  const u32 nFirstLds = firstLds ? nGlobal : 0;
+  cluster_classify_kernel<<<divUp(span, 256), 256, 0, st>>>(c->blocks.p, c->nGood.p, (u32)codeMin, (u32)codeMax, nFirstLds, budgetSmall, budgetBig,
                                                           list0.p, list1.p, list2.p, list3.p, counts.p);
   u32 hc[4];
   H10X_HIP(c, hipMemcpyAsync(hc, counts.p, 16, hipMemcpyDeviceToHost, st));
@@ -620,6 +626,14 @@ int stageC_cluster(Ctx *c, int codeMin, int codeMax, int threshold) {
     H10X_HIP(c, scratch.alloc(stride * grid3));
     H10X_HIP(c, hipMemsetAsync(scratch.p, 0xFF, stride * grid3, st));    // first[] = unseen everywhere
   }
+  // hybrid placement: one first[] slot per resident workgroup of each LDS class
+  DevBuf<unsigned char> firstSlots[3];
+  const size_t firstStride = (((size_t)nGlobal * 2 + 255) & ~(size_t)255);
+  const u32 gridOf[3] = {hmin<u32>(hc[0], (u32)c->numCU * 2), hmin<u32>(hc[1], (u32)c->numCU), hmin<u32>(hc[2], (u32)c->numCU)};
+  if (!firstLds) for (int k = 0; k < 3; ++k) if (hc[k]) {
+    H10X_HIP(c, firstSlots[k].alloc(firstStride * gridOf[k]));
+    H10X_HIP(c, hipMemsetAsync(firstSlots[k].p, 0xFF, firstStride * gridOf[k], st));
+  }
   // The four classes are independent: fork them onto side streams so that the few largest barcodes (long, low
   // parallelism) run beside the many small ones instead of in front of them. Every buffer they touch was
   // allocated before the fork and is released after the join, which is what the block cache requires.
@@ -627,23 +641,24 @@ int stageC_cluster(Ctx *c, int codeMin, int codeMax, int threshold) {
   H10X_TRY(c->forkStreams(3));
   if (hc[3]) {
     ClusterArgs g = a; g.list = list3.p; g.nList = hc[3]; g.workCounter = counts.p + 7; g.scratch = scratch.p; g.scratchStride = stride;
-    cluster_kernel<false, CL_THREADS_SMALL><<<grid3, CL_THREADS_SMALL, 0, c->aux[0]>>>(g);
+    cluster_kernel<false, false, CL_THREADS_SMALL><<<grid3, CL_THREADS_SMALL, 0, c->aux[0]>>>(g);
   }
-  if (hc[2]) {
-    ClusterArgs g = a; g.list = list2.p; g.nList = hc[2]; g.workCounter = counts.p + 6;
-    H10X_HIP(c, hipFuncSetAttribute((const void *)cluster_kernel<true, CL_THREADS_HUGE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)budgetBig));
-    cluster_kernel<true, CL_THREADS_HUGE><<<hmin<u32>(hc[2], (u32)c->numCU), CL_THREADS_HUGE, budgetBig, c->aux[1]>>>(g);
+#define H10X_LAUNCH_LDS(K, THREADS, BUDGET, STREAM, LIST, CNT)                                                                     \
+  if (hc[K]) {                                                                                                                     \
+    ClusterArgs g = a; g.list = LIST; g.nList = hc[K]; g.workCounter = counts.p + CNT;                                            \
+    if (firstLds) {                                                                                                                \
+      H10X_HIP(c, hipFuncSetAttribute((const void *)cluster_kernel<true, true, THREADS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(BUDGET))); \
+      cluster_kernel<true, true, THREADS><<<gridOf[K], THREADS, BUDGET, STREAM>>>(g);                                              \
+    } else {                                                                                                                       \
+      g.scratch = firstSlots[K].p; g.scratchStride = firstStride;                                                                  \
+      H10X_HIP(c, hipFuncSetAttribute((const void *)cluster_kernel<true, false, THREADS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(BUDGET))); \
+      cluster_kernel<true, false, THREADS><<<gridOf[K], THREADS, BUDGET, STREAM>>>(g);                                             \
+    }                                                                                                                              \
   }
-  if (hc[1]) {
-    ClusterArgs g = a; g.list = list1.p; g.nList = hc[1]; g.workCounter = counts.p + 5;
-    H10X_HIP(c, hipFuncSetAttribute((const void *)cluster_kernel<true, CL_THREADS_BIG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)budgetBig));
-    cluster_kernel<true, CL_THREADS_BIG><<<hmin<u32>(hc[1], (u32)c->numCU), CL_THREADS_BIG, budgetBig, c->aux[2]>>>(g);
-  }
-  if (hc[0]) {
-    ClusterArgs g = a; g.list = list0.p; g.nList = hc[0]; g.workCounter = counts.p + 4;
-    H10X_HIP(c, hipFuncSetAttribute((const void *)cluster_kernel<true, CL_THREADS_SMALL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)budgetSmall));
-    cluster_kernel<true, CL_THREADS_SMALL><<<hmin<u32>(hc[0], (u32)c->numCU * 2), CL_THREADS_SMALL, budgetSmall, st>>>(g);
-  }
+  H10X_LAUNCH_LDS(2, CL_THREADS_HUGE, budgetBig, c->aux[1], list2.p, 6)
+  H10X_LAUNCH_LDS(1, CL_THREADS_BIG, budgetBig, c->aux[2], list1.p, 5)
+  H10X_LAUNCH_LDS(0, CL_THREADS_SMALL, budgetSmall, st, list0.p, 4)
+#undef H10X_LAUNCH_LDS
   H10X_HIP(c, hipGetLastError());
   H10X_TRY(c->joinStreams(3));
   c->tstop(T_CLUSTER_K);

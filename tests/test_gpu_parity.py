@@ -92,6 +92,15 @@ def test_cluster_hbm_scratch_and_big_lds_paths(workdir, budget):
     assert hf.blocks["nSubCluster"].sum() > 0
 
 
+def test_cluster_first_table_on_hbm_slots(workdir):
+    """Hybrid placement used when the data set has too many barcodes for first[] to sit in LDS: first[] on a
+    per-workgroup HBM slot (atomics + L1-bypassing loads), per-rank arrays in LDS."""
+    orc.gen_fqb(workdir.file("x.fqb"), 60000, 300, 400000, 0.003, 43, 4.0, 150, 6000)
+    hf = _against_oracle(workdir, "x.fqb", ["-ct", 3, "--readFQB", "x.fqb", "--hashDepthRange", 4, 40, "--cluster", 1, 0],
+                         cluster_first_global=1)
+    assert hf.blocks["nSubCluster"].sum() > 0
+
+
 @pytest.mark.parametrize("k,w,r", [(21, 31, 17), (16, 5, 3), (24, 31, 5), (25, 31, 17), (31, 7, 1), (11, 32, 9)])
 def test_other_hashers(workdir, k, w, r):
     """k > 24 cannot pack (hash, read) into 64 bits and takes the global path; w != 31 the generic modulo."""
