@@ -152,7 +152,8 @@ struct Ctx {
   // options / measurement
   int64_t optMaxSlots = 0;    // testing knob: cap stage-A LDS table
   int64_t optClusterLds = 0;  // testing knob: LDS budget of cluster_kernel (forces the HBM-scratch path when small)
-  int64_t optFirstGlobal = 0; // testing knob: keep cluster_kernel's first[] on HBM slots even when it would fit LDS
+  int64_t optFirstGlobal = 0; // testing knob: 1 = first[] on HBM slots, 2 = ranked first[] in LDS, even when the dense table would fit
+  int64_t optFirstCap = 0;    // testing knob: entries of the ranked first[]
   int64_t optStamps = 0;      // diagnostic: per-phase wall-clock stamps in cluster_kernel
   bool timing = false;
   Timer timers[T_COUNT];

@@ -22,6 +22,7 @@
 // Barcodes whose working set exceeds the LDS budget run the same code on a per-workgroup HBM scratch.
 #include "common.hpp"
 #include "prim.hpp"
+#include <type_traits>
 
 namespace h10x {
 
@@ -131,6 +132,8 @@ struct ClusterArgs {
   u32 nBlocks; int threshold;
   u32 codeBase;                                             // sharded runs: global barcode number = codeBase + local block number
   u32 nBlocksFirst;                                         // size of first[]: barcodes of the whole data set + 1
+  u32 firstCap;                                             // ranked placement: first[] entries available (barcodes present in a block)
+  u32 *overflow, *overflowCount;                            // ranked placement: blocks with more present barcodes than firstCap
   unsigned char *scratch; size_t scratchStride;             // global-mode working set per workgroup
   size_t mergeOffset;                                       // global mode: read-merge tables live behind the rank arrays
   u32 maxGood;
@@ -142,7 +145,8 @@ struct PairCT { u32 cnt, tot; };                            // overwritten by th
 
 // working set layout inside a region (LDS or HBM scratch)
 struct Work {
-  u16 *first;        // nBlocks entries, NONE16 = unseen
+  u16 *first;        // NONE16 = unseen; indexed by barcode (dense) or by the barcode's rank among those present (ranked)
+  u32 *bm, *pre;     // ranked placement: presence bitmap over all barcodes and its exclusive popcount prefix per word
   PairCT *ct;        // msMax / msTot per rank, later the quotient (as double)
   u32 *rs;           // offset of the rank's barcode list in rows[] (prefetched once)
   u32 *dd;           // its length (hashDepth)
@@ -152,8 +156,8 @@ struct Work {
   u32 *hist;         // CL_WAVES private byte-histograms over ranks (4 counters per word), all zero between lists
   u32 histWords;     // words per wave
 };
-__host__ __device__ inline size_t workBytes(u32 nBlocks, u32 n, u32 nWaves) {
-  size_t b = (((size_t)nBlocks * 2 + 15) & ~(size_t)15);
+__host__ __device__ inline size_t workBytes(u32 nFirst, u32 n, u32 nWaves, u32 bmWords = 0) {
+  size_t b = (((size_t)nFirst * 2 + 15) & ~(size_t)15) + (size_t)bmWords * 8;
   b += (size_t)n * 8;                                       // ct (8-byte aligned first)
   b += (size_t)n * 4 * 2;                                   // rs, dd
   b += (size_t)n * 2 * 2;                                   // best, qj
@@ -161,9 +165,11 @@ __host__ __device__ inline size_t workBytes(u32 nBlocks, u32 n, u32 nWaves) {
   b += (size_t)nWaves * (((size_t)n + 3) / 4) * 4;          // hist
   return b + 16;
 }
-__device__ inline Work carve(unsigned char *base, u32 nBlocks, u32 n) {
+__device__ inline Work carve(unsigned char *base, u32 nFirst, u32 n, u32 bmWords = 0) {
   Work w; size_t o = 0;
-  w.first = (u16 *)(base + o); o += (((size_t)nBlocks * 2 + 15) & ~(size_t)15);
+  w.first = (u16 *)(base + o); o += (((size_t)nFirst * 2 + 15) & ~(size_t)15);
+  w.bm = (u32 *)(base + o); o += (size_t)bmWords * 4;
+  w.pre = (u32 *)(base + o); o += (size_t)bmWords * 4;
   w.ct = (PairCT *)(base + o); o += (size_t)n * 8;
   w.rs = (u32 *)(base + o); o += (size_t)n * 4;
   w.dd = (u32 *)(base + o); o += (size_t)n * 4;
@@ -187,6 +193,15 @@ template <bool IN_LDS, typename T> __device__ __forceinline__ T ld_shared(const 
   if (IN_LDS) return *p;
   return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
+
+// where a barcode's first[] entry lives: at its own number (dense table) or at its rank among the barcodes present in
+// this block's lists (bitmap + per-word popcount prefix: 3 LDS reads instead of 1, but 2 B per PRESENT barcode plus
+// 1 bit + 1/8 B per barcode of the data set instead of 2 B per barcode of the data set)
+struct MapDense { __device__ __forceinline__ u32 operator()(u32 cj) const { return cj; } };
+struct MapRanked {
+  const u32 *bm, *pre;
+  __device__ __forceinline__ u32 operator()(u32 cj) const { const u32 w = cj >> 5; return pre[w] + (u32)__popc(bm[w] & ((1u << (cj & 31)) - 1u)); }
+};
 
 // CAS-min on a u16 living in a u32 word (LDS or global)
 template <bool IN_LDS>
@@ -221,8 +236,8 @@ __device__ __forceinline__ u32 wave_max_u32(u32 v) {
 // last at a value sees its full count, so a DPP wave max over (arrival count, lowest rank) is the mode —
 // one LDS round trip for the gather, one for the atomics. Lists with fewer usable entries than the
 // threshold are skipped (only "msMax < threshold" matters to the caller then).
-template <bool IN_LDS, bool FIRST_LDS, int RCHUNK>
-__device__ __forceinline__ void row_mode_hist(const u32 *__restrict__ row, u32 cj0, u32 d, u32 code, u32 i, const u16 *first, u32 *hist,
+template <bool IN_LDS, bool FIRST_LDS, int RCHUNK, typename FM>
+__device__ __forceinline__ void row_mode_hist(const u32 *__restrict__ row, u32 cj0, u32 d, u32 code, u32 i, const u16 *first, const FM &fm, u32 *hist,
                                               u32 thr, u32 &best, u32 &bcnt, u32 &tot) {
   const int lane = threadIdx.x & (WAVE - 1);
   u32 f[RCHUNK]; bool ok[RCHUNK];
@@ -232,7 +247,7 @@ __device__ __forceinline__ void row_mode_hist(const u32 *__restrict__ row, u32 c
     f[r] = NONE16; ok[r] = false;
     if ((u32)(r * WAVE) < d) {
       const u32 j = r * WAVE + lane;
-      if (j < d) { const u32 cj = r == 0 ? cj0 : row[j]; if (cj != code) { f[r] = ld_shared<FIRST_LDS>(&first[cj]); ok[r] = f[r] < i; } }
+      if (j < d) { const u32 cj = r == 0 ? cj0 : row[j]; if (cj != code) { f[r] = ld_shared<FIRST_LDS>(&first[fm(cj)]); ok[r] = f[r] < i; } }
       tot += (u32)__popcll(__ballot(ok[r]));
     }
   }
@@ -258,13 +273,13 @@ __device__ __forceinline__ void row_mode_hist(const u32 *__restrict__ row, u32 c
   best = key ? 0xFFFFu - (key & 0xFFFFu) : NONE16;
 }
 // lists of 256 entries and more (exotic depth ranges): re-gather per candidate
-template <bool IN_LDS>
-__device__ void row_mode_long(const u32 *__restrict__ row, u32 d, u32 code, u32 i, const u16 *first, u32 &best, u32 &bcnt, u32 &tot) {
+template <bool IN_LDS, typename FM>
+__device__ void row_mode_long(const u32 *__restrict__ row, u32 d, u32 code, u32 i, const u16 *first, const FM &fm, u32 &best, u32 &bcnt, u32 &tot) {
   const int lane = threadIdx.x & (WAVE - 1);
   best = NONE16; bcnt = 0; tot = 0;
   for (u32 a0 = 0; a0 < d; a0 += WAVE) {
     u32 fa = NONE16; bool va = false;
-    if (a0 + lane < d) { const u32 cj = row[a0 + lane]; if (cj != code) { fa = ld_shared<IN_LDS>(&first[cj]); va = fa < i; } }
+    if (a0 + lane < d) { const u32 cj = row[a0 + lane]; if (cj != code) { fa = ld_shared<IN_LDS>(&first[fm(cj)]); va = fa < i; } }
     u64 rem = __ballot(va); tot += (u32)__popcll(rem);
     while (rem) {
       const int src = __ffsll((long long)rem) - 1;
@@ -273,7 +288,7 @@ __device__ void row_mode_long(const u32 *__restrict__ row, u32 d, u32 code, u32 
       u32 cnt = 0; bool seenBefore = false;
       for (u32 b0 = 0; b0 < d; b0 += WAVE) {
         u32 fb = NONE16;
-        if (b0 + lane < d) { const u32 cj = row[b0 + lane]; if (cj != code) fb = ld_shared<IN_LDS>(&first[cj]); }
+        if (b0 + lane < d) { const u32 cj = row[b0 + lane]; if (cj != code) fb = ld_shared<IN_LDS>(&first[fm(cj)]); }
         const u32 m = (u32)__popcll(__ballot(fb == v));
         if (b0 < a0 && m) { seenBefore = true; break; }
         cnt += m;
@@ -292,7 +307,7 @@ __device__ void row_mode_long(const u32 *__restrict__ row, u32 d, u32 code, u32 
 // flight (a full __syncthreads() drains vmcnt too). The HBM-scratch instantiation keeps the full barrier + L1 drop.
 #define SYNC_LDS() do { if (IN_LDS) { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); } else SYNC(); } while (0)
 
-template <bool IN_LDS, bool FIRST_LDS, int CL_THREADS>
+template <bool IN_LDS, int FIRST_MODE /* 0 dense in LDS, 1 ranked in LDS, 2 dense on an HBM slot */, int CL_THREADS>
 __device__ void cluster_one_block(const ClusterArgs &a, u32 code, unsigned char *region, u16 *firstGlobal, u32 *sh /* small shared ints */) {   // code: local block number
   constexpr int CL_WAVES = CL_THREADS / WAVE;
   const int tid = threadIdx.x, lane = tid & (WAVE - 1), wave = tid / WAVE;
@@ -300,14 +315,20 @@ __device__ void cluster_one_block(const ClusterArgs &a, u32 code, unsigned char 
   if (n == 0) return;                                        // hash10x.c:780: block left untouched
   const u64 o = a.blockOff[code];
   const u32 nHash = a.blocks[code].nHash, nRead = a.blocks[code].nRead;
-  Work w = carve(region, FIRST_LDS || !IN_LDS ? a.nBlocksFirst : 0, n);
-  if (IN_LDS && !FIRST_LDS) w.first = firstGlobal;           // hybrid: first[] on this workgroup's HBM slot, the rest in LDS
+  constexpr bool FIRST_LDS = IN_LDS && FIRST_MODE != 2;
+  constexpr bool RANKED = IN_LDS && FIRST_MODE == 1;
+  const u32 bmWords = RANKED ? (a.nBlocksFirst + 31) / 32 : 0;
+  Work w = carve(region, RANKED ? a.firstCap : (FIRST_LDS || !IN_LDS ? a.nBlocksFirst : 0), n, bmWords);
+  if (IN_LDS && FIRST_MODE == 2) w.first = firstGlobal;      // hybrid: first[] on this workgroup's HBM slot, the rest in LDS
+  typename std::conditional<RANKED, MapRanked, MapDense>::type fm{};
+  if constexpr (RANKED) { fm.bm = w.bm; fm.pre = w.pre; }
   const u32 lcode = code; code += a.codeBase;                // from here on `code` is the global barcode number (what the lists hold)
   h10x_clushash *ch = a.clusHash + o; const u16 *g = a.goodPos + o;
 
   u64 tPrev = a.phase ? wall_clock64() : 0;
   // ---- init: prefetch every rank's list offset/length once
-  if (FIRST_LDS) for (u32 i = tid; i < (a.nBlocksFirst + 1) / 2; i += CL_THREADS) ((u32 *)w.first)[i] = 0xFFFFFFFFu;
+  if (FIRST_LDS && !RANKED) for (u32 i = tid; i < (a.nBlocksFirst + 1) / 2; i += CL_THREADS) ((u32 *)w.first)[i] = 0xFFFFFFFFu;
+  if (RANKED) for (u32 i = tid; i < bmWords; i += CL_THREADS) w.bm[i] = 0;
   for (u32 i = tid; i < CL_WAVES * w.histWords; i += CL_THREADS) w.hist[i] = 0;
   u64 myDepth = 0;
   for (u32 i = tid; i < n; i += CL_THREADS) {
@@ -316,6 +337,33 @@ __device__ void cluster_one_block(const ClusterArgs &a, u32 code, unsigned char 
     w.ct[i].cnt = 0; w.ct[i].tot = 0; myDepth += d;
   }
   SYNC();
+  if constexpr (RANKED) {
+    // ---- (0) which barcodes occur in this block's lists: presence bitmap, per-word popcount prefix, and a first[] sized by
+    // the number present. More present than the table holds => the block is handed to the HBM-slot variant.
+    for (u32 i = 1 + wave; i < n; i += CL_WAVES) {
+      const u32 d = w.dd[i]; const u32 *row = a.rows + w.rs[i];
+      for (u32 j = lane; j < d; j += WAVE) { const u32 cj = row[j]; if (cj != code) atomicOr(&w.bm[cj >> 5], 1u << (cj & 31)); }
+    }
+    SYNC();
+    const u32 ipt = (bmWords + CL_THREADS - 1) / CL_THREADS, s0 = tid * ipt < bmWords ? tid * ipt : bmWords, s1 = s0 + ipt < bmWords ? s0 + ipt : bmWords;
+    u32 mine = 0;
+    for (u32 q = s0; q < s1; ++q) mine += (u32)__popc(w.bm[q]);
+    u32 inc = mine;
+#pragma unroll
+    for (int dd = 1; dd < WAVE; dd <<= 1) { const u32 o2 = (u32)__shfl_up((int)inc, dd); if (lane >= dd) inc += o2; }
+    if (lane == WAVE - 1) sh[4 + wave] = inc;
+    SYNC();
+    u32 run = inc - mine, total = 0;
+    for (int q = 0; q < CL_WAVES; ++q) { if (q < wave) run += sh[4 + q]; total += sh[4 + q]; }
+    for (u32 q = s0; q < s1; ++q) { w.pre[q] = run; run += (u32)__popc(w.bm[q]); }
+    if (total > a.firstCap) {                                 // uniform: every thread sees the same total
+      if (tid == 0) a.overflow[atomicAdd(a.overflowCount, 1u)] = lcode;
+      SYNC();
+      return;
+    }
+    for (u32 q = tid; q < (total + 1) / 2; q += CL_THREADS) ((u32 *)w.first)[q] = 0xFFFFFFFFu;
+    SYNC();
+  }
   STAMP(0);
 
   // ---- (a)+(b) in one pass over the lists, in rank order, CL_WAVES * ROWS_IN_FLIGHT ranks per round:
@@ -344,8 +392,8 @@ __device__ void cluster_one_block(const ClusterArgs &a, u32 code, unsigned char 
 #pragma unroll
     for (int t = 0; t < ROWS_IN_FLIGHT; ++t) {
       const u32 i = i0 + t;
-      if (cj[t] != code) min_u16<FIRST_LDS>(w.first, cj[t], i);
-      if (dl[t] > WAVE) { const u32 *row = a.rows + w.rs[i]; for (u32 j = WAVE + lane; j < dl[t]; j += WAVE) { const u32 c2 = row[j]; if (c2 != code) min_u16<FIRST_LDS>(w.first, c2, i); } }
+      if (cj[t] != code) min_u16<FIRST_LDS>(w.first, fm(cj[t]), i);
+      if (dl[t] > WAVE) { const u32 *row = a.rows + w.rs[i]; for (u32 j = WAVE + lane; j < dl[t]; j += WAVE) { const u32 c2 = row[j]; if (c2 != code) min_u16<FIRST_LDS>(w.first, fm(c2), i); } }
     }
     SYNC_LDS();
 #pragma unroll
@@ -354,9 +402,9 @@ __device__ void cluster_one_block(const ClusterArgs &a, u32 code, unsigned char 
       if (i < n) {
         const u32 d = dl[t]; const u32 *row = a.rows + w.rs[i];
         u32 best, bcnt, tot;
-        if (d <= WAVE) row_mode_hist<IN_LDS, FIRST_LDS, 1>(row, cj[t], d, code, i, w.first, w.hist + wave * w.histWords, (u32)a.threshold, best, bcnt, tot);
-        else if (d < RCHUNK * WAVE) row_mode_hist<IN_LDS, FIRST_LDS, RCHUNK>(row, cj[t], d, code, i, w.first, w.hist + wave * w.histWords, (u32)a.threshold, best, bcnt, tot);
-        else row_mode_long<FIRST_LDS>(row, d, code, i, w.first, best, bcnt, tot);
+        if (d <= WAVE) row_mode_hist<IN_LDS, FIRST_LDS, 1>(row, cj[t], d, code, i, w.first, fm, w.hist + wave * w.histWords, (u32)a.threshold, best, bcnt, tot);
+        else if (d < RCHUNK * WAVE) row_mode_hist<IN_LDS, FIRST_LDS, RCHUNK>(row, cj[t], d, code, i, w.first, fm, w.hist + wave * w.histWords, (u32)a.threshold, best, bcnt, tot);
+        else row_mode_long<FIRST_LDS>(row, d, code, i, w.first, fm, best, bcnt, tot);
         if (lane == 0) { w.best[i] = (u16)best; w.ct[i].cnt = bcnt; w.ct[i].tot = tot; }
       }
     }
@@ -446,8 +494,8 @@ __device__ void cluster_one_block(const ClusterArgs &a, u32 code, unsigned char 
       u32 q;
       if (dl[t] == 0) q = w.ct[i].cnt;
       else {
-        q = (u32)__popcll(__ballot(cj[t] != code && ld_shared<FIRST_LDS>(&w.first[cj[t]]) == qv[t]));
-        if (dl[t] > WAVE) { const u32 *row = a.rows + w.rs[i]; for (u32 b0 = WAVE; b0 < dl[t]; b0 += WAVE) { bool m = false; if (b0 + lane < dl[t]) { const u32 c2 = row[b0 + lane]; m = c2 != code && ld_shared<FIRST_LDS>(&w.first[c2]) == qv[t]; } q += (u32)__popcll(__ballot(m)); } }
+        q = (u32)__popcll(__ballot(cj[t] != code && ld_shared<FIRST_LDS>(&w.first[fm(cj[t])]) == qv[t]));
+        if (dl[t] > WAVE) { const u32 *row = a.rows + w.rs[i]; for (u32 b0 = WAVE; b0 < dl[t]; b0 += WAVE) { bool m = false; if (b0 + lane < dl[t]) { const u32 c2 = row[b0 + lane]; m = c2 != code && ld_shared<FIRST_LDS>(&w.first[fm(c2)]) == qv[t]; } q += (u32)__popcll(__ballot(m)); } }
       }
       if (lane == 0) { const double tq = (double)(int)q / (double)(int)w.ct[i].tot; *(double *)&w.ct[i] = tq; }
     }
@@ -543,20 +591,20 @@ __device__ void cluster_one_block(const ClusterArgs &a, u32 code, unsigned char 
 #undef SYNC
 #undef SYNC_LDS
 
-template <bool IN_LDS, bool FIRST_LDS, int CL_THREADS>
+template <bool IN_LDS, int FIRST_MODE, int CL_THREADS>
 __global__ __launch_bounds__(CL_THREADS)
 void cluster_kernel(ClusterArgs a) {
   extern __shared__ __align__(16) unsigned char smem[];
   __shared__ u32 sh[4 + 128];                               // [0..3] scalars, then clusterMin[256] as u16
   unsigned char *region = IN_LDS ? smem : a.scratch + (size_t)blockIdx.x * a.scratchStride;
-  u16 *firstGlobal = (IN_LDS && !FIRST_LDS) ? (u16 *)(a.scratch + (size_t)blockIdx.x * a.scratchStride) : nullptr;
+  u16 *firstGlobal = (IN_LDS && FIRST_MODE == 2) ? (u16 *)(a.scratch + (size_t)blockIdx.x * a.scratchStride) : nullptr;
   for (;;) {
     __syncthreads();
     if (threadIdx.x == 0) sh[3] = atomicAdd(a.workCounter, 1u);
     __syncthreads();
     const u32 wi = sh[3];
     if (wi >= a.nList) break;                                // every wave of the workgroup leaves together
-    cluster_one_block<IN_LDS, FIRST_LDS, CL_THREADS>(a, a.list[wi], region, firstGlobal, sh);
+    cluster_one_block<IN_LDS, FIRST_MODE, CL_THREADS>(a, a.list[wi], region, firstGlobal, sh);
   }
 }
 
@@ -564,7 +612,7 @@ void cluster_kernel(ClusterArgs a) {
 // (one 1024-lane workgroup), 2 = the whole LDS with 512 lanes (fewer per-wave histograms => more ranks fit),
 // 3 = HBM scratch
 __global__ void cluster_classify_kernel(const h10x_block *__restrict__ blocks, const u32 *__restrict__ nGood, u32 codeMin, u32 codeMax,
-                                        u32 nBlocks /* size of first[] */, size_t budgetSmall, size_t budgetBig,
+                                        u32 nBlocks /* LDS entries of first[] */, u32 bmWords, size_t budgetSmall, size_t budgetBig,
                                         u32 *__restrict__ list0, u32 *__restrict__ list1, u32 *__restrict__ list2, u32 *__restrict__ list3,
                                         u32 *__restrict__ counts) {
   const u32 c = codeMin + blockIdx.x * blockDim.x + threadIdx.x;
@@ -572,9 +620,9 @@ __global__ void cluster_classify_kernel(const h10x_block *__restrict__ blocks, c
   const u32 n = nGood[c];
   if (!n) return;
   const size_t mb = mergeBytes(blocks[c].nRead);
-  if (max(workBytes(nBlocks, n, CL_THREADS_SMALL / WAVE), mb) <= budgetSmall) list0[atomicAdd(&counts[0], 1u)] = c;
-  else if (max(workBytes(nBlocks, n, CL_THREADS_BIG / WAVE), mb) <= budgetBig) list1[atomicAdd(&counts[1], 1u)] = c;
-  else if (max(workBytes(nBlocks, n, CL_THREADS_HUGE / WAVE), mb) <= budgetBig) list2[atomicAdd(&counts[2], 1u)] = c;
+  if (max(workBytes(nBlocks, n, CL_THREADS_SMALL / WAVE, bmWords), mb) <= budgetSmall) list0[atomicAdd(&counts[0], 1u)] = c;
+  else if (max(workBytes(nBlocks, n, CL_THREADS_BIG / WAVE, bmWords), mb) <= budgetBig) list1[atomicAdd(&counts[1], 1u)] = c;
+  else if (max(workBytes(nBlocks, n, CL_THREADS_HUGE / WAVE, bmWords), mb) <= budgetBig) list2[atomicAdd(&counts[2], 1u)] = c;
   else list3[atomicAdd(&counts[3], 1u)] = c;
 }
 
@@ -601,9 +649,13 @@ int stageC_cluster(Ctx *c, int codeMin, int codeMax, int threshold) {
   const size_t budgetBig = c->optClusterLds > 0 ? (size_t)c->optClusterLds : 160 * 1024 - 1024;
   // first[] (2 B per barcode of the data set) stays in LDS while it is small; past that each workgroup keeps it on an
   // HBM slot of its own (L2/MALL resident, atomics + L1-bypassing loads) and only the per-rank arrays live in LDS
-  const bool firstLds = c->optFirstGlobal ? false : (size_t)nGlobal * 2 <= 48 * 1024;
-  const u32 nFirstLds = firstLds ? nGlobal : 0;
-  cluster_classify_kernel<<<divUp(span, 256), 256, 0, st>>>(c->blocks.p, c->nGood.p, (u32)codeMin, (u32)codeMax, nFirstLds, budgetSmall, budgetBig,
+  const u32 bmWordsAll = (nGlobal + 31) / 32;
+  int firstMode = (size_t)nGlobal * 2 <= 48 * 1024 ? 0 : ((size_t)bmWordsAll * 8 <= 64 * 1024 ? 1 : 2);
+  if (c->optFirstGlobal == 1) firstMode = 2; else if (c->optFirstGlobal == 2) firstMode = 1;   // test knobs
+  const u32 firstCap = hmin<u32>(nGlobal, c->optFirstCap > 0 ? (u32)c->optFirstCap : 12288u);
+  const u32 nFirstLds = firstMode == 0 ? nGlobal : (firstMode == 1 ? firstCap : 0);
+  const u32 bmWords = firstMode == 1 ? bmWordsAll : 0;
+  cluster_classify_kernel<<<divUp(span, 256), 256, 0, st>>>(c->blocks.p, c->nGood.p, (u32)codeMin, (u32)codeMax, nFirstLds, bmWords, budgetSmall, budgetBig,
                                                           list0.p, list1.p, list2.p, list3.p, counts.p);
   u32 hc[4];
   H10X_HIP(c, hipMemcpyAsync(hc, counts.p, 16, hipMemcpyDeviceToHost, st));
@@ -613,6 +665,8 @@ int stageC_cluster(Ctx *c, int codeMin, int codeMax, int threshold) {
   a.hashDepth = c->hashDepth.p; a.rowStart = c->rowStart.p; a.rows = c->rows.p; a.nBlocks = c->nBlocks; a.threshold = threshold;
   a.codeBase = c->sharded ? c->codeBase : 0; a.nBlocksFirst = nGlobal;
   a.maxGood = c->maxGood; a.stats = stats.p;
+  DevBuf<u32> overflow; H10X_HIP(c, overflow.alloc((size_t)span + 1));
+  a.firstCap = firstCap; a.overflow = overflow.p + 1; a.overflowCount = overflow.p; H10X_HIP(c, hipMemsetAsync(overflow.p, 0, 4, st));
   DevBuf<u64> phase;
   if (c->optStamps) { H10X_HIP(c, phase.alloc(8)); H10X_HIP(c, hipMemsetAsync(phase.p, 0, 64, st)); a.phase = phase.p; }
   // HBM working set per workgroup (class 3): first[] + per-rank arrays + read-merge tables for the largest barcode
@@ -630,7 +684,7 @@ int stageC_cluster(Ctx *c, int codeMin, int codeMax, int threshold) {
   DevBuf<unsigned char> firstSlots[3];
   const size_t firstStride = (((size_t)nGlobal * 2 + 255) & ~(size_t)255);
   const u32 gridOf[3] = {hmin<u32>(hc[0], (u32)c->numCU * 2), hmin<u32>(hc[1], (u32)c->numCU), hmin<u32>(hc[2], (u32)c->numCU)};
-  if (!firstLds) for (int k = 0; k < 3; ++k) if (hc[k]) {
+  if (firstMode == 2) for (int k = 0; k < 3; ++k) if (hc[k]) {
     H10X_HIP(c, firstSlots[k].alloc(firstStride * gridOf[k]));
     H10X_HIP(c, hipMemsetAsync(firstSlots[k].p, 0xFF, firstStride * gridOf[k], st));
   }
@@ -641,18 +695,21 @@ int stageC_cluster(Ctx *c, int codeMin, int codeMax, int threshold) {
   H10X_TRY(c->forkStreams(3));
   if (hc[3]) {
     ClusterArgs g = a; g.list = list3.p; g.nList = hc[3]; g.workCounter = counts.p + 7; g.scratch = scratch.p; g.scratchStride = stride;
-    cluster_kernel<false, false, CL_THREADS_SMALL><<<grid3, CL_THREADS_SMALL, 0, c->aux[0]>>>(g);
+    cluster_kernel<false, 2, CL_THREADS_SMALL><<<grid3, CL_THREADS_SMALL, 0, c->aux[0]>>>(g);
   }
 #define H10X_LAUNCH_LDS(K, THREADS, BUDGET, STREAM, LIST, CNT)                                                                     \
   if (hc[K]) {                                                                                                                     \
     ClusterArgs g = a; g.list = LIST; g.nList = hc[K]; g.workCounter = counts.p + CNT;                                            \
-    if (firstLds) {                                                                                                                \
-      H10X_HIP(c, hipFuncSetAttribute((const void *)cluster_kernel<true, true, THREADS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(BUDGET))); \
-      cluster_kernel<true, true, THREADS><<<gridOf[K], THREADS, BUDGET, STREAM>>>(g);                                              \
+    if (firstMode == 0) {                                                                                                          \
+      H10X_HIP(c, hipFuncSetAttribute((const void *)cluster_kernel<true, 0, THREADS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(BUDGET))); \
+      cluster_kernel<true, 0, THREADS><<<gridOf[K], THREADS, BUDGET, STREAM>>>(g);                                                 \
+    } else if (firstMode == 1) {                                                                                                   \
+      H10X_HIP(c, hipFuncSetAttribute((const void *)cluster_kernel<true, 1, THREADS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(BUDGET))); \
+      cluster_kernel<true, 1, THREADS><<<gridOf[K], THREADS, BUDGET, STREAM>>>(g);                                                 \
     } else {                                                                                                                       \
       g.scratch = firstSlots[K].p; g.scratchStride = firstStride;                                                                  \
-      H10X_HIP(c, hipFuncSetAttribute((const void *)cluster_kernel<true, false, THREADS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(BUDGET))); \
-      cluster_kernel<true, false, THREADS><<<gridOf[K], THREADS, BUDGET, STREAM>>>(g);                                             \
+      H10X_HIP(c, hipFuncSetAttribute((const void *)cluster_kernel<true, 2, THREADS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(BUDGET))); \
+      cluster_kernel<true, 2, THREADS><<<gridOf[K], THREADS, BUDGET, STREAM>>>(g);                                                 \
     }                                                                                                                              \
   }
   H10X_LAUNCH_LDS(2, CL_THREADS_HUGE, budgetBig, c->aux[1], list2.p, 6)
@@ -661,6 +718,24 @@ int stageC_cluster(Ctx *c, int codeMin, int codeMax, int threshold) {
 #undef H10X_LAUNCH_LDS
   H10X_HIP(c, hipGetLastError());
   H10X_TRY(c->joinStreams(3));
+  u32 nOverflow = 0;
+  DevBuf<unsigned char> scratch2;
+  if (firstMode == 1) {                                      // blocks whose lists touch more barcodes than the ranked first[] holds
+    H10X_HIP(c, hipMemcpyAsync(&nOverflow, overflow.p, 4, hipMemcpyDeviceToHost, st));
+    H10X_HIP(c, hipStreamSynchronize(st));
+    if (nOverflow) {
+      const size_t mergeOff = (workBytes(nGlobal, c->maxGood, CL_THREADS_SMALL / WAVE) + 255) & ~(size_t)255;
+      const size_t stride2 = mergeOff + ((mergeBytes(65536) + 255) & ~(size_t)255);
+      const u32 grid = hmin<u32>(nOverflow, (u32)c->numCU);
+      H10X_HIP(c, scratch2.alloc(stride2 * grid));
+      H10X_HIP(c, hipMemsetAsync(scratch2.p, 0xFF, stride2 * grid, st));
+      H10X_HIP(c, hipMemsetAsync(counts.p + 7, 0, 4, st));
+      ClusterArgs g = a; g.list = overflow.p + 1; g.nList = nOverflow; g.workCounter = counts.p + 7; g.scratch = scratch2.p; g.scratchStride = stride2;
+      g.mergeOffset = mergeOff;
+      cluster_kernel<false, 2, CL_THREADS_SMALL><<<grid, CL_THREADS_SMALL, 0, st>>>(g);
+      H10X_HIP(c, hipGetLastError());
+    }
+  }
   c->tstop(T_CLUSTER_K);
   u64 hs[4];
   H10X_HIP(c, hipMemcpyAsync(hs, stats.p, 32, hipMemcpyDeviceToHost, st));
@@ -668,6 +743,7 @@ int stageC_cluster(Ctx *c, int codeMin, int codeMax, int threshold) {
   c->tstop(T_CLUSTER);
   if (c->optStamps) { H10X_HIP(c, hipMemcpy(c->ctr.cluster_phase_ticks, phase.p, 64, hipMemcpyDeviceToHost)); }
   c->ctr.sum_good = hs[0]; c->ctr.sum_good_depth = hs[1]; c->ctr.sum_hash_clustered = hs[2]; c->ctr.clustered_codes = span;
+  c->ctr.cluster_first_mode = (uint64_t)firstMode; c->ctr.cluster_overflow_blocks = nOverflow;
   c->ctr.cluster_class_counts[0] = hc[0]; c->ctr.cluster_class_counts[1] = hc[1]; c->ctr.cluster_class_counts[2] = hc[2]; c->ctr.cluster_class_counts[3] = hc[3];
   return 0;
 }

@@ -14,6 +14,7 @@ struct h10x_session {
   int k, w, r, B, N, chunk, ct, device;                /* params (hash10x.c:25-33) */
   int timing;                                          /* measurement hook: enable hipEvent timers on every new context */
   int clusterLds;                                      /* test knob forwarded to h10x_set_option("cluster_lds_budget") */
+  int firstCap;                                        /* test knob forwarded to h10x_set_option("cluster_first_cap") */
   int firstGlobal;                                     /* test knob forwarded to h10x_set_option("cluster_first_global") */
   int stamps;                                          /* diagnostic knob forwarded to h10x_set_option("cluster_stamps") */
   int maxSlots;                                        /* test knob forwarded to h10x_set_option("stage_a_max_slots") */
@@ -60,6 +61,7 @@ static int *param_slot(h10x_session *s, const char *n) {
   if (!strcmp(n, "cluster_stamps")) return &s->stamps;
   if (!strcmp(n, "cluster_lds_budget")) return &s->clusterLds;
   if (!strcmp(n, "cluster_first_global")) return &s->firstGlobal;
+  if (!strcmp(n, "cluster_first_cap")) return &s->firstCap;
   return 0;
 }
 int h10x_session_set(h10x_session *s, const char *name, int value) {
@@ -118,6 +120,7 @@ static int apply_options(h10x_session *s) {
   h10x_set_option(s->ctx, "cluster_stamps", s->stamps);
   h10x_set_option(s->ctx, "cluster_lds_budget", s->clusterLds);
   h10x_set_option(s->ctx, "cluster_first_global", s->firstGlobal);
+  h10x_set_option(s->ctx, "cluster_first_cap", s->firstCap);
   if (h10x_set_option(s->ctx, "stage_a_max_slots", s->maxSlots)) return fail_ctx(s);
   return 0;
 }

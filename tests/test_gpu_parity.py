@@ -92,6 +92,19 @@ def test_cluster_hbm_scratch_and_big_lds_paths(workdir, budget):
     assert hf.blocks["nSubCluster"].sum() > 0
 
 
+@pytest.mark.parametrize("cap", [0, 64])
+def test_cluster_ranked_first_table(workdir, cap):
+    """Ranked placement (presence bitmap + popcount prefix, first[] sized by the barcodes present): forced on a small set;
+    cap = 64 makes most blocks overflow into the HBM re-run."""
+    import hash10x_amd
+    orc.gen_fqb(workdir.file("x.fqb"), 60000, 300, 400000, 0.003, 43, 4.0, 150, 6000)
+    opts = dict(cluster_first_global=2)
+    if cap:
+        opts["cluster_first_cap"] = cap
+    hf = _against_oracle(workdir, "x.fqb", ["-ct", 3, "--readFQB", "x.fqb", "--hashDepthRange", 4, 40, "--cluster", 1, 0], **opts)
+    assert hf.blocks["nSubCluster"].sum() > 0
+
+
 def test_cluster_first_table_on_hbm_slots(workdir):
     """Hybrid placement used when the data set has too many barcodes for first[] to sit in LDS: first[] on a
     per-workgroup HBM slot (atomics + L1-bypassing loads), per-rank arrays in LDS."""
