@@ -284,9 +284,11 @@ def have_ref():
 
 
 def run_ref(args, cwd, binary="hash10x", timeout=600):
-    """Run the real reference (oracle/_ref) deterministically: MALLOC_PERTURB_=255 zero-fills fresh
-    allocations."""
-    env = dict(os.environ, MALLOC_PERTURB_="255")
+    """Run the real reference (oracle/_ref) deterministically (ClusterHash.subCluster/flags are never
+    initialised by --readFQB): MALLOC_PERTURB_=255 makes malloc hand out zero-filled memory, and the tcache must be
+    off because chunks recycled through it skip that fill (they come back full of the 0xFF free pattern — seen on
+    barcodes with ~100 hashes in a 10 M-pair run, where codeClusterReadMerge then indexes trueCluster[255])."""
+    env = dict(os.environ, MALLOC_PERTURB_="255", GLIBC_TUNABLES="glibc.malloc.tcache_count=0")
     return subprocess.run([os.path.join(REF_DIR, binary)] + [str(a) for a in args], cwd=cwd, env=env,
                           stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=timeout)
 
