@@ -229,6 +229,68 @@ int h10x_session_clusterSplit(h10x_session *s) {
   return 0;
 }
 
+/* histogramReport (hash10x.c:351-375), same arithmetic (ints and doubles) and text */
+static void histogram_report(FILE *f, const char *prefix, const int *a, int n) {
+  uint64_t sum = 0, total = 0;
+  for (int i = 0; i < n; ++i) { sum += (uint64_t)a[i]; total += (uint64_t)((int64_t)i * a[i]); }
+  uint64_t partSum = 0, partTotal = 0, max = 0, massMax = 0;
+  int median = 0, massMedian = 0, n99 = 0, nMass99 = 0, mode = 0, massMode = 0;
+  int t50 = (int)(sum * 0.5), tMass50 = (int)(total * 0.5), t99 = (int)(sum * 0.99), tMass99 = (int)(total * 0.99);
+  for (int i = 0; i < n; ++i) {
+    int v = a[i];
+    partSum += (uint64_t)v; partTotal += (uint64_t)((int64_t)i * v);
+    fprintf(f, "%s_HIST %6d %d %.4f %.4f\n", prefix, i, v, partSum / (double)sum, partTotal / (double)total);
+    if ((uint64_t)v > max) { mode = i; max = (uint64_t)v; }
+    if ((uint64_t)((int64_t)i * v) > massMax) { massMode = i; massMax = (uint64_t)((int64_t)i * v); }
+    if (partSum > (uint64_t)t50 && !median) median = i;
+    if (partTotal > (uint64_t)tMass50 && !massMedian) massMedian = i;
+    if (partSum > (uint64_t)t99 && !n99) n99 = i;
+    if (partTotal > (uint64_t)tMass99 && !nMass99) nMass99 = i;
+  }
+  fprintf(f, "%s_STATS MEAN %.1f", prefix, total / (double)sum);
+  fprintf(f, "  MODE %d  MEDIAN %d  PERCENT99 %d", mode, median, n99);
+  fprintf(f, "  MASS_MODE %d  N50 %d  N99 %d\n", massMode, massMedian, nMass99);
+}
+static int *hist_grow(int *h, int *cap, int need) {
+  if (need < *cap) return h;
+  int nc = *cap; while (nc <= need) nc *= 2;
+  h = (int *)realloc(h, (size_t)nc * sizeof(int)); memset(h + *cap, 0, (size_t)(nc - *cap) * sizeof(int)); *cap = nc;
+  return h;
+}
+
+int h10x_session_hashStats(h10x_session *s, FILE *f) {         /* hashDepthHist, hash10x.c:377-386 */
+  h10x_sizes z;
+  if (!s->ctx || h10x_get_sizes(s->ctx, &z) || !s->depthMax) { fprintf(stderr, "  no hash list to print stats for\n"); return 0; }
+  uint32_t *depth = (uint32_t *)calloc((size_t)z.hashNumber + 1, 4);
+  if (h10x_export(s->ctx, 0, 0, depth, 0, 0)) { free(depth); return fail_ctx(s); }
+  int cap = 1024, top = 0; int *h = (int *)calloc((size_t)cap, sizeof(int));
+  for (int i = 0; i < s->depthMax; ++i) {                      /* arrayMax(hashDepth) entries, index 0 included */
+    int d = (uint32_t)i < z.hashNumber ? (int)depth[i] : 0;
+    h = hist_grow(h, &cap, d); ++h[d]; if (d + 1 > top) top = d + 1;
+  }
+  histogram_report(f, "HASH_COUNT", h, top);
+  free(h); free(depth);
+  return 0;
+}
+
+int h10x_session_codeStats(h10x_session *s, FILE *f) {         /* codeSizeHist, hash10x.c:388-402 */
+  h10x_sizes z;
+  if (!s->ctx || h10x_get_sizes(s->ctx, &z) || !z.nBlocks) { fprintf(stderr, "  no barcodes to print stats for\n"); return 0; }
+  h10x_block *b = (h10x_block *)calloc((size_t)z.nBlocks, sizeof *b);
+  if (h10x_export(s->ctx, 0, 0, 0, b, 0)) { free(b); return fail_ctx(s); }
+  int capH = 1024, capC = 1024, topH = 0, topC = 0;
+  int *hh = (int *)calloc((size_t)capH, sizeof(int)), *hc = (int *)calloc((size_t)capC, sizeof(int));
+  for (uint32_t i = 0; i < z.nBlocks; ++i) {
+    int nh = (int)b[i].nHash, ns = (int)b[i].nSubCluster;
+    hh = hist_grow(hh, &capH, nh); ++hh[nh]; if (nh + 1 > topH) topH = nh + 1;
+    hc = hist_grow(hc, &capC, ns); ++hc[ns]; if (ns + 1 > topC) topC = ns + 1;
+  }
+  histogram_report(f, "CODE_SIZE", hh, topH);
+  if (topC > 1) histogram_report(f, "CODE_CLUSTER", hc, topC);
+  free(hh); free(hc); free(b);
+  return 0;
+}
+
 /* writeHashFile (hash10x.c:244-267) + arrayWrite (array.c:213-218); heap-pointer fields are written as 0 */
 int h10x_session_writeHash(h10x_session *s, const char *path) {
   if (!s->ctx) return fail(s, "no hash state loaded: use readFQB or readHash first");

@@ -9,6 +9,7 @@
 #ifndef H10X_HOST_H
 #define H10X_HOST_H
 #include <stdint.h>
+#include <stdio.h>
 #include "../../include/h10x.h"
 
 #ifdef __cplusplus
@@ -34,6 +35,12 @@ int  h10x_session_writeHash(h10x_session *s, const char *path);                 
 int  h10x_session_hashDepthRange(h10x_session *s, int min, int max);                  /* hash10x.c:1216-1219 */
 int  h10x_session_cluster(h10x_session *s, int codeMin, int codeMax);                 /* hash10x.c:1241-1261 */
 int  h10x_session_clusterSplit(h10x_session *s);                                      /* hash10x.c:1267 */
+
+/* --hashStats / --codeStats (hash10x.c:351-402): the reference's histogram reports, printed to f from host copies
+   of hashDepth / clusterBlocks (cheap host loops; same text as the reference, including its Array dim: hashDepth is
+   histogrammed over arrayMax entries, index 0 included) */
+int  h10x_session_hashStats(h10x_session *s, FILE *f);
+int  h10x_session_codeStats(h10x_session *s, FILE *f);
 
 /* multi-GPU (include/h10x.h "multi-GPU"): this rank's contiguous barcode range of the sorted file, cut with
    h10x_host_partition; -N and the chunkSize check are the launcher's business here. After shardGather rank 0's

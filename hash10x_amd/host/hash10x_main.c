@@ -60,6 +60,8 @@ static void usage(h10x_session *s) {
   fprintf(stderr, "   --hashDepthRange <min> <max>: set limits for hash counts for cluster\n");
   fprintf(stderr, "   --cluster <codeMin> <codeMax>: cluster reads for range of barcodes (1, 0 for all)\n");
   fprintf(stderr, "   --clusterSplit\n");
+  fprintf(stderr, "   --hashStats : distribution of hash counts and summary info\n");
+  fprintf(stderr, "   --codeStats : distribution of barcode/cluster sizes and summary info\n");
   fprintf(stderr, "   --help : print this usage message\n");
 }
 
@@ -141,6 +143,8 @@ int main(int argc, char **argv) {
       }
     }
     else if (ARGMATCH("--clusterSplit", 1)) { if (h10x_session_clusterSplit(s)) die("%s", h10x_session_error(s)); }
+    else if (ARGMATCH("--hashStats", 1)) { if (h10x_session_hashStats(s, outFile)) die("%s", h10x_session_error(s)); }
+    else if (ARGMATCH("--codeStats", 1)) { if (h10x_session_codeStats(s, outFile)) die("%s", h10x_session_error(s)); }
     else if (ARGMATCH("--help", 1)) usage(s);
     else if (ARGMATCH("--quit", 1) || ARGMATCH("--exit", 1)) break;
     else die("unknown option/command %s; run without arguments for usage", *argv);

@@ -266,3 +266,28 @@ def test_rccl_communicator_single_rank(workdir):
     got = open(workdir.file("hip.hash"), "rb").read()
     exp = orc.read_maybe_gz(os.path.join(orc.GOLDEN, "small.e2e.hash.gz"))
     assert got == exp, orc.describe_diff(got, exp)
+
+
+@pytest.mark.skipif(not orc.have_ref(), reason="oracle/_ref not present")
+def test_cli_matches_reference_commands_and_reports(workdir):
+    """bin/hash10x-amd (C host program) against the reference binary on the same command line: identical .hash bytes and
+    identical --hashStats / --codeStats report lines."""
+    import subprocess
+    orc.gen_fqb(workdir.file("x.fqb"), 30000, 150, 300000, 0.003, 41, 4.0, 150, 6000)
+    args = ["-B", "20", "-ct", "3", "--readFQB", "x.fqb", "--hashStats", "--hashDepthRange", "4", "30", "--cluster", "1", "0", "--codeStats",
+            "--writeHash", "OUT"]
+    r = orc.run_ref([a if a != "OUT" else "ref.hash" for a in args], workdir.path)
+    assert r.returncode == 0, r.stderr.decode()
+    g = subprocess.run([os.path.join(orc.REPO, "bin", "hash10x-amd")] + [a if a != "OUT" else "hip.hash" for a in args], cwd=workdir.path,
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert g.returncode == 0, g.stderr.decode()
+    exp = orc.canonical_hash_bytes(open(workdir.file("ref.hash"), "rb").read())
+    got = open(workdir.file("hip.hash"), "rb").read()
+    assert got == exp, orc.describe_diff(got, exp)
+
+    def report(txt):
+        return [ln for ln in txt.decode().splitlines() if ln.startswith(("HASH_COUNT_", "CODE_SIZE_", "CODE_CLUSTER_"))]
+    assert report(g.stdout) == report(r.stdout) and len(report(g.stdout)) > 50
+    # die() conditions of the command line
+    bad = subprocess.run([os.path.join(orc.REPO, "bin", "hash10x-amd"), "-B", "19", "--readFQB", "x.fqb"], cwd=workdir.path, stderr=subprocess.PIPE, stdout=subprocess.PIPE)
+    assert bad.returncode == 255 and b"FATAL ERROR: hashTableBits 19 out of range 20-30" in bad.stderr
