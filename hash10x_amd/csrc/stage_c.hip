@@ -16,9 +16,10 @@
 //   (c) one lane replays the order-dependent part (cluster creation, > 255 abort, labels)
 //   (d) per rank i  : the count for the cluster's founding rank (a second gather only when it is not
 //                     msBest) and the IEEE double quotient
-//   (e) one lane adds the quotients in rank order => bit-identical pointToMin
-//   (f) read merge : connected components over <= 255 labels linked by shared reads, renumbered by
-//                     ascending minimum label.
+//   (e) point_sum_kernel: one LANE per barcode adds the quotients in rank order => bit-identical pointToMin
+//       (a serial fp64 chain per barcode: 64 barcodes per wave instruction instead of one)
+//   (f) read_merge_kernel: connected components over <= 255 labels linked by shared reads, renumbered by
+//       ascending minimum label — small workgroups of its own, not 1024 lanes waiting on 255 labels.
 // Barcodes whose working set exceeds the LDS budget run the same code on a per-workgroup HBM scratch.
 #include "common.hpp"
 #include "prim.hpp"
@@ -26,11 +27,15 @@
 
 namespace h10x {
 
-constexpr int CL_THREADS_SMALL = 1024;                     // 64 KB working sets, two workgroups per CU
-constexpr int CL_THREADS_BIG = 1024;                       // up to the whole LDS of a CU, one workgroup per CU
-constexpr int CL_THREADS_HUGE = 512;                       // same LDS with half the waves: per-wave histograms cost 8 instead of 16 B per rank
+constexpr int CL_THREADS_SMALL = 1024;                     // <= 79 KB working sets, two workgroups per CU
+constexpr int CL_THREADS_BIG = 512;                        // same LDS with half the waves (per-wave histograms cost 8 instead of 16 B per rank):
+                                                           // more ranks fit, and such a workgroup still shares a CU with one of either kind
+constexpr int CL_THREADS_HUGE = 512;                       // the whole LDS of a CU, one workgroup per CU
 constexpr u16 NONE16 = 0xFFFF;
-constexpr int ROWS_IN_FLIGHT = 4;                          // barcode lists a wavefront keeps in flight
+#ifndef H10X_RIF
+#define H10X_RIF 4
+#endif
+constexpr int ROWS_IN_FLIGHT = H10X_RIF;                          // barcode lists a wavefront keeps in flight
 constexpr int RCHUNK = 4;                                   // register chunks: lists up to 256 entries
 
 // ------------------------------------------------------------------------------------------ depth range
@@ -135,54 +140,56 @@ struct ClusterArgs {
   u32 firstCap;                                             // ranked placement: first[] entries available (barcodes present in a block)
   u32 *overflow, *overflowCount;                            // ranked placement: blocks with more present barcodes than firstCap
   unsigned char *scratch; size_t scratchStride;             // global-mode working set per workgroup
-  size_t mergeOffset;                                       // global mode: read-merge tables live behind the rank arrays
   u32 maxGood;
+  double *term;                                             // per rank (slice of block c at blockOff[c]): its pointToMin term, 0.0 if none
   u64 *stats;                                               // [0] sum good, [1] sum good depth, [2] sum nHash, [3] codes
   u64 *phase;                                               // diagnostic per-phase ticks (null = off)
 };
 
-struct PairCT { u32 cnt, tot; };                            // overwritten by the double quotient in phase (d)
-
-// working set layout inside a region (LDS or HBM scratch)
-struct Work {
+// working set layout inside a region (LDS or HBM scratch). CT = type of the per-rank counts and list lengths:
+// u16 in the LDS instantiations (the driver sends every barcode to the HBM-scratch class when a list of the
+// depth range is longer than 65535), u32 on the HBM scratch.
+template <typename CT> struct Work {
   u16 *first;        // NONE16 = unseen; indexed by barcode (dense) or by the barcode's rank among those present (ranked)
   u32 *bm, *pre;     // ranked placement: presence bitmap over all barcodes and its exclusive popcount prefix per word
-  PairCT *ct;        // msMax / msTot per rank, later the quotient (as double)
   u32 *rs;           // offset of the rank's barcode list in rows[] (prefetched once)
-  u32 *dd;           // its length (hashDepth)
+  CT  *dd;           // its length (hashDepth)
+  CT  *cnt, *tot;    // msMax / msTot per rank; cnt later holds minShareCount[clusterMin] (phase d)
   u16 *best;         // msBest per rank
   u16 *qj;           // founding rank of the cluster the rank joins (NONE16 = no term)
   u8  *lab;          // label per rank
   u32 *hist;         // CL_WAVES private byte-histograms over ranks (4 counters per word), all zero between lists
   u32 histWords;     // words per wave
 };
-__host__ __device__ inline size_t workBytes(u32 nFirst, u32 n, u32 nWaves, u32 bmWords = 0) {
+__host__ __device__ inline size_t workBytes(u32 nFirst, u32 n, u32 nWaves, u32 bmWords, u32 ctBytes) {
   size_t b = (((size_t)nFirst * 2 + 15) & ~(size_t)15) + (size_t)bmWords * 8;
-  b += (size_t)n * 8;                                       // ct (8-byte aligned first)
-  b += (size_t)n * 4 * 2;                                   // rs, dd
-  b += (size_t)n * 2 * 2;                                   // best, qj
+  b += (size_t)n * 4;                                       // rs
+  b += (((size_t)n * ctBytes + 3) & ~(size_t)3) * 3;        // dd, cnt, tot
+  b += (((size_t)n * 2 + 3) & ~(size_t)3) * 2;              // best, qj
   b += ((size_t)n + 15) & ~(size_t)15;                      // lab
-  b += (size_t)nWaves * (((size_t)n + 3) / 4) * 4;          // hist
+  b += (size_t)nWaves * (((size_t)n + 3) / 4) * 4;          // hist (the replay's temporaries, 4 n + 8 bytes, overlay it: nWaves >= 8)
   return b + 16;
 }
-__device__ inline Work carve(unsigned char *base, u32 nFirst, u32 n, u32 bmWords = 0) {
-  Work w; size_t o = 0;
+template <typename CT>
+__device__ inline Work<CT> carve(unsigned char *base, u32 nFirst, u32 n, u32 bmWords = 0) {
+  Work<CT> w; size_t o = 0;
+  const size_t ctb = ((size_t)n * sizeof(CT) + 3) & ~(size_t)3, b2 = ((size_t)n * 2 + 3) & ~(size_t)3;
   w.first = (u16 *)(base + o); o += (((size_t)nFirst * 2 + 15) & ~(size_t)15);
   w.bm = (u32 *)(base + o); o += (size_t)bmWords * 4;
   w.pre = (u32 *)(base + o); o += (size_t)bmWords * 4;
-  w.ct = (PairCT *)(base + o); o += (size_t)n * 8;
   w.rs = (u32 *)(base + o); o += (size_t)n * 4;
-  w.dd = (u32 *)(base + o); o += (size_t)n * 4;
-  w.best = (u16 *)(base + o); o += (size_t)n * 2;
-  w.qj = (u16 *)(base + o); o += (size_t)n * 2;
+  w.dd = (CT *)(base + o); o += ctb;
+  w.cnt = (CT *)(base + o); o += ctb;
+  w.tot = (CT *)(base + o); o += ctb;
+  w.best = (u16 *)(base + o); o += b2;
+  w.qj = (u16 *)(base + o); o += b2;
   w.lab = (u8 *)(base + o); o += ((size_t)n + 15) & ~(size_t)15;
   w.hist = (u32 *)(base + o); w.histWords = (n + 3) / 4;
   return w;
 }
-// read-merge working set: readRep[min(nRead,65536)] bytes, adj[256][8] u32, comp[256] u32, newLab[512] u32
-__host__ __device__ inline size_t mergeBytes(u32 nRead) {
-  const size_t r = nRead < 65536u ? nRead : 65536u;
-  return ((r + 15) & ~(size_t)15) + 256 * 8 * 4 + 256 * 4 + 512 * 4 + 16;
+// read-merge working set: readRep[nRep] bytes, adj[256][8] u32, comp[256] u32, newLab[512] u32
+__host__ __device__ inline size_t mergeBytes(u32 nRep) {
+  return (((size_t)nRep + 15) & ~(size_t)15) + 256 * 8 * 4 + 256 * 4 + 512 * 4 + 16;
 }
 
 // Loads of words that other waves of the workgroup modify with ATOMICS. Atomics on global memory execute in
@@ -237,7 +244,7 @@ __device__ __forceinline__ u32 wave_max_u32(u32 v) {
 // one LDS round trip for the gather, one for the atomics. Lists with fewer usable entries than the
 // threshold are skipped (only "msMax < threshold" matters to the caller then).
 template <bool IN_LDS, bool FIRST_LDS, int RCHUNK, typename FM>
-__device__ __forceinline__ void row_mode_hist(const u32 *__restrict__ row, u32 cj0, u32 d, u32 code, u32 i, const u16 *first, const FM &fm, u32 *hist,
+__device__ __forceinline__ void row_mode_hist(const u32 *__restrict__ row, u32 cj0, u32 cj1, u32 d, u32 code, u32 i, const u16 *first, const FM &fm, u32 *hist,
                                               u32 thr, u32 &best, u32 &bcnt, u32 &tot) {
   const int lane = threadIdx.x & (WAVE - 1);
   u32 f[RCHUNK]; bool ok[RCHUNK];
@@ -247,7 +254,7 @@ __device__ __forceinline__ void row_mode_hist(const u32 *__restrict__ row, u32 c
     f[r] = NONE16; ok[r] = false;
     if ((u32)(r * WAVE) < d) {
       const u32 j = r * WAVE + lane;
-      if (j < d) { const u32 cj = r == 0 ? cj0 : row[j]; if (cj != code) { f[r] = ld_shared<FIRST_LDS>(&first[fm(cj)]); ok[r] = f[r] < i; } }
+      if (j < d) { const u32 cj = r == 0 ? cj0 : (r == 1 ? cj1 : row[j]); if (cj != code) { f[r] = ld_shared<FIRST_LDS>(&first[fm(cj)]); ok[r] = f[r] < i; } }
       tot += (u32)__popcll(__ballot(ok[r]));
     }
   }
@@ -310,15 +317,16 @@ __device__ void row_mode_long(const u32 *__restrict__ row, u32 d, u32 code, u32 
 template <bool IN_LDS, int FIRST_MODE /* 0 dense in LDS, 1 ranked in LDS, 2 dense on an HBM slot */, int CL_THREADS>
 __device__ void cluster_one_block(const ClusterArgs &a, u32 code, unsigned char *region, u16 *firstGlobal, u32 *sh /* small shared ints */) {   // code: local block number
   constexpr int CL_WAVES = CL_THREADS / WAVE;
+  typedef typename std::conditional<IN_LDS, u16, u32>::type CT;
   const int tid = threadIdx.x, lane = tid & (WAVE - 1), wave = tid / WAVE;
   const u32 n = a.nGood[code];
   if (n == 0) return;                                        // hash10x.c:780: block left untouched
   const u64 o = a.blockOff[code];
-  const u32 nHash = a.blocks[code].nHash, nRead = a.blocks[code].nRead;
+  const u32 nHash = a.blocks[code].nHash;
   constexpr bool FIRST_LDS = IN_LDS && FIRST_MODE != 2;
   constexpr bool RANKED = IN_LDS && FIRST_MODE == 1;
   const u32 bmWords = RANKED ? (a.nBlocksFirst + 31) / 32 : 0;
-  Work w = carve(region, RANKED ? a.firstCap : (FIRST_LDS || !IN_LDS ? a.nBlocksFirst : 0), n, bmWords);
+  Work<CT> w = carve<CT>(region, RANKED ? a.firstCap : (FIRST_LDS || !IN_LDS ? a.nBlocksFirst : 0), n, bmWords);
   if (IN_LDS && FIRST_MODE == 2) w.first = firstGlobal;      // hybrid: first[] on this workgroup's HBM slot, the rest in LDS
   typename std::conditional<RANKED, MapRanked, MapDense>::type fm{};
   if constexpr (RANKED) { fm.bm = w.bm; fm.pre = w.pre; }
@@ -333,8 +341,8 @@ __device__ void cluster_one_block(const ClusterArgs &a, u32 code, unsigned char 
   u64 myDepth = 0;
   for (u32 i = tid; i < n; i += CL_THREADS) {
     const u32 x = ch[g[i]].hash; const u32 d = a.hashDepth[x];
-    w.rs[i] = (u32)a.rowStart[x]; w.dd[i] = d; w.lab[i] = 0; w.qj[i] = NONE16; w.best[i] = NONE16;
-    w.ct[i].cnt = 0; w.ct[i].tot = 0; myDepth += d;
+    w.rs[i] = (u32)a.rowStart[x]; w.dd[i] = (CT)d; w.lab[i] = 0; w.qj[i] = NONE16; w.best[i] = NONE16;
+    w.cnt[i] = 0; w.tot[i] = 0; myDepth += d;
   }
   SYNC();
   if constexpr (RANKED) {
@@ -373,27 +381,28 @@ __device__ void cluster_one_block(const ClusterArgs &a, u32 code, unsigned char 
   // offer larger ranks), so one barrier per round is enough.
   // The lists of round r+1 are requested before round r is processed, so their HBM latency hides behind the
   // CAS-min / barrier / mode work of round r.
-  u32 cjN[ROWS_IN_FLIGHT], dlN[ROWS_IN_FLIGHT];
-#pragma unroll
-  for (int t = 0; t < ROWS_IN_FLIGHT; ++t) {
-    const u32 i = 1 + wave * ROWS_IN_FLIGHT + t; dlN[t] = i < n ? w.dd[i] : 0;
-    cjN[t] = (u32)lane < dlN[t] ? a.rows[w.rs[i] + lane] : code;
+  // A wave keeps the first two chunks (128 entries) of each of its lists in registers; longer lists re-read the rest.
+  u32 cjN[ROWS_IN_FLIGHT], cj2N[ROWS_IN_FLIGHT], dlN[ROWS_IN_FLIGHT];
+#define H10X_LOAD_AB(I0)                                                                                      \
+  _Pragma("unroll") for (int t = 0; t < ROWS_IN_FLIGHT; ++t) {                                                \
+    const u32 i = (I0) + t; dlN[t] = i < n ? (u32)w.dd[i] : 0; const u32 *row = a.rows + w.rs[i < n ? i : n - 1]; \
+    cjN[t] = (u32)lane < dlN[t] ? row[lane] : code; cj2N[t] = (u32)(WAVE + lane) < dlN[t] ? row[WAVE + lane] : code; \
   }
+  H10X_LOAD_AB(1 + wave * ROWS_IN_FLIGHT)
   for (u32 r0 = 1; r0 < n; r0 += CL_WAVES * ROWS_IN_FLIGHT) {
     const u32 i0 = r0 + wave * ROWS_IN_FLIGHT;
-    u32 cj[ROWS_IN_FLIGHT], dl[ROWS_IN_FLIGHT];
+    u32 cj[ROWS_IN_FLIGHT], cj2[ROWS_IN_FLIGHT], dl[ROWS_IN_FLIGHT];
 #pragma unroll
-    for (int t = 0; t < ROWS_IN_FLIGHT; ++t) { cj[t] = cjN[t]; dl[t] = dlN[t]; }
-#pragma unroll
-    for (int t = 0; t < ROWS_IN_FLIGHT; ++t) {
-      const u32 i = i0 + CL_WAVES * ROWS_IN_FLIGHT + t; dlN[t] = i < n ? w.dd[i] : 0;
-      cjN[t] = (u32)lane < dlN[t] ? a.rows[w.rs[i] + lane] : code;
-    }
+    for (int t = 0; t < ROWS_IN_FLIGHT; ++t) { cj[t] = cjN[t]; cj2[t] = cj2N[t]; dl[t] = dlN[t]; }
+    H10X_LOAD_AB(i0 + CL_WAVES * ROWS_IN_FLIGHT)
 #pragma unroll
     for (int t = 0; t < ROWS_IN_FLIGHT; ++t) {
       const u32 i = i0 + t;
       if (cj[t] != code) min_u16<FIRST_LDS>(w.first, fm(cj[t]), i);
-      if (dl[t] > WAVE) { const u32 *row = a.rows + w.rs[i]; for (u32 j = WAVE + lane; j < dl[t]; j += WAVE) { const u32 c2 = row[j]; if (c2 != code) min_u16<FIRST_LDS>(w.first, fm(c2), i); } }
+      if (dl[t] > WAVE) {
+        if (cj2[t] != code) min_u16<FIRST_LDS>(w.first, fm(cj2[t]), i);
+        if (dl[t] > 2 * WAVE) { const u32 *row = a.rows + w.rs[i]; for (u32 j = 2 * WAVE + lane; j < dl[t]; j += WAVE) { const u32 c2 = row[j]; if (c2 != code) min_u16<FIRST_LDS>(w.first, fm(c2), i); } }
+      }
     }
     SYNC_LDS();
 #pragma unroll
@@ -402,13 +411,15 @@ __device__ void cluster_one_block(const ClusterArgs &a, u32 code, unsigned char 
       if (i < n) {
         const u32 d = dl[t]; const u32 *row = a.rows + w.rs[i];
         u32 best, bcnt, tot;
-        if (d <= WAVE) row_mode_hist<IN_LDS, FIRST_LDS, 1>(row, cj[t], d, code, i, w.first, fm, w.hist + wave * w.histWords, (u32)a.threshold, best, bcnt, tot);
-        else if (d < RCHUNK * WAVE) row_mode_hist<IN_LDS, FIRST_LDS, RCHUNK>(row, cj[t], d, code, i, w.first, fm, w.hist + wave * w.histWords, (u32)a.threshold, best, bcnt, tot);
+        if (d <= WAVE) row_mode_hist<IN_LDS, FIRST_LDS, 1>(row, cj[t], code, d, code, i, w.first, fm, w.hist + wave * w.histWords, (u32)a.threshold, best, bcnt, tot);
+        else if (d <= 2 * WAVE) row_mode_hist<IN_LDS, FIRST_LDS, 2>(row, cj[t], cj2[t], d, code, i, w.first, fm, w.hist + wave * w.histWords, (u32)a.threshold, best, bcnt, tot);
+        else if (d < RCHUNK * WAVE) row_mode_hist<IN_LDS, FIRST_LDS, RCHUNK>(row, cj[t], cj2[t], d, code, i, w.first, fm, w.hist + wave * w.histWords, (u32)a.threshold, best, bcnt, tot);
         else row_mode_long<FIRST_LDS>(row, d, code, i, w.first, fm, best, bcnt, tot);
-        if (lane == 0) { w.best[i] = (u16)best; w.ct[i].cnt = bcnt; w.ct[i].tot = tot; }
+        if (lane == 0) { w.best[i] = (u16)best; w.cnt[i] = (CT)bcnt; w.tot[i] = (CT)tot; }
       }
     }
   }
+#undef H10X_LOAD_AB
   STAMP(1);
   SYNC();
   STAMP(2);
@@ -424,14 +435,14 @@ __device__ void cluster_one_block(const ClusterArgs &a, u32 code, unsigned char 
     u16 *ft = (u16 *)w.hist;                                 // founding turn of each inactive rank (NONE16 = never)
     u16 *fl = ft + ((n + 2) & ~1u);                          // 1 at founding turns -> inclusive scan = cluster number
     for (u32 i = tid; i < n; i += CL_THREADS) {
-      const bool act = i >= 1 && (int)w.ct[i].cnt >= a.threshold;
+      const bool act = i >= 1 && (int)w.cnt[i] >= a.threshold;
       ptr[i] = act ? w.best[i] : (u16)i; ft[i] = NONE16; fl[i] = 0;
     }
     SYNC();
     for (u32 i = tid; i < n; i += CL_THREADS)
-      if (i >= 1 && (int)w.ct[i].cnt >= a.threshold) {
+      if (i >= 1 && (int)w.cnt[i] >= a.threshold) {
         const u32 b = w.best[i];
-        if (!(b >= 1 && (int)w.ct[b].cnt >= a.threshold)) min_u16<IN_LDS>(ft, b, i);
+        if (!(b >= 1 && (int)w.cnt[b] >= a.threshold)) min_u16<IN_LDS>(ft, b, i);
       }
     u32 rounds = 1; while ((1u << rounds) < n) ++rounds;
     for (u32 r = 0; r <= rounds; ++r) {                      // chains only run downwards: in-place jumping converges
@@ -459,12 +470,12 @@ __device__ void cluster_one_block(const ClusterArgs &a, u32 code, unsigned char 
       for (u32 i = tid; i < n; i += CL_THREADS) {
         if (fl[i] == 256 && (i == 0 || fl[i - 1] == 255)) { sh[0] = 0; sh[1] = i; }
         w.lab[i] = 0;
-        if (!(i >= 1 && (int)w.ct[i].cnt >= a.threshold)) ptr[i] = NONE16;
+        if (!(i >= 1 && (int)w.cnt[i] >= a.threshold)) ptr[i] = NONE16;
       }
     } else {
       if (tid == 0) { sh[0] = nRoots; sh[1] = n; }
       for (u32 i = tid; i < n; i += CL_THREADS) {
-        const bool act = i >= 1 && (int)w.ct[i].cnt >= a.threshold;
+        const bool act = i >= 1 && (int)w.cnt[i] >= a.threshold;
         u32 L = 0;
         if (act) L = fl[ld_shared<IN_LDS>(&ft[ptr[i]])];
         else { const u32 t = ld_shared<IN_LDS>(&ft[i]); if (t != NONE16) L = fl[t]; ptr[i] = NONE16; }
@@ -476,52 +487,47 @@ __device__ void cluster_one_block(const ClusterArgs &a, u32 code, unsigned char 
   const u32 nSub = sh[0], stop = sh[1];
   STAMP(3);
 
-  // ---- (d) minShareCount[clusterMin[label]] / (double) msTot per rank (hash10x.c:821); the list is re-read only
-  // when the cluster's founder is not msBest, ROWS_IN_FLIGHT lists at a time
-  for (u32 i0 = 1 + wave * ROWS_IN_FLIGHT; i0 < stop; i0 += CL_WAVES * ROWS_IN_FLIGHT) {
-    u32 cj[ROWS_IN_FLIGHT], dl[ROWS_IN_FLIGHT], qv[ROWS_IN_FLIGHT];
-#pragma unroll
-    for (int t = 0; t < ROWS_IN_FLIGHT; ++t) {
-      const u32 i = i0 + t; qv[t] = i < stop ? (u32)w.qj[i] : NONE16;
-      const bool need = qv[t] != NONE16 && qv[t] != w.best[i];
-      dl[t] = need ? w.dd[i] : 0;
-      cj[t] = (u32)lane < dl[t] ? a.rows[w.rs[i] + lane] : code;
+  // ---- (d) minShareCount[clusterMin[label]] per rank (hash10x.c:821) into cnt[]; the list is re-read only when the
+  // cluster's founder is not msBest, ROWS_IN_FLIGHT lists at a time, the next group's lists already in flight
+  {
+    u32 cjN2[ROWS_IN_FLIGHT], dlN2[ROWS_IN_FLIGHT], qvN[ROWS_IN_FLIGHT];
+#define H10X_LOAD_D(I0, CJ, DL, QV)                                                                        \
+    _Pragma("unroll") for (int t = 0; t < ROWS_IN_FLIGHT; ++t) {                                           \
+      const u32 i = (I0) + t; QV[t] = i < stop ? (u32)w.qj[i] : NONE16;                                    \
+      const bool need = QV[t] != NONE16 && QV[t] != w.best[i];                                             \
+      DL[t] = need ? (u32)w.dd[i] : 0;                                                                     \
+      CJ[t] = (u32)lane < DL[t] ? a.rows[w.rs[i] + lane] : code;                                           \
     }
+    H10X_LOAD_D(1 + wave * ROWS_IN_FLIGHT, cjN2, dlN2, qvN)
+    for (u32 i0 = 1 + wave * ROWS_IN_FLIGHT; i0 < stop; i0 += CL_WAVES * ROWS_IN_FLIGHT) {
+      u32 cj[ROWS_IN_FLIGHT], dl[ROWS_IN_FLIGHT], qv[ROWS_IN_FLIGHT];
 #pragma unroll
-    for (int t = 0; t < ROWS_IN_FLIGHT; ++t) {
-      const u32 i = i0 + t;
-      if (qv[t] == NONE16) continue;
-      u32 q;
-      if (dl[t] == 0) q = w.ct[i].cnt;
-      else {
-        q = (u32)__popcll(__ballot(cj[t] != code && ld_shared<FIRST_LDS>(&w.first[fm(cj[t])]) == qv[t]));
+      for (int t = 0; t < ROWS_IN_FLIGHT; ++t) { cj[t] = cjN2[t]; dl[t] = dlN2[t]; qv[t] = qvN[t]; }
+      H10X_LOAD_D(i0 + CL_WAVES * ROWS_IN_FLIGHT, cjN2, dlN2, qvN)
+#pragma unroll
+      for (int t = 0; t < ROWS_IN_FLIGHT; ++t) {
+        const u32 i = i0 + t;
+        if (qv[t] == NONE16 || dl[t] == 0) continue;         // no term, or founder == msBest: cnt[i] already holds the count
+        u32 q = (u32)__popcll(__ballot(cj[t] != code && ld_shared<FIRST_LDS>(&w.first[fm(cj[t])]) == qv[t]));
         if (dl[t] > WAVE) { const u32 *row = a.rows + w.rs[i]; for (u32 b0 = WAVE; b0 < dl[t]; b0 += WAVE) { bool m = false; if (b0 + lane < dl[t]) { const u32 c2 = row[b0 + lane]; m = c2 != code && ld_shared<FIRST_LDS>(&w.first[fm(c2)]) == qv[t]; } q += (u32)__popcll(__ballot(m)); } }
+        if (lane == 0) w.cnt[i] = (CT)q;
       }
-      if (lane == 0) { const double tq = (double)(int)q / (double)(int)w.ct[i].tot; *(double *)&w.ct[i] = tq; }
     }
+#undef H10X_LOAD_D
   }
   SYNC();
   STAMP(4);
 
-  // ---- (e) ordered fp64 sum (wavefront 0: 64 quotients per LDS read, added in rank order via readlane), labels out
-  if (wave == 0) {
-    double p = 0.0;
-    for (u32 base = 0; base < stop; base += WAVE) {
-      const u32 il = base + lane;
-      const bool has = il >= 1 && il < stop && w.qj[il] != NONE16;
-      const double t = has ? *(const double *)&w.ct[il] : 0.0;
-      const int tlo = (int)(u32)__double_as_longlong(t), thi = (int)(u32)((u64)__double_as_longlong(t) >> 32);
-      if (__ballot(has)) {
-#pragma unroll
-        for (int j = 0; j < WAVE; ++j) {                     // + 0.0 for ranks without a term is exact (p >= +0)
-          const u64 bits = ((u64)(u32)__builtin_amdgcn_readlane(thi, j) << 32) | (u64)(u32)__builtin_amdgcn_readlane(tlo, j);
-          p += __longlong_as_double((long long)bits);
-        }
-      }
-    }
-    if (lane == 0) { a.blocks[lcode].pointToMin = p; a.blocks[lcode].nSubCluster = nSub; }
+  // ---- out: the pointToMin term of every rank (IEEE double quotient; 0.0 where the reference adds nothing — adding
+  // +0.0 is exact), labels (includes the wipe of hash10x.c:783), the raw cluster count. point_sum_kernel and
+  // read_merge_kernel finish the block.
+  double *term = a.term + o;
+  for (u32 i = tid; i < n; i += CL_THREADS) {
+    const bool has = i >= 1 && i < stop && w.qj[i] != NONE16;
+    term[i] = has ? (double)(int)w.cnt[i] / (double)(int)w.tot[i] : 0.0;
+    ch[g[i]].subCluster = w.lab[i];
   }
-  for (u32 i = tid; i < n; i += CL_THREADS) ch[g[i]].subCluster = w.lab[i];     // includes the wipe of hash10x.c:783
+  if (tid == 0) a.blocks[lcode].nSubCluster = nSub;
   // wave-reduce the per-thread depth sums for the work counters
   for (int s = 32; s; s >>= 1) myDepth += __shfl_down(myDepth, s);
   if (lane == 0) atomicAdd((u64 *)&a.stats[1], (u64)myDepth);
@@ -535,67 +541,19 @@ __device__ void cluster_one_block(const ClusterArgs &a, u32 code, unsigned char 
   }
   SYNC();
   STAMP(5);
-  if (!nSub) return;                                         // hash10x.c:840
-
-  // ---- (f) codeClusterReadMerge (hash10x.c:837-868): components of labels that share a read
-  const u32 nRep = nRead < 65536u ? nRead : 65536u;
-  unsigned char *mregion = IN_LDS ? region : region + a.mergeOffset;   // LDS: the rank arrays are dead by now
-  u8 *readRep = (u8 *)mregion;
-  u32 *adj = (u32 *)(mregion + ((nRep + 15) & ~15u));
-  u32 *comp = adj + 256 * 8, *newLab = comp + 256;
-  for (u32 i = tid; i < (nRep + 3) / 4; i += CL_THREADS) ((u32 *)readRep)[i] = 0;
-  for (u32 i = tid; i < 256 * 8; i += CL_THREADS) adj[i] = 0;
-  if (tid < 256) comp[tid] = tid;
-  __threadfence_block();
-  SYNC();
-  for (u32 p = tid; p < nHash; p += CL_THREADS) {            // any one label of each read is its representative
-    const h10x_clushash e = ch[p];
-    if (e.subCluster && e.subCluster <= nSub && e.read < nRep) readRep[e.read] = e.subCluster;
-  }
-  SYNC();
-  for (u32 p = tid; p < nHash; p += CL_THREADS) {
-    const h10x_clushash e = ch[p];
-    if (e.subCluster && e.subCluster <= nSub && e.read < nRep) {
-      const u32 L = e.subCluster, R = readRep[e.read];
-      if (R != L) { atomicOr(&adj[L * 8 + (R >> 5)], 1u << (R & 31)); atomicOr(&adj[R * 8 + (L >> 5)], 1u << (L & 31)); }
-    }
-  }
-  SYNC();
-  for (int iter = 0; iter < 256; ++iter) {                   // min-label propagation; <= 255 rounds
-    if (tid == 0) sh[2] = 0;
-    SYNC();
-    if (tid >= 1 && tid <= (int)nSub) {
-      const u32 mine = ld_shared<IN_LDS>(&comp[tid]); u32 m = mine;
-      for (int wd = 0; wd < 8; ++wd) { u32 bits = ld_shared<IN_LDS>(&adj[tid * 8 + wd]); while (bits) { const int b = __ffs((int)bits) - 1; bits &= bits - 1; const u32 cR = ld_shared<IN_LDS>(&comp[wd * 32 + b]); m = cR < m ? cR : m; } }
-      if (m < mine) { atomicMin(&comp[tid], m); sh[2] = 1; }
-    }
-    SYNC();
-    if (!sh[2]) break;
-    SYNC();
-  }
-  if (tid == 0) {                                            // renumber components by ascending minimum label
-    u32 alive = 0; newLab[0] = 0;
-    for (u32 L = 1; L <= nSub; ++L) { if (ld_shared<IN_LDS>(&comp[L]) == L) ++alive; newLab[L] = alive; }   // rank of L if it is a minimum
-    for (u32 L = 1; L <= nSub; ++L) newLab[256 + L] = newLab[ld_shared<IN_LDS>(&comp[L])];                 // label -> rank of its minimum
-    a.blocks[lcode].nSubCluster = alive;
-  }
-  SYNC();
-  for (u32 p = tid; p < nHash; p += CL_THREADS) {
-    const u32 L = ch[p].subCluster;
-    if (L && L <= nSub) ch[p].subCluster = (u8)newLab[256 + L];
-  }
-  SYNC();
-  STAMP(6);
 }
 
 #undef SYNC
 #undef SYNC_LDS
 
+// Two 1024-lane workgroups share a CU only if a wave stays within 64 VGPRs (8 waves per SIMD): the kernel is latency
+// bound (chains of LDS round trips per list), so the second workgroup is worth far more than the few loop-invariant
+// values the compiler then keeps in scratch (measured: 4.3 -> 3.4 ms on the yeast-scale set).
 template <bool IN_LDS, int FIRST_MODE, int CL_THREADS>
-__global__ __launch_bounds__(CL_THREADS)
+__global__ __launch_bounds__(CL_THREADS) __attribute__((amdgpu_waves_per_eu(CL_THREADS == 1024 ? 8 : 4)))
 void cluster_kernel(ClusterArgs a) {
   extern __shared__ __align__(16) unsigned char smem[];
-  __shared__ u32 sh[4 + 128];                               // [0..3] scalars, then clusterMin[256] as u16
+  __shared__ u32 sh[4 + 128];                               // [0..3] scalars, then per-wave scan totals
   unsigned char *region = IN_LDS ? smem : a.scratch + (size_t)blockIdx.x * a.scratchStride;
   u16 *firstGlobal = (IN_LDS && FIRST_MODE == 2) ? (u16 *)(a.scratch + (size_t)blockIdx.x * a.scratchStride) : nullptr;
   for (;;) {
@@ -608,22 +566,142 @@ void cluster_kernel(ClusterArgs a) {
   }
 }
 
-// launch classes by working-set size: 0 = small LDS (two 1024-lane workgroups per CU), 1 = the whole LDS of a CU
-// (one 1024-lane workgroup), 2 = the whole LDS with 512 lanes (fewer per-wave histograms => more ranks fit),
-// 3 = HBM scratch
-__global__ void cluster_classify_kernel(const h10x_block *__restrict__ blocks, const u32 *__restrict__ nGood, u32 codeMin, u32 codeMax,
-                                        u32 nBlocks /* LDS entries of first[] */, u32 bmWords, size_t budgetSmall, size_t budgetBig,
-                                        u32 *__restrict__ list0, u32 *__restrict__ list1, u32 *__restrict__ list2, u32 *__restrict__ list3,
-                                        u32 *__restrict__ counts) {
-  const u32 c = codeMin + blockIdx.x * blockDim.x + threadIdx.x;
+// ---- (e) pointToMin = the terms added in rank order (hash10x.c:821): a serial fp64 chain per barcode. One WAVE per
+// barcode: 64 terms per coalesced load, added in order through readlane (the chain costs one v_add_f64 latency per
+// term; the chip holds 8192 waves, so the chains of thousands of barcodes run side by side). Blocks without good
+// hashes are left untouched.
+constexpr int SUM_THREADS = 256;
+__global__ __launch_bounds__(SUM_THREADS)
+void point_sum_kernel(h10x_block *__restrict__ blocks, const u64 *__restrict__ blockOff, const u32 *__restrict__ nGood,
+                      const double *__restrict__ term, u32 codeMin, u32 codeMax) {
+  const int lane = threadIdx.x & (WAVE - 1);
+  const u32 c = codeMin + blockIdx.x * (SUM_THREADS / WAVE) + threadIdx.x / WAVE;
   if (c >= codeMax) return;
   const u32 n = nGood[c];
   if (!n) return;
-  const size_t mb = mergeBytes(blocks[c].nRead);
-  if (max(workBytes(nBlocks, n, CL_THREADS_SMALL / WAVE, bmWords), mb) <= budgetSmall) list0[atomicAdd(&counts[0], 1u)] = c;
-  else if (max(workBytes(nBlocks, n, CL_THREADS_BIG / WAVE, bmWords), mb) <= budgetBig) list1[atomicAdd(&counts[1], 1u)] = c;
-  else if (max(workBytes(nBlocks, n, CL_THREADS_HUGE / WAVE, bmWords), mb) <= budgetBig) list2[atomicAdd(&counts[2], 1u)] = c;
-  else list3[atomicAdd(&counts[3], 1u)] = c;
+  const double *t = term + blockOff[c];
+  double p = 0.0;
+  double nxt = (u32)lane < n ? t[lane] : 0.0;                // term[0] is 0.0 (rank 0 is never processed)
+  for (u32 base = 0; base < n; base += WAVE) {
+    const double cur = nxt;
+    nxt = base + WAVE + lane < n ? t[base + WAVE + lane] : 0.0;
+    const int tlo = (int)(u32)__double_as_longlong(cur), thi = (int)(u32)((u64)__double_as_longlong(cur) >> 32);
+    if (__ballot(cur != 0.0)) {                               // + 0.0 is exact (p >= +0): skip all-zero groups
+#pragma unroll
+      for (int j = 0; j < WAVE; ++j) {
+        const u64 bits = ((u64)(u32)__builtin_amdgcn_readlane(thi, j) << 32) | (u64)(u32)__builtin_amdgcn_readlane(tlo, j);
+        p += __longlong_as_double((long long)bits);
+      }
+    }
+  }
+  if (lane == 0) blocks[c].pointToMin = p;
+}
+
+// ---- (f) codeClusterReadMerge (hash10x.c:837-868): components of labels that share a read, renumbered by ascending
+// minimum label. One small workgroup per barcode; BIG = blocks with more than MERGE_SMALL_READS read pairs.
+constexpr int MERGE_THREADS = 256;
+constexpr u32 MERGE_SMALL_READS = 4096;
+template <bool BIG>
+__global__ __launch_bounds__(MERGE_THREADS)
+void read_merge_kernel(h10x_block *__restrict__ blocks, const u64 *__restrict__ blockOff, const u32 *__restrict__ nGood,
+                       h10x_clushash *__restrict__ clusHash, u32 codeMin) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  __shared__ u32 changed;
+  const u32 c = codeMin + blockIdx.x;
+  if (!nGood[c]) return;
+  const h10x_block blk = blocks[c];
+  const u32 nSub = blk.nSubCluster, nHash = blk.nHash, nRead = blk.nRead;
+  if (!nSub) return;                                         // hash10x.c:840
+  if ((nRead > MERGE_SMALL_READS) != BIG) return;
+  const int tid = threadIdx.x;
+  const u32 nRep = nRead < 65536u ? nRead : 65536u;
+  h10x_clushash *ch = clusHash + blockOff[c];
+  u8 *readRep = (u8 *)smem;
+  u32 *adj = (u32 *)(smem + ((nRep + 15) & ~15u));
+  u32 *comp = adj + 256 * 8, *newLab = comp + 256;
+  for (u32 i = tid; i < (nRep + 3) / 4; i += MERGE_THREADS) ((u32 *)readRep)[i] = 0;
+  for (u32 i = tid; i < 256 * 8; i += MERGE_THREADS) adj[i] = 0;
+  comp[tid] = tid;
+  __syncthreads();
+  for (u32 p = tid; p < nHash; p += MERGE_THREADS) {         // any one label of each read is its representative
+    const h10x_clushash e = ch[p];
+    if (e.subCluster && e.subCluster <= nSub && e.read < nRep) readRep[e.read] = e.subCluster;
+  }
+  __syncthreads();
+  for (u32 p = tid; p < nHash; p += MERGE_THREADS) {
+    const h10x_clushash e = ch[p];
+    if (e.subCluster && e.subCluster <= nSub && e.read < nRep) {
+      const u32 L = e.subCluster, R = readRep[e.read];
+      if (R != L) { atomicOr(&adj[L * 8 + (R >> 5)], 1u << (R & 31)); atomicOr(&adj[R * 8 + (L >> 5)], 1u << (L & 31)); }
+    }
+  }
+  __syncthreads();
+  for (int iter = 0; iter < 256; ++iter) {                   // min-label propagation; <= 255 rounds
+    if (tid == 0) changed = 0;
+    __syncthreads();
+    if (tid >= 1 && tid <= (int)nSub) {
+      const u32 mine = comp[tid]; u32 m = mine;
+      for (int wd = 0; wd < 8; ++wd) { u32 bits = adj[tid * 8 + wd]; while (bits) { const int b = __ffs((int)bits) - 1; bits &= bits - 1; const u32 cR = *(volatile u32 *)&comp[wd * 32 + b]; m = cR < m ? cR : m; } }
+      if (m < mine) { atomicMin(&comp[tid], m); changed = 1; }
+    }
+    __syncthreads();
+    if (!changed) break;
+    __syncthreads();
+  }
+  // renumber components by ascending minimum label: rank of L among the labels that are their component's minimum
+  {
+    const bool isMin = tid >= 1 && tid <= (int)nSub && comp[tid] == (u32)tid;
+    const u64 bal = __ballot(isMin);
+    const int lane = tid & (WAVE - 1), wv = tid / WAVE;
+    if (lane == 0) newLab[256 + 256 - 4 + wv] = (u32)__popcll(bal);          // scratch slots above the label map (labels <= 255)
+    __syncthreads();
+    u32 before = 0;
+    for (int q = 0; q < wv; ++q) before += newLab[256 + 256 - 4 + q];
+    newLab[tid] = before + (u32)__popcll(bal & ((2ULL << lane) - 1));   // inclusive count: rank of L if it is a minimum
+    __syncthreads();
+    if (tid == 0) blocks[c].nSubCluster = newLab[nSub];
+    u32 mapped = 0;
+    if (tid >= 1 && tid <= (int)nSub) mapped = newLab[comp[tid]];             // label -> rank of its minimum
+    __syncthreads();
+    newLab[256 + tid] = mapped;
+    __syncthreads();
+  }
+  for (u32 p = tid; p < nHash; p += MERGE_THREADS) {
+    const u32 L = ch[p].subCluster;
+    if (L && L <= nSub) ch[p].subCluster = (u8)newLab[256 + L];
+  }
+}
+
+// launch classes by working-set size: 0 = half a CU's LDS with 1024 lanes, 1 = half a CU's LDS with 512 lanes (fewer
+// per-wave histograms => more ranks fit), 2 = the whole LDS of a CU with 512 lanes, 3 = HBM scratch
+__global__ void cluster_classify_kernel(const h10x_block *__restrict__ blocks, const u32 *__restrict__ nGood, u32 codeMin, u32 codeMax,
+                                        u32 nBlocks /* LDS entries of first[] */, u32 bmWords, u32 waves0, size_t budget0, size_t budgetSmall, size_t budgetBig, int wide,
+                                        u32 *__restrict__ list0, u32 *__restrict__ list1, u32 *__restrict__ list2, u32 *__restrict__ list3,
+                                        u32 *__restrict__ counts) {
+  const u32 c = codeMin + blockIdx.x * blockDim.x + threadIdx.x;
+  const int lane = threadIdx.x & (WAVE - 1);
+  const u32 n = c < codeMax ? nGood[c] : 0;
+  int cls = -1; u32 nRead = 0;
+  if (n) {
+    nRead = blocks[c].nRead;
+    if (wide) cls = 3;                                       // counts do not fit the u16 arrays of the LDS instantiations
+    else if (workBytes(nBlocks, n, waves0, bmWords, 2) <= budget0) cls = 0;
+    else if (workBytes(nBlocks, n, CL_THREADS_BIG / WAVE, bmWords, 2) <= budgetSmall) cls = 1;
+    else if (workBytes(nBlocks, n, CL_THREADS_HUGE / WAVE, bmWords, 2) <= budgetBig) cls = 2;
+    else cls = 3;
+  }
+  for (int s = 32; s; s >>= 1) nRead = max(nRead, (u32)__shfl_xor((int)nRead, s));
+  if (lane == 0 && nRead) atomicMax(&counts[8], nRead);
+  u32 *const lists[4] = {list0, list1, list2, list3};
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {                              // one atomic per wave and class
+    const u64 bal = __ballot(cls == k);
+    if (!bal) continue;
+    u32 base = 0;
+    if (lane == 0) base = atomicAdd(&counts[k], (u32)__popcll(bal));
+    base = (u32)__shfl((int)base, 0);
+    if (cls == k) lists[k][base + (u32)__popcll(bal & ((1ULL << lane) - 1))] = c;
+  }
 }
 
 int stageC_cluster(Ctx *c, int codeMin, int codeMax, int threshold) {
@@ -641,12 +719,14 @@ int stageC_cluster(Ctx *c, int codeMin, int codeMax, int threshold) {
   if (codeMax <= codeMin) { memset(c->ctr.cluster_class_counts, 0, sizeof c->ctr.cluster_class_counts); c->ctr.sum_good = c->ctr.sum_good_depth = c->ctr.sum_hash_clustered = c->ctr.clustered_codes = 0; return 0; }
   c->tstart(T_CLUSTER);
   const u32 span = (u32)(codeMax - codeMin);
-  DevBuf<u32> list0, list1, list2, list3, counts; DevBuf<u64> stats;
+  DevBuf<u32> list0, list1, list2, list3, counts; DevBuf<u64> stats; DevBuf<double> term;
   H10X_HIP(c, list0.alloc(span)); H10X_HIP(c, list1.alloc(span)); H10X_HIP(c, list2.alloc(span)); H10X_HIP(c, list3.alloc(span));
-  H10X_HIP(c, counts.alloc(8)); H10X_HIP(c, stats.alloc(4));
-  H10X_HIP(c, hipMemsetAsync(counts.p, 0, 32, st)); H10X_HIP(c, hipMemsetAsync(stats.p, 0, 32, st));
+  H10X_HIP(c, counts.alloc(12)); H10X_HIP(c, stats.alloc(4)); H10X_HIP(c, term.alloc(c->nEntries));
+  H10X_HIP(c, hipMemsetAsync(counts.p, 0, 48, st)); H10X_HIP(c, hipMemsetAsync(stats.p, 0, 32, st));
   const size_t budgetSmall = c->optClusterLds > 0 ? (size_t)c->optClusterLds : 80 * 1024 - 1024;
   const size_t budgetBig = c->optClusterLds > 0 ? (size_t)c->optClusterLds : 160 * 1024 - 1024;
+  const int threads0 = c->optClusterThreads0 == 512 ? 512 : 1024;                            // tuning knobs for class 0
+  const size_t budget0 = c->optClusterLds > 0 ? (size_t)c->optClusterLds : (c->optClusterBudget0 > 0 ? (size_t)c->optClusterBudget0 : budgetSmall);
   // first[] (2 B per barcode of the data set) stays in LDS while it is small; past that each workgroup keeps it on an
   // HBM slot of its own (L2/MALL resident, atomics + L1-bypassing loads) and only the per-rank arrays live in LDS
   const u32 bmWordsAll = (nGlobal + 31) / 32;
@@ -655,27 +735,26 @@ int stageC_cluster(Ctx *c, int codeMin, int codeMax, int threshold) {
   const u32 firstCap = hmin<u32>(nGlobal, c->optFirstCap > 0 ? (u32)c->optFirstCap : 12288u);
   const u32 nFirstLds = firstMode == 0 ? nGlobal : (firstMode == 1 ? firstCap : 0);
   const u32 bmWords = firstMode == 1 ? bmWordsAll : 0;
-  cluster_classify_kernel<<<divUp(span, 256), 256, 0, st>>>(c->blocks.p, c->nGood.p, (u32)codeMin, (u32)codeMax, nFirstLds, bmWords, budgetSmall, budgetBig,
+  const int wide = c->maxGoodDepth > 65535u ? 1 : 0;         // list lengths / counts beyond the u16 arrays of the LDS instantiations
+  cluster_classify_kernel<<<divUp(span, 256), 256, 0, st>>>(c->blocks.p, c->nGood.p, (u32)codeMin, (u32)codeMax, nFirstLds, bmWords, (u32)threads0 / WAVE, budget0, budgetSmall, budgetBig, wide,
                                                           list0.p, list1.p, list2.p, list3.p, counts.p);
-  u32 hc[4];
-  H10X_HIP(c, hipMemcpyAsync(hc, counts.p, 16, hipMemcpyDeviceToHost, st));
+  u32 hc[12];
+  H10X_HIP(c, hipMemcpyAsync(hc, counts.p, 48, hipMemcpyDeviceToHost, st));
   H10X_HIP(c, hipStreamSynchronize(st));
   ClusterArgs a{};
   a.blocks = c->blocks.p; a.blockOff = c->blockOff.p; a.clusHash = c->clusHash.p; a.goodPos = c->goodPos.p; a.nGood = c->nGood.p;
   a.hashDepth = c->hashDepth.p; a.rowStart = c->rowStart.p; a.rows = c->rows.p; a.nBlocks = c->nBlocks; a.threshold = threshold;
   a.codeBase = c->sharded ? c->codeBase : 0; a.nBlocksFirst = nGlobal;
-  a.maxGood = c->maxGood; a.stats = stats.p;
+  a.maxGood = c->maxGood; a.stats = stats.p; a.term = term.p;
   DevBuf<u32> overflow; H10X_HIP(c, overflow.alloc((size_t)span + 1));
   a.firstCap = firstCap; a.overflow = overflow.p + 1; a.overflowCount = overflow.p; H10X_HIP(c, hipMemsetAsync(overflow.p, 0, 4, st));
   DevBuf<u64> phase;
   if (c->optStamps) { H10X_HIP(c, phase.alloc(8)); H10X_HIP(c, hipMemsetAsync(phase.p, 0, 64, st)); a.phase = phase.p; }
-  // HBM working set per workgroup (class 3): first[] + per-rank arrays + read-merge tables for the largest barcode
+  // HBM working set per workgroup (class 3): first[] + per-rank arrays for the largest barcode
   DevBuf<unsigned char> scratch;
   size_t stride = 0; u32 grid3 = 0;
   if (hc[3]) {
-    const size_t mergeOff = (workBytes(nGlobal, c->maxGood, CL_THREADS_SMALL / WAVE) + 255) & ~(size_t)255;
-    stride = mergeOff + ((mergeBytes(65536) + 255) & ~(size_t)255);
-    a.mergeOffset = mergeOff;
+    stride = (workBytes(nGlobal, c->maxGood, CL_THREADS_SMALL / WAVE, 0, 4) + 255) & ~(size_t)255;
     grid3 = hmin<u32>(hc[3], (u32)c->numCU);
     H10X_HIP(c, scratch.alloc(stride * grid3));
     H10X_HIP(c, hipMemsetAsync(scratch.p, 0xFF, stride * grid3, st));    // first[] = unseen everywhere
@@ -683,7 +762,7 @@ int stageC_cluster(Ctx *c, int codeMin, int codeMax, int threshold) {
   // hybrid placement: one first[] slot per resident workgroup of each LDS class
   DevBuf<unsigned char> firstSlots[3];
   const size_t firstStride = (((size_t)nGlobal * 2 + 255) & ~(size_t)255);
-  const u32 gridOf[3] = {hmin<u32>(hc[0], (u32)c->numCU * 2), hmin<u32>(hc[1], (u32)c->numCU), hmin<u32>(hc[2], (u32)c->numCU)};
+  const u32 gridOf[3] = {hmin<u32>(hc[0], (u32)c->numCU * (u32)hmax<size_t>(1, (160 * 1024) / (budget0 + 1024))), hmin<u32>(hc[1], (u32)c->numCU * 2), hmin<u32>(hc[2], (u32)c->numCU)};
   if (firstMode == 2) for (int k = 0; k < 3; ++k) if (hc[k]) {
     H10X_HIP(c, firstSlots[k].alloc(firstStride * gridOf[k]));
     H10X_HIP(c, hipMemsetAsync(firstSlots[k].p, 0xFF, firstStride * gridOf[k], st));
@@ -713,8 +792,8 @@ int stageC_cluster(Ctx *c, int codeMin, int codeMax, int threshold) {
     }                                                                                                                              \
   }
   H10X_LAUNCH_LDS(2, CL_THREADS_HUGE, budgetBig, c->aux[1], list2.p, 6)
-  H10X_LAUNCH_LDS(1, CL_THREADS_BIG, budgetBig, c->aux[2], list1.p, 5)
-  H10X_LAUNCH_LDS(0, CL_THREADS_SMALL, budgetSmall, st, list0.p, 4)
+  H10X_LAUNCH_LDS(1, CL_THREADS_BIG, budgetSmall, c->aux[2], list1.p, 5)
+  if (threads0 == 512) { H10X_LAUNCH_LDS(0, 512, budget0, st, list0.p, 4) } else { H10X_LAUNCH_LDS(0, CL_THREADS_SMALL, budget0, st, list0.p, 4) }
 #undef H10X_LAUNCH_LDS
   H10X_HIP(c, hipGetLastError());
   H10X_TRY(c->joinStreams(3));
@@ -724,18 +803,29 @@ int stageC_cluster(Ctx *c, int codeMin, int codeMax, int threshold) {
     H10X_HIP(c, hipMemcpyAsync(&nOverflow, overflow.p, 4, hipMemcpyDeviceToHost, st));
     H10X_HIP(c, hipStreamSynchronize(st));
     if (nOverflow) {
-      const size_t mergeOff = (workBytes(nGlobal, c->maxGood, CL_THREADS_SMALL / WAVE) + 255) & ~(size_t)255;
-      const size_t stride2 = mergeOff + ((mergeBytes(65536) + 255) & ~(size_t)255);
+      const size_t stride2 = (workBytes(nGlobal, c->maxGood, CL_THREADS_SMALL / WAVE, 0, 4) + 255) & ~(size_t)255;
       const u32 grid = hmin<u32>(nOverflow, (u32)c->numCU);
       H10X_HIP(c, scratch2.alloc(stride2 * grid));
       H10X_HIP(c, hipMemsetAsync(scratch2.p, 0xFF, stride2 * grid, st));
       H10X_HIP(c, hipMemsetAsync(counts.p + 7, 0, 4, st));
       ClusterArgs g = a; g.list = overflow.p + 1; g.nList = nOverflow; g.workCounter = counts.p + 7; g.scratch = scratch2.p; g.scratchStride = stride2;
-      g.mergeOffset = mergeOff;
       cluster_kernel<false, 2, CL_THREADS_SMALL><<<grid, CL_THREADS_SMALL, 0, st>>>(g);
       H10X_HIP(c, hipGetLastError());
     }
   }
+  // (e) the ordered sums on a side stream beside (f) the read merges: they touch disjoint fields
+  H10X_TRY(c->forkStreams(1));
+  point_sum_kernel<<<divUp(span, SUM_THREADS / WAVE), SUM_THREADS, 0, c->aux[0]>>>(c->blocks.p, c->blockOff.p, c->nGood.p, term.p, (u32)codeMin, (u32)codeMax);
+  {
+    const size_t ldsSmall = mergeBytes(MERGE_SMALL_READS), ldsBig = mergeBytes(65536);
+    read_merge_kernel<false><<<span, MERGE_THREADS, ldsSmall, st>>>(c->blocks.p, c->blockOff.p, c->nGood.p, c->clusHash.p, (u32)codeMin);
+    if (hc[8] > MERGE_SMALL_READS) {
+      H10X_HIP(c, hipFuncSetAttribute((const void *)read_merge_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsBig));
+      read_merge_kernel<true><<<span, MERGE_THREADS, ldsBig, st>>>(c->blocks.p, c->blockOff.p, c->nGood.p, c->clusHash.p, (u32)codeMin);
+    }
+  }
+  H10X_HIP(c, hipGetLastError());
+  H10X_TRY(c->joinStreams(1));
   c->tstop(T_CLUSTER_K);
   u64 hs[4];
   H10X_HIP(c, hipMemcpyAsync(hs, stats.p, 32, hipMemcpyDeviceToHost, st));

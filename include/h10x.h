@@ -163,7 +163,7 @@ typedef struct {
   uint64_t sum_good_depth;   /* sum over good hashes of depth (gathered row entries)*/
   uint64_t sum_hash_clustered; /* sum nHash over barcodes with good hashes          */
   uint64_t fallback_blocks;  /* barcodes that took the global-memory path in stage A */
-  uint64_t cluster_class_counts[4]; /* barcodes clustered in: half-CU LDS, full-CU LDS (1024 lanes), full-CU LDS (512 lanes), HBM scratch */
+  uint64_t cluster_class_counts[4]; /* barcodes clustered in: half-CU LDS with 1024 lanes, half-CU LDS with 512 lanes, full-CU LDS (512 lanes), HBM scratch */
   uint64_t cluster_first_mode;     /* placement of the first[] table: 0 dense in LDS, 1 ranked (bitmap) in LDS, 2 per-workgroup HBM slot */
   uint64_t cluster_overflow_blocks; /* ranked placement: barcodes re-run on the HBM path because too many barcodes were present */
   uint64_t cluster_phase_ticks[8]; /* diagnostic (option "cluster_stamps"): 100 MHz ticks per phase summed over workgroups:
