@@ -28,9 +28,7 @@
 namespace h10x {
 
 constexpr int CL_THREADS_SMALL = 1024;                     // <= 79 KB working sets, two workgroups per CU
-constexpr int CL_THREADS_BIG = 512;                        // same LDS with half the waves (per-wave histograms cost 8 instead of 16 B per rank):
-                                                           // more ranks fit, and such a workgroup still shares a CU with one of either kind
-constexpr int CL_THREADS_HUGE = 512;                       // the whole LDS of a CU, one workgroup per CU
+constexpr int CL_THREADS_HUGE = 1024;                      // the whole LDS of a CU, one workgroup per CU
 constexpr u16 NONE16 = 0xFFFF;
 #ifndef H10X_RIF
 #define H10X_RIF 4
@@ -141,6 +139,7 @@ struct ClusterArgs {
   u32 *overflow, *overflowCount;                            // ranked placement: blocks with more present barcodes than firstCap
   unsigned char *scratch; size_t scratchStride;             // global-mode working set per workgroup
   u32 maxGood;
+  u32 ldsBudget;                                            // LDS bytes of the launch class (list loop: as many waves as have room for a histogram)
   double *term;                                             // per rank (slice of block c at blockOff[c]): its pointToMin term, 0.0 if none
   u64 *stats;                                               // [0] sum good, [1] sum good depth, [2] sum nHash, [3] codes
   u64 *phase;                                               // diagnostic per-phase ticks (null = off)
@@ -169,6 +168,15 @@ __host__ __device__ inline size_t workBytes(u32 nFirst, u32 n, u32 nWaves, u32 b
   b += ((size_t)n + 15) & ~(size_t)15;                      // lab
   b += (size_t)nWaves * (((size_t)n + 3) / 4) * 4;          // hist (the replay's temporaries, 4 n + 8 bytes, overlay it: nWaves >= 8)
   return b + 16;
+}
+// waves of the workgroup that take part in the list loop of a barcode with n ranks: as many as have room for a private
+// histogram in what the fixed part leaves of `budget` (0 = does not fit; the replay's temporaries need >= MIN_HIST_WAVES)
+constexpr u32 MIN_HIST_WAVES = 5;
+__host__ __device__ inline u32 histWaves(u32 nFirst, u32 n, u32 maxWaves, u32 bmWords, u32 ctBytes, size_t budget) {
+  const size_t fixed = workBytes(nFirst, n, 0, bmWords, ctBytes), per = (((size_t)n + 3) / 4) * 4;
+  if (fixed + MIN_HIST_WAVES * per > budget) return 0;
+  const size_t wv = (budget - fixed) / (per ? per : 1);
+  return wv < maxWaves ? (u32)wv : maxWaves;
 }
 template <typename CT>
 __device__ inline Work<CT> carve(unsigned char *base, u32 nFirst, u32 n, u32 bmWords = 0) {
@@ -330,6 +338,9 @@ __device__ void cluster_one_block(const ClusterArgs &a, u32 code, unsigned char 
   if (IN_LDS && FIRST_MODE == 2) w.first = firstGlobal;      // hybrid: first[] on this workgroup's HBM slot, the rest in LDS
   typename std::conditional<RANKED, MapRanked, MapDense>::type fm{};
   if constexpr (RANKED) { fm.bm = w.bm; fm.pre = w.pre; }
+  // list-loop waves: all of them where the histograms fit, fewer for a barcode with many ranks (one kernel and one
+  // work queue then serve nearly every barcode; the rest of the phases always use the whole workgroup)
+  const u32 nW = IN_LDS ? histWaves(RANKED ? a.firstCap : (FIRST_LDS ? a.nBlocksFirst : 0), n, CL_WAVES, bmWords, sizeof(CT), a.ldsBudget) : (u32)CL_WAVES;
   const u32 lcode = code; code += a.codeBase;                // from here on `code` is the global barcode number (what the lists hold)
   h10x_clushash *ch = a.clusHash + o; const u16 *g = a.goodPos + o;
 
@@ -337,7 +348,7 @@ __device__ void cluster_one_block(const ClusterArgs &a, u32 code, unsigned char 
   // ---- init: prefetch every rank's list offset/length once
   if (FIRST_LDS && !RANKED) for (u32 i = tid; i < (a.nBlocksFirst + 1) / 2; i += CL_THREADS) ((u32 *)w.first)[i] = 0xFFFFFFFFu;
   if (RANKED) for (u32 i = tid; i < bmWords; i += CL_THREADS) w.bm[i] = 0;
-  for (u32 i = tid; i < CL_WAVES * w.histWords; i += CL_THREADS) w.hist[i] = 0;
+  for (u32 i = tid; i < nW * w.histWords; i += CL_THREADS) w.hist[i] = 0;
   u64 myDepth = 0;
   for (u32 i = tid; i < n; i += CL_THREADS) {
     const u32 x = ch[g[i]].hash; const u32 d = a.hashDepth[x];
@@ -388,13 +399,14 @@ __device__ void cluster_one_block(const ClusterArgs &a, u32 code, unsigned char 
     const u32 i = (I0) + t; dlN[t] = i < n ? (u32)w.dd[i] : 0; const u32 *row = a.rows + w.rs[i < n ? i : n - 1]; \
     cjN[t] = (u32)lane < dlN[t] ? row[lane] : code; cj2N[t] = (u32)(WAVE + lane) < dlN[t] ? row[WAVE + lane] : code; \
   }
-  H10X_LOAD_AB(1 + wave * ROWS_IN_FLIGHT)
-  for (u32 r0 = 1; r0 < n; r0 += CL_WAVES * ROWS_IN_FLIGHT) {
-    const u32 i0 = r0 + wave * ROWS_IN_FLIGHT;
+  const bool listWave = (u32)wave < nW;                      // the other waves only keep the barriers company
+  H10X_LOAD_AB(listWave ? 1 + wave * ROWS_IN_FLIGHT : n)
+  for (u32 r0 = 1; r0 < n; r0 += nW * ROWS_IN_FLIGHT) {
+    const u32 i0 = listWave ? r0 + wave * ROWS_IN_FLIGHT : n;
     u32 cj[ROWS_IN_FLIGHT], cj2[ROWS_IN_FLIGHT], dl[ROWS_IN_FLIGHT];
 #pragma unroll
     for (int t = 0; t < ROWS_IN_FLIGHT; ++t) { cj[t] = cjN[t]; cj2[t] = cj2N[t]; dl[t] = dlN[t]; }
-    H10X_LOAD_AB(i0 + CL_WAVES * ROWS_IN_FLIGHT)
+    H10X_LOAD_AB(listWave ? i0 + nW * ROWS_IN_FLIGHT : n)
 #pragma unroll
     for (int t = 0; t < ROWS_IN_FLIGHT; ++t) {
       const u32 i = i0 + t;
@@ -549,7 +561,7 @@ __device__ void cluster_one_block(const ClusterArgs &a, u32 code, unsigned char 
 // Two 1024-lane workgroups share a CU only if a wave stays within 64 VGPRs (8 waves per SIMD): the kernel is latency
 // bound (chains of LDS round trips per list), so the second workgroup is worth far more than the few loop-invariant
 // values the compiler then keeps in scratch (measured: 4.3 -> 3.4 ms on the yeast-scale set).
-template <bool IN_LDS, int FIRST_MODE, int CL_THREADS>
+template <bool IN_LDS, int FIRST_MODE, int CL_THREADS, int KLASS = 0 /* distinct functions per launch class */>
 __global__ __launch_bounds__(CL_THREADS) __attribute__((amdgpu_waves_per_eu(CL_THREADS == 1024 ? 8 : 4)))
 void cluster_kernel(ClusterArgs a) {
   extern __shared__ __align__(16) unsigned char smem[];
@@ -672,8 +684,8 @@ void read_merge_kernel(h10x_block *__restrict__ blocks, const u64 *__restrict__ 
   }
 }
 
-// launch classes by working-set size: 0 = half a CU's LDS with 1024 lanes, 1 = half a CU's LDS with 512 lanes (fewer
-// per-wave histograms => more ranks fit), 2 = the whole LDS of a CU with 512 lanes, 3 = HBM scratch
+// launch classes by working-set size: 0 = half a CU's LDS (barcodes with many ranks run their list loop on fewer waves:
+// histWaves), 2 = the whole LDS of a CU, 3 = HBM scratch (class 1 is no longer used)
 __global__ void cluster_classify_kernel(const h10x_block *__restrict__ blocks, const u32 *__restrict__ nGood, u32 codeMin, u32 codeMax,
                                         u32 nBlocks /* LDS entries of first[] */, u32 bmWords, u32 waves0, size_t budget0, size_t budgetSmall, size_t budgetBig, int wide,
                                         u32 *__restrict__ list0, u32 *__restrict__ list1, u32 *__restrict__ list2, u32 *__restrict__ list3,
@@ -685,9 +697,8 @@ __global__ void cluster_classify_kernel(const h10x_block *__restrict__ blocks, c
   if (n) {
     nRead = blocks[c].nRead;
     if (wide) cls = 3;                                       // counts do not fit the u16 arrays of the LDS instantiations
-    else if (workBytes(nBlocks, n, waves0, bmWords, 2) <= budget0) cls = 0;
-    else if (workBytes(nBlocks, n, CL_THREADS_BIG / WAVE, bmWords, 2) <= budgetSmall) cls = 1;
-    else if (workBytes(nBlocks, n, CL_THREADS_HUGE / WAVE, bmWords, 2) <= budgetBig) cls = 2;
+    else if (histWaves(nBlocks, n, waves0, bmWords, 2, budget0)) cls = 0;
+    else if (histWaves(nBlocks, n, CL_THREADS_HUGE / WAVE, bmWords, 2, budgetBig)) cls = 2;
     else cls = 3;
   }
   for (int s = 32; s; s >>= 1) nRead = max(nRead, (u32)__shfl_xor((int)nRead, s));
@@ -741,6 +752,9 @@ int stageC_cluster(Ctx *c, int codeMin, int codeMax, int threshold) {
   u32 hc[12];
   H10X_HIP(c, hipMemcpyAsync(hc, counts.p, 48, hipMemcpyDeviceToHost, st));
   H10X_HIP(c, hipStreamSynchronize(st));
+  // (the work queue hands barcodes out in the order the classification appended them, i.e. mixed sizes: sorting the
+  // queue by descending rank count was measured 17 % SLOWER — workgroups of like size run their phases in step and
+  // contend for the same unit at the same time)
   ClusterArgs a{};
   a.blocks = c->blocks.p; a.blockOff = c->blockOff.p; a.clusHash = c->clusHash.p; a.goodPos = c->goodPos.p; a.nGood = c->nGood.p;
   a.hashDepth = c->hashDepth.p; a.rowStart = c->rowStart.p; a.rows = c->rows.p; a.nBlocks = c->nBlocks; a.threshold = threshold;
@@ -762,7 +776,7 @@ int stageC_cluster(Ctx *c, int codeMin, int codeMax, int threshold) {
   // hybrid placement: one first[] slot per resident workgroup of each LDS class
   DevBuf<unsigned char> firstSlots[3];
   const size_t firstStride = (((size_t)nGlobal * 2 + 255) & ~(size_t)255);
-  const u32 gridOf[3] = {hmin<u32>(hc[0], (u32)c->numCU * (u32)hmax<size_t>(1, (160 * 1024) / (budget0 + 1024))), hmin<u32>(hc[1], (u32)c->numCU * 2), hmin<u32>(hc[2], (u32)c->numCU)};
+  const u32 gridOf[3] = {hmin<u32>(hc[0], (u32)c->numCU * (u32)hmax<size_t>(1, (160 * 1024) / (budget0 + 1024))), hmin<u32>(hc[1], (u32)c->numCU * 2), hmin<u32>(hc[2], (u32)c->numCU)};   // class 1 unused
   if (firstMode == 2) for (int k = 0; k < 3; ++k) if (hc[k]) {
     H10X_HIP(c, firstSlots[k].alloc(firstStride * gridOf[k]));
     H10X_HIP(c, hipMemsetAsync(firstSlots[k].p, 0xFF, firstStride * gridOf[k], st));
@@ -778,21 +792,20 @@ int stageC_cluster(Ctx *c, int codeMin, int codeMax, int threshold) {
   }
 #define H10X_LAUNCH_LDS(K, THREADS, BUDGET, STREAM, LIST, CNT)                                                                     \
   if (hc[K]) {                                                                                                                     \
-    ClusterArgs g = a; g.list = LIST; g.nList = hc[K]; g.workCounter = counts.p + CNT;                                            \
+    ClusterArgs g = a; g.list = LIST; g.nList = hc[K]; g.workCounter = counts.p + CNT; g.ldsBudget = (u32)(BUDGET);               \
     if (firstMode == 0) {                                                                                                          \
-      H10X_HIP(c, hipFuncSetAttribute((const void *)cluster_kernel<true, 0, THREADS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(BUDGET))); \
-      cluster_kernel<true, 0, THREADS><<<gridOf[K], THREADS, BUDGET, STREAM>>>(g);                                                 \
+      H10X_HIP(c, hipFuncSetAttribute((const void *)cluster_kernel<true, 0, THREADS, K>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(BUDGET))); \
+      cluster_kernel<true, 0, THREADS, K><<<gridOf[K], THREADS, BUDGET, STREAM>>>(g);                                              \
     } else if (firstMode == 1) {                                                                                                   \
-      H10X_HIP(c, hipFuncSetAttribute((const void *)cluster_kernel<true, 1, THREADS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(BUDGET))); \
-      cluster_kernel<true, 1, THREADS><<<gridOf[K], THREADS, BUDGET, STREAM>>>(g);                                                 \
+      H10X_HIP(c, hipFuncSetAttribute((const void *)cluster_kernel<true, 1, THREADS, K>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(BUDGET))); \
+      cluster_kernel<true, 1, THREADS, K><<<gridOf[K], THREADS, BUDGET, STREAM>>>(g);                                              \
     } else {                                                                                                                       \
       g.scratch = firstSlots[K].p; g.scratchStride = firstStride;                                                                  \
-      H10X_HIP(c, hipFuncSetAttribute((const void *)cluster_kernel<true, 2, THREADS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(BUDGET))); \
-      cluster_kernel<true, 2, THREADS><<<gridOf[K], THREADS, BUDGET, STREAM>>>(g);                                                 \
+      H10X_HIP(c, hipFuncSetAttribute((const void *)cluster_kernel<true, 2, THREADS, K>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(BUDGET))); \
+      cluster_kernel<true, 2, THREADS, K><<<gridOf[K], THREADS, BUDGET, STREAM>>>(g);                                              \
     }                                                                                                                              \
   }
   H10X_LAUNCH_LDS(2, CL_THREADS_HUGE, budgetBig, c->aux[1], list2.p, 6)
-  H10X_LAUNCH_LDS(1, CL_THREADS_BIG, budgetSmall, c->aux[2], list1.p, 5)
   if (threads0 == 512) { H10X_LAUNCH_LDS(0, 512, budget0, st, list0.p, 4) } else { H10X_LAUNCH_LDS(0, CL_THREADS_SMALL, budget0, st, list0.p, 4) }
 #undef H10X_LAUNCH_LDS
   H10X_HIP(c, hipGetLastError());
