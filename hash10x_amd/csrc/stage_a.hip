@@ -28,6 +28,7 @@ constexpr int SEQ_WORDS = 12;           // 10 packed words + 2 pad words per rea
 struct MoshConst {
   int k, w, shift1;      // shift1 = 64 - 2k
   int n1, n2;            // k-mers per read 1 (127 bases from base 23) and read 2 (150 bases)
+  int run;               // consecutive k-mer slots per lane in mosh_lds_kernel: ceil(n1/run) + ceil(n2/run) <= 32
   u64 factor1;
 };
 
@@ -102,23 +103,31 @@ __global__ void classify_kernel(const u64 *__restrict__ startRec, u32 nBlocks, h
                                 u32 *__restrict__ list0, u32 *__restrict__ list1, u32 *__restrict__ list2, u32 *__restrict__ listF,
                                 u32 *__restrict__ counts /* 4: <=4096, 8192, 16384 slots, global path */, int hashLast) {
   const u32 c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= nBlocks) return;
-  h10x_block b; memset(&b, 0, sizeof b);
-  if (c == 0) { blocks[0] = b; slots[0] = 0; return; }
-  const u64 nr = startRec[c + 1] - startRec[c];
-  b.nRead = (u32)nr;
-  blocks[c] = b;
-  u32 s = 0;
-  if (c + 1 < nBlocks || hashLast) {                         // the file's last block is never hashed; a shard's last block is
-    u64 want = 256; while (want < nr * 10) want <<= 1;      // expected load <= 0.76 at 7.6 unique / pair (overflow at 0.875 => global path)
-    if (packedOK && nr <= 65535 && want <= maxSlots) {
-      s = (u32)want;
-      if (s <= 4096) list0[atomicAdd(&counts[0], 1u)] = c;
-      else if (s <= 8192) list1[atomicAdd(&counts[1], 1u)] = c;
-      else list2[atomicAdd(&counts[2], 1u)] = c;
-    } else listF[atomicAdd(&counts[3], 1u)] = c;
+  const int lane = threadIdx.x & (WAVE - 1);
+  int cls = -1; u32 s = 0;
+  if (c < nBlocks) {
+    h10x_block b; memset(&b, 0, sizeof b);
+    if (c > 0) {
+      const u64 nr = startRec[c + 1] - startRec[c];
+      b.nRead = (u32)nr;
+      if (c + 1 < nBlocks || hashLast) {                     // the file's last block is never hashed; a shard's last block is
+        u64 want = 256; while (want < nr * 10) want <<= 1;  // expected load <= 0.76 at 7.6 unique / pair (overflow at 0.875 => global path)
+        if (packedOK && nr <= 65535 && want <= maxSlots) { s = (u32)want; cls = s <= 4096 ? 0 : (s <= 8192 ? 1 : 2); }
+        else cls = 3;
+      }
+    }
+    blocks[c] = b; slots[c] = s;
   }
-  slots[c] = s;
+  u32 *const lists[4] = {list0, list1, list2, listF};
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {                              // one atomic per wave and class
+    const u64 bal = __ballot(cls == k);
+    if (!bal) continue;
+    u32 base = 0;
+    if (lane == 0) base = atomicAdd(&counts[k], (u32)__popcll(bal));
+    base = (u32)__shfl((int)base, 0);
+    if (cls == k) lists[k][base + (u32)__popcll(bal & ((1ULL << lane) - 1))] = c;
+  }
 }
 
 // ------------------------------------------------------------------------------------------ LDS path
@@ -138,8 +147,15 @@ __device__ __forceinline__ bool lds_set_insert(u64 *table, u32 mask, u64 hash, u
   return false;                                              // table full
 }
 
-template <bool W31>
-__global__ __launch_bounds__(MOSH_THREADS)
+// One workgroup per barcode block, no staging tile and no barrier in the main loop: 32 lanes share a read pair, each
+// lane owns a run of L (8 or 9) consecutive k-mer slots of one read. It fetches the 4 packed dwords that cover its run
+// straight from HBM (the next pair's are requested before the current pair is hashed), keeps them as a 128-bit shift
+// register, and ROLLS the forward word (2 bits in per step) and the reverse-complement word (seqhash.c:75: shift
+// right, complement of the new base in at the top) instead of re-extracting a window per slot; what is left per slot
+// is the two 64-bit multiplies of hashFunc, the min and the divisibility test. Survivors (1 in w) are parked, two
+// per lane, and inserted into the LDS hash set once per pair.
+template <bool W31, int L /* slots per lane: mc.run */, int THREADS /* 256 / 512 / 1024 for the 32 / 64 / 128 KB table classes */>
+__global__ __launch_bounds__(THREADS)
 void mosh_lds_kernel(const u32 *__restrict__ rec, const u32 *__restrict__ list, u32 nList,
                      const u64 *__restrict__ startRec, const u32 *__restrict__ slots, const u64 *__restrict__ capOff,
                      MoshConst mc, u64 *__restrict__ stHash, u32 *__restrict__ stRead, u32 *__restrict__ nHashOut) {
@@ -148,33 +164,53 @@ void mosh_lds_kernel(const u32 *__restrict__ rec, const u32 *__restrict__ list, 
   const u32 code = list[blockIdx.x];
   const u32 S = slots[code], mask = S - 1;
   u64 *table = (u64 *)smem;
-  u32 *tile = (u32 *)(table + S);
   __shared__ u32 sOverflow, sCount;
   const u64 rec0 = startRec[code];
   const u32 nRead = (u32)(startRec[code + 1] - rec0);
-  const int nk = mc.n1 + mc.n2;
 
   for (u32 i = threadIdx.x; i < S; i += blockDim.x) table[i] = EMPTY64;
-  for (u32 i = threadIdx.x; i < REC_TILE * 2 * SEQ_WORDS; i += blockDim.x) tile[i] = 0;   // pad words stay 0
   if (threadIdx.x == 0) { sOverflow = 0; sCount = 0; }
+  __syncthreads();
 
-  for (u32 r0 = 0; r0 < nRead; r0 += REC_TILE) {
-    const int cnt = (int)min((u32)REC_TILE, nRead - r0);
-    __syncthreads();
-    stage_records(rec, rec0 + r0, cnt, tile);
-    __syncthreads();
-    // survivors are rare (1 in w): park one per lane and insert them together once per tile, so the insert
-    // loop runs with many lanes active instead of ~2 per wavefront per record
-    u64 pendH = EMPTY64; u32 pendR = 0;
-    for (int rr = 0; rr < cnt; ++rr)
-      for (int t = threadIdx.x; t < nk; t += blockDim.x) {
-        u64 h;
-        if (mosh_of_slot<W31>(tile + rr * 2 * SEQ_WORDS, t, mc, h)) {
-          if (pendH != EMPTY64 && !lds_set_insert(table, mask, pendH, pendR)) sOverflow = 1;
-          pendH = h; pendR = r0 + rr;
-        }
+  // this lane's run of slots
+  const int lane = threadIdx.x & (WAVE - 1), sub = lane & 31, wv = threadIdx.x / WAVE;
+  const int lanes1 = (mc.n1 + L - 1) / L, lanes2 = (mc.n2 + L - 1) / L;                 // lanes1 + lanes2 <= 32 (stageA_run picks L)
+  int cnt = 0, pos0 = 0, wordBase = 0;
+  if (sub < lanes1) { const int t0 = sub * L; cnt = min(L, mc.n1 - t0); pos0 = 23 + t0; }                                  // hash10x.c:162  &s1[23], 127 bases
+  else if (sub < lanes1 + lanes2) { const int t0 = (sub - lanes1) * L; cnt = min(L, mc.n2 - t0); pos0 = t0; wordBase = 15; }   // hash10x.c:163  s2, 150 bases
+  const int wi = wordBase + (pos0 >> 4), sh = (pos0 & 15) * 2;
+  const int k2 = 2 * mc.k, down = 64 - k2;
+  constexpr u32 PAIRS_PER_ROUND = (THREADS / WAVE) * 2;
+  u32 r = (u32)wv * 2 + (u32)(lane >> 5);
+  uint4 nx = make_uint4(0, 0, 0, 0);
+  if (r < nRead && cnt > 0) { const u32 *p = rec + (rec0 + r) * 30 + wi; nx = make_uint4(p[0], p[1], p[2], p[3]); }
+  for (; __builtin_amdgcn_ballot_w64(r < nRead); r += PAIRS_PER_ROUND) {
+    const uint4 cw = nx;
+    const u32 rn = r + PAIRS_PER_ROUND;
+    if (rn < nRead && cnt > 0) { const u32 *p = rec + (rec0 + rn) * 30 + wi; nx = make_uint4(p[0], p[1], p[2], p[3]); }
+    // 128-bit shift register, bases MSB first (fq2b.c:33-42; the un-justified tail word is consumed as is: SURVEY F6)
+    u64 hi = ((u64)cw.x << 32) | cw.y, lo = ((u64)cw.z << 32) | cw.w;
+    if (sh) { hi = (hi << sh) | (lo >> (64 - sh)); lo <<= sh; }
+    u64 f = hi >> down;
+    u64 rc = revcomp_word(f, mc.k);
+    const bool live = r < nRead;
+    u64 pendA = EMPTY64, pendB = EMPTY64;
+#pragma unroll
+    for (int j = 0; j < L; ++j) {
+      const u64 hf = (f * mc.factor1) >> mc.shift1;          // seqhash.c:58-59
+      const u64 hr = (rc * mc.factor1) >> mc.shift1;
+      const u64 h = hf < hr ? hf : hr;                       // seqhash.c:67-68
+      if (live && j < cnt && divisible<W31>(h, mc.w)) {
+        if (pendA == EMPTY64) pendA = h;
+        else if (pendB == EMPTY64) pendB = h;
+        else { if (!lds_set_insert(table, mask, pendA, r)) sOverflow = 1; pendA = h; }
       }
-    if (pendH != EMPTY64 && !lds_set_insert(table, mask, pendH, pendR)) sOverflow = 1;
+      hi = (hi << 2) | (lo >> 62); lo <<= 2;                 // next base in
+      f = hi >> down;
+      rc = (rc >> 2) | ((u64)(3u - ((u32)f & 3u)) << (k2 - 2));
+    }
+    if (pendA != EMPTY64 && !lds_set_insert(table, mask, pendA, r)) sOverflow = 1;
+    if (pendB != EMPTY64 && !lds_set_insert(table, mask, pendB, r)) sOverflow = 1;
   }
   __syncthreads();
 
@@ -269,6 +305,7 @@ int stageA_run(Ctx *c, const u32 *dRec, u64 nRec, DevBuf<u64> &entHash, DevBuf<u
   MoshConst mc; mc.k = k; mc.w = c->prm.w; mc.shift1 = 64 - 2 * k; mc.factor1 = c->prm.factor1;
   mc.n1 = 127 - k + 1 > 0 ? 127 - k + 1 : 0;               // len < k => no k-mer (seqhash.c:162)
   mc.n2 = 150 - k + 1 > 0 ? 150 - k + 1 : 0;
+  mc.run = 8; while ((mc.n1 + mc.run - 1) / mc.run + (mc.n2 + mc.run - 1) / mc.run > 32) ++mc.run;   // 8 at k = 21, 9 for k <= 7
   const bool w31 = c->prm.w == 31;
 
   // ---- barcode runs (hash10x.c:212-220)
@@ -322,20 +359,25 @@ int stageA_run(Ctx *c, const u32 *dRec, u64 nRec, DevBuf<u64> &entHash, DevBuf<u
   DevBuf<u64> stHash; DevBuf<u32> stRead;
   H10X_HIP(c, stHash.alloc(capTotal)); H10X_HIP(c, stRead.alloc(capTotal));
   c->tstart(T_MOSH);
-  const size_t tileBytes = REC_TILE * 2 * SEQ_WORDS * 4;
-  for (int cls = 2; cls >= 0; --cls) {                       // biggest tables first
+  // the three table classes are independent: side by side on forked streams, the few blocks with many read pairs
+  // (largest tables, most lanes per workgroup) first
+  H10X_TRY(c->forkStreams(2));
+#define H10X_MOSH_LAUNCH(W, LL, TH, STREAM)                                                                                        \
+    { if (lds > 48 * 1024) H10X_HIP(c, hipFuncSetAttribute((const void *)mosh_lds_kernel<W, LL, TH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+      mosh_lds_kernel<W, LL, TH><<<n, TH, lds, STREAM>>>(dRec, list, n, startRec.p, slots.p, capOff.p, mc, stHash.p, stRead.p, nHash.p); }
+#define H10X_MOSH_CLASS(TH, STREAM)                                                                                                \
+    { if (w31 && mc.run == 8) H10X_MOSH_LAUNCH(true, 8, TH, STREAM) else if (w31) H10X_MOSH_LAUNCH(true, 9, TH, STREAM)           \
+      else if (mc.run == 8) H10X_MOSH_LAUNCH(false, 8, TH, STREAM) else H10X_MOSH_LAUNCH(false, 9, TH, STREAM) }
+  for (int cls = 2; cls >= 0; --cls) {
     const u32 n = hc[cls]; if (!n) continue;
     const u32 *list = cls == 0 ? list0.p : cls == 1 ? list1.p : list2.p;
-    const size_t lds = (size_t)hmin<u32>(4096u << cls, maxSlots) * 8 + tileBytes;
-    if (w31) {
-      if (lds > 48 * 1024) H10X_HIP(c, hipFuncSetAttribute((const void *)mosh_lds_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-      mosh_lds_kernel<true><<<n, MOSH_THREADS, lds, st>>>(dRec, list, n, startRec.p, slots.p, capOff.p, mc, stHash.p, stRead.p, nHash.p);
-    } else {
-      if (lds > 48 * 1024) H10X_HIP(c, hipFuncSetAttribute((const void *)mosh_lds_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-      mosh_lds_kernel<false><<<n, MOSH_THREADS, lds, st>>>(dRec, list, n, startRec.p, slots.p, capOff.p, mc, stHash.p, stRead.p, nHash.p);
-    }
+    const size_t lds = (size_t)hmin<u32>(4096u << cls, maxSlots) * 8;
+    if (cls == 2) H10X_MOSH_CLASS(1024, c->aux[0]) else if (cls == 1) H10X_MOSH_CLASS(512, c->aux[1]) else H10X_MOSH_CLASS(256, st)
     H10X_HIP(c, hipGetLastError());
   }
+#undef H10X_MOSH_CLASS
+#undef H10X_MOSH_LAUNCH
+  H10X_TRY(c->joinStreams(2));
   c->tstop(T_MOSH);
 
   // ---- global path: class F plus any block whose LDS set overflowed
