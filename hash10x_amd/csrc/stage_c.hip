@@ -277,13 +277,16 @@ __device__ __forceinline__ void row_mode_hist(const u32 *__restrict__ row, u32 c
       const u32 k = (c << 16) | (0xFFFFu - f[r]);
       key = k > key ? k : key;
     }
-  key = wave_max_u32(key);
 #pragma unroll
   for (int r = 0; r < RCHUNK; ++r)
     if ((u32)(r * WAVE) < d && ok[r]) {
       if (IN_LDS) hist[f[r] >> 2] = 0;                       // ds ops of a wave stay in order
       else atomicAnd(&hist[f[r] >> 2], 0u);                  // HBM scratch: a plain store could be overtaken by the next list's atomics
     }
+  // no value reached the threshold (most lists): the caller only tests msMax >= threshold (hash10x.c:807), so the
+  // wave reduction is skipped and the rank is reported inactive
+  if (!__builtin_amdgcn_ballot_w64((key >> 16) >= thr)) return;
+  key = wave_max_u32(key);
   bcnt = key >> 16;
   best = key ? 0xFFFFu - (key & 0xFFFFu) : NONE16;
 }
