@@ -143,6 +143,13 @@ struct Ctx {
   bool haveRange = false, haveGood = false; int rangeMin = 0, rangeMax = 0;
   u32 maxGoodDepth = 0, maxGood = 0;
 
+  // crib (hash10x.c:406-521): per hash index, where the two truth genomes hold it
+  DevBuf<u32> cribCount[2];   // occurrences in genome 1 / 2
+  DevBuf<u64> cribFirst[2];   // (sequence number << 32 | position) of the first occurrence
+  DevBuf<int16_t> cribChr; DevBuf<u16> cribPos; DevBuf<u8> cribType;   // the merged crib[] / cribType[] of cribBuild
+  DevBuf<u32> cribHist;       // 4 depth histograms (err, het, hom, mul), cribHistDim entries each, then the 4 arrayMax values
+  u32 cribHistDim = 0; int cribGenomes = 0; bool haveCrib = false;
+
   // sharded (multi-GPU) operation: this context owns barcodes codeBase+1 .. codeBase+nBlocks-1 of nBlocksGlobal-1 and,
   // as hash owner, the barcode lists of the hashes in its hash range (shard.hip)
   struct Comm *comm = nullptr; bool sharded = false;
@@ -211,6 +218,15 @@ static inline unsigned divUp(u64 a, u64 b) { return (unsigned)((a + b - 1) / b);
 template <typename T> static inline T hmin(T a, T b) { return a < b ? a : b; }
 template <typename T> static inline T hmax(T a, T b) { return a > b ? a : b; }
 
+// hashIndexFind(hash, FALSE) (hash10x.c:139-152): start hash & mask, odd stride ((hash >> B) & mask) | 1; 0 = absent
+__device__ __forceinline__ u32 probe_find(const u32 *__restrict__ table, const u64 *__restrict__ hashValue, int B, u64 h) {
+  const u64 mask = ((u64)1 << B) - 1;
+  u64 slot = h & mask; const u64 step = ((h >> B) & mask) | 1;
+  u32 ix;
+  while ((ix = table[slot]) && hashValue[ix] != h) slot = (slot + step) & mask;
+  return ix;
+}
+
 // stage entry points (one per translation unit)
 int stageA_run(Ctx *c, const u32 *dRecords, u64 nRecords,
                DevBuf<u64> &entHash, DevBuf<u32> &entCode, DevBuf<u32> &entRead, bool hashLast = false);
@@ -221,6 +237,8 @@ int stageB_buildProbeTable(Ctx *c);            // hashIndex[] from hashValue[1..
 int stageC_depthRange(Ctx *c, int min, int max);
 int stageC_cluster(Ctx *c, int codeMin, int codeMax, int threshold);
 int stageC_split(Ctx *c);
+int stageD_cribGenome(Ctx *c, const u8 *hostCodes, const u64 *seqStart, u32 nSeq, int which, u64 *nPresent, u64 *nAbsent);
+int stageD_cribFinish(Ctx *c);
 int shard_exchangeRows(Ctx *c);                 // sharded --hashDepthRange: allgather the in-range barcode lists
 
 }  // namespace h10x

@@ -95,6 +95,8 @@ static void reset_state(Ctx &c) {
   c.hashNumber = 1; c.nBlocks = 0; c.nEntries = 0; c.nRecords = 0;
   c.sharded = false; c.codeBase = 0; c.nBlocksGlobal = 0; c.oRows.release(); c.oSegStart.release(); c.oIndex.release(); c.oU = 0; c.oM = 0;
   memset(&c.ctr, 0, sizeof c.ctr);
+  c.haveCrib = false; c.cribGenomes = 0; c.cribChr.release(); c.cribPos.release(); c.cribType.release(); c.cribHist.release();
+  for (int g = 0; g < 2; ++g) { c.cribCount[g].release(); c.cribFirst[g].release(); }
 }
 
 int h10x_read_fqb_device(h10x_ctx *h, const uint32_t *dRec, uint64_t n) {
@@ -274,6 +276,42 @@ int h10x_timing_reset(h10x_ctx *h) {
   for (int i = 0; i < T_COUNT; ++i) { h->c.flush((TimerId)i); h->c.timers[i].ms = 0; h->c.timers[i].launches = 0; }
   return 0;
 }
+int h10x_crib_genome(h10x_ctx *h, const uint8_t *codes, const uint64_t *seqStart, uint32_t nSeq, int which, uint64_t *nPresent, uint64_t *nAbsent) {
+  if (!h) return -1;
+  Ctx &c = h->c; H10X_TRY(enter(c));
+  if (!seqStart || (seqStart[nSeq] && !codes)) return c.fail("h10x_crib_genome: null argument");
+  return stageD_cribGenome(&c, codes, (const u64 *)seqStart, nSeq, which, (u64 *)nPresent, (u64 *)nAbsent);
+}
+int h10x_crib_finish(h10x_ctx *h) { if (!h) return -1; Ctx &c = h->c; H10X_TRY(enter(c)); return stageD_cribFinish(&c); }
+int h10x_crib_sizes(h10x_ctx *h, uint32_t *histDim, uint32_t arrayMax[4]) {
+  if (!h) return -1;
+  Ctx &c = h->c; H10X_TRY(enter(c));
+  if (!c.haveCrib) return c.fail("no crib: use cribBuild first");
+  if (histDim) *histDim = c.cribHistDim;
+  if (arrayMax) { H10X_HIP(&c, hipMemcpyAsync(arrayMax, c.cribHist.p + (size_t)4 * c.cribHistDim, 16, hipMemcpyDeviceToHost, c.stream)); H10X_HIP(&c, hipStreamSynchronize(c.stream)); }
+  return 0;
+}
+int h10x_crib_export(h10x_ctx *h, int16_t *chr, uint16_t *pos, uint8_t *type, uint32_t *hist) {
+  if (!h) return -1;
+  Ctx &c = h->c; H10X_TRY(enter(c));
+  if (!c.haveCrib) return c.fail("no crib: use cribBuild first");
+  const size_t U1 = c.hashNumber;
+  if (chr) H10X_HIP(&c, hipMemcpyAsync(chr, c.cribChr.p, U1 * 2, hipMemcpyDeviceToHost, c.stream));
+  if (pos) H10X_HIP(&c, hipMemcpyAsync(pos, c.cribPos.p, U1 * 2, hipMemcpyDeviceToHost, c.stream));
+  if (type) H10X_HIP(&c, hipMemcpyAsync(type, c.cribType.p, U1, hipMemcpyDeviceToHost, c.stream));
+  if (hist) H10X_HIP(&c, hipMemcpyAsync(hist, c.cribHist.p, (size_t)4 * c.cribHistDim * 4, hipMemcpyDeviceToHost, c.stream));
+  H10X_HIP(&c, hipStreamSynchronize(c.stream));
+  return 0;
+}
+int h10x_export_ngood(h10x_ctx *h, uint32_t *nGood) {
+  if (!h || !nGood) return -1;
+  Ctx &c = h->c; H10X_TRY(enter(c));
+  if (!c.haveGood) return c.fail("!! you must set hashDepthRange before clusterReport");
+  H10X_HIP(&c, hipMemcpyAsync(nGood, c.nGood.p, (size_t)c.nBlocks * 4, hipMemcpyDeviceToHost, c.stream));
+  H10X_HIP(&c, hipStreamSynchronize(c.stream));
+  return 0;
+}
+
 int h10x_get_counters(h10x_ctx *h, h10x_counters *out) { if (!h || !out) return -1; *out = h->c.ctr; return 0; }
 
 int h10x_set_option(h10x_ctx *h, const char *name, int64_t value) {

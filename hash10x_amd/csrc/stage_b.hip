@@ -73,14 +73,6 @@ __global__ void probe_finish_kernel(u32 *__restrict__ table, u64 n) {
   for (; i < n; i += stride) if (table[i] == SLOT_EMPTY) table[i] = 0;
 }
 
-__device__ __forceinline__ u32 probe_find(const u32 *__restrict__ table, const u64 *__restrict__ hashValue, int B, u64 h) {
-  const u64 mask = ((u64)1 << B) - 1;
-  u64 slot = h & mask; const u64 step = ((h >> B) & mask) | 1;
-  u32 ix;
-  while ((ix = table[slot]) && hashValue[ix] != h) slot = (slot + step) & mask;
-  return ix;
-}
-
 // ------------------------------------------------------------------------------------------ clusHash
 __global__ void lookup_pack_kernel(const u64 *__restrict__ entHash, const u32 *__restrict__ entRead, u64 n,
                                    const u32 *__restrict__ table, const u64 *__restrict__ hashValue, int B, u64 *__restrict__ key) {

@@ -19,6 +19,7 @@ struct h10x_session {
   int threads0, budget0;                               /* tuning knobs forwarded to h10x_set_option("cluster_threads0" / "cluster_budget0") */
   int stamps;                                          /* diagnostic knob forwarded to h10x_set_option("cluster_stamps") */
   int maxSlots;                                        /* test knob forwarded to h10x_set_option("stage_a_max_slots") */
+  int16_t *cribChr; uint16_t *cribPos; uint8_t *cribType; uint32_t cribN;   /* host copy of crib[] / cribType[] for the reports */
   h10x_ctx *ctx;
   int ctxK, ctxW, ctxR, ctxB, ctxDev;                   /* parameters the live context was created with */
   /* Array bookkeeping of the reference for the two arrays that are dumped raw into .hash */
@@ -43,7 +44,7 @@ h10x_session *h10x_session_new(void) {
 void h10x_session_free(h10x_session *s) {
   if (!s) return;
   if (s->ctx) h10x_destroy(s->ctx);
-  free(s->depthTail); free(s);
+  free(s->depthTail); free(s->cribChr); free(s->cribPos); free(s->cribType); free(s);
 }
 const char *h10x_session_error(const h10x_session *s) { return s->err; }
 h10x_ctx *h10x_session_ctx(h10x_session *s) { return s->ctx; }
@@ -388,4 +389,232 @@ done:
   fclose(f);
   free(hashIndex); free(hashValue); free(depth); free(blocks); free(ch);
   return rc;
+}
+
+/* ---------------------------------------------------------------------------------------------------------------------
+ * crib: --cribBuild, --clusterReport, --cribSummary (hash10x.c:406-521, 870-952, 1017-1061). The genomes are hashed and
+ * looked up on the device (h10x_crib_genome / h10x_crib_finish); what is left here is the FASTA reader and the text.
+ * ------------------------------------------------------------------------------------------------------------------- */
+static const char *const cribTypeName[5] = {"err", "htA", "htB", "hom", "mul"};     /* hash10x.c:417 */
+
+/* One genome as readSequence() + dna2indexConv deliver it to cribAddGenome (readseq.c:66-152, 513-522, hash10x.c:432):
+   '>' anywhere starts a record, blanks / tabs / newlines are skipped, ACGT in either case are 0..3, N is 0, any other
+   character is a "Bad char": the reference then stops reading the file, so do we (same message on stderr). A record
+   without bases also ends the file. Returns the number of sequences; codes / start are malloc'ed. */
+static int read_crib_fasta(const char *path, uint8_t **codesOut, uint64_t **startOut, uint32_t *nSeqOut, char *err, int errlen) {
+  FILE *f = fopen(path, "r");
+  if (!f) { snprintf(err, (size_t)errlen, "failed to open .fa file %s", path); return -1; }
+  static signed char conv[256]; static int convInit = 0;
+  if (!convInit) {
+    memset(conv, -2, sizeof conv);
+    conv['A'] = conv['a'] = 0; conv['C'] = conv['c'] = 1; conv['G'] = conv['g'] = 2; conv['T'] = conv['t'] = 3; conv['N'] = conv['n'] = 0;
+    conv[' '] = conv['\t'] = -1; conv['\n'] = -3;
+    convInit = 1;
+  }
+  size_t cap = 1 << 20, n = 0, capS = 64; uint32_t nSeq = 0;
+  uint8_t *codes = (uint8_t *)malloc(cap); uint64_t *start = (uint64_t *)malloc(capS * 8);
+  int line = 1, c;
+  start[0] = 0;
+  for (;;) {
+    c = getc(f);
+    if (c == '>') { while ((c = getc(f)) != EOF && c != '\n') {} ++line; }             /* id and description are not used */
+    else if (c != EOF) ungetc(c, f);
+    const size_t n0 = n; int bad = 0;
+    while ((c = getc(f)) != EOF) {
+      if (c == '>') { ungetc(c, f); break; }
+      const int v = conv[c & 0xFF];
+      if (v == -3) { ++line; continue; }
+      if (v == -1) continue;
+      if (v < 0) { fprintf(stderr, "Bad char 0x%x = '%c' at line %d, base %d\n", c, c, line, (int)(n - n0)); bad = 1; break; }
+      if (n + 1 >= cap) { cap *= 2; codes = (uint8_t *)realloc(codes, cap); if (!codes) { fclose(f); snprintf(err, (size_t)errlen, "out of memory reading %s", path); return -1; } }
+      codes[n++] = (uint8_t)v;
+    }
+    if (bad) { n = n0; break; }
+    if (n == n0) break;                                                               /* readSequence returned 0: end of input */
+    if (nSeq + 2 >= capS) { capS *= 2; start = (uint64_t *)realloc(start, capS * 8); }
+    start[++nSeq] = n;
+  }
+  fclose(f);
+  *codesOut = codes; *startOut = start; *nSeqOut = nSeq;
+  return 0;
+}
+
+/* printArrayStats (hash10x.c:456-468) over a depth histogram with the reference's arrayMax */
+static void crib_array_stats(FILE *f, const uint32_t *a, uint32_t arrayMax) {
+  int sum = 0, min = -1, max = (int)arrayMax - 1; double total = 0;
+  for (uint32_t i = 0; i < arrayMax; ++i) if (a[i]) { sum += (int)a[i]; total += (double)((int)a[i] * (int)i); if (min == -1) min = (int)i; }
+  fprintf(f, "  %d mean %.1f min %d max %d\n", sum, total / sum, min, max);
+}
+
+static void crib_free(h10x_session *s) { free(s->cribChr); free(s->cribPos); free(s->cribType); s->cribChr = 0; s->cribPos = 0; s->cribType = 0; s->cribN = 0; }
+
+int h10x_session_cribBuild(h10x_session *s, const char *fa1, const char *fa2, FILE *out, int printTables) {
+  if (!s->ctx) return fail(s, "no hash state loaded: use readFQB or readHash first");
+  crib_free(s);
+  const char *paths[2] = {fa1, fa2};
+  /* the reference opens both files before it reads either (hash10x.c:1235-1236) */
+  for (int g = 0; g < 2; ++g) { FILE *t = fopen(paths[g], "r"); if (!t) return fail(s, "failed to open .fa file %s", paths[g]); fclose(t); }
+  for (int g = 0; g < 2; ++g) {
+    uint8_t *codes = 0; uint64_t *start = 0; uint32_t nSeq = 0; uint64_t nPresent = 0, nAbsent = 0;
+    if (read_crib_fasta(paths[g], &codes, &start, &nSeq, s->err, (int)sizeof s->err)) return -1;
+    const int rc = h10x_crib_genome(s->ctx, codes, start, nSeq, g, &nPresent, &nAbsent);
+    free(codes); free(start);
+    if (rc) return fail_ctx(s);
+    fprintf(out, "  read %d known and %d unknown hashes from %d sequences in crib genome\n", (int)nPresent, (int)nAbsent, (int)nSeq);
+    if (out != stdout) printf("  read %d known and %d unknown hashes from %d sequences in crib genome\n", (int)nPresent, (int)nAbsent, (int)nSeq);
+  }
+  if (h10x_crib_finish(s->ctx)) return fail_ctx(s);
+  uint32_t dim = 0, amax[4];
+  if (h10x_crib_sizes(s->ctx, &dim, amax)) return fail_ctx(s);
+  uint32_t *hist = (uint32_t *)calloc((size_t)4 * dim + 4, 4);
+  if (!hist || h10x_crib_export(s->ctx, 0, 0, 0, hist)) { free(hist); return hist ? fail_ctx(s) : fail(s, "out of host memory"); }
+  const uint32_t *aErr = hist, *aHet = hist + dim, *aHom = hist + 2 * (size_t)dim, *aMul = hist + 3 * (size_t)dim;
+  fprintf(out, "  crib matches\n");
+  fprintf(out, "    hom  "); crib_array_stats(out, aHom, amax[2]);
+  fprintf(out, "    het  "); crib_array_stats(out, aHet, amax[1]);
+  fprintf(out, "    mul "); crib_array_stats(out, aMul, amax[3]);
+  fprintf(out, "    err "); crib_array_stats(out, aErr, amax[0]);
+  if (printTables) {                                                                 /* hash10x.c:502-509 */
+    fprintf(out, "CRIB_TABLE      i   err         het          hom         mul\n");
+    for (uint32_t i = 1; i < 256; ++i)
+      fprintf(out, "CRIB_TABLE      %4d%12d%12d%12d%12d\n", (int)i, amax[0] > i ? (int)aErr[i] : 0, amax[1] > i ? (int)aHet[i] : 0,
+              amax[2] > i ? (int)aHom[i] : 0, amax[3] > i ? (int)aMul[i] : 0);
+  }
+  free(hist);
+  return 0;
+}
+
+/* host copies of crib[] / cribType[] for the text reports, fetched once per crib */
+static int crib_fetch(h10x_session *s) {
+  h10x_sizes z; if (h10x_get_sizes(s->ctx, &z)) return fail_ctx(s);
+  if (s->cribChr && s->cribN == z.hashNumber) return 0;
+  crib_free(s);
+  s->cribChr = (int16_t *)malloc((size_t)z.hashNumber * 2); s->cribPos = (uint16_t *)malloc((size_t)z.hashNumber * 2); s->cribType = (uint8_t *)malloc(z.hashNumber);
+  if (!s->cribChr || !s->cribPos || !s->cribType) { crib_free(s); return fail(s, "out of host memory for the crib"); }
+  if (h10x_crib_export(s->ctx, s->cribChr, s->cribPos, s->cribType, 0)) { crib_free(s); return fail_ctx(s); }
+  s->cribN = z.hashNumber;
+  return 0;
+}
+
+/* cribText (hash10x.c:511-521) */
+static const char *crib_text(const h10x_session *s, const uint32_t *depth, uint32_t x, char *text) {
+  char *t = text;
+  t += sprintf(t, "%d", (int)x);
+  if (s->cribChr) t += sprintf(t, ":%s", cribTypeName[s->cribType[x]]);
+  if (s->cribChr && s->cribType[x] > 0 && s->cribType[x] < 4) t += sprintf(t, "_%d.%d", (int)s->cribChr[x], (int)s->cribPos[x]);
+  sprintf(t, "-%d", (int)depth[x]);
+  return text;
+}
+
+/* codeClusterReport (hash10x.c:870-952): per barcode a CLUSTER_SUMMARY line and one CODE_CLUSTER line per sub-cluster
+   with its reads, hashes, crib composition, the chromosome / position span of its first located hash and the hashes
+   that disagree with it. With or without a crib, like the reference. */
+int h10x_session_clusterReport(h10x_session *s, int codeMin, int codeMax, FILE *out) {
+  if (!s->ctx) return fail(s, "no hash state loaded: use readFQB or readHash first");
+  h10x_sizes z; if (h10x_get_sizes(s->ctx, &z)) return fail_ctx(s);
+  if (!codeMax) codeMax = (int)z.nBlocks;                                            /* hash10x.c:1263-1264: codeMin 0 stays 0 (block 0 is reported, empty) */
+  if (codeMin < 0 || codeMax > (int)z.nBlocks) return fail(s, "clusterReport code range %d..%d outside 0..%u", codeMin, codeMax, z.nBlocks);
+  uint32_t sizes_dim = 0; const int haveCrib = h10x_crib_sizes(s->ctx, &sizes_dim, 0) == 0;
+  if (haveCrib) { if (crib_fetch(s)) return -1; } else crib_free(s);
+  int rc = 0;
+  h10x_block *blocks = (h10x_block *)calloc((size_t)z.nBlocks + 1, sizeof *blocks);
+  h10x_clushash *ch = (h10x_clushash *)malloc(z.nClusHash ? z.nClusHash * 8 : 8);
+  uint32_t *depth = (uint32_t *)calloc((size_t)z.hashNumber + 1, 4), *nGood = (uint32_t *)calloc((size_t)z.nBlocks + 1, 4);
+  typedef struct { int n, nRead, nt[5]; int16_t chr; uint16_t pMin, pMax; int nBad, bad; } ReportInfo;
+  ReportInfo *info = 0; int *readClus = 0, *badLink = 0; size_t capInfo = 0, capRead = 0, capLink = 0;
+  if (!blocks || !ch || !depth || !nGood) { rc = fail(s, "out of host memory for clusterReport"); goto done; }
+  if (h10x_export(s->ctx, 0, 0, depth, blocks, ch)) { rc = fail_ctx(s); goto done; }
+  if (h10x_export_ngood(s->ctx, nGood)) { rc = fail_ctx(s); goto done; }
+  {
+    uint64_t off = 0, totalGoodHash = 0; double totalPointToMin = 0.0;
+    for (int c = 1; c < codeMin; ++c) off += blocks[c].nHash;
+    for (int code = codeMin; code < codeMax; ++code) {
+      const h10x_block *b = &blocks[code]; const h10x_clushash *e = ch + off; off += b->nHash;
+      const size_t nInfo = (size_t)b->nSubCluster + 1;
+      if (nInfo > capInfo) { capInfo = nInfo * 2; info = (ReportInfo *)realloc(info, capInfo * sizeof *info); }
+      if ((size_t)b->nRead + 1 > capRead) { capRead = ((size_t)b->nRead + 1) * 2; readClus = (int *)realloc(readClus, capRead * sizeof(int)); }
+      if ((size_t)b->nHash + 1 > capLink) { capLink = ((size_t)b->nHash + 1) * 2; badLink = (int *)realloc(badLink, capLink * sizeof(int)); }
+      memset(info, 0, nInfo * sizeof *info); memset(readClus, 0, ((size_t)b->nRead + 1) * sizeof(int)); memset(badLink, 0, ((size_t)b->nHash + 1) * sizeof(int));
+      int nClusHash = 0;
+      for (uint32_t i = 0; i < b->nHash; ++i) {
+        const int cl = e[i].subCluster; if (!cl) continue;
+        ++nClusHash;
+        if (e[i].read < b->nRead) readClus[e[i].read] = cl;
+        if ((size_t)cl >= nInfo) continue;                                           /* stale label beyond nSubCluster: out of bounds in the reference */
+        ReportInfo *r = &info[cl];
+        ++r->n;
+        const uint32_t bh = e[i].hash;
+        if (haveCrib) {
+          const int t = s->cribType[bh];
+          ++r->nt[t];
+          if (t > 0 && t < 4) {
+            const int16_t hc = s->cribChr[bh]; const uint16_t hp = s->cribPos[bh];
+            if (!r->chr) { r->chr = hc; r->pMin = r->pMax = hp; }
+            else if (hc == r->chr) { if (hp < r->pMin) r->pMin = hp; if (hp > r->pMax) r->pMax = hp; }
+            else { ++r->nBad; badLink[i] = r->bad; r->bad = (int)i; }
+          }
+        }
+      }
+      int nClusRead = 0;
+      for (uint32_t i = 0; i < b->nRead; ++i) { const int cl = readClus[i]; if (cl) { if ((size_t)cl < nInfo) ++info[cl].nRead; ++nClusRead; } }
+      fprintf(out, "  CLUSTER_SUMMARY %d nRead %d nHash %d nGoodHash %d nClusHash %d nClusRead %d nSubCluster %d\n",
+              code, (int)b->nRead, (int)b->nHash, (int)nGood[code], nClusHash, nClusRead, (int)b->nSubCluster);
+      for (uint32_t i = 1; i <= b->nSubCluster; ++i) {
+        const ReportInfo *r = &info[i]; if (!r->n) continue;
+        fprintf(out, "    CODE_CLUSTER %d %d : %d reads %d hashes", code, (int)i, r->nRead, r->n);
+        if (haveCrib) {
+          fprintf(out, " %d hom, %d htA, %d htB, %d mul, %d err", r->nt[3], r->nt[1], r->nt[2], r->nt[4], r->nt[0]);
+          if (r->chr) fprintf(out, "  chr %d pos %d %d", (int)r->chr, (int)r->pMin, (int)r->pMax - (int)r->pMin + 1);
+          if (r->nBad) {
+            fprintf(out, "  OTHER %d", r->nBad);
+            int x = r->bad, j = 10; char text[64];
+            while (x && j--) { fprintf(out, " %s", crib_text(s, depth, e[x].hash, text)); x = badLink[x]; }
+          }
+        }
+        fputc('\n', out);
+      }
+      totalGoodHash += nGood[code];
+      totalPointToMin += b->pointToMin;
+    }
+    if (totalGoodHash) fprintf(out, "  MIN_POINT_DENSITY %.3f\n", totalPointToMin / totalGoodHash);
+  }
+done:
+  free(blocks); free(ch); free(depth); free(nGood); free(info); free(readClus); free(badLink);
+  return rc;
+}
+
+/* cribSummary (hash10x.c:1017-1061): per crib type, hash entries and distinct hashes in base barcodes and in the barcodes
+   --clusterSplit made (clusterParent != 0) */
+int h10x_session_cribSummary(h10x_session *s, FILE *out) {
+  if (!s->ctx) return fail(s, "no hash state loaded: use readFQB or readHash first");
+  uint32_t dim = 0;
+  if (h10x_crib_sizes(s->ctx, &dim, 0)) { fprintf(stderr, "cribSummary requires crib\n"); return 0; }
+  if (crib_fetch(s)) return -1;
+  h10x_sizes z; if (h10x_get_sizes(s->ctx, &z)) return fail_ctx(s);
+  h10x_block *blocks = (h10x_block *)calloc((size_t)z.nBlocks + 1, sizeof *blocks);
+  h10x_clushash *ch = (h10x_clushash *)malloc(z.nClusHash ? z.nClusHash * 8 : 8);
+  uint8_t *seen = (uint8_t *)calloc((size_t)z.hashNumber + 1, 1);                     /* bit 0: in a base barcode, bit 1: in a cluster barcode */
+  if (!blocks || !ch || !seen) { free(blocks); free(ch); free(seen); return fail(s, "out of host memory for cribSummary"); }
+  if (h10x_export(s->ctx, 0, 0, 0, blocks, ch)) { free(blocks); free(ch); free(seen); return fail_ctx(s); }
+  fprintf(stderr, "made hash objects\n");
+  unsigned long long countBase[5] = {0}, countCluster[5] = {0}; int distinctBase[5] = {0}, distinctCluster[5] = {0};
+  int nBaseCode = 0, nSubClusterCode = 0; uint64_t off = 0;
+  for (uint32_t i = 0; i < z.nBlocks; ++i) {
+    const h10x_block *b = &blocks[i]; const int isCluster = b->clusterParent != 0;
+    if (isCluster) ++nSubClusterCode; else ++nBaseCode;
+    if (i == 0) continue;                                                            /* block 0 owns no hashes (hash10x.c:256) */
+    for (uint32_t j = 0; j < b->nHash; ++j) {
+      const uint32_t h = ch[off + j].hash; const int t = s->cribType[h]; const uint8_t bit = isCluster ? 2 : 1;
+      if (isCluster) ++countCluster[t]; else ++countBase[t];
+      if (!(seen[h] & bit)) { seen[h] |= bit; if (isCluster) ++distinctCluster[t]; else ++distinctBase[t]; }
+    }
+    off += b->nHash;
+  }
+  fprintf(out, "  %d base codes ", nBaseCode);
+  for (int i = 0; i < 5; ++i) fprintf(out, " %s %llu %d %.1f", cribTypeName[i], countBase[i], distinctBase[i], countBase[i] / (double)distinctBase[i]);
+  fprintf(out, "\n  %d cluster codes ", nSubClusterCode);
+  for (int i = 0; i < 5; ++i) fprintf(out, " %s %llu %d %.1f", cribTypeName[i], countCluster[i], distinctCluster[i], countCluster[i] / (double)distinctCluster[i]);
+  fputc('\n', out);
+  free(blocks); free(ch); free(seen);
+  return 0;
 }

@@ -42,6 +42,13 @@ int  h10x_session_clusterSplit(h10x_session *s);                                
 int  h10x_session_hashStats(h10x_session *s, FILE *f);
 int  h10x_session_codeStats(h10x_session *s, FILE *f);
 
+/* --cribBuild <genome1.fa> <genome2.fa>, --clusterReport <codeMin> <codeMax>, --cribSummary (hash10x.c:470-521, 870-952,
+   1017-1061): truth labels from two haplotype FASTAs (hashed and looked up on the device) and the reference's text
+   reports. printTables = the --tables flag (CRIB_TABLE lines). */
+int  h10x_session_cribBuild(h10x_session *s, const char *fa1, const char *fa2, FILE *out, int printTables);
+int  h10x_session_clusterReport(h10x_session *s, int codeMin, int codeMax, FILE *out);
+int  h10x_session_cribSummary(h10x_session *s, FILE *out);
+
 /* multi-GPU (include/h10x.h "multi-GPU"): this rank's contiguous barcode range of the sorted file, cut with
    h10x_host_partition; -N and the chunkSize check are the launcher's business here. After shardGather rank 0's
    session holds the whole state and --writeHash works as usual. */

@@ -60,6 +60,10 @@ static void usage(h10x_session *s) {
   fprintf(stderr, "   --hashDepthRange <min> <max>: set limits for hash counts for cluster\n");
   fprintf(stderr, "   --cluster <codeMin> <codeMax>: cluster reads for range of barcodes (1, 0 for all)\n");
   fprintf(stderr, "   --clusterSplit\n");
+  fprintf(stderr, "   --cribBuild <genome1.fa> <genome2.fa>: match to genomic hashes\n");
+  fprintf(stderr, "   --clusterReport <codeMin> <codeMax>\n");
+  fprintf(stderr, "   --cribSummary\n");
+  fprintf(stderr, "   --tables : toggle the CRIB_TABLE lines of cribBuild\n");
   fprintf(stderr, "   --hashStats : distribution of hash counts and summary info\n");
   fprintf(stderr, "   --codeStats : distribution of barcode/cluster sizes and summary info\n");
   fprintf(stderr, "   --help : print this usage message\n");
@@ -73,6 +77,7 @@ static void say(const char *fmt, ...) {                      /* outFile, and std
 int main(int argc, char **argv) {
   --argc; ++argv;
   outFile = stdout;
+  int printTables = 0;
   timeUpdate(stdout, 0);
   h10x_session *s = h10x_session_new();
   if (!s) die("out of memory");
@@ -97,7 +102,8 @@ int main(int argc, char **argv) {
       if (!strcmp(argv[-1], "-")) outFile = stdout;
       else if (!(outFile = fopen(argv[-1], "w"))) { fprintf(stderr, "can't open output file %s\n", argv[-1]); outFile = stdout; }
     }
-    else if (ARGMATCH("--verbose", 1) || ARGMATCH("--tables", 1)) { /* accepted: no per-barcode text on the device path */ }
+    else if (ARGMATCH("--tables", 1)) printTables = !printTables;                       /* hash10x.c:1198 */
+    else if (ARGMATCH("--verbose", 1)) { /* accepted: no per-barcode text on the device path */ }
     else if (ARGMATCH("--readFQB", 2)) {
       fprintf(outFile, "hash10x initialised with k = %d, w = %d, random seed = %d, hashtable bits = %d\n",
               h10x_session_get(s, "k"), h10x_session_get(s, "w"), h10x_session_get(s, "r"), h10x_session_get(s, "B"));
@@ -143,6 +149,14 @@ int main(int argc, char **argv) {
       }
     }
     else if (ARGMATCH("--clusterSplit", 1)) { if (h10x_session_clusterSplit(s)) die("%s", h10x_session_error(s)); }
+    else if (ARGMATCH("--cribBuild", 3)) { if (h10x_session_cribBuild(s, argv[-2], argv[-1], outFile, printTables)) die("%s", h10x_session_error(s)); }
+    else if (ARGMATCH("--clusterReport", 3)) {
+      if (h10x_session_clusterReport(s, atoi(argv[-2]), atoi(argv[-1]), outFile)) {
+        const char *e = h10x_session_error(s);
+        if (!strncmp(e, "!!", 2)) { fprintf(outFile, "%s\n", e); if (outFile != stdout) fprintf(stderr, "%s\n", e); } else die("%s", e);
+      }
+    }
+    else if (ARGMATCH("--cribSummary", 1)) { if (h10x_session_cribSummary(s, outFile)) die("%s", h10x_session_error(s)); }
     else if (ARGMATCH("--hashStats", 1)) { if (h10x_session_hashStats(s, outFile)) die("%s", h10x_session_error(s)); }
     else if (ARGMATCH("--codeStats", 1)) { if (h10x_session_codeStats(s, outFile)) die("%s", h10x_session_error(s)); }
     else if (ARGMATCH("--help", 1)) usage(s);

@@ -103,6 +103,22 @@ int  h10x_cluster(h10x_ctx *ctx, int32_t codeMin, int32_t codeMax, int32_t clust
 /* replaces clusterSplitCodes() (hash10x.c:956-1013) */
 int  h10x_cluster_split(h10x_ctx *ctx);
 
+/* ---- crib: truth labels from two haplotype genomes (csrc/stage_d.hip) ----
+   h10x_crib_genome replaces cribAddGenome() (hash10x.c:426-453) for one genome: `codes` holds one byte per base
+   (0..3 as readSequence() yields them with dna2indexConv, 'N' -> 0: hash10x.c:432), all sequences concatenated,
+   sequence s = codes[seqStart[s] .. seqStart[s+1]); which = 0 for the first .fa, 1 for the second. nPresent / nAbsent
+   receive the "known" / "unknown" mosh counts the reference prints. h10x_crib_finish is the classification loop of
+   cribBuild() (hash10x.c:476-494): cribType[], the merged crib[], and the four depth histograms (err, het, hom, mul). */
+int  h10x_crib_genome(h10x_ctx *ctx, const uint8_t *codes, const uint64_t *seqStart, uint32_t nSeq, int which,
+                      uint64_t *nPresent, uint64_t *nAbsent);
+int  h10x_crib_finish(h10x_ctx *ctx);
+/* histDim = entries per depth histogram; arrayMax[4] = arrayMax() of the reference's aErr, aHet, aHom, aMul */
+int  h10x_crib_sizes(h10x_ctx *ctx, uint32_t *histDim, uint32_t arrayMax[4]);
+/* copy-out (NULL = skip): chr/pos/type have hashNumber entries (CribInfo.chr, CribInfo.pos, cribType), hist 4 * histDim */
+int  h10x_crib_export(h10x_ctx *ctx, int16_t *chr, uint16_t *pos, uint8_t *type, uint32_t *hist);
+/* per-block good-hash counts (nGoodHashes[], hash10x.c:723) for --clusterReport: nBlocks entries; fails before --hashDepthRange */
+int  h10x_export_ngood(h10x_ctx *ctx, uint32_t *nGood);
+
 /* what writeHashFile() needs (hash10x.c:244-267): sizes, then a copy-out of any subset of the
    tables (NULL = skip). hashIndex: 2^B, hashValue/hashDepth: hashNumber, blocks: nBlocks,
    clusHash: nClusHash entries. */

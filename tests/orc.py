@@ -303,9 +303,10 @@ def build_gen():
     return out
 
 
-def gen_fqb(path, pairs, barcodes, genome, err=0.005, seed=1, mol=10.0, snp=150, mol_len=50000):
+def gen_fqb(path, pairs, barcodes, genome, err=0.005, seed=1, mol=10.0, snp=150, mol_len=50000, fa=None):
+    """fa = prefix: also writes the two haplotypes as prefix.A.fa / prefix.B.fa (the truth genomes for --cribBuild)."""
     subprocess.run([build_gen(), "-o", str(path), "-P", str(pairs), "-C", str(barcodes), "-G", str(genome),
-                    "-e", str(err), "-s", str(seed), "-m", str(mol), "-S", str(snp), "-L", str(mol_len)],
+                    "-e", str(err), "-s", str(seed), "-m", str(mol), "-S", str(snp), "-L", str(mol_len)] + (["-fa", str(fa)] if fa else []),
                    check=True, stderr=subprocess.DEVNULL)
     return np.fromfile(path, dtype=np.uint32).reshape(-1, 30)
 

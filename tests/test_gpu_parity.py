@@ -291,3 +291,40 @@ def test_cli_matches_reference_commands_and_reports(workdir):
     # die() conditions of the command line
     bad = subprocess.run([os.path.join(orc.REPO, "bin", "hash10x-amd"), "-B", "19", "--readFQB", "x.fqb"], cwd=workdir.path, stderr=subprocess.PIPE, stdout=subprocess.PIPE)
     assert bad.returncode == 255 and b"FATAL ERROR: hashTableBits 19 out of range 20-30" in bad.stderr
+
+
+@pytest.mark.skipif(not orc.have_ref(), reason="oracle/_ref not present")
+def test_cli_crib_reports_match_reference(workdir):
+    """--cribBuild (both haplotypes hashed and looked up on the device), --clusterReport, --clusterSplit, --cribSummary:
+    every report line of bin/hash10x-amd equals the reference binary's on the same command line (config 5's accuracy
+    check), including the CRIB_TABLE, the per-cluster chr / pos spans and the OTHER hash lists."""
+    import subprocess
+    orc.gen_fqb(workdir.file("x.fqb"), 30000, 150, 300000, 0.003, 41, 4.0, 150, 6000, fa=workdir.file("x"))
+    # cut both haplotypes into 30 kb "chromosomes" so that clusters straddle sequence boundaries (OTHER lists)
+    for hap in ("A", "B"):
+        lines = open(workdir.file("x.%s.fa" % hap)).read().splitlines()[1:]
+        with open(workdir.file("x.%s.fa" % hap), "w") as f:
+            for i in range(0, len(lines), 500):
+                f.write(">c%d\n%s\n" % (i // 500 + 1, "\n".join(lines[i:i + 500])))
+    # more sequences in haplotype B: lower case, Ns, a record shorter than k, a repeat of part of A ('mul' class)
+    with open(workdir.file("x.B.fa"), "a") as f:
+        f.write(">extra some description\n" + "acgtnACGTN" * 30 + "\n>tiny\nACGT\n>dup\n")
+        a = open(workdir.file("x.A.fa")).read().splitlines()[1:40]
+        f.write("\n".join(a) + "\n")
+    args = ["-B", "20", "-ct", "3", "--readFQB", "x.fqb", "--hashDepthRange", "4", "30", "--cluster", "1", "0", "--tables",
+            "--cribBuild", "x.A.fa", "x.B.fa", "--clusterReport", "0", "0", "--clusterReport", "3", "9", "--clusterSplit", "--cribSummary",
+            "--hashDepthRange", "4", "30", "--clusterReport", "140", "175"]
+    r = orc.run_ref(args, workdir.path)
+    assert r.returncode == 0, r.stderr.decode()
+    g = subprocess.run([os.path.join(orc.REPO, "bin", "hash10x-amd")] + args, cwd=workdir.path, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert g.returncode == 0, g.stderr.decode()
+
+    def report(txt):
+        keep = ("  crib matches", "    hom", "    het", "    mul", "    err", "CRIB_TABLE", "  CLUSTER_SUMMARY", "    CODE_CLUSTER",
+                "  MIN_POINT_DENSITY")
+        return [ln for ln in txt.decode().splitlines() if ln.startswith(keep) or " base codes " in ln or " cluster codes " in ln or " in crib genome" in ln]
+    got, exp = report(g.stdout), report(r.stdout)
+    for i, (a, b) in enumerate(zip(got, exp)):
+        assert a == b, "line %d differs:\n  hip: %s\n  ref: %s" % (i, a, b)
+    assert len(got) == len(exp) and len(got) > 400
+    assert any("OTHER" in ln for ln in got) and any(" mul," in ln for ln in got)
