@@ -276,6 +276,25 @@ int h10x_timing_reset(h10x_ctx *h) {
   for (int i = 0; i < T_COUNT; ++i) { h->c.flush((TimerId)i); h->c.timers[i].ms = 0; h->c.timers[i].launches = 0; }
   return 0;
 }
+int h10x_sort_fqb_device(h10x_ctx *h, const uint32_t *dIn, uint64_t n, uint32_t *dOut) {
+  if (!h) return -1;
+  Ctx &c = h->c; H10X_TRY(enter(c));
+  if (n && (!dIn || !dOut)) return c.fail("h10x_sort_fqb_device: null buffer");
+  return stageA_sortRecords(&c, dIn, n, dOut);
+}
+int h10x_sort_fqb(h10x_ctx *h, const uint32_t *in, uint64_t n, uint32_t *out) {
+  if (!h) return -1;
+  Ctx &c = h->c; H10X_TRY(enter(c));
+  if (n && (!in || !out)) return c.fail("h10x_sort_fqb: null buffer");
+  DevBuf<u32> dIn, dOut;
+  H10X_HIP(&c, dIn.alloc(n * 30)); H10X_HIP(&c, dOut.alloc(n * 30));
+  if (n) H10X_HIP(&c, hipMemcpyAsync(dIn.p, in, n * 120, hipMemcpyHostToDevice, c.stream));
+  H10X_TRY(stageA_sortRecords(&c, dIn.p, n, dOut.p));
+  if (n) H10X_HIP(&c, hipMemcpyAsync(out, dOut.p, n * 120, hipMemcpyDeviceToHost, c.stream));
+  H10X_HIP(&c, hipStreamSynchronize(c.stream));
+  return 0;
+}
+
 int h10x_crib_genome(h10x_ctx *h, const uint8_t *codes, const uint64_t *seqStart, uint32_t nSeq, int which, uint64_t *nPresent, uint64_t *nAbsent) {
   if (!h) return -1;
   Ctx &c = h->c; H10X_TRY(enter(c));

@@ -297,6 +297,36 @@ __global__ void compact_entries_kernel(const u64 *__restrict__ stHash, const u32
   }
 }
 
+// ------------------------------------------------------------------------------------------ record sort
+// What the reference leaves to an external tool (README.md:26 `bsort -k 4 -r 120`): order the 120-byte records by
+// their first four BYTES (byte 0 most significant = the byte-swapped barcode word), so that equal barcodes are
+// contiguous. Stable: records of a barcode keep their file order (bsort is not stable; hash10x only needs the runs).
+__global__ void sort_keys_kernel(const u32 *__restrict__ rec, u64 n, u32 *__restrict__ key, u32 *__restrict__ idx) {
+  u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  const u64 stride = (u64)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) { key[i] = __builtin_bswap32(rec[i * 30]); idx[i] = (u32)i; }
+}
+// one lane per dword: a record's 30 dwords are read from one 120-byte stretch and written fully coalesced
+__global__ void gather_records_kernel(const u32 *__restrict__ rec, const u32 *__restrict__ idx, u64 n, u32 *__restrict__ out) {
+  u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  const u64 stride = (u64)gridDim.x * blockDim.x, total = n * 30;
+  for (; t < total; t += stride) { const u64 j = t / 30; const u32 w = (u32)(t - j * 30); out[t] = rec[(u64)idx[j] * 30 + w]; }
+}
+int stageA_sortRecords(Ctx *c, const u32 *dIn, u64 n, u32 *dOut) {
+  hipStream_t st = c->stream; PrimTemp pt;
+  if (n >= (1ULL << 32)) return c->fail("record sort: %llu records exceed this build's 2^32 limit", (u64)n);
+  if (!n) return 0;
+  DevBuf<u32> key, keyS, idx, idxS;
+  H10X_HIP(c, key.alloc(n)); H10X_HIP(c, keyS.alloc(n)); H10X_HIP(c, idx.alloc(n)); H10X_HIP(c, idxS.alloc(n));
+  const unsigned g = (unsigned)hmin<u64>(divUp(n, 256), 65535u * 4);
+  sort_keys_kernel<<<g, 256, 0, st>>>(dIn, n, key.p, idx.p);
+  H10X_TRY(prim_sort_pairs_u32_u32(c, pt, key.p, keyS.p, idx.p, idxS.p, n, 0, 32));
+  gather_records_kernel<<<(unsigned)hmin<u64>(divUp(n * 30, 256), 65535u * 16), 256, 0, st>>>(dIn, idxS.p, n, dOut);
+  H10X_HIP(c, hipGetLastError());
+  H10X_HIP(c, hipStreamSynchronize(st));
+  return 0;
+}
+
 // ------------------------------------------------------------------------------------------ driver
 int stageA_run(Ctx *c, const u32 *dRec, u64 nRec, DevBuf<u64> &entHash, DevBuf<u32> &entCode, DevBuf<u32> &entRead, bool hashLast) {
   hipStream_t st = c->stream;

@@ -7,6 +7,7 @@
 #include <stdarg.h>
 #include <time.h>
 
+#include <sys/types.h>
 #define ARRAY_MAGIC 8918274                            /* array.h:56 */
 typedef struct { int32_t magic, pad0; uint64_t base; int32_t dim, size, max, pad1; } array_hdr;   /* array.h:41-50 */
 
@@ -617,4 +618,27 @@ int h10x_session_cribSummary(h10x_session *s, FILE *out) {
   fputc('\n', out);
   free(blocks); free(ch); free(seen);
   return 0;
+}
+
+
+/* --sortFQB <in.fqb> <out.fqb>: the record sort between fq2b and --readFQB (README.md:26 shells out to
+   `bsort -k 4 -r 120`), on the device. Needs a context only for its stream and allocator: created with the session's
+   current parameters if there is none yet. */
+int h10x_session_sortFQB(h10x_session *s, const char *inPath, const char *outPath) {
+  FILE *f = fopen(inPath, "rb");
+  if (!f) return fail(s, "failed to open fqb file %s", inPath);
+  fseeko(f, 0, SEEK_END); const off_t bytes = ftello(f); fseeko(f, 0, SEEK_SET);
+  if (bytes % 120) { fclose(f); return fail(s, "%s: size %lld is not a multiple of the 120-byte record", inPath, (long long)bytes); }
+  const uint64_t n = (uint64_t)bytes / 120;
+  uint32_t *in = (uint32_t *)malloc(bytes ? (size_t)bytes : 8), *out = (uint32_t *)malloc(bytes ? (size_t)bytes : 8);
+  int rc = 0; FILE *g = 0;
+  if (!in || !out) { rc = fail(s, "out of host memory for %lld bytes of records", (long long)bytes); goto done; }
+  if (n && fread(in, 120, n, f) != n) { rc = fail(s, "failed to read %s", inPath); goto done; }
+  if (!s->ctx && session_init(s)) { rc = -1; goto done; }
+  if (h10x_sort_fqb(s->ctx, in, n, out)) { rc = fail_ctx(s); goto done; }
+  if (!(g = fopen(outPath, "wb"))) { rc = fail(s, "failed to open output file %s", outPath); goto done; }
+  if (n && fwrite(out, 120, n, g) != n) rc = fail(s, "failed to write %s", outPath);
+done:
+  fclose(f); if (g) fclose(g); free(in); free(out);
+  return rc;
 }

@@ -49,6 +49,10 @@ int  h10x_session_cribBuild(h10x_session *s, const char *fa1, const char *fa2, F
 int  h10x_session_clusterReport(h10x_session *s, int codeMin, int codeMax, FILE *out);
 int  h10x_session_cribSummary(h10x_session *s, FILE *out);
 
+/* --sortFQB <in.fqb> <out.fqb> (addition): the record sort the reference leaves to `bsort -k 4 -r 120` (README.md:26),
+   on the device: records ordered by their first 4 bytes, stably */
+int  h10x_session_sortFQB(h10x_session *s, const char *inPath, const char *outPath);
+
 /* multi-GPU (include/h10x.h "multi-GPU"): this rank's contiguous barcode range of the sorted file, cut with
    h10x_host_partition; -N and the chunkSize check are the launcher's business here. After shardGather rank 0's
    session holds the whole state and --writeHash works as usual. */

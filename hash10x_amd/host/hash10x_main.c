@@ -54,6 +54,7 @@ static void usage(h10x_session *s) {
   fprintf(stderr, "   -t | --threads <n> : accepted and ignored (clustering runs on the GPU)\n");
   fprintf(stderr, "   -o | --output <output filename> : '-' for stdout\n");
   fprintf(stderr, "   --device <HIP device ordinal> [0]\n");
+  fprintf(stderr, "   --sortFQB <fqb from fq2b> <sorted fqb output>: sort records by barcode on the GPU (instead of bsort -k 4 -r 120)\n");
   fprintf(stderr, "   --readFQB <sorted fqb input file name>: must have this or readHash\n");
   fprintf(stderr, "   --readHash <hash input file name>\n");
   fprintf(stderr, "   --writeHash <hash output file name>\n");
@@ -149,6 +150,7 @@ int main(int argc, char **argv) {
       }
     }
     else if (ARGMATCH("--clusterSplit", 1)) { if (h10x_session_clusterSplit(s)) die("%s", h10x_session_error(s)); }
+    else if (ARGMATCH("--sortFQB", 3)) { if (h10x_session_sortFQB(s, argv[-2], argv[-1])) die("%s", h10x_session_error(s)); }
     else if (ARGMATCH("--cribBuild", 3)) { if (h10x_session_cribBuild(s, argv[-2], argv[-1], outFile, printTables)) die("%s", h10x_session_error(s)); }
     else if (ARGMATCH("--clusterReport", 3)) {
       if (h10x_session_clusterReport(s, atoi(argv[-2]), atoi(argv[-1]), outFile)) {

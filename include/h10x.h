@@ -83,6 +83,12 @@ const char *h10x_last_error(const h10x_ctx *ctx);
 int  h10x_read_fqb(h10x_ctx *ctx, const uint32_t *host_records, uint64_t n_records);
 int  h10x_read_fqb_device(h10x_ctx *ctx, const uint32_t *dev_records, uint64_t n_records);
 
+/* replaces the external record sort between fq2b and hash10x (README.md:26 `bsort -k 4 -r 120 x.fqb`): orders the
+   120-byte records by their first 4 bytes (byte 0 most significant), stably, so that equal barcodes are contiguous.
+   in / out must not overlap. _device: both buffers in device memory. */
+int  h10x_sort_fqb(h10x_ctx *ctx, const uint32_t *host_in, uint64_t n_records, uint32_t *host_out);
+int  h10x_sort_fqb_device(h10x_ctx *ctx, const uint32_t *dev_in, uint64_t n_records, uint32_t *dev_out);
+
 /* replaces the state that readHashFile() + fillHashTable() leave behind (hash10x.c:269-315,
    317-347): uploads the tables of a parsed .hash file and rebuilds the hash->barcode lists.
    hashDepth has hashNumber entries, blocks has nBlocks entries (entry 0 unused), clusHash is the

@@ -328,3 +328,22 @@ def test_cli_crib_reports_match_reference(workdir):
         assert a == b, "line %d differs:\n  hip: %s\n  ref: %s" % (i, a, b)
     assert len(got) == len(exp) and len(got) > 400
     assert any("OTHER" in ln for ln in got) and any(" mul," in ln for ln in got)
+
+
+def test_sort_fqb_on_device(workdir):
+    """--sortFQB (the reference leaves this step to `bsort -k 4 -r 120`): records ordered by their first four bytes,
+    stably — equal to numpy's stable sort on the byte-swapped barcode word; the sorted file then reads like any other."""
+    import subprocess
+    recs = orc.gen_fqb(workdir.file("x.fqb"), 20000, 300, 200000, 0.003, 47, 3.0, 150, 5000)
+    rng = np.random.default_rng(3)
+    shuffled = recs[rng.permutation(recs.shape[0])]
+    shuffled.tofile(workdir.file("shuf.fqb"))
+    g = subprocess.run([os.path.join(orc.REPO, "bin", "hash10x-amd"), "--sortFQB", "shuf.fqb", "sorted.fqb", "-B", "20", "--readFQB", "sorted.fqb",
+                        "--writeHash", "hip.hash"], cwd=workdir.path, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert g.returncode == 0, g.stderr.decode()
+    got = np.fromfile(workdir.file("sorted.fqb"), dtype=np.uint32).reshape(-1, 30)
+    exp = shuffled[np.argsort(shuffled[:, 0].byteswap(), kind="stable")]
+    assert got.shape == exp.shape and np.array_equal(got, exp)
+    o = orc.Oracle(B=20); o.read_fqb(exp.reshape(-1)); o.write_hash(workdir.file("orc.hash"))
+    a, b = open(workdir.file("hip.hash"), "rb").read(), open(workdir.file("orc.hash"), "rb").read()
+    assert a == b, orc.describe_diff(a, b)

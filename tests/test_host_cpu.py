@@ -108,3 +108,41 @@ def test_partition_cuts_on_barcode_boundaries(native):
         for x in c[1:-1]:
             assert x == n or recs[x, 0] != recs[x - 1, 0]
         assert max(np.diff(c)) <= n / parts + 400       # balanced up to one barcode
+
+
+@pytest.mark.skipif(not os.path.exists(os.path.join(orc.REF_DIR, "fq2b")), reason="oracle/_ref/fq2b not present")
+@pytest.mark.parametrize("whitelist", [False, True])
+def test_fq2b_matches_reference_bytes_and_stats(tmp_path, whitelist):
+    """bin/fq2b-amd against the reference's fq2b on the same gzipped FASTQ pair: identical .fqb bytes (2-bit packing with
+    the unjustified tail word, quality bits, N -> A) and identical statistics, with and without the 10x whitelist
+    (one-mismatch correction, dropped pairs)."""
+    import gzip
+    rng = np.random.default_rng(5)
+    wl = ["".join(rng.choice(list("ACGT"), 16)) for _ in range(40)]
+    n = 600
+    with gzip.open(tmp_path / "r1.fq.gz", "wt") as f1, gzip.open(tmp_path / "r2.fq.gz", "wt") as f2:
+        for i in range(n):
+            bc = list(wl[rng.integers(len(wl))])
+            u = rng.random()
+            if u < 0.3:
+                bc[rng.integers(16)] = "ACGT"[rng.integers(4)]                     # at most one mismatch (or none)
+            elif u < 0.4:
+                bc = list(rng.choice(list("ACGT"), 16))                              # random: usually dropped
+            elif u < 0.45:
+                bc[rng.integers(16)] = "N"
+            s1 = "".join(bc) + "".join(rng.choice(list("ACGTN"), 135, p=[.24, .24, .24, .24, .04]))
+            s2 = "".join(rng.choice(list("acgtACGTN"), 151))
+            q1 = "".join(chr(int(c)) for c in rng.integers(35, 75, 151))
+            q2 = "".join(chr(int(c)) for c in rng.integers(35, 75, 151))
+            f1.write("@read%d 1:N:0\n%s\n+\n%s\n" % (i, s1, q1))
+            f2.write("@read%d %s\n%s\n+\n%s\n" % (i, "1:N:0" if i != 7 else "2:N:0", s2, q2))
+    (tmp_path / "wl.txt").write_text("\n".join(wl) + "\n")
+    opts = ["-10x", "wl.txt"] if whitelist else []
+    ref = subprocess.run([os.path.join(orc.REF_DIR, "fq2b")] + opts + ["-o", "ref.fqb", "r1.fq.gz", "r2.fq.gz"], cwd=tmp_path, stderr=subprocess.PIPE)
+    got = subprocess.run([os.path.join(REPO, "bin", "fq2b-amd")] + opts + ["-o", "hip.fqb", "r1.fq.gz", "r2.fq.gz"], cwd=tmp_path, stderr=subprocess.PIPE)
+    assert ref.returncode == 0 and got.returncode == 0, (ref.stderr, got.stderr)
+    a, b = (tmp_path / "ref.fqb").read_bytes(), (tmp_path / "hip.fqb").read_bytes()
+    assert len(a) % 120 == 0 and len(a) > 0 and a == b
+    assert got.stderr == ref.stderr and b"read pairs 151 + 151 bp packed in 30 word records" in got.stderr
+    if whitelist:
+        assert len(a) < n * 120 and b"were error corrected" in got.stderr
