@@ -330,3 +330,20 @@ class Hash10x:
         if self._hip.h10x_export(self._ctx(), None, None, None, b.ctypes.data, None):
             raise Hash10xError(self._hip.h10x_last_error(self._ctx()).decode())
         return b
+
+    def export_clushash(self):
+        """All ClusterHash records (blocks 1.. concatenated) as a structured array."""
+        z = self.sizes()
+        dt = np.dtype([("hash", "<u4"), ("read", "<u2"), ("subCluster", "u1"), ("flags", "u1")])
+        ch = np.zeros(max(z["nClusHash"], 1), dtype=dt)
+        if self._hip.h10x_export(self._ctx(), None, None, None, None, ch.ctypes.data):
+            raise Hash10xError(self._hip.h10x_last_error(self._ctx()).decode())
+        return ch[: z["nClusHash"]]
+
+    def export_depth(self):
+        """hashDepth[0 .. hashNumber) as uint32."""
+        z = self.sizes()
+        d = np.zeros(z["hashNumber"], dtype=np.uint32)
+        if self._hip.h10x_export(self._ctx(), None, None, d.ctypes.data, None, None):
+            raise Hash10xError(self._hip.h10x_last_error(self._ctx()).decode())
+        return d

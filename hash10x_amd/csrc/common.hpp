@@ -140,6 +140,7 @@ struct Ctx {
   DevBuf<u8>  within;         // hashNumber
   DevBuf<u16> goodPos;        // H : per block [blockOff[c], blockOff[c]+nGood[c])
   DevBuf<u32> nGood;          // nBlocks
+  DevBuf<u32> goodEntries;    // nBlocks : sum of the depths of a block's good hashes = entries of its barcode lists
   bool haveRange = false, haveGood = false; int rangeMin = 0, rangeMax = 0;
   u32 maxGoodDepth = 0, maxGood = 0;
 

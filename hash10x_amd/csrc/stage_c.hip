@@ -52,18 +52,19 @@ __global__ void within_depth_kernel(const u32 *__restrict__ depth, const u8 *__r
 __global__ __launch_bounds__(256)
 void good_keys_kernel(const h10x_clushash *__restrict__ ch, const u64 *__restrict__ blockOff, const h10x_block *__restrict__ blocks,
                       u32 nBlocks, const u8 *__restrict__ within, const u32 *__restrict__ depth,
-                      u64 *__restrict__ key, u32 *__restrict__ nGood, u32 *__restrict__ segEnd) {
-  __shared__ u32 sCount;
+                      u64 *__restrict__ key, u32 *__restrict__ nGood, u32 *__restrict__ segEnd, u32 *__restrict__ entries /* sum of depths, saturating */) {
+  __shared__ u32 sCount; __shared__ unsigned long long sDepth;
   for (u32 c = blockIdx.x; c < nBlocks; c += gridDim.x) {
     const u64 o = blockOff[c]; const u32 nHash = blocks[c].nHash;
     __syncthreads();
-    if (threadIdx.x == 0) sCount = 0;
+    if (threadIdx.x == 0) { sCount = 0; sDepth = 0; }
     __syncthreads();
+    unsigned long long myDepth = 0;
     if (nHash <= 65535) {                                    // hash10x.c:748-753: bigger blocks are ignored
       for (u32 base = 0; base < nHash; base += blockDim.x) {
         const u32 p = base + threadIdx.x;
         u32 ix = 0; bool good = false;
-        if (p < nHash) { ix = ch[o + p].hash; good = within[ix] != 0; }
+        if (p < nHash) { ix = ch[o + p].hash; good = within[ix] != 0; if (good) myDepth += depth[ix]; }
         const u64 bal = __ballot(good);
         const int lane = threadIdx.x & (WAVE - 1);
         u32 wb = 0;
@@ -72,8 +73,10 @@ void good_keys_kernel(const h10x_clushash *__restrict__ ch, const u64 *__restric
         if (good) key[o + wb + (u32)__popcll(bal & ((1ULL << lane) - 1))] = ((u64)depth[ix] << 16) | (u64)p;
       }
     }
+    for (int sft = 32; sft; sft >>= 1) myDepth += __shfl_down(myDepth, sft);
+    if ((threadIdx.x & (WAVE - 1)) == 0 && myDepth) atomicAdd(&sDepth, myDepth);
     __syncthreads();
-    if (threadIdx.x == 0) { nGood[c] = sCount; segEnd[c] = (u32)o + sCount; }
+    if (threadIdx.x == 0) { nGood[c] = sCount; segEnd[c] = (u32)o + sCount; entries[c] = sDepth > 0xFFFFFFFFull ? 0xFFFFFFFFu : (u32)sDepth; }
   }
 }
 __global__ void good_pos_kernel(const u64 *__restrict__ key, u64 n, u16 *__restrict__ pos) {
@@ -102,11 +105,11 @@ int stageC_depthRange(Ctx *c, int lo, int hi) {
   DevBuf<u64> key, keyS; DevBuf<u32> off32, segEnd, wdepth, red;
   H10X_HIP(c, key.alloc(H)); H10X_HIP(c, keyS.alloc(H)); H10X_HIP(c, off32.alloc((size_t)nBlocks + 1));
   H10X_HIP(c, segEnd.alloc(nBlocks)); H10X_HIP(c, wdepth.alloc(U1)); H10X_HIP(c, red.alloc(2));
-  H10X_HIP(c, c->nGood.alloc(nBlocks)); H10X_HIP(c, c->goodPos.alloc(H));
+  H10X_HIP(c, c->nGood.alloc(nBlocks)); H10X_HIP(c, c->goodPos.alloc(H)); H10X_HIP(c, c->goodEntries.alloc(nBlocks));
   within_depth_kernel<<<divUp(U1, 256), 256, 0, st>>>(c->hashDepth.p, c->within.p, U1, wdepth.p);
   H10X_TRY(prim_reduce_max_u32(c, pt, wdepth.p, red.p, U1));
   good_keys_kernel<<<hmin<u32>(nBlocks, 16384), 256, 0, st>>>(c->clusHash.p, c->blockOff.p, c->blocks.p, nBlocks, c->within.p,
-                                                            c->hashDepth.p, key.p, c->nGood.p, segEnd.p);
+                                                            c->hashDepth.p, key.p, c->nGood.p, segEnd.p, c->goodEntries.p);
   H10X_TRY(prim_reduce_max_u32(c, pt, c->nGood.p, red.p + 1, nBlocks));
   u32 hr[2];
   H10X_HIP(c, hipMemcpyAsync(hr, red.p, 8, hipMemcpyDeviceToHost, st));
@@ -135,7 +138,7 @@ struct ClusterArgs {
   u32 nBlocks; int threshold;
   u32 codeBase;                                             // sharded runs: global barcode number = codeBase + local block number
   u32 nBlocksFirst;                                         // size of first[]: barcodes of the whole data set + 1
-  u32 firstCap;                                             // ranked placement: first[] entries available (barcodes present in a block)
+  u32 firstCap;                                             // ranked placement, test knob: cap on the first[] entries of a block (0 = what the budget leaves)
   u32 *overflow, *overflowCount;                            // ranked placement: blocks with more present barcodes than firstCap
   unsigned char *scratch; size_t scratchStride;             // global-mode working set per workgroup
   u32 maxGood;
@@ -150,7 +153,7 @@ struct ClusterArgs {
 // depth range is longer than 65535), u32 on the HBM scratch.
 template <typename CT> struct Work {
   u16 *first;        // NONE16 = unseen; indexed by barcode (dense) or by the barcode's rank among those present (ranked)
-  u32 *bm, *pre;     // ranked placement: presence bitmap over all barcodes and its exclusive popcount prefix per word
+  u32 *bm; u16 *pre; // ranked placement: presence bitmap over all barcodes and its exclusive popcount prefix per word (< 65536 present)
   u32 *rs;           // offset of the rank's barcode list in rows[] (prefetched once)
   CT  *dd;           // its length (hashDepth)
   CT  *cnt, *tot;    // msMax / msTot per rank; cnt later holds minShareCount[clusterMin] (phase d)
@@ -161,7 +164,7 @@ template <typename CT> struct Work {
   u32 histWords;     // words per wave
 };
 __host__ __device__ inline size_t workBytes(u32 nFirst, u32 n, u32 nWaves, u32 bmWords, u32 ctBytes) {
-  size_t b = (((size_t)nFirst * 2 + 15) & ~(size_t)15) + (size_t)bmWords * 8;
+  size_t b = (((size_t)nFirst * 2 + 15) & ~(size_t)15) + (size_t)bmWords * 4 + (((size_t)bmWords * 2 + 3) & ~(size_t)3);
   b += (size_t)n * 4;                                       // rs
   b += (((size_t)n * ctBytes + 3) & ~(size_t)3) * 3;        // dd, cnt, tot
   b += (((size_t)n * 2 + 3) & ~(size_t)3) * 2;              // best, qj
@@ -172,6 +175,14 @@ __host__ __device__ inline size_t workBytes(u32 nFirst, u32 n, u32 nWaves, u32 b
 // waves of the workgroup that take part in the list loop of a barcode with n ranks: as many as have room for a private
 // histogram in what the fixed part leaves of `budget` (0 = does not fit; the replay's temporaries need >= MIN_HIST_WAVES)
 constexpr u32 MIN_HIST_WAVES = 5;
+constexpr u32 RANKED_FIRST_PER_RANK = 8;                    // ranked placement: first[] entries budgeted per rank when a block is classified
+                                                           // (3-7 barcodes present per rank on the synthetic sets); the kernel then takes
+                                                           // whatever the budget leaves, and a block that still overflows is re-run with
+                                                           // first[] on an HBM slot
+__host__ __device__ inline u32 rankedFirstEstimate(u32 nBarcodes, u32 n) { const u64 e = (u64)RANKED_FIRST_PER_RANK * n; return e < nBarcodes ? (u32)e : nBarcodes; }
+// … and, where the entries of the block's lists are known (classification): a fifth of them (6-8 % on the yeast-like sets,
+// more on deeper ones), whichever is larger
+__host__ __device__ inline u32 rankedFirstEstimateE(u32 nBarcodes, u32 n, u32 entries) { const u32 a = rankedFirstEstimate(nBarcodes, n), b = entries / 5; const u32 m = a > b ? a : b; return m < nBarcodes ? m : nBarcodes; }
 __host__ __device__ inline u32 histWaves(u32 nFirst, u32 n, u32 maxWaves, u32 bmWords, u32 ctBytes, size_t budget) {
   const size_t fixed = workBytes(nFirst, n, 0, bmWords, ctBytes), per = (((size_t)n + 3) / 4) * 4;
   if (fixed + MIN_HIST_WAVES * per > budget) return 0;
@@ -184,7 +195,7 @@ __device__ inline Work<CT> carve(unsigned char *base, u32 nFirst, u32 n, u32 bmW
   const size_t ctb = ((size_t)n * sizeof(CT) + 3) & ~(size_t)3, b2 = ((size_t)n * 2 + 3) & ~(size_t)3;
   w.first = (u16 *)(base + o); o += (((size_t)nFirst * 2 + 15) & ~(size_t)15);
   w.bm = (u32 *)(base + o); o += (size_t)bmWords * 4;
-  w.pre = (u32 *)(base + o); o += (size_t)bmWords * 4;
+  w.pre = (u16 *)(base + o); o += ((size_t)bmWords * 2 + 3) & ~(size_t)3;
   w.rs = (u32 *)(base + o); o += (size_t)n * 4;
   w.dd = (CT *)(base + o); o += ctb;
   w.cnt = (CT *)(base + o); o += ctb;
@@ -214,7 +225,7 @@ template <bool IN_LDS, typename T> __device__ __forceinline__ T ld_shared(const 
 // 1 bit + 1/8 B per barcode of the data set instead of 2 B per barcode of the data set)
 struct MapDense { __device__ __forceinline__ u32 operator()(u32 cj) const { return cj; } };
 struct MapRanked {
-  const u32 *bm, *pre;
+  const u32 *bm; const u16 *pre;
   __device__ __forceinline__ u32 operator()(u32 cj) const { const u32 w = cj >> 5; return pre[w] + (u32)__popc(bm[w] & ((1u << (cj & 31)) - 1u)); }
 };
 
@@ -337,13 +348,21 @@ __device__ void cluster_one_block(const ClusterArgs &a, u32 code, unsigned char 
   constexpr bool FIRST_LDS = IN_LDS && FIRST_MODE != 2;
   constexpr bool RANKED = IN_LDS && FIRST_MODE == 1;
   const u32 bmWords = RANKED ? (a.nBlocksFirst + 31) / 32 : 0;
-  Work<CT> w = carve<CT>(region, RANKED ? a.firstCap : (FIRST_LDS || !IN_LDS ? a.nBlocksFirst : 0), n, bmWords);
+  // list-loop waves: all of them where the histograms fit, fewer for a barcode with many ranks (one kernel and one
+  // work queue then serve nearly every barcode; the rest of the phases always use the whole workgroup)
+  const u32 nW = IN_LDS ? histWaves(RANKED ? rankedFirstEstimate(a.nBlocksFirst, n) : (FIRST_LDS ? a.nBlocksFirst : 0), n, CL_WAVES, bmWords, sizeof(CT), a.ldsBudget) : (u32)CL_WAVES;
+  if (!nW) return;                                           // cannot happen: the classification sends such a barcode to the HBM-scratch class
+  u32 firstCap = 0;                                          // ranked placement: first[] gets every byte the budget leaves
+  if constexpr (RANKED) {
+    const size_t used = workBytes(0, n, nW, bmWords, sizeof(CT));
+    const size_t room = a.ldsBudget > used + 32 ? (a.ldsBudget - used - 32) / 2 : 0;
+    firstCap = (u32)(room < 65535 ? room : 65535); if (firstCap > a.nBlocksFirst) firstCap = a.nBlocksFirst;
+    if (a.firstCap && firstCap > a.firstCap) firstCap = a.firstCap;          // test knob
+  }
+  Work<CT> w = carve<CT>(region, RANKED ? firstCap : (FIRST_LDS || !IN_LDS ? a.nBlocksFirst : 0), n, bmWords);
   if (IN_LDS && FIRST_MODE == 2) w.first = firstGlobal;      // hybrid: first[] on this workgroup's HBM slot, the rest in LDS
   typename std::conditional<RANKED, MapRanked, MapDense>::type fm{};
   if constexpr (RANKED) { fm.bm = w.bm; fm.pre = w.pre; }
-  // list-loop waves: all of them where the histograms fit, fewer for a barcode with many ranks (one kernel and one
-  // work queue then serve nearly every barcode; the rest of the phases always use the whole workgroup)
-  const u32 nW = IN_LDS ? histWaves(RANKED ? a.firstCap : (FIRST_LDS ? a.nBlocksFirst : 0), n, CL_WAVES, bmWords, sizeof(CT), a.ldsBudget) : (u32)CL_WAVES;
   const u32 lcode = code; code += a.codeBase;                // from here on `code` is the global barcode number (what the lists hold)
   h10x_clushash *ch = a.clusHash + o; const u16 *g = a.goodPos + o;
 
@@ -377,8 +396,8 @@ __device__ void cluster_one_block(const ClusterArgs &a, u32 code, unsigned char 
     SYNC();
     u32 run = inc - mine, total = 0;
     for (int q = 0; q < CL_WAVES; ++q) { if (q < wave) run += sh[4 + q]; total += sh[4 + q]; }
-    for (u32 q = s0; q < s1; ++q) { w.pre[q] = run; run += (u32)__popc(w.bm[q]); }
-    if (total > a.firstCap) {                                 // uniform: every thread sees the same total
+    for (u32 q = s0; q < s1; ++q) { w.pre[q] = (u16)run; run += (u32)__popc(w.bm[q]); }
+    if (total > firstCap) {                                   // uniform: every thread sees the same total
       if (tid == 0) a.overflow[atomicAdd(a.overflowCount, 1u)] = lcode;
       SYNC();
       return;
@@ -689,8 +708,8 @@ void read_merge_kernel(h10x_block *__restrict__ blocks, const u64 *__restrict__ 
 
 // launch classes by working-set size: 0 = half a CU's LDS (barcodes with many ranks run their list loop on fewer waves:
 // histWaves), 2 = the whole LDS of a CU, 3 = HBM scratch (class 1 is no longer used)
-__global__ void cluster_classify_kernel(const h10x_block *__restrict__ blocks, const u32 *__restrict__ nGood, u32 codeMin, u32 codeMax,
-                                        u32 nBlocks /* LDS entries of first[] */, u32 bmWords, u32 waves0, size_t budget0, size_t budgetSmall, size_t budgetBig, int wide,
+__global__ void cluster_classify_kernel(const h10x_block *__restrict__ blocks, const u32 *__restrict__ nGood, const u32 *__restrict__ entries, u32 codeMin, u32 codeMax,
+                                        u32 nBlocks /* LDS entries of first[] (ranked: barcodes of the data set) */, int ranked, u32 bmWords, u32 waves0, size_t budget0, size_t budgetSmall, size_t budgetBig, int wide,
                                         u32 *__restrict__ list0, u32 *__restrict__ list1, u32 *__restrict__ list2, u32 *__restrict__ list3,
                                         u32 *__restrict__ counts) {
   const u32 c = codeMin + blockIdx.x * blockDim.x + threadIdx.x;
@@ -700,8 +719,8 @@ __global__ void cluster_classify_kernel(const h10x_block *__restrict__ blocks, c
   if (n) {
     nRead = blocks[c].nRead;
     if (wide) cls = 3;                                       // counts do not fit the u16 arrays of the LDS instantiations
-    else if (histWaves(nBlocks, n, waves0, bmWords, 2, budget0)) cls = 0;
-    else if (histWaves(nBlocks, n, CL_THREADS_HUGE / WAVE, bmWords, 2, budgetBig)) cls = 2;
+    else if (histWaves(ranked ? rankedFirstEstimateE(nBlocks, n, entries[c]) : nBlocks, n, waves0, bmWords, 2, budget0)) cls = 0;
+    else if (histWaves(ranked ? rankedFirstEstimate(nBlocks, n) : nBlocks, n, CL_THREADS_HUGE / WAVE, bmWords, 2, budgetBig)) cls = 2;
     else cls = 3;
   }
   for (int s = 32; s; s >>= 1) nRead = max(nRead, (u32)__shfl_xor((int)nRead, s));
@@ -744,13 +763,13 @@ int stageC_cluster(Ctx *c, int codeMin, int codeMax, int threshold) {
   // first[] (2 B per barcode of the data set) stays in LDS while it is small; past that each workgroup keeps it on an
   // HBM slot of its own (L2/MALL resident, atomics + L1-bypassing loads) and only the per-rank arrays live in LDS
   const u32 bmWordsAll = (nGlobal + 31) / 32;
-  int firstMode = (size_t)nGlobal * 2 <= 48 * 1024 ? 0 : ((size_t)bmWordsAll * 8 <= 64 * 1024 ? 1 : 2);
+  int firstMode = (size_t)nGlobal * 2 <= 48 * 1024 ? 0 : ((size_t)bmWordsAll * 6 <= 48 * 1024 ? 1 : 2);
   if (c->optFirstGlobal == 1) firstMode = 2; else if (c->optFirstGlobal == 2) firstMode = 1;   // test knobs
-  const u32 firstCap = hmin<u32>(nGlobal, c->optFirstCap > 0 ? (u32)c->optFirstCap : 12288u);
-  const u32 nFirstLds = firstMode == 0 ? nGlobal : (firstMode == 1 ? firstCap : 0);
+  const u32 firstCap = c->optFirstCap > 0 ? (u32)c->optFirstCap : 0u;      // test knob only
+  const u32 nFirstLds = firstMode == 0 ? nGlobal : 0;
   const u32 bmWords = firstMode == 1 ? bmWordsAll : 0;
   const int wide = c->maxGoodDepth > 65535u ? 1 : 0;         // list lengths / counts beyond the u16 arrays of the LDS instantiations
-  cluster_classify_kernel<<<divUp(span, 256), 256, 0, st>>>(c->blocks.p, c->nGood.p, (u32)codeMin, (u32)codeMax, nFirstLds, bmWords, (u32)threads0 / WAVE, budget0, budgetSmall, budgetBig, wide,
+  cluster_classify_kernel<<<divUp(span, 256), 256, 0, st>>>(c->blocks.p, c->nGood.p, c->goodEntries.p, (u32)codeMin, (u32)codeMax, firstMode == 1 ? nGlobal : nFirstLds, firstMode == 1 ? 1 : 0, bmWords, (u32)threads0 / WAVE, budget0, budgetSmall, budgetBig, wide,
                                                           list0.p, list1.p, list2.p, list3.p, counts.p);
   u32 hc[12];
   H10X_HIP(c, hipMemcpyAsync(hc, counts.p, 48, hipMemcpyDeviceToHost, st));
@@ -819,13 +838,16 @@ int stageC_cluster(Ctx *c, int codeMin, int codeMax, int threshold) {
     H10X_HIP(c, hipMemcpyAsync(&nOverflow, overflow.p, 4, hipMemcpyDeviceToHost, st));
     H10X_HIP(c, hipStreamSynchronize(st));
     if (nOverflow) {
-      const size_t stride2 = (workBytes(nGlobal, c->maxGood, CL_THREADS_SMALL / WAVE, 0, 4) + 255) & ~(size_t)255;
+      // re-run with first[] dense on a per-workgroup HBM slot and everything else in LDS (the hybrid form): a block that
+      // was classified for LDS with its first[] estimate fits the whole-CU budget without it
       const u32 grid = hmin<u32>(nOverflow, (u32)c->numCU);
-      H10X_HIP(c, scratch2.alloc(stride2 * grid));
-      H10X_HIP(c, hipMemsetAsync(scratch2.p, 0xFF, stride2 * grid, st));
+      H10X_HIP(c, scratch2.alloc(firstStride * grid));
+      H10X_HIP(c, hipMemsetAsync(scratch2.p, 0xFF, firstStride * grid, st));
       H10X_HIP(c, hipMemsetAsync(counts.p + 7, 0, 4, st));
-      ClusterArgs g = a; g.list = overflow.p + 1; g.nList = nOverflow; g.workCounter = counts.p + 7; g.scratch = scratch2.p; g.scratchStride = stride2;
-      cluster_kernel<false, 2, CL_THREADS_SMALL><<<grid, CL_THREADS_SMALL, 0, st>>>(g);
+      ClusterArgs g = a; g.list = overflow.p + 1; g.nList = nOverflow; g.workCounter = counts.p + 7; g.scratch = scratch2.p; g.scratchStride = firstStride;
+      g.ldsBudget = (u32)budgetBig;
+      H10X_HIP(c, hipFuncSetAttribute((const void *)cluster_kernel<true, 2, CL_THREADS_HUGE, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)budgetBig));
+      cluster_kernel<true, 2, CL_THREADS_HUGE, 3><<<grid, CL_THREADS_HUGE, budgetBig, st>>>(g);
       H10X_HIP(c, hipGetLastError());
     }
   }
@@ -947,7 +969,7 @@ int stageC_split(Ctx *c) {
   H10X_HIP(c, hipStreamSynchronize(st));
   c->blocks.swap(newB); c->blockOff.swap(newOff); c->clusHash.swap(out);
   c->nBlocks = nNew;
-  c->haveGood = false; c->goodPos.release(); c->nGood.release();      // lists refer to the old blocks: a new --hashDepthRange is required
+  c->haveGood = false; c->goodPos.release(); c->nGood.release(); c->goodEntries.release();      // lists refer to the old blocks: a new --hashDepthRange is required
   H10X_TRY(stageB_buildCSR(c));                              // hash10x.c:1008-1012: hashCodes rebuilt, hashDepth unchanged
   c->tstop(T_SPLIT);
   return 0;
