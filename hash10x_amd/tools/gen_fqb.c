@@ -136,11 +136,24 @@ static uint64_t generate(const h10x_gen_params *p, uint32_t *out, FILE *f) {
 
   /* distinct non-zero barcodes, ascending */
   uint32_t *bc = (uint32_t *)malloc(sizeof(uint32_t) * (size_t)C);
-  for (;;) {
-    for (uint32_t i = 0; i < C; ++i) { uint32_t b; do b = (uint32_t)rng_next(&r); while (!b); bc[i] = b; }
-    qsort(bc, C, sizeof(uint32_t), cmp_u32);
-    int dup = 0; for (uint32_t i = 1; i < C; ++i) if (bc[i] == bc[i - 1]) { dup = 1; break; }
-    if (!dup) break;
+  if (C <= 100000) {
+    for (;;) {                                                /* redraw everything on a duplicate: fine while C^2 << 2^33 */
+      for (uint32_t i = 0; i < C; ++i) { uint32_t b; do b = (uint32_t)rng_next(&r); while (!b); bc[i] = b; }
+      qsort(bc, C, sizeof(uint32_t), cmp_u32);
+      int dup = 0; for (uint32_t i = 1; i < C; ++i) if (bc[i] == bc[i - 1]) { dup = 1; break; }
+      if (!dup) break;
+    }
+  } else {
+    /* many barcodes: duplicates among C random 32-bit words are certain (birthday bound), so keep the distinct ones
+       and top up until there are C (sets of up to 100000 barcodes keep the older scheme and therefore their data) */
+    uint32_t have = 0;
+    while (have < C) {
+      for (uint32_t i = have; i < C; ++i) { uint32_t b; do b = (uint32_t)rng_next(&r); while (!b); bc[i] = b; }
+      qsort(bc, C, sizeof(uint32_t), cmp_u32);
+      uint32_t u = 0;
+      for (uint32_t i = 0; i < C; ++i) if (i == 0 || bc[i] != bc[i - 1]) bc[u++] = bc[i];
+      have = u;
+    }
   }
 
   /* molecules per barcode */

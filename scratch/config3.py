@@ -10,6 +10,12 @@ import numpy as np, bench, hash10x_amd
 a = [int(x) for x in sys.argv[1:]] + [None] * 4
 wl = dict(pairs=(a[0] or 200) * 1000000, barcodes=(a[1] or 1000) * 1000, genome=(a[2] or 500) * 1000000, err=0.001, mol=10.0, snp=150, mol_len=50000.0,
           B=a[3] or 28, lo=30, hi=100, ct=5)
+import threading
+_stop = threading.Event()
+def _beat():                                                  # gpurun kills a run that stays silent for 7 minutes
+    t0 = time.time()
+    while not _stop.wait(45): print("  ... %.0f s" % (time.time() - t0), flush=True)
+threading.Thread(target=_beat, daemon=True).start()
 t = time.time(); recs = bench.generate(wl, 2); print("generated %d pairs in %.1fs" % (recs.size // 30, time.time() - t), flush=True)
 h = hash10x_amd.Hash10x(B=wl["B"]); h.enable_timing(True)
 t = time.time(); dr = hash10x_amd.DeviceRecords(recs); print("uploaded %.1f GB in %.1fs" % (recs.nbytes / 1e9, time.time() - t), flush=True)
@@ -29,6 +35,7 @@ print("device ms (last pass)", {k: round(v[0], 2) for k, v in tm.items() if v[0]
 alg = 4.0 * c["sum_good_depth"] + 14.0 * c["sum_good"] + 16.0 * c["sum_hash_clustered"]
 print("cluster_kernel: %.2f GB algorithmic in %.1f ms -> %.0f GB/s = %.1f %% of 8 TB/s" % (alg / 1e9, tm["cluster_kernel"][0], alg / (tm["cluster_kernel"][0] * 1e-3) / 1e9,
       alg / (tm["cluster_kernel"][0] * 1e-3) / 8e12 * 100))
+_stop.set()
 print("determinism: two passes", "identical" if digests[0] == digests[1] else "DIFFER", digests[0][:16])
 # invariants of the state (size-independent properties)
 off = np.concatenate([[0], np.cumsum(b["nHash"][1:].astype(np.int64))])
