@@ -139,7 +139,9 @@ struct ClusterArgs {
   u32 codeBase;                                             // sharded runs: global barcode number = codeBase + local block number
   u32 nBlocksFirst;                                         // size of first[]: barcodes of the whole data set + 1
   u32 firstCap;                                             // ranked placement, test knob: cap on the first[] entries of a block (0 = what the budget leaves)
-  u32 *overflow, *overflowCount;                            // ranked placement: blocks with more present barcodes than firstCap
+  u32 hashMask, hashMinSlots;                               // hashed placement: 2^b - 1 with 2^b >= barcodes of the data set; slots below which the 8-bit tag is too narrow
+  const u32 *entries;                                       // per block: entries of its barcode lists (sum of depths of its good hashes)
+  u32 *overflow, *overflowCount;                            // ranked / hashed placement: blocks whose table was too small (re-run in the next larger placement)
   unsigned char *scratch; size_t scratchStride;             // global-mode working set per workgroup
   u32 maxGood;
   u32 ldsBudget;                                            // LDS bytes of the launch class (list loop: as many waves as have room for a histogram)
@@ -189,6 +191,25 @@ __host__ __device__ inline u32 histWaves(u32 nFirst, u32 n, u32 maxWaves, u32 bm
   const size_t wv = (budget - fixed) / (per ? per : 1);
   return wv < maxWaves ? (u32)wv : maxWaves;
 }
+// Hashed placement (FirstHashed): slots wanted for a block = 1.5 x the barcodes expected in its lists (see
+// rankedFirstEstimateE), so that the table stays under ~2/3 full. The kernel gives the table every byte the budget
+// leaves; a block whose table still fills up is re-run in the next larger placement.
+constexpr u32 HASHED_MIN_SLOTS = 1024, HASHED_MAX_SLOTS = 1u << 16;
+// list-loop waves and table slots of a block in the hashed placement: all waves if the table then still has `want`
+// slots, else 8, else the minimum (fewer waves => more slots); slots = 0 if nothing fits
+__host__ __device__ inline void hashedShape(u32 n, u32 maxWaves, u32 ctBytes, size_t budget, u32 minSlots, u32 want, u32 &nW, u32 &slots) {
+  const u32 tryW[3] = {maxWaves, maxWaves < 8 ? maxWaves : 8, MIN_HIST_WAVES};
+  const size_t need = minSlots > HASHED_MIN_SLOTS ? minSlots : HASHED_MIN_SLOTS;
+  nW = 0; slots = 0;
+  for (int t = 0; t < 3; ++t) {
+    const size_t used = workBytes(0, n, tryW[t], 0, ctBytes) + 32;
+    if (used >= budget) continue;
+    size_t sl = (budget - used) / 4; if (sl > HASHED_MAX_SLOTS) sl = HASHED_MAX_SLOTS;
+    if (sl < need) continue;
+    nW = tryW[t]; slots = (u32)sl;
+    if (sl >= want) return;
+  }
+}
 template <typename CT>
 __device__ inline Work<CT> carve(unsigned char *base, u32 nFirst, u32 n, u32 bmWords = 0) {
   Work<CT> w; size_t o = 0;
@@ -220,15 +241,6 @@ template <bool IN_LDS, typename T> __device__ __forceinline__ T ld_shared(const 
   return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-// where a barcode's first[] entry lives: at its own number (dense table) or at its rank among the barcodes present in
-// this block's lists (bitmap + per-word popcount prefix: 3 LDS reads instead of 1, but 2 B per PRESENT barcode plus
-// 1 bit + 1/8 B per barcode of the data set instead of 2 B per barcode of the data set)
-struct MapDense { __device__ __forceinline__ u32 operator()(u32 cj) const { return cj; } };
-struct MapRanked {
-  const u32 *bm; const u16 *pre;
-  __device__ __forceinline__ u32 operator()(u32 cj) const { const u32 w = cj >> 5; return pre[w] + (u32)__popc(bm[w] & ((1u << (cj & 31)) - 1u)); }
-};
-
 // CAS-min on a u16 living in a u32 word (LDS or global)
 template <bool IN_LDS>
 __device__ __forceinline__ void min_u16(u16 *arr, u32 idx, u32 val) {
@@ -242,6 +254,61 @@ __device__ __forceinline__ void min_u16(u16 *arr, u32 idx, u32 val) {
     old = prev;
   }
 }
+
+// first[cj] = lowest rank >= 1 of this barcode's good hashes whose list holds barcode cj (the reference's minShare), three
+// placements behind one interface (update = minimum with rank i, lookup = current value, NONE16 if unseen):
+//  * FirstDense : a u16 per barcode of the data set — in LDS while that is small, else on a per-workgroup HBM slot;
+//  * FirstRanked: a u16 per barcode PRESENT in this block's lists, found through a presence bitmap over all barcodes and a
+//    per-word popcount prefix (3 LDS reads instead of 1; 1 bit + 1/16 B per barcode of the data set);
+//  * FirstHashed: an open-addressing table in LDS keyed by barcode, for data sets whose bitmap no longer fits — a barcode's
+//    lists only ever meet some thousand others, whatever the data set holds. Entry = rank << 16 | displacement << 8 | tag
+//    with (home slot, tag) = (q mod S, q div S), q = a bijective scramble of cj: the slot and the low 16 bits identify
+//    the barcode exactly, so entries of one barcode differ only in the rank and a plain ds_min_u32 is "minimum rank".
+//    Empty slots are claimed by CAS; a slot never empties, so two waves inserting the same barcode meet in the same
+//    slot. A table that fills up (displacement > 255) flags the block, which is then re-run in a larger placement.
+template <bool FIRST_LDS> struct FirstDense {
+  u16 *first;
+  __device__ __forceinline__ void update(u32 cj, u32 i) const { min_u16<FIRST_LDS>(first, cj, i); }
+  __device__ __forceinline__ u32 lookup(u32 cj) const { return ld_shared<FIRST_LDS>(&first[cj]); }
+};
+struct FirstRanked {
+  u16 *first; const u32 *bm; const u16 *pre;
+  __device__ __forceinline__ u32 at(u32 cj) const { const u32 w = cj >> 5; return pre[w] + (u32)__popc(bm[w] & ((1u << (cj & 31)) - 1u)); }
+  __device__ __forceinline__ void update(u32 cj, u32 i) const { min_u16<true>(first, at(cj), i); }
+  __device__ __forceinline__ u32 lookup(u32 cj) const { return first[at(cj)]; }
+};
+struct FirstHashed {
+  u32 *tab; u32 S, recip /* ceil(2^32 / S) */, bmask; u32 *ovf;
+  static constexpr u32 SCRAMBLE = 0x9E3779u | 1u;            // odd multiplier: x -> x * SCRAMBLE mod 2^b is a bijection
+  __device__ __forceinline__ void split(u32 cj, u32 &home, u32 &tag) const {
+    const u32 q = (cj * SCRAMBLE) & bmask;
+    tag = __umulhi(q, recip); home = q - tag * S;
+    if (home >= S) { if ((int)home < 0) { --tag; home += S; } else { ++tag; home -= S; } }   // recip is rounded up: off by one at most
+  }
+  __device__ __forceinline__ void update(u32 cj, u32 i) const {
+    u32 home, tag; split(cj, home, tag);
+    u32 slot = home;
+    for (u32 d = 0; d < 256; ++d) {
+      const u32 mine = (i << 16) | (d << 8) | tag;
+      u32 e = tab[slot];
+      if (e == 0xFFFFFFFFu) { e = atomicCAS(&tab[slot], 0xFFFFFFFFu, mine); if (e == 0xFFFFFFFFu) return; }
+      if ((e & 0xFFFFu) == (mine & 0xFFFFu)) { if ((e >> 16) > i) atomicMin(&tab[slot], mine); return; }
+      if (++slot == S) slot = 0;
+    }
+    *ovf = 1;
+  }
+  __device__ __forceinline__ u32 lookup(u32 cj) const {
+    u32 home, tag; split(cj, home, tag);
+    u32 slot = home;
+    for (u32 d = 0; d < 256; ++d) {
+      const u32 e = tab[slot];
+      if ((e & 0xFFFFu) == ((d << 8) | tag)) return e >> 16;
+      if (e == 0xFFFFFFFFu) return NONE16;
+      if (++slot == S) slot = 0;
+    }
+    return NONE16;
+  }
+};
 
 // wave64 max in registers: DPP row shifts (1,2,4,8) then row broadcasts 15/31 (gfx9 DPP), result in lane 63.
 // Identity 0 (keys are unsigned); no LDS round trips unlike ds_bpermute-based shuffles.
@@ -262,8 +329,8 @@ __device__ __forceinline__ u32 wave_max_u32(u32 v) {
 // last at a value sees its full count, so a DPP wave max over (arrival count, lowest rank) is the mode —
 // one LDS round trip for the gather, one for the atomics. Lists with fewer usable entries than the
 // threshold are skipped (only "msMax < threshold" matters to the caller then).
-template <bool IN_LDS, bool FIRST_LDS, int RCHUNK, typename FM>
-__device__ __forceinline__ void row_mode_hist(const u32 *__restrict__ row, u32 cj0, u32 cj1, u32 d, u32 code, u32 i, const u16 *first, const FM &fm, u32 *hist,
+template <bool IN_LDS, int RCHUNK, typename FT>
+__device__ __forceinline__ void row_mode_hist(const u32 *__restrict__ row, u32 cj0, u32 cj1, u32 d, u32 code, u32 i, const FT &ft, u32 *hist,
                                               u32 thr, u32 &best, u32 &bcnt, u32 &tot) {
   const int lane = threadIdx.x & (WAVE - 1);
   u32 f[RCHUNK]; bool ok[RCHUNK];
@@ -273,7 +340,7 @@ __device__ __forceinline__ void row_mode_hist(const u32 *__restrict__ row, u32 c
     f[r] = NONE16; ok[r] = false;
     if ((u32)(r * WAVE) < d) {
       const u32 j = r * WAVE + lane;
-      if (j < d) { const u32 cj = r == 0 ? cj0 : (r == 1 ? cj1 : row[j]); if (cj != code) { f[r] = ld_shared<FIRST_LDS>(&first[fm(cj)]); ok[r] = f[r] < i; } }
+      if (j < d) { const u32 cj = r == 0 ? cj0 : (r == 1 ? cj1 : row[j]); if (cj != code) { f[r] = ft.lookup(cj); ok[r] = f[r] < i; } }
       tot += (u32)__popcll(__ballot(ok[r]));
     }
   }
@@ -302,13 +369,13 @@ __device__ __forceinline__ void row_mode_hist(const u32 *__restrict__ row, u32 c
   best = key ? 0xFFFFu - (key & 0xFFFFu) : NONE16;
 }
 // lists of 256 entries and more (exotic depth ranges): re-gather per candidate
-template <bool IN_LDS, typename FM>
-__device__ void row_mode_long(const u32 *__restrict__ row, u32 d, u32 code, u32 i, const u16 *first, const FM &fm, u32 &best, u32 &bcnt, u32 &tot) {
+template <typename FT>
+__device__ void row_mode_long(const u32 *__restrict__ row, u32 d, u32 code, u32 i, const FT &ft, u32 &best, u32 &bcnt, u32 &tot) {
   const int lane = threadIdx.x & (WAVE - 1);
   best = NONE16; bcnt = 0; tot = 0;
   for (u32 a0 = 0; a0 < d; a0 += WAVE) {
     u32 fa = NONE16; bool va = false;
-    if (a0 + lane < d) { const u32 cj = row[a0 + lane]; if (cj != code) { fa = ld_shared<IN_LDS>(&first[fm(cj)]); va = fa < i; } }
+    if (a0 + lane < d) { const u32 cj = row[a0 + lane]; if (cj != code) { fa = ft.lookup(cj); va = fa < i; } }
     u64 rem = __ballot(va); tot += (u32)__popcll(rem);
     while (rem) {
       const int src = __ffsll((long long)rem) - 1;
@@ -317,7 +384,7 @@ __device__ void row_mode_long(const u32 *__restrict__ row, u32 d, u32 code, u32 
       u32 cnt = 0; bool seenBefore = false;
       for (u32 b0 = 0; b0 < d; b0 += WAVE) {
         u32 fb = NONE16;
-        if (b0 + lane < d) { const u32 cj = row[b0 + lane]; if (cj != code) fb = ld_shared<IN_LDS>(&first[fm(cj)]); }
+        if (b0 + lane < d) { const u32 cj = row[b0 + lane]; if (cj != code) fb = ft.lookup(cj); }
         const u32 m = (u32)__popcll(__ballot(fb == v));
         if (b0 < a0 && m) { seenBefore = true; break; }
         cnt += m;
@@ -347,10 +414,20 @@ __device__ void cluster_one_block(const ClusterArgs &a, u32 code, unsigned char 
   const u32 nHash = a.blocks[code].nHash;
   constexpr bool FIRST_LDS = IN_LDS && FIRST_MODE != 2;
   constexpr bool RANKED = IN_LDS && FIRST_MODE == 1;
+  constexpr bool HASHED = IN_LDS && FIRST_MODE == 3;
   const u32 bmWords = RANKED ? (a.nBlocksFirst + 31) / 32 : 0;
   // list-loop waves: all of them where the histograms fit, fewer for a barcode with many ranks (one kernel and one
   // work queue then serve nearly every barcode; the rest of the phases always use the whole workgroup)
-  const u32 nW = IN_LDS ? histWaves(RANKED ? rankedFirstEstimate(a.nBlocksFirst, n) : (FIRST_LDS ? a.nBlocksFirst : 0), n, CL_WAVES, bmWords, sizeof(CT), a.ldsBudget) : (u32)CL_WAVES;
+  u32 nW, slots = 0;
+  if constexpr (HASHED) {
+    const u32 want = rankedFirstEstimateE(a.nBlocksFirst, n, a.entries[code]) + rankedFirstEstimateE(a.nBlocksFirst, n, a.entries[code]) / 2;
+    hashedShape(n, CL_WAVES, sizeof(CT), a.ldsBudget, a.hashMinSlots, want, nW, slots);
+    if (a.firstCap && slots > a.firstCap) slots = a.firstCap;                  // test knob: small tables, to exercise the overflow chain
+    if (!nW || !slots) {                                     // cannot hold this barcode at all: hand it on
+      if (tid == 0) a.overflow[atomicAdd(a.overflowCount, 1u)] = code;
+      return;
+    }
+  } else nW = IN_LDS ? histWaves(RANKED ? rankedFirstEstimate(a.nBlocksFirst, n) : (FIRST_LDS ? a.nBlocksFirst : 0), n, CL_WAVES, bmWords, sizeof(CT), a.ldsBudget) : (u32)CL_WAVES;
   if (!nW) return;                                           // cannot happen: the classification sends such a barcode to the HBM-scratch class
   u32 firstCap = 0;                                          // ranked placement: first[] gets every byte the budget leaves
   if constexpr (RANKED) {
@@ -359,16 +436,19 @@ __device__ void cluster_one_block(const ClusterArgs &a, u32 code, unsigned char 
     firstCap = (u32)(room < 65535 ? room : 65535); if (firstCap > a.nBlocksFirst) firstCap = a.nBlocksFirst;
     if (a.firstCap && firstCap > a.firstCap) firstCap = a.firstCap;          // test knob
   }
-  Work<CT> w = carve<CT>(region, RANKED ? firstCap : (FIRST_LDS || !IN_LDS ? a.nBlocksFirst : 0), n, bmWords);
+  Work<CT> w = carve<CT>(region, HASHED ? 2 * slots : (RANKED ? firstCap : (FIRST_LDS || !IN_LDS ? a.nBlocksFirst : 0)), n, bmWords);
   if (IN_LDS && FIRST_MODE == 2) w.first = firstGlobal;      // hybrid: first[] on this workgroup's HBM slot, the rest in LDS
-  typename std::conditional<RANKED, MapRanked, MapDense>::type fm{};
-  if constexpr (RANKED) { fm.bm = w.bm; fm.pre = w.pre; }
+  typename std::conditional<HASHED, FirstHashed, typename std::conditional<RANKED, FirstRanked, FirstDense<FIRST_LDS>>::type>::type ft{};
+  if constexpr (HASHED) { ft.tab = (u32 *)w.first; ft.S = slots; ft.recip = (u32)((0x100000000ULL + slots - 1) / slots); ft.bmask = a.hashMask; ft.ovf = &sh[2]; }
+  else if constexpr (RANKED) { ft.first = w.first; ft.bm = w.bm; ft.pre = w.pre; }
+  else ft.first = w.first;
   const u32 lcode = code; code += a.codeBase;                // from here on `code` is the global barcode number (what the lists hold)
   h10x_clushash *ch = a.clusHash + o; const u16 *g = a.goodPos + o;
 
   u64 tPrev = a.phase ? wall_clock64() : 0;
   // ---- init: prefetch every rank's list offset/length once
-  if (FIRST_LDS && !RANKED) for (u32 i = tid; i < (a.nBlocksFirst + 1) / 2; i += CL_THREADS) ((u32 *)w.first)[i] = 0xFFFFFFFFu;
+  if (FIRST_LDS && !RANKED) for (u32 i = tid; i < (HASHED ? slots : (a.nBlocksFirst + 1) / 2); i += CL_THREADS) ((u32 *)w.first)[i] = 0xFFFFFFFFu;
+  if (HASHED && tid == 0) sh[2] = 0;
   if (RANKED) for (u32 i = tid; i < bmWords; i += CL_THREADS) w.bm[i] = 0;
   for (u32 i = tid; i < nW * w.histWords; i += CL_THREADS) w.hist[i] = 0;
   u64 myDepth = 0;
@@ -432,23 +512,24 @@ __device__ void cluster_one_block(const ClusterArgs &a, u32 code, unsigned char 
 #pragma unroll
     for (int t = 0; t < ROWS_IN_FLIGHT; ++t) {
       const u32 i = i0 + t;
-      if (cj[t] != code) min_u16<FIRST_LDS>(w.first, fm(cj[t]), i);
+      if (cj[t] != code) ft.update(cj[t], i);
       if (dl[t] > WAVE) {
-        if (cj2[t] != code) min_u16<FIRST_LDS>(w.first, fm(cj2[t]), i);
-        if (dl[t] > 2 * WAVE) { const u32 *row = a.rows + w.rs[i]; for (u32 j = 2 * WAVE + lane; j < dl[t]; j += WAVE) { const u32 c2 = row[j]; if (c2 != code) min_u16<FIRST_LDS>(w.first, fm(c2), i); } }
+        if (cj2[t] != code) ft.update(cj2[t], i);
+        if (dl[t] > 2 * WAVE) { const u32 *row = a.rows + w.rs[i]; for (u32 j = 2 * WAVE + lane; j < dl[t]; j += WAVE) { const u32 c2 = row[j]; if (c2 != code) ft.update(c2, i); } }
       }
     }
     SYNC_LDS();
+    if (HASHED && sh[2]) break;                              // the table filled up (uniform: read after the barrier)
 #pragma unroll
     for (int t = 0; t < ROWS_IN_FLIGHT; ++t) {
       const u32 i = i0 + t;
       if (i < n) {
         const u32 d = dl[t]; const u32 *row = a.rows + w.rs[i];
         u32 best, bcnt, tot;
-        if (d <= WAVE) row_mode_hist<IN_LDS, FIRST_LDS, 1>(row, cj[t], code, d, code, i, w.first, fm, w.hist + wave * w.histWords, (u32)a.threshold, best, bcnt, tot);
-        else if (d <= 2 * WAVE) row_mode_hist<IN_LDS, FIRST_LDS, 2>(row, cj[t], cj2[t], d, code, i, w.first, fm, w.hist + wave * w.histWords, (u32)a.threshold, best, bcnt, tot);
-        else if (d < RCHUNK * WAVE) row_mode_hist<IN_LDS, FIRST_LDS, RCHUNK>(row, cj[t], cj2[t], d, code, i, w.first, fm, w.hist + wave * w.histWords, (u32)a.threshold, best, bcnt, tot);
-        else row_mode_long<FIRST_LDS>(row, d, code, i, w.first, fm, best, bcnt, tot);
+        if (d <= WAVE) row_mode_hist<IN_LDS, 1>(row, cj[t], code, d, code, i, ft, w.hist + wave * w.histWords, (u32)a.threshold, best, bcnt, tot);
+        else if (d <= 2 * WAVE) row_mode_hist<IN_LDS, 2>(row, cj[t], cj2[t], d, code, i, ft, w.hist + wave * w.histWords, (u32)a.threshold, best, bcnt, tot);
+        else if (d < RCHUNK * WAVE) row_mode_hist<IN_LDS, RCHUNK>(row, cj[t], cj2[t], d, code, i, ft, w.hist + wave * w.histWords, (u32)a.threshold, best, bcnt, tot);
+        else row_mode_long(row, d, code, i, ft, best, bcnt, tot);
         if (lane == 0) { w.best[i] = (u16)best; w.cnt[i] = (CT)bcnt; w.tot[i] = (CT)tot; }
       }
     }
@@ -456,6 +537,11 @@ __device__ void cluster_one_block(const ClusterArgs &a, u32 code, unsigned char 
 #undef H10X_LOAD_AB
   STAMP(1);
   SYNC();
+  if (HASHED && sh[2]) {                                     // hand the block to the next larger placement; nothing has been written yet
+    if (tid == 0) a.overflow[atomicAdd(a.overflowCount, 1u)] = lcode;
+    SYNC();
+    return;
+  }
   STAMP(2);
 
   // ---- (c) the order-dependent part of hash10x.c:807-822, restated without a serial walk.
@@ -542,8 +628,8 @@ __device__ void cluster_one_block(const ClusterArgs &a, u32 code, unsigned char 
       for (int t = 0; t < ROWS_IN_FLIGHT; ++t) {
         const u32 i = i0 + t;
         if (qv[t] == NONE16 || dl[t] == 0) continue;         // no term, or founder == msBest: cnt[i] already holds the count
-        u32 q = (u32)__popcll(__ballot(cj[t] != code && ld_shared<FIRST_LDS>(&w.first[fm(cj[t])]) == qv[t]));
-        if (dl[t] > WAVE) { const u32 *row = a.rows + w.rs[i]; for (u32 b0 = WAVE; b0 < dl[t]; b0 += WAVE) { bool m = false; if (b0 + lane < dl[t]) { const u32 c2 = row[b0 + lane]; m = c2 != code && ld_shared<FIRST_LDS>(&w.first[fm(c2)]) == qv[t]; } q += (u32)__popcll(__ballot(m)); } }
+        u32 q = (u32)__popcll(__ballot(cj[t] != code && ft.lookup(cj[t]) == qv[t]));
+        if (dl[t] > WAVE) { const u32 *row = a.rows + w.rs[i]; for (u32 b0 = WAVE; b0 < dl[t]; b0 += WAVE) { bool m = false; if (b0 + lane < dl[t]) { const u32 c2 = row[b0 + lane]; m = c2 != code && ft.lookup(c2) == qv[t]; } q += (u32)__popcll(__ballot(m)); } }
         if (lane == 0) w.cnt[i] = (CT)q;
       }
     }
@@ -709,7 +795,7 @@ void read_merge_kernel(h10x_block *__restrict__ blocks, const u64 *__restrict__ 
 // launch classes by working-set size: 0 = half a CU's LDS (barcodes with many ranks run their list loop on fewer waves:
 // histWaves), 2 = the whole LDS of a CU, 3 = HBM scratch (class 1 is no longer used)
 __global__ void cluster_classify_kernel(const h10x_block *__restrict__ blocks, const u32 *__restrict__ nGood, const u32 *__restrict__ entries, u32 codeMin, u32 codeMax,
-                                        u32 nBlocks /* LDS entries of first[] (ranked: barcodes of the data set) */, int ranked, u32 bmWords, u32 waves0, size_t budget0, size_t budgetSmall, size_t budgetBig, int wide,
+                                        u32 nBlocks /* LDS entries of first[] (ranked, hashed: barcodes of the data set) */, int ranked /* 1 ranked, 2 hashed */, u32 hashMinSlots, u32 bmWords, u32 waves0, size_t budget0, size_t budgetSmall, size_t budgetBig, int wide,
                                         u32 *__restrict__ list0, u32 *__restrict__ list1, u32 *__restrict__ list2, u32 *__restrict__ list3,
                                         u32 *__restrict__ counts) {
   const u32 c = codeMin + blockIdx.x * blockDim.x + threadIdx.x;
@@ -719,6 +805,13 @@ __global__ void cluster_classify_kernel(const h10x_block *__restrict__ blocks, c
   if (n) {
     nRead = blocks[c].nRead;
     if (wide) cls = 3;                                       // counts do not fit the u16 arrays of the LDS instantiations
+    else if (ranked == 2) {                                  // hashed placement
+      const u32 est = rankedFirstEstimateE(nBlocks, n, entries[c]), want = est + est / 2;
+      u32 nW, slots;
+      hashedShape(n, waves0, 2, budget0, hashMinSlots, want, nW, slots);
+      if (slots >= want) cls = 0;
+      else { hashedShape(n, CL_THREADS_HUGE / WAVE, 2, budgetBig, hashMinSlots, want, nW, slots); cls = slots ? 2 : 3; }
+    }
     else if (histWaves(ranked ? rankedFirstEstimateE(nBlocks, n, entries[c]) : nBlocks, n, waves0, bmWords, 2, budget0)) cls = 0;
     else if (histWaves(ranked ? rankedFirstEstimate(nBlocks, n) : nBlocks, n, CL_THREADS_HUGE / WAVE, bmWords, 2, budgetBig)) cls = 2;
     else cls = 3;
@@ -760,17 +853,22 @@ int stageC_cluster(Ctx *c, int codeMin, int codeMax, int threshold) {
   const size_t budgetBig = c->optClusterLds > 0 ? (size_t)c->optClusterLds : 160 * 1024 - 1024;
   const int threads0 = c->optClusterThreads0 == 512 ? 512 : 1024;                            // tuning knobs for class 0
   const size_t budget0 = c->optClusterLds > 0 ? (size_t)c->optClusterLds : (c->optClusterBudget0 > 0 ? (size_t)c->optClusterBudget0 : budgetSmall);
-  // first[] (2 B per barcode of the data set) stays in LDS while it is small; past that each workgroup keeps it on an
-  // HBM slot of its own (L2/MALL resident, atomics + L1-bypassing loads) and only the per-rank arrays live in LDS
+  // Placement of first[] (FirstDense / FirstRanked / FirstHashed): dense in LDS while 2 B per barcode of the data set is
+  // small; ranked in LDS while the presence bitmap + prefix (3/16 B per barcode) leaves room for the rest; hashed in LDS
+  // up to 2^22 barcodes (beyond that the 8-bit tag needs more slots than LDS has); dense on a per-workgroup HBM slot
+  // (L2/MALL resident, atomics + L1-bypassing loads) as the last resort and for blocks whose LDS table filled up twice.
   const u32 bmWordsAll = (nGlobal + 31) / 32;
-  int firstMode = (size_t)nGlobal * 2 <= 48 * 1024 ? 0 : ((size_t)bmWordsAll * 6 <= 48 * 1024 ? 1 : 2);
-  if (c->optFirstGlobal == 1) firstMode = 2; else if (c->optFirstGlobal == 2) firstMode = 1;   // test knobs
+  int hashBits = 1; while (hashBits < 32 && (1ull << hashBits) < (unsigned long long)nGlobal) ++hashBits;
+  const u32 hashMinSlots = hashBits > 8 ? 1u << (hashBits - 8) : 0u;
+  int firstMode = (size_t)nGlobal * 2 <= 48 * 1024 ? 0 : ((size_t)bmWordsAll * 6 <= 48 * 1024 ? 1 : (hashBits <= 22 ? 3 : 2));
+  if (c->optFirstGlobal == 1) firstMode = 2; else if (c->optFirstGlobal == 2) firstMode = 1; else if (c->optFirstGlobal == 3) firstMode = 3;   // test knobs
   const u32 firstCap = c->optFirstCap > 0 ? (u32)c->optFirstCap : 0u;      // test knob only
   const u32 nFirstLds = firstMode == 0 ? nGlobal : 0;
   const u32 bmWords = firstMode == 1 ? bmWordsAll : 0;
   const int wide = c->maxGoodDepth > 65535u ? 1 : 0;         // list lengths / counts beyond the u16 arrays of the LDS instantiations
-  cluster_classify_kernel<<<divUp(span, 256), 256, 0, st>>>(c->blocks.p, c->nGood.p, c->goodEntries.p, (u32)codeMin, (u32)codeMax, firstMode == 1 ? nGlobal : nFirstLds, firstMode == 1 ? 1 : 0, bmWords, (u32)threads0 / WAVE, budget0, budgetSmall, budgetBig, wide,
-                                                          list0.p, list1.p, list2.p, list3.p, counts.p);
+  cluster_classify_kernel<<<divUp(span, 256), 256, 0, st>>>(c->blocks.p, c->nGood.p, c->goodEntries.p, (u32)codeMin, (u32)codeMax,
+                                                          firstMode == 1 || firstMode == 3 ? nGlobal : nFirstLds, firstMode == 1 ? 1 : (firstMode == 3 ? 2 : 0), hashMinSlots,
+                                                          bmWords, (u32)threads0 / WAVE, budget0, budgetSmall, budgetBig, wide, list0.p, list1.p, list2.p, list3.p, counts.p);
   u32 hc[12];
   H10X_HIP(c, hipMemcpyAsync(hc, counts.p, 48, hipMemcpyDeviceToHost, st));
   H10X_HIP(c, hipStreamSynchronize(st));
@@ -781,9 +879,12 @@ int stageC_cluster(Ctx *c, int codeMin, int codeMax, int threshold) {
   a.blocks = c->blocks.p; a.blockOff = c->blockOff.p; a.clusHash = c->clusHash.p; a.goodPos = c->goodPos.p; a.nGood = c->nGood.p;
   a.hashDepth = c->hashDepth.p; a.rowStart = c->rowStart.p; a.rows = c->rows.p; a.nBlocks = c->nBlocks; a.threshold = threshold;
   a.codeBase = c->sharded ? c->codeBase : 0; a.nBlocksFirst = nGlobal;
-  a.maxGood = c->maxGood; a.stats = stats.p; a.term = term.p;
-  DevBuf<u32> overflow; H10X_HIP(c, overflow.alloc((size_t)span + 1));
-  a.firstCap = firstCap; a.overflow = overflow.p + 1; a.overflowCount = overflow.p; H10X_HIP(c, hipMemsetAsync(overflow.p, 0, 4, st));
+  a.maxGood = c->maxGood; a.stats = stats.p; a.term = term.p; a.entries = c->goodEntries.p;
+  a.firstCap = firstCap; a.hashMask = hashBits >= 32 ? 0xFFFFFFFFu : (1u << hashBits) - 1u; a.hashMinSlots = hashMinSlots;
+  // ranked / hashed placement: blocks whose table was too small are re-run — those of the half-CU class (list A) with the
+  // whole LDS of a CU, those that fail there as well (list B) with first[] dense on an HBM slot
+  DevBuf<u32> ovfA, ovfB; H10X_HIP(c, ovfA.alloc((size_t)span + 1)); H10X_HIP(c, ovfB.alloc((size_t)span + 1));
+  H10X_HIP(c, hipMemsetAsync(ovfA.p, 0, 4, st)); H10X_HIP(c, hipMemsetAsync(ovfB.p, 0, 4, st));
   DevBuf<u64> phase;
   if (c->optStamps) { H10X_HIP(c, phase.alloc(8)); H10X_HIP(c, hipMemsetAsync(phase.p, 0, 64, st)); a.phase = phase.p; }
   // HBM working set per workgroup (class 3): first[] + per-rank arrays for the largest barcode
@@ -803,7 +904,7 @@ int stageC_cluster(Ctx *c, int codeMin, int codeMax, int threshold) {
     H10X_HIP(c, firstSlots[k].alloc(firstStride * gridOf[k]));
     H10X_HIP(c, hipMemsetAsync(firstSlots[k].p, 0xFF, firstStride * gridOf[k], st));
   }
-  // The four classes are independent: fork them onto side streams so that the few largest barcodes (long, low
+  // The classes are independent: fork them onto side streams so that the few largest barcodes (long, low
   // parallelism) run beside the many small ones instead of in front of them. Every buffer they touch was
   // allocated before the fork and is released after the join, which is what the block cache requires.
   c->tstart(T_CLUSTER_K);
@@ -812,45 +913,52 @@ int stageC_cluster(Ctx *c, int codeMin, int codeMax, int threshold) {
     ClusterArgs g = a; g.list = list3.p; g.nList = hc[3]; g.workCounter = counts.p + 7; g.scratch = scratch.p; g.scratchStride = stride;
     cluster_kernel<false, 2, CL_THREADS_SMALL><<<grid3, CL_THREADS_SMALL, 0, c->aux[0]>>>(g);
   }
-#define H10X_LAUNCH_LDS(K, THREADS, BUDGET, STREAM, LIST, CNT)                                                                     \
-  if (hc[K]) {                                                                                                                     \
-    ClusterArgs g = a; g.list = LIST; g.nList = hc[K]; g.workCounter = counts.p + CNT; g.ldsBudget = (u32)(BUDGET);               \
-    if (firstMode == 0) {                                                                                                          \
-      H10X_HIP(c, hipFuncSetAttribute((const void *)cluster_kernel<true, 0, THREADS, K>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(BUDGET))); \
-      cluster_kernel<true, 0, THREADS, K><<<gridOf[K], THREADS, BUDGET, STREAM>>>(g);                                              \
-    } else if (firstMode == 1) {                                                                                                   \
-      H10X_HIP(c, hipFuncSetAttribute((const void *)cluster_kernel<true, 1, THREADS, K>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(BUDGET))); \
-      cluster_kernel<true, 1, THREADS, K><<<gridOf[K], THREADS, BUDGET, STREAM>>>(g);                                              \
-    } else {                                                                                                                       \
-      g.scratch = firstSlots[K].p; g.scratchStride = firstStride;                                                                  \
-      H10X_HIP(c, hipFuncSetAttribute((const void *)cluster_kernel<true, 2, THREADS, K>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(BUDGET))); \
-      cluster_kernel<true, 2, THREADS, K><<<gridOf[K], THREADS, BUDGET, STREAM>>>(g);                                              \
-    }                                                                                                                              \
+#define H10X_LAUNCH_ONE(MODE, K, THREADS, BUDGET, GRID, STREAM)                                                                    \
+      { H10X_HIP(c, hipFuncSetAttribute((const void *)cluster_kernel<true, MODE, THREADS, K>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(BUDGET))); \
+        cluster_kernel<true, MODE, THREADS, K><<<GRID, THREADS, BUDGET, STREAM>>>(g); }
+#define H10X_LAUNCH_LDS(K, THREADS, BUDGET, STREAM, LIST, NLIST, GRID, CNT, OVF)                                                   \
+  {                                                                                                                                \
+    ClusterArgs g = a; g.list = LIST; g.nList = NLIST; g.workCounter = counts.p + CNT; g.ldsBudget = (u32)(BUDGET);                \
+    g.overflow = (OVF) + 1; g.overflowCount = (OVF);                                                                               \
+    if (firstMode == 0) H10X_LAUNCH_ONE(0, K, THREADS, BUDGET, GRID, STREAM)                                                       \
+    else if (firstMode == 1) H10X_LAUNCH_ONE(1, K, THREADS, BUDGET, GRID, STREAM)                                                  \
+    else if (firstMode == 3) H10X_LAUNCH_ONE(3, K, THREADS, BUDGET, GRID, STREAM)                                                  \
+    else { g.scratch = firstSlots[K].p; g.scratchStride = firstStride; H10X_LAUNCH_ONE(2, K, THREADS, BUDGET, GRID, STREAM) }      \
   }
-  H10X_LAUNCH_LDS(2, CL_THREADS_HUGE, budgetBig, c->aux[1], list2.p, 6)
-  if (threads0 == 512) { H10X_LAUNCH_LDS(0, 512, budget0, st, list0.p, 4) } else { H10X_LAUNCH_LDS(0, CL_THREADS_SMALL, budget0, st, list0.p, 4) }
-#undef H10X_LAUNCH_LDS
+  if (hc[2]) H10X_LAUNCH_LDS(2, CL_THREADS_HUGE, budgetBig, c->aux[1], list2.p, hc[2], gridOf[2], 6, ovfB.p)
+  if (hc[0]) { if (threads0 == 512) H10X_LAUNCH_LDS(0, 512, budget0, st, list0.p, hc[0], gridOf[0], 4, ovfA.p) else H10X_LAUNCH_LDS(0, CL_THREADS_SMALL, budget0, st, list0.p, hc[0], gridOf[0], 4, ovfA.p) }
   H10X_HIP(c, hipGetLastError());
   H10X_TRY(c->joinStreams(3));
   u32 nOverflow = 0;
   DevBuf<unsigned char> scratch2;
-  if (firstMode == 1) {                                      // blocks whose lists touch more barcodes than the ranked first[] holds
-    H10X_HIP(c, hipMemcpyAsync(&nOverflow, overflow.p, 4, hipMemcpyDeviceToHost, st));
+  if (firstMode == 1 || firstMode == 3) {
+    u32 nA = 0, nB = 0;
+    H10X_HIP(c, hipMemcpyAsync(&nA, ovfA.p, 4, hipMemcpyDeviceToHost, st));
     H10X_HIP(c, hipStreamSynchronize(st));
-    if (nOverflow) {
-      // re-run with first[] dense on a per-workgroup HBM slot and everything else in LDS (the hybrid form): a block that
-      // was classified for LDS with its first[] estimate fits the whole-CU budget without it
-      const u32 grid = hmin<u32>(nOverflow, (u32)c->numCU);
+    if (nA) {                                                // half-CU tables that were too small: again with the whole LDS of a CU
+      H10X_HIP(c, hipMemsetAsync(counts.p + 6, 0, 4, st));
+      H10X_LAUNCH_LDS(2, CL_THREADS_HUGE, budgetBig, st, ovfA.p + 1, nA, hmin<u32>(nA, (u32)c->numCU), 6, ovfB.p)
+      H10X_HIP(c, hipGetLastError());
+    }
+    H10X_HIP(c, hipMemcpyAsync(&nB, ovfB.p, 4, hipMemcpyDeviceToHost, st));
+    H10X_HIP(c, hipStreamSynchronize(st));
+    nOverflow = nA + nB;
+    if (nB) {
+      // last resort: first[] dense on a per-workgroup HBM slot and everything else in LDS (the hybrid form); a block that
+      // got this far fits the whole-CU budget without its table
+      const u32 grid = hmin<u32>(nB, (u32)c->numCU);
       H10X_HIP(c, scratch2.alloc(firstStride * grid));
       H10X_HIP(c, hipMemsetAsync(scratch2.p, 0xFF, firstStride * grid, st));
       H10X_HIP(c, hipMemsetAsync(counts.p + 7, 0, 4, st));
-      ClusterArgs g = a; g.list = overflow.p + 1; g.nList = nOverflow; g.workCounter = counts.p + 7; g.scratch = scratch2.p; g.scratchStride = firstStride;
+      ClusterArgs g = a; g.list = ovfB.p + 1; g.nList = nB; g.workCounter = counts.p + 7; g.scratch = scratch2.p; g.scratchStride = firstStride;
       g.ldsBudget = (u32)budgetBig;
       H10X_HIP(c, hipFuncSetAttribute((const void *)cluster_kernel<true, 2, CL_THREADS_HUGE, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)budgetBig));
       cluster_kernel<true, 2, CL_THREADS_HUGE, 3><<<grid, CL_THREADS_HUGE, budgetBig, st>>>(g);
       H10X_HIP(c, hipGetLastError());
     }
   }
+#undef H10X_LAUNCH_LDS
+#undef H10X_LAUNCH_ONE
   // (e) the ordered sums on a side stream beside (f) the read merges: they touch disjoint fields
   H10X_TRY(c->forkStreams(1));
   point_sum_kernel<<<divUp(span, SUM_THREADS / WAVE), SUM_THREADS, 0, c->aux[0]>>>(c->blocks.p, c->blockOff.p, c->nGood.p, term.p, (u32)codeMin, (u32)codeMax);

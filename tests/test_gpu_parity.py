@@ -92,13 +92,14 @@ def test_cluster_hbm_scratch_and_big_lds_paths(workdir, budget):
     assert hf.blocks["nSubCluster"].sum() > 0
 
 
-@pytest.mark.parametrize("cap", [0, 64])
-def test_cluster_ranked_first_table(workdir, cap):
-    """Ranked placement (presence bitmap + popcount prefix, first[] sized by the barcodes present): forced on a small set;
-    cap = 64 makes most blocks overflow into the HBM re-run."""
-    import hash10x_amd
+@pytest.mark.parametrize("mode,cap", [(2, 0), (2, 64), (3, 0), (3, 1500), (3, 64)])
+def test_cluster_ranked_and_hashed_first_tables(workdir, mode, cap):
+    """Placements of first[] for data sets with many barcodes, forced on a small set: mode 2 = ranked (presence bitmap +
+    popcount prefix, first[] sized by the barcodes present), mode 3 = hashed (open-addressing table in LDS keyed by
+    barcode). A small cap makes the tables overflow: the blocks are re-run with the whole LDS of a CU and, when that
+    fails too, with first[] dense on an HBM slot."""
     orc.gen_fqb(workdir.file("x.fqb"), 60000, 300, 400000, 0.003, 43, 4.0, 150, 6000)
-    opts = dict(cluster_first_global=2)
+    opts = dict(cluster_first_global=mode)
     if cap:
         opts["cluster_first_cap"] = cap
     hf = _against_oracle(workdir, "x.fqb", ["-ct", 3, "--readFQB", "x.fqb", "--hashDepthRange", 4, 40, "--cluster", 1, 0], **opts)
