@@ -30,6 +30,7 @@ namespace h10x {
 constexpr int CL_THREADS_SMALL = 1024;                     // <= 79 KB working sets, two workgroups per CU
 constexpr int CL_THREADS_HUGE = 1024;                      // the whole LDS of a CU, one workgroup per CU
 constexpr u16 NONE16 = 0xFFFF;
+constexpr u32 NOHANDLE = 0xFFFFFFFFu;                        // FirstDense/Ranked/Hashed::update handle of a lane without an entry
 #ifndef H10X_RIF
 #define H10X_RIF 4
 #endif
@@ -266,15 +267,19 @@ __device__ __forceinline__ void min_u16(u16 *arr, u32 idx, u32 val) {
 //    the barcode exactly, so entries of one barcode differ only in the rank and a plain ds_min_u32 is "minimum rank".
 //    Empty slots are claimed by CAS; a slot never empties, so two waves inserting the same barcode meet in the same
 //    slot. A table that fills up (displacement > 255) flags the block, which is then re-run in a larger placement.
+// update() returns a handle under which peek() finds the entry again without repeating the search: the list loop reads
+// every entry twice (before and after the round's barrier).
 template <bool FIRST_LDS> struct FirstDense {
   u16 *first;
-  __device__ __forceinline__ void update(u32 cj, u32 i) const { min_u16<FIRST_LDS>(first, cj, i); }
+  __device__ __forceinline__ u32 update(u32 cj, u32 i) const { min_u16<FIRST_LDS>(first, cj, i); return cj; }
+  __device__ __forceinline__ u32 peek(u32 h) const { return ld_shared<FIRST_LDS>(&first[h]); }
   __device__ __forceinline__ u32 lookup(u32 cj) const { return ld_shared<FIRST_LDS>(&first[cj]); }
 };
 struct FirstRanked {
   u16 *first; const u32 *bm; const u16 *pre;
   __device__ __forceinline__ u32 at(u32 cj) const { const u32 w = cj >> 5; return pre[w] + (u32)__popc(bm[w] & ((1u << (cj & 31)) - 1u)); }
-  __device__ __forceinline__ void update(u32 cj, u32 i) const { min_u16<true>(first, at(cj), i); }
+  __device__ __forceinline__ u32 update(u32 cj, u32 i) const { const u32 h = at(cj); min_u16<true>(first, h, i); return h; }
+  __device__ __forceinline__ u32 peek(u32 h) const { return first[h]; }
   __device__ __forceinline__ u32 lookup(u32 cj) const { return first[at(cj)]; }
 };
 struct FirstHashed {
@@ -285,18 +290,20 @@ struct FirstHashed {
     tag = __umulhi(q, recip); home = q - tag * S;
     if (home >= S) { if ((int)home < 0) { --tag; home += S; } else { ++tag; home -= S; } }   // recip is rounded up: off by one at most
   }
-  __device__ __forceinline__ void update(u32 cj, u32 i) const {
+  __device__ __forceinline__ u32 update(u32 cj, u32 i) const {
     u32 home, tag; split(cj, home, tag);
     u32 slot = home;
     for (u32 d = 0; d < 256; ++d) {
       const u32 mine = (i << 16) | (d << 8) | tag;
       u32 e = tab[slot];
-      if (e == 0xFFFFFFFFu) { e = atomicCAS(&tab[slot], 0xFFFFFFFFu, mine); if (e == 0xFFFFFFFFu) return; }
-      if ((e & 0xFFFFu) == (mine & 0xFFFFu)) { if ((e >> 16) > i) atomicMin(&tab[slot], mine); return; }
+      if (e == 0xFFFFFFFFu) { e = atomicCAS(&tab[slot], 0xFFFFFFFFu, mine); if (e == 0xFFFFFFFFu) return slot; }
+      if ((e & 0xFFFFu) == (mine & 0xFFFFu)) { if ((e >> 16) > i) atomicMin(&tab[slot], mine); return slot; }
       if (++slot == S) slot = 0;
     }
     *ovf = 1;
+    return home;                                             // the block is abandoned
   }
+  __device__ __forceinline__ u32 peek(u32 h) const { return tab[h] >> 16; }
   __device__ __forceinline__ u32 lookup(u32 cj) const {
     u32 home, tag; split(cj, home, tag);
     u32 slot = home;
@@ -330,7 +337,7 @@ __device__ __forceinline__ u32 wave_max_u32(u32 v) {
 // one LDS round trip for the gather, one for the atomics. Lists with fewer usable entries than the
 // threshold are skipped (only "msMax < threshold" matters to the caller then).
 template <bool IN_LDS, int RCHUNK, typename FT>
-__device__ __forceinline__ void row_mode_hist(const u32 *__restrict__ row, u32 cj0, u32 cj1, u32 d, u32 code, u32 i, const FT &ft, u32 *hist,
+__device__ __forceinline__ void row_mode_hist(const u32 *__restrict__ row, u32 h0, u32 h1 /* handles of entries lane, 64 + lane; NOHANDLE = none */, u32 d, u32 code, u32 i, const FT &ft, u32 *hist,
                                               u32 thr, u32 &best, u32 &bcnt, u32 &tot) {
   const int lane = threadIdx.x & (WAVE - 1);
   u32 f[RCHUNK]; bool ok[RCHUNK];
@@ -340,7 +347,8 @@ __device__ __forceinline__ void row_mode_hist(const u32 *__restrict__ row, u32 c
     f[r] = NONE16; ok[r] = false;
     if ((u32)(r * WAVE) < d) {
       const u32 j = r * WAVE + lane;
-      if (j < d) { const u32 cj = r == 0 ? cj0 : (r == 1 ? cj1 : row[j]); if (cj != code) { f[r] = ft.lookup(cj); ok[r] = f[r] < i; } }
+      if (r < 2) { const u32 h = r == 0 ? h0 : h1; if (h != NOHANDLE) { f[r] = ft.peek(h); ok[r] = f[r] < i; } }
+      else if (j < d) { const u32 cj = row[j]; if (cj != code) { f[r] = ft.lookup(cj); ok[r] = f[r] < i; } }
       tot += (u32)__popcll(__ballot(ok[r]));
     }
   }
@@ -512,9 +520,9 @@ __device__ void cluster_one_block(const ClusterArgs &a, u32 code, unsigned char 
 #pragma unroll
     for (int t = 0; t < ROWS_IN_FLIGHT; ++t) {
       const u32 i = i0 + t;
-      if (cj[t] != code) ft.update(cj[t], i);
+      cj[t] = cj[t] != code ? ft.update(cj[t], i) : NOHANDLE;          // from here on cj / cj2 hold handles
       if (dl[t] > WAVE) {
-        if (cj2[t] != code) ft.update(cj2[t], i);
+        cj2[t] = cj2[t] != code ? ft.update(cj2[t], i) : NOHANDLE;
         if (dl[t] > 2 * WAVE) { const u32 *row = a.rows + w.rs[i]; for (u32 j = 2 * WAVE + lane; j < dl[t]; j += WAVE) { const u32 c2 = row[j]; if (c2 != code) ft.update(c2, i); } }
       }
     }
@@ -526,7 +534,7 @@ __device__ void cluster_one_block(const ClusterArgs &a, u32 code, unsigned char 
       if (i < n) {
         const u32 d = dl[t]; const u32 *row = a.rows + w.rs[i];
         u32 best, bcnt, tot;
-        if (d <= WAVE) row_mode_hist<IN_LDS, 1>(row, cj[t], code, d, code, i, ft, w.hist + wave * w.histWords, (u32)a.threshold, best, bcnt, tot);
+        if (d <= WAVE) row_mode_hist<IN_LDS, 1>(row, cj[t], NOHANDLE, d, code, i, ft, w.hist + wave * w.histWords, (u32)a.threshold, best, bcnt, tot);
         else if (d <= 2 * WAVE) row_mode_hist<IN_LDS, 2>(row, cj[t], cj2[t], d, code, i, ft, w.hist + wave * w.histWords, (u32)a.threshold, best, bcnt, tot);
         else if (d < RCHUNK * WAVE) row_mode_hist<IN_LDS, RCHUNK>(row, cj[t], cj2[t], d, code, i, ft, w.hist + wave * w.histWords, (u32)a.threshold, best, bcnt, tot);
         else row_mode_long(row, d, code, i, ft, best, bcnt, tot);
@@ -670,7 +678,7 @@ __device__ void cluster_one_block(const ClusterArgs &a, u32 code, unsigned char 
 // bound (chains of LDS round trips per list), so the second workgroup is worth far more than the few loop-invariant
 // values the compiler then keeps in scratch (measured: 4.3 -> 3.4 ms on the yeast-scale set).
 template <bool IN_LDS, int FIRST_MODE, int CL_THREADS, int KLASS = 0 /* distinct functions per launch class */>
-__global__ __launch_bounds__(CL_THREADS) __attribute__((amdgpu_waves_per_eu(CL_THREADS == 1024 ? 8 : 4)))
+__global__ __launch_bounds__(CL_THREADS) __attribute__((amdgpu_waves_per_eu(CL_THREADS == 1024 && KLASS == 0 ? 8 : 4)))   // classes 2, 3: one workgroup per CU anyway
 void cluster_kernel(ClusterArgs a) {
   extern __shared__ __align__(16) unsigned char smem[];
   __shared__ u32 sh[4 + 128];                               // [0..3] scalars, then per-wave scan totals
