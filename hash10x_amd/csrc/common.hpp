@@ -105,10 +105,10 @@ template <typename T> struct DevBuf {
 
 // ---- timers ---------------------------------------------------------------------------------------
 enum TimerId { T_RUNS = 0, T_MOSH, T_FALLBACK, T_COMPACT, T_SORT_HASH, T_RANK, T_PROBE, T_CLUSHASH, T_CSR,
-               T_GOOD, T_CLUSTER, T_CLUSTER_K, T_SPLIT, T_COUNT };
+               T_GOOD, T_CLUSTER, T_CLUSTER_K, T_CLUSTER_MAIN, T_SPLIT, T_COUNT };
 static const char *const kTimerNames[T_COUNT] = {
   "block_runs", "mosh_extract", "mosh_fallback", "compact_entries", "sort_by_hash", "index_rank",
-  "probe_table", "clushash_build", "csr_build", "good_hashes", "cluster", "cluster_kernel", "cluster_split" };
+  "probe_table", "clushash_build", "csr_build", "good_hashes", "cluster", "cluster_kernel", "cluster_main", "cluster_split" };
 
 struct Timer { hipEvent_t a = nullptr, b = nullptr; double ms = 0; uint64_t launches = 0; bool pending = false; };
 

@@ -168,7 +168,8 @@ int   h10x_device_synchronize(int device);
 
 /* ---- measurement hooks (not part of the reference surface) ----
    Per-kernel device timings collected with hipEvents on the context's stream when enabled.
-   names: "mosh_extract", "index_build", "good_hashes", "cluster" ... (h10x_timing_name(i)). */
+   names: "mosh_extract", "sort_by_hash", ..., "good_hashes", "cluster" (whole command), "cluster_kernel" (all device work of
+   --cluster), "cluster_main" (the main cluster_kernel launch alone) ... (h10x_timing_name(i)). */
 int  h10x_timing_enable(h10x_ctx *ctx, int on);
 int  h10x_timing_count(const h10x_ctx *ctx);
 const char *h10x_timing_name(const h10x_ctx *ctx, int i);
@@ -188,6 +189,7 @@ typedef struct {
   uint64_t cluster_class_counts[4]; /* barcodes clustered in: half-CU LDS with 1024 lanes, half-CU LDS with 512 lanes, full-CU LDS (512 lanes), HBM scratch */
   uint64_t cluster_first_mode;     /* placement of the first[] table: 0 dense in LDS, 1 ranked (bitmap) in LDS, 2 per-workgroup HBM slot */
   uint64_t cluster_overflow_blocks; /* ranked placement: barcodes re-run on the HBM path because too many barcodes were present */
+  uint64_t cluster_main[4];        /* work of the main cluster launch alone (timer "cluster_main"): good hashes, gathered list entries, nHash, barcodes */
   uint64_t cluster_phase_ticks[8]; /* diagnostic (option "cluster_stamps"): 100 MHz ticks per phase summed over workgroups:
                                       init, first[], mode, replay, quotient, sum+labels, read merge, idle/queue */
 } h10x_counters;
