@@ -178,14 +178,15 @@ __host__ __device__ inline size_t workBytes(u32 nFirst, u32 n, u32 nWaves, u32 b
 // waves of the workgroup that take part in the list loop of a barcode with n ranks: as many as have room for a private
 // histogram in what the fixed part leaves of `budget` (0 = does not fit; the replay's temporaries need >= MIN_HIST_WAVES)
 constexpr u32 MIN_HIST_WAVES = 5;
-constexpr u32 RANKED_FIRST_PER_RANK = 8;                    // ranked placement: first[] entries budgeted per rank when a block is classified
+constexpr u32 RANKED_FIRST_PER_RANK = 6;                    // ranked placement: first[] entries budgeted per rank when a block is classified
                                                            // (3-7 barcodes present per rank on the synthetic sets); the kernel then takes
                                                            // whatever the budget leaves, and a block that still overflows is re-run with
                                                            // first[] on an HBM slot
 __host__ __device__ inline u32 rankedFirstEstimate(u32 nBarcodes, u32 n) { const u64 e = (u64)RANKED_FIRST_PER_RANK * n; return e < nBarcodes ? (u32)e : nBarcodes; }
-// … and, where the entries of the block's lists are known (classification): a fifth of them (6-8 % on the yeast-like sets,
-// more on deeper ones), whichever is larger
-__host__ __device__ inline u32 rankedFirstEstimateE(u32 nBarcodes, u32 n, u32 entries) { const u32 a = rankedFirstEstimate(nBarcodes, n), b = entries / 5; const u32 m = a > b ? a : b; return m < nBarcodes ? m : nBarcodes; }
+// … and, where the entries of the block's lists are known (classification): a seventh of them (6-8 % on the yeast-like
+// sets, more on deeper ones), whichever is larger. Erring low is cheap: the ranked kernel knows the true number right
+// after its bitmap pass and hands the block on before the list loop.
+__host__ __device__ inline u32 rankedFirstEstimateE(u32 nBarcodes, u32 n, u32 entries) { const u32 a = rankedFirstEstimate(nBarcodes, n), b = entries / 7; const u32 m = a > b ? a : b; return m < nBarcodes ? m : nBarcodes; }
 __host__ __device__ inline u32 histWaves(u32 nFirst, u32 n, u32 maxWaves, u32 bmWords, u32 ctBytes, size_t budget) {
   const size_t fixed = workBytes(nFirst, n, 0, bmWords, ctBytes), per = (((size_t)n + 3) / 4) * 4;
   if (fixed + MIN_HIST_WAVES * per > budget) return 0;
@@ -411,9 +412,12 @@ __device__ void row_mode_long(const u32 *__restrict__ row, u32 d, u32 code, u32 
 // flight (a full __syncthreads() drains vmcnt too). The HBM-scratch instantiation keeps the full barrier + L1 drop.
 #define SYNC_LDS() do { if (IN_LDS) { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); } else SYNC(); } while (0)
 
-template <bool IN_LDS, int FIRST_MODE /* 0 dense in LDS, 1 ranked in LDS, 2 dense on an HBM slot */, int CL_THREADS>
+template <bool IN_LDS, int FIRST_MODE /* 0 dense in LDS, 1 ranked in LDS, 2 dense on an HBM slot, 3 hashed in LDS */, int CL_THREADS, int KLASS>
 __device__ void cluster_one_block(const ClusterArgs &a, u32 code, unsigned char *region, u16 *firstGlobal, u32 *sh /* small shared ints */) {   // code: local block number
   constexpr int CL_WAVES = CL_THREADS / WAVE;
+  // lists a wave keeps in flight: 4, but 2 where the kernel must stay within 64 VGPRs (two workgroups per CU) AND carries
+  // the ranked / hashed lookup: fewer registers spilled is worth more there than the deeper prefetch (8x set: 52.8 -> 41.4 ms)
+  constexpr int RIF = (KLASS == 0 && CL_THREADS == 1024 && (FIRST_MODE == 1 || FIRST_MODE == 3)) ? 2 : ROWS_IN_FLIGHT;
   typedef typename std::conditional<IN_LDS, u16, u32>::type CT;
   const int tid = threadIdx.x, lane = tid & (WAVE - 1), wave = tid / WAVE;
   const u32 n = a.nGood[code];
@@ -495,7 +499,7 @@ __device__ void cluster_one_block(const ClusterArgs &a, u32 code, unsigned char 
   }
   STAMP(0);
 
-  // ---- (a)+(b) in one pass over the lists, in rank order, CL_WAVES * ROWS_IN_FLIGHT ranks per round:
+  // ---- (a)+(b) in one pass over the lists, in rank order, CL_WAVES * RIF ranks per round:
   //   (a) first[cj] = lowest rank >= 1 sharing barcode cj (hash10x.c:794-799, minShare) by CAS-min,
   //   (b) msBest / msMax / msTot of the same ranks (hash10x.c:801-806) from the list entries still in registers.
   // first[cj] for a barcode of list i is final once every list <= i has been merged (later lists can only
@@ -503,22 +507,22 @@ __device__ void cluster_one_block(const ClusterArgs &a, u32 code, unsigned char 
   // The lists of round r+1 are requested before round r is processed, so their HBM latency hides behind the
   // CAS-min / barrier / mode work of round r.
   // A wave keeps the first two chunks (128 entries) of each of its lists in registers; longer lists re-read the rest.
-  u32 cjN[ROWS_IN_FLIGHT], cj2N[ROWS_IN_FLIGHT], dlN[ROWS_IN_FLIGHT];
+  u32 cjN[RIF], cj2N[RIF], dlN[RIF];
 #define H10X_LOAD_AB(I0)                                                                                      \
-  _Pragma("unroll") for (int t = 0; t < ROWS_IN_FLIGHT; ++t) {                                                \
+  _Pragma("unroll") for (int t = 0; t < RIF; ++t) {                                                \
     const u32 i = (I0) + t; dlN[t] = i < n ? (u32)w.dd[i] : 0; const u32 *row = a.rows + w.rs[i < n ? i : n - 1]; \
     cjN[t] = (u32)lane < dlN[t] ? row[lane] : code; cj2N[t] = (u32)(WAVE + lane) < dlN[t] ? row[WAVE + lane] : code; \
   }
   const bool listWave = (u32)wave < nW;                      // the other waves only keep the barriers company
-  H10X_LOAD_AB(listWave ? 1 + wave * ROWS_IN_FLIGHT : n)
-  for (u32 r0 = 1; r0 < n; r0 += nW * ROWS_IN_FLIGHT) {
-    const u32 i0 = listWave ? r0 + wave * ROWS_IN_FLIGHT : n;
-    u32 cj[ROWS_IN_FLIGHT], cj2[ROWS_IN_FLIGHT], dl[ROWS_IN_FLIGHT];
+  H10X_LOAD_AB(listWave ? 1 + wave * RIF : n)
+  for (u32 r0 = 1; r0 < n; r0 += nW * RIF) {
+    const u32 i0 = listWave ? r0 + wave * RIF : n;
+    u32 cj[RIF], cj2[RIF], dl[RIF];
 #pragma unroll
-    for (int t = 0; t < ROWS_IN_FLIGHT; ++t) { cj[t] = cjN[t]; cj2[t] = cj2N[t]; dl[t] = dlN[t]; }
-    H10X_LOAD_AB(listWave ? i0 + nW * ROWS_IN_FLIGHT : n)
+    for (int t = 0; t < RIF; ++t) { cj[t] = cjN[t]; cj2[t] = cj2N[t]; dl[t] = dlN[t]; }
+    H10X_LOAD_AB(listWave ? i0 + nW * RIF : n)
 #pragma unroll
-    for (int t = 0; t < ROWS_IN_FLIGHT; ++t) {
+    for (int t = 0; t < RIF; ++t) {
       const u32 i = i0 + t;
       cj[t] = cj[t] != code ? ft.update(cj[t], i) : NOHANDLE;          // from here on cj / cj2 hold handles
       if (dl[t] > WAVE) {
@@ -529,7 +533,7 @@ __device__ void cluster_one_block(const ClusterArgs &a, u32 code, unsigned char 
     SYNC_LDS();
     if (HASHED && sh[2]) break;                              // the table filled up (uniform: read after the barrier)
 #pragma unroll
-    for (int t = 0; t < ROWS_IN_FLIGHT; ++t) {
+    for (int t = 0; t < RIF; ++t) {
       const u32 i = i0 + t;
       if (i < n) {
         const u32 d = dl[t]; const u32 *row = a.rows + w.rs[i];
@@ -616,24 +620,24 @@ __device__ void cluster_one_block(const ClusterArgs &a, u32 code, unsigned char 
   STAMP(3);
 
   // ---- (d) minShareCount[clusterMin[label]] per rank (hash10x.c:821) into cnt[]; the list is re-read only when the
-  // cluster's founder is not msBest, ROWS_IN_FLIGHT lists at a time, the next group's lists already in flight
+  // cluster's founder is not msBest, RIF lists at a time, the next group's lists already in flight
   {
-    u32 cjN2[ROWS_IN_FLIGHT], dlN2[ROWS_IN_FLIGHT], qvN[ROWS_IN_FLIGHT];
+    u32 cjN2[RIF], dlN2[RIF], qvN[RIF];
 #define H10X_LOAD_D(I0, CJ, DL, QV)                                                                        \
-    _Pragma("unroll") for (int t = 0; t < ROWS_IN_FLIGHT; ++t) {                                           \
+    _Pragma("unroll") for (int t = 0; t < RIF; ++t) {                                           \
       const u32 i = (I0) + t; QV[t] = i < stop ? (u32)w.qj[i] : NONE16;                                    \
       const bool need = QV[t] != NONE16 && QV[t] != w.best[i];                                             \
       DL[t] = need ? (u32)w.dd[i] : 0;                                                                     \
       CJ[t] = (u32)lane < DL[t] ? a.rows[w.rs[i] + lane] : code;                                           \
     }
-    H10X_LOAD_D(1 + wave * ROWS_IN_FLIGHT, cjN2, dlN2, qvN)
-    for (u32 i0 = 1 + wave * ROWS_IN_FLIGHT; i0 < stop; i0 += CL_WAVES * ROWS_IN_FLIGHT) {
-      u32 cj[ROWS_IN_FLIGHT], dl[ROWS_IN_FLIGHT], qv[ROWS_IN_FLIGHT];
+    H10X_LOAD_D(1 + wave * RIF, cjN2, dlN2, qvN)
+    for (u32 i0 = 1 + wave * RIF; i0 < stop; i0 += CL_WAVES * RIF) {
+      u32 cj[RIF], dl[RIF], qv[RIF];
 #pragma unroll
-      for (int t = 0; t < ROWS_IN_FLIGHT; ++t) { cj[t] = cjN2[t]; dl[t] = dlN2[t]; qv[t] = qvN[t]; }
-      H10X_LOAD_D(i0 + CL_WAVES * ROWS_IN_FLIGHT, cjN2, dlN2, qvN)
+      for (int t = 0; t < RIF; ++t) { cj[t] = cjN2[t]; dl[t] = dlN2[t]; qv[t] = qvN[t]; }
+      H10X_LOAD_D(i0 + CL_WAVES * RIF, cjN2, dlN2, qvN)
 #pragma unroll
-      for (int t = 0; t < ROWS_IN_FLIGHT; ++t) {
+      for (int t = 0; t < RIF; ++t) {
         const u32 i = i0 + t;
         if (qv[t] == NONE16 || dl[t] == 0) continue;         // no term, or founder == msBest: cnt[i] already holds the count
         u32 q = (u32)__popcll(__ballot(cj[t] != code && ft.lookup(cj[t]) == qv[t]));
@@ -690,7 +694,7 @@ void cluster_kernel(ClusterArgs a) {
     __syncthreads();
     const u32 wi = sh[3];
     if (wi >= a.nList) break;                                // every wave of the workgroup leaves together
-    cluster_one_block<IN_LDS, FIRST_MODE, CL_THREADS>(a, a.list[wi], region, firstGlobal, sh);
+    cluster_one_block<IN_LDS, FIRST_MODE, CL_THREADS, KLASS>(a, a.list[wi], region, firstGlobal, sh);
   }
 }
 
