@@ -263,11 +263,12 @@ __device__ __forceinline__ void min_u16(u16 *arr, u32 idx, u32 val) {
 //  * FirstRanked: a u16 per barcode PRESENT in this block's lists, found through a presence bitmap over all barcodes and a
 //    per-word popcount prefix (3 LDS reads instead of 1; 1 bit + 1/16 B per barcode of the data set);
 //  * FirstHashed: an open-addressing table in LDS keyed by barcode, for data sets whose bitmap no longer fits — a barcode's
-//    lists only ever meet some thousand others, whatever the data set holds. Entry = rank << 16 | displacement << 8 | tag
-//    with (home slot, tag) = (q mod S, q div S), q = a bijective scramble of cj: the slot and the low 16 bits identify
-//    the barcode exactly, so entries of one barcode differ only in the rank and a plain ds_min_u32 is "minimum rank".
-//    Empty slots are claimed by CAS; a slot never empties, so two waves inserting the same barcode meet in the same
-//    slot. A table that fills up (displacement > 255) flags the block, which is then re-run in a larger placement.
+//    lists only ever meet some thousand others, whatever the data set holds. Buckets of 4 entries, entry = rank << 16 |
+//    bucket displacement << 10 | tag with (home bucket, tag) = (q mod NB, q div NB), q = a bijective scramble of cj: the
+//    bucket and the low 16 bits identify the barcode exactly, so entries of one barcode differ only in the rank and a
+//    plain ds_min_u32 is "minimum rank". Empty words are claimed by CAS, in order; a word never empties, so two waves
+//    inserting the same barcode meet in the same word. A table that fills up (displacement > 62) flags the block, which
+//    is then re-run in a larger placement.
 // update() returns a handle under which peek() finds the entry again without repeating the search: the list loop reads
 // every entry twice (before and after the round's barrier).
 template <bool FIRST_LDS> struct FirstDense {
@@ -284,35 +285,51 @@ struct FirstRanked {
   __device__ __forceinline__ u32 lookup(u32 cj) const { return first[at(cj)]; }
 };
 struct FirstHashed {
-  u32 *tab; u32 S, recip /* ceil(2^32 / S) */, bmask; u32 *ovf;
+  // Buckets of 4 entries (one ds_read_b128 shows a whole bucket: at 2/3 load nearly every search ends in its home bucket).
+  // Entry = rank << 16 | bucket displacement << 10 | tag, (home bucket, tag) = (q mod NB, q div NB); 0xFFFFFFFF = empty.
+  u32 *tab; u32 NB /* buckets */, recip /* ceil(2^32 / NB) */, bmask; u32 *ovf;
   static constexpr u32 SCRAMBLE = 0x9E3779u | 1u;            // odd multiplier: x -> x * SCRAMBLE mod 2^b is a bijection
+  static constexpr u32 MAXD = 63;                            // 6-bit displacement (never 63 with tag 1023: that is the empty pattern's low half)
   __device__ __forceinline__ void split(u32 cj, u32 &home, u32 &tag) const {
     const u32 q = (cj * SCRAMBLE) & bmask;
-    tag = __umulhi(q, recip); home = q - tag * S;
-    if (home >= S) { if ((int)home < 0) { --tag; home += S; } else { ++tag; home -= S; } }   // recip is rounded up: off by one at most
+    tag = __umulhi(q, recip); home = q - tag * NB;
+    if (home >= NB) { if ((int)home < 0) { --tag; home += NB; } else { ++tag; home -= NB; } }   // recip is rounded up: off by one at most
   }
   __device__ __forceinline__ u32 update(u32 cj, u32 i) const {
     u32 home, tag; split(cj, home, tag);
-    u32 slot = home;
-    for (u32 d = 0; d < 256; ++d) {
-      const u32 mine = (i << 16) | (d << 8) | tag;
-      u32 e = tab[slot];
-      if (e == 0xFFFFFFFFu) { e = atomicCAS(&tab[slot], 0xFFFFFFFFu, mine); if (e == 0xFFFFFFFFu) return slot; }
-      if ((e & 0xFFFFu) == (mine & 0xFFFFu)) { if ((e >> 16) > i) atomicMin(&tab[slot], mine); return slot; }
-      if (++slot == S) slot = 0;
+    u32 b = home;
+    for (u32 d = 0; d < MAXD; ++d) {
+      const u32 key = (d << 10) | tag, mine = (i << 16) | key;
+      const uint4 e4 = *(const uint4 *)&tab[4 * b];
+      const u32 e[4] = {e4.x, e4.y, e4.z, e4.w};
+#pragma unroll
+      for (int w = 0; w < 4; ++w)                            // already here?
+        if ((e[w] & 0xFFFFu) == key && e[w] != 0xFFFFFFFFu) { if ((e[w] >> 16) > i) atomicMin(&tab[4 * b + w], mine); return 4 * b + w; }
+#pragma unroll
+      for (int w = 0; w < 4; ++w)                            // first empty word, in order: every inserter of a barcode walks the same words
+        if (e[w] == 0xFFFFFFFFu) {
+          const u32 old = atomicCAS(&tab[4 * b + w], 0xFFFFFFFFu, mine);
+          if (old == 0xFFFFFFFFu) return 4 * b + w;
+          if ((old & 0xFFFFu) == key) { if ((old >> 16) > i) atomicMin(&tab[4 * b + w], mine); return 4 * b + w; }
+        }
+      if (++b == NB) b = 0;
     }
     *ovf = 1;
-    return home;                                             // the block is abandoned
+    return 4 * home;                                         // the block is abandoned
   }
   __device__ __forceinline__ u32 peek(u32 h) const { return tab[h] >> 16; }
   __device__ __forceinline__ u32 lookup(u32 cj) const {
     u32 home, tag; split(cj, home, tag);
-    u32 slot = home;
-    for (u32 d = 0; d < 256; ++d) {
-      const u32 e = tab[slot];
-      if ((e & 0xFFFFu) == ((d << 8) | tag)) return e >> 16;
-      if (e == 0xFFFFFFFFu) return NONE16;
-      if (++slot == S) slot = 0;
+    u32 b = home;
+    for (u32 d = 0; d < MAXD; ++d) {
+      const u32 key = (d << 10) | tag;
+      const uint4 e4 = *(const uint4 *)&tab[4 * b];
+      const u32 e[4] = {e4.x, e4.y, e4.z, e4.w};
+      bool hole = false; u32 r = NONE16;
+#pragma unroll
+      for (int w = 0; w < 4; ++w) { if (e[w] == 0xFFFFFFFFu) hole = true; else if ((e[w] & 0xFFFFu) == key) r = e[w] >> 16; }
+      if (r != NONE16 || hole) return r;                     // a bucket with a hole ends every search that reaches it
+      if (++b == NB) b = 0;
     }
     return NONE16;
   }
@@ -451,7 +468,7 @@ __device__ void cluster_one_block(const ClusterArgs &a, u32 code, unsigned char 
   Work<CT> w = carve<CT>(region, HASHED ? 2 * slots : (RANKED ? firstCap : (FIRST_LDS || !IN_LDS ? a.nBlocksFirst : 0)), n, bmWords);
   if (IN_LDS && FIRST_MODE == 2) w.first = firstGlobal;      // hybrid: first[] on this workgroup's HBM slot, the rest in LDS
   typename std::conditional<HASHED, FirstHashed, typename std::conditional<RANKED, FirstRanked, FirstDense<FIRST_LDS>>::type>::type ft{};
-  if constexpr (HASHED) { ft.tab = (u32 *)w.first; ft.S = slots; ft.recip = (u32)((0x100000000ULL + slots - 1) / slots); ft.bmask = a.hashMask; ft.ovf = &sh[2]; }
+  if constexpr (HASHED) { slots &= ~3u; ft.tab = (u32 *)w.first; ft.NB = slots / 4; ft.recip = (u32)((0x100000000ULL + ft.NB - 1) / ft.NB); ft.bmask = a.hashMask; ft.ovf = &sh[2]; }
   else if constexpr (RANKED) { ft.first = w.first; ft.bm = w.bm; ft.pre = w.pre; }
   else ft.first = w.first;
   const u32 lcode = code; code += a.codeBase;                // from here on `code` is the global barcode number (what the lists hold)
@@ -871,7 +888,7 @@ int stageC_cluster(Ctx *c, int codeMin, int codeMax, int threshold) {
   // (L2/MALL resident, atomics + L1-bypassing loads) as the last resort and for blocks whose LDS table filled up twice.
   const u32 bmWordsAll = (nGlobal + 31) / 32;
   int hashBits = 1; while (hashBits < 32 && (1ull << hashBits) < (unsigned long long)nGlobal) ++hashBits;
-  const u32 hashMinSlots = hashBits > 8 ? 1u << (hashBits - 8) : 0u;
+  const u32 hashMinSlots = hashBits > 10 ? 4u << (hashBits - 10) : 0u;       // 10-bit tag: buckets >= 2^(b-10)
   int firstMode = (size_t)nGlobal * 2 <= 48 * 1024 ? 0 : ((size_t)bmWordsAll * 6 <= 48 * 1024 ? 1 : (hashBits <= 22 ? 3 : 2));
   if (c->optFirstGlobal == 1) firstMode = 2; else if (c->optFirstGlobal == 2) firstMode = 1; else if (c->optFirstGlobal == 3) firstMode = 3;   // test knobs
   const u32 firstCap = c->optFirstCap > 0 ? (u32)c->optFirstCap : 0u;      // test knob only
