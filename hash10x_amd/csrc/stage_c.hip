@@ -490,9 +490,18 @@ __device__ void cluster_one_block(const ClusterArgs &a, u32 code, unsigned char 
   if constexpr (RANKED) {
     // ---- (0) which barcodes occur in this block's lists: presence bitmap, per-word popcount prefix, and a first[] sized by
     // the number present. More present than the table holds => the block is handed to the HBM-slot variant.
-    for (u32 i = 1 + wave; i < n; i += CL_WAVES) {
-      const u32 d = w.dd[i]; const u32 *row = a.rows + w.rs[i];
-      for (u32 j = lane; j < d; j += WAVE) { const u32 cj = row[j]; if (cj != code) atomicOr(&w.bm[cj >> 5], 1u << (cj & 31)); }
+    // four lists per wave in flight (their first chunks are requested together); most entries meet a bit that is already
+    // set: look before the atomic (LDS atomics cost per active lane)
+    auto mark = [&](u32 cj) { if (cj != code) { const u32 bit = 1u << (cj & 31); if (!(*(volatile u32 *)&w.bm[cj >> 5] & bit)) atomicOr(&w.bm[cj >> 5], bit); } };
+    for (u32 i0 = 1 + wave * 4; i0 < n; i0 += CL_WAVES * 4) {
+      u32 c0[4], d4[4];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) { const u32 i = i0 + t; d4[t] = i < n ? (u32)w.dd[i] : 0; c0[t] = (u32)lane < d4[t] ? a.rows[w.rs[i < n ? i : n - 1] + lane] : code; }
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        mark(c0[t]);
+        if (d4[t] > WAVE) { const u32 *row = a.rows + w.rs[i0 + t]; for (u32 j = WAVE + lane; j < d4[t]; j += WAVE) mark(row[j]); }
+      }
     }
     SYNC();
     const u32 ipt = (bmWords + CL_THREADS - 1) / CL_THREADS, s0 = tid * ipt < bmWords ? tid * ipt : bmWords, s1 = s0 + ipt < bmWords ? s0 + ipt : bmWords;
