@@ -348,3 +348,46 @@ def test_sort_fqb_on_device(workdir):
     o = orc.Oracle(B=20); o.read_fqb(exp.reshape(-1)); o.write_hash(workdir.file("orc.hash"))
     a, b = open(workdir.file("hip.hash"), "rb").read(), open(workdir.file("orc.hash"), "rb").read()
     assert a == b, orc.describe_diff(a, b)
+
+
+def test_full_size_properties_and_round_trip(workdir):
+    """BASELINE configs[1] at full size (2.5 M read pairs, 10 k barcodes, -B 24; the reference needs 13 s for it, bench.py
+    does that byte comparison): size-independent properties of the state instead — clusHash strictly ascending inside every
+    block, hashDepth = barcodes per hash, every stored index present in hashValue[], labels within nSubCluster, a second
+    pass bit-identical, --writeHash -> --readHash -> --writeHash a fixed point, and re-clustering the read-back state
+    reproduces the clustered file."""
+    import sys
+    sys.path.insert(0, orc.REPO)
+    import bench
+    import hash10x_amd
+    wl = bench.WORKLOADS["yeast-like-2.5M"]
+    recs = bench.generate(wl, 1)
+    h = hash10x_amd.Hash10x(B=wl["B"])
+    d = hash10x_amd.DeviceRecords(recs)
+    h.read_fqb_device(d.ptr, d.n_records)
+    h.depth_range(wl["lo"], wl["hi"])
+    h.cluster(1, 0, wl["ct"])
+    z = h.sizes(); b = h.export_blocks(); ch = h.export_clushash(); depth = h.export_depth()
+    assert z["nRecords"] == wl["pairs"] and z["nBlocks"] == wl["barcodes"] + 1 and b["nHash"][-1] == 0        # last barcode never hashed (SURVEY F5)
+    off = np.concatenate([[0], np.cumsum(b["nHash"][1:].astype(np.int64))])
+    ix = ch["hash"].astype(np.int64)
+    starts = np.zeros(ix.size, bool); starts[off[:-1][off[:-1] < ix.size]] = True
+    assert np.all((np.diff(ix) > 0) | starts[1:])
+    assert ix.min() >= 1 and ix.max() == z["hashNumber"] - 1
+    assert np.array_equal(np.bincount(ix, minlength=z["hashNumber"])[1:], depth[1:])
+    assert np.all(ch["subCluster"] <= np.repeat(b["nSubCluster"][1:], b["nHash"][1:])) and b["nSubCluster"].max() <= 255
+    assert np.all(ch["read"] < np.repeat(b["nRead"][1:], b["nHash"][1:]))
+    h.write_hash(workdir.file("a.hash"))
+    # second pass on the same context
+    h.read_fqb_device(d.ptr, d.n_records); h.depth_range(wl["lo"], wl["hi"]); h.cluster(1, 0, wl["ct"])
+    h.write_hash(workdir.file("b.hash"))
+    a = open(workdir.file("a.hash"), "rb").read()
+    assert a == open(workdir.file("b.hash"), "rb").read()
+    h.close()
+    # file round trip, then re-cluster from the file
+    g = hash10x_amd.Hash10x(B=wl["B"])
+    g.read_hash(workdir.file("a.hash")); g.write_hash(workdir.file("c.hash"))
+    assert a == open(workdir.file("c.hash"), "rb").read()
+    g.depth_range(wl["lo"], wl["hi"]); g.cluster(1, 0, wl["ct"]); g.write_hash(workdir.file("d.hash"))
+    assert a == open(workdir.file("d.hash"), "rb").read()
+    g.close()
