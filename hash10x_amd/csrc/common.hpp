@@ -163,6 +163,7 @@ struct Ctx {
   int64_t optFirstGlobal = 0; // testing knob: 1 = first[] on HBM slots, 2 = ranked first[] in LDS, even when the dense table would fit
   int64_t optFirstCap = 0;    // testing knob: entries of the ranked first[]
   int64_t optClusterThreads0 = 0, optClusterBudget0 = 0;   // tuning knobs: lanes and LDS bytes of the first cluster class
+  int64_t optDbgSkip = 0;     // diagnostic: what-if timing of cluster_kernel with phases switched off (results wrong)
   int64_t optStamps = 0;      // diagnostic: per-phase wall-clock stamps in cluster_kernel
   bool timing = false;
   Timer timers[T_COUNT];

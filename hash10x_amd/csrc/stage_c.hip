@@ -149,6 +149,7 @@ struct ClusterArgs {
   double *term;                                             // per rank (slice of block c at blockOff[c]): its pointToMin term, 0.0 if none
   u64 *stats;                                               // [0] sum good, [1] sum good depth, [2] sum nHash, [3] codes
   u64 *phase;                                               // diagnostic per-phase ticks (null = off)
+  u32 dbgSkip;                                              // diagnostic what-if timing (results are WRONG): 1 no first[] update, 2 no mode, 4 no phase (d), 8 no barrier
 };
 
 // working set layout inside a region (LDS or HBM scratch). CT = type of the per-rank counts and list lengths:
@@ -167,8 +168,8 @@ template <typename CT> struct Work {
   u32 histWords;     // words per wave
 };
 __host__ __device__ inline size_t workBytes(u32 nFirst, u32 n, u32 nWaves, u32 bmWords, u32 ctBytes) {
-  size_t b = (((size_t)nFirst * 2 + 15) & ~(size_t)15) + (size_t)bmWords * 4 + (((size_t)bmWords * 2 + 3) & ~(size_t)3);
-  b += (size_t)n * 4;                                       // rs
+  size_t b = (((size_t)nFirst * 2 + 15) & ~(size_t)15) + (((size_t)bmWords * 4 + 15) & ~(size_t)15) + (((size_t)bmWords * 2 + 15) & ~(size_t)15);
+  b += ((size_t)n * 4 + 15) & ~(size_t)15;                  // rs (padded: rs and dd are read RIF ranks at a time)
   b += (((size_t)n * ctBytes + 3) & ~(size_t)3) * 3;        // dd, cnt, tot
   b += (((size_t)n * 2 + 3) & ~(size_t)3) * 2;              // best, qj
   b += ((size_t)n + 15) & ~(size_t)15;                      // lab
@@ -217,9 +218,9 @@ __device__ inline Work<CT> carve(unsigned char *base, u32 nFirst, u32 n, u32 bmW
   Work<CT> w; size_t o = 0;
   const size_t ctb = ((size_t)n * sizeof(CT) + 3) & ~(size_t)3, b2 = ((size_t)n * 2 + 3) & ~(size_t)3;
   w.first = (u16 *)(base + o); o += (((size_t)nFirst * 2 + 15) & ~(size_t)15);
-  w.bm = (u32 *)(base + o); o += (size_t)bmWords * 4;
-  w.pre = (u16 *)(base + o); o += ((size_t)bmWords * 2 + 3) & ~(size_t)3;
-  w.rs = (u32 *)(base + o); o += (size_t)n * 4;
+  w.bm = (u32 *)(base + o); o += ((size_t)bmWords * 4 + 15) & ~(size_t)15;
+  w.pre = (u16 *)(base + o); o += ((size_t)bmWords * 2 + 15) & ~(size_t)15;
+  w.rs = (u32 *)(base + o); o += ((size_t)n * 4 + 15) & ~(size_t)15;
   w.dd = (CT *)(base + o); o += ctb;
   w.cnt = (CT *)(base + o); o += ctb;
   w.tot = (CT *)(base + o); o += ctb;
@@ -534,34 +535,56 @@ __device__ void cluster_one_block(const ClusterArgs &a, u32 code, unsigned char 
   // CAS-min / barrier / mode work of round r.
   // A wave keeps the first two chunks (128 entries) of each of its lists in registers; longer lists re-read the rest.
   u32 cjN[RIF], cj2N[RIF], dlN[RIF];
-#define H10X_LOAD_AB(I0)                                                                                      \
-  _Pragma("unroll") for (int t = 0; t < RIF; ++t) {                                                \
-    const u32 i = (I0) + t; dlN[t] = i < n ? (u32)w.dd[i] : 0; const u32 *row = a.rows + w.rs[i < n ? i : n - 1]; \
-    cjN[t] = (u32)lane < dlN[t] ? row[lane] : code; cj2N[t] = (u32)(WAVE + lane) < dlN[t] ? row[WAVE + lane] : code; \
-  }
+  // The rounds start at rank 0 (never processed, hash10x.c:789: its slot gets length 0), so a wave's RIF ranks start at a
+  // multiple of RIF: their lengths and offsets come in ONE wide LDS read each (wave-uniform), are made scalar, and the
+  // list loads use a scalar base + lane offset.
+#define H10X_LOAD_AB(I0, CJ, DL, RS)                                                                          \
+  { const u32 ib = (I0); u32 dv[RIF], rv[RIF];                                                                \
+    if constexpr (IN_LDS && RIF == 4) { const uint2 d2 = *(const uint2 *)&w.dd[ib < n ? ib : 0]; const uint4 r4 = *(const uint4 *)&w.rs[ib < n ? ib : 0]; \
+      dv[0] = d2.x & 0xFFFFu; dv[1] = d2.x >> 16; dv[2] = d2.y & 0xFFFFu; dv[3] = d2.y >> 16; rv[0] = r4.x; rv[1] = r4.y; rv[2] = r4.z; rv[3] = r4.w; } \
+    else if constexpr (IN_LDS && RIF == 2) { const u32 d1 = *(const u32 *)&w.dd[ib < n ? ib : 0]; const uint2 r2 = *(const uint2 *)&w.rs[ib < n ? ib : 0]; \
+      dv[0] = d1 & 0xFFFFu; dv[1] = d1 >> 16; rv[0] = r2.x; rv[1] = r2.y; }                                   \
+    else { _Pragma("unroll") for (int t = 0; t < RIF; ++t) { const u32 i = ib + t; dv[t] = i < n ? (u32)w.dd[i] : 0; rv[t] = w.rs[i < n ? i : 0]; } } \
+    _Pragma("unroll") for (int t = 0; t < RIF; ++t) {                                                         \
+      const u32 i = ib + t;                                                                                   \
+      DL[t] = (i >= 1 && i < n) ? (u32)__builtin_amdgcn_readfirstlane((int)dv[t]) : 0;                        \
+      RS[t] = (u32)__builtin_amdgcn_readfirstlane((int)rv[t]);                                                \
+      CJ[t] = (u32)lane < DL[t] ? a.rows[RS[t] + lane] : code;                                                \
+    } }
+  // the first chunk of a list is requested TWO rounds before its turn (the loop is bound by the latency of these short
+  // random reads), the second chunk — one list in seven has one — a round before
   const bool listWave = (u32)wave < nW;                      // the other waves only keep the barriers company
-  H10X_LOAD_AB(listWave ? 1 + wave * RIF : n)
-  for (u32 r0 = 1; r0 < n; r0 += nW * RIF) {
-    const u32 i0 = listWave ? r0 + wave * RIF : n;
+  const u32 uwave = (u32)__builtin_amdgcn_readfirstlane(wave);
+  u32 cjNN[RIF], dlNN[RIF], rsN[RIF], rsNN[RIF];
+  H10X_LOAD_AB(listWave ? uwave * RIF : n, cjN, dlN, rsN)
+#pragma unroll
+  for (int t = 0; t < RIF; ++t) cj2N[t] = (u32)(WAVE + lane) < dlN[t] ? a.rows[rsN[t] + WAVE + lane] : code;
+  H10X_LOAD_AB(listWave ? (uwave + nW) * RIF : n, cjNN, dlNN, rsNN)
+  for (u32 r0 = 0; r0 < n; r0 += nW * RIF) {
+    const u32 i0 = listWave ? r0 + uwave * RIF : n;
     u32 cj[RIF], cj2[RIF], dl[RIF];
 #pragma unroll
-    for (int t = 0; t < RIF; ++t) { cj[t] = cjN[t]; cj2[t] = cj2N[t]; dl[t] = dlN[t]; }
-    H10X_LOAD_AB(listWave ? i0 + nW * RIF : n)
+    for (int t = 0; t < RIF; ++t) { cj[t] = cjN[t]; cj2[t] = cj2N[t]; dl[t] = dlN[t]; cjN[t] = cjNN[t]; dlN[t] = dlNN[t]; rsN[t] = rsNN[t]; }
+#pragma unroll
+    for (int t = 0; t < RIF; ++t) cj2N[t] = (u32)(WAVE + lane) < dlN[t] ? a.rows[rsN[t] + WAVE + lane] : code;
+    H10X_LOAD_AB(listWave ? i0 + 2 * nW * RIF : n, cjNN, dlNN, rsNN)
 #pragma unroll
     for (int t = 0; t < RIF; ++t) {
       const u32 i = i0 + t;
+      if (a.dbgSkip & 1) { cj[t] = cj[t] != code ? cj[t] : NOHANDLE; continue; }
       cj[t] = cj[t] != code ? ft.update(cj[t], i) : NOHANDLE;          // from here on cj / cj2 hold handles
       if (dl[t] > WAVE) {
         cj2[t] = cj2[t] != code ? ft.update(cj2[t], i) : NOHANDLE;
         if (dl[t] > 2 * WAVE) { const u32 *row = a.rows + w.rs[i]; for (u32 j = 2 * WAVE + lane; j < dl[t]; j += WAVE) { const u32 c2 = row[j]; if (c2 != code) ft.update(c2, i); } }
       }
     }
-    SYNC_LDS();
+    if (!(a.dbgSkip & 8)) SYNC_LDS();
     if (HASHED && sh[2]) break;                              // the table filled up (uniform: read after the barrier)
+    if (a.dbgSkip & 2) continue;
 #pragma unroll
     for (int t = 0; t < RIF; ++t) {
       const u32 i = i0 + t;
-      if (i < n) {
+      if (i >= 1 && i < n) {
         const u32 d = dl[t]; const u32 *row = a.rows + w.rs[i];
         u32 best, bcnt, tot;
         if (d <= WAVE) row_mode_hist<IN_LDS, 1>(row, cj[t], NOHANDLE, d, code, i, ft, w.hist + wave * w.histWords, (u32)a.threshold, best, bcnt, tot);
@@ -657,7 +680,7 @@ __device__ void cluster_one_block(const ClusterArgs &a, u32 code, unsigned char 
       CJ[t] = (u32)lane < DL[t] ? a.rows[w.rs[i] + lane] : code;                                           \
     }
     H10X_LOAD_D(1 + wave * RIF, cjN2, dlN2, qvN)
-    for (u32 i0 = 1 + wave * RIF; i0 < stop; i0 += CL_WAVES * RIF) {
+    for (u32 i0 = 1 + wave * RIF; i0 < ((a.dbgSkip & 4) ? 0u : stop); i0 += CL_WAVES * RIF) {
       u32 cj[RIF], dl[RIF], qv[RIF];
 #pragma unroll
       for (int t = 0; t < RIF; ++t) { cj[t] = cjN2[t]; dl[t] = dlN2[t]; qv[t] = qvN[t]; }
@@ -917,6 +940,7 @@ int stageC_cluster(Ctx *c, int codeMin, int codeMax, int threshold) {
   a.blocks = c->blocks.p; a.blockOff = c->blockOff.p; a.clusHash = c->clusHash.p; a.goodPos = c->goodPos.p; a.nGood = c->nGood.p;
   a.hashDepth = c->hashDepth.p; a.rowStart = c->rowStart.p; a.rows = c->rows.p; a.nBlocks = c->nBlocks; a.threshold = threshold;
   a.codeBase = c->sharded ? c->codeBase : 0; a.nBlocksFirst = nGlobal;
+  a.dbgSkip = (u32)c->optDbgSkip;
   a.maxGood = c->maxGood; a.stats = stats.p; a.term = term.p; a.entries = c->goodEntries.p;
   a.firstCap = firstCap; a.hashMask = hashBits >= 32 ? 0xFFFFFFFFu : (1u << hashBits) - 1u; a.hashMinSlots = hashMinSlots;
   // ranked / hashed placement: blocks whose table was too small are re-run — those of the half-CU class (list A) with the
