@@ -431,7 +431,7 @@ __device__ void row_mode_long(const u32 *__restrict__ row, u32 d, u32 code, u32 
 #define SYNC_LDS() do { if (IN_LDS) { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); } else SYNC(); } while (0)
 
 template <bool IN_LDS, int FIRST_MODE /* 0 dense in LDS, 1 ranked in LDS, 2 dense on an HBM slot, 3 hashed in LDS */, int CL_THREADS, int KLASS>
-__device__ void cluster_one_block(const ClusterArgs &a, u32 code, unsigned char *region, u16 *firstGlobal, u32 *sh /* small shared ints */) {   // code: local block number
+__device__ void cluster_one_block(const ClusterArgs &a, u32 code, unsigned char *region, u16 *firstGlobal, u32 *sh /* small shared ints */, u64 (&acc)[4]) {   // code: local block number
   constexpr int CL_WAVES = CL_THREADS / WAVE;
   // lists a wave keeps in flight: 4, but 2 where the kernel must stay within 64 VGPRs (two workgroups per CU) AND carries
   // the ranked / hashed lookup: fewer registers spilled is worth more there than the deeper prefetch (8x set: 52.8 -> 41.4 ms)
@@ -710,9 +710,10 @@ __device__ void cluster_one_block(const ClusterArgs &a, u32 code, unsigned char 
   }
   if (tid == 0) a.blocks[lcode].nSubCluster = nSub;
   // wave-reduce the per-thread depth sums for the work counters
-  for (int s = 32; s; s >>= 1) myDepth += __shfl_down(myDepth, s);
-  if (lane == 0) atomicAdd((u64 *)&a.stats[1], (u64)myDepth);
-  if (tid == 0) { atomicAdd((u64 *)&a.stats[0], (u64)n); atomicAdd((u64 *)&a.stats[2], (u64)nHash); atomicAdd((u64 *)&a.stats[3], 1ULL); }
+  // work counters: kept per lane over the barcodes of the workgroup, posted once when the kernel ends (19 atomics per
+  // barcode on four shared words would queue up in L2 behind those of every other workgroup)
+  acc[1] += myDepth;
+  if (tid == 0) { acc[0] += n; acc[2] += nHash; acc[3] += 1; }
   if (!FIRST_LDS) {                                          // leave first[] clean for the next barcode of this workgroup
     SYNC();
     for (u32 i = 1 + wave; i < n; i += CL_WAVES) {
@@ -737,14 +738,19 @@ void cluster_kernel(ClusterArgs a) {
   __shared__ u32 sh[4 + 128];                               // [0..3] scalars, then per-wave scan totals
   unsigned char *region = IN_LDS ? smem : a.scratch + (size_t)blockIdx.x * a.scratchStride;
   u16 *firstGlobal = (IN_LDS && FIRST_MODE == 2) ? (u16 *)(a.scratch + (size_t)blockIdx.x * a.scratchStride) : nullptr;
+  u64 acc[4] = {0, 0, 0, 0};                                 // good hashes, gathered list entries, nHash, barcodes
   for (;;) {
     __syncthreads();
     if (threadIdx.x == 0) sh[3] = atomicAdd(a.workCounter, 1u);
     __syncthreads();
     const u32 wi = sh[3];
     if (wi >= a.nList) break;                                // every wave of the workgroup leaves together
-    cluster_one_block<IN_LDS, FIRST_MODE, CL_THREADS, KLASS>(a, a.list[wi], region, firstGlobal, sh);
+    cluster_one_block<IN_LDS, FIRST_MODE, CL_THREADS, KLASS>(a, a.list[wi], region, firstGlobal, sh, acc);
   }
+  u64 depth = acc[1];
+  for (int s = 32; s; s >>= 1) depth += __shfl_down(depth, s);
+  if ((threadIdx.x & (WAVE - 1)) == 0 && depth) atomicAdd((u64 *)&a.stats[1], depth);
+  if (threadIdx.x == 0 && acc[3]) { atomicAdd((u64 *)&a.stats[0], acc[0]); atomicAdd((u64 *)&a.stats[2], acc[2]); atomicAdd((u64 *)&a.stats[3], acc[3]); }
 }
 
 // ---- (e) pointToMin = the terms added in rank order (hash10x.c:821): a serial fp64 chain per barcode. One WAVE per
