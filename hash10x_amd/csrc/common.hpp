@@ -142,7 +142,7 @@ struct Ctx {
   DevBuf<u32> nGood;          // nBlocks
   DevBuf<u32> goodEntries;    // nBlocks : sum of the depths of a block's good hashes = entries of its barcode lists
   bool haveRange = false, haveGood = false; int rangeMin = 0, rangeMax = 0;
-  u32 maxGoodDepth = 0, maxGood = 0;
+  u32 maxGoodDepth = 0, maxGood = 0, meanGood = 0;
 
   // crib (hash10x.c:406-521): per hash index, where the two truth genomes hold it
   DevBuf<u32> cribCount[2];   // occurrences in genome 1 / 2
@@ -163,6 +163,7 @@ struct Ctx {
   int64_t optFirstGlobal = 0; // testing knob: 1 = first[] on HBM slots, 2 = ranked first[] in LDS, even when the dense table would fit
   int64_t optFirstCap = 0;    // testing knob: entries of the ranked first[]
   int64_t optClusterThreads0 = 0, optClusterBudget0 = 0;   // tuning knobs: lanes and LDS bytes of the first cluster class
+  int64_t optBigRanks = 0;    // tuning knob: rank count above which a barcode goes to the front of the main work queue (0 = 1.5 x the mean)
   int64_t optDbgSkip = 0;     // diagnostic: what-if timing of cluster_kernel with phases switched off (results wrong)
   int64_t optStamps = 0;      // diagnostic: per-phase wall-clock stamps in cluster_kernel
   bool timing = false;

@@ -344,6 +344,7 @@ int h10x_set_option(h10x_ctx *h, const char *name, int64_t value) {
   if (!strcmp(name, "cluster_first_cap")) { h->c.optFirstCap = value; return 0; }
   if (!strcmp(name, "cluster_threads0")) { h->c.optClusterThreads0 = value; return 0; }
   if (!strcmp(name, "cluster_budget0")) { h->c.optClusterBudget0 = value; return 0; }
+  if (!strcmp(name, "cluster_big_ranks")) { h->c.optBigRanks = value; return 0; }
   if (!strcmp(name, "cluster_dbg_skip")) { h->c.optDbgSkip = value; return 0; }
   if (!strcmp(name, "cluster_stamps")) { h->c.optStamps = value; return 0; }
   return h->c.fail("unknown option %s", name);

@@ -112,10 +112,13 @@ int stageC_depthRange(Ctx *c, int lo, int hi) {
   good_keys_kernel<<<hmin<u32>(nBlocks, 16384), 256, 0, st>>>(c->clusHash.p, c->blockOff.p, c->blocks.p, nBlocks, c->within.p,
                                                             c->hashDepth.p, key.p, c->nGood.p, segEnd.p, c->goodEntries.p);
   H10X_TRY(prim_reduce_max_u32(c, pt, c->nGood.p, red.p + 1, nBlocks));
-  u32 hr[2];
+  DevBuf<u64> redSum; H10X_HIP(c, redSum.alloc(1));
+  H10X_TRY(prim_reduce_sum_u32_u64(c, pt, c->nGood.p, redSum.p, nBlocks));
+  u32 hr[2]; u64 sumGood = 0;
   H10X_HIP(c, hipMemcpyAsync(hr, red.p, 8, hipMemcpyDeviceToHost, st));
+  H10X_HIP(c, hipMemcpyAsync(&sumGood, redSum.p, 8, hipMemcpyDeviceToHost, st));
   H10X_HIP(c, hipStreamSynchronize(st));
-  c->maxGoodDepth = hr[0]; c->maxGood = hr[1];
+  c->maxGoodDepth = hr[0]; c->maxGood = hr[1]; c->meanGood = nBlocks > 1 ? (u32)(sumGood / (nBlocks - 1)) : 0;
   offsets32c_kernel<<<divUp((u64)nBlocks + 1, 256), 256, 0, st>>>(c->blockOff.p, nBlocks + 1, off32.p);
   // ascending (depth, position): qsort by depth, stable => ties by position (hash10x.c:726-730,758)
   if (H) {
@@ -136,6 +139,7 @@ struct ClusterArgs {
   const u16 *goodPos; const u32 *nGood;
   const u32 *hashDepth; const u64 *rowStart; const u32 *rows;
   const u32 *list; u32 nList; u32 *workCounter;
+  const u32 *front; u32 nFront;                             // handed out before list[]: the largest barcodes of the launch
   u32 nBlocks; int threshold;
   u32 codeBase;                                             // sharded runs: global barcode number = codeBase + local block number
   u32 nBlocksFirst;                                         // size of first[]: barcodes of the whole data set + 1
@@ -744,8 +748,8 @@ void cluster_kernel(ClusterArgs a) {
     if (threadIdx.x == 0) sh[3] = atomicAdd(a.workCounter, 1u);
     __syncthreads();
     const u32 wi = sh[3];
-    if (wi >= a.nList) break;                                // every wave of the workgroup leaves together
-    cluster_one_block<IN_LDS, FIRST_MODE, CL_THREADS, KLASS>(a, a.list[wi], region, firstGlobal, sh, acc);
+    if (wi >= a.nFront + a.nList) break;                     // every wave of the workgroup leaves together
+    cluster_one_block<IN_LDS, FIRST_MODE, CL_THREADS, KLASS>(a, wi < a.nFront ? a.front[wi] : a.list[wi - a.nFront], region, firstGlobal, sh, acc);
   }
   u64 depth = acc[1];
   for (int s = 32; s; s >>= 1) depth += __shfl_down(depth, s);
@@ -862,7 +866,7 @@ void read_merge_kernel(h10x_block *__restrict__ blocks, const u64 *__restrict__ 
 // launch classes by working-set size: 0 = half a CU's LDS (barcodes with many ranks run their list loop on fewer waves:
 // histWaves), 2 = the whole LDS of a CU, 3 = HBM scratch (class 1 is no longer used)
 __global__ void cluster_classify_kernel(const h10x_block *__restrict__ blocks, const u32 *__restrict__ nGood, const u32 *__restrict__ entries, u32 codeMin, u32 codeMax,
-                                        u32 nBlocks /* LDS entries of first[] (ranked, hashed: barcodes of the data set) */, int ranked /* 1 ranked, 2 hashed */, u32 hashMinSlots, u32 bmWords, u32 waves0, size_t budget0, size_t budgetSmall, size_t budgetBig, int wide,
+                                        u32 nBlocks /* LDS entries of first[] (ranked, hashed: barcodes of the data set) */, int ranked /* 1 ranked, 2 hashed */, u32 hashMinSlots, u32 bmWords, u32 waves0, size_t budget0, size_t budgetSmall, size_t budgetBig, int wide, u32 bigRanks,
                                         u32 *__restrict__ list0, u32 *__restrict__ list1, u32 *__restrict__ list2, u32 *__restrict__ list3,
                                         u32 *__restrict__ counts) {
   const u32 c = codeMin + blockIdx.x * blockDim.x + threadIdx.x;
@@ -883,6 +887,10 @@ __global__ void cluster_classify_kernel(const h10x_block *__restrict__ blocks, c
     else if (histWaves(ranked ? rankedFirstEstimate(nBlocks, n) : nBlocks, n, CL_THREADS_HUGE / WAVE, bmWords, 2, budgetBig)) cls = 2;
     else cls = 3;
   }
+  // the largest barcodes of the main class go to the front of its work queue (list1, handed out before list0): the launch
+  // then does not end on a workgroup that drew a big one last. (Ordering the WHOLE queue by size was measured 17 % slower:
+  // like-sized workgroups run their phases in step.)
+  if (cls == 0 && n > bigRanks) cls = 1;
   for (int s = 32; s; s >>= 1) nRead = max(nRead, (u32)__shfl_xor((int)nRead, s));
   if (lane == 0 && nRead) atomicMax(&counts[8], nRead);
   u32 *const lists[4] = {list0, list1, list2, list3};
@@ -935,7 +943,8 @@ int stageC_cluster(Ctx *c, int codeMin, int codeMax, int threshold) {
   const int wide = c->maxGoodDepth > 65535u ? 1 : 0;         // list lengths / counts beyond the u16 arrays of the LDS instantiations
   cluster_classify_kernel<<<divUp(span, 256), 256, 0, st>>>(c->blocks.p, c->nGood.p, c->goodEntries.p, (u32)codeMin, (u32)codeMax,
                                                           firstMode == 1 || firstMode == 3 ? nGlobal : nFirstLds, firstMode == 1 ? 1 : (firstMode == 3 ? 2 : 0), hashMinSlots,
-                                                          bmWords, (u32)threads0 / WAVE, budget0, budgetSmall, budgetBig, wide, list0.p, list1.p, list2.p, list3.p, counts.p);
+                                                          bmWords, (u32)threads0 / WAVE, budget0, budgetSmall, budgetBig, wide, c->optBigRanks > 0 ? (u32)c->optBigRanks : c->meanGood + c->meanGood / 2,
+                                                          list0.p, list1.p, list2.p, list3.p, counts.p);
   u32 hc[12];
   H10X_HIP(c, hipMemcpyAsync(hc, counts.p, 48, hipMemcpyDeviceToHost, st));
   H10X_HIP(c, hipStreamSynchronize(st));
@@ -967,7 +976,7 @@ int stageC_cluster(Ctx *c, int codeMin, int codeMax, int threshold) {
   // hybrid placement: one first[] slot per resident workgroup of each LDS class
   DevBuf<unsigned char> firstSlots[3];
   const size_t firstStride = (((size_t)nGlobal * 2 + 255) & ~(size_t)255);
-  const u32 gridOf[3] = {hmin<u32>(hc[0], (u32)c->numCU * (u32)hmax<size_t>(1, (160 * 1024) / (budget0 + 1024))), hmin<u32>(hc[1], (u32)c->numCU * 2), hmin<u32>(hc[2], (u32)c->numCU)};   // class 1 unused
+  const u32 gridOf[3] = {hmin<u32>(hc[0] + hc[1], (u32)c->numCU * (u32)hmax<size_t>(1, (160 * 1024) / (budget0 + 1024))), hmin<u32>(hc[1], (u32)c->numCU * 2), hmin<u32>(hc[2], (u32)c->numCU)};   // class 1 unused
   if (firstMode == 2) for (int k = 0; k < 3; ++k) if (hc[k]) {
     H10X_HIP(c, firstSlots[k].alloc(firstStride * gridOf[k]));
     H10X_HIP(c, hipMemsetAsync(firstSlots[k].p, 0xFF, firstStride * gridOf[k], st));
@@ -996,12 +1005,12 @@ int stageC_cluster(Ctx *c, int codeMin, int codeMax, int threshold) {
   if (hc[2]) H10X_LAUNCH_LDS(2, CL_THREADS_HUGE, budgetBig, c->aux[1], list2.p, hc[2], gridOf[2], 6, ovfB.p)
   // the main launch (class 0) counts its own work and has its own hipEvent bracket on its stream: that is the launch the
   // roofline figure of bench.py is quoted for, and what a rocprofv3 kernel trace reports as cluster_kernel<true, *, 1024, 0>
-  if (hc[0]) {
-    a.stats = stats.p + 4;
+  if (hc[0] || hc[1]) {
+    a.stats = stats.p + 4; a.front = list1.p; a.nFront = hc[1];
     c->tstart(T_CLUSTER_MAIN);
     if (threads0 == 512) H10X_LAUNCH_LDS(0, 512, budget0, st, list0.p, hc[0], gridOf[0], 4, ovfA.p) else H10X_LAUNCH_LDS(0, CL_THREADS_SMALL, budget0, st, list0.p, hc[0], gridOf[0], 4, ovfA.p)
     c->tstop(T_CLUSTER_MAIN);
-    a.stats = stats.p;
+    a.stats = stats.p; a.front = nullptr; a.nFront = 0;
   }
   H10X_HIP(c, hipGetLastError());
   H10X_TRY(c->joinStreams(3));

@@ -17,6 +17,7 @@ struct h10x_session {
   int clusterLds;                                      /* test knob forwarded to h10x_set_option("cluster_lds_budget") */
   int firstCap;                                        /* test knob forwarded to h10x_set_option("cluster_first_cap") */
   int firstGlobal;                                     /* test knob forwarded to h10x_set_option("cluster_first_global") */
+  int bigRanks;                                        /* tuning knob forwarded to h10x_set_option("cluster_big_ranks") */
   int dbgSkip;                                         /* diagnostic knob forwarded to h10x_set_option("cluster_dbg_skip") */
   int threads0, budget0;                               /* tuning knobs forwarded to h10x_set_option("cluster_threads0" / "cluster_budget0") */
   int stamps;                                          /* diagnostic knob forwarded to h10x_set_option("cluster_stamps") */
@@ -67,6 +68,7 @@ static int *param_slot(h10x_session *s, const char *n) {
   if (!strcmp(n, "cluster_first_global")) return &s->firstGlobal;
   if (!strcmp(n, "cluster_first_cap")) return &s->firstCap;
   if (!strcmp(n, "cluster_dbg_skip")) return &s->dbgSkip;
+  if (!strcmp(n, "cluster_big_ranks")) return &s->bigRanks;
   if (!strcmp(n, "cluster_threads0")) return &s->threads0;
   if (!strcmp(n, "cluster_budget0")) return &s->budget0;
   return 0;
@@ -129,6 +131,7 @@ static int apply_options(h10x_session *s) {
   h10x_set_option(s->ctx, "cluster_first_global", s->firstGlobal);
   h10x_set_option(s->ctx, "cluster_first_cap", s->firstCap);
   h10x_set_option(s->ctx, "cluster_dbg_skip", s->dbgSkip);
+  h10x_set_option(s->ctx, "cluster_big_ranks", s->bigRanks);
   h10x_set_option(s->ctx, "cluster_threads0", s->threads0);
   h10x_set_option(s->ctx, "cluster_budget0", s->budget0);
   if (h10x_set_option(s->ctx, "stage_a_max_slots", s->maxSlots)) return fail_ctx(s);
