@@ -26,6 +26,29 @@ __global__ void gather_code_kernel(const u32 *__restrict__ entCode, const u32 *_
   u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; const u64 stride = (u64)gridDim.x * blockDim.x;
   for (; i < n; i += stride) out[i] = entCode[perm[i]] + codeBase;
 }
+// owner of a hash = the o with lowHash[o] <= h < lowHash[o + 1] (value ranges, so owner o's hashes are all smaller than owner o + 1's)
+__global__ void owner_key_kernel(const u64 *__restrict__ entHash, u64 n, const u64 *__restrict__ lowHash /* N+1 */, int N, u32 *__restrict__ key) {
+  u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; const u64 stride = (u64)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) {
+    const u64 h = entHash[i];
+    int lo = 0, hi = N;                                      // largest o with lowHash[o] <= h
+    while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (lowHash[mid] <= h) lo = mid; else hi = mid; }
+    key[i] = (u32)lo;
+  }
+}
+__global__ void owner_key_bounds_kernel(const u32 *__restrict__ sKey, u64 n, int N, u64 *__restrict__ bound) {
+  const int o = blockIdx.x * blockDim.x + threadIdx.x;
+  if (o > N) return;
+  if (o == N) { bound[o] = n; return; }
+  u64 lo = 0, hi = n;
+  while (lo < hi) { const u64 mid = (lo + hi) >> 1; if (sKey[mid] < (u32)o) lo = mid + 1; else hi = mid; }
+  bound[o] = lo;
+}
+__global__ void gather_send_kernel(const u64 *__restrict__ entHash, const u32 *__restrict__ entCode, const u32 *__restrict__ perm, u64 n, u32 codeBase,
+                                   u64 *__restrict__ sHash, u32 *__restrict__ sCode) {
+  u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; const u64 stride = (u64)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) { const u32 p = perm[i]; sHash[i] = entHash[p]; sCode[i] = entCode[p] + codeBase; }
+}
 // first position in the ascending array whose hash belongs to owner >= o, for o = 0..N
 __global__ void owner_bounds_kernel(const u64 *__restrict__ sHash, u64 n, const u64 *__restrict__ lowHash /* N+1 */, int N, u64 *__restrict__ bound) {
   const int o = blockIdx.x * blockDim.x + threadIdx.x;
@@ -108,20 +131,23 @@ int shard_readFqb(Ctx *c, Comm *cm, const u32 *dRec, u64 nRec) {
   c->codeBase = (u32)codeBase; c->nBlocksGlobal = (u32)totalBarcodes + 1;
   const u32 nB = c->nBlocksGlobal;
 
-  // ---- 2. my entries by hash owner
+  // ---- 2. my entries by hash owner: a stable partition on the owner number (ONE radix pass on log2 N bits; the owners
+  //         sort by hash anyway), so every owner's part stays in block = barcode order
   c->tstart(T_SORT_HASH);
-  DevBuf<u64> sHash; DevBuf<u32> perm, sCodeG, io;
+  DevBuf<u64> sHash; DevBuf<u32> perm, sCodeG, io, oKey, oKeyS;
   H10X_HIP(c, sHash.alloc(H)); H10X_HIP(c, perm.alloc(H)); H10X_HIP(c, sCodeG.alloc(H)); H10X_HIP(c, io.alloc(H));
-  if (H) iota_kernel<<<gridFor(H), 256, 0, st>>>(io.p, H);
-  H10X_TRY(prim_sort_pairs_u64_u32(c, pt, entHash.p, sHash.p, io.p, perm.p, H, 0, 2 * k));
-  if (H) gather_code_kernel<<<gridFor(H), 256, 0, st>>>(entCode.p, perm.p, H, c->codeBase, sCodeG.p);
+  H10X_HIP(c, oKey.alloc(H)); H10X_HIP(c, oKeyS.alloc(H));
   std::vector<u64> lowHash((size_t)N + 1), bound((size_t)N + 1);
   for (int o = 0; o <= N; ++o) lowHash[o] = (u64)((((unsigned __int128)o << (2 * k)) + (unsigned)N - 1) / (unsigned)N);   // ceil(o * 4^k / N)
   DevBuf<u64> dLow, dBound; H10X_HIP(c, dLow.alloc((size_t)N + 1)); H10X_HIP(c, dBound.alloc((size_t)N + 1));
   H10X_HIP(c, hipMemcpyAsync(dLow.p, lowHash.data(), ((size_t)N + 1) * 8, hipMemcpyHostToDevice, st));
-  owner_bounds_kernel<<<1, 64 * ((N + 64) / 64), 0, st>>>(sHash.p, H, dLow.p, N, dBound.p);
+  if (H) { iota_kernel<<<gridFor(H), 256, 0, st>>>(io.p, H); owner_key_kernel<<<gridFor(H), 256, 0, st>>>(entHash.p, H, dLow.p, N, oKey.p); }
+  H10X_TRY(prim_sort_pairs_u32_u32(c, pt, oKey.p, oKeyS.p, io.p, perm.p, H, 0, bitsForS((u64)N - 1)));
+  if (H) gather_send_kernel<<<gridFor(H), 256, 0, st>>>(entHash.p, entCode.p, perm.p, H, c->codeBase, sHash.p, sCodeG.p);
+  owner_key_bounds_kernel<<<1, 64 * ((N + 64) / 64), 0, st>>>(oKeyS.p, H, N, dBound.p);
   H10X_HIP(c, hipMemcpyAsync(bound.data(), dBound.p, ((size_t)N + 1) * 8, hipMemcpyDeviceToHost, st));
   H10X_HIP(c, hipStreamSynchronize(st));
+  oKey.release(); oKeyS.release();
   std::vector<u64> sendCnt((size_t)N), sendOff((size_t)N), matrix((size_t)N * N), recvCnt((size_t)N), recvOff((size_t)N);
   for (int o = 0; o < N; ++o) { sendOff[o] = bound[o]; sendCnt[o] = bound[o + 1] - bound[o]; }
   H10X_TRY(cm->allgatherHost(c, sendCnt.data(), matrix.data(), (size_t)N * 8));
@@ -137,7 +163,8 @@ int shard_readFqb(Ctx *c, Comm *cm, const u32 *dRec, u64 nRec) {
   // ---- 3. owner side: received runs are in rank (= barcode) order, a stable sort by hash keeps barcodes ascending
   DevBuf<u64> oHash; DevBuf<u32> oQ; H10X_HIP(c, oHash.alloc(M)); H10X_HIP(c, oQ.alloc(M));
   { DevBuf<u32> qio; H10X_HIP(c, qio.alloc(M)); if (M) iota_kernel<<<gridFor(M), 256, 0, st>>>(qio.p, M);
-    H10X_TRY(prim_sort_pairs_u64_u32(c, pt, rHash.p, oHash.p, qio.p, oQ.p, M, 0, 2 * k)); H10X_HIP(c, hipStreamSynchronize(st)); }
+    int topConst = 0; if ((N & (N - 1)) == 0) while ((1 << topConst) < N) ++topConst;     // N = 2^t: an owner's hashes share their top t bits
+    H10X_TRY(prim_sort_pairs_u64_u32(c, pt, rHash.p, oHash.p, qio.p, oQ.p, M, 0, 2 * k > topConst ? 2 * k - topConst : 1)); H10X_HIP(c, hipStreamSynchronize(st)); }
   H10X_HIP(c, c->oRows.alloc(M));
   if (M) gather_u32_kernel<<<gridFor(M), 256, 0, st>>>(rCode.p, oQ.p, M, c->oRows.p);
   c->tstop(T_SORT_HASH);
