@@ -156,6 +156,8 @@ struct Ctx {
   struct Comm *comm = nullptr; bool sharded = false;
   u32 codeBase = 0, nBlocksGlobal = 0;
   DevBuf<u32> oRows, oSegStart, oIndex; u32 oU = 0; u64 oM = 0;
+  DevBuf<u64> oHash;          // this owner's distinct hashes (by oIndex) until the global tables are built
+  bool tablesPending = false; // sharded: hashValue[] / hashIndex[] not built yet (shard_materializeTables, collective)
 
   // options / measurement
   int64_t optMaxSlots = 0;    // testing knob: cap stage-A LDS table
@@ -243,6 +245,7 @@ int stageC_cluster(Ctx *c, int codeMin, int codeMax, int threshold);
 int stageC_split(Ctx *c);
 int stageD_cribGenome(Ctx *c, const u8 *hostCodes, const u64 *seqStart, u32 nSeq, int which, u64 *nPresent, u64 *nAbsent);
 int stageD_cribFinish(Ctx *c);
-int shard_exchangeRows(Ctx *c);                 // sharded --hashDepthRange: allgather the in-range barcode lists
+int shard_exchangeRows(Ctx *c);
+int shard_materializeTables(Ctx *c);            // collective: hashValue[] + hashIndex[] on every rank (deferred by the sharded --readFQB)                 // sharded --hashDepthRange: allgather the in-range barcode lists
 
 }  // namespace h10x

@@ -94,6 +94,7 @@ static void reset_state(Ctx &c) {
   c.within.release(); c.goodPos.release(); c.nGood.release(); c.goodEntries.release();
   c.hashNumber = 1; c.nBlocks = 0; c.nEntries = 0; c.nRecords = 0;
   c.sharded = false; c.codeBase = 0; c.nBlocksGlobal = 0; c.oRows.release(); c.oSegStart.release(); c.oIndex.release(); c.oU = 0; c.oM = 0;
+  c.oHash.release(); c.tablesPending = false;
   memset(&c.ctr, 0, sizeof c.ctr);
   c.haveCrib = false; c.cribGenomes = 0; c.cribChr.release(); c.cribPos.release(); c.cribType.release(); c.cribHist.release();
   for (int g = 0; g < 2; ++g) { c.cribCount[g].release(); c.cribFirst[g].release(); }

@@ -105,10 +105,13 @@ __global__ void depth_of_kernel(const u32 *__restrict__ segStart, u32 U, u32 *__
   const u32 d = blockIdx.x * blockDim.x + threadIdx.x;
   if (d < U) depth[d] = segStart[d + 1] - segStart[d];
 }
-__global__ void scatter_tables_kernel(const u32 *__restrict__ idx, const u64 *__restrict__ hash, const u32 *__restrict__ depth, u64 n,
-                                      u64 *__restrict__ hashValue, u32 *__restrict__ hashDepth) {
+__global__ void scatter_depth_kernel(const u32 *__restrict__ idx, const u32 *__restrict__ depth, u64 n, u32 *__restrict__ hashDepth) {
   u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; const u64 stride = (u64)gridDim.x * blockDim.x;
-  for (; i < n; i += stride) { hashValue[idx[i]] = hash[i]; hashDepth[idx[i]] = depth[i]; }
+  for (; i < n; i += stride) hashDepth[idx[i]] = depth[i];
+}
+__global__ void scatter_value_kernel(const u32 *__restrict__ idx, const u64 *__restrict__ hash, u64 n, u64 *__restrict__ hashValue) {
+  u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; const u64 stride = (u64)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) hashValue[idx[i]] = hash[i];
 }
 
 static int bitsForS(u64 v) { int b = 1; while (b < 64 && (v >> b)) ++b; return b; }
@@ -217,27 +220,51 @@ int shard_readFqb(Ctx *c, Comm *cm, const u32 *dRec, u64 nRec) {
     H10X_TRY(stageB_finishClusHash(c, key)); }
   c->tstop(T_CLUSHASH);
 
-  // ---- 6. everyone gets hashValue[] / hashDepth[] (the .hash tables and the depth filter need them in full)
+  // ---- 6. everyone gets hashDepth[] (the depth filter needs it in full). hashValue[] and the probe table hashIndex[] are
+  //         only wanted by --writeHash / the crib: they are built when the shards are gathered (shard_materializeTables),
+  //         not on every rank after every --readFQB (at N = 8: 24 M hash values allgathered and inserted into a 512 MB
+  //         table per rank, for nothing on the clustering path)
   c->tstart(T_PROBE);
   std::vector<u64> uo((size_t)N); { u64 u = Uo; H10X_TRY(cm->allgatherHost(c, &u, uo.data(), 8)); }
   std::vector<u64> sc((size_t)N, Uo), so((size_t)N, 0), rc((size_t)N), ro((size_t)N); u64 Utot = 0;
   for (int r = 0; r < N; ++r) { rc[r] = uo[r]; ro[r] = Utot; Utot += uo[r]; }
   if (Utot != U) return c->fail("sharded index: %llu distinct hashes gathered, %u numbered", (u64)Utot, U);
-  DevBuf<u32> dDepth, gIdx, gDepth; DevBuf<u64> gHash;
-  H10X_HIP(c, dDepth.alloc(Uo)); H10X_HIP(c, gIdx.alloc(U)); H10X_HIP(c, gDepth.alloc(U)); H10X_HIP(c, gHash.alloc(U));
+  DevBuf<u32> dDepth, gIdx, gDepth;
+  H10X_HIP(c, dDepth.alloc(Uo)); H10X_HIP(c, gIdx.alloc(U)); H10X_HIP(c, gDepth.alloc(U));
   if (Uo) depth_of_kernel<<<divUp(Uo, 256), 256, 0, st>>>(c->oSegStart.p, Uo, dDepth.p);
   H10X_TRY(cm->alltoallv(c, c->oIndex.p, sc.data(), so.data(), gIdx.p, rc.data(), ro.data(), 4));
   H10X_TRY(cm->alltoallv(c, dDepth.p, sc.data(), so.data(), gDepth.p, rc.data(), ro.data(), 4));
-  H10X_TRY(cm->alltoallv(c, dHash.p, sc.data(), so.data(), gHash.p, rc.data(), ro.data(), 8));
-  H10X_HIP(c, c->hashValue.alloc((size_t)U + 1)); H10X_HIP(c, c->hashDepth.alloc((size_t)U + 1));
-  H10X_HIP(c, hipMemsetAsync(c->hashValue.p, 0, 8, st)); H10X_HIP(c, hipMemsetAsync(c->hashDepth.p, 0, 4, st));
-  if (U) scatter_tables_kernel<<<gridFor(U), 256, 0, st>>>(gIdx.p, gHash.p, gDepth.p, U, c->hashValue.p, c->hashDepth.p);
+  H10X_HIP(c, c->hashDepth.alloc((size_t)U + 1));
+  H10X_HIP(c, hipMemsetAsync(c->hashDepth.p, 0, 4, st));
+  if (U) scatter_depth_kernel<<<gridFor(U), 256, 0, st>>>(gIdx.p, gDepth.p, U, c->hashDepth.p);
+  c->oHash.swap(dHash);                                      // this owner's distinct hashes, for shard_materializeTables
+  c->hashValue.release(); c->hashIndex.release(); c->tablesPending = true;
   c->tstop(T_PROBE);
-  H10X_TRY(stageB_buildProbeTable(c));
   H10X_HIP(c, hipStreamSynchronize(st));
   c->rows.release(); c->rowStart.release();                  // barcode lists arrive with --hashDepthRange
   c->ctr.distinct = U;
   c->comm = cm; c->sharded = true; c->haveState = true;
+  return 0;
+}
+
+// collective: hashValue[] (allgather of every owner's distinct hashes, by index) and the probe table on every rank
+int shard_materializeTables(Ctx *c) {
+  if (!c->tablesPending) return 0;
+  hipStream_t st = c->stream; Comm *cm = c->comm;
+  const int N = cm->n; const u32 Uo = c->oU, U = c->hashNumber - 1;
+  std::vector<u64> uo((size_t)N); { u64 u = Uo; H10X_TRY(cm->allgatherHost(c, &u, uo.data(), 8)); }
+  std::vector<u64> sc((size_t)N, Uo), so((size_t)N, 0), rc((size_t)N), ro((size_t)N); u64 Utot = 0;
+  for (int r = 0; r < N; ++r) { rc[r] = uo[r]; ro[r] = Utot; Utot += uo[r]; }
+  DevBuf<u32> gIdx; DevBuf<u64> gHash;
+  H10X_HIP(c, gIdx.alloc(U)); H10X_HIP(c, gHash.alloc(U));
+  H10X_TRY(cm->alltoallv(c, c->oIndex.p, sc.data(), so.data(), gIdx.p, rc.data(), ro.data(), 4));
+  H10X_TRY(cm->alltoallv(c, c->oHash.p, sc.data(), so.data(), gHash.p, rc.data(), ro.data(), 8));
+  H10X_HIP(c, c->hashValue.alloc((size_t)U + 1));
+  H10X_HIP(c, hipMemsetAsync(c->hashValue.p, 0, 8, st));
+  if (U) scatter_value_kernel<<<gridFor(U), 256, 0, st>>>(gIdx.p, gHash.p, U, c->hashValue.p);
+  H10X_TRY(stageB_buildProbeTable(c));
+  H10X_HIP(c, hipStreamSynchronize(st));
+  c->oHash.release(); c->tablesPending = false;
   return 0;
 }
 
@@ -312,6 +339,7 @@ __global__ void blocks_nhash_kernel(const h10x_block *__restrict__ blocks, u32 n
 int shard_gather(Ctx *c) {
   hipStream_t st = c->stream; PrimTemp pt; Comm *cm = c->comm;
   if (!c->sharded) return 0;
+  H10X_TRY(shard_materializeTables(c));                      // what --writeHash needs beside blocks / clusHash
   const int N = cm->n, me = cm->rank;
   ShardInfo mine{(u64)c->nBlocks - 1, c->nEntries, c->nRecords}; std::vector<ShardInfo> all((size_t)N);
   H10X_TRY(cm->allgatherHost(c, &mine, all.data(), sizeof mine));

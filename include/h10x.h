@@ -148,12 +148,14 @@ int  h10x_comm_size(const h10x_comm *comm);
 /* bind a communicator to a context (collective calls below are made by every rank in the same order) */
 int  h10x_shard_attach(h10x_ctx *ctx, h10x_comm *comm);
 /* --readFQB on this rank's contiguous barcode range of the sorted file (cut with h10x_host_partition): stage A
-   locally, then the hash-owner exchange; afterwards every rank holds hashValue/hashDepth/hashIndex of the whole data
-   set and blocks/clusHash of its own barcodes. h10x_depth_range / h10x_cluster work as usual (global barcode
-   numbers; --hashDepthRange also allgathers the barcode lists of the in-range hashes). */
+   locally, then the hash-owner exchange; afterwards every rank holds hashDepth of the whole data set and
+   blocks/clusHash of its own barcodes. h10x_depth_range / h10x_cluster work as usual (global barcode numbers;
+   --hashDepthRange also allgathers the barcode lists of the in-range hashes). hashValue / hashIndex of the whole
+   set (only --writeHash and the crib read them) are built by h10x_shard_gather, not here. */
 int  h10x_shard_read_fqb(h10x_ctx *ctx, const uint32_t *host_records, uint64_t n_records);
 int  h10x_shard_read_fqb_device(h10x_ctx *ctx, const uint32_t *dev_records, uint64_t n_records);
-/* collective: rank 0 receives every rank's blocks and clusHash and from then on exports like a single-GPU context */
+/* collective: every rank builds hashValue / hashIndex of the whole set; rank 0 receives every rank's blocks and
+   clusHash and from then on exports like a single-GPU context */
 int  h10x_shard_gather(h10x_ctx *ctx);
 /* collective plumbing for launchers: barrier, and max over ranks of a host double (timing) */
 int  h10x_shard_barrier(h10x_ctx *ctx);
