@@ -115,6 +115,11 @@ struct Timer { hipEvent_t a = nullptr, b = nullptr; double ms = 0; uint64_t laun
 // ---- the context ------------------------------------------------------------------------------------
 struct Ctx {
   h10x_params prm{};
+  // Every mosh is a multiple of w (and the stand-in entry of a block without moshes is 0): the entries travel and are
+  // sorted as q = hash / w, log2(w) fewer key bits (k = 21, w = 31: 38 instead of 42 = one radix pass less), and are
+  // multiplied back where hashValue[] is written or the probe table is searched. Exact division: w = 2^keyShift * m,
+  // q = (hash >> keyShift) * keyInv with keyInv = m^-1 mod 2^64. Set by stageA_run.
+  u64 keyInv = 1; int keyShift = 0; int keyBits = 64;
   int device = 0;
   hipStream_t stream = nullptr;
   hipStream_t aux[3] = {nullptr, nullptr, nullptr};   // side streams for independent launches (fork/join around them)

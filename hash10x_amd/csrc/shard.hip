@@ -1,7 +1,7 @@
 // shard.hip — the multi-GPU form of --readFQB / --hashDepthRange / --writeHash.
 //
 // Barcodes are sharded by contiguous ranges of the sorted .fqb (rank r owns barcodes codeBase_r+1 ..); hashes are
-// owned by value range (owner(h) = floor(h * N / 4^k)), so the distinct hashes of owner o all precede those of o+1.
+// owned by value range (owner(h) = floor(q * N / nKeys), q = h / w the key the entries travel with), so the distinct hashes of owner o all precede those of o+1.
 //   1. every rank: mosh extraction of its records (stage A, unchanged)                                  — no traffic
 //   2. all-to-all: each (hash, global barcode) entry goes to the hash's owner                           — 12 B per entry
 //   3. owner: stable sort by hash => distinct hashes, first barcode, depth, barcode lists (ascending)
@@ -109,9 +109,9 @@ __global__ void scatter_depth_kernel(const u32 *__restrict__ idx, const u32 *__r
   u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; const u64 stride = (u64)gridDim.x * blockDim.x;
   for (; i < n; i += stride) hashDepth[idx[i]] = depth[i];
 }
-__global__ void scatter_value_kernel(const u32 *__restrict__ idx, const u64 *__restrict__ hash, u64 n, u64 *__restrict__ hashValue) {
+__global__ void scatter_value_kernel(const u32 *__restrict__ idx, const u64 *__restrict__ hash /* hash / w */, u64 n, u64 w, u64 *__restrict__ hashValue) {
   u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; const u64 stride = (u64)gridDim.x * blockDim.x;
-  for (; i < n; i += stride) hashValue[idx[i]] = hash[i];
+  for (; i < n; i += stride) hashValue[idx[i]] = hash[i] * w;
 }
 
 static int bitsForS(u64 v) { int b = 1; while (b < 64 && (v >> b)) ++b; return b; }
@@ -141,7 +141,9 @@ int shard_readFqb(Ctx *c, Comm *cm, const u32 *dRec, u64 nRec) {
   H10X_HIP(c, sHash.alloc(H)); H10X_HIP(c, perm.alloc(H)); H10X_HIP(c, sCodeG.alloc(H)); H10X_HIP(c, io.alloc(H));
   H10X_HIP(c, oKey.alloc(H)); H10X_HIP(c, oKeyS.alloc(H));
   std::vector<u64> lowHash((size_t)N + 1), bound((size_t)N + 1);
-  for (int o = 0; o <= N; ++o) lowHash[o] = (u64)((((unsigned __int128)o << (2 * k)) + (unsigned)N - 1) / (unsigned)N);   // ceil(o * 4^k / N)
+  // (the entries hold hash / w, Ctx::keyInv: the owner ranges are cut in that space)
+  const u64 nKeys = ((2 * k >= 64 ? ~0ULL : ((u64)1 << (2 * k)) - 1) / (u64)c->prm.w) + 1;
+  for (int o = 0; o <= N; ++o) lowHash[o] = (u64)(((unsigned __int128)o * nKeys + (unsigned)N - 1) / (unsigned)N);          // ceil(o * nKeys / N)
   DevBuf<u64> dLow, dBound; H10X_HIP(c, dLow.alloc((size_t)N + 1)); H10X_HIP(c, dBound.alloc((size_t)N + 1));
   H10X_HIP(c, hipMemcpyAsync(dLow.p, lowHash.data(), ((size_t)N + 1) * 8, hipMemcpyHostToDevice, st));
   if (H) { iota_kernel<<<gridFor(H), 256, 0, st>>>(io.p, H); owner_key_kernel<<<gridFor(H), 256, 0, st>>>(entHash.p, H, dLow.p, N, oKey.p); }
@@ -166,8 +168,7 @@ int shard_readFqb(Ctx *c, Comm *cm, const u32 *dRec, u64 nRec) {
   // ---- 3. owner side: received runs are in rank (= barcode) order, a stable sort by hash keeps barcodes ascending
   DevBuf<u64> oHash; DevBuf<u32> oQ; H10X_HIP(c, oHash.alloc(M)); H10X_HIP(c, oQ.alloc(M));
   { DevBuf<u32> qio; H10X_HIP(c, qio.alloc(M)); if (M) iota_kernel<<<gridFor(M), 256, 0, st>>>(qio.p, M);
-    int topConst = 0; if ((N & (N - 1)) == 0) while ((1 << topConst) < N) ++topConst;     // N = 2^t: an owner's hashes share their top t bits
-    H10X_TRY(prim_sort_pairs_u64_u32(c, pt, rHash.p, oHash.p, qio.p, oQ.p, M, 0, 2 * k > topConst ? 2 * k - topConst : 1)); H10X_HIP(c, hipStreamSynchronize(st)); }
+    H10X_TRY(prim_sort_pairs_u64_u32(c, pt, rHash.p, oHash.p, qio.p, oQ.p, M, 0, c->keyBits)); H10X_HIP(c, hipStreamSynchronize(st)); }
   H10X_HIP(c, c->oRows.alloc(M));
   if (M) gather_u32_kernel<<<gridFor(M), 256, 0, st>>>(rCode.p, oQ.p, M, c->oRows.p);
   c->tstop(T_SORT_HASH);
@@ -261,7 +262,7 @@ int shard_materializeTables(Ctx *c) {
   H10X_TRY(cm->alltoallv(c, c->oHash.p, sc.data(), so.data(), gHash.p, rc.data(), ro.data(), 8));
   H10X_HIP(c, c->hashValue.alloc((size_t)U + 1));
   H10X_HIP(c, hipMemsetAsync(c->hashValue.p, 0, 8, st));
-  if (U) scatter_value_kernel<<<gridFor(U), 256, 0, st>>>(gIdx.p, gHash.p, U, c->hashValue.p);
+  if (U) scatter_value_kernel<<<gridFor(U), 256, 0, st>>>(gIdx.p, gHash.p, U, (u64)c->prm.w, c->hashValue.p);
   H10X_TRY(stageB_buildProbeTable(c));
   H10X_HIP(c, hipStreamSynchronize(st));
   c->oHash.release(); c->tablesPending = false;

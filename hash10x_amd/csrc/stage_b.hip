@@ -38,12 +38,12 @@ __global__ void seg_scatter_kernel(const u64 *__restrict__ sHash, const u32 *__r
 
 // i-th distinct hash in (firstBarcode, hash) order gets index i + 1
 __global__ void assign_index_kernel(const u32 *__restrict__ order, const u64 *__restrict__ dHash, const u32 *__restrict__ segStart,
-                                    u32 U, u64 *__restrict__ hashValue, u32 *__restrict__ hashDepth, u64 *__restrict__ rowStart) {
+                                    u32 U, u64 w /* dHash holds hash / w */, u64 *__restrict__ hashValue, u32 *__restrict__ hashDepth, u64 *__restrict__ rowStart) {
   const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i == 0) { hashValue[0] = 0; hashDepth[0] = 0; rowStart[0] = 0; }
   if (i >= U) return;
   const u32 d = order[i];
-  hashValue[i + 1] = dHash[d];
+  hashValue[i + 1] = dHash[d] * w;
   hashDepth[i + 1] = segStart[d + 1] - segStart[d];
   rowStart[i + 1] = segStart[d];
 }
@@ -75,11 +75,11 @@ __global__ void probe_finish_kernel(u32 *__restrict__ table, u64 n) {
 
 // ------------------------------------------------------------------------------------------ clusHash
 __global__ void lookup_pack_kernel(const u64 *__restrict__ entHash, const u32 *__restrict__ entRead, u64 n,
-                                   const u32 *__restrict__ table, const u64 *__restrict__ hashValue, int B, u64 *__restrict__ key) {
+                                   const u32 *__restrict__ table, const u64 *__restrict__ hashValue, int B, u64 w /* entHash holds hash / w */, u64 *__restrict__ key) {
   u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
   const u64 stride = (u64)gridDim.x * blockDim.x;
   for (; i < n; i += stride) {
-    const u32 ix = probe_find(table, hashValue, B, entHash[i]);
+    const u32 ix = probe_find(table, hashValue, B, entHash[i] * w);
     key[i] = ((u64)ix << 32) | (u64)(entRead[i] & 0xFFFFu);  // ClusterHash.read is U16 (hash10x.c:37,180)
   }
 }
@@ -108,7 +108,7 @@ int stageB_run(Ctx *c, DevBuf<u64> &entHash, DevBuf<u32> &entCode, DevBuf<u32> &
   c->tstart(T_SORT_HASH);
   DevBuf<u64> sHash; DevBuf<u32> sCode;
   H10X_HIP(c, sHash.alloc(H)); H10X_HIP(c, sCode.alloc(H));
-  H10X_TRY(prim_sort_pairs_u64_u32(c, pt, entHash.p, sHash.p, entCode.p, sCode.p, H, 0, 2 * c->prm.k));
+  H10X_TRY(prim_sort_pairs_u64_u32(c, pt, entHash.p, sHash.p, entCode.p, sCode.p, H, 0, c->keyBits));
   c->tstop(T_SORT_HASH);
 
   // ---- distinct hashes, first barcode, depth
@@ -137,7 +137,7 @@ int stageB_run(Ctx *c, DevBuf<u64> &entHash, DevBuf<u32> &entCode, DevBuf<u32> &
   c->hashNumber = U + 1;
   H10X_HIP(c, c->hashValue.alloc((size_t)U + 1)); H10X_HIP(c, c->hashDepth.alloc((size_t)U + 1));
   H10X_HIP(c, c->rowStart.alloc((size_t)U + 2));
-  assign_index_kernel<<<divUp((u64)U + 1, 256), 256, 0, st>>>(order.p, dHash.p, segStart.p, U, c->hashValue.p, c->hashDepth.p, c->rowStart.p);
+  assign_index_kernel<<<divUp((u64)U + 1, 256), 256, 0, st>>>(order.p, dHash.p, segStart.p, U, (u64)c->prm.w, c->hashValue.p, c->hashDepth.p, c->rowStart.p);
   c->rows.swap(sCode);                                       // barcode lists, grouped by hash (ascending barcodes)
   c->tstop(T_RANK);
   sHash.release(); dHash.release(); dFirst.release(); iota.release(); dFirstSorted.release();
@@ -148,7 +148,7 @@ int stageB_run(Ctx *c, DevBuf<u64> &entHash, DevBuf<u32> &entCode, DevBuf<u32> &
   c->tstart(T_CLUSHASH);
   if (H) {
     DevBuf<u64> key; H10X_HIP(c, key.alloc(H));
-    lookup_pack_kernel<<<gH, 256, 0, st>>>(entHash.p, entRead.p, H, c->hashIndex.p, c->hashValue.p, B, key.p);
+    lookup_pack_kernel<<<gH, 256, 0, st>>>(entHash.p, entRead.p, H, c->hashIndex.p, c->hashValue.p, B, (u64)c->prm.w, key.p);
     H10X_TRY(stageB_finishClusHash(c, key));
   } else H10X_HIP(c, c->clusHash.alloc(0));
   c->tstop(T_CLUSHASH);
