@@ -45,6 +45,11 @@ int prim_seg_sort_keys_u64(Ctx *c, PrimTemp &t, const u64 *kin, u64 *kout, u32 n
   PRIM_TWO_PHASE(c, t, rocprim::segmented_radix_sort_keys(tmp, bytes, kin, kout, n, nSeg, begin, end, (unsigned)b0, (unsigned)b1, c->stream));
   return 0;
 }
+int prim_seg_sort_keys_u32(Ctx *c, PrimTemp &t, const u32 *kin, u32 *kout, u32 n, u32 nSeg, const u32 *begin, const u32 *end, int b0, int b1) {
+  if (!n || !nSeg) return 0;
+  PRIM_TWO_PHASE(c, t, rocprim::segmented_radix_sort_keys(tmp, bytes, kin, kout, n, nSeg, begin, end, (unsigned)b0, (unsigned)b1, c->stream));
+  return 0;
+}
 int prim_reduce_max_u32(Ctx *c, PrimTemp &t, const u32 *in, u32 *out, size_t n) {
   PRIM_TWO_PHASE(c, t, rocprim::reduce(tmp, bytes, in, out, (u32)0, n, rocprim::maximum<u32>(), c->stream));
   return 0;

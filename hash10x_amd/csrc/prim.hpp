@@ -16,6 +16,7 @@ int prim_sort_pairs_u64_u32(Ctx *c, PrimTemp &t, const u64 *kin, u64 *kout, cons
 int prim_sort_pairs_u32_u32(Ctx *c, PrimTemp &t, const u32 *kin, u32 *kout, const u32 *vin, u32 *vout, size_t n, int beginBit, int endBit);
 // per-segment sort of 64-bit keys (segments = [begin[i], end[i]) ), keys must be distinct per segment
 int prim_seg_sort_keys_u64(Ctx *c, PrimTemp &t, const u64 *kin, u64 *kout, u32 n, u32 nSeg, const u32 *begin, const u32 *end, int beginBit, int endBit);
+int prim_seg_sort_keys_u32(Ctx *c, PrimTemp &t, const u32 *kin, u32 *kout, u32 n, u32 nSeg, const u32 *begin, const u32 *end, int beginBit, int endBit);
 int prim_reduce_max_u32(Ctx *c, PrimTemp &t, const u32 *in, u32 *out, size_t n);
 int prim_reduce_sum_u32_u64(Ctx *c, PrimTemp &t, const u32 *in, u64 *out, size_t n);
 

@@ -49,11 +49,13 @@ __global__ void within_depth_kernel(const u32 *__restrict__ depth, const u8 *__r
   if (i < hashNumber) out[i] = within[i] ? depth[i] : 0;
 }
 
-// per block: keys (depth << 16 | position) of its in-range hashes, appended in any order
+// per block: keys (depth << 16 | position) of its in-range hashes, appended in any order; KT = u32 while the largest
+// in-range depth fits 16 bits (the segmented sort then moves half the bytes)
+template <typename KT>
 __global__ __launch_bounds__(256)
 void good_keys_kernel(const h10x_clushash *__restrict__ ch, const u64 *__restrict__ blockOff, const h10x_block *__restrict__ blocks,
                       u32 nBlocks, const u8 *__restrict__ within, const u32 *__restrict__ depth,
-                      u64 *__restrict__ key, u32 *__restrict__ nGood, u32 *__restrict__ segEnd, u32 *__restrict__ entries /* sum of depths, saturating */) {
+                      KT *__restrict__ key, u32 *__restrict__ nGood, u32 *__restrict__ segEnd, u32 *__restrict__ entries /* sum of depths, saturating */) {
   __shared__ u32 sCount; __shared__ unsigned long long sDepth;
   for (u32 c = blockIdx.x; c < nBlocks; c += gridDim.x) {
     const u64 o = blockOff[c]; const u32 nHash = blocks[c].nHash;
@@ -71,7 +73,7 @@ void good_keys_kernel(const h10x_clushash *__restrict__ ch, const u64 *__restric
         u32 wb = 0;
         if (lane == 0 && bal) wb = atomicAdd(&sCount, (u32)__popcll(bal));
         wb = __shfl(wb, 0);
-        if (good) key[o + wb + (u32)__popcll(bal & ((1ULL << lane) - 1))] = ((u64)depth[ix] << 16) | (u64)p;
+        if (good) key[o + wb + (u32)__popcll(bal & ((1ULL << lane) - 1))] = (KT)(((KT)depth[ix] << 16) | (KT)p);
       }
     }
     for (int sft = 32; sft; sft >>= 1) myDepth += __shfl_down(myDepth, sft);
@@ -80,7 +82,8 @@ void good_keys_kernel(const h10x_clushash *__restrict__ ch, const u64 *__restric
     if (threadIdx.x == 0) { nGood[c] = sCount; segEnd[c] = (u32)o + sCount; entries[c] = sDepth > 0xFFFFFFFFull ? 0xFFFFFFFFu : (u32)sDepth; }
   }
 }
-__global__ void good_pos_kernel(const u64 *__restrict__ key, u64 n, u16 *__restrict__ pos) {
+template <typename KT>
+__global__ void good_pos_kernel(const KT *__restrict__ key, u64 n, u16 *__restrict__ pos) {
   u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
   const u64 stride = (u64)gridDim.x * blockDim.x;
   for (; i < n; i += stride) pos[i] = (u16)(key[i] & 0xFFFF);
@@ -103,14 +106,21 @@ int stageC_depthRange(Ctx *c, int lo, int hi) {
     c->haveRange = true; c->rangeMin = lo; c->rangeMax = hi;
   }
   // goodHashesBuild (hash10x.c:738-766)
-  DevBuf<u64> key, keyS; DevBuf<u32> off32, segEnd, wdepth, red;
-  H10X_HIP(c, key.alloc(H)); H10X_HIP(c, keyS.alloc(H)); H10X_HIP(c, off32.alloc((size_t)nBlocks + 1));
+  DevBuf<u64> key, keyS; DevBuf<u32> key32, keyS32, off32, segEnd, wdepth, red;
+  H10X_HIP(c, off32.alloc((size_t)nBlocks + 1));
   H10X_HIP(c, segEnd.alloc(nBlocks)); H10X_HIP(c, wdepth.alloc(U1)); H10X_HIP(c, red.alloc(2));
   H10X_HIP(c, c->nGood.alloc(nBlocks)); H10X_HIP(c, c->goodPos.alloc(H)); H10X_HIP(c, c->goodEntries.alloc(nBlocks));
   within_depth_kernel<<<divUp(U1, 256), 256, 0, st>>>(c->hashDepth.p, c->within.p, U1, wdepth.p);
   H10X_TRY(prim_reduce_max_u32(c, pt, wdepth.p, red.p, U1));
-  good_keys_kernel<<<hmin<u32>(nBlocks, 16384), 256, 0, st>>>(c->clusHash.p, c->blockOff.p, c->blocks.p, nBlocks, c->within.p,
-                                                            c->hashDepth.p, key.p, c->nGood.p, segEnd.p, c->goodEntries.p);
+  u32 maxDepth = 0;
+  H10X_HIP(c, hipMemcpyAsync(&maxDepth, red.p, 4, hipMemcpyDeviceToHost, st));
+  H10X_HIP(c, hipStreamSynchronize(st));
+  const bool narrow = maxDepth <= 65535u;
+  if (narrow) { H10X_HIP(c, key32.alloc(H)); H10X_HIP(c, keyS32.alloc(H)); } else { H10X_HIP(c, key.alloc(H)); H10X_HIP(c, keyS.alloc(H)); }
+  if (narrow) good_keys_kernel<u32><<<hmin<u32>(nBlocks, 16384), 256, 0, st>>>(c->clusHash.p, c->blockOff.p, c->blocks.p, nBlocks, c->within.p,
+                                                                             c->hashDepth.p, key32.p, c->nGood.p, segEnd.p, c->goodEntries.p);
+  else good_keys_kernel<u64><<<hmin<u32>(nBlocks, 16384), 256, 0, st>>>(c->clusHash.p, c->blockOff.p, c->blocks.p, nBlocks, c->within.p,
+                                                                      c->hashDepth.p, key.p, c->nGood.p, segEnd.p, c->goodEntries.p);
   H10X_TRY(prim_reduce_max_u32(c, pt, c->nGood.p, red.p + 1, nBlocks));
   DevBuf<u64> redSum; H10X_HIP(c, redSum.alloc(1));
   H10X_TRY(prim_reduce_sum_u32_u64(c, pt, c->nGood.p, redSum.p, nBlocks));
@@ -122,8 +132,13 @@ int stageC_depthRange(Ctx *c, int lo, int hi) {
   offsets32c_kernel<<<divUp((u64)nBlocks + 1, 256), 256, 0, st>>>(c->blockOff.p, nBlocks + 1, off32.p);
   // ascending (depth, position): qsort by depth, stable => ties by position (hash10x.c:726-730,758)
   if (H) {
-    H10X_TRY(prim_seg_sort_keys_u64(c, pt, key.p, keyS.p, (u32)H, nBlocks, off32.p, segEnd.p, 0, 16 + bitsForC(hr[0])));
-    good_pos_kernel<<<(unsigned)hmin<u64>(divUp(H, 256), 65535u * 2), 256, 0, st>>>(keyS.p, H, c->goodPos.p);
+    if (narrow) {
+      H10X_TRY(prim_seg_sort_keys_u32(c, pt, key32.p, keyS32.p, (u32)H, nBlocks, off32.p, segEnd.p, 0, 16 + bitsForC(hr[0])));
+      good_pos_kernel<u32><<<(unsigned)hmin<u64>(divUp(H, 256), 65535u * 2), 256, 0, st>>>(keyS32.p, H, c->goodPos.p);
+    } else {
+      H10X_TRY(prim_seg_sort_keys_u64(c, pt, key.p, keyS.p, (u32)H, nBlocks, off32.p, segEnd.p, 0, 16 + bitsForC(hr[0])));
+      good_pos_kernel<u64><<<(unsigned)hmin<u64>(divUp(H, 256), 65535u * 2), 256, 0, st>>>(keyS.p, H, c->goodPos.p);
+    }
   }
   H10X_HIP(c, hipGetLastError());
   H10X_HIP(c, hipStreamSynchronize(st));
