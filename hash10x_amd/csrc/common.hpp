@@ -174,6 +174,7 @@ struct Ctx {
   int64_t optDbgSkip = 0;     // diagnostic: what-if timing of cluster_kernel with phases switched off (results wrong)
   int64_t optStamps = 0;      // diagnostic: per-phase wall-clock stamps in cluster_kernel
   bool timing = false;
+  u32 *startFlags = nullptr;   // pinned host words a side-stream kernel's workgroups set when they start (stageC_cluster)
   Timer timers[T_COUNT];
   h10x_counters ctr{};
 

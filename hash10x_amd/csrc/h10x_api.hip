@@ -80,6 +80,7 @@ void h10x_destroy(h10x_ctx *h) {
   for (auto &t : h->c.timers) { if (t.a) (void)hipEventDestroy(t.a); if (t.b) (void)hipEventDestroy(t.b); }
   for (int i = 0; i < 3; ++i) { if (h->c.aux[i]) { (void)hipStreamSynchronize(h->c.aux[i]); (void)hipStreamDestroy(h->c.aux[i]); } if (h->c.evJoin[i]) (void)hipEventDestroy(h->c.evJoin[i]); }
   if (h->c.evFork) (void)hipEventDestroy(h->c.evFork);
+  if (h->c.startFlags) (void)hipHostFree(h->c.startFlags);
   hipStream_t own = h->c.ownStream ? h->c.stream : nullptr; const hipStream_t used = h->c.stream; const int dev = h->c.device;
   delete h;                                                  // parks every buffer of the context
   (void)hipStreamSynchronize(used);
