@@ -4,16 +4,17 @@
 // processBlock (hash10x.c:108-132, 154-172; seqhash.c:58-80, 154-195) and readFQB's barcode run
 // detection (hash10x.c:212-220).
 //
-// MI355X design: one workgroup per barcode block. Packed 2-bit records are streamed from HBM into an
-// LDS tile; each lane owns one k-mer start position of a read pair (107 + 130 = 237 positions at
-// k = 21), rebuilds the forward word with a 64-bit funnel shift straight from the packed dwords and
-// the reverse-complement word with v_bfrev, multiplies both by factor1 and keeps the canonical
-// hash if it is divisible by w (modulo sampling, SURVEY F1 — there is no window minimum to select).
-// Survivors go into an open-addressing hash set in LDS holding (hash << 16 | read), inserted with
-// ds 64-bit cmpswap/min atomics, so duplicates inside a barcode collapse on chip and the lowest
-// read index wins. Only the unique set (≈ 6-8 entries per pair) is written back to HBM.
-// Blocks that cannot use the LDS set (k > 24, > 65535 pairs, or more unique hashes than the table
-// holds) take a global-memory path: raw slots in read order + stable device radix sort + unique.
+// MI355X design: one workgroup per barcode block (mosh_lds_kernel). 32 lanes share a read pair; each lane owns a run of
+// consecutive k-mer start positions of one read, fetches the 4 packed dwords that cover its run straight from HBM (the
+// next pair's are requested before the current pair is hashed), keeps them as a 128-bit shift register and ROLLS the
+// forward and the reverse-complement word (2 bits per step) — what is left per position is the two 64-bit multiplies
+// of hashFunc, the minimum and the divisibility test (modulo sampling, SURVEY F1 — there is no window minimum to select).
+// Survivors go into an open-addressing hash set in LDS holding (hash << 16 | read), inserted with ds 64-bit
+// cmpswap/min atomics, so duplicates inside a barcode collapse on chip and the lowest read index wins.
+// Only the unique set (≈ 6-8 entries per pair) is written back to HBM; three table sizes = three launch classes, side by
+// side on forked streams. Blocks that cannot use the LDS set (k > 24, > 65535 pairs, or more unique hashes than the
+// table holds) take a global-memory path: raw slots in read order + stable device radix sort + unique.
+// The entries leave this stage as (hash / w, barcode, read): every mosh is a multiple of w (Ctx::keyInv, common.hpp).
 #include "common.hpp"
 #include "prim.hpp"
 
