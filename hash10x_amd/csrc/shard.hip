@@ -49,6 +49,39 @@ __global__ void gather_send_kernel(const u64 *__restrict__ entHash, const u32 *_
   u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; const u64 stride = (u64)gridDim.x * blockDim.x;
   for (; i < n; i += stride) { const u32 p = perm[i]; sHash[i] = entHash[p]; sCode[i] = entCode[p] + codeBase; }
 }
+// Partition by owner, block by block (the entries of a barcode block are contiguous, blockOff[]): one workgroup per block
+// counts its entries per owner (pass 0), and after an exclusive scan of the counts in (owner, block) order places them
+// (pass 1). An owner's slice then holds the blocks in barcode order — all the owner's stable sort by hash needs, hashes
+// being unique inside a block — without a sort and a gather over all entries.
+constexpr int PART_MAX_OWNERS = 1024;
+template <int PASS>
+__global__ __launch_bounds__(256)
+void owner_partition_kernel(const u64 *__restrict__ entHash, const u32 *__restrict__ entCode, const u64 *__restrict__ blockOff, u32 nBlocks,
+                            const u64 *__restrict__ lowHash /* N+1 */, int N, u32 codeBase, u32 *__restrict__ cnt /* N x nBlocks: counts, then offsets */,
+                            u64 *__restrict__ sHash, u32 *__restrict__ sCode, u32 *__restrict__ perm) {
+  __shared__ u64 low[PART_MAX_OWNERS + 1];
+  __shared__ u32 fill[PART_MAX_OWNERS];
+  for (int o = threadIdx.x; o <= N; o += blockDim.x) low[o] = lowHash[o];
+  for (u32 b = blockIdx.x + 1; b < nBlocks; b += gridDim.x) {
+    const u64 e0 = blockOff[b], e1 = blockOff[b + 1];
+    __syncthreads();
+    for (int o = threadIdx.x; o < N; o += blockDim.x) fill[o] = PASS ? cnt[(size_t)o * nBlocks + b] : 0u;
+    __syncthreads();
+    for (u64 e = e0 + threadIdx.x; e < e1; e += blockDim.x) {
+      const u64 h = entHash[e];
+      int lo = 0, hi = N;                                    // largest o with low[o] <= h
+      while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (low[mid] <= h) lo = mid; else hi = mid; }
+      const u32 pos = atomicAdd(&fill[lo], 1u);
+      if (PASS) { sHash[pos] = h; sCode[pos] = entCode[e] + codeBase; perm[pos] = (u32)e; }
+    }
+    if (!PASS) { __syncthreads(); for (int o = threadIdx.x; o < N; o += blockDim.x) cnt[(size_t)o * nBlocks + b] = fill[o]; }
+  }
+}
+__global__ void partition_bounds_kernel(const u32 *__restrict__ off, u32 nBlocks, int N, u64 n, u64 *__restrict__ bound) {
+  const int o = blockIdx.x * blockDim.x + threadIdx.x;
+  if (o > N) return;
+  bound[o] = o == N ? n : (u64)off[(size_t)o * nBlocks];
+}
 // first position in the ascending array whose hash belongs to owner >= o, for o = 0..N
 __global__ void owner_bounds_kernel(const u64 *__restrict__ sHash, u64 n, const u64 *__restrict__ lowHash /* N+1 */, int N, u64 *__restrict__ bound) {
   const int o = blockIdx.x * blockDim.x + threadIdx.x;
@@ -134,25 +167,37 @@ int shard_readFqb(Ctx *c, Comm *cm, const u32 *dRec, u64 nRec) {
   c->codeBase = (u32)codeBase; c->nBlocksGlobal = (u32)totalBarcodes + 1;
   const u32 nB = c->nBlocksGlobal;
 
-  // ---- 2. my entries by hash owner: a stable partition on the owner number (ONE radix pass on log2 N bits; the owners
-  //         sort by hash anyway), so every owner's part stays in block = barcode order
+  // ---- 2. my entries by hash owner, each owner's part in block = barcode order (owner_partition_kernel; the owners sort by
+  //         hash anyway)
   c->tstart(T_SORT_HASH);
-  DevBuf<u64> sHash; DevBuf<u32> perm, sCodeG, io, oKey, oKeyS;
-  H10X_HIP(c, sHash.alloc(H)); H10X_HIP(c, perm.alloc(H)); H10X_HIP(c, sCodeG.alloc(H)); H10X_HIP(c, io.alloc(H));
-  H10X_HIP(c, oKey.alloc(H)); H10X_HIP(c, oKeyS.alloc(H));
+  DevBuf<u64> sHash; DevBuf<u32> perm, sCodeG;
+  H10X_HIP(c, sHash.alloc(H)); H10X_HIP(c, perm.alloc(H)); H10X_HIP(c, sCodeG.alloc(H));
   std::vector<u64> lowHash((size_t)N + 1), bound((size_t)N + 1);
   // (the entries hold hash / w, Ctx::keyInv: the owner ranges are cut in that space)
   const u64 nKeys = ((2 * k >= 64 ? ~0ULL : ((u64)1 << (2 * k)) - 1) / (u64)c->prm.w) + 1;
   for (int o = 0; o <= N; ++o) lowHash[o] = (u64)(((unsigned __int128)o * nKeys + (unsigned)N - 1) / (unsigned)N);          // ceil(o * nKeys / N)
   DevBuf<u64> dLow, dBound; H10X_HIP(c, dLow.alloc((size_t)N + 1)); H10X_HIP(c, dBound.alloc((size_t)N + 1));
   H10X_HIP(c, hipMemcpyAsync(dLow.p, lowHash.data(), ((size_t)N + 1) * 8, hipMemcpyHostToDevice, st));
-  if (H) { iota_kernel<<<gridFor(H), 256, 0, st>>>(io.p, H); owner_key_kernel<<<gridFor(H), 256, 0, st>>>(entHash.p, H, dLow.p, N, oKey.p); }
-  H10X_TRY(prim_sort_pairs_u32_u32(c, pt, oKey.p, oKeyS.p, io.p, perm.p, H, 0, bitsForS((u64)N - 1)));
-  if (H) gather_send_kernel<<<gridFor(H), 256, 0, st>>>(entHash.p, entCode.p, perm.p, H, c->codeBase, sHash.p, sCodeG.p);
-  owner_key_bounds_kernel<<<1, 64 * ((N + 64) / 64), 0, st>>>(oKeyS.p, H, N, dBound.p);
-  H10X_HIP(c, hipMemcpyAsync(bound.data(), dBound.p, ((size_t)N + 1) * 8, hipMemcpyDeviceToHost, st));
-  H10X_HIP(c, hipStreamSynchronize(st));
-  oKey.release(); oKeyS.release();
+  if (N <= PART_MAX_OWNERS) {
+    const u32 nBl = c->nBlocks; const size_t cells = (size_t)N * nBl;
+    DevBuf<u32> cnt, off; H10X_HIP(c, cnt.alloc(cells + 1)); H10X_HIP(c, off.alloc(cells + 1));
+    H10X_HIP(c, hipMemsetAsync(cnt.p, 0, (cells + 1) * 4, st));                  // block 0 (unused) and the sentinel stay 0
+    const unsigned grid = hmin<u32>(nBl, 16384);
+    if (H) owner_partition_kernel<0><<<grid, 256, 0, st>>>(entHash.p, entCode.p, c->blockOff.p, nBl, dLow.p, N, c->codeBase, cnt.p, nullptr, nullptr, nullptr);
+    H10X_TRY(prim_exclusive_scan_u32(c, pt, cnt.p, off.p, cells + 1));
+    if (H) owner_partition_kernel<1><<<grid, 256, 0, st>>>(entHash.p, entCode.p, c->blockOff.p, nBl, dLow.p, N, c->codeBase, off.p, sHash.p, sCodeG.p, perm.p);
+    partition_bounds_kernel<<<divUp((u64)N + 1, 256), 256, 0, st>>>(off.p, nBl, N, H, dBound.p);
+    H10X_HIP(c, hipMemcpyAsync(bound.data(), dBound.p, ((size_t)N + 1) * 8, hipMemcpyDeviceToHost, st));
+    H10X_HIP(c, hipStreamSynchronize(st));
+  } else {                                                   // very many ranks: a stable one-pass radix partition on the owner number
+    DevBuf<u32> io, oKey, oKeyS; H10X_HIP(c, io.alloc(H)); H10X_HIP(c, oKey.alloc(H)); H10X_HIP(c, oKeyS.alloc(H));
+    if (H) { iota_kernel<<<gridFor(H), 256, 0, st>>>(io.p, H); owner_key_kernel<<<gridFor(H), 256, 0, st>>>(entHash.p, H, dLow.p, N, oKey.p); }
+    H10X_TRY(prim_sort_pairs_u32_u32(c, pt, oKey.p, oKeyS.p, io.p, perm.p, H, 0, bitsForS((u64)N - 1)));
+    if (H) gather_send_kernel<<<gridFor(H), 256, 0, st>>>(entHash.p, entCode.p, perm.p, H, c->codeBase, sHash.p, sCodeG.p);
+    owner_key_bounds_kernel<<<divUp((u64)N + 1, 256), 256, 0, st>>>(oKeyS.p, H, N, dBound.p);
+    H10X_HIP(c, hipMemcpyAsync(bound.data(), dBound.p, ((size_t)N + 1) * 8, hipMemcpyDeviceToHost, st));
+    H10X_HIP(c, hipStreamSynchronize(st));
+  }
   std::vector<u64> sendCnt((size_t)N), sendOff((size_t)N), matrix((size_t)N * N), recvCnt((size_t)N), recvOff((size_t)N);
   for (int o = 0; o < N; ++o) { sendOff[o] = bound[o]; sendCnt[o] = bound[o + 1] - bound[o]; }
   H10X_TRY(cm->allgatherHost(c, sendCnt.data(), matrix.data(), (size_t)N * 8));
