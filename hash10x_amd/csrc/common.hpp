@@ -147,6 +147,7 @@ struct Ctx {
   DevBuf<u32> nGood;          // nBlocks
   DevBuf<u32> goodEntries;    // nBlocks : sum of the depths of a block's good hashes = entries of its barcode lists
   bool haveRange = false, haveGood = false; int rangeMin = 0, rangeMax = 0;
+  u32 depthBound = 0xFFFFFFFFu;   // no hashDepth[] value exceeds this: barcodes of the data set after --readFQB, the largest value read after --readHash
   u32 maxGoodDepth = 0, maxGood = 0, meanGood = 0;
 
   // crib (hash10x.c:406-521): per hash index, where the two truth genomes hold it

@@ -91,7 +91,7 @@ void h10x_destroy(h10x_ctx *h) {
 const char *h10x_last_error(const h10x_ctx *h) { return h ? h->c.err.c_str() : "null context"; }
 
 static void reset_state(Ctx &c) {
-  c.haveState = false; c.haveRange = false; c.haveGood = false; c.rangeMin = c.rangeMax = 0;
+  c.haveState = false; c.haveRange = false; c.haveGood = false; c.rangeMin = c.rangeMax = 0; c.depthBound = 0xFFFFFFFFu;
   c.within.release(); c.goodPos.release(); c.nGood.release(); c.goodEntries.release();
   c.hashNumber = 1; c.nBlocks = 0; c.nEntries = 0; c.nRecords = 0;
   c.sharded = false; c.codeBase = 0; c.nBlocksGlobal = 0; c.oRows.release(); c.oSegStart.release(); c.oIndex.release(); c.oU = 0; c.oM = 0;
@@ -161,6 +161,7 @@ int h10x_load_state(h10x_ctx *h, const uint32_t *hashIndex, uint32_t hashNumber,
   H10X_HIP(&c, hipMemcpyAsync(c.hashIndex.p, hashIndex, tableSize * 4, hipMemcpyHostToDevice, st));
   H10X_HIP(&c, hipMemcpyAsync(c.hashValue.p, hashValue, (size_t)hashNumber * 8, hipMemcpyHostToDevice, st));
   H10X_HIP(&c, hipMemcpyAsync(c.hashDepth.p, hashDepth, (size_t)hashNumber * 4, hipMemcpyHostToDevice, st));
+  { u32 mx = 0; for (uint32_t i = 0; i < hashNumber; ++i) mx = hashDepth[i] > mx ? hashDepth[i] : mx; c.depthBound = mx; }
   H10X_HIP(&c, hipMemcpyAsync(c.blocks.p, blocks, (size_t)nBlocks * sizeof(h10x_block), hipMemcpyHostToDevice, st));
   if (H) H10X_HIP(&c, hipMemcpyAsync(c.clusHash.p, clusHash, H * sizeof(h10x_clushash), hipMemcpyHostToDevice, st));
   PrimTemp pt; DevBuf<u32> nh; H10X_HIP(&c, nh.alloc((size_t)nBlocks + 1));

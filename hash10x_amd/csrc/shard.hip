@@ -229,9 +229,7 @@ int shard_readFqb(Ctx *c, Comm *cm, const u32 *dRec, u64 nRec) {
   H10X_HIP(c, dHash.alloc(Uo)); H10X_HIP(c, dFirst.alloc(Uo)); H10X_HIP(c, c->oSegStart.alloc((size_t)Uo + 1)); H10X_HIP(c, dio.alloc(Uo));
   H10X_HIP(c, cntFirst.alloc(nB)); H10X_HIP(c, hipMemsetAsync(cntFirst.p, 0, (size_t)nB * 4, st));
   if (M) owner_distinct_kernel<<<gridFor(M), 256, 0, st>>>(oHash.p, c->oRows.p, flags.p, ord.p, M, dHash.p, dFirst.p, c->oSegStart.p, dio.p, cntFirst.p);
-  const u32 M32 = (u32)M;
-  H10X_HIP(c, hipMemcpyAsync(c->oSegStart.p + Uo, &M32, 4, hipMemcpyHostToDevice, st));
-  H10X_HIP(c, hipStreamSynchronize(st));
+  H10X_HIP(c, hipMemsetD32Async((hipDeviceptr_t)(c->oSegStart.p + Uo), (int)(u32)M, 1, st));          // end of the last segment
 
   // ---- 4. numbering: index = 1 + #(hashes first seen in an earlier barcode) + #(same barcode, smaller hash);
   //         hashes of owners before me are smaller, those after me larger
@@ -258,7 +256,7 @@ int shard_readFqb(Ctx *c, Comm *cm, const u32 *dRec, u64 nRec) {
   DevBuf<u32> reply, rIdx; H10X_HIP(c, reply.alloc(M)); H10X_HIP(c, rIdx.alloc(H));
   if (M) reply_kernel<<<gridFor(M), 256, 0, st>>>(ord.p, flags.p, oQ.p, M, c->oIndex.p, reply.p);
   H10X_TRY(cm->alltoallv(c, reply.p, recvCnt.data(), recvOff.data(), rIdx.p, sendCnt.data(), sendOff.data(), 4));
-  c->hashNumber = U + 1;
+  c->hashNumber = U + 1; c->depthBound = nB;
   c->tstop(T_RANK);
   c->tstart(T_CLUSHASH);
   { DevBuf<u64> key; H10X_HIP(c, key.alloc(H));

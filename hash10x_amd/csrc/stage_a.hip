@@ -284,6 +284,11 @@ __global__ void set_nhash_kernel(h10x_block *__restrict__ blocks, const u32 *__r
 }
 
 struct SrcPtr { const u64 *hash; const u32 *read; };
+__global__ void count_overflow_kernel(const u32 *__restrict__ nHash, u32 nBlocks, u32 *__restrict__ count) {
+  const u32 c = blockIdx.x * blockDim.x + threadIdx.x;
+  const u64 bal = __ballot(c < nBlocks && nHash[c] == NHASH_OVERFLOW);
+  if ((threadIdx.x & (WAVE - 1)) == 0 && bal) atomicAdd(count, (u32)__popcll(bal));
+}
 
 __global__ void compact_entries_kernel(const u64 *__restrict__ stHash, const u32 *__restrict__ stRead, const u64 *__restrict__ capOff,
                                        const SrcPtr *__restrict__ fb /* per block, null hash = staging */,
@@ -356,8 +361,8 @@ int stageA_run(Ctx *c, const u32 *dRec, u64 nRec, DevBuf<u64> &entHash, DevBuf<u
     H10X_HIP(c, startRec.alloc((size_t)nBlocks + 1));
     H10X_HIP(c, hipMemsetAsync(startRec.p, 0, 8, st));
     block_starts_kernel<<<g, 256, 0, st>>>(flags.p, code.p, nRec, startRec.p);
-    H10X_HIP(c, hipMemcpyAsync(startRec.p + nBlocks, &nRec, 8, hipMemcpyHostToDevice, st));
-    H10X_HIP(c, hipStreamSynchronize(st));                   // flags/code are released below
+    H10X_HIP(c, hipMemsetD32Async((hipDeviceptr_t)((u32 *)(startRec.p + nBlocks)), (int)(u32)nRec, 1, st));            // startRec[nBlocks] = nRec
+    H10X_HIP(c, hipMemsetD32Async((hipDeviceptr_t)((u32 *)(startRec.p + nBlocks) + 1), (int)(u32)(nRec >> 32), 1, st));
   } else {
     H10X_HIP(c, startRec.alloc(3));
     H10X_HIP(c, hipMemsetAsync(startRec.p, 0, 24, st));
@@ -411,18 +416,33 @@ int stageA_run(Ctx *c, const u32 *dRec, u64 nRec, DevBuf<u64> &entHash, DevBuf<u
   H10X_TRY(c->joinStreams(2));
   c->tstop(T_MOSH);
 
-  // ---- global path: class F plus any block whose LDS set overflowed
-  std::vector<u32> hNHash(nBlocks + 1), hListF(hc[3]);
-  std::vector<u64> hStart(nBlocks + 1);
-  H10X_HIP(c, hipMemcpyAsync(hNHash.data(), nHash.p, (size_t)nBlocks * 4, hipMemcpyDeviceToHost, st));
-  H10X_HIP(c, hipMemcpyAsync(hStart.data(), startRec.p, ((size_t)nBlocks + 1) * 8, hipMemcpyDeviceToHost, st));
-  if (hc[3]) H10X_HIP(c, hipMemcpyAsync(hListF.data(), listF.p, (size_t)hc[3] * 4, hipMemcpyDeviceToHost, st));
+  // ---- global path: class F plus any block whose LDS set overflowed. The usual case — no such block — is recognised
+  // from one counter that comes back together with the entry total (no copy of the per-block arrays, no extra round trip).
+  DevBuf<u32> nOverflow; H10X_HIP(c, nOverflow.alloc(1)); H10X_HIP(c, hipMemsetAsync(nOverflow.p, 0, 4, st));
+  count_overflow_kernel<<<divUp(nBlocks, 256), 256, 0, st>>>(nHash.p, nBlocks, nOverflow.p);
+  H10X_HIP(c, c->blockOff.alloc((size_t)nBlocks + 1));
+  H10X_TRY(prim_exclusive_scan_u32_u64(c, pt, nHash.p, c->blockOff.p, (size_t)nBlocks + 1));
+  u64 H = 0, lastStart = 0; u32 hOverflow = 0;
+  H10X_HIP(c, hipMemcpyAsync(&H, c->blockOff.p + nBlocks, 8, hipMemcpyDeviceToHost, st));
+  H10X_HIP(c, hipMemcpyAsync(&lastStart, startRec.p + (nBlocks - 1), 8, hipMemcpyDeviceToHost, st));
+  H10X_HIP(c, hipMemcpyAsync(&hOverflow, nOverflow.p, 4, hipMemcpyDeviceToHost, st));
   H10X_HIP(c, hipStreamSynchronize(st));
-  for (u32 b = 1; b + (hashLast ? 0 : 1) < nBlocks; ++b) if (hNHash[b] == NHASH_OVERFLOW) hListF.push_back(b);
-  std::vector<SrcPtr> hFb(nBlocks, SrcPtr{nullptr, nullptr});
+  const bool anyFallback = hc[3] || hOverflow;
+  std::vector<u32> hNHash, hListF(hc[3]);
+  std::vector<u64> hStart;
+  if (anyFallback) {
+    hNHash.resize(nBlocks + 1); hStart.resize(nBlocks + 1);
+    H10X_HIP(c, hipMemcpyAsync(hNHash.data(), nHash.p, (size_t)nBlocks * 4, hipMemcpyDeviceToHost, st));
+    H10X_HIP(c, hipMemcpyAsync(hStart.data(), startRec.p, ((size_t)nBlocks + 1) * 8, hipMemcpyDeviceToHost, st));
+    if (hc[3]) H10X_HIP(c, hipMemcpyAsync(hListF.data(), listF.p, (size_t)hc[3] * 4, hipMemcpyDeviceToHost, st));
+    H10X_HIP(c, hipStreamSynchronize(st));
+    for (u32 b = 1; b + (hashLast ? 0 : 1) < nBlocks; ++b) if (hNHash[b] == NHASH_OVERFLOW) hListF.push_back(b);
+  }
+  std::vector<SrcPtr> hFb;
   std::vector<DevBuf<u64> *> keepH; std::vector<DevBuf<u32> *> keepR;
   c->ctr.fallback_blocks = hListF.size();
   if (!hListF.empty()) {
+    hFb.assign(nBlocks, SrcPtr{nullptr, nullptr});
     c->tstart(T_FALLBACK);
     const u32 nk = (u32)(mc.n1 + mc.n2);
     for (u32 b : hListF) {
@@ -461,12 +481,13 @@ int stageA_run(Ctx *c, const u32 *dRec, u64 nRec, DevBuf<u64> &entHash, DevBuf<u
   // ---- gather into one (block-ordered) entry list
   c->tstart(T_COMPACT);
   DevBuf<SrcPtr> dFb; H10X_HIP(c, dFb.alloc(nBlocks));
-  H10X_HIP(c, hipMemcpyAsync(dFb.p, hFb.data(), (size_t)nBlocks * sizeof(SrcPtr), hipMemcpyHostToDevice, st));
-  H10X_HIP(c, c->blockOff.alloc((size_t)nBlocks + 1));
-  H10X_TRY(prim_exclusive_scan_u32_u64(c, pt, nHash.p, c->blockOff.p, (size_t)nBlocks + 1));
-  u64 H = 0;
-  H10X_HIP(c, hipMemcpyAsync(&H, c->blockOff.p + nBlocks, 8, hipMemcpyDeviceToHost, st));
-  H10X_HIP(c, hipStreamSynchronize(st));
+  if (hFb.empty()) H10X_HIP(c, hipMemsetAsync(dFb.p, 0, (size_t)nBlocks * sizeof(SrcPtr), st));       // every block comes from the staging area
+  else {
+    H10X_HIP(c, hipMemcpyAsync(dFb.p, hFb.data(), (size_t)nBlocks * sizeof(SrcPtr), hipMemcpyHostToDevice, st));
+    H10X_TRY(prim_exclusive_scan_u32_u64(c, pt, nHash.p, c->blockOff.p, (size_t)nBlocks + 1));          // again, with the repaired counts
+    H10X_HIP(c, hipMemcpyAsync(&H, c->blockOff.p + nBlocks, 8, hipMemcpyDeviceToHost, st));
+    H10X_HIP(c, hipStreamSynchronize(st));
+  }
   if (H >= (1ULL << 32)) return c->fail("%llu (barcode,hash) entries exceed this build's 2^32 per-GPU limit", (u64)H);
   c->nEntries = H;
   set_nhash_kernel<<<divUp(nBlocks, 256), 256, 0, st>>>(c->blocks.p, nHash.p, nBlocks);
@@ -486,7 +507,7 @@ int stageA_run(Ctx *c, const u32 *dRec, u64 nRec, DevBuf<u64> &entHash, DevBuf<u
   for (auto *p : keepH) delete p;
   for (auto *p : keepR) delete p;
 
-  u64 hashedPairs = hashLast ? nRec : (nBlocks >= 2 ? hStart[nBlocks - 1] : 0);  // all blocks but the file's last
+  u64 hashedPairs = hashLast ? nRec : (nBlocks >= 2 ? lastStart : 0);  // all blocks but the file's last
   c->ctr.pairs = nRec; c->ctr.kmers = hashedPairs * (u64)(mc.n1 + mc.n2); c->ctr.entries = H;
   return 0;
 }

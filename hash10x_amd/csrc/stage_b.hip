@@ -128,13 +128,11 @@ int stageB_run(Ctx *c, DevBuf<u64> &entHash, DevBuf<u32> &entCode, DevBuf<u32> &
     H10X_HIP(c, dHash.alloc(U)); H10X_HIP(c, dFirst.alloc(U)); H10X_HIP(c, segStart.alloc((size_t)U + 1));
     H10X_HIP(c, iota.alloc(U)); H10X_HIP(c, order.alloc(U)); H10X_HIP(c, dFirstSorted.alloc(U));
     if (H) seg_scatter_kernel<<<gH, 256, 0, st>>>(sHash.p, sCode.p, flags.p, ord.p, H, dHash.p, dFirst.p, segStart.p, iota.p);
-    const u32 H32 = (u32)H;
-    H10X_HIP(c, hipMemcpyAsync(segStart.p + U, &H32, 4, hipMemcpyHostToDevice, st));
-    H10X_HIP(c, hipStreamSynchronize(st));
+    H10X_HIP(c, hipMemsetD32Async((hipDeviceptr_t)(segStart.p + U), (int)(u32)H, 1, st));      // end of the last segment
   }
   // distinct hashes are in ascending hash order; a stable sort by first barcode gives (first, hash) order
   H10X_TRY(prim_sort_pairs_u32_u32(c, pt, dFirst.p, dFirstSorted.p, iota.p, order.p, U, 0, bitsFor(nBlocks)));
-  c->hashNumber = U + 1;
+  c->hashNumber = U + 1; c->depthBound = nBlocks;             // a hash is met at most once per barcode
   H10X_HIP(c, c->hashValue.alloc((size_t)U + 1)); H10X_HIP(c, c->hashDepth.alloc((size_t)U + 1));
   H10X_HIP(c, c->rowStart.alloc((size_t)U + 2));
   assign_index_kernel<<<divUp((u64)U + 1, 256), 256, 0, st>>>(order.p, dHash.p, segStart.p, U, (u64)c->prm.w, c->hashValue.p, c->hashDepth.p, c->rowStart.p);

@@ -113,10 +113,7 @@ int stageC_depthRange(Ctx *c, int lo, int hi) {
   H10X_HIP(c, c->nGood.alloc(nBlocks)); H10X_HIP(c, c->goodPos.alloc(H)); H10X_HIP(c, c->goodEntries.alloc(nBlocks));
   within_depth_kernel<<<divUp(U1, 256), 256, 0, st>>>(c->hashDepth.p, c->within.p, U1, wdepth.p);
   H10X_TRY(prim_reduce_max_u32(c, pt, wdepth.p, red.p, U1));
-  u32 maxDepth = 0;
-  H10X_HIP(c, hipMemcpyAsync(&maxDepth, red.p, 4, hipMemcpyDeviceToHost, st));
-  H10X_HIP(c, hipStreamSynchronize(st));
-  const bool narrow = maxDepth <= 65535u;
+  const bool narrow = c->depthBound <= 65535u;                // known without a round trip (Ctx::depthBound)
   if (narrow) { H10X_HIP(c, key32.alloc(H)); H10X_HIP(c, keyS32.alloc(H)); } else { H10X_HIP(c, key.alloc(H)); H10X_HIP(c, keyS.alloc(H)); }
   if (narrow) good_keys_kernel<u32><<<hmin<u32>(nBlocks, 16384), 256, 0, st>>>(c->clusHash.p, c->blockOff.p, c->blocks.p, nBlocks, c->within.p,
                                                                              c->hashDepth.p, key32.p, c->nGood.p, segEnd.p, c->goodEntries.p);
