@@ -502,7 +502,7 @@ int stageA_run(Ctx *c, const u32 *dRec, u64 nRec, DevBuf<u64> &entHash, DevBuf<u
   if (H) compact_entries_kernel<<<hmin<u32>(nBlocks, 8192), 256, 0, st>>>(stHash.p, stRead.p, capOff.p, dFb.p, nHash.p, c->blockOff.p, nBlocks,
                                                                         c->keyInv, c->keyShift, entHash.p, entCode.p, entRead.p);
   H10X_HIP(c, hipGetLastError());
-  H10X_HIP(c, hipStreamSynchronize(st));
+  if (!hFb.empty()) H10X_HIP(c, hipStreamSynchronize(st));   // the host copy of the fallback pointers is still being read
   c->tstop(T_COMPACT);
   for (auto *p : keepH) delete p;
   for (auto *p : keepR) delete p;

@@ -138,8 +138,7 @@ int stageC_depthRange(Ctx *c, int lo, int hi) {
       good_pos_kernel<u64><<<(unsigned)hmin<u64>(divUp(H, 256), 65535u * 2), 256, 0, st>>>(keyS.p, H, c->goodPos.p);
     }
   }
-  H10X_HIP(c, hipGetLastError());
-  H10X_HIP(c, hipStreamSynchronize(st));
+  H10X_HIP(c, hipGetLastError());                            // (no round trip here: --cluster, the next command, starts with one)
   c->haveGood = true;
   c->tstop(T_GOOD);
   if (c->sharded) H10X_TRY(shard_exchangeRows(c));           // barcode lists of the in-range hashes, from their owners
