@@ -11,6 +11,7 @@ static int enter(Ctx &c) {
   if (hipSetDevice(c.device) != hipSuccess) return c.fail("hipSetDevice(%d) failed", c.device);
   AllocScope::stream() = c.stream; AllocScope::device() = c.device;
   DevCache::noteStream(c.device, c.stream);
+  c.pendingReads.clear(); c.mailUsed = 0;                    // read-backs a failed call left behind point into its dead frame
   return 0;
 }
 
@@ -81,6 +82,7 @@ void h10x_destroy(h10x_ctx *h) {
   for (int i = 0; i < 3; ++i) { if (h->c.aux[i]) { (void)hipStreamSynchronize(h->c.aux[i]); (void)hipStreamDestroy(h->c.aux[i]); } if (h->c.evJoin[i]) (void)hipEventDestroy(h->c.evJoin[i]); }
   if (h->c.evFork) (void)hipEventDestroy(h->c.evFork);
   if (h->c.startFlags) (void)hipHostFree(h->c.startFlags);
+  if (h->c.mail) (void)hipHostFree(h->c.mail);
   hipStream_t own = h->c.ownStream ? h->c.stream : nullptr; const hipStream_t used = h->c.stream; const int dev = h->c.device;
   delete h;                                                  // parks every buffer of the context
   (void)hipStreamSynchronize(used);

@@ -355,8 +355,8 @@ int stageA_run(Ctx *c, const u32 *dRec, u64 nRec, DevBuf<u64> &entHash, DevBuf<u
     head_flags_kernel<<<g, 256, 0, st>>>(dRec, nRec, flags.p);
     H10X_TRY(prim_inclusive_scan_u32(c, pt, flags.p, code.p, nRec));
     u32 nRuns = 0;
-    H10X_HIP(c, hipMemcpyAsync(&nRuns, code.p + (nRec - 1), 4, hipMemcpyDeviceToHost, st));
-    H10X_HIP(c, hipStreamSynchronize(st));
+    H10X_TRY(c->readback(&nRuns, code.p + (nRec - 1), 4));
+    H10X_TRY(c->syncReadbacks());
     nBlocks = nRuns + 1;
     H10X_HIP(c, startRec.alloc((size_t)nBlocks + 1));
     H10X_HIP(c, hipMemsetAsync(startRec.p, 0, 8, st));
@@ -384,10 +384,10 @@ int stageA_run(Ctx *c, const u32 *dRec, u64 nRec, DevBuf<u64> &entHash, DevBuf<u
   DevBuf<u64> capOff; H10X_HIP(c, capOff.alloc((size_t)nBlocks + 1));
   H10X_TRY(prim_exclusive_scan_u32_u64(c, pt, slots.p, capOff.p, nBlocks));
   u32 hc[4]; u64 capTotal = 0; u32 lastSlots = 0;
-  H10X_HIP(c, hipMemcpyAsync(hc, counts.p, 16, hipMemcpyDeviceToHost, st));
-  H10X_HIP(c, hipMemcpyAsync(&capTotal, capOff.p + (nBlocks - 1), 8, hipMemcpyDeviceToHost, st));
-  H10X_HIP(c, hipMemcpyAsync(&lastSlots, slots.p + (nBlocks - 1), 4, hipMemcpyDeviceToHost, st));
-  H10X_HIP(c, hipStreamSynchronize(st));
+  H10X_TRY(c->readback(hc, counts.p, 16));
+  H10X_TRY(c->readback(&capTotal, capOff.p + (nBlocks - 1), 8));
+  H10X_TRY(c->readback(&lastSlots, slots.p + (nBlocks - 1), 4));
+  H10X_TRY(c->syncReadbacks());
   capTotal += lastSlots;
   c->tstop(T_RUNS);
 
@@ -423,10 +423,10 @@ int stageA_run(Ctx *c, const u32 *dRec, u64 nRec, DevBuf<u64> &entHash, DevBuf<u
   H10X_HIP(c, c->blockOff.alloc((size_t)nBlocks + 1));
   H10X_TRY(prim_exclusive_scan_u32_u64(c, pt, nHash.p, c->blockOff.p, (size_t)nBlocks + 1));
   u64 H = 0, lastStart = 0; u32 hOverflow = 0;
-  H10X_HIP(c, hipMemcpyAsync(&H, c->blockOff.p + nBlocks, 8, hipMemcpyDeviceToHost, st));
-  H10X_HIP(c, hipMemcpyAsync(&lastStart, startRec.p + (nBlocks - 1), 8, hipMemcpyDeviceToHost, st));
-  H10X_HIP(c, hipMemcpyAsync(&hOverflow, nOverflow.p, 4, hipMemcpyDeviceToHost, st));
-  H10X_HIP(c, hipStreamSynchronize(st));
+  H10X_TRY(c->readback(&H, c->blockOff.p + nBlocks, 8));
+  H10X_TRY(c->readback(&lastStart, startRec.p + (nBlocks - 1), 8));
+  H10X_TRY(c->readback(&hOverflow, nOverflow.p, 4));
+  H10X_TRY(c->syncReadbacks());
   const bool anyFallback = hc[3] || hOverflow;
   std::vector<u32> hNHash, hListF(hc[3]);
   std::vector<u64> hStart;

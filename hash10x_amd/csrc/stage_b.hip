@@ -121,8 +121,8 @@ int stageB_run(Ctx *c, DevBuf<u64> &entHash, DevBuf<u32> &entCode, DevBuf<u32> &
     if (H) seg_head_flags_kernel<<<gH, 256, 0, st>>>(sHash.p, H, flags.p);
     H10X_HIP(c, hipMemsetAsync(flags.p + H, 0, 4, st));
     H10X_TRY(prim_exclusive_scan_u32(c, pt, flags.p, ord.p, H + 1));
-    H10X_HIP(c, hipMemcpyAsync(&U, ord.p + H, 4, hipMemcpyDeviceToHost, st));
-    H10X_HIP(c, hipStreamSynchronize(st));
+    H10X_TRY(c->readback(&U, ord.p + H, 4));
+    H10X_TRY(c->syncReadbacks());
     // hash10x.c:149: die once hashNumber exceeds 2^(B-2) - 2; hashNumber ends at U + 1
     if ((u64)U + 1 > (tableSize >> 2) - 2) return c->fail("hashTableSize is too small");
     H10X_HIP(c, dHash.alloc(U)); H10X_HIP(c, dFirst.alloc(U)); H10X_HIP(c, segStart.alloc((size_t)U + 1));

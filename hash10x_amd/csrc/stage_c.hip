@@ -123,9 +123,9 @@ int stageC_depthRange(Ctx *c, int lo, int hi) {
   DevBuf<u64> redSum; H10X_HIP(c, redSum.alloc(1));
   H10X_TRY(prim_reduce_sum_u32_u64(c, pt, c->nGood.p, redSum.p, nBlocks));
   u32 hr[2]; u64 sumGood = 0;
-  H10X_HIP(c, hipMemcpyAsync(hr, red.p, 8, hipMemcpyDeviceToHost, st));
-  H10X_HIP(c, hipMemcpyAsync(&sumGood, redSum.p, 8, hipMemcpyDeviceToHost, st));
-  H10X_HIP(c, hipStreamSynchronize(st));
+  H10X_TRY(c->readback(hr, red.p, 8));
+  H10X_TRY(c->readback(&sumGood, redSum.p, 8));
+  H10X_TRY(c->syncReadbacks());
   c->maxGoodDepth = hr[0]; c->maxGood = hr[1]; c->meanGood = nBlocks > 1 ? (u32)(sumGood / (nBlocks - 1)) : 0;
   offsets32c_kernel<<<divUp((u64)nBlocks + 1, 256), 256, 0, st>>>(c->blockOff.p, nBlocks + 1, off32.p);
   // ascending (depth, position): qsort by depth, stable => ties by position (hash10x.c:726-730,758)
@@ -960,8 +960,8 @@ int stageC_cluster(Ctx *c, int codeMin, int codeMax, int threshold) {
                                                           bmWords, (u32)threads0 / WAVE, budget0, budgetSmall, budgetBig, wide, c->optBigRanks > 0 ? (u32)c->optBigRanks : c->meanGood + c->meanGood / 2,
                                                           list0.p, list1.p, list2.p, list3.p, counts.p);
   u32 hc[12];
-  H10X_HIP(c, hipMemcpyAsync(hc, counts.p, 48, hipMemcpyDeviceToHost, st));
-  H10X_HIP(c, hipStreamSynchronize(st));
+  H10X_TRY(c->readback(hc, counts.p, 48));
+  H10X_TRY(c->syncReadbacks());
   // (the work queue hands barcodes out in the order the classification appended them, i.e. mixed sizes: sorting the
   // queue by descending rank count was measured 17 % SLOWER — workgroups of like size run their phases in step and
   // contend for the same unit at the same time)
@@ -1091,8 +1091,8 @@ int stageC_cluster(Ctx *c, int codeMin, int codeMax, int threshold) {
   H10X_TRY(c->joinStreams(1));
   c->tstop(T_CLUSTER_K);
   u64 hs[8];
-  H10X_HIP(c, hipMemcpyAsync(hs, stats.p, 64, hipMemcpyDeviceToHost, st));
-  H10X_HIP(c, hipStreamSynchronize(st));
+  H10X_TRY(c->readback(hs, stats.p, 64));
+  H10X_TRY(c->syncReadbacks());
   c->tstop(T_CLUSTER);
   if (c->optStamps) { H10X_HIP(c, hipMemcpy(c->ctr.cluster_phase_ticks, phase.p, 64, hipMemcpyDeviceToHost)); }
   for (int k = 0; k < 4; ++k) { c->ctr.cluster_main[k] = hs[4 + k]; hs[k] += hs[4 + k]; }   // re-runs of overflowed blocks count again (they did the work twice)
