@@ -187,8 +187,8 @@ int shard_readFqb(Ctx *c, Comm *cm, const u32 *dRec, u64 nRec) {
     H10X_TRY(prim_exclusive_scan_u32(c, pt, cnt.p, off.p, cells + 1));
     if (H) owner_partition_kernel<1><<<grid, 256, 0, st>>>(entHash.p, entCode.p, c->blockOff.p, nBl, dLow.p, N, c->codeBase, off.p, sHash.p, sCodeG.p, perm.p);
     partition_bounds_kernel<<<divUp((u64)N + 1, 256), 256, 0, st>>>(off.p, nBl, N, H, dBound.p);
-    H10X_HIP(c, hipMemcpyAsync(bound.data(), dBound.p, ((size_t)N + 1) * 8, hipMemcpyDeviceToHost, st));
-    H10X_HIP(c, hipStreamSynchronize(st));
+    H10X_TRY(c->readback(bound.data(), dBound.p, ((size_t)N + 1) * 8));
+    H10X_TRY(c->syncReadbacks());
   } else {                                                   // very many ranks: a stable one-pass radix partition on the owner number
     DevBuf<u32> io, oKey, oKeyS; H10X_HIP(c, io.alloc(H)); H10X_HIP(c, oKey.alloc(H)); H10X_HIP(c, oKeyS.alloc(H));
     if (H) { iota_kernel<<<gridFor(H), 256, 0, st>>>(io.p, H); owner_key_kernel<<<gridFor(H), 256, 0, st>>>(entHash.p, H, dLow.p, N, oKey.p); }
@@ -223,8 +223,8 @@ int shard_readFqb(Ctx *c, Comm *cm, const u32 *dRec, u64 nRec) {
   H10X_HIP(c, hipMemsetAsync(flags.p + M, 0, 4, st));
   H10X_TRY(prim_exclusive_scan_u32(c, pt, flags.p, ord.p, M + 1));
   u32 Uo = 0;
-  H10X_HIP(c, hipMemcpyAsync(&Uo, ord.p + M, 4, hipMemcpyDeviceToHost, st));
-  H10X_HIP(c, hipStreamSynchronize(st));
+  H10X_TRY(c->readback(&Uo, ord.p + M, 4));
+  H10X_TRY(c->syncReadbacks());
   DevBuf<u64> dHash; DevBuf<u32> dFirst, dio, cntFirst;
   H10X_HIP(c, dHash.alloc(Uo)); H10X_HIP(c, dFirst.alloc(Uo)); H10X_HIP(c, c->oSegStart.alloc((size_t)Uo + 1)); H10X_HIP(c, dio.alloc(Uo));
   H10X_HIP(c, cntFirst.alloc(nB)); H10X_HIP(c, hipMemsetAsync(cntFirst.p, 0, (size_t)nB * 4, st));
@@ -244,8 +244,8 @@ int shard_readFqb(Ctx *c, Comm *cm, const u32 *dRec, u64 nRec) {
   H10X_TRY(prim_exclusive_scan_u32(c, pt, total.p, base.p, (size_t)nB + 1));
   H10X_TRY(prim_exclusive_scan_u32(c, pt, cntFirst.p, myStart.p, nB));
   u32 U = 0;
-  H10X_HIP(c, hipMemcpyAsync(&U, base.p + nB, 4, hipMemcpyDeviceToHost, st));
-  H10X_HIP(c, hipStreamSynchronize(st));
+  H10X_TRY(c->readback(&U, base.p + nB, 4));
+  H10X_TRY(c->syncReadbacks());
   if ((u64)U + 1 > (((u64)1 << c->prm.B) >> 2) - 2) return c->fail("hashTableSize is too small");     // hash10x.c:149, same verdict on every rank
   DevBuf<u32> order, dFirstSorted; H10X_HIP(c, order.alloc(Uo)); H10X_HIP(c, dFirstSorted.alloc(Uo)); H10X_HIP(c, c->oIndex.alloc(Uo));
   H10X_TRY(prim_sort_pairs_u32_u32(c, pt, dFirst.p, dFirstSorted.p, dio.p, order.p, Uo, 0, bitsForS(nB)));
@@ -345,9 +345,9 @@ int shard_exchangeRows(Ctx *c) {
   H10X_TRY(prim_exclusive_scan_u32(c, pt, isGood.p, pos.p, (size_t)Uo + 1));
   H10X_TRY(prim_exclusive_scan_u32(c, pt, len.p, off.p, (size_t)Uo + 1));
   u32 tail[2];
-  H10X_HIP(c, hipMemcpyAsync(&tail[0], pos.p + Uo, 4, hipMemcpyDeviceToHost, st));
-  H10X_HIP(c, hipMemcpyAsync(&tail[1], off.p + Uo, 4, hipMemcpyDeviceToHost, st));
-  H10X_HIP(c, hipStreamSynchronize(st));
+  H10X_TRY(c->readback(&tail[0], pos.p + Uo, 4));
+  H10X_TRY(c->readback(&tail[1], off.p + Uo, 4));
+  H10X_TRY(c->syncReadbacks());
   u64 mine[2] = {tail[0], tail[1]}; std::vector<u64> all((size_t)2 * N);
   H10X_TRY(cm->allgatherHost(c, mine, all.data(), 16));
   DevBuf<u32> gIdx, gLen, gRows;
