@@ -1023,7 +1023,10 @@ int stageC_cluster(Ctx *c, int codeMin, int codeMax, int threshold) {
     // host words; the host holds the main launch back until they have (some 10 us), with a time limit as a safeguard.
     if (!c->startFlags) H10X_HIP(c, hipHostMalloc((void **)&c->startFlags, 1024 * sizeof(u32), hipHostMallocDefault));
     memset(c->startFlags, 0, 1024 * sizeof(u32));
-    a.started = gridOf[2] <= 1024 ? c->startFlags : nullptr;
+    // (only while that class is a side show: when it holds most of the barcodes its persistent workgroups would keep every
+    // CU to themselves until their queue is empty, and the two launches share the chip better by racing for the CUs —
+    // 1 M-barcode set: 2.20 s against 2.52 s)
+    a.started = gridOf[2] * 2 <= (u32)c->numCU ? c->startFlags : nullptr;
     H10X_LAUNCH_LDS(2, CL_THREADS_HUGE, budgetBig, c->aux[1], list2.p, hc[2], gridOf[2], 6, ovfB.p)
     if (a.started) {
       const auto t0 = std::chrono::steady_clock::now();
