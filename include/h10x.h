@@ -98,7 +98,9 @@ int  h10x_load_state(h10x_ctx *ctx, const uint32_t *hashIndex, uint32_t hashNumb
                      const h10x_block *blocks, uint32_t nBlocks, const h10x_clushash *clusHash);
 
 /* replaces hashWithinRangeBuild() + goodHashesBuild() (hash10x.c:528-539, 738-766); ranges
-   accumulate over calls exactly as in the reference */
+   accumulate over calls exactly as in the reference. Returns once the work is queued on the context's stream (it has
+   no host-side result); the next call on the context — h10x_cluster, an export — waits for it, and a device fault in
+   it is reported there. */
 int  h10x_depth_range(h10x_ctx *ctx, int32_t min, int32_t max);
 
 /* replaces the --cluster loop: codeClusterFind() + codeClusterReadMerge() for code in
