@@ -262,7 +262,7 @@ __device__ __forceinline__ u32 probe_find(const u32 *__restrict__ table, const u
 
 // stage entry points (one per translation unit)
 int stageA_run(Ctx *c, const u32 *dRecords, u64 nRecords,
-               DevBuf<u64> &entHash, DevBuf<u32> &entCode, DevBuf<u32> &entRead, bool hashLast = false);
+               DevBuf<u64> &entHash, DevBuf<u32> &entCode, DevBuf<u32> &entRead, bool hashLast = false, bool emptyIsNoBlock = false);
 int stageA_sortRecords(Ctx *c, const u32 *dIn, u64 nRecords, u32 *dOut);   // stable sort of .fqb records by their first 4 bytes
 int stageB_run(Ctx *c, DevBuf<u64> &entHash, DevBuf<u32> &entCode, DevBuf<u32> &entRead);
 int stageB_buildCSR(Ctx *c);                   // rows/rowStart from clusHash + hashDepth (fillHashTable)

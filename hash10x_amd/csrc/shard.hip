@@ -155,9 +155,14 @@ struct ShardInfo { u64 barcodes, entries, records; };
 int shard_readFqb(Ctx *c, Comm *cm, const u32 *dRec, u64 nRec) {
   hipStream_t st = c->stream; PrimTemp pt;
   const int N = cm->n, me = cm->rank; const int k = c->prm.k;
-  // ---- 1. local mosh extraction; only the last shard's last barcode is the file's unhashed trailing block
+  // ---- 1. local mosh extraction. The file's last barcode is never hashed: that is the last barcode of the last
+  //         shard that holds any record (with fewer barcodes than ranks the trailing shards are empty). A shard without
+  //         records holds no barcode; if every shard is empty, rank 0 keeps the reference's empty block 1 (hash10x.c:200-201).
+  std::vector<u64> recsOf((size_t)N); { u64 mineRec = nRec; H10X_TRY(cm->allgatherHost(c, &mineRec, recsOf.data(), 8)); }
+  bool laterRecords = false, anyRecords = false;
+  for (int r = 0; r < N; ++r) { if (recsOf[r]) { anyRecords = true; if (r > me) laterRecords = true; } }
   DevBuf<u64> entHash; DevBuf<u32> entCode, entRead;
-  H10X_TRY(stageA_run(c, dRec, nRec, entHash, entCode, entRead, me != N - 1));
+  H10X_TRY(stageA_run(c, dRec, nRec, entHash, entCode, entRead, laterRecords, anyRecords || me != 0));
   const u64 H = c->nEntries;
   ShardInfo mine{(u64)c->nBlocks - 1, H, nRec}; std::vector<ShardInfo> all((size_t)N);
   H10X_TRY(cm->allgatherHost(c, &mine, all.data(), sizeof mine));

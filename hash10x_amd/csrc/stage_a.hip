@@ -334,7 +334,7 @@ int stageA_sortRecords(Ctx *c, const u32 *dIn, u64 n, u32 *dOut) {
 }
 
 // ------------------------------------------------------------------------------------------ driver
-int stageA_run(Ctx *c, const u32 *dRec, u64 nRec, DevBuf<u64> &entHash, DevBuf<u32> &entCode, DevBuf<u32> &entRead, bool hashLast) {
+int stageA_run(Ctx *c, const u32 *dRec, u64 nRec, DevBuf<u64> &entHash, DevBuf<u32> &entCode, DevBuf<u32> &entRead, bool hashLast, bool emptyIsNoBlock) {
   hipStream_t st = c->stream;
   PrimTemp pt;
   const int k = c->prm.k;
@@ -364,6 +364,7 @@ int stageA_run(Ctx *c, const u32 *dRec, u64 nRec, DevBuf<u64> &entHash, DevBuf<u
     H10X_HIP(c, hipMemsetD32Async((hipDeviceptr_t)((u32 *)(startRec.p + nBlocks)), (int)(u32)nRec, 1, st));            // startRec[nBlocks] = nRec
     H10X_HIP(c, hipMemsetD32Async((hipDeviceptr_t)((u32 *)(startRec.p + nBlocks) + 1), (int)(u32)(nRec >> 32), 1, st));
   } else {
+    if (emptyIsNoBlock) nBlocks = 1;                         // a shard without records holds no barcode at all (only the unused block 0)
     H10X_HIP(c, startRec.alloc(3));
     H10X_HIP(c, hipMemsetAsync(startRec.p, 0, 24, st));
   }

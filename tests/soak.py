@@ -1,0 +1,88 @@
+"""Randomised differential soak (test infrastructure): the HIP path against the CPU oracle on seeded random sets and random
+parameters — k, w, r, depth ranges, threshold, the cluster placement / budget knobs, a second range, clusterSplit + re-cluster,
+and the sharded form with 1-4 ranks as threads (fewer barcodes than ranks included). `run(n, seed)` returns the
+descriptions of the cases that differ; tests/test_gpu_parity.py runs a short one, `python tests/soak.py 500 7` a long one."""
+import os, random, shutil, sys, tempfile, threading, time
+
+import numpy as np
+
+import orc
+from driver import run_commands
+
+
+def run(n_cases, seed, verbose=False):
+    import hash10x_amd
+    rng = random.Random(seed)
+    bad = []
+    for case in range(n_cases):
+        d = tempfile.mkdtemp()
+        k = rng.choice([21, 21, 21, 16, 24, 25, 31, 11, 19]); w = rng.choice([31, 31, 31, 5, 7, 32, 13, 64])
+        r = rng.choice([17, 17, 3, 9, 101])
+        pairs = rng.choice([3000, 8000, 20000, 40000]); barcodes = rng.choice([5, 20, 60, 150, 400]); genome = rng.choice([40000, 100000, 300000])
+        mol = rng.choice([2.0, 3.0, 4.0]); mol_len = rng.choice([2500, 5000, 8000]); err = rng.choice([0.001, 0.003, 0.01])
+        lo = rng.choice([2, 3, 4, 6]); hi = lo + rng.choice([3, 10, 30, 100]); ct = rng.choice([1, 2, 3, 5])
+        B = 23 if w < 13 else 21
+        opts = {}
+        if rng.random() < 0.3: opts["cluster_first_global"] = rng.choice([1, 2, 3])
+        if rng.random() < 0.2: opts["cluster_lds_budget"] = rng.choice([2048, 16 * 1024, 24 * 1024, 48 * 1024])
+        if rng.random() < 0.15: opts["stage_a_max_slots"] = rng.choice([256, 1024, 4096])
+        if rng.random() < 0.15 and "cluster_first_global" in opts: opts["cluster_first_cap"] = rng.choice([64, 500, 1500])
+        tail = ["-ct", ct, "--readFQB", "x.fqb", "--hashDepthRange", lo, hi, "--cluster", 1, 0]
+        simple = True
+        if rng.random() < 0.3: tail += ["--hashDepthRange", lo + 1, hi + 5, "--cluster", 1, 0]; simple = False
+        if rng.random() < 0.3: tail += ["--clusterSplit", "--hashDepthRange", lo, hi, "--cluster", 1, 0]; simple = False
+        desc = dict(case=case, k=k, w=w, r=r, pairs=pairs, barcodes=barcodes, genome=genome, mol=mol, mol_len=mol_len, err=err, B=B, opts=opts, tail=tail)
+        try:
+            recs = orc.gen_fqb(os.path.join(d, "x.fqb"), pairs, barcodes, genome, err, 1000 + case, mol, 150, mol_len)
+            base = ["-k", k, "-w", w, "-r", r, "-B", B] + tail
+
+            def make(k_, w_, r_, B_):
+                h = hash10x_amd.Hash10x(k=k_, w=w_, r=r_, B=B_)
+                for n, v in opts.items(): h.set_option(n, v)
+                return h
+            run_commands(make, base + ["--writeHash", "hip.hash"], d)
+            run_commands(lambda k_, w_, r_, B_: orc.Oracle(k_, w_, r_, B_), base + ["--writeHash", "orc.hash"], d)
+            got = open(os.path.join(d, "hip.hash"), "rb").read(); exp = open(os.path.join(d, "orc.hash"), "rb").read()
+            ok = got == exp
+            nr = rng.choice([1, 2, 3, 4])
+            if ok and simple and rng.random() < 0.6:          # the sharded form of the same commands, ranks as threads
+                flat = np.ascontiguousarray(recs, dtype=np.uint32).reshape(-1)
+                cut = hash10x_amd.partition(recs, nr); comms = hash10x_amd.Comm.local(nr); errs = [None] * nr
+
+                def work(rk):
+                    try:
+                        h = hash10x_amd.Hash10x(k=k, w=w, r=r, B=B)
+                        for n, v in opts.items(): h.set_option(n, v)
+                        h.shard_read_fqb(comms[rk], flat[30 * cut[rk]: 30 * cut[rk + 1]])
+                        h.depth_range(lo, hi); h.cluster(1, 0, ct)
+                        h.shard_gather()
+                        if rk == 0: h.write_hash(os.path.join(d, "sh.hash"))
+                        h.close()
+                    except Exception as e:                    # noqa: BLE001
+                        errs[rk] = e
+                th = [threading.Thread(target=work, args=(rk,)) for rk in range(nr)]
+                [x.start() for x in th]; [x.join() for x in th]
+                for cm in comms: cm.destroy()
+                for e in errs:
+                    if e: raise e
+                got = open(os.path.join(d, "sh.hash"), "rb").read()
+                ok = got == exp
+                desc["sharded_ranks"] = nr
+            if verbose: print("case %3d %s %s" % (case, "ok " if ok else "MISMATCH", desc if not ok else {x: desc[x] for x in ("k", "w", "barcodes")}), flush=True)
+            if not ok:
+                desc["diff"] = orc.describe_diff(got, exp)[:400]; bad.append(desc)
+        except Exception as e:                                # noqa: BLE001
+            desc["exception"] = repr(e); bad.append(desc)
+            if verbose: print("case %3d EXCEPTION %r" % (case, e), flush=True)
+        shutil.rmtree(d, ignore_errors=True)
+    return bad
+
+
+if __name__ == "__main__":
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+    n = int(sys.argv[1]) if len(sys.argv) > 1 else 30
+    t0 = time.time()
+    bad = run(n, int(sys.argv[2]) if len(sys.argv) > 2 else 2026, verbose=True)
+    for b in bad: print("BAD", b)
+    print("soak: %d cases, %d bad, %.0f s" % (n, len(bad), time.time() - t0))
+    sys.exit(1 if bad else 0)

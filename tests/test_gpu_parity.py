@@ -242,6 +242,38 @@ def test_sharded_equals_single_gpu_and_oracle(workdir, nranks):
     assert orc.HashFile(exp).blocks["nSubCluster"].sum() > 0
 
 
+@pytest.mark.parametrize("nranks", [2, 4, 8])
+def test_sharded_with_fewer_barcodes_than_ranks(workdir, nranks):
+    """Trailing (and middle) shards without a record: the file's unhashed last barcode is then the last barcode
+    of the last shard that holds any, and an empty shard contributes no block."""
+    recs = orc.gen_fqb(workdir.file("x.fqb"), 6000, 3, 60000, 0.003, 77, 3.0, 150, 4000)
+    o = orc.Oracle(B=20)
+    o.read_fqb(recs)
+    o.depth_range(2, 30)
+    o.cluster(1, 0, 2)
+    o.write_hash(workdir.file("orc.hash"))
+    exp = open(workdir.file("orc.hash"), "rb").read()
+    _run_sharded(recs, nranks, 20, 2, 30, 2, workdir.file("hip.hash"))
+    got = open(workdir.file("hip.hash"), "rb").read()
+    assert got == exp, orc.describe_diff(got, exp)
+    # no record at all: rank 0 keeps the reference's empty block 1 (hash10x.c:200-201)
+    empty = recs[:0]
+    o = orc.Oracle(B=20)
+    o.read_fqb(empty)
+    o.depth_range(2, 30)
+    o.cluster(1, 0, 2)
+    o.write_hash(workdir.file("orc0.hash"))
+    _run_sharded(empty, nranks, 20, 2, 30, 2, workdir.file("hip0.hash"))
+    assert open(workdir.file("hip0.hash"), "rb").read() == open(workdir.file("orc0.hash"), "rb").read()
+
+
+def test_random_parameter_soak():
+    """24 seeded random cases of tests/soak.py (parameters, knobs, second range, clusterSplit, sharded with 1-4 ranks)."""
+    import soak
+    bad = soak.run(24, 314)
+    assert not bad, bad
+
+
 def test_sharded_golden_small(workdir):
     recs = np.frombuffer(orc.read_maybe_gz(os.path.join(orc.GOLDEN, "small.fqb.gz")), dtype=np.uint32)
     _run_sharded(recs, 4, 20, 3, 14, 2, workdir.file("hip.hash"))
