@@ -991,7 +991,7 @@ int stageC_cluster(Ctx *c, int codeMin, int codeMax, int threshold) {
   DevBuf<unsigned char> firstSlots[3];
   const size_t firstStride = (((size_t)nGlobal * 2 + 255) & ~(size_t)255);
   const u32 gridOf[3] = {hmin<u32>(hc[0] + hc[1], (u32)c->numCU * (u32)hmax<size_t>(1, (160 * 1024) / (budget0 + 1024))), hmin<u32>(hc[1], (u32)c->numCU * 2), hmin<u32>(hc[2], (u32)c->numCU)};   // class 1 unused
-  if (firstMode == 2) for (int k = 0; k < 3; ++k) if (hc[k]) {
+  if (firstMode == 2) for (int k = 0; k < 3; k += 2) if (gridOf[k]) {       // class 0 serves list 0 AND the front list (hc[1]); class 1 has no launch
     H10X_HIP(c, firstSlots[k].alloc(firstStride * gridOf[k]));
     H10X_HIP(c, hipMemsetAsync(firstSlots[k].p, 0xFF, firstStride * gridOf[k], st));
   }

@@ -1,6 +1,7 @@
 """Randomised differential soak (test infrastructure): the HIP path against the CPU oracle on seeded random sets and random
 parameters — k, w, r, depth ranges, threshold, the cluster placement / budget knobs, a second range, clusterSplit + re-cluster,
-and the sharded form with 1-4 ranks as threads (fewer barcodes than ranks included). `run(n, seed)` returns the
+a barcode sub-range, -N, a write/read round trip
+through a .hash file, and the sharded form with 1-8 ranks as threads (fewer barcodes than ranks included). `run(n, seed)` returns the
 descriptions of the cases that differ; tests/test_gpu_parity.py runs a short one, `python tests/soak.py 500 7` a long one."""
 import os, random, shutil, sys, tempfile, threading, time
 
@@ -18,9 +19,10 @@ def run(n_cases, seed, verbose=False):
         d = tempfile.mkdtemp()
         k = rng.choice([21, 21, 21, 16, 24, 25, 31, 11, 19]); w = rng.choice([31, 31, 31, 5, 7, 32, 13, 64])
         r = rng.choice([17, 17, 3, 9, 101])
-        pairs = rng.choice([3000, 8000, 20000, 40000]); barcodes = rng.choice([5, 20, 60, 150, 400]); genome = rng.choice([40000, 100000, 300000])
+        pairs = rng.choice([60, 500, 3000, 8000, 20000, 40000]); barcodes = rng.choice([1, 2, 3, 5, 20, 60, 150, 400]); genome = rng.choice([40000, 100000, 300000])
+        if barcodes > pairs // 4: barcodes = max(1, pairs // 4)
         mol = rng.choice([2.0, 3.0, 4.0]); mol_len = rng.choice([2500, 5000, 8000]); err = rng.choice([0.001, 0.003, 0.01])
-        lo = rng.choice([2, 3, 4, 6]); hi = lo + rng.choice([3, 10, 30, 100]); ct = rng.choice([1, 2, 3, 5])
+        lo = rng.choice([1, 2, 3, 4, 6]); hi = lo + rng.choice([1, 3, 10, 30, 100, 100000]); ct = rng.choice([1, 2, 3, 5, 40])
         B = 23 if w < 13 else 21
         opts = {}
         if rng.random() < 0.3: opts["cluster_first_global"] = rng.choice([1, 2, 3])
@@ -29,6 +31,13 @@ def run(n_cases, seed, verbose=False):
         if rng.random() < 0.15 and "cluster_first_global" in opts: opts["cluster_first_cap"] = rng.choice([64, 500, 1500])
         tail = ["-ct", ct, "--readFQB", "x.fqb", "--hashDepthRange", lo, hi, "--cluster", 1, 0]
         simple = True
+        u = rng.random()
+        if u < 0.12:                                          # a sub-range of barcodes
+            c0 = rng.randint(1, max(1, barcodes // 2)); tail[-2:] = [c0, rng.choice([0, c0, c0 + 1, c0 + max(1, barcodes // 3)])]; simple = False   # (the set may hold fewer barcodes than asked for: stay in its lower part)
+        elif u < 0.22:                                        # -N: only the first records of the file
+            tail = ["-N", rng.randint(1, pairs)] + tail; simple = False
+        elif u < 0.32:                                        # through a .hash file: write, read back, cluster again
+            tail += ["--writeHash", "mid.hash", "--readHash", "mid.hash", "--hashDepthRange", lo, hi + 2, "--cluster", 1, 0]; simple = False
         if rng.random() < 0.3: tail += ["--hashDepthRange", lo + 1, hi + 5, "--cluster", 1, 0]; simple = False
         if rng.random() < 0.3: tail += ["--clusterSplit", "--hashDepthRange", lo, hi, "--cluster", 1, 0]; simple = False
         desc = dict(case=case, k=k, w=w, r=r, pairs=pairs, barcodes=barcodes, genome=genome, mol=mol, mol_len=mol_len, err=err, B=B, opts=opts, tail=tail)
@@ -44,7 +53,7 @@ def run(n_cases, seed, verbose=False):
             run_commands(lambda k_, w_, r_, B_: orc.Oracle(k_, w_, r_, B_), base + ["--writeHash", "orc.hash"], d)
             got = open(os.path.join(d, "hip.hash"), "rb").read(); exp = open(os.path.join(d, "orc.hash"), "rb").read()
             ok = got == exp
-            nr = rng.choice([1, 2, 3, 4])
+            nr = rng.choice([1, 2, 3, 4, 8])
             if ok and simple and rng.random() < 0.6:          # the sharded form of the same commands, ranks as threads
                 flat = np.ascontiguousarray(recs, dtype=np.uint32).reshape(-1)
                 cut = hash10x_amd.partition(recs, nr); comms = hash10x_amd.Comm.local(nr); errs = [None] * nr

@@ -115,6 +115,18 @@ def test_cluster_first_table_on_hbm_slots(workdir):
     assert hf.blocks["nSubCluster"].sum() > 0
 
 
+def test_cluster_tiny_set_front_queue_only(workdir):
+    """60 read pairs in 15 barcodes, depth range [3,4): the mean number of good hashes per barcode is 0, so every barcode with
+    any counts as 'large' and sits in the front queue while the ordinary queue is empty (a null first[] slot in the hybrid
+    placement, found by tests/soak.py)."""
+    orc.gen_fqb(workdir.file("x.fqb"), 60, 15, 40000, 0.001, 1507, 4.0, 150, 2500)
+    for mode in (0, 1, 2, 3):
+        _against_oracle(workdir, "x.fqb", ["-ct", 5, "--readFQB", "x.fqb", "--hashDepthRange", 3, 4, "--cluster", 1, 0],
+                        k=24, w=32, r=9, B=21, cluster_first_global=mode)
+        _against_oracle(workdir, "x.fqb", ["-ct", 1, "--readFQB", "x.fqb", "--hashDepthRange", 2, 4, "--cluster", 1, 0],
+                        k=24, w=32, r=9, B=21, cluster_first_global=mode)
+
+
 @pytest.mark.parametrize("k,w,r", [(21, 31, 17), (16, 5, 3), (24, 31, 5), (25, 31, 17), (31, 7, 1), (11, 32, 9)])
 def test_other_hashers(workdir, k, w, r):
     """k > 24 cannot pack (hash, read) into 64 bits and takes the global path; w != 31 the generic modulo."""
