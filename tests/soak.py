@@ -19,7 +19,7 @@ def run(n_cases, seed, verbose=False):
         d = tempfile.mkdtemp()
         k = rng.choice([21, 21, 21, 16, 24, 25, 31, 11, 19]); w = rng.choice([31, 31, 31, 5, 7, 32, 13, 64])
         r = rng.choice([17, 17, 3, 9, 101])
-        pairs = rng.choice([60, 500, 3000, 8000, 20000, 40000]); barcodes = rng.choice([1, 2, 3, 5, 20, 60, 150, 400]); genome = rng.choice([40000, 100000, 300000])
+        pairs = rng.choice([60, 500, 3000, 8000, 20000, 40000]); barcodes = rng.choice([1, 2, 3, 5, 20, 60, 150, 400]); genome = rng.choice([3000, 12000, 40000, 100000, 300000])      # small genomes: hashes shared by hundreds of barcodes (long lists)
         if barcodes > pairs // 4: barcodes = max(1, pairs // 4)
         mol = rng.choice([2.0, 3.0, 4.0]); mol_len = rng.choice([2500, 5000, 8000]); err = rng.choice([0.001, 0.003, 0.01])
         lo = rng.choice([1, 2, 3, 4, 6]); hi = lo + rng.choice([1, 3, 10, 30, 100, 100000]); ct = rng.choice([1, 2, 3, 5, 40])
