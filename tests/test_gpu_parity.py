@@ -286,6 +286,15 @@ def test_random_parameter_soak():
     assert not bad, bad
 
 
+@pytest.mark.skipif(not orc.have_ref(), reason="oracle/_ref not present")
+def test_random_command_line_soak():
+    """12 seeded random command lines of tests/soak_cli.py: bin/hash10x-amd against the reference binary, .hash bytes and
+    every report line (--hashStats, --codeStats, --cribBuild, --clusterReport, --clusterSplit, --cribSummary)."""
+    import soak_cli
+    bad = soak_cli.run(12, 271)
+    assert not bad, bad
+
+
 def test_sharded_golden_small(workdir):
     recs = np.frombuffer(orc.read_maybe_gz(os.path.join(orc.GOLDEN, "small.fqb.gz")), dtype=np.uint32)
     _run_sharded(recs, 4, 20, 3, 14, 2, workdir.file("hip.hash"))
