@@ -11,7 +11,8 @@ import orc
 from driver import run_commands
 
 
-def run(n_cases, seed, verbose=False):
+def run(n_cases, seed, verbose=False, scale=1):
+    """scale > 1: pairs, barcodes and genome multiplied (launch classes, table overflows and multi-round lists at real sizes)"""
     import hash10x_amd
     rng = random.Random(seed)
     bad = []
@@ -20,10 +21,11 @@ def run(n_cases, seed, verbose=False):
         k = rng.choice([21, 21, 21, 16, 24, 25, 31, 11, 19]); w = rng.choice([31, 31, 31, 5, 7, 32, 13, 64])
         r = rng.choice([17, 17, 3, 9, 101])
         pairs = rng.choice([60, 500, 3000, 8000, 20000, 40000]); barcodes = rng.choice([1, 2, 3, 5, 20, 60, 150, 400]); genome = rng.choice([3000, 12000, 40000, 100000, 300000])      # small genomes: hashes shared by hundreds of barcodes (long lists)
+        pairs *= scale; barcodes *= max(1, scale // 3); genome *= scale
         if barcodes > pairs // 4: barcodes = max(1, pairs // 4)
         mol = rng.choice([2.0, 3.0, 4.0]); mol_len = rng.choice([2500, 5000, 8000]); err = rng.choice([0.001, 0.003, 0.01])
         lo = rng.choice([1, 2, 3, 4, 6]); hi = lo + rng.choice([1, 3, 10, 30, 100, 100000]); ct = rng.choice([1, 2, 3, 5, 40])
-        B = 23 if w < 13 else 21
+        B = (23 if w < 13 else 21) + (scale - 1).bit_length()
         opts = {}
         if rng.random() < 0.3: opts["cluster_first_global"] = rng.choice([1, 2, 3])
         if rng.random() < 0.2: opts["cluster_lds_budget"] = rng.choice([2048, 16 * 1024, 24 * 1024, 48 * 1024])
@@ -43,7 +45,7 @@ def run(n_cases, seed, verbose=False):
         desc = dict(case=case, k=k, w=w, r=r, pairs=pairs, barcodes=barcodes, genome=genome, mol=mol, mol_len=mol_len, err=err, B=B, opts=opts, tail=tail)
         try:
             recs = orc.gen_fqb(os.path.join(d, "x.fqb"), pairs, barcodes, genome, err, 1000 + case, mol, 150, mol_len)
-            base = ["-k", k, "-w", w, "-r", r, "-B", B] + tail
+            base = ["-k", k, "-w", w, "-r", r, "-B", B] + (["-c", pairs + 1] if scale > 1 else []) + tail   # (a barcode of > 100000 pairs needs -c, as in the reference)
 
             def make(k_, w_, r_, B_):
                 h = hash10x_amd.Hash10x(k=k_, w=w_, r=r_, B=B_)
@@ -91,7 +93,7 @@ if __name__ == "__main__":
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 30
     t0 = time.time()
-    bad = run(n, int(sys.argv[2]) if len(sys.argv) > 2 else 2026, verbose=True)
+    bad = run(n, int(sys.argv[2]) if len(sys.argv) > 2 else 2026, verbose=True, scale=int(sys.argv[3]) if len(sys.argv) > 3 else 1)
     for b in bad: print("BAD", b)
     print("soak: %d cases, %d bad, %.0f s" % (n, len(bad), time.time() - t0))
     sys.exit(1 if bad else 0)
