@@ -685,33 +685,47 @@ __device__ void cluster_one_block(const ClusterArgs &a, u32 code, unsigned char 
   const u32 nSub = sh[0], stop = sh[1];
   STAMP(3);
 
-  // ---- (d) minShareCount[clusterMin[label]] per rank (hash10x.c:821) into cnt[]; the list is re-read only when the
-  // cluster's founder is not msBest, RIF lists at a time, the next group's lists already in flight
+  // ---- (d) minShareCount[clusterMin[label]] per rank (hash10x.c:821) into cnt[]. The barcode list is read again only for
+  // the ranks whose cluster founder is not msBest — one rank in sixteen — so those ranks are first collected (what a wave
+  // would otherwise meet is a handful of 2 us loads scattered over twenty near-empty iterations, each waited for in
+  // turn), then worked off RIF lists per wave at a time with their loads issued together.
   {
-    u32 cjN2[RIF], dlN2[RIF], qvN[RIF];
-#define H10X_LOAD_D(I0, CJ, DL, QV)                                                                        \
-    _Pragma("unroll") for (int t = 0; t < RIF; ++t) {                                           \
-      const u32 i = (I0) + t; QV[t] = i < stop ? (u32)w.qj[i] : NONE16;                                    \
-      const bool need = QV[t] != NONE16 && QV[t] != w.best[i];                                             \
-      DL[t] = need ? (u32)w.dd[i] : 0;                                                                     \
-      CJ[t] = (u32)lane < DL[t] ? a.rows[w.rs[i] + lane] : code;                                           \
-    }
-    H10X_LOAD_D(1 + wave * RIF, cjN2, dlN2, qvN)
-    for (u32 i0 = 1 + wave * RIF; i0 < ((a.dbgSkip & 4) ? 0u : stop); i0 += CL_WAVES * RIF) {
-      u32 cj[RIF], dl[RIF], qv[RIF];
-#pragma unroll
-      for (int t = 0; t < RIF; ++t) { cj[t] = cjN2[t]; dl[t] = dlN2[t]; qv[t] = qvN[t]; }
-      H10X_LOAD_D(i0 + CL_WAVES * RIF, cjN2, dlN2, qvN)
+    u16 *todo = (u16 *)w.hist;                               // the histograms are idle from here on
+    if (tid == 0) sh[2] = 0;
+    SYNC();
+    if (!(a.dbgSkip & 4))
+      for (u32 i0 = 0; i0 < stop; i0 += CL_THREADS) {
+        const u32 i = i0 + tid;
+        bool need = false;
+        if (i >= 1 && i < stop) { const u32 q = w.qj[i]; need = q != NONE16 && q != w.best[i]; }
+        const u64 bal = __ballot(need);
+        if (bal) {
+          u32 base = 0;
+          if (lane == 0) base = atomicAdd(&sh[2], (u32)__popcll(bal));
+          base = (u32)__shfl((int)base, 0);
+          if (need) todo[base + (u32)__popcll(bal & ((1ULL << lane) - 1))] = (u16)i;
+        }
+      }
+    SYNC();
+    const u32 nTodo = sh[2];
+    for (u32 k0 = wave * RIF; k0 < nTodo; k0 += CL_WAVES * RIF) {
+      u32 ii[RIF], cj[RIF], dl[RIF], qv[RIF];
 #pragma unroll
       for (int t = 0; t < RIF; ++t) {
-        const u32 i = i0 + t;
-        if (qv[t] == NONE16 || dl[t] == 0) continue;         // no term, or founder == msBest: cnt[i] already holds the count
+        const bool on = k0 + t < nTodo;
+        ii[t] = on ? (u32)ld_shared<IN_LDS>(&todo[k0 + t]) : 0u;
+        qv[t] = on ? (u32)w.qj[ii[t]] : NONE16; dl[t] = on ? (u32)w.dd[ii[t]] : 0u;
+        cj[t] = (u32)lane < dl[t] ? a.rows[w.rs[ii[t]] + lane] : code;
+      }
+#pragma unroll
+      for (int t = 0; t < RIF; ++t) {
+        if (dl[t] == 0) continue;
+        const u32 i = ii[t];
         u32 q = (u32)__popcll(__ballot(cj[t] != code && ft.lookup(cj[t]) == qv[t]));
         if (dl[t] > WAVE) { const u32 *row = a.rows + w.rs[i]; for (u32 b0 = WAVE; b0 < dl[t]; b0 += WAVE) { bool m = false; if (b0 + lane < dl[t]) { const u32 c2 = row[b0 + lane]; m = c2 != code && ft.lookup(c2) == qv[t]; } q += (u32)__popcll(__ballot(m)); } }
         if (lane == 0) w.cnt[i] = (CT)q;
       }
     }
-#undef H10X_LOAD_D
   }
   SYNC();
   STAMP(4);
