@@ -451,8 +451,10 @@ template <bool IN_LDS, int FIRST_MODE /* 0 dense in LDS, 1 ranked in LDS, 2 dens
 __device__ void cluster_one_block(const ClusterArgs &a, u32 code, unsigned char *region, u16 *firstGlobal, u32 *sh /* small shared ints */, u64 (&acc)[4]) {   // code: local block number
   constexpr int CL_WAVES = CL_THREADS / WAVE;
   // lists a wave keeps in flight: 4, but 2 where the kernel must stay within 64 VGPRs (two workgroups per CU) AND carries
-  // the ranked / hashed lookup: fewer registers spilled is worth more there than the deeper prefetch (8x set: 52.8 -> 41.4 ms)
-  constexpr int RIF = (KLASS == 0 && CL_THREADS == 1024 && (FIRST_MODE == 1 || FIRST_MODE == 3)) ? 2 : ROWS_IN_FLIGHT;
+  // the ranked / hashed lookup: fewer registers spilled is worth more there than the deeper prefetch (8x set: 52.8 -> 41.4 ms);
+  // and 2 for the hashed placement in every class: with 4 its list loop unrolls to 61 KB of code (the compiler then keeps
+  // the block function out of line) against 42 KB — 300 k-barcode set: 0.533 -> 0.507 s
+  constexpr int RIF = ((KLASS == 0 && CL_THREADS == 1024 && FIRST_MODE == 1) || FIRST_MODE == 3) ? 2 : ROWS_IN_FLIGHT;
   typedef typename std::conditional<IN_LDS, u16, u32>::type CT;
   const int tid = threadIdx.x, lane = tid & (WAVE - 1), wave = tid / WAVE;
   const u32 n = a.nGood[code];
