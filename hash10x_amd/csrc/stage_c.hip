@@ -217,6 +217,10 @@ __host__ __device__ inline u32 histWaves(u32 nFirst, u32 n, u32 maxWaves, u32 bm
 constexpr u32 HASHED_MIN_SLOTS = 1024, HASHED_MAX_SLOTS = 1u << 16;
 // list-loop waves and table slots of a block in the hashed placement: all waves if the table then still has `want`
 // slots, else 8, else the minimum (fewer waves => more slots); slots = 0 if nothing fits
+#ifndef H10X_HASHED_WANT_PCT
+#define H10X_HASHED_WANT_PCT 150
+#endif
+__host__ __device__ inline u32 hashedWant(u32 est) { return (u32)(((u64)est * H10X_HASHED_WANT_PCT) / 100); }   // slots asked for per barcode expected in the table
 __host__ __device__ inline void hashedShape(u32 n, u32 maxWaves, u32 ctBytes, size_t budget, u32 minSlots, u32 want, u32 &nW, u32 &slots) {
   const u32 tryW[3] = {maxWaves, maxWaves < 8 ? maxWaves : 8, MIN_HIST_WAVES};
   const size_t need = minSlots > HASHED_MIN_SLOTS ? minSlots : HASHED_MIN_SLOTS;
@@ -469,7 +473,7 @@ __device__ void cluster_one_block(const ClusterArgs &a, u32 code, unsigned char 
   // work queue then serve nearly every barcode; the rest of the phases always use the whole workgroup)
   u32 nW, slots = 0;
   if constexpr (HASHED) {
-    const u32 want = rankedFirstEstimateE(a.nBlocksFirst, n, a.entries[code]) + rankedFirstEstimateE(a.nBlocksFirst, n, a.entries[code]) / 2;
+    const u32 want = hashedWant(rankedFirstEstimateE(a.nBlocksFirst, n, a.entries[code]));
     hashedShape(n, CL_WAVES, sizeof(CT), a.ldsBudget, a.hashMinSlots, want, nW, slots);
     if (a.firstCap && slots > a.firstCap) slots = a.firstCap;                  // test knob: small tables, to exercise the overflow chain
     if (!nW || !slots) {                                     // cannot hold this barcode at all: hand it on
@@ -907,7 +911,7 @@ __global__ void cluster_classify_kernel(const h10x_block *__restrict__ blocks, c
     nRead = blocks[c].nRead;
     if (wide) cls = 3;                                       // counts do not fit the u16 arrays of the LDS instantiations
     else if (ranked == 2) {                                  // hashed placement
-      const u32 est = rankedFirstEstimateE(nBlocks, n, entries[c]), want = est + est / 2;
+      const u32 want = hashedWant(rankedFirstEstimateE(nBlocks, n, entries[c]));
       u32 nW, slots;
       hashedShape(n, waves0, 2, budget0, hashMinSlots, want, nW, slots);
       if (slots >= want) cls = 0;
