@@ -100,14 +100,23 @@ __global__ void heads_kernel(const u64 *__restrict__ sHash, u64 n, u32 *__restri
   for (; i < n; i += stride) flags[i] = (i == 0 || sHash[i] != sHash[i - 1]) ? 1u : 0u;
 }
 __global__ void owner_distinct_kernel(const u64 *__restrict__ sHash, const u32 *__restrict__ rows, const u32 *__restrict__ flags, const u32 *__restrict__ ord,
-                                      u64 n, u64 *__restrict__ dHash, u32 *__restrict__ dFirst, u32 *__restrict__ segStart, u32 *__restrict__ iota,
-                                      u32 *__restrict__ cntFirst) {
+                                      u64 n, u64 *__restrict__ dHash, u32 *__restrict__ dFirst, u32 *__restrict__ segStart, u32 *__restrict__ iota) {
   u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; const u64 stride = (u64)gridDim.x * blockDim.x;
   for (; i < n; i += stride) if (flags[i]) {
     const u32 d = ord[i];
-    dHash[d] = sHash[i]; dFirst[d] = rows[i]; segStart[d] = (u32)i; iota[d] = d;
-    atomicAdd(&cntFirst[rows[i]], 1u);                      // stable sort => rows[i] is the lowest barcode of the hash
+    dHash[d] = sHash[i]; dFirst[d] = rows[i]; segStart[d] = (u32)i; iota[d] = d;   // stable sort => rows[i] is the lowest barcode of the hash
   }
+}
+// per barcode f: where its run starts in the distinct hashes sorted by first barcode, and how long it is (counting the
+// "first seen here" hashes with one atomic per hash put 3 M adds on 10 k words: 0.5 ms; the sort is needed anyway)
+__global__ void first_runs_kernel(const u32 *__restrict__ dFirstSorted, u32 U, u32 nB, u32 *__restrict__ myStart, u32 *__restrict__ cntFirst) {
+  const u32 f = blockIdx.x * blockDim.x + threadIdx.x;
+  if (f >= nB) return;
+  u32 lo = 0, hi = U;                                        // first position with dFirstSorted >= f
+  while (lo < hi) { const u32 mid = (lo + hi) >> 1; if (dFirstSorted[mid] < f) lo = mid + 1; else hi = mid; }
+  u32 lo2 = lo, hi2 = U;                                     // first position with dFirstSorted > f
+  while (lo2 < hi2) { const u32 mid = (lo2 + hi2) >> 1; if (dFirstSorted[mid] <= f) lo2 = mid + 1; else hi2 = mid; }
+  myStart[f] = lo; cntFirst[f] = lo2 - lo;
 }
 // per barcode c: how many new hashes it introduces in total and on owners before me
 __global__ void first_totals_kernel(const u32 *__restrict__ all /* N x nB */, int N, int me, u32 nB, u32 *__restrict__ total, u32 *__restrict__ before) {
@@ -232,8 +241,8 @@ int shard_readFqb(Ctx *c, Comm *cm, const u32 *dRec, u64 nRec) {
   H10X_TRY(c->syncReadbacks());
   DevBuf<u64> dHash; DevBuf<u32> dFirst, dio, cntFirst;
   H10X_HIP(c, dHash.alloc(Uo)); H10X_HIP(c, dFirst.alloc(Uo)); H10X_HIP(c, c->oSegStart.alloc((size_t)Uo + 1)); H10X_HIP(c, dio.alloc(Uo));
-  H10X_HIP(c, cntFirst.alloc(nB)); H10X_HIP(c, hipMemsetAsync(cntFirst.p, 0, (size_t)nB * 4, st));
-  if (M) owner_distinct_kernel<<<gridFor(M), 256, 0, st>>>(oHash.p, c->oRows.p, flags.p, ord.p, M, dHash.p, dFirst.p, c->oSegStart.p, dio.p, cntFirst.p);
+  H10X_HIP(c, cntFirst.alloc(nB));
+  if (M) owner_distinct_kernel<<<gridFor(M), 256, 0, st>>>(oHash.p, c->oRows.p, flags.p, ord.p, M, dHash.p, dFirst.p, c->oSegStart.p, dio.p);
   H10X_HIP(c, hipMemsetD32Async((hipDeviceptr_t)(c->oSegStart.p + Uo), (int)(u32)M, 1, st));          // end of the last segment
 
   // ---- 4. numbering: index = 1 + #(hashes first seen in an earlier barcode) + #(same barcode, smaller hash);
@@ -241,19 +250,21 @@ int shard_readFqb(Ctx *c, Comm *cm, const u32 *dRec, u64 nRec) {
   DevBuf<u32> allFirst, total, before, base, myStart;
   H10X_HIP(c, allFirst.alloc((size_t)N * nB)); H10X_HIP(c, total.alloc((size_t)nB + 1)); H10X_HIP(c, before.alloc(nB));
   H10X_HIP(c, base.alloc((size_t)nB + 1)); H10X_HIP(c, myStart.alloc(nB));
+  // my distinct hashes in (first barcode, hash) order: a stable sort by first barcode of the hash-ordered list; the runs of
+  // equal first barcode give the per-barcode counts the numbering needs
+  DevBuf<u32> order, dFirstSorted; H10X_HIP(c, order.alloc(Uo)); H10X_HIP(c, dFirstSorted.alloc(Uo)); H10X_HIP(c, c->oIndex.alloc(Uo));
+  H10X_TRY(prim_sort_pairs_u32_u32(c, pt, dFirst.p, dFirstSorted.p, dio.p, order.p, Uo, 0, bitsForS(nB)));
+  first_runs_kernel<<<divUp(nB, 256), 256, 0, st>>>(dFirstSorted.p, Uo, nB, myStart.p, cntFirst.p);
   { std::vector<u64> sc((size_t)N, nB), so((size_t)N, 0), rc((size_t)N, nB), ro((size_t)N);
     for (int r = 0; r < N; ++r) ro[r] = (u64)r * nB;
     H10X_TRY(cm->alltoallv(c, cntFirst.p, sc.data(), so.data(), allFirst.p, rc.data(), ro.data(), 4)); }   // allgather
   first_totals_kernel<<<divUp(nB, 256), 256, 0, st>>>(allFirst.p, N, me, nB, total.p, before.p);
   H10X_HIP(c, hipMemsetAsync(total.p + nB, 0, 4, st));
   H10X_TRY(prim_exclusive_scan_u32(c, pt, total.p, base.p, (size_t)nB + 1));
-  H10X_TRY(prim_exclusive_scan_u32(c, pt, cntFirst.p, myStart.p, nB));
   u32 U = 0;
   H10X_TRY(c->readback(&U, base.p + nB, 4));
   H10X_TRY(c->syncReadbacks());
   if ((u64)U + 1 > (((u64)1 << c->prm.B) >> 2) - 2) return c->fail("hashTableSize is too small");     // hash10x.c:149, same verdict on every rank
-  DevBuf<u32> order, dFirstSorted; H10X_HIP(c, order.alloc(Uo)); H10X_HIP(c, dFirstSorted.alloc(Uo)); H10X_HIP(c, c->oIndex.alloc(Uo));
-  H10X_TRY(prim_sort_pairs_u32_u32(c, pt, dFirst.p, dFirstSorted.p, dio.p, order.p, Uo, 0, bitsForS(nB)));
   if (Uo) owner_index_kernel<<<divUp(Uo, 256), 256, 0, st>>>(order.p, dFirstSorted.p, Uo, base.p, before.p, myStart.p, c->oIndex.p);
   c->oU = Uo; c->oM = M;
 
