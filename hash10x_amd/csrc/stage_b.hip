@@ -73,6 +73,48 @@ __global__ void probe_finish_kernel(u32 *__restrict__ table, u64 n) {
   for (; i < n; i += stride) if (table[i] == SLOT_EMPTY) table[i] = 0;
 }
 
+// The same table with the key beside the index — entry = index << qBits | hash / w, all ones = empty — while that fits 64
+// bits (k = 21, w = 31: 38 + B - 2 <= 64 up to B = 28): a look-up then needs ONE random 8-byte read per probe step
+// instead of the table word and then hashValue[index] behind it. Built with the same minimum-and-evict walk (entries
+// compare by index first), hashIndex[] is its index column; the wide table lives only until the entries are looked up.
+constexpr u64 SLOT_EMPTY64 = ~0ULL;
+__global__ void probe_insert64_kernel(const u64 *__restrict__ hashValue, u32 hashNumber, int B, u64 w, int qBits, u64 *__restrict__ table) {
+  const u32 first = blockIdx.x * blockDim.x + threadIdx.x + 1;
+  const u64 mask = ((u64)1 << B) - 1, qmask = ((u64)1 << qBits) - 1;
+  for (u32 start = first; start < hashNumber; start += gridDim.x * blockDim.x) {
+    u64 h = hashValue[start];
+    u64 cur = ((u64)start << qBits) | (h / w);
+    u64 slot = h & mask, step = ((h >> B) & mask) | 1;
+    for (;;) {
+      const u64 old = atomicMin((unsigned long long *)&table[slot], (unsigned long long)cur);
+      if (old == SLOT_EMPTY64) break;                        // took a free slot
+      if (old > cur) {                                       // evicted a later index: it continues from here
+        cur = old; h = (old & qmask) * w; step = ((h >> B) & mask) | 1;
+      }
+      slot = (slot + step) & mask;
+    }
+  }
+}
+__global__ void probe_finish64_kernel(const u64 *__restrict__ table64, u64 n, int qBits, u32 *__restrict__ table) {
+  u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  const u64 stride = (u64)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) { const u64 e = table64[i]; table[i] = e == SLOT_EMPTY64 ? 0u : (u32)(e >> qBits); }
+}
+__global__ void lookup_pack64_kernel(const u64 *__restrict__ entHash /* hash / w */, const u32 *__restrict__ entRead, u64 n,
+                                     const u64 *__restrict__ table64, int B, u64 w, int qBits, u64 *__restrict__ key) {
+  u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  const u64 stride = (u64)gridDim.x * blockDim.x;
+  const u64 mask = ((u64)1 << B) - 1, qmask = ((u64)1 << qBits) - 1;
+  for (; i < n; i += stride) {
+    const u64 q = entHash[i], h = q * w;
+    u64 slot = h & mask; const u64 step = ((h >> B) & mask) | 1;
+    u64 e;
+    while ((e = table64[slot]) != SLOT_EMPTY64 && (e & qmask) != q) slot = (slot + step) & mask;
+    const u32 ix = e == SLOT_EMPTY64 ? 0u : (u32)(e >> qBits);
+    key[i] = ((u64)ix << 32) | (u64)(entRead[i] & 0xFFFFu);
+  }
+}
+
 // ------------------------------------------------------------------------------------------ clusHash
 __global__ void lookup_pack_kernel(const u64 *__restrict__ entHash, const u32 *__restrict__ entRead, u64 n,
                                    const u32 *__restrict__ table, const u64 *__restrict__ hashValue, int B, u64 w /* entHash holds hash / w */, u64 *__restrict__ key) {
@@ -140,13 +182,24 @@ int stageB_run(Ctx *c, DevBuf<u64> &entHash, DevBuf<u32> &entCode, DevBuf<u32> &
   c->tstop(T_RANK);
   sHash.release(); dHash.release(); dFirst.release(); iota.release(); dFirstSorted.release();
 
-  H10X_TRY(stageB_buildProbeTable(c));
+  const bool wideTable = c->keyBits + (B - 2) <= 64 && c->keyBits < 64;   // index < 2^(B-2) (hash10x.c:149)
+  DevBuf<u64> table64;
+  if (wideTable) {
+    c->tstart(T_PROBE);
+    H10X_HIP(c, table64.alloc(tableSize)); H10X_HIP(c, c->hashIndex.alloc(tableSize));
+    H10X_HIP(c, hipMemsetAsync(table64.p, 0xFF, tableSize * 8, st));
+    if (U) probe_insert64_kernel<<<hmin<u32>(divUp(U, 256), 16384), 256, 0, st>>>(c->hashValue.p, U + 1, B, (u64)c->prm.w, c->keyBits, table64.p);
+    probe_finish64_kernel<<<(unsigned)hmin<u64>(divUp(tableSize, 256), 65535u * 2), 256, 0, st>>>(table64.p, tableSize, c->keyBits, c->hashIndex.p);
+    c->tstop(T_PROBE);
+  } else H10X_TRY(stageB_buildProbeTable(c));
 
   // ---- clusHash: look every entry up, order each block by index (hash10x.c:177-183)
   c->tstart(T_CLUSHASH);
   if (H) {
     DevBuf<u64> key; H10X_HIP(c, key.alloc(H));
-    lookup_pack_kernel<<<gH, 256, 0, st>>>(entHash.p, entRead.p, H, c->hashIndex.p, c->hashValue.p, B, (u64)c->prm.w, key.p);
+    if (wideTable) lookup_pack64_kernel<<<gH, 256, 0, st>>>(entHash.p, entRead.p, H, table64.p, B, (u64)c->prm.w, c->keyBits, key.p);
+    else lookup_pack_kernel<<<gH, 256, 0, st>>>(entHash.p, entRead.p, H, c->hashIndex.p, c->hashValue.p, B, (u64)c->prm.w, key.p);
+    table64.release();
     H10X_TRY(stageB_finishClusHash(c, key));
   } else H10X_HIP(c, c->clusHash.alloc(0));
   c->tstop(T_CLUSHASH);
