@@ -47,7 +47,7 @@ __global__ void within_kernel(const u32 *__restrict__ depth, u32 hashNumber, int
 }
 __global__ void within_depth_kernel(const u32 *__restrict__ depth, const u8 *__restrict__ within, u32 hashNumber, u32 *__restrict__ out) {
   const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < hashNumber) out[i] = within[i] ? depth[i] : 0;
+  if (i < hashNumber) out[i] = within[i] ? depth[i] + 1 : 0;   // 0 = outside the range(s); depth + 1 otherwise (one word tells both)
 }
 
 // per block: keys (depth << 16 | position) of its in-range hashes, appended in any order; KT = u32 while the largest
@@ -55,7 +55,7 @@ __global__ void within_depth_kernel(const u32 *__restrict__ depth, const u8 *__r
 template <typename KT>
 __global__ __launch_bounds__(256)
 void good_keys_kernel(const h10x_clushash *__restrict__ ch, const u64 *__restrict__ blockOff, const h10x_block *__restrict__ blocks,
-                      u32 nBlocks, const u8 *__restrict__ within, const u32 *__restrict__ depth,
+                      u32 nBlocks, const u32 *__restrict__ wdepth /* 0 = not in range, else depth + 1 */,
                       KT *__restrict__ key, u32 *__restrict__ nGood, u32 *__restrict__ segEnd, u32 *__restrict__ entries /* sum of depths, saturating */) {
   __shared__ u32 sCount; __shared__ unsigned long long sDepth;
   for (u32 c = blockIdx.x; c < nBlocks; c += gridDim.x) {
@@ -67,14 +67,14 @@ void good_keys_kernel(const h10x_clushash *__restrict__ ch, const u64 *__restric
     if (nHash <= 65535) {                                    // hash10x.c:748-753: bigger blocks are ignored
       for (u32 base = 0; base < nHash; base += blockDim.x) {
         const u32 p = base + threadIdx.x;
-        u32 ix = 0; bool good = false;
-        if (p < nHash) { ix = ch[o + p].hash; good = within[ix] != 0; if (good) myDepth += depth[ix]; }
+        u32 wd = 0; bool good = false;
+        if (p < nHash) { wd = wdepth[ch[o + p].hash]; good = wd != 0; if (good) myDepth += wd - 1; }
         const u64 bal = __ballot(good);
         const int lane = threadIdx.x & (WAVE - 1);
         u32 wb = 0;
         if (lane == 0 && bal) wb = atomicAdd(&sCount, (u32)__popcll(bal));
         wb = __shfl(wb, 0);
-        if (good) key[o + wb + (u32)__popcll(bal & ((1ULL << lane) - 1))] = (KT)(((KT)depth[ix] << 16) | (KT)p);
+        if (good) key[o + wb + (u32)__popcll(bal & ((1ULL << lane) - 1))] = (KT)(((KT)(wd - 1) << 16) | (KT)p);
       }
     }
     for (int sft = 32; sft; sft >>= 1) myDepth += __shfl_down(myDepth, sft);
@@ -115,10 +115,10 @@ int stageC_depthRange(Ctx *c, int lo, int hi) {
   H10X_TRY(prim_reduce_max_u32(c, pt, wdepth.p, red.p, U1));
   const bool narrow = c->depthBound <= 65535u;                // known without a round trip (Ctx::depthBound)
   if (narrow) { H10X_HIP(c, key32.alloc(H)); H10X_HIP(c, keyS32.alloc(H)); } else { H10X_HIP(c, key.alloc(H)); H10X_HIP(c, keyS.alloc(H)); }
-  if (narrow) good_keys_kernel<u32><<<hmin<u32>(nBlocks, 16384), 256, 0, st>>>(c->clusHash.p, c->blockOff.p, c->blocks.p, nBlocks, c->within.p,
-                                                                             c->hashDepth.p, key32.p, c->nGood.p, segEnd.p, c->goodEntries.p);
-  else good_keys_kernel<u64><<<hmin<u32>(nBlocks, 16384), 256, 0, st>>>(c->clusHash.p, c->blockOff.p, c->blocks.p, nBlocks, c->within.p,
-                                                                      c->hashDepth.p, key.p, c->nGood.p, segEnd.p, c->goodEntries.p);
+  if (narrow) good_keys_kernel<u32><<<hmin<u32>(nBlocks, 16384), 256, 0, st>>>(c->clusHash.p, c->blockOff.p, c->blocks.p, nBlocks, wdepth.p,
+                                                                             key32.p, c->nGood.p, segEnd.p, c->goodEntries.p);
+  else good_keys_kernel<u64><<<hmin<u32>(nBlocks, 16384), 256, 0, st>>>(c->clusHash.p, c->blockOff.p, c->blocks.p, nBlocks, wdepth.p,
+                                                                      key.p, c->nGood.p, segEnd.p, c->goodEntries.p);
   H10X_TRY(prim_reduce_max_u32(c, pt, c->nGood.p, red.p + 1, nBlocks));
   DevBuf<u64> redSum; H10X_HIP(c, redSum.alloc(1));
   H10X_TRY(prim_reduce_sum_u32_u64(c, pt, c->nGood.p, redSum.p, nBlocks));
@@ -126,6 +126,7 @@ int stageC_depthRange(Ctx *c, int lo, int hi) {
   H10X_TRY(c->readback(hr, red.p, 8));
   H10X_TRY(c->readback(&sumGood, redSum.p, 8));
   H10X_TRY(c->syncReadbacks());
+  hr[0] = hr[0] ? hr[0] - 1 : 0;                              // wdepth holds depth + 1
   c->maxGoodDepth = hr[0]; c->maxGood = hr[1]; c->meanGood = nBlocks > 1 ? (u32)(sumGood / (nBlocks - 1)) : 0;
   offsets32c_kernel<<<divUp((u64)nBlocks + 1, 256), 256, 0, st>>>(c->blockOff.p, nBlocks + 1, off32.p);
   // ascending (depth, position): qsort by depth, stable => ties by position (hash10x.c:726-730,758)
