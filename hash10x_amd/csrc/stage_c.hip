@@ -845,22 +845,27 @@ void read_merge_kernel(h10x_block *__restrict__ blocks, const u64 *__restrict__ 
   u8 *readRep = (u8 *)smem;
   u32 *adj = (u32 *)(smem + ((nRep + 15) & ~15u));
   u32 *comp = adj + 256 * 8, *newLab = comp + 256;
+  // the block's entries are looked at three times: the first MERGE_KEEP per thread stay in registers (a block of up to
+  // 2048 hashes is then read from HBM once — each pass was a round trip of its own in front of a barrier)
+  constexpr int MERGE_KEEP = 8;
+  h10x_clushash keep[MERGE_KEEP];
+#pragma unroll
+  for (int j = 0; j < MERGE_KEEP; ++j) { const u32 p = tid + j * MERGE_THREADS; if (p < nHash) keep[j] = ch[p]; }
+#define H10X_FOR_ENTRIES(...)                                                                                          \
+  { _Pragma("unroll") for (int j = 0; j < MERGE_KEEP; ++j) { const u32 p = tid + j * MERGE_THREADS; if (p < nHash) { const h10x_clushash e = keep[j]; __VA_ARGS__ } } \
+    for (u32 p = tid + MERGE_KEEP * MERGE_THREADS; p < nHash; p += MERGE_THREADS) { const h10x_clushash e = ch[p]; __VA_ARGS__ } }
   for (u32 i = tid; i < (nRep + 3) / 4; i += MERGE_THREADS) ((u32 *)readRep)[i] = 0;
   for (u32 i = tid; i < 256 * 8; i += MERGE_THREADS) adj[i] = 0;
   comp[tid] = tid;
   __syncthreads();
-  for (u32 p = tid; p < nHash; p += MERGE_THREADS) {         // any one label of each read is its representative
-    const h10x_clushash e = ch[p];
-    if (e.subCluster && e.subCluster <= nSub && e.read < nRep) readRep[e.read] = e.subCluster;
-  }
+  H10X_FOR_ENTRIES(                                          // any one label of each read is its representative
+    if (e.subCluster && e.subCluster <= nSub && e.read < nRep) readRep[e.read] = e.subCluster; )
   __syncthreads();
-  for (u32 p = tid; p < nHash; p += MERGE_THREADS) {
-    const h10x_clushash e = ch[p];
+  H10X_FOR_ENTRIES(
     if (e.subCluster && e.subCluster <= nSub && e.read < nRep) {
       const u32 L = e.subCluster, R = readRep[e.read];
       if (R != L) { atomicOr(&adj[L * 8 + (R >> 5)], 1u << (R & 31)); atomicOr(&adj[R * 8 + (L >> 5)], 1u << (L & 31)); }
-    }
-  }
+    } )
   __syncthreads();
   for (int iter = 0; iter < 256; ++iter) {                   // min-label propagation; <= 255 rounds
     if (tid == 0) changed = 0;
@@ -892,10 +897,10 @@ void read_merge_kernel(h10x_block *__restrict__ blocks, const u64 *__restrict__ 
     newLab[256 + tid] = mapped;
     __syncthreads();
   }
-  for (u32 p = tid; p < nHash; p += MERGE_THREADS) {
-    const u32 L = ch[p].subCluster;
-    if (L && L <= nSub) ch[p].subCluster = (u8)newLab[256 + L];
-  }
+  H10X_FOR_ENTRIES(
+    const u32 L = e.subCluster;
+    if (L && L <= nSub) ch[p].subCluster = (u8)newLab[256 + L]; )
+#undef H10X_FOR_ENTRIES
 }
 
 // launch classes by working-set size: 0 = half a CU's LDS (barcodes with many ranks run their list loop on fewer waves:
