@@ -91,10 +91,11 @@ __global__ void head_flags_kernel(const u32 *__restrict__ rec, u64 n, u32 *__res
 }
 
 // code[i] = inclusive scan of flags = 1-based block number of record i
-__global__ void block_starts_kernel(const u32 *__restrict__ flags, const u32 *__restrict__ code, u64 n,
+__global__ void block_starts_kernel(const u32 *__restrict__ flags, const u32 *__restrict__ code, u64 n, u32 nBlocks,
                                     u64 *__restrict__ startRec /* nBlocks+1 */) {
   u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
   const u64 stride = (u64)gridDim.x * blockDim.x;
+  if (i == 0) { startRec[0] = 0; startRec[nBlocks] = n; }    // block 0 is unused; the end of the last block
   for (; i < n; i += stride) if (flags[i]) startRec[code[i]] = i;
 }
 
@@ -359,10 +360,7 @@ int stageA_run(Ctx *c, const u32 *dRec, u64 nRec, DevBuf<u64> &entHash, DevBuf<u
     H10X_TRY(c->syncReadbacks());
     nBlocks = nRuns + 1;
     H10X_HIP(c, startRec.alloc((size_t)nBlocks + 1));
-    H10X_HIP(c, hipMemsetAsync(startRec.p, 0, 8, st));
-    block_starts_kernel<<<g, 256, 0, st>>>(flags.p, code.p, nRec, startRec.p);
-    H10X_HIP(c, hipMemsetD32Async((hipDeviceptr_t)((u32 *)(startRec.p + nBlocks)), (int)(u32)nRec, 1, st));            // startRec[nBlocks] = nRec
-    H10X_HIP(c, hipMemsetD32Async((hipDeviceptr_t)((u32 *)(startRec.p + nBlocks) + 1), (int)(u32)(nRec >> 32), 1, st));
+    block_starts_kernel<<<g, 256, 0, st>>>(flags.p, code.p, nRec, nBlocks, startRec.p);
   } else {
     if (emptyIsNoBlock) nBlocks = 1;                         // a shard without records holds no barcode at all (only the unused block 0)
     H10X_HIP(c, startRec.alloc(3));

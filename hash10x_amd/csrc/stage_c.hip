@@ -960,10 +960,13 @@ int stageC_cluster(Ctx *c, int codeMin, int codeMax, int threshold) {
   if (codeMax <= codeMin) { memset(c->ctr.cluster_class_counts, 0, sizeof c->ctr.cluster_class_counts); c->ctr.sum_good = c->ctr.sum_good_depth = c->ctr.sum_hash_clustered = c->ctr.clustered_codes = 0; return 0; }
   c->tstart(T_CLUSTER);
   const u32 span = (u32)(codeMax - codeMin);
-  DevBuf<u32> list0, list1, list2, list3, counts; DevBuf<u64> stats; DevBuf<double> term;
+  DevBuf<u32> list0, list1, list2, list3; DevBuf<u64> zeroed; DevBuf<double> term;
   H10X_HIP(c, list0.alloc(span)); H10X_HIP(c, list1.alloc(span)); H10X_HIP(c, list2.alloc(span)); H10X_HIP(c, list3.alloc(span));
-  H10X_HIP(c, counts.alloc(12)); H10X_HIP(c, stats.alloc(8)); H10X_HIP(c, term.alloc(c->nEntries));
-  H10X_HIP(c, hipMemsetAsync(counts.p, 0, 48, st)); H10X_HIP(c, hipMemsetAsync(stats.p, 0, 64, st));
+  // every small counter of the command in one buffer, cleared by one memset: counts[0..3] class sizes, [4] [6] [7] work
+  // queue positions, [8] largest nRead, [10] [11] overflowed blocks (lists A, B); stats[0..7] the work counters
+  H10X_HIP(c, zeroed.alloc(6 + 8)); H10X_HIP(c, term.alloc(c->nEntries));
+  H10X_HIP(c, hipMemsetAsync(zeroed.p, 0, (6 + 8) * 8, st));
+  struct { u32 *p; } counts{(u32 *)zeroed.p}; struct { u64 *p; } stats{zeroed.p + 6};
   const size_t budgetSmall = c->optClusterLds > 0 ? (size_t)c->optClusterLds : 80 * 1024 - 1024;
   const size_t budgetBig = c->optClusterLds > 0 ? (size_t)c->optClusterLds : 160 * 1024 - 1024;
   const int threads0 = c->optClusterThreads0 == 512 ? 512 : 1024;                            // tuning knobs for class 0
@@ -1000,8 +1003,8 @@ int stageC_cluster(Ctx *c, int codeMin, int codeMax, int threshold) {
   a.firstCap = firstCap; a.hashMask = hashBits >= 32 ? 0xFFFFFFFFu : (1u << hashBits) - 1u; a.hashMinSlots = hashMinSlots;
   // ranked / hashed placement: blocks whose table was too small are re-run — those of the half-CU class (list A) with the
   // whole LDS of a CU, those that fail there as well (list B) with first[] dense on an HBM slot
-  DevBuf<u32> ovfA, ovfB; H10X_HIP(c, ovfA.alloc((size_t)span + 1)); H10X_HIP(c, ovfB.alloc((size_t)span + 1));
-  H10X_HIP(c, hipMemsetAsync(ovfA.p, 0, 4, st)); H10X_HIP(c, hipMemsetAsync(ovfB.p, 0, 4, st));
+  DevBuf<u32> ovfA, ovfB; H10X_HIP(c, ovfA.alloc(span)); H10X_HIP(c, ovfB.alloc(span));
+  u32 *const ovfCountA = counts.p + 10, *const ovfCountB = counts.p + 11;
   DevBuf<u64> phase;
   if (c->optStamps) { H10X_HIP(c, phase.alloc(8)); H10X_HIP(c, hipMemsetAsync(phase.p, 0, 64, st)); a.phase = phase.p; }
   // HBM working set per workgroup (class 3): first[] + per-rank arrays for the largest barcode
@@ -1033,10 +1036,10 @@ int stageC_cluster(Ctx *c, int codeMin, int codeMax, int threshold) {
 #define H10X_LAUNCH_ONE(MODE, K, THREADS, BUDGET, GRID, STREAM)                                                                    \
       { H10X_HIP(c, hipFuncSetAttribute((const void *)cluster_kernel<true, MODE, THREADS, K>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(BUDGET))); \
         cluster_kernel<true, MODE, THREADS, K><<<GRID, THREADS, BUDGET, STREAM>>>(g); }
-#define H10X_LAUNCH_LDS(K, THREADS, BUDGET, STREAM, LIST, NLIST, GRID, CNT, OVF)                                                   \
+#define H10X_LAUNCH_LDS(K, THREADS, BUDGET, STREAM, LIST, NLIST, GRID, CNT, OVFCNT, OVF)                                           \
   {                                                                                                                                \
     ClusterArgs g = a; g.list = LIST; g.nList = NLIST; g.workCounter = counts.p + CNT; g.ldsBudget = (u32)(BUDGET);                \
-    g.overflow = (OVF) + 1; g.overflowCount = (OVF);                                                                               \
+    g.overflow = (OVF); g.overflowCount = (OVFCNT);                                                                                \
     if (firstMode == 0) H10X_LAUNCH_ONE(0, K, THREADS, BUDGET, GRID, STREAM)                                                       \
     else if (firstMode == 1) H10X_LAUNCH_ONE(1, K, THREADS, BUDGET, GRID, STREAM)                                                  \
     else if (firstMode == 3) H10X_LAUNCH_ONE(3, K, THREADS, BUDGET, GRID, STREAM)                                                  \
@@ -1053,7 +1056,7 @@ int stageC_cluster(Ctx *c, int codeMin, int codeMax, int threshold) {
     // CU to themselves until their queue is empty, and the two launches share the chip better by racing for the CUs —
     // 1 M-barcode set: 2.20 s against 2.52 s)
     a.started = gridOf[2] * 2 <= (u32)c->numCU ? c->startFlags : nullptr;
-    H10X_LAUNCH_LDS(2, CL_THREADS_HUGE, budgetBig, c->aux[1], list2.p, hc[2], gridOf[2], 6, ovfB.p)
+    H10X_LAUNCH_LDS(2, CL_THREADS_HUGE, budgetBig, c->aux[1], list2.p, hc[2], gridOf[2], 6, ovfCountB, ovfB.p)
     if (a.started) {
       const auto t0 = std::chrono::steady_clock::now();
       for (;;) {
@@ -1069,7 +1072,7 @@ int stageC_cluster(Ctx *c, int codeMin, int codeMax, int threshold) {
   if (hc[0] || hc[1]) {
     a.stats = stats.p + 4; a.front = list1.p; a.nFront = hc[1];
     c->tstart(T_CLUSTER_MAIN);
-    if (threads0 == 512) H10X_LAUNCH_LDS(0, 512, budget0, st, list0.p, hc[0], gridOf[0], 4, ovfA.p) else H10X_LAUNCH_LDS(0, CL_THREADS_SMALL, budget0, st, list0.p, hc[0], gridOf[0], 4, ovfA.p)
+    if (threads0 == 512) H10X_LAUNCH_LDS(0, 512, budget0, st, list0.p, hc[0], gridOf[0], 4, ovfCountA, ovfA.p) else H10X_LAUNCH_LDS(0, CL_THREADS_SMALL, budget0, st, list0.p, hc[0], gridOf[0], 4, ovfCountA, ovfA.p)
     c->tstop(T_CLUSTER_MAIN);
     a.stats = stats.p; a.front = nullptr; a.nFront = 0;
   }
@@ -1079,14 +1082,14 @@ int stageC_cluster(Ctx *c, int codeMin, int codeMax, int threshold) {
   DevBuf<unsigned char> scratch2;
   if (firstMode == 1 || firstMode == 3) {
     u32 nA = 0, nB = 0;
-    H10X_HIP(c, hipMemcpyAsync(&nA, ovfA.p, 4, hipMemcpyDeviceToHost, st));
+    H10X_HIP(c, hipMemcpyAsync(&nA, ovfCountA, 4, hipMemcpyDeviceToHost, st));
     H10X_HIP(c, hipStreamSynchronize(st));
     if (nA) {                                                // half-CU tables that were too small: again with the whole LDS of a CU
       H10X_HIP(c, hipMemsetAsync(counts.p + 6, 0, 4, st));
-      H10X_LAUNCH_LDS(2, CL_THREADS_HUGE, budgetBig, st, ovfA.p + 1, nA, hmin<u32>(nA, (u32)c->numCU), 6, ovfB.p)
+      H10X_LAUNCH_LDS(2, CL_THREADS_HUGE, budgetBig, st, ovfA.p, nA, hmin<u32>(nA, (u32)c->numCU), 6, ovfCountB, ovfB.p)
       H10X_HIP(c, hipGetLastError());
     }
-    H10X_HIP(c, hipMemcpyAsync(&nB, ovfB.p, 4, hipMemcpyDeviceToHost, st));
+    H10X_HIP(c, hipMemcpyAsync(&nB, ovfCountB, 4, hipMemcpyDeviceToHost, st));
     H10X_HIP(c, hipStreamSynchronize(st));
     nOverflow = nA + nB;
     if (nB) {
@@ -1096,7 +1099,7 @@ int stageC_cluster(Ctx *c, int codeMin, int codeMax, int threshold) {
       H10X_HIP(c, scratch2.alloc(firstStride * grid));
       H10X_HIP(c, hipMemsetAsync(scratch2.p, 0xFF, firstStride * grid, st));
       H10X_HIP(c, hipMemsetAsync(counts.p + 7, 0, 4, st));
-      ClusterArgs g = a; g.list = ovfB.p + 1; g.nList = nB; g.workCounter = counts.p + 7; g.scratch = scratch2.p; g.scratchStride = firstStride;
+      ClusterArgs g = a; g.list = ovfB.p; g.nList = nB; g.workCounter = counts.p + 7; g.scratch = scratch2.p; g.scratchStride = firstStride;
       g.ldsBudget = (u32)budgetBig;
       H10X_HIP(c, hipFuncSetAttribute((const void *)cluster_kernel<true, 2, CL_THREADS_HUGE, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)budgetBig));
       cluster_kernel<true, 2, CL_THREADS_HUGE, 3><<<grid, CL_THREADS_HUGE, budgetBig, st>>>(g);
