@@ -115,6 +115,15 @@ def test_cluster_first_table_on_hbm_slots(workdir):
     assert hf.blocks["nSubCluster"].sum() > 0
 
 
+def test_more_than_65535_barcodes(workdir):
+    """70 000 barcodes: barcode numbers beyond 16 bits in the lists, 64-bit (depth, position) keys for the good lists (the
+    depth bound no longer fits 16 bits), ranked placement of first[] by itself, and the hashed one forced."""
+    orc.gen_fqb(workdir.file("x.fqb"), 840000, 70000, 150000, 0.002, 91, 1.0, 150, 3000)
+    hf = _against_oracle(workdir, "x.fqb", ["-ct", 1, "--readFQB", "x.fqb", "--hashDepthRange", 3, 200, "--cluster", 1, 0], B=23)
+    assert hf.blocks["nSubCluster"].sum() > 10000 and hf.blocks_max > 65535
+    _against_oracle(workdir, "x.fqb", ["-ct", 1, "--readFQB", "x.fqb", "--hashDepthRange", 3, 200, "--cluster", 1, 0], B=23, cluster_first_global=3)
+
+
 def test_cluster_tiny_set_front_queue_only(workdir):
     """60 read pairs in 15 barcodes, depth range [3,4): the mean number of good hashes per barcode is 0, so every barcode with
     any counts as 'large' and sits in the front queue while the ordinary queue is empty (a null first[] slot in the hybrid
