@@ -122,6 +122,12 @@ def test_more_than_65535_barcodes(workdir):
     hf = _against_oracle(workdir, "x.fqb", ["-ct", 1, "--readFQB", "x.fqb", "--hashDepthRange", 3, 200, "--cluster", 1, 0], B=23)
     assert hf.blocks["nSubCluster"].sum() > 10000 and hf.blocks_max > 65535
     _against_oracle(workdir, "x.fqb", ["-ct", 1, "--readFQB", "x.fqb", "--hashDepthRange", 3, 200, "--cluster", 1, 0], B=23, cluster_first_global=3)
+    # and sharded over 4 ranks (global barcode numbers beyond 16 bits in every rank's lists)
+    exp = open(workdir.file("orc.hash"), "rb").read()
+    recs = np.fromfile(workdir.file("x.fqb"), dtype=np.uint32)
+    _run_sharded(recs, 4, 23, 3, 200, 1, workdir.file("sh.hash"))
+    got = open(workdir.file("sh.hash"), "rb").read()
+    assert got == exp, orc.describe_diff(got, exp)
 
 
 def test_cluster_tiny_set_front_queue_only(workdir):
