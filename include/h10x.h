@@ -195,7 +195,7 @@ typedef struct {
   uint64_t cluster_overflow_blocks; /* ranked placement: barcodes re-run on the HBM path because too many barcodes were present */
   uint64_t cluster_main[4];        /* work of the main cluster launch alone (timer "cluster_main"): good hashes, gathered list entries, nHash, barcodes */
   uint64_t cluster_phase_ticks[8]; /* diagnostic (option "cluster_stamps"): 100 MHz ticks per phase summed over workgroups:
-                                      init, first[], mode, replay, quotient, sum+labels, read merge, idle/queue */
+                                      [0] init (+ bitmap), [1] list loop, [2] barrier, [3] replay, [4] quotient, [5] output */
 } h10x_counters;
 int  h10x_get_counters(h10x_ctx *ctx, h10x_counters *out);
 /* testing knob: cap the LDS hash-set slots per barcode in stage A (0 = default) so that the
