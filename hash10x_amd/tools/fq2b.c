@@ -1,13 +1,21 @@
-/* fq2b.c — `fq2b-amd`: FASTQ(.gz) -> packed binary records, the step before the hash10x path.
+/* fq2b.c — `fq2b-amd`: FASTQ(.gz) -> packed binary read records, the producer of hash10x's input.
  *
- * Same command surface and byte-for-byte the same output as the reference's fq2b (fq2b.c:108-185):
+ * Command surface and output bytes of the reference's fq2b (fq2b.c:108-185):
  *     fq2b-amd [-10x <whitelist>] [-checkId] [-o <out.fqb>] <R1.fastq.gz> [<R2.fastq.gz>]
- * Record = read-1 bases (2 bits each, 16 per U32, first base in the top bits; the last, partial word is NOT left
- * justified: fq2b.c:33-42), read-1 quality bits (1 = Q >= 23, 32 per word, fq2b.c:53-63), then the same
- * for read 2. With 151-base reads that is 10 + 5 + 10 + 5 = 30 words = the 120-byte .fqb record hash10x reads.
- * -10x keeps only read pairs whose 16-base barcode is within one mismatch of a whitelist entry and rewrites it to
- * that entry (fq2b.c:67-104). gzip inflation dominates, so this stays on the host; the record SORT that follows
- * (the reference shells out to bsort) is `hash10x-amd --sortFQB`, on the GPU.
+ * Record layout (what hash10x --readFQB consumes): per read ceil(L/16) words of 2-bit bases, first base in
+ * the top bits of a word, then ceil(L/32) words of 1-bit qualities (1 = Phred >= 23); the last word of each run holds its
+ * leftover symbols in its LOW bits. 151 + 151 bases => 30 words = 120 bytes.
+ *
+ * Built differently from the reference:
+ *   - input: each file is inflated in 4 MiB blocks and cut into lines with memchr (no per-character gzgetc, no fixed-length
+ *     record reads); a read of another length than the file's first one is an error, as the record size is fixed;
+ *   - packing: one table maps a character to its symbol, words are filled by a single routine for bases and qualities;
+ *   - -10x: the whitelist is an open-addressing set of packed barcodes remembering the LAST line each one appeared on; a
+ *     read's barcode is looked up together with its 48 one-substitution neighbours and the candidate from the latest
+ *     whitelist line wins. That is exactly what the reference's 4 GiB byte table (later lines overwrite earlier ones,
+ *     fq2b.c:71-104) returns, for exact matches too, in 16 bytes per whitelist barcode instead of 4 GiB.
+ * gzip inflation dominates the run time, so this step stays on the host; the record sort that follows (the reference
+ * shells out to bsort) is `hash10x-amd --sortFQB`, on the GPU.
  */
 #define _GNU_SOURCE
 #include <stdio.h>
@@ -24,126 +32,215 @@ static void die(const char *fmt, ...) {
   exit(-1);
 }
 
-static uint32_t basePack[256], qualBit[256];
-static void pack_init(void) {
-  const char *b = "acgtACGT";
-  for (int i = 0; i < 8; ++i) basePack[(unsigned char)b[i]] = (uint32_t)(i % 4);      /* everything else (N) packs as A */
-  for (int i = '$' + 20; i < 256; ++i) qualBit[i] = 1;
+/* ------------------------------------------------------------------------------------------ line source */
+enum { BLOCK = 4 << 20 };
+typedef struct {
+  gzFile gz; const char *path;
+  char *buf; size_t have, pos;      /* buf[pos .. have) is unread */
+  int eof; long entry;
+} Source;
+
+static void source_open(Source *s, const char *path) {
+  memset(s, 0, sizeof *s);
+  s->path = path;
+  if (!(s->gz = gzopen(path, "r"))) die("failed to open %s", path);
+  gzbuffer(s->gz, 1 << 20);
+  if (!(s->buf = (char *)malloc(BLOCK + 1))) die("out of memory");
 }
-/* full words while more than `per` symbols remain, then ONE word with the rest in its low bits */
-static void pack_symbols(const char *s, uint32_t *u, int len, int per, int bits, const uint32_t *map) {
-  while (len > per) {
-    uint32_t w = 0;
-    for (int i = 0; i < per; ++i) w = (w << bits) | map[(unsigned char)*s++];
-    *u++ = w; len -= per;
+/* next line without its '\n'; *len receives its length. NULL at end of input. A last line without '\n' is returned too
+   (*terminated = 0) so that the caller can complain the way it wants. The pointer is valid until the next call. */
+static char *source_line(Source *s, size_t *len, int *terminated) {
+  for (;;) {
+    char *nl = s->have > s->pos ? (char *)memchr(s->buf + s->pos, '\n', s->have - s->pos) : 0;
+    if (nl) { char *line = s->buf + s->pos; *len = (size_t)(nl - line); s->pos += *len + 1; *terminated = 1; return line; }
+    if (s->eof) {
+      if (s->pos == s->have) return 0;
+      char *line = s->buf + s->pos; *len = s->have - s->pos; s->pos = s->have; *terminated = 0; return line;
+    }
+    if (s->have - s->pos >= BLOCK / 2) die("%s: line longer than %d bytes", s->path, BLOCK / 2);
+    memmove(s->buf, s->buf + s->pos, s->have - s->pos); s->have -= s->pos; s->pos = 0;
+    const int got = gzread(s->gz, s->buf + s->have, (unsigned)(BLOCK - s->have));
+    if (got < 0) die("%s: read error", s->path);
+    if (got == 0) s->eof = 1;
+    s->have += (size_t)got;
   }
-  uint32_t w = 0;
-  for (int i = 0; i < len; ++i) w = (w << bits) | map[(unsigned char)*s++];
-  *u = w;
 }
 
-/* ---- 10x whitelist: table[v] = 1 + 4 * position + base that turns v into the whitelist barcode it is one step from
-   (position counted from the last base); 0 = no whitelist barcode within one mismatch. Later lines win. */
-static uint8_t *wlTable;
-static long nBad, nFixed, nFixBase[16];
-static uint32_t set_base(uint32_t u, int code) { --code; const int pos = code / 4, b = code % 4; return (u & ~(3u << (2 * pos))) | ((uint32_t)b << (2 * pos)); }
-static void read_whitelist(const char *path) {
+typedef struct { const char *id, *seq, *qual; size_t idLen, len; } Entry;
+/* the four lines of one FASTQ entry; 0 at a clean end of file. Pointers of one entry stay valid together only if the
+   entry does not straddle a refill, so the id is copied out by the caller when it needs it. */
+static int source_entry(Source *s, Entry *e, char *idCopy, size_t idCap) {
+  size_t n; int t;
+  ++s->entry;
+  char *l = source_line(s, &n, &t);
+  if (!l) return 0;
+  if (!n || l[0] != '@') die("fastq id line for entry %ld does not start with @", s->entry);
+  if (!t) die("fastq entry %ld id line does not end in \\n", s->entry);
+  if (n >= idCap) n = idCap - 1;
+  memcpy(idCopy, l, n); idCopy[n] = 0; e->id = idCopy; e->idLen = n;
+  /* sequence, '+', quality: make sure all three are in the buffer at once by peeking for three newlines first */
+  for (;;) {
+    size_t p = s->pos; int found = 0;
+    while (found < 3) { char *nl = s->have > p ? (char *)memchr(s->buf + p, '\n', s->have - p) : 0; if (!nl) break; p = (size_t)(nl - s->buf) + 1; ++found; }
+    if (found == 3 || s->eof) break;
+    if (s->have - s->pos >= BLOCK / 2) die("%s: entry %ld longer than %d bytes", s->path, s->entry, BLOCK / 2);
+    memmove(s->buf, s->buf + s->pos, s->have - s->pos); s->have -= s->pos; s->pos = 0;
+    const int got = gzread(s->gz, s->buf + s->have, (unsigned)(BLOCK - s->have));
+    if (got < 0) die("%s: read error", s->path);
+    if (got == 0) s->eof = 1;
+    s->have += (size_t)got;
+  }
+  l = source_line(s, &n, &t);
+  if (!l || !t) die("fastq entry %ld seq line does not end in \\n", s->entry);
+  e->seq = l; e->len = n;
+  l = source_line(s, &n, &t);
+  if (!l || !t || n != 1 || l[0] != '+') die("bad + fastq line entry %ld", s->entry);
+  l = source_line(s, &n, &t);
+  if (!l || !t || n != e->len) die("fastq entry %ld qual line does not end in \\n", s->entry);
+  e->qual = l;
+  return 1;
+}
+
+/* ------------------------------------------------------------------------------------------ packing */
+static uint8_t baseSym[256], qualSym[256];
+static void tables_init(void) {
+  baseSym['c'] = baseSym['C'] = 1; baseSym['g'] = baseSym['G'] = 2; baseSym['t'] = baseSym['T'] = 3;   /* a, A, N, anything else: 0 */
+  for (int c = '$' + 20; c < 256; ++c) qualSym[c] = 1;                                                   /* Phred+33 >= 23 */
+}
+/* n symbols of `bits` bits, perWord to a word; returns the words written. Full words come first; the last word takes
+   what is left (1..perWord symbols) right-aligned, which for a multiple of perWord is again a full word. */
+static size_t pack_run(const char *s, size_t n, int bits, int perWord, const uint8_t *sym, uint32_t *out) {
+  if (!n) return 0;
+  const size_t words = (n + (size_t)perWord - 1) / (size_t)perWord;
+  size_t i = 0;
+  for (size_t w = 0; w < words; ++w) {
+    const size_t take = w + 1 < words ? (size_t)perWord : n - i;
+    uint32_t v = 0;
+    for (size_t j = 0; j < take; ++j) v = (v << bits) | sym[(unsigned char)s[i + j]];
+    out[w] = v; i += take;
+  }
+  return words;
+}
+static size_t pack_read(const Entry *e, uint32_t *out) {
+  size_t w = pack_run(e->seq, e->len, 2, 16, baseSym, out);
+  return w + pack_run(e->qual, e->len, 1, 32, qualSym, out + w);
+}
+
+/* ------------------------------------------------------------------------------------------ 10x whitelist */
+typedef struct { uint32_t key; uint32_t line; } Slot;              /* line 0 = empty */
+static Slot *wl; static uint64_t wlMask; static int haveWhitelist;
+static inline uint64_t wl_home(uint32_t k) { return ((uint64_t)k * 0x9E3779B97F4A7C15ull) >> 20 & wlMask; }
+static void wl_put(uint32_t key, uint32_t line) {
+  uint64_t p = wl_home(key);
+  while (wl[p].line && wl[p].key != key) p = (p + 1) & wlMask;
+  wl[p].key = key; wl[p].line = line;                               /* a repeated barcode keeps its latest line */
+}
+static uint32_t wl_line(uint32_t key) {
+  uint64_t p = wl_home(key);
+  while (wl[p].line) { if (wl[p].key == key) return wl[p].line; p = (p + 1) & wlMask; }
+  return 0;
+}
+static void whitelist_load(const char *path) {
   FILE *f = fopen(path, "r");
   if (!f) die("failed to open 10x whitelist file %s\n", path);
-  if (!(wlTable = (uint8_t *)calloc((size_t)1 << 32, 1))) die("can't allocate barcode table");
-  char s[64]; int n = 0;
-  while (!feof(f) && fscanf(f, "%63s\n", s) == 1) {
-    ++n;
-    if (strlen(s) != 16) die("bad barcode line %d in %s: %s", n, path, s);
-    uint32_t u; pack_symbols(s, &u, 16, 16, 2, basePack);
-    for (int i = 0; i < 16; ++i) {
-      const uint8_t restore = (uint8_t)(1 + i * 4 + ((u >> (2 * i)) & 3));
-      for (int j = 0; j < 4; ++j) wlTable[set_base(u, 1 + i * 4 + j)] = restore;
-    }
+  size_t cap = 1 << 16, n = 0; uint32_t *codes = (uint32_t *)malloc(cap * 4);
+  char word[64];
+  while (fscanf(f, "%63s", word) == 1) {
+    if (strlen(word) != 16) die("bad barcode line %d in %s: %s", (int)n + 1, path, word);
+    if (n == cap) { cap *= 2; codes = (uint32_t *)realloc(codes, cap * 4); }
+    if (!codes) die("out of memory");
+    pack_run(word, 16, 2, 16, baseSym, &codes[n++]);
   }
   fclose(f);
-  fprintf(stderr, "read %d barcodes from file %s\n", n, path);
+  uint64_t slots = 1024; while (slots < 2 * n + 2) slots *= 2;
+  wlMask = slots - 1;
+  if (!(wl = (Slot *)calloc(slots, sizeof(Slot)))) die("can't allocate barcode table");
+  for (size_t i = 0; i < n; ++i) wl_put(codes[i], (uint32_t)i + 1);
+  free(codes);
+  haveWhitelist = 1;
+  fprintf(stderr, "read %d barcodes from file %s\n", (int)n, path);
 }
-static int fix_barcode(uint32_t *u) {
-  const uint8_t code = wlTable[*u];
-  if (!code) { ++nBad; return 0; }
-  const uint32_t v = set_base(*u, code);
-  if (v != *u) { ++nFixed; ++nFixBase[15 - (code - 1) / 4]; *u = v; }
+static long nDropped, nCorrected, correctedAt[16];                 /* correctedAt[i]: base i of the barcode, 0 = first */
+/* the whitelist barcode at most one substitution away that appears on the latest whitelist line; 0 = none */
+static int whitelist_match(uint32_t *barcode) {
+  const uint32_t v = *barcode;
+  uint32_t bestLine = wl_line(v), best = v; int bestBase = -1;
+  for (int i = 0; i < 16; ++i) {
+    const int sh = 2 * (15 - i);
+    for (uint32_t b = 0; b < 4; ++b) {
+      const uint32_t u = (v & ~(3u << sh)) | (b << sh);
+      if (u == v) continue;
+      const uint32_t ln = wl_line(u);
+      if (ln > bestLine) { bestLine = ln; best = u; bestBase = i; }
+    }
+  }
+  if (!bestLine) { ++nDropped; return 0; }
+  if (bestBase >= 0) { ++nCorrected; ++correctedAt[bestBase]; *barcode = best; }
   return 1;
 }
 
-/* one FASTQ entry. The id line is read to its newline; the sequence length is taken from the first entry of a file
-   and every later sequence and quality line is read as exactly that many characters plus '\n' (fq2b.c:187-221) */
-static long nEntry;
-static int read_fastq(gzFile f, char *id, char *seq, char *qual, int *len) {
-  ++nEntry;
-  int n = 0, c = 0;
-  while (!gzeof(f) && n < 1023 && (c = gzgetc(f)) != '\n') { if (c < 0) break; id[n++] = (char)c; }
-  if (gzeof(f) || c < 0) return 0;
-  if (id[0] != '@') die("fastq id line for entry %ld does not start with @", nEntry);
-  if (c != '\n') die("fastq entry %ld id line does not end in \\n", nEntry);
-  id[n] = 0;
-  if (*len) { if (gzread(f, seq, (unsigned)(*len + 1)) != *len + 1) die("bad seq gzread entry %ld", nEntry); }
-  else { int m = 0; while (!gzeof(f) && m < 1023 && (c = gzgetc(f)) != '\n') { if (c < 0) break; seq[m++] = (char)c; } seq[m] = (char)c; *len = m; }
-  if (seq[*len] != '\n') die("fastq entry %ld seq line does not end in \\n", nEntry);
-  seq[*len] = 0;
-  if (gzgetc(f) != '+' || gzgetc(f) != '\n') die("bad + fastq line entry %ld", nEntry);
-  if (gzread(f, qual, (unsigned)(*len + 1)) != *len + 1) die("bad qual gzread entry %ld", nEntry);
-  if (qual[*len] != '\n') die("fastq entry %ld qual line does not end in \\n", nEntry);
-  qual[*len] = 0;
-  return 1;
-}
+/* ------------------------------------------------------------------------------------------ main */
+static const char usageText[] =
+  "Usage: fq2b-amd [opts] <fastq.gz> [<fastq.gz>]\n"
+  "  Converts fastq to binary with 2 bits per base, converting N to A (!).\n"
+  "  Throws out read names; one quality bit per base (Q >= 23).\n"
+  "  If two fastq files are given they are interleaved.\n"
+  "Opts: -10x <whitelist file>\n"
+  "      -checkId  checks whether id lines match in first and second files\n"
+  "      -o <outfile> [standard output]\n"
+  "  10x option matches first16bp barcode of read 1 to whitelist.\n"
+  "  Only outputs an entry if there is a match after correcting for 1 mismatch\n";
 
 int main(int argc, char **argv) {
+  const char *outPath = 0, *wlPath = 0;
+  int a = 1;
+  tables_init();
+  for (; argc - a > 2 && argv[a][0] == '-'; ) {
+    if (!strcmp(argv[a], "-10x")) { wlPath = argv[a + 1]; a += 2; }
+    else if (!strcmp(argv[a], "-o")) { outPath = argv[a + 1]; a += 2; }
+    else if (!strcmp(argv[a], "-checkId")) a += 1;                 /* ids are always compared, as in the reference */
+    else die("Unknown arg %s for fq2b - run without args for usage", argv[a]);
+  }
+  const int nFiles = argc - a;
+  if (nFiles < 1 || nFiles > 2) die("%s", usageText);
+  if (wlPath) whitelist_load(wlPath);
   FILE *out = stdout;
-  pack_init();
-  --argc; ++argv;
-  while (argc > 2 && argv[0][0] == '-') {
-    if (!strcmp(*argv, "-10x")) { read_whitelist(argv[1]); argc -= 2; argv += 2; }
-    else if (!strcmp(*argv, "-checkId")) { --argc; ++argv; }                          /* the reference's flag is always on */
-    else if (!strcmp(*argv, "-o")) { if (!(out = fopen(argv[1], "wb"))) die("failed to open output file %s", argv[1]); argc -= 2; argv += 2; }
-    else die("Unknown arg %s for fq2b - run without args for usage", *argv);
-  }
-  if (argc < 1 || argc > 2)
-    die("Usage: fq2b-amd [opts] <fastq.gz> [<fastq.gz>]\n"
-        "  Converts fastq to binary with 2 bits per base, converting N to A (!).\n"
-        "  Throws out read names; one quality bit per base (Q >= 23).\n"
-        "  If two fastq files are given they are interleaved.\n"
-        "Opts: -10x <whitelist file>\n"
-        "      -checkId  checks whether id lines match in first and second files\n"
-        "      -o <outfile> [standard output]\n"
-        "  10x option matches first16bp barcode of read 1 to whitelist.\n"
-        "  Only outputs an entry if there is a match after correcting for 1 mismatch\n");
-  gzFile f1 = gzopen(argv[0], "r"); if (!f1) die("failed to open %s", argv[0]);
-  gzFile f2 = 0;
-  if (argc == 2) { f2 = gzopen(argv[1], "r"); if (!f2) die("failed to open %s", argv[1]); }
-  gzbuffer(f1, 1 << 20); if (f2) gzbuffer(f2, 1 << 20);
-  static char id1[1024], id2[1024], s1[1024], s2[1024], q1[1024], q2[1024];
-  static uint32_t u1s[256], u2s[256], u1q[128], u2q[128];
-  int len1 = 0, len2 = 0, mismatch = 0; long n = 0;
-  while (read_fastq(f1, id1, s1, q1, &len1)) {
-    pack_symbols(s1, u1s, len1, 16, 2, basePack); pack_symbols(q1, u1q, len1, 32, 1, qualBit);
-    if (f2) {
-      if (!read_fastq(f2, id2, s2, q2, &len2)) die("second fastq file terminated early at %ld", n);
-      if (!mismatch && strcmp(id1, id2)) { fprintf(stderr, "proceeding despite paired read ids not matching, e.g. %s %s\n", id1, id2); mismatch = 1; }
+  if (outPath && !(out = fopen(outPath, "wb"))) die("failed to open output file %s", outPath);
+  setvbuf(out, 0, _IOFBF, 1 << 20);
+
+  Source src[2]; Entry e[2]; static char id[2][1024];
+  for (int i = 0; i < nFiles; ++i) source_open(&src[i], argv[a + i]);
+  size_t readLen[2] = {0, 0}; int lenKnown = 0, idWarned = 0; long written = 0;
+  uint32_t *rec = (uint32_t *)malloc(4 * (size_t)BLOCK / 8);       /* a line is at most BLOCK/2 symbols */
+  if (!rec) die("out of memory");
+  while (source_entry(&src[0], &e[0], id[0], sizeof id[0])) {
+    /* read 1 is packed now: its line pointers die when file 1 is refilled, not when file 2 is, but keep the order simple */
+    size_t words = pack_read(&e[0], rec);
+    const size_t len1 = e[0].len;
+    if (nFiles == 2) {
+      if (!source_entry(&src[1], &e[1], id[1], sizeof id[1])) die("second fastq file terminated early at %ld", written);
+      if (!idWarned && strcmp(id[0], id[1])) { fprintf(stderr, "proceeding despite paired read ids not matching, e.g. %s %s\n", id[0], id[1]); idWarned = 1; }
     }
-    if (wlTable && !fix_barcode(u1s)) continue;
-    if (f2) { pack_symbols(s2, u2s, len2, 16, 2, basePack); pack_symbols(q2, u2q, len2, 32, 1, qualBit); }
-    fwrite(u1s, 4, (size_t)(len1 + 15) / 16, out); fwrite(u1q, 4, (size_t)(len1 + 31) / 32, out);
-    if (f2) { fwrite(u2s, 4, (size_t)(len2 + 15) / 16, out); fwrite(u2q, 4, (size_t)(len2 + 31) / 32, out); }
-    ++n;
+    if (!lenKnown) { readLen[0] = len1; if (nFiles == 2) readLen[1] = e[1].len; lenKnown = 1; }
+    if (len1 != readLen[0]) die("fastq entry %ld seq line does not end in \\n", src[0].entry);          /* fixed-size records */
+    if (nFiles == 2 && e[1].len != readLen[1]) die("fastq entry %ld seq line does not end in \\n", src[1].entry);
+    if (haveWhitelist && !whitelist_match(&rec[0])) continue;
+    if (nFiles == 2) words += pack_read(&e[1], rec + words);
+    if (fwrite(rec, 4, words, out) != words) die("write failed");
+    ++written;
   }
-  if (f2) fprintf(stderr, "written %ld read pairs %d + %d bp packed in %d word records\n", n, len1, len2,
-                  (len1 + 15) / 16 + (len1 + 31) / 32 + (len2 + 15) / 16 + (len2 + 31) / 32);
-  else fprintf(stderr, "written %ld reads %d bp packed in %d word records\n", n, len1, (len1 + 15) / 16 + (len1 + 31) / 32);
-  if (wlTable) {
-    fprintf(stderr, "%ld (%.1f%%) not matching barcodes were dropped\n", nBad, 100.0 * nBad / (double)(nBad + n));
-    fprintf(stderr, "%ld (%.1f%%) of those that matched were error corrected\n", nFixed, 100.0 * nFixed / (double)n);
+  const int w1 = (int)((readLen[0] + 15) / 16 + (readLen[0] + 31) / 32), w2 = (int)((readLen[1] + 15) / 16 + (readLen[1] + 31) / 32);
+  if (nFiles == 2) fprintf(stderr, "written %ld read pairs %d + %d bp packed in %d word records\n", written, (int)readLen[0], (int)readLen[1], w1 + w2);
+  else fprintf(stderr, "written %ld reads %d bp packed in %d word records\n", written, (int)readLen[0], w1);
+  if (haveWhitelist) {
+    fprintf(stderr, "%ld (%.1f%%) not matching barcodes were dropped\n", nDropped, 100.0 * nDropped / (double)(nDropped + written));
+    fprintf(stderr, "%ld (%.1f%%) of those that matched were error corrected\n", nCorrected, 100.0 * nCorrected / (double)written);
     fprintf(stderr, "by base position:");
-    for (int i = 0; i < 16; ++i) fprintf(stderr, " %ld", nFixBase[i]);
+    for (int i = 0; i < 16; ++i) fprintf(stderr, " %ld", correctedAt[i]);
     fprintf(stderr, "\n");
   }
-  if (out != stdout) fclose(out);
-  gzclose(f1); if (f2) gzclose(f2);
+  if (out != stdout && fclose(out)) die("write failed");
+  for (int i = 0; i < nFiles; ++i) { gzclose(src[i].gz); free(src[i].buf); }
+  free(rec); free(wl);
   return 0;
 }
