@@ -36,6 +36,16 @@ class _Sizes(ctypes.Structure):
                 ("reserved", ctypes.c_uint32), ("nClusHash", ctypes.c_uint64), ("nRecords", ctypes.c_uint64)]
 
 
+class _ShardInfo(ctypes.Structure):
+    _fields_ = [("rank", ctypes.c_int32), ("nranks", ctypes.c_int32), ("B", ctypes.c_int32), ("hashNumber", ctypes.c_uint32),
+                ("nBlocksGlobal", ctypes.c_uint32), ("nSegs", ctypes.c_uint32), ("nEntriesGlobal", ctypes.c_uint64), ("nRecordsGlobal", ctypes.c_uint64)]
+
+
+class _ShardSeg(ctypes.Structure):
+    _fields_ = [("rank", ctypes.c_uint32), ("localStart", ctypes.c_uint32), ("count", ctypes.c_uint32), ("globalBase", ctypes.c_uint32),
+                ("entries", ctypes.c_uint64), ("localEntryStart", ctypes.c_uint64), ("globalEntryStart", ctypes.c_uint64)]
+
+
 _libs = None
 
 
@@ -74,6 +84,17 @@ def load_native():
     host.h10x_session_shardReadFQB_mem.argtypes = [vp, vp, vp, cu64]
     host.h10x_session_shardReadFQB_dev.argtypes = [vp, vp, vp, cu64]
     host.h10x_session_shardGather.argtypes = [vp]
+    host.h10x_session_shardReadFQB_file.argtypes = [vp, vp, cs, cu64, cu64]
+    host.h10x_host_partition_file.argtypes = [cs, cu64, ci, vp, cs, ci]
+    host.h10x_session_cribBuild.argtypes = [vp, cs, cs, vp, ci]
+    host.h10x_session_clusterReport.argtypes = [vp, ci, ci, vp]
+    host.h10x_session_cribSummary.argtypes = [vp, vp]
+    host.h10x_session_hashStats.argtypes = [vp, vp]
+    host.h10x_session_codeStats.argtypes = [vp, vp]
+    hip.h10x_shard_info.argtypes = [vp, ctypes.POINTER(_ShardInfo)]
+    hip.h10x_shard_segments.argtypes = [vp, vp, ctypes.c_uint32]
+    hip.h10x_export_slice.argtypes = [vp, ci, cu64, cu64, vp]
+    hip.h10x_shard_prepare_export.argtypes = [vp]
     hip.h10x_comm_unique_id.argtypes = [vp]
     hip.h10x_comm_create_rccl.argtypes = [ctypes.POINTER(vp), ci, ci, vp, ci, cs, ci]
     hip.h10x_comm_create_local.argtypes = [ctypes.POINTER(vp), ci]
@@ -254,13 +275,63 @@ class Hash10x:
         """Collective: rank 0 ends up with the whole state (then write_hash there)."""
         self._chk(self._host.h10x_session_shardGather(self._s))
 
+    def shard_read_fqb_file(self, comm, path, first, n, chunk=100000):
+        """Sharded --readFQB from a file: this rank's records [first, first + n), streamed into HBM; the reference's chunk
+        semantics (-c) are applied over the whole file."""
+        self._host.h10x_session_set(self._s, b"c", int(chunk))
+        self._chk(self._host.h10x_session_shardReadFQB_file(self._s, comm.handle, os.fsencode(path), int(first), int(n)))
+        self._after_init()
+
+    def _chk_ctx(self, rc):
+        if rc != 0:
+            raise Hash10xError(self._hip.h10x_last_error(self._ctx()).decode())
+
     def shard_barrier(self):
-        self._hip.h10x_shard_barrier(self._ctx())
+        self._chk_ctx(self._hip.h10x_shard_barrier(self._ctx()))
 
     def shard_allreduce_max(self, value):
         v = ctypes.c_double(value)
-        self._hip.h10x_shard_allreduce_max(self._ctx(), ctypes.byref(v))
+        self._chk_ctx(self._hip.h10x_shard_allreduce_max(self._ctx(), ctypes.byref(v)))
         return v.value
+
+    def shard_info(self):
+        z = _ShardInfo()
+        self._chk_ctx(self._hip.h10x_shard_info(self._ctx(), ctypes.byref(z)))
+        return {n: int(getattr(z, n)) for n, _ in _ShardInfo._fields_}
+
+    def shard_segments(self):
+        n = self.shard_info()["nSegs"]
+        arr = (_ShardSeg * (n + 1))()
+        self._chk_ctx(self._hip.h10x_shard_segments(self._ctx(), arr, n + 1))
+        return [{f: int(getattr(arr[i], f)) for f, _ in _ShardSeg._fields_} for i in range(n)]
+
+    # ---- text commands: `out` = a path (this rank prints there) or None (take part only) ----------------
+    def _with_file(self, out, fn):
+        libc = ctypes.CDLL(None)
+        libc.fopen.restype = ctypes.c_void_p
+        libc.fopen.argtypes = [ctypes.c_char_p, ctypes.c_char_p]
+        libc.fclose.argtypes = [ctypes.c_void_p]
+        f = libc.fopen(os.fsencode(out), b"a") if out else None
+        try:
+            self._chk(fn(ctypes.c_void_p(f) if f else None))
+        finally:
+            if f:
+                libc.fclose(f)
+
+    def crib_build(self, fa1, fa2, out=None, tables=False):
+        self._with_file(out, lambda f: self._host.h10x_session_cribBuild(self._s, os.fsencode(fa1), os.fsencode(fa2), f, 1 if tables else 0))
+
+    def cluster_report(self, code_min, code_max, out=None):
+        self._with_file(out, lambda f: self._host.h10x_session_clusterReport(self._s, int(code_min), int(code_max), f))
+
+    def crib_summary(self, out=None):
+        self._with_file(out, lambda f: self._host.h10x_session_cribSummary(self._s, f))
+
+    def hash_stats(self, out=None):
+        self._with_file(out, lambda f: self._host.h10x_session_hashStats(self._s, f))
+
+    def code_stats(self, out=None):
+        self._with_file(out, lambda f: self._host.h10x_session_codeStats(self._s, f))
 
     def read_hash(self, path):
         self._chk(self._host.h10x_session_readHash(self._s, os.fsencode(path)))

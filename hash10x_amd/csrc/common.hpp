@@ -112,6 +112,22 @@ static const char *const kTimerNames[T_COUNT] = {
 
 struct Timer { hipEvent_t a = nullptr, b = nullptr; double ms = 0; uint64_t launches = 0; bool pending = false; };
 
+// ---- local block number -> global block number ------------------------------------------------------
+// An unsharded context numbers its blocks as the reference does (one segment, identity). A shard owns a contiguous range
+// of the file's barcodes (segment 0: local l = global codeBase + l, slot 0 unused), and every --clusterSplit appends, per
+// segment that held parents, one segment for the blocks it created: the reference numbers those after ALL existing
+// blocks, in the order of their parents (hash10x.c:961-1003), so in a sharded run they sit behind the blocks of every rank.
+constexpr int MAX_SEGS = 8;
+struct BlockSeg { u32 localStart, count, globalBase; };     // global = globalBase + (l - localStart)
+struct SegMap {
+  int n; BlockSeg s[MAX_SEGS];
+  __host__ __device__ u32 globalOf(u32 l) const {
+    for (int k = n - 1; k > 0; --k) if (l >= s[k].localStart) return s[k].globalBase + (l - s[k].localStart);
+    return s[0].globalBase + l;
+  }
+};
+struct ShardSegInfo { u32 rank, localStart, count, globalBase; u64 entries; };   // one segment of one rank (allgathered: shard.hip)
+
 // ---- the context ------------------------------------------------------------------------------------
 struct Ctx {
   h10x_params prm{};
@@ -161,6 +177,11 @@ struct Ctx {
   // as hash owner, the barcode lists of the hashes in its hash range (shard.hip)
   struct Comm *comm = nullptr; bool sharded = false;
   u32 codeBase = 0, nBlocksGlobal = 0;
+  SegMap segs{1, {{0, 0, 0}}};                               // this context's blocks in global numbering (identity when unsharded)
+  std::vector<ShardSegInfo> allSegs;                         // sharded: every rank's segments, ascending globalBase = file order
+  u64 nEntriesGlobal = 0, nRecordsGlobal = 0;                // sharded: whole data set
+  int rowShift = 0;                                          // rows[]: lists start at multiples of 2^rowShift entries, rowStart[] in entries (shard.hip: > 2^32 list entries)
+  bool ownerListsStale = false;                              // sharded: oRows predates a --clusterSplit
   DevBuf<u32> oRows, oSegStart, oIndex; u32 oU = 0; u64 oM = 0;
   DevBuf<u64> oHash;          // this owner's distinct hashes (by oIndex) until the global tables are built
   bool tablesPending = false; // sharded: hashValue[] / hashIndex[] not built yet (shard_materializeTables, collective)
@@ -174,6 +195,11 @@ struct Ctx {
   int64_t optBigRanks = 0;    // tuning knob: rank count above which a barcode goes to the front of the main work queue (0 = 1.5 x the mean)
   int64_t optDbgSkip = 0;     // diagnostic: what-if timing of cluster_kernel with phases switched off (results wrong)
   int64_t optStamps = 0;      // diagnostic: per-phase wall-clock stamps in cluster_kernel
+  int64_t optChunk = 0;       // -c <chunkSize> of the reference's readFQB loop (hash10x.c:202-223): 0 = no chunk semantics (no "chunkSize too small", no
+                              // all-A-barcode quirk); set by the session layer for --readFQB
+  std::vector<u64> mergePoints; bool replayDone = false;     // records whose barcode change does NOT start a block (chunk replay; consumed by stageA_run)
+  int64_t optRowShift = -1;   // testing knob: force the list alignment of the sharded rows[] (-1 = as small as the offsets allow)
+  int64_t optRowsFakeBase = 0; // testing knob: list offsets start at this many entries (multiple of 2^rowShift) in front of the real array: 64-bit offsets on small inputs
   bool timing = false;
   u32 *startFlags = nullptr;   // pinned host words a side-stream kernel's workgroups set when they start (stageC_cluster)
   Timer timers[T_COUNT];
@@ -263,7 +289,12 @@ __device__ __forceinline__ u32 probe_find(const u32 *__restrict__ table, const u
 // stage entry points (one per translation unit)
 int stageA_run(Ctx *c, const u32 *dRecords, u64 nRecords,
                DevBuf<u64> &entHash, DevBuf<u32> &entCode, DevBuf<u32> &entRead, bool hashLast = false, bool emptyIsNoBlock = false);
-int stageA_sortRecords(Ctx *c, const u32 *dIn, u64 nRecords, u32 *dOut);   // stable sort of .fqb records by their first 4 bytes
+int stageA_sortRecords(Ctx *c, const u32 *dIn, u64 nRecords, u32 *dOut);
+// barcode runs of a record image: starts[r] = first record of run r (r = 0 .. R-1), starts[R] = nRecords; zeroRuns = runs whose barcode word is 0
+int stageA_runStarts(Ctx *c, const u32 *dRec, u64 nRec, std::vector<u64> &starts, std::vector<u32> &zeroRuns);
+// the reference's chunk loop replayed over the runs of the whole file: 1 = "chunkSize too small"; merges = records (file positions) that
+// start a run but not a block (an all-A barcode's run ended exactly at a chunk boundary: hash10x.c:212)
+int replayChunks(const std::vector<u64> &starts, const std::vector<u32> &zeroRuns, u64 chunk, std::vector<u64> &merges);   // stable sort of .fqb records by their first 4 bytes
 int stageB_run(Ctx *c, DevBuf<u64> &entHash, DevBuf<u32> &entCode, DevBuf<u32> &entRead);
 int stageB_buildCSR(Ctx *c);                   // rows/rowStart from clusHash + hashDepth (fillHashTable)
 int stageB_finishClusHash(Ctx *c, DevBuf<u64> &key);   // key[e] = index << 32 | read16 in block order -> clusHash sorted per block
@@ -273,7 +304,15 @@ int stageC_cluster(Ctx *c, int codeMin, int codeMax, int threshold);
 int stageC_split(Ctx *c);
 int stageD_cribGenome(Ctx *c, const u8 *hostCodes, const u64 *seqStart, u32 nSeq, int which, u64 *nPresent, u64 *nAbsent);
 int stageD_cribFinish(Ctx *c);
+int stageE_histMax(Ctx *c, int which, u64 first, u64 count, u32 *maxValue);
+int stageE_histogram(Ctx *c, int which, u64 first, u64 count, u32 bins, u64 *hist);
+int stageE_clusterReport(Ctx *c, u32 firstBlock, u32 nBlk, h10x_block_rep *hostB, h10x_cluster_rep *hostC, u64 clusterCap, u64 *nClusters);
+int stageE_cribSummary(Ctx *c, u64 *counts12, u32 *hostSeenBase, u32 *hostSeenCluster);
+int shard_allreduceU64(Ctx *c, u64 *v, u32 n, int op);
+int shard_gatherBytes(Ctx *c, const void *send, u64 nbytes, void *recv, u64 cap, u64 *counts);
 int shard_exchangeRows(Ctx *c);
+int shard_split(Ctx *c, const u32 *dSubBefore, u32 totalSubLocal);   // collective part of a sharded --clusterSplit: new segments, layout, owner lists
+int shard_refreshLayout(Ctx *c);                // collective: allSegs / global totals from every rank's current segments
 int shard_materializeTables(Ctx *c);            // collective: hashValue[] + hashIndex[] on every rank (deferred by the sharded --readFQB)                 // sharded --hashDepthRange: allgather the in-range barcode lists
 
 }  // namespace h10x

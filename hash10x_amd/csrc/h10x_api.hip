@@ -98,6 +98,7 @@ static void reset_state(Ctx &c) {
   c.hashNumber = 1; c.nBlocks = 0; c.nEntries = 0; c.nRecords = 0;
   c.sharded = false; c.codeBase = 0; c.nBlocksGlobal = 0; c.oRows.release(); c.oSegStart.release(); c.oIndex.release(); c.oU = 0; c.oM = 0;
   c.oHash.release(); c.tablesPending = false;
+  c.segs.n = 1; c.segs.s[0] = BlockSeg{0, 0, 0}; c.allSegs.clear(); c.nEntriesGlobal = c.nRecordsGlobal = 0; c.rowShift = 0; c.ownerListsStale = false;
   memset(&c.ctr, 0, sizeof c.ctr);
   c.haveCrib = false; c.cribGenomes = 0; c.cribChr.release(); c.cribPos.release(); c.cribType.release(); c.cribHist.release();
   for (int g = 0; g < 2; ++g) { c.cribCount[g].release(); c.cribFirst[g].release(); }
@@ -113,6 +114,7 @@ int h10x_read_fqb_device(h10x_ctx *h, const uint32_t *dRec, uint64_t n) {
   timespec t0, t1, t2; clock_gettime(CLOCK_MONOTONIC, &t0);
   DevBuf<u64> entHash; DevBuf<u32> entCode, entRead;
   H10X_TRY(stageA_run(&c, dRec, n, entHash, entCode, entRead));
+  c.segs.n = 1; c.segs.s[0] = BlockSeg{0, c.nBlocks, 0};
   clock_gettime(CLOCK_MONOTONIC, &t1);
   H10X_TRY(stageB_run(&c, entHash, entCode, entRead));
   clock_gettime(CLOCK_MONOTONIC, &t2);
@@ -136,6 +138,28 @@ int h10x_read_fqb(h10x_ctx *h, const uint32_t *hostRec, uint64_t n) {
 __global__ void block_offsets_kernel(const h10x_block *__restrict__ blocks, u32 nBlocks, u32 *__restrict__ nHash) {
   const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i <= nBlocks) nHash[i] = (i >= 1 && i < nBlocks) ? blocks[i].nHash : 0;   // block 0 owns no clusHash (hash10x.c:256)
+}
+
+// --readHash takes the file at its word: before the tables are used as indices, look for values that would send a kernel
+// out of bounds (a truncated, padded or hand-made file). bad[0..3]: hash index of an entry / table slot beyond hashNumber,
+// more than 255 sub-clusters in a block, a label beyond its block's count.
+__global__ void validate_entries_kernel(const h10x_clushash *__restrict__ ch, const u64 *__restrict__ blockOff, const h10x_block *__restrict__ blocks, u32 nBlocks,
+                                        u32 hashNumber, u32 *__restrict__ bad) {
+  for (u32 b = blockIdx.x + 1; b < nBlocks; b += gridDim.x) {
+    const u64 e0 = blockOff[b], e1 = blockOff[b + 1]; const u32 nSub = blocks[b].nSubCluster;
+    if (threadIdx.x == 0 && nSub > 255) atomicAdd(&bad[2], 1u);
+    for (u64 e = e0 + threadIdx.x; e < e1; e += blockDim.x) {
+      const h10x_clushash x = ch[e];
+      if (x.hash >= hashNumber) atomicAdd(&bad[0], 1u);
+      if (x.subCluster > nSub) atomicAdd(&bad[3], 1u);
+    }
+  }
+}
+__global__ void validate_table_kernel(const u32 *__restrict__ table, u64 n, u32 hashNumber, u32 *__restrict__ bad) {
+  u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; const u64 stride = (u64)gridDim.x * blockDim.x;
+  u32 mine = 0;
+  for (; i < n; i += stride) if (table[i] >= hashNumber) ++mine;
+  if (mine) atomicAdd(&bad[1], mine);
 }
 
 }  // extern "C"
@@ -169,7 +193,18 @@ int h10x_load_state(h10x_ctx *h, const uint32_t *hashIndex, uint32_t hashNumber,
   PrimTemp pt; DevBuf<u32> nh; H10X_HIP(&c, nh.alloc((size_t)nBlocks + 1));
   block_offsets_kernel<<<divUp((u64)nBlocks + 1, 256), 256, 0, st>>>(c.blocks.p, nBlocks, nh.p);
   H10X_TRY(prim_exclusive_scan_u32_u64(&c, pt, nh.p, c.blockOff.p, (size_t)nBlocks + 1));
-  H10X_HIP(&c, hipStreamSynchronize(st));
+  {
+    DevBuf<u32> bad; H10X_HIP(&c, bad.alloc(4)); H10X_HIP(&c, hipMemsetAsync(bad.p, 0, 16, st));
+    if (H) validate_entries_kernel<<<hmin<u32>(nBlocks, 8192), 256, 0, st>>>(c.clusHash.p, c.blockOff.p, c.blocks.p, nBlocks, hashNumber, bad.p);
+    validate_table_kernel<<<(unsigned)hmin<u64>(divUp(tableSize, 256), 8192), 256, 0, st>>>(c.hashIndex.p, tableSize, hashNumber, bad.p);
+    u32 hb[4];
+    H10X_TRY(c.readback(hb, bad.p, 16));
+    H10X_TRY(c.syncReadbacks());
+    if (hb[0] || hb[1]) return c.fail("corrupt hash file: %u clusHash entries and %u hashIndex slots point beyond hashNumber %u", hb[0], hb[1], hashNumber);
+    if (hb[2]) return c.fail("corrupt hash file: %u blocks with more than 255 sub-clusters", hb[2]);
+    // (a label above its block's nSubCluster is what re-clustering a clustered file can leave behind in the reference too: tolerated, see DESIGN)
+  }
+  c.segs.n = 1; c.segs.s[0] = BlockSeg{0, nBlocks, 0};
   H10X_TRY(stageB_buildCSR(&c));                              // fillHashTable (hash10x.c:1210)
   c.ctr.entries = H; c.ctr.distinct = hashNumber - 1;
   c.haveState = true;
@@ -266,6 +301,24 @@ int h10x_shard_gather(h10x_ctx *h) { if (!h) return -1; H10X_TRY(enter(h->c)); i
 int h10x_shard_barrier(h10x_ctx *h) { if (!h) return -1; H10X_TRY(enter(h->c)); if (!h->c.comm) return 0; return h->c.comm->barrier(&h->c); }
 int h10x_shard_allreduce_max(h10x_ctx *h, double *v) { if (!h || !v) return -1; H10X_TRY(enter(h->c)); if (!h->c.comm) return 0; return h->c.comm->allreduceMaxHost(&h->c, v); }
 
+int h10x_shard_allreduce_sum_u64(h10x_ctx *h, uint64_t *v, uint32_t n) { if (!h || !v) return -1; H10X_TRY(enter(h->c)); return shard_allreduceU64(&h->c, (u64 *)v, n, 0); }
+int h10x_shard_allreduce_max_u64(h10x_ctx *h, uint64_t *v, uint32_t n) { if (!h || !v) return -1; H10X_TRY(enter(h->c)); return shard_allreduceU64(&h->c, (u64 *)v, n, 1); }
+int h10x_shard_gather_bytes(h10x_ctx *h, const void *send, uint64_t nbytes, void *recv, uint64_t cap, uint64_t *counts) {
+  if (!h) return -1; H10X_TRY(enter(h->c)); return shard_gatherBytes(&h->c, send, nbytes, recv, cap, (u64 *)counts);
+}
+int h10x_report_max(h10x_ctx *h, int which, uint64_t first, uint64_t count, uint32_t *maxValue) {
+  if (!h || !maxValue) return -1; H10X_TRY(enter(h->c)); return stageE_histMax(&h->c, which, first, count, maxValue);
+}
+int h10x_report_histogram(h10x_ctx *h, int which, uint64_t first, uint64_t count, uint32_t bins, uint64_t *hist) {
+  if (!h || !hist || !bins) return -1; H10X_TRY(enter(h->c)); return stageE_histogram(&h->c, which, first, count, bins, (u64 *)hist);
+}
+int h10x_cluster_report(h10x_ctx *h, uint32_t firstBlock, uint32_t nBlocks, h10x_block_rep *blocks, h10x_cluster_rep *clusters, uint64_t clusterCap, uint64_t *nClusters) {
+  if (!h || (nBlocks && !blocks)) return -1; H10X_TRY(enter(h->c)); return stageE_clusterReport(&h->c, firstBlock, nBlocks, blocks, clusters, clusterCap, (u64 *)nClusters);
+}
+int h10x_crib_summary(h10x_ctx *h, uint64_t counts[12], uint32_t *seenBase, uint32_t *seenCluster) {
+  if (!h || !counts || !seenBase || !seenCluster) return -1; H10X_TRY(enter(h->c)); return stageE_cribSummary(&h->c, (u64 *)counts, seenBase, seenCluster);
+}
+
 int h10x_timing_enable(h10x_ctx *h, int on) { if (!h) return -1; h->c.timing = on != 0; return 0; }
 int h10x_timing_count(const h10x_ctx *) { return T_COUNT; }
 const char *h10x_timing_name(const h10x_ctx *, int i) { return (i >= 0 && i < T_COUNT) ? kTimerNames[i] : ""; }
@@ -338,6 +391,69 @@ int h10x_export_ngood(h10x_ctx *h, uint32_t *nGood) {
 
 int h10x_get_counters(h10x_ctx *h, h10x_counters *out) { if (!h || !out) return -1; *out = h->c.ctr; return 0; }
 
+// ---- sharded contexts: where the blocks are, and copy-out by slices (no gather) ----
+int h10x_shard_info(h10x_ctx *h, h10x_shard_info_t *out) {
+  if (!h || !out) return -1;
+  Ctx &c = h->c;
+  if (!c.haveState) return c.fail("no hash state loaded: use readFQB or readHash first");
+  memset(out, 0, sizeof *out);
+  out->rank = c.sharded ? c.comm->rank : 0; out->nranks = c.sharded ? c.comm->n : 1;
+  out->hashNumber = c.hashNumber; out->B = c.prm.B;
+  if (c.sharded) { out->nBlocksGlobal = c.nBlocksGlobal; out->nEntriesGlobal = c.nEntriesGlobal; out->nRecordsGlobal = c.nRecordsGlobal; out->nSegs = (uint32_t)c.allSegs.size(); }
+  else { out->nBlocksGlobal = c.nBlocks; out->nEntriesGlobal = c.nEntries; out->nRecordsGlobal = c.nRecords; out->nSegs = c.nBlocks > 1 ? 1 : 0; }
+  return 0;
+}
+int h10x_shard_segments(h10x_ctx *h, h10x_shard_seg *out, uint32_t cap) {
+  if (!h || !out) return -1;
+  Ctx &c = h->c; H10X_TRY(enter(c));
+  if (!c.haveState) return c.fail("no hash state loaded: use readFQB or readHash first");
+  if (!c.sharded) {
+    if (c.nBlocks <= 1) return 0;
+    if (cap < 1) return c.fail("h10x_shard_segments: room for %u segments, 1 needed", cap);
+    out[0] = h10x_shard_seg{0, 1, c.nBlocks - 1, 1, c.nEntries, 0, 0};
+    return 0;
+  }
+  if (cap < c.allSegs.size()) return c.fail("h10x_shard_segments: room for %u segments, %zu needed", cap, c.allSegs.size());
+  u64 g = 0;
+  for (size_t i = 0; i < c.allSegs.size(); ++i) {
+    const ShardSegInfo &s = c.allSegs[i];
+    u64 local = 0;                                           // where the segment's entries start in this rank's clusHash (own segments only)
+    if ((int)s.rank == c.comm->rank) H10X_HIP(&c, hipMemcpy(&local, c.blockOff.p + s.localStart, 8, hipMemcpyDeviceToHost));
+    out[i] = h10x_shard_seg{s.rank, s.localStart, s.count, s.globalBase, s.entries, local, g};
+    g += s.entries;
+  }
+  return 0;
+}
+int h10x_shard_prepare_export(h10x_ctx *h) {
+  if (!h) return -1;
+  Ctx &c = h->c; H10X_TRY(enter(c));
+  if (!c.haveState) return c.fail("no hash state loaded: use readFQB or readHash first");
+  if (!c.sharded) return 0;
+  return shard_materializeTables(&c);
+}
+int h10x_export_slice(h10x_ctx *h, int table, uint64_t first, uint64_t count, void *dst) {
+  if (!h) return -1;
+  Ctx &c = h->c; H10X_TRY(enter(c));
+  if (!c.haveState) return c.fail("no hash state loaded: use readFQB or readHash first");
+  if (!count) return 0;
+  if (!dst) return c.fail("h10x_export_slice: null destination");
+  const void *src = nullptr; size_t eb = 0; u64 limit = 0;
+  switch (table) {
+    case H10X_TABLE_HASHINDEX: src = c.hashIndex.p; eb = 4; limit = (u64)1 << c.prm.B; break;
+    case H10X_TABLE_HASHVALUE: src = c.hashValue.p; eb = 8; limit = c.hashNumber; break;
+    case H10X_TABLE_HASHDEPTH: src = c.hashDepth.p; eb = 4; limit = c.hashNumber; break;
+    case H10X_TABLE_BLOCKS:    src = c.blocks.p; eb = sizeof(h10x_block); limit = c.nBlocks; break;
+    case H10X_TABLE_CLUSHASH:  src = c.clusHash.p; eb = sizeof(h10x_clushash); limit = c.nEntries; break;
+    case H10X_TABLE_NGOOD:     if (!c.haveGood) return c.fail("!! you must set hashDepthRange before clusterReport"); src = c.nGood.p; eb = 4; limit = c.nBlocks; break;
+    default: return c.fail("h10x_export_slice: unknown table %d", table);
+  }
+  if ((table == H10X_TABLE_HASHINDEX || table == H10X_TABLE_HASHVALUE) && c.tablesPending) return c.fail("h10x_export_slice: call h10x_shard_prepare_export first (collective)");
+  if (!src || first > limit || count > limit - first) return c.fail("h10x_export_slice: table %d, range %llu + %llu outside %llu", table, (u64)first, (u64)count, (u64)limit);
+  H10X_HIP(&c, hipMemcpyAsync(dst, (const char *)src + first * eb, count * eb, hipMemcpyDeviceToHost, c.stream));
+  H10X_HIP(&c, hipStreamSynchronize(c.stream));
+  return 0;
+}
+
 int h10x_set_option(h10x_ctx *h, const char *name, int64_t value) {
   if (!h || !name) return -1;
   if (!strcmp(name, "stage_a_max_slots")) {
@@ -352,6 +468,9 @@ int h10x_set_option(h10x_ctx *h, const char *name, int64_t value) {
   if (!strcmp(name, "cluster_big_ranks")) { h->c.optBigRanks = value; return 0; }
   if (!strcmp(name, "cluster_dbg_skip")) { h->c.optDbgSkip = value; return 0; }
   if (!strcmp(name, "cluster_stamps")) { h->c.optStamps = value; return 0; }
+  if (!strcmp(name, "chunk_size")) { if (value < 0) return h->c.fail("chunk_size must be >= 0"); h->c.optChunk = value; return 0; }
+  if (!strcmp(name, "shard_row_shift")) { if (value < -1 || value > 8) return h->c.fail("shard_row_shift must be -1..8"); h->c.optRowShift = value; return 0; }
+  if (!strcmp(name, "shard_rows_fake_base")) { if (value < 0) return h->c.fail("shard_rows_fake_base must be >= 0"); h->c.optRowsFakeBase = value; return 0; }
   return h->c.fail("unknown option %s", name);
 }
 

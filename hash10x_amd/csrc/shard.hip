@@ -15,6 +15,7 @@
 #include "common.hpp"
 #include "prim.hpp"
 #include "comm.hpp"
+#include <algorithm>
 
 namespace h10x {
 
@@ -170,6 +171,36 @@ int shard_readFqb(Ctx *c, Comm *cm, const u32 *dRec, u64 nRec) {
   std::vector<u64> recsOf((size_t)N); { u64 mineRec = nRec; H10X_TRY(cm->allgatherHost(c, &mineRec, recsOf.data(), 8)); }
   bool laterRecords = false, anyRecords = false;
   for (int r = 0; r < N; ++r) { if (recsOf[r]) { anyRecords = true; if (r > me) laterRecords = true; } }
+  if (c->optChunk > 0) {
+    // the reference's chunk loop runs over the WHOLE file (hash10x.c:202-223): every rank replays it from the run starts of
+    // all shards (same verdict everywhere) and keeps the merge points that fall into its own records
+    std::vector<u64> st; std::vector<u32> zr;
+    H10X_TRY(stageA_runStarts(c, dRec, nRec, st, zr));
+    u64 mineN[2] = {(u64)st.size() - 1, (u64)zr.size()}; std::vector<u64> allN((size_t)2 * N);
+    H10X_TRY(cm->allgatherHost(c, mineN, allN.data(), 16));
+    u64 maxRuns = 0, maxZero = 0; for (int r = 0; r < N; ++r) { maxRuns = hmax(maxRuns, allN[2 * r]); maxZero = hmax(maxZero, allN[2 * r + 1]); }
+    std::vector<u64> pad((size_t)maxRuns + maxZero + 1, 0), allPad((size_t)N * (maxRuns + maxZero + 1));
+    for (size_t i = 0; i + 1 < st.size(); ++i) pad[i] = st[i];
+    for (size_t i = 0; i < zr.size(); ++i) pad[maxRuns + i] = zr[i];
+    H10X_TRY(cm->allgatherHost(c, pad.data(), allPad.data(), pad.size() * 8));
+    std::vector<u64> starts; std::vector<u32> zeroRuns; std::vector<u64> recBase((size_t)N + 1, 0);
+    for (int r = 0; r < N; ++r) {
+      const u64 *p = allPad.data() + (size_t)r * pad.size(); const u32 runBase = (u32)starts.size();
+      for (u64 i = 0; i < allN[2 * r]; ++i) starts.push_back(recBase[r] + p[i]);
+      for (u64 i = 0; i < allN[2 * r + 1]; ++i) zeroRuns.push_back(runBase + (u32)p[maxRuns + i]);
+      recBase[r + 1] = recBase[r] + recsOf[r];
+    }
+    starts.push_back(recBase[N]);
+    std::vector<u64> merges;
+    if (replayChunks(starts, zeroRuns, (u64)c->optChunk, merges)) return c->fail("chunkSize too small");       // hash10x.c:206
+    c->mergePoints.clear();
+    for (u64 m : merges) {
+      for (int r = 1; r < N; ++r) if (m == recBase[r] && recsOf[r])
+        return c->fail("an all-A barcode run ends at a chunk boundary that is also the boundary of shards %d and %d: the reference merges the two barcodes there (hash10x.c:212); cut the shards elsewhere", r - 1, r);
+      if (m >= recBase[me] && m < recBase[me + 1]) c->mergePoints.push_back(m - recBase[me]);
+    }
+    c->replayDone = true;
+  }
   DevBuf<u64> entHash; DevBuf<u32> entCode, entRead;
   H10X_TRY(stageA_run(c, dRec, nRec, entHash, entCode, entRead, laterRecords, anyRecords || me != 0));
   const u64 H = c->nEntries;
@@ -304,6 +335,48 @@ int shard_readFqb(Ctx *c, Comm *cm, const u32 *dRec, u64 nRec) {
   c->rows.release(); c->rowStart.release();                  // barcode lists arrive with --hashDepthRange
   c->ctr.distinct = U;
   c->comm = cm; c->sharded = true; c->haveState = true;
+  c->segs.n = 1; c->segs.s[0] = BlockSeg{0, c->nBlocks, c->codeBase};
+  c->rowShift = 0; c->ownerListsStale = false;
+  H10X_TRY(shard_refreshLayout(c));
+  if (c->nBlocksGlobal != nB) return c->fail("sharded layout: %u blocks counted, %u numbered", c->nBlocksGlobal, nB);
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------- who holds which blocks
+// Every rank's segments (owned local range, global number of its first block, entries), in file order. The sharded
+// --writeHash, the reports and --clusterSplit's numbering all read this table; it is rebuilt whenever blocks move.
+struct LayoutMsg { u32 n, pad; u32 localStart[MAX_SEGS], count[MAX_SEGS], globalBase[MAX_SEGS]; u64 entries[MAX_SEGS]; u64 records; };
+int shard_refreshLayout(Ctx *c) {
+  Comm *cm = c->comm; const int N = cm->n;
+  LayoutMsg m; memset(&m, 0, sizeof m);
+  m.n = (u32)c->segs.n; m.records = c->nRecords;
+  u64 ends[2 * MAX_SEGS];
+  for (int k = 0; k < c->segs.n; ++k) {
+    const BlockSeg &sg = c->segs.s[k];
+    const u32 skip = k == 0 && sg.count ? 1u : 0u;           // slot 0 of the first segment is nobody's block
+    m.localStart[k] = sg.localStart + skip; m.count[k] = sg.count - skip; m.globalBase[k] = sg.globalBase + skip;
+    H10X_TRY(c->readback(&ends[2 * k], c->blockOff.p + m.localStart[k], 8));
+    H10X_TRY(c->readback(&ends[2 * k + 1], c->blockOff.p + m.localStart[k] + m.count[k], 8));
+  }
+  H10X_TRY(c->syncReadbacks());
+  for (int k = 0; k < c->segs.n; ++k) m.entries[k] = ends[2 * k + 1] - ends[2 * k];
+  std::vector<LayoutMsg> all((size_t)N);
+  H10X_TRY(cm->allgatherHost(c, &m, all.data(), sizeof m));
+  c->allSegs.clear();
+  u64 blocks = 1, entries = 0, records = 0;
+  for (int r = 0; r < N; ++r) {
+    records += all[r].records;
+    for (u32 k = 0; k < all[r].n && k < (u32)MAX_SEGS; ++k) {
+      if (!all[r].count[k]) continue;
+      c->allSegs.push_back(ShardSegInfo{(u32)r, all[r].localStart[k], all[r].count[k], all[r].globalBase[k], all[r].entries[k]});
+      blocks += all[r].count[k]; entries += all[r].entries[k];
+    }
+  }
+  std::sort(c->allSegs.begin(), c->allSegs.end(), [](const ShardSegInfo &a, const ShardSegInfo &b) { return a.globalBase < b.globalBase; });
+  u64 expect = 1;
+  for (const ShardSegInfo &g : c->allSegs) { if (g.globalBase != expect) return c->fail("sharded layout: block %llu follows block %u", (u64)expect - 1, g.globalBase); expect += g.count; }
+  if (blocks >= (1ULL << 32)) return c->fail("too many barcode blocks for this build");
+  c->nBlocksGlobal = (u32)blocks; c->nEntriesGlobal = entries; c->nRecordsGlobal = records;
   return 0;
 }
 
@@ -329,6 +402,8 @@ int shard_materializeTables(Ctx *c) {
 }
 
 // ---------------------------------------------------------------------------------------- lists of in-range hashes
+// Lists are sent with their length rounded up to a multiple of 2^shift entries (shift = 0 unless the in-range lists of the
+// whole data set hold 2^32 entries or more): cluster_kernel keeps a list's offset as a 32-bit number of 2^shift-entry units.
 __global__ void good_len_kernel(const u32 *__restrict__ oIndex, const u32 *__restrict__ segStart, const u8 *__restrict__ within, u32 U,
                                 u32 *__restrict__ isGood, u32 *__restrict__ len) {
   const u32 d = blockIdx.x * blockDim.x + threadIdx.x;
@@ -336,46 +411,68 @@ __global__ void good_len_kernel(const u32 *__restrict__ oIndex, const u32 *__res
   const bool g = d < U && within[oIndex[d]] != 0;
   isGood[d] = g ? 1u : 0u; len[d] = g ? segStart[d + 1] - segStart[d] : 0u;
 }
+__global__ void pad_len_kernel(u32 *__restrict__ len, u32 n, u32 pad) {
+  const u32 d = blockIdx.x * blockDim.x + threadIdx.x;
+  if (d < n) len[d] = (len[d] + pad) & ~pad;
+}
 __global__ void good_pack_kernel(const u32 *__restrict__ oIndex, const u32 *__restrict__ segStart, const u32 *__restrict__ oRows, const u32 *__restrict__ isGood,
-                                 const u32 *__restrict__ pos, const u32 *__restrict__ off, u32 U, u32 *__restrict__ gIdx, u32 *__restrict__ gLen, u32 *__restrict__ gRows) {
+                                 const u32 *__restrict__ pos, const u64 *__restrict__ off, const u32 *__restrict__ padLen, u32 U,
+                                 u32 *__restrict__ gIdx, u32 *__restrict__ gLen, u32 *__restrict__ gRows) {
   for (u32 d = blockIdx.x; d < U; d += gridDim.x) {
     if (!isGood[d]) continue;
-    const u32 s = segStart[d], n = segStart[d + 1] - s, o = off[d];
-    if (threadIdx.x == 0) { gIdx[pos[d]] = oIndex[d]; gLen[pos[d]] = n; }
+    const u32 s = segStart[d], n = segStart[d + 1] - s; const u64 o = off[d];
+    if (threadIdx.x == 0) { gIdx[pos[d]] = oIndex[d]; gLen[pos[d]] = padLen[d]; }
     for (u32 j = threadIdx.x; j < n; j += blockDim.x) gRows[o + j] = oRows[s + j];
   }
 }
-__global__ void row_start_kernel(const u32 *__restrict__ gIdx, const u64 *__restrict__ gOff, u64 n, u64 *__restrict__ rowStart) {
+__global__ void row_start_kernel(const u32 *__restrict__ gIdx, const u64 *__restrict__ gOff, u64 n, u64 base, u64 *__restrict__ rowStart) {
   u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; const u64 stride = (u64)gridDim.x * blockDim.x;
-  for (; i < n; i += stride) rowStart[gIdx[i]] = gOff[i];
+  for (; i < n; i += stride) rowStart[gIdx[i]] = base + gOff[i];
 }
+
+int shard_rebuildOwnerLists(Ctx *c);
 
 // after hashWithinRangeBuild: every rank receives the barcode lists of all in-range hashes (allgather of the filtered lists)
 int shard_exchangeRows(Ctx *c) {
   hipStream_t st = c->stream; PrimTemp pt; Comm *cm = c->comm;
   const int N = cm->n; const u32 Uo = c->oU;
+  if (c->ownerListsStale) H10X_TRY(shard_rebuildOwnerLists(c));
   c->tstart(T_CSR);
-  DevBuf<u32> isGood, len, pos, off;
+  DevBuf<u32> isGood, len, pos; DevBuf<u64> off;
   H10X_HIP(c, isGood.alloc((size_t)Uo + 1)); H10X_HIP(c, len.alloc((size_t)Uo + 1)); H10X_HIP(c, pos.alloc((size_t)Uo + 1)); H10X_HIP(c, off.alloc((size_t)Uo + 1));
   good_len_kernel<<<divUp((u64)Uo + 1, 256), 256, 0, st>>>(c->oIndex.p, c->oSegStart.p, c->within.p, Uo, isGood.p, len.p);
   H10X_TRY(prim_exclusive_scan_u32(c, pt, isGood.p, pos.p, (size_t)Uo + 1));
-  H10X_TRY(prim_exclusive_scan_u32(c, pt, len.p, off.p, (size_t)Uo + 1));
-  u32 tail[2];
-  H10X_TRY(c->readback(&tail[0], pos.p + Uo, 4));
-  H10X_TRY(c->readback(&tail[1], off.p + Uo, 4));
+  H10X_TRY(prim_exclusive_scan_u32_u64(c, pt, len.p, off.p, (size_t)Uo + 1));
+  u32 nGoodMine = 0; u64 rawMine = 0;
+  H10X_TRY(c->readback(&nGoodMine, pos.p + Uo, 4));
+  H10X_TRY(c->readback(&rawMine, off.p + Uo, 8));
   H10X_TRY(c->syncReadbacks());
-  u64 mine[2] = {tail[0], tail[1]}; std::vector<u64> all((size_t)2 * N);
+  // the list alignment: the smallest shift that keeps every offset, in 2^shift-entry units, below 2^32 — the same on every rank
+  u64 mine[2] = {nGoodMine, rawMine}; std::vector<u64> all((size_t)2 * N);
   H10X_TRY(cm->allgatherHost(c, mine, all.data(), 16));
+  u64 totG = 0, totRaw = 0; for (int r = 0; r < N; ++r) { totG += all[2 * r]; totRaw += all[2 * r + 1]; }
+  const u64 fake = c->optRowsFakeBase > 0 ? (u64)c->optRowsFakeBase : 0;
+  int shift = c->optRowShift >= 0 ? (int)c->optRowShift : 0;
+  while (shift < 8 && ((fake + totRaw + totG * ((1ull << shift) - 1)) >> shift) >= (1ull << 32)) ++shift;
+  if (((fake + totRaw + totG * ((1ull << shift) - 1)) >> shift) >= (1ull << 32))
+    return c->fail("%llu barcode-list entries in the depth range: beyond 2^40, the limit of this build", (u64)totRaw);
+  const u32 pad = (1u << shift) - 1;
+  if (pad) {
+    pad_len_kernel<<<divUp((u64)Uo + 1, 256), 256, 0, st>>>(len.p, Uo + 1, pad);
+    H10X_TRY(prim_exclusive_scan_u32_u64(c, pt, len.p, off.p, (size_t)Uo + 1));
+    H10X_TRY(c->readback(&mine[1], off.p + Uo, 8));
+    H10X_TRY(c->syncReadbacks());
+    H10X_TRY(cm->allgatherHost(c, mine, all.data(), 16));
+  }
   DevBuf<u32> gIdx, gLen, gRows;
   H10X_HIP(c, gIdx.alloc(mine[0])); H10X_HIP(c, gLen.alloc(mine[0])); H10X_HIP(c, gRows.alloc(mine[1]));
-  if (Uo) good_pack_kernel<<<hmin<u32>(Uo, 16384), 64, 0, st>>>(c->oIndex.p, c->oSegStart.p, c->oRows.p, isGood.p, pos.p, off.p, Uo, gIdx.p, gLen.p, gRows.p);
+  if (Uo) good_pack_kernel<<<hmin<u32>(Uo, 16384), 64, 0, st>>>(c->oIndex.p, c->oSegStart.p, c->oRows.p, isGood.p, pos.p, off.p, len.p, Uo, gIdx.p, gLen.p, gRows.p);
   std::vector<u64> sc((size_t)N), so((size_t)N, 0), rc((size_t)N), ro((size_t)N); u64 nG = 0, nR = 0;
   for (int r = 0; r < N; ++r) { sc[r] = mine[0]; rc[r] = all[2 * r]; ro[r] = nG; nG += rc[r]; }
   DevBuf<u32> aIdx, aLen; H10X_HIP(c, aIdx.alloc(nG)); H10X_HIP(c, aLen.alloc(nG + 1));
   H10X_TRY(cm->alltoallv(c, gIdx.p, sc.data(), so.data(), aIdx.p, rc.data(), ro.data(), 4));
   H10X_TRY(cm->alltoallv(c, gLen.p, sc.data(), so.data(), aLen.p, rc.data(), ro.data(), 4));
   for (int r = 0; r < N; ++r) { sc[r] = mine[1]; rc[r] = all[2 * r + 1]; ro[r] = nR; nR += rc[r]; }
-  if (nR >= (1ULL << 32)) return c->fail("%llu barcode-list entries in the depth range exceed this build's 2^32 limit", (u64)nR);
   H10X_HIP(c, c->rows.alloc(nR));
   H10X_TRY(cm->alltoallv(c, gRows.p, sc.data(), so.data(), c->rows.p, rc.data(), ro.data(), 4));
   DevBuf<u64> aOff; H10X_HIP(c, aOff.alloc(nG + 1));
@@ -383,46 +480,219 @@ int shard_exchangeRows(Ctx *c) {
   H10X_TRY(prim_exclusive_scan_u32_u64(c, pt, aLen.p, aOff.p, nG + 1));
   H10X_HIP(c, c->rowStart.alloc((size_t)c->hashNumber + 1));
   H10X_HIP(c, hipMemsetAsync(c->rowStart.p, 0, ((size_t)c->hashNumber + 1) * 8, st));
-  if (nG) row_start_kernel<<<gridFor(nG), 256, 0, st>>>(aIdx.p, aOff.p, nG, c->rowStart.p);
+  const u64 fakeAligned = (fake + pad) & ~(u64)pad;
+  c->optRowsFakeBase = (int64_t)fakeAligned;                  // what stageC_cluster takes off the rows pointer
+  if (nG) row_start_kernel<<<gridFor(nG), 256, 0, st>>>(aIdx.p, aOff.p, nG, fakeAligned, c->rowStart.p);
   H10X_HIP(c, hipStreamSynchronize(st));
+  c->rowShift = shift;
   c->tstop(T_CSR);
   return 0;
 }
 
-// ---------------------------------------------------------------------------------------- gather for --writeHash
+// ---------------------------------------------------------------------------------------- owner lists after --clusterSplit
+// clusterSplitCodes ends by rebuilding hashCodes from the blocks (hash10x.c:1008-1012): entries have moved to new blocks,
+// hashDepth is unchanged. Sharded: every rank sends (hash index, global block) of each of its entries to the hash's owner,
+// which sorts them into its lists again (same lengths, new barcode numbers).
+__global__ void owner_of_index_kernel(const u32 *__restrict__ gIdx, const u64 *__restrict__ bound /* N+1 */, int N, u64 U, u16 *__restrict__ idxOwner) {
+  u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; const u64 stride = (u64)gridDim.x * blockDim.x;
+  for (; i < U; i += stride) {
+    int lo = 0, hi = N;                                      // largest o with bound[o] <= i
+    while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (bound[mid] <= i) lo = mid; else hi = mid; }
+    idxOwner[gIdx[i]] = (u16)lo;
+  }
+}
+__global__ void ord_of_index_kernel(const u32 *__restrict__ oIndex, u32 Uo, u32 *__restrict__ ordOf) {
+  const u32 d = blockIdx.x * blockDim.x + threadIdx.x;
+  if (d < Uo) ordOf[oIndex[d]] = d;
+}
+// PASS 0: entries per owner (device totals); PASS 1: place (index << 32 | global block) into the owner's slice
+template <int PASS>
+__global__ __launch_bounds__(256)
+void entry_owner_kernel(const h10x_clushash *__restrict__ ch, const u64 *__restrict__ blockOff, u32 nBlocks, SegMap segs, const u16 *__restrict__ idxOwner, int N,
+                        unsigned long long *__restrict__ cursor /* N: totals (PASS 0) / next free position (PASS 1) */, u64 *__restrict__ out) {
+  __shared__ u32 fill[PART_MAX_OWNERS];
+  __shared__ unsigned long long base[PART_MAX_OWNERS];
+  for (u32 b = blockIdx.x + 1; b < nBlocks; b += gridDim.x) {
+    const u64 e0 = blockOff[b], e1 = blockOff[b + 1];
+    const u32 g = segs.globalOf(b);
+    __syncthreads();
+    for (int o = threadIdx.x; o < N; o += blockDim.x) fill[o] = 0;
+    __syncthreads();
+    for (u64 e = e0 + threadIdx.x; e < e1; e += blockDim.x) atomicAdd(&fill[idxOwner[ch[e].hash]], 1u);
+    __syncthreads();
+    for (int o = threadIdx.x; o < N; o += blockDim.x) { const u32 n = fill[o]; if (n) base[o] = atomicAdd(&cursor[o], (unsigned long long)n); fill[o] = 0; }
+    if (!PASS) continue;
+    __syncthreads();
+    for (u64 e = e0 + threadIdx.x; e < e1; e += blockDim.x) {
+      const u32 ix = ch[e].hash; const int o = idxOwner[ix];
+      out[base[o] + atomicAdd(&fill[o], 1u)] = ((u64)ix << 32) | g;
+    }
+  }
+}
+__global__ void owner_key_of_kernel(u64 *__restrict__ pairs, u64 n, const u32 *__restrict__ ordOf) {
+  u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; const u64 stride = (u64)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) { const u64 v = pairs[i]; pairs[i] = ((u64)ordOf[(u32)(v >> 32)] << 32) | (v & 0xFFFFFFFFull); }
+}
+__global__ void low_word_kernel(const u64 *__restrict__ key, u64 n, u32 *__restrict__ out) {
+  u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; const u64 stride = (u64)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) out[i] = (u32)key[i];
+}
+
+int shard_rebuildOwnerLists(Ctx *c) {
+  hipStream_t st = c->stream; PrimTemp pt; Comm *cm = c->comm;
+  const int N = cm->n, me = cm->rank; const u32 Uo = c->oU, U = c->hashNumber - 1;
+  if (N > PART_MAX_OWNERS) return c->fail("clusterSplit on %d ranks: at most %d are supported", N, PART_MAX_OWNERS);
+  c->tstart(T_CSR);
+  // who owns which index: allgather of every owner's indices
+  std::vector<u64> uo((size_t)N); { u64 u = Uo; H10X_TRY(cm->allgatherHost(c, &u, uo.data(), 8)); }
+  std::vector<u64> sc((size_t)N, Uo), so((size_t)N, 0), rc((size_t)N), ro((size_t)N), bound((size_t)N + 1); u64 Utot = 0;
+  for (int r = 0; r < N; ++r) { rc[r] = uo[r]; ro[r] = Utot; bound[r] = Utot; Utot += uo[r]; }
+  bound[N] = Utot;
+  if (Utot != U) return c->fail("sharded index: %llu distinct hashes gathered, %u numbered", (u64)Utot, U);
+  DevBuf<u32> gIdx; DevBuf<u64> dBound; DevBuf<u16> idxOwner; DevBuf<u32> ordOf;
+  H10X_HIP(c, gIdx.alloc(U)); H10X_HIP(c, dBound.alloc((size_t)N + 1)); H10X_HIP(c, idxOwner.alloc((size_t)U + 1)); H10X_HIP(c, ordOf.alloc((size_t)U + 1));
+  H10X_TRY(cm->alltoallv(c, c->oIndex.p, sc.data(), so.data(), gIdx.p, rc.data(), ro.data(), 4));
+  H10X_HIP(c, hipMemcpyAsync(dBound.p, bound.data(), ((size_t)N + 1) * 8, hipMemcpyHostToDevice, st));
+  H10X_HIP(c, hipMemsetAsync(idxOwner.p, 0, ((size_t)U + 1) * 2, st));
+  if (U) owner_of_index_kernel<<<gridFor(U), 256, 0, st>>>(gIdx.p, dBound.p, N, U, idxOwner.p);
+  if (Uo) ord_of_index_kernel<<<divUp(Uo, 256), 256, 0, st>>>(c->oIndex.p, Uo, ordOf.p);
+  gIdx.release();
+  // my entries, by owner
+  const u64 H = c->nEntries; const u32 nBl = c->nBlocks;
+  DevBuf<unsigned long long> cursor; H10X_HIP(c, cursor.alloc((size_t)N)); H10X_HIP(c, hipMemsetAsync(cursor.p, 0, (size_t)N * 8, st));
+  const unsigned grid = hmin<u32>(nBl ? nBl : 1, 16384);
+  if (H) entry_owner_kernel<0><<<grid, 256, 0, st>>>(c->clusHash.p, c->blockOff.p, nBl, c->segs, idxOwner.p, N, cursor.p, nullptr);
+  std::vector<u64> sendCnt((size_t)N), sendOff((size_t)N), matrix((size_t)N * N), recvCnt((size_t)N), recvOff((size_t)N);
+  H10X_HIP(c, hipMemcpyAsync(sendCnt.data(), cursor.p, (size_t)N * 8, hipMemcpyDeviceToHost, st));
+  H10X_HIP(c, hipStreamSynchronize(st));
+  u64 acc = 0; for (int o = 0; o < N; ++o) { sendOff[o] = acc; acc += sendCnt[o]; }
+  if (acc != H) return c->fail("owner lists: %llu of %llu entries placed", (u64)acc, (u64)H);
+  H10X_HIP(c, hipMemcpyAsync(cursor.p, sendOff.data(), (size_t)N * 8, hipMemcpyHostToDevice, st));
+  DevBuf<u64> sPair; H10X_HIP(c, sPair.alloc(H));
+  if (H) entry_owner_kernel<1><<<grid, 256, 0, st>>>(c->clusHash.p, c->blockOff.p, nBl, c->segs, idxOwner.p, N, cursor.p, sPair.p);
+  H10X_TRY(cm->allgatherHost(c, sendCnt.data(), matrix.data(), (size_t)N * 8));
+  u64 M = 0; bool bad = false;
+  for (int r = 0; r < N; ++r) { recvCnt[r] = matrix[(size_t)r * N + me]; recvOff[r] = M; M += recvCnt[r]; }
+  for (int o = 0; o < N; ++o) { u64 m = 0; for (int r = 0; r < N; ++r) m += matrix[(size_t)r * N + o]; if (m >= (1ULL << 32)) bad = true; }   // the same verdict on every rank
+  if (bad) return c->fail("more than 2^32 entries land on one hash owner: over this build's per-GPU limit");
+  DevBuf<u64> rPair, rSorted; H10X_HIP(c, rPair.alloc(M)); H10X_HIP(c, rSorted.alloc(M));
+  H10X_TRY(cm->alltoallv(c, sPair.p, sendCnt.data(), sendOff.data(), rPair.p, recvCnt.data(), recvOff.data(), 8));
+  sPair.release();
+  if (M != c->oM) return c->fail("owner lists: %llu entries arrived for %llu list slots", (u64)M, (u64)c->oM);
+  if (M) owner_key_of_kernel<<<gridFor(M), 256, 0, st>>>(rPair.p, M, ordOf.p);
+  H10X_TRY(prim_sort_keys_u64(c, pt, rPair.p, rSorted.p, M, 0, 32 + bitsForS(Uo)));
+  H10X_HIP(c, c->oRows.alloc(M));
+  if (M) low_word_kernel<<<gridFor(M), 256, 0, st>>>(rSorted.p, M, c->oRows.p);
+  H10X_HIP(c, hipStreamSynchronize(st));
+  c->ownerListsStale = false;
+  c->tstop(T_CSR);
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------- --clusterSplit, sharded
+// stageC_split has moved the entries locally (children of local parent i at local nCodes - 1 + subBefore[i] + j). What is
+// left is collective: the children's GLOBAL numbers — the reference appends them after all existing blocks in the order
+// of their parents, i.e. in the order of the existing segments of all ranks by global number — then the layout table and
+// the owners' lists.
+struct SplitMsg { u32 n, pad; u32 globalBase[MAX_SEGS], children[MAX_SEGS]; };
+int shard_split(Ctx *c, const u32 *dSubBefore, u32 totalSubLocal) {
+  Comm *cm = c->comm; const int N = cm->n, me = cm->rank;
+  const u32 nCodesOld = c->nBlocks - totalSubLocal;
+  SplitMsg m; memset(&m, 0, sizeof m); m.n = (u32)c->segs.n;
+  u32 edge[2 * MAX_SEGS];
+  for (int k = 0; k < c->segs.n; ++k) {
+    H10X_TRY(c->readback(&edge[2 * k], dSubBefore + c->segs.s[k].localStart, 4));
+    H10X_TRY(c->readback(&edge[2 * k + 1], dSubBefore + c->segs.s[k].localStart + c->segs.s[k].count, 4));
+  }
+  H10X_TRY(c->syncReadbacks());
+  for (int k = 0; k < c->segs.n; ++k) { m.globalBase[k] = c->segs.s[k].globalBase; m.children[k] = edge[2 * k + 1] - edge[2 * k]; }
+  std::vector<SplitMsg> all((size_t)N);
+  H10X_TRY(cm->allgatherHost(c, &m, all.data(), sizeof m));
+  struct Par { u32 base, children; int rank, k; };
+  std::vector<Par> pars; u64 added = 0; bool tooMany = false;
+  for (int r = 0; r < N; ++r) {
+    int segsAfter = (int)all[r].n;
+    for (u32 k = 0; k < all[r].n; ++k) if (all[r].children[k]) { pars.push_back(Par{all[r].globalBase[k], all[r].children[k], r, (int)k}); ++segsAfter; added += all[r].children[k]; }
+    if (segsAfter > MAX_SEGS) tooMany = true;
+  }
+  if (tooMany) return c->fail("clusterSplit on a sharded context: more than %d block segments on one rank (three splits in a row are supported)", MAX_SEGS);
+  if ((u64)c->nBlocksGlobal + added >= (1ULL << 31)) return c->fail("clusterSplit would create %llu barcode blocks", (u64)c->nBlocksGlobal + added);
+  std::sort(pars.begin(), pars.end(), [](const Par &a, const Par &b) { return a.base < b.base; });
+  u32 next = c->nBlocksGlobal;                               // children are numbered from the old arrayMax on (hash10x.c:961-962)
+  const int nOld = c->segs.n;
+  for (const Par &p : pars) {
+    if (p.rank == me) c->segs.s[c->segs.n++] = BlockSeg{nCodesOld + edge[2 * p.k], p.children, next};
+    next += p.children;
+  }
+  // local order of the new segments = order of their parents' segments = what the loop above appended only if my old
+  // segments were already in ascending global order, which they are (segments are created in that order)
+  for (int k = nOld + 1; k < c->segs.n; ++k) if (c->segs.s[k].localStart < c->segs.s[k - 1].localStart) return c->fail("clusterSplit: segment order");
+  H10X_TRY(shard_refreshLayout(c));
+  if (c->nBlocksGlobal != next) return c->fail("clusterSplit: %u blocks numbered, %u laid out", next, c->nBlocksGlobal);
+  c->rows.release(); c->rowStart.release(); c->rowShift = 0;   // the in-range lists arrive with the next --hashDepthRange
+  c->ownerListsStale = true;
+  return shard_rebuildOwnerLists(c);
+}
+
+// ---------------------------------------------------------------------------------------- gather for a single-GPU continuation
 __global__ void blocks_nhash_kernel(const h10x_block *__restrict__ blocks, u32 nBlocks, u32 *__restrict__ nHash) {
   const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i <= nBlocks) nHash[i] = (i >= 1 && i < nBlocks) ? blocks[i].nHash : 0;
 }
 
-// collective; afterwards rank 0 holds blocks[] and clusHash[] of the whole data set (and behaves like an unsharded context)
+// collective; afterwards rank 0 holds blocks[] and clusHash[] of the whole data set in file order and is an unsharded
+// context (its barcode lists are rebuilt from the gathered blocks). --writeHash and the reports do not need this
+// (h10x_shard_segments + h10x_export_slice); it exists for continuing on one GPU.
 int shard_gather(Ctx *c) {
   hipStream_t st = c->stream; PrimTemp pt; Comm *cm = c->comm;
   if (!c->sharded) return 0;
-  H10X_TRY(shard_materializeTables(c));                      // what --writeHash needs beside blocks / clusHash
+  H10X_TRY(shard_materializeTables(c));
+  H10X_TRY(shard_refreshLayout(c));
   const int N = cm->n, me = cm->rank;
-  ShardInfo mine{(u64)c->nBlocks - 1, c->nEntries, c->nRecords}; std::vector<ShardInfo> all((size_t)N);
-  H10X_TRY(cm->allgatherHost(c, &mine, all.data(), sizeof mine));
-  std::vector<u64> sc((size_t)N, 0), so((size_t)N, 1), rc((size_t)N, 0), ro((size_t)N, 0);
-  u64 totB = 0, totH = 0, totR = 0;
-  for (int r = 0; r < N; ++r) { if (me == 0) { rc[r] = all[r].barcodes; ro[r] = 1 + totB; } totB += all[r].barcodes; totH += all[r].entries; totR += all[r].records; }
-  sc[0] = mine.barcodes;                                       // everyone sends blocks[1..] to rank 0 only
+  // limits first, from the table every rank holds: the same verdict everywhere, before any data moves
+  if (c->nEntriesGlobal >= (1ULL << 32)) return c->fail("%llu entries exceed this build's 2^32 limit on the gathering rank", (u64)c->nEntriesGlobal);
+  const u64 totB = (u64)c->nBlocksGlobal - 1, totH = c->nEntriesGlobal;
   DevBuf<h10x_block> gBlocks; DevBuf<h10x_clushash> gClus;
   if (me == 0) { H10X_HIP(c, gBlocks.alloc(totB + 1)); H10X_HIP(c, hipMemsetAsync(gBlocks.p, 0, sizeof(h10x_block), st)); H10X_HIP(c, gClus.alloc(totH)); }
-  H10X_TRY(cm->alltoallv(c, c->blocks.p, sc.data(), so.data(), gBlocks.p, rc.data(), ro.data(), sizeof(h10x_block)));
-  u64 acc = 0;
-  for (int r = 0; r < N; ++r) { so[r] = 0; sc[r] = 0; if (me == 0) { rc[r] = all[r].entries; ro[r] = acc; } acc += all[r].entries; }
-  sc[0] = mine.entries;
-  H10X_TRY(cm->alltoallv(c, c->clusHash.p, sc.data(), so.data(), gClus.p, rc.data(), ro.data(), sizeof(h10x_clushash)));
+  // k-th segment of every rank per round (a rank's segments in local order)
+  std::vector<std::vector<ShardSegInfo>> perRank((size_t)N);
+  std::vector<u64> entryStart(c->allSegs.size()); { u64 a = 0; for (size_t i = 0; i < c->allSegs.size(); ++i) { entryStart[i] = a; a += c->allSegs[i].entries; } }
+  std::vector<std::vector<u64>> perRankEntry((size_t)N);
+  for (size_t i = 0; i < c->allSegs.size(); ++i) { perRank[c->allSegs[i].rank].push_back(c->allSegs[i]); perRankEntry[c->allSegs[i].rank].push_back(entryStart[i]); }
+  for (int r = 0; r < N; ++r) {                              // local order
+    std::vector<size_t> ix(perRank[r].size()); for (size_t i = 0; i < ix.size(); ++i) ix[i] = i;
+    std::sort(ix.begin(), ix.end(), [&](size_t a, size_t b) { return perRank[r][a].localStart < perRank[r][b].localStart; });
+    std::vector<ShardSegInfo> a; std::vector<u64> b; for (size_t i : ix) { a.push_back(perRank[r][i]); b.push_back(perRankEntry[r][i]); }
+    perRank[r].swap(a); perRankEntry[r].swap(b);
+  }
+  for (int k = 0; k < MAX_SEGS; ++k) {
+    std::vector<u64> sc((size_t)N, 0), so((size_t)N, 0), rc((size_t)N, 0), ro((size_t)N, 0), sc2((size_t)N, 0), so2((size_t)N, 0), rc2((size_t)N, 0), ro2((size_t)N, 0);
+    bool any = false;
+    for (int r = 0; r < N; ++r) if ((size_t)k < perRank[r].size()) {
+      any = true;
+      if (me == 0) { rc[r] = perRank[r][k].count; ro[r] = perRank[r][k].globalBase; rc2[r] = perRank[r][k].entries; ro2[r] = perRankEntry[r][k]; }
+    }
+    if (!any) break;
+    if ((size_t)k < perRank[me].size()) {
+      const ShardSegInfo &g = perRank[me][k];
+      u64 e0 = 0; H10X_HIP(c, hipMemcpyAsync(&e0, c->blockOff.p + g.localStart, 8, hipMemcpyDeviceToHost, st)); H10X_HIP(c, hipStreamSynchronize(st));
+      sc[0] = g.count; so[0] = g.localStart; sc2[0] = g.entries; so2[0] = e0;
+    }
+    H10X_TRY(cm->alltoallv(c, c->blocks.p, sc.data(), so.data(), gBlocks.p, rc.data(), ro.data(), sizeof(h10x_block)));
+    H10X_TRY(cm->alltoallv(c, c->clusHash.p, sc2.data(), so2.data(), gClus.p, rc2.data(), ro2.data(), sizeof(h10x_clushash)));
+  }
   if (me == 0) {
-    if (totH >= (1ULL << 32)) return c->fail("%llu entries exceed this build's 2^32 limit on the gathering rank", (u64)totH);
     c->blocks.swap(gBlocks); c->clusHash.swap(gClus);
-    c->nBlocks = (u32)totB + 1; c->nEntries = totH; c->nRecords = totR;
+    c->nBlocks = (u32)totB + 1; c->nEntries = totH; c->nRecords = c->nRecordsGlobal;
     DevBuf<u32> nh; H10X_HIP(c, nh.alloc((size_t)c->nBlocks + 1)); H10X_HIP(c, c->blockOff.alloc((size_t)c->nBlocks + 1));
     blocks_nhash_kernel<<<divUp((u64)c->nBlocks + 1, 256), 256, 0, st>>>(c->blocks.p, c->nBlocks, nh.p);
     H10X_TRY(prim_exclusive_scan_u32_u64(c, pt, nh.p, c->blockOff.p, (size_t)c->nBlocks + 1));
     H10X_HIP(c, hipStreamSynchronize(st));
     c->sharded = false; c->codeBase = 0; c->haveGood = false;  // a full, unsharded state from here on (good lists were per shard)
+    c->goodPos.release(); c->nGood.release(); c->goodEntries.release();
+    c->segs.n = 1; c->segs.s[0] = BlockSeg{0, c->nBlocks, 0}; c->rowShift = 0; c->optRowsFakeBase = 0; c->allSegs.clear();
+    c->oRows.release(); c->oSegStart.release(); c->oIndex.release(); c->oU = 0; c->oM = 0;
+    H10X_TRY(stageB_buildCSR(c));                            // the barcode lists of the gathered state (fillHashTable)
   }
   H10X_TRY(cm->barrier(c));
   return 0;

@@ -16,6 +16,7 @@
 // table holds) take a global-memory path: raw slots in read order + stable device radix sort + unique.
 // The entries leave this stage as (hash / w, barcode, read): every mosh is a multiple of w (Ctx::keyInv, common.hpp).
 #include "common.hpp"
+#include <algorithm>
 #include "prim.hpp"
 
 namespace h10x {
@@ -97,6 +98,15 @@ __global__ void block_starts_kernel(const u32 *__restrict__ flags, const u32 *__
   const u64 stride = (u64)gridDim.x * blockDim.x;
   if (i == 0) { startRec[0] = 0; startRec[nBlocks] = n; }    // block 0 is unused; the end of the last block
   for (; i < n; i += stride) if (flags[i]) startRec[code[i]] = i;
+}
+
+__global__ void clear_heads_kernel(u32 *__restrict__ flags, const u64 *__restrict__ at, u32 n) {
+  const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) flags[at[i]] = 0;
+}
+__global__ void zero_runs_kernel(const u32 *__restrict__ rec, const u64 *__restrict__ startRec, u32 nBlocks, u32 *__restrict__ list, u32 cap, u32 *__restrict__ count) {
+  const u32 b = blockIdx.x * blockDim.x + threadIdx.x + 1;
+  if (b < nBlocks && rec[startRec[b] * 30] == 0) { const u32 p = atomicAdd(count, 1u); if (p < cap) list[p] = b - 1; }
 }
 
 // per block: nRead, the LDS table size it gets (0 = global path), and its class list
@@ -334,6 +344,68 @@ int stageA_sortRecords(Ctx *c, const u32 *dIn, u64 n, u32 *dOut) {
   return 0;
 }
 
+// ------------------------------------------------------------------------------------------ the reference's chunk loop
+// readFQB reads chunkSize - (records of the open block) records at a time (hash10x.c:202-211), so a chunk always ends
+// chunkSize records behind the start of the block that was open when it began. Two things follow from the chunk
+// boundaries and nothing else: a block with chunkSize or more records dies ("chunkSize too small"), and — `if (!barcode)
+// barcode = u[0]` at every chunk start (hash10x.c:212) — a run of the all-A barcode (word 0) that ends exactly at a chunk
+// boundary swallows the run behind it. Both are replayed here from the run starts alone.
+int replayChunks(const std::vector<u64> &starts, const std::vector<u32> &zeroRuns, u64 chunk, std::vector<u64> &merges) {
+  merges.clear();
+  const size_t R = starts.size() - 1; const u64 total = starts[R];
+  if (!R || !total) return 0;
+  std::vector<u32> zr(zeroRuns); std::sort(zr.begin(), zr.end());
+  auto isZero = [&](size_t r) { return std::binary_search(zr.begin(), zr.end(), (u32)r); };
+  auto runOf = [&](u64 pos) { return (size_t)(std::upper_bound(starts.begin(), starts.begin() + R, pos) - starts.begin()) - 1; };
+  std::vector<size_t> swallowed;                             // runs without a head of their own (ascending)
+  u64 pos = 0, head = 0; bool open = false, barcodeZero = true;
+  while (pos < total) {
+    const u64 carry = open ? pos - head : 0;
+    if (chunk <= carry) return 1;
+    if (barcodeZero && open) {                               // barcode = u[0]: the first record of this chunk joins the open block whatever it is
+      const size_t r = runOf(pos);
+      if (starts[r] == pos) { merges.push_back(pos); swallowed.push_back(r); }
+    }
+    if (!open) { head = pos; open = true; }
+    const u64 end = head + chunk < total ? head + chunk : total;
+    size_t q = runOf(end - 1);
+    barcodeZero = isZero(q);                                 // the barcode the loop holds at the end of the chunk
+    while (std::binary_search(swallowed.begin(), swallowed.end(), q)) --q;
+    head = starts[q];
+    pos = end;
+  }
+  return 0;
+}
+
+int stageA_runStarts(Ctx *c, const u32 *dRec, u64 nRec, std::vector<u64> &starts, std::vector<u32> &zeroRuns) {
+  hipStream_t st = c->stream; PrimTemp pt;
+  starts.assign(1, 0); zeroRuns.clear();
+  if (!nRec) return 0;
+  DevBuf<u32> flags, code; DevBuf<u64> startRec;
+  H10X_HIP(c, flags.alloc(nRec)); H10X_HIP(c, code.alloc(nRec));
+  const unsigned g = (unsigned)hmin<u64>(divUp(nRec, 256), 65535u * 4);
+  head_flags_kernel<<<g, 256, 0, st>>>(dRec, nRec, flags.p);
+  H10X_TRY(prim_inclusive_scan_u32(c, pt, flags.p, code.p, nRec));
+  u32 nRuns = 0;
+  H10X_TRY(c->readback(&nRuns, code.p + (nRec - 1), 4));
+  H10X_TRY(c->syncReadbacks());
+  const u32 nBlocks = nRuns + 1;
+  H10X_HIP(c, startRec.alloc((size_t)nBlocks + 1));
+  block_starts_kernel<<<g, 256, 0, st>>>(flags.p, code.p, nRec, nBlocks, startRec.p);
+  constexpr u32 ZCAP = 4096;
+  DevBuf<u32> zl, zc; H10X_HIP(c, zl.alloc(ZCAP)); H10X_HIP(c, zc.alloc(1)); H10X_HIP(c, hipMemsetAsync(zc.p, 0, 4, st));
+  zero_runs_kernel<<<divUp(nBlocks, 256), 256, 0, st>>>(dRec, startRec.p, nBlocks, zl.p, ZCAP, zc.p);
+  starts.resize((size_t)nRuns + 1);
+  H10X_HIP(c, hipMemcpyAsync(starts.data(), startRec.p + 1, ((size_t)nRuns + 1) * 8, hipMemcpyDeviceToHost, st));
+  u32 nz = 0;
+  H10X_TRY(c->readback(&nz, zc.p, 4));
+  H10X_TRY(c->syncReadbacks());
+  if (nz > ZCAP) return c->fail("%u separate runs of the all-A barcode: the input is not grouped by barcode", nz);
+  zeroRuns.resize(nz);
+  if (nz) { H10X_HIP(c, hipMemcpyAsync(zeroRuns.data(), zl.p, (size_t)nz * 4, hipMemcpyDeviceToHost, st)); H10X_HIP(c, hipStreamSynchronize(st)); }
+  return 0;
+}
+
 // ------------------------------------------------------------------------------------------ driver
 int stageA_run(Ctx *c, const u32 *dRec, u64 nRec, DevBuf<u64> &entHash, DevBuf<u32> &entCode, DevBuf<u32> &entRead, bool hashLast, bool emptyIsNoBlock) {
   hipStream_t st = c->stream;
@@ -353,7 +425,20 @@ int stageA_run(Ctx *c, const u32 *dRec, u64 nRec, DevBuf<u64> &entHash, DevBuf<u
     DevBuf<u32> flags, code;
     H10X_HIP(c, flags.alloc(nRec)); H10X_HIP(c, code.alloc(nRec));
     const unsigned g = (unsigned)hmin<u64>(divUp(nRec, 256), 65535u * 4);
+    if (c->optChunk > 0 && !c->replayDone) {                 // the reference's chunk loop over this (whole) file
+      std::vector<u64> starts; std::vector<u32> zeroRuns;
+      H10X_TRY(stageA_runStarts(c, dRec, nRec, starts, zeroRuns));
+      if (replayChunks(starts, zeroRuns, (u64)c->optChunk, c->mergePoints)) return c->fail("chunkSize too small");   // hash10x.c:206
+    }
+    c->replayDone = false;
     head_flags_kernel<<<g, 256, 0, st>>>(dRec, nRec, flags.p);
+    if (!c->mergePoints.empty()) {
+      DevBuf<u64> at; H10X_HIP(c, at.alloc(c->mergePoints.size()));
+      H10X_HIP(c, hipMemcpyAsync(at.p, c->mergePoints.data(), c->mergePoints.size() * 8, hipMemcpyHostToDevice, st));
+      clear_heads_kernel<<<divUp(c->mergePoints.size(), 256), 256, 0, st>>>(flags.p, at.p, (u32)c->mergePoints.size());
+      H10X_HIP(c, hipStreamSynchronize(st));                 // the host vector is released next
+      c->mergePoints.clear();
+    }
     H10X_TRY(prim_inclusive_scan_u32(c, pt, flags.p, code.p, nRec));
     u32 nRuns = 0;
     H10X_TRY(c->readback(&nRuns, code.p + (nRec - 1), 4));

@@ -155,7 +155,8 @@ struct ClusterArgs {
   u32 *started;                 // host-visible word per workgroup, set when the workgroup starts (whole-CU class only)
   const u32 *front; u32 nFront;                             // handed out before list[]: the largest barcodes of the launch
   u32 nBlocks; int threshold;
-  u32 codeBase;                                             // sharded runs: global barcode number = codeBase + local block number
+  SegMap segs;                                              // local block number -> global barcode number (what the lists hold); identity when unsharded
+  u32 rowShift;                                             // rows[]: a list starts at entry (rs << rowShift) — sharded runs with more than 2^32 list entries
   u32 nBlocksFirst;                                         // size of first[]: barcodes of the whole data set + 1
   u32 firstCap;                                             // ranked placement, test knob: cap on the first[] entries of a block (0 = what the budget leaves)
   u32 hashMask, hashMinSlots;                               // hashed placement: 2^b - 1 with 2^b >= barcodes of the data set; slots below which the 8-bit tag is too narrow
@@ -496,7 +497,9 @@ __device__ void cluster_one_block(const ClusterArgs &a, u32 code, unsigned char 
   if constexpr (HASHED) { slots &= ~3u; ft.tab = (u32 *)w.first; ft.NB = slots / 4; ft.recip = (u32)((0x100000000ULL + ft.NB - 1) / ft.NB); ft.bmask = a.hashMask; ft.ovf = &sh[2]; }
   else if constexpr (RANKED) { ft.first = w.first; ft.bm = w.bm; ft.pre = w.pre; }
   else ft.first = w.first;
-  const u32 lcode = code; code += a.codeBase;                // from here on `code` is the global barcode number (what the lists hold)
+  const u32 lcode = code; code = a.segs.globalOf(lcode);     // from here on `code` is the global barcode number (what the lists hold)
+  const u32 rsh = a.rowShift;
+#define ROWP(rs) (a.rows + ((size_t)(rs) << rsh))
   h10x_clushash *ch = a.clusHash + o; const u16 *g = a.goodPos + o;
 
   u64 tPrev = a.phase ? wall_clock64() : 0;
@@ -508,7 +511,7 @@ __device__ void cluster_one_block(const ClusterArgs &a, u32 code, unsigned char 
   u64 myDepth = 0;
   for (u32 i = tid; i < n; i += CL_THREADS) {
     const u32 x = ch[g[i]].hash; const u32 d = a.hashDepth[x];
-    w.rs[i] = (u32)a.rowStart[x]; w.dd[i] = (CT)d; w.lab[i] = 0; w.qj[i] = NONE16; w.best[i] = NONE16;
+    w.rs[i] = (u32)(a.rowStart[x] >> rsh); w.dd[i] = (CT)d; w.lab[i] = 0; w.qj[i] = NONE16; w.best[i] = NONE16;
     w.cnt[i] = 0; w.tot[i] = 0; myDepth += d;
   }
   SYNC();
@@ -521,11 +524,11 @@ __device__ void cluster_one_block(const ClusterArgs &a, u32 code, unsigned char 
     for (u32 i0 = 1 + wave * 4; i0 < n; i0 += CL_WAVES * 4) {
       u32 c0[4], d4[4];
 #pragma unroll
-      for (int t = 0; t < 4; ++t) { const u32 i = i0 + t; d4[t] = i < n ? (u32)w.dd[i] : 0; c0[t] = (u32)lane < d4[t] ? a.rows[w.rs[i < n ? i : n - 1] + lane] : code; }
+      for (int t = 0; t < 4; ++t) { const u32 i = i0 + t; d4[t] = i < n ? (u32)w.dd[i] : 0; c0[t] = (u32)lane < d4[t] ? ROWP(w.rs[i < n ? i : n - 1])[lane] : code; }
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
         mark(c0[t]);
-        if (d4[t] > WAVE) { const u32 *row = a.rows + w.rs[i0 + t]; for (u32 j = WAVE + lane; j < d4[t]; j += WAVE) mark(row[j]); }
+        if (d4[t] > WAVE) { const u32 *row = ROWP(w.rs[i0 + t]); for (u32 j = WAVE + lane; j < d4[t]; j += WAVE) mark(row[j]); }
       }
     }
     SYNC();
@@ -573,7 +576,7 @@ __device__ void cluster_one_block(const ClusterArgs &a, u32 code, unsigned char 
       const u32 i = ib + t;                                                                                   \
       DL[t] = (i >= 1 && i < n) ? (u32)__builtin_amdgcn_readfirstlane((int)dv[t]) : 0;                        \
       RS[t] = (u32)__builtin_amdgcn_readfirstlane((int)rv[t]);                                                \
-      CJ[t] = (u32)lane < DL[t] ? a.rows[RS[t] + lane] : code;                                                \
+      CJ[t] = (u32)lane < DL[t] ? ROWP(RS[t])[lane] : code;                                                   \
     } }
   // the first chunk of a list is requested TWO rounds before its turn (the loop is bound by the latency of these short
   // random reads), the second chunk — one list in seven has one — a round before
@@ -582,7 +585,7 @@ __device__ void cluster_one_block(const ClusterArgs &a, u32 code, unsigned char 
   u32 cjNN[RIF], dlNN[RIF], rsN[RIF], rsNN[RIF];
   H10X_LOAD_AB(listWave ? uwave * RIF : n, cjN, dlN, rsN)
 #pragma unroll
-  for (int t = 0; t < RIF; ++t) cj2N[t] = (u32)(WAVE + lane) < dlN[t] ? a.rows[rsN[t] + WAVE + lane] : code;
+  for (int t = 0; t < RIF; ++t) cj2N[t] = (u32)(WAVE + lane) < dlN[t] ? ROWP(rsN[t])[WAVE + lane] : code;
   H10X_LOAD_AB(listWave ? (uwave + nW) * RIF : n, cjNN, dlNN, rsNN)
   for (u32 r0 = 0; r0 < n; r0 += nW * RIF) {
     const u32 i0 = listWave ? r0 + uwave * RIF : n;
@@ -590,7 +593,7 @@ __device__ void cluster_one_block(const ClusterArgs &a, u32 code, unsigned char 
 #pragma unroll
     for (int t = 0; t < RIF; ++t) { cj[t] = cjN[t]; cj2[t] = cj2N[t]; dl[t] = dlN[t]; cjN[t] = cjNN[t]; dlN[t] = dlNN[t]; rsN[t] = rsNN[t]; }
 #pragma unroll
-    for (int t = 0; t < RIF; ++t) cj2N[t] = (u32)(WAVE + lane) < dlN[t] ? a.rows[rsN[t] + WAVE + lane] : code;
+    for (int t = 0; t < RIF; ++t) cj2N[t] = (u32)(WAVE + lane) < dlN[t] ? ROWP(rsN[t])[WAVE + lane] : code;
     H10X_LOAD_AB(listWave ? i0 + 2 * nW * RIF : n, cjNN, dlNN, rsNN)
 #pragma unroll
     for (int t = 0; t < RIF; ++t) {
@@ -599,7 +602,7 @@ __device__ void cluster_one_block(const ClusterArgs &a, u32 code, unsigned char 
       cj[t] = cj[t] != code ? ft.update(cj[t], i) : NOHANDLE;          // from here on cj / cj2 hold handles
       if (dl[t] > WAVE) {
         cj2[t] = cj2[t] != code ? ft.update(cj2[t], i) : NOHANDLE;
-        if (dl[t] > 2 * WAVE) { const u32 *row = a.rows + w.rs[i]; for (u32 j = 2 * WAVE + lane; j < dl[t]; j += WAVE) { const u32 c2 = row[j]; if (c2 != code) ft.update(c2, i); } }
+        if (dl[t] > 2 * WAVE) { const u32 *row = ROWP(w.rs[i]); for (u32 j = 2 * WAVE + lane; j < dl[t]; j += WAVE) { const u32 c2 = row[j]; if (c2 != code) ft.update(c2, i); } }
       }
     }
     if (!(a.dbgSkip & 8)) SYNC_LDS();
@@ -609,7 +612,7 @@ __device__ void cluster_one_block(const ClusterArgs &a, u32 code, unsigned char 
     for (int t = 0; t < RIF; ++t) {
       const u32 i = i0 + t;
       if (i >= 1 && i < n) {
-        const u32 d = dl[t]; const u32 *row = a.rows + w.rs[i];
+        const u32 d = dl[t]; const u32 *row = ROWP(w.rs[i]);
         u32 best, bcnt, tot;
         if (d <= WAVE) row_mode_hist<IN_LDS, 1>(row, cj[t], NOHANDLE, d, code, i, ft, w.hist + wave * w.histWords, (u32)a.threshold, best, bcnt, tot);
         else if (d <= 2 * WAVE) row_mode_hist<IN_LDS, 2>(row, cj[t], cj2[t], d, code, i, ft, w.hist + wave * w.histWords, (u32)a.threshold, best, bcnt, tot);
@@ -722,14 +725,14 @@ __device__ void cluster_one_block(const ClusterArgs &a, u32 code, unsigned char 
         const bool on = k0 + t < nTodo;
         ii[t] = on ? (u32)ld_shared<IN_LDS>(&todo[k0 + t]) : 0u;
         qv[t] = on ? (u32)w.qj[ii[t]] : NONE16; dl[t] = on ? (u32)w.dd[ii[t]] : 0u;
-        cj[t] = (u32)lane < dl[t] ? a.rows[w.rs[ii[t]] + lane] : code;
+        cj[t] = (u32)lane < dl[t] ? ROWP(w.rs[ii[t]])[lane] : code;
       }
 #pragma unroll
       for (int t = 0; t < RIF; ++t) {
         if (dl[t] == 0) continue;
         const u32 i = ii[t];
         u32 q = (u32)__popcll(__ballot(cj[t] != code && ft.lookup(cj[t]) == qv[t]));
-        if (dl[t] > WAVE) { const u32 *row = a.rows + w.rs[i]; for (u32 b0 = WAVE; b0 < dl[t]; b0 += WAVE) { bool m = false; if (b0 + lane < dl[t]) { const u32 c2 = row[b0 + lane]; m = c2 != code && ft.lookup(c2) == qv[t]; } q += (u32)__popcll(__ballot(m)); } }
+        if (dl[t] > WAVE) { const u32 *row = ROWP(w.rs[i]); for (u32 b0 = WAVE; b0 < dl[t]; b0 += WAVE) { bool m = false; if (b0 + lane < dl[t]) { const u32 c2 = row[b0 + lane]; m = c2 != code && ft.lookup(c2) == qv[t]; } q += (u32)__popcll(__ballot(m)); } }
         if (lane == 0) w.cnt[i] = (CT)q;
       }
     }
@@ -755,7 +758,7 @@ __device__ void cluster_one_block(const ClusterArgs &a, u32 code, unsigned char 
   if (!FIRST_LDS) {                                          // leave first[] clean for the next barcode of this workgroup
     SYNC();
     for (u32 i = 1 + wave; i < n; i += CL_WAVES) {
-      const u32 d = w.dd[i]; const u32 *row = a.rows + w.rs[i];
+      const u32 d = w.dd[i]; const u32 *row = ROWP(w.rs[i]);
       for (u32 j = lane; j < d; j += WAVE) w.first[row[j]] = NONE16;
     }
   }
@@ -765,6 +768,7 @@ __device__ void cluster_one_block(const ClusterArgs &a, u32 code, unsigned char 
 
 #undef SYNC
 #undef SYNC_LDS
+#undef ROWP
 
 // Two 1024-lane workgroups share a CU only if a wave stays within 64 VGPRs (8 waves per SIMD): the kernel is latency
 // bound (chains of LDS round trips per list), so the second workgroup is worth far more than the few loop-invariant
@@ -945,19 +949,10 @@ __global__ void cluster_classify_kernel(const h10x_block *__restrict__ blocks, c
   }
 }
 
-int stageC_cluster(Ctx *c, int codeMin, int codeMax, int threshold) {
+// one contiguous range of LOCAL block numbers; `more` = a further range of the same command has run before (counters add up)
+static int cluster_local_range(Ctx *c, int codeMin, int codeMax, int threshold, bool more) {
   hipStream_t st = c->stream;
-  if (!c->haveGood) return c->fail("!! you must set hashDepthRange before cluster");          // hash10x.c:1258
-  if (threshold < 1) return c->fail("clusterThreshold %d must be >= 1 (the reference reads an uninitialised msBest otherwise)", threshold);
   const u32 nGlobal = c->sharded ? c->nBlocksGlobal : c->nBlocks;
-  if (!codeMin) codeMin = 1;                                                                    // hash10x.c:1243-1244
-  if (!codeMax) codeMax = (int)nGlobal;
-  if (codeMin < 0 || codeMax > (int)nGlobal) return c->fail("cluster code range %d..%d outside 1..%u", codeMin, codeMax, nGlobal);
-  if (c->sharded) {                                          // keep this shard's part of the (global) range, as local block numbers
-    const long lo = (long)codeMin - (long)c->codeBase, hi = (long)codeMax - (long)c->codeBase;
-    codeMin = (int)(lo < 1 ? 1 : lo); codeMax = (int)(hi > (long)c->nBlocks ? (long)c->nBlocks : hi);
-  }
-  if (codeMax <= codeMin) { memset(c->ctr.cluster_class_counts, 0, sizeof c->ctr.cluster_class_counts); c->ctr.sum_good = c->ctr.sum_good_depth = c->ctr.sum_hash_clustered = c->ctr.clustered_codes = 0; return 0; }
   c->tstart(T_CLUSTER);
   const u32 span = (u32)(codeMax - codeMin);
   DevBuf<u32> list0, list1, list2, list3; DevBuf<u64> zeroed; DevBuf<double> term;
@@ -997,7 +992,8 @@ int stageC_cluster(Ctx *c, int codeMin, int codeMax, int threshold) {
   ClusterArgs a{};
   a.blocks = c->blocks.p; a.blockOff = c->blockOff.p; a.clusHash = c->clusHash.p; a.goodPos = c->goodPos.p; a.nGood = c->nGood.p;
   a.hashDepth = c->hashDepth.p; a.rowStart = c->rowStart.p; a.rows = c->rows.p; a.nBlocks = c->nBlocks; a.threshold = threshold;
-  a.codeBase = c->sharded ? c->codeBase : 0; a.nBlocksFirst = nGlobal;
+  a.segs = c->segs; a.nBlocksFirst = nGlobal; a.rowShift = (u32)c->rowShift;
+  if (c->sharded && c->optRowsFakeBase) a.rows = c->rows.p - (size_t)c->optRowsFakeBase;   // test knob: rowStart[] carries the same offset (shard_exchangeRows)
   a.dbgSkip = (u32)c->optDbgSkip;
   a.maxGood = c->maxGood; a.stats = stats.p; a.term = term.p; a.entries = c->goodEntries.p;
   a.firstCap = firstCap; a.hashMask = hashBits >= 32 ? 0xFFFFFFFFu : (1u << hashBits) - 1u; a.hashMinSlots = hashMinSlots;
@@ -1027,6 +1023,9 @@ int stageC_cluster(Ctx *c, int codeMin, int codeMax, int threshold) {
   // The classes are independent: fork them onto side streams so that the few largest barcodes (long, low
   // parallelism) run beside the many small ones instead of in front of them. Every buffer they touch was
   // allocated before the fork and is released after the join, which is what the block cache requires.
+  // a failure between here and the join must not let the buffers above go back to the block cache while a side stream
+  // still runs a kernel on them (the cache orders reuse within ONE stream only)
+  struct ForkGuard { Ctx *c; bool armed; ~ForkGuard() { if (!armed) return; for (int i = 0; i < 3; ++i) if (c->aux[i]) (void)hipStreamSynchronize(c->aux[i]); (void)hipStreamSynchronize(c->stream); } } forkGuard{c, true};
   c->tstart(T_CLUSTER_K);
   H10X_TRY(c->forkStreams(3));
   if (hc[3]) {
@@ -1127,10 +1126,37 @@ int stageC_cluster(Ctx *c, int codeMin, int codeMax, int threshold) {
   H10X_TRY(c->syncReadbacks());
   c->tstop(T_CLUSTER);
   if (c->optStamps) { H10X_HIP(c, hipMemcpy(c->ctr.cluster_phase_ticks, phase.p, 64, hipMemcpyDeviceToHost)); }
-  for (int k = 0; k < 4; ++k) { c->ctr.cluster_main[k] = hs[4 + k]; hs[k] += hs[4 + k]; }   // re-runs of overflowed blocks count again (they did the work twice)
-  c->ctr.sum_good = hs[0]; c->ctr.sum_good_depth = hs[1]; c->ctr.sum_hash_clustered = hs[2]; c->ctr.clustered_codes = span;
-  c->ctr.cluster_first_mode = (uint64_t)firstMode; c->ctr.cluster_overflow_blocks = nOverflow;
-  c->ctr.cluster_class_counts[0] = hc[0]; c->ctr.cluster_class_counts[1] = hc[1]; c->ctr.cluster_class_counts[2] = hc[2]; c->ctr.cluster_class_counts[3] = hc[3];
+  forkGuard.armed = false;                                   // everything has been waited for
+  if (!more) { memset(c->ctr.cluster_main, 0, sizeof c->ctr.cluster_main); memset(c->ctr.cluster_class_counts, 0, sizeof c->ctr.cluster_class_counts);
+               c->ctr.sum_good = c->ctr.sum_good_depth = c->ctr.sum_hash_clustered = c->ctr.clustered_codes = c->ctr.cluster_overflow_blocks = 0; }
+  for (int k = 0; k < 4; ++k) { c->ctr.cluster_main[k] += hs[4 + k]; hs[k] += hs[4 + k]; }   // re-runs of overflowed blocks count again (they did the work twice)
+  c->ctr.sum_good += hs[0]; c->ctr.sum_good_depth += hs[1]; c->ctr.sum_hash_clustered += hs[2]; c->ctr.clustered_codes += span;
+  c->ctr.cluster_first_mode = (uint64_t)firstMode; c->ctr.cluster_overflow_blocks += nOverflow;
+  for (int k = 0; k < 4; ++k) c->ctr.cluster_class_counts[k] += hc[k];
+  return 0;
+}
+
+// the --cluster loop over GLOBAL block numbers [codeMin, codeMax): every segment of this context runs its part
+int stageC_cluster(Ctx *c, int codeMin, int codeMax, int threshold) {
+  if (!c->haveGood) return c->fail("!! you must set hashDepthRange before cluster");          // hash10x.c:1258
+  if (threshold < 1) return c->fail("clusterThreshold %d must be >= 1 (the reference reads an uninitialised msBest otherwise)", threshold);
+  const u32 nGlobal = c->sharded ? c->nBlocksGlobal : c->nBlocks;
+  if (!codeMin) codeMin = 1;                                                                    // hash10x.c:1243-1244
+  if (!codeMax) codeMax = (int)nGlobal;
+  if (codeMin < 0 || codeMax > (int)nGlobal) return c->fail("cluster code range %d..%d outside 1..%u", codeMin, codeMax, nGlobal);
+  bool any = false;
+  for (int k = 0; k < c->segs.n; ++k) {
+    const BlockSeg &sg = c->segs.s[k];
+    const long first = (long)sg.localStart + (k == 0 ? 1 : 0);                                  // slot 0 of the first segment is nobody's block
+    long lo = (long)codeMin - (long)sg.globalBase + (long)sg.localStart, hi = (long)codeMax - (long)sg.globalBase + (long)sg.localStart;
+    if (lo < first) lo = first;
+    if (hi > (long)sg.localStart + (long)sg.count) hi = (long)sg.localStart + (long)sg.count;
+    if (hi <= lo) continue;
+    H10X_TRY(cluster_local_range(c, (int)lo, (int)hi, threshold, any));
+    any = true;
+  }
+  if (!any) { memset(c->ctr.cluster_class_counts, 0, sizeof c->ctr.cluster_class_counts); memset(c->ctr.cluster_main, 0, sizeof c->ctr.cluster_main);
+              c->ctr.sum_good = c->ctr.sum_good_depth = c->ctr.sum_hash_clustered = c->ctr.clustered_codes = c->ctr.cluster_overflow_blocks = 0; }
   return 0;
 }
 
@@ -1140,7 +1166,7 @@ int stageC_cluster(Ctx *c, int codeMin, int codeMax, int threshold) {
 // reads renumbered in order of first appearance, labels cleared; the parent keeps its unclustered hashes.
 // Not a hot path: one wavefront per parent block, lane 0 replays the reference's single pass over the block.
 __global__ void split_count_kernel(const h10x_block *__restrict__ oldB, const u64 *__restrict__ oldOff, const h10x_clushash *__restrict__ ch,
-                                   u32 nCodes, const u32 *__restrict__ subBefore /* exclusive scan of nSubCluster */,
+                                   u32 nCodes, const u32 *__restrict__ subBefore /* exclusive scan of nSubCluster */, SegMap segs,
                                    h10x_block *__restrict__ newB, u32 *__restrict__ newNHash) {
   const u32 i = blockIdx.x; if (i >= nCodes) return;
   const h10x_block ob = oldB[i];
@@ -1158,7 +1184,7 @@ __global__ void split_count_kernel(const h10x_block *__restrict__ oldB, const u6
   for (u32 j = threadIdx.x; j <= ob.nSubCluster && j < 256; j += blockDim.x) {
     h10x_block b; memset(&b, 0, sizeof b);
     if (j == 0) { b.nRead = ob.nRead; b.nHash = cnt[0]; newB[i] = b; newNHash[i] = cnt[0]; }      // hash10x.c:990: nRead kept, rest calloc'd
-    else { b.nHash = cnt[j]; b.clusterParent = i + 1; newB[ext + j] = b; newNHash[ext + j] = cnt[j]; }   // nRead filled by the move pass
+    else { b.nHash = cnt[j]; b.clusterParent = segs.globalOf(i) + 1; newB[ext + j] = b; newNHash[ext + j] = cnt[j]; }   // nRead filled by the move pass (parent: global number)
   }
 }
 
@@ -1196,7 +1222,6 @@ __global__ void split_aux_kernel(const h10x_block *__restrict__ b, u32 n, u32 *_
 
 int stageC_split(Ctx *c) {
   hipStream_t st = c->stream; PrimTemp pt;
-  if (c->sharded) return c->fail("clusterSplit on a sharded context: gather first (h10x_shard_gather) and split on rank 0");
   if (!c->haveState) return c->fail("no hash state loaded: use readFQB or readHash first");
   c->tstart(T_SPLIT);
   const u32 nCodes = c->nBlocks;
@@ -1220,7 +1245,7 @@ int stageC_split(Ctx *c) {
   H10X_HIP(c, hipMemsetAsync(newB.p, 0, (size_t)nNew * sizeof(h10x_block), st));
   H10X_HIP(c, hipMemsetAsync(newNHash.p, 0, ((size_t)nNew + 1) * 4, st));
   H10X_HIP(c, hipMemsetAsync(readMap.p, 0, (totalRead + 1) * 4, st));
-  split_count_kernel<<<nCodes, 256, 0, st>>>(c->blocks.p, c->blockOff.p, c->clusHash.p, nCodes, subBefore.p, newB.p, newNHash.p);
+  split_count_kernel<<<nCodes, 256, 0, st>>>(c->blocks.p, c->blockOff.p, c->clusHash.p, nCodes, subBefore.p, c->segs, newB.p, newNHash.p);
   H10X_TRY(prim_exclusive_scan_u32_u64(c, pt, newNHash.p, newOff.p, (size_t)nNew + 1));
   split_move_kernel<<<nCodes, 64, 0, st>>>(c->blocks.p, c->blockOff.p, c->clusHash.p, nCodes, subBefore.p, readOff.p, readMap.p, newB.p, newOff.p, out.p);
   H10X_HIP(c, hipGetLastError());
@@ -1228,7 +1253,8 @@ int stageC_split(Ctx *c) {
   c->blocks.swap(newB); c->blockOff.swap(newOff); c->clusHash.swap(out);
   c->nBlocks = nNew;
   c->haveGood = false; c->goodPos.release(); c->nGood.release(); c->goodEntries.release();      // lists refer to the old blocks: a new --hashDepthRange is required
-  H10X_TRY(stageB_buildCSR(c));                              // hash10x.c:1008-1012: hashCodes rebuilt, hashDepth unchanged
+  if (c->sharded) H10X_TRY(shard_split(c, subBefore.p, totalSub));   // new blocks get their global numbers; the hash owners rebuild their lists
+  else { c->segs.n = 1; c->segs.s[0] = BlockSeg{0, nNew, 0}; H10X_TRY(stageB_buildCSR(c)); }   // hash10x.c:1008-1012: hashCodes rebuilt, hashDepth unchanged
   c->tstop(T_SPLIT);
   return 0;
 }

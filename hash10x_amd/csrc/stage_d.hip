@@ -86,7 +86,7 @@ __global__ void crib_classify_kernel(const u32 *__restrict__ c1, const u64 *__re
 int stageD_cribGenome(Ctx *c, const u8 *hostCodes, const u64 *seqStart, u32 nSeq, int which, u64 *nPresent, u64 *nAbsent) {
   hipStream_t st = c->stream;
   if (!c->haveState) return c->fail("no hash state loaded: use readFQB or readHash first");
-  if (c->sharded) return c->fail("cribBuild on a sharded context: gather first (h10x_shard_gather) and build the crib on rank 0");
+  if (c->sharded) H10X_TRY(shard_materializeTables(c));     // collective: every rank looks the genomes up in the whole table (replicated crib)
   if (which < 0 || which > 1) return c->fail("crib genome %d: must be 0 or 1", which);
   if (nSeq > 32767) return c->fail("crib genome with %u sequences: CribInfo.chr is a 16-bit integer (hash10x.c:407), at most 32767 are supported", nSeq);
   const u32 U1 = c->hashNumber; const int k = c->prm.k;

@@ -1,28 +1,25 @@
-/* h10x_host.c — see h10x_host.h. Plain C; links libh10x_hip.so. */
+/* h10x_host.c — see h10x_host.h. Plain C; links libh10x_hip.so. No compute here: files, Array bookkeeping, text. */
 #define _GNU_SOURCE
 #include "h10x_host.h"
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 #include <stdarg.h>
+#include <limits.h>
 #include <time.h>
-
+#include <fcntl.h>
+#include <unistd.h>
 #include <sys/types.h>
+#include <sys/stat.h>
+
 #define ARRAY_MAGIC 8918274                            /* array.h:56 */
 typedef struct { int32_t magic, pad0; uint64_t base; int32_t dim, size, max, pad1; } array_hdr;   /* array.h:41-50 */
 
 struct h10x_session {
   int k, w, r, B, N, chunk, ct, device;                /* params (hash10x.c:25-33) */
   int timing;                                          /* measurement hook: enable hipEvent timers on every new context */
-  int clusterLds;                                      /* test knob forwarded to h10x_set_option("cluster_lds_budget") */
-  int firstCap;                                        /* test knob forwarded to h10x_set_option("cluster_first_cap") */
-  int firstGlobal;                                     /* test knob forwarded to h10x_set_option("cluster_first_global") */
-  int bigRanks;                                        /* tuning knob forwarded to h10x_set_option("cluster_big_ranks") */
-  int dbgSkip;                                         /* diagnostic knob forwarded to h10x_set_option("cluster_dbg_skip") */
-  int threads0, budget0;                               /* tuning knobs forwarded to h10x_set_option("cluster_threads0" / "cluster_budget0") */
-  int stamps;                                          /* diagnostic knob forwarded to h10x_set_option("cluster_stamps") */
-  int maxSlots;                                        /* test knob forwarded to h10x_set_option("stage_a_max_slots") */
-  int16_t *cribChr; uint16_t *cribPos; uint8_t *cribType; uint32_t cribN;   /* host copy of crib[] / cribType[] for the reports */
+  int knob[11];                                        /* test / tuning knobs forwarded to h10x_set_option (names in knobName[]) */
+  int16_t *cribChr; uint16_t *cribPos; uint8_t *cribType; uint32_t *cribDepth; uint32_t cribN;   /* per-hash host copies for the report texts */
   h10x_ctx *ctx;
   int ctxK, ctxW, ctxR, ctxB, ctxDev;                   /* parameters the live context was created with */
   /* Array bookkeeping of the reference for the two arrays that are dumped raw into .hash */
@@ -30,6 +27,9 @@ struct h10x_session {
   uint32_t *depthTail; int depthTailFrom;              /* entries [hashNumber, dim) as read from a file (normally zero) */
   char err[1024];
 };
+enum { N_KNOBS = 11 };
+static const char *const knobName[N_KNOBS] = {"cluster_stamps", "cluster_lds_budget", "cluster_first_global", "cluster_first_cap", "cluster_dbg_skip",
+                                              "cluster_big_ranks", "cluster_threads0", "cluster_budget0", "shard_row_shift", "shard_rows_fake_base", "stage_a_max_slots"};
 
 static int fail(h10x_session *s, const char *fmt, ...) {
   va_list ap; va_start(ap, fmt); vsnprintf(s->err, sizeof s->err, fmt, ap); va_end(ap);
@@ -41,36 +41,24 @@ h10x_session *h10x_session_new(void) {
   h10x_session *s = (h10x_session *)calloc(1, sizeof *s);
   if (!s) return 0;
   s->k = 21; s->w = 31; s->r = 17; s->B = 28; s->N = 0; s->chunk = 100000; s->ct = 5; s->device = 0;
+  s->knob[8] = -1;                                     /* shard_row_shift: as small as the offsets allow */
   s->blocksDim = 1200;                                 /* arrayCreate(1200, ClusterBlock), hash10x.c:1151 */
   return s;
 }
+static void crib_free(h10x_session *s) { free(s->cribChr); free(s->cribPos); free(s->cribType); free(s->cribDepth); s->cribChr = 0; s->cribPos = 0; s->cribType = 0; s->cribDepth = 0; s->cribN = 0; }
 void h10x_session_free(h10x_session *s) {
   if (!s) return;
   if (s->ctx) h10x_destroy(s->ctx);
-  free(s->depthTail); free(s->cribChr); free(s->cribPos); free(s->cribType); free(s);
+  crib_free(s); free(s->depthTail); free(s);
 }
 const char *h10x_session_error(const h10x_session *s) { return s->err; }
 h10x_ctx *h10x_session_ctx(h10x_session *s) { return s->ctx; }
 
 static int *param_slot(h10x_session *s, const char *n) {
-  if (!strcmp(n, "k")) return &s->k;
-  if (!strcmp(n, "w")) return &s->w;
-  if (!strcmp(n, "r")) return &s->r;
-  if (!strcmp(n, "B")) return &s->B;
-  if (!strcmp(n, "N")) return &s->N;
-  if (!strcmp(n, "c")) return &s->chunk;
-  if (!strcmp(n, "ct")) return &s->ct;
-  if (!strcmp(n, "device")) return &s->device;
-  if (!strcmp(n, "stage_a_max_slots")) return &s->maxSlots;
-  if (!strcmp(n, "timing")) return &s->timing;
-  if (!strcmp(n, "cluster_stamps")) return &s->stamps;
-  if (!strcmp(n, "cluster_lds_budget")) return &s->clusterLds;
-  if (!strcmp(n, "cluster_first_global")) return &s->firstGlobal;
-  if (!strcmp(n, "cluster_first_cap")) return &s->firstCap;
-  if (!strcmp(n, "cluster_dbg_skip")) return &s->dbgSkip;
-  if (!strcmp(n, "cluster_big_ranks")) return &s->bigRanks;
-  if (!strcmp(n, "cluster_threads0")) return &s->threads0;
-  if (!strcmp(n, "cluster_budget0")) return &s->budget0;
+  static const char *const names[] = {"k", "w", "r", "B", "N", "c", "ct", "device", "timing", 0};
+  int *const slots[] = {&s->k, &s->w, &s->r, &s->B, &s->N, &s->chunk, &s->ct, &s->device, &s->timing};
+  for (int i = 0; names[i]; ++i) if (!strcmp(n, names[i])) return slots[i];
+  for (int i = 0; i < N_KNOBS; ++i) if (!strcmp(n, knobName[i])) return &s->knob[i];
   return 0;
 }
 int h10x_session_set(h10x_session *s, const char *name, int value) {
@@ -81,30 +69,25 @@ int h10x_session_get(const h10x_session *s, const char *name) {
   int *p = param_slot((h10x_session *)s, name); return p ? *p : 0;
 }
 
+/* arrayExtend (array.c:144-170) entered with n == dim when an Array is touched at ascending indices */
 int h10x_host_array_dim(int dim, int size, int64_t last) {
-  while (last >= dim) {                                /* arrayExtend is entered with n == dim when touching in order */
-    if (dim * size < (1 << 23)) dim *= 2; else dim += 1024 + ((1 << 23) / size);
-  }
+  while (last >= dim) dim = dim * size < (1 << 23) ? dim * 2 : dim + 1024 + (1 << 23) / size;
   return dim;
 }
 
+/* readFQB's chunk loop (hash10x.c:202-223) on a record image in host memory: how many records it consumes, or -1 with
+   "chunkSize too small". (The library replays the same loop from the run starts alone when the "chunk_size" option is set;
+   this host form serves callers that hold the records and want the verdict before any upload.) */
 int64_t h10x_host_check_chunks(const uint32_t *rec, uint64_t total, int N, int chunk, char *err, int errlen) {
-  int64_t nReads = 0; uint64_t pos = 0; uint32_t barcode = 0; int64_t curRead = 0;
-  while (!N || nReads < N) {
-    int64_t thisChunk = (int64_t)chunk - curRead;
-    if (thisChunk <= 0) { if (err) snprintf(err, errlen, "chunkSize too small"); return -1; }   /* hash10x.c:206 */
-    if (N && nReads + thisChunk > N) thisChunk = N - nReads;
-    uint64_t avail = total - pos;
-    int64_t nRec = avail < (uint64_t)thisChunk ? (int64_t)avail : thisChunk;
-    if (!nRec) break;
-    const uint32_t *u = rec + 30 * pos;
-    if (!barcode) barcode = u[0];
-    for (int64_t i = 0; i < nRec; ++i) {
-      if (u[30 * i] == barcode) ++curRead; else { curRead = 1; barcode = u[30 * i]; }
-    }
-    nReads += nRec; pos += (uint64_t)nRec;
+  const uint64_t limit = N > 0 && (uint64_t)N < total ? (uint64_t)N : total;
+  uint64_t pos = 0, runLen = 0; uint32_t cur = 0;
+  while (pos < limit) {
+    if (runLen >= (uint64_t)chunk) { if (err) snprintf(err, (size_t)errlen, "chunkSize too small"); return -1; }   /* hash10x.c:206 */
+    uint64_t end = pos + ((uint64_t)chunk - runLen); if (end > limit) end = limit;
+    if (!cur) cur = rec[30 * pos];                                                      /* hash10x.c:212 */
+    for (; pos < end; ++pos) { const uint32_t b = rec[30 * pos]; if (b == cur) ++runLen; else { cur = b; runLen = 1; } }
   }
-  return nReads;
+  return (int64_t)limit;
 }
 
 int h10x_host_partition(const uint32_t *rec, uint64_t n, int nParts, uint64_t *cut) {
@@ -119,22 +102,36 @@ int h10x_host_partition(const uint32_t *rec, uint64_t n, int nParts, uint64_t *c
   return 0;
 }
 
+/* the same cuts for a file, reading only the barcode words around each cut */
+int h10x_host_partition_file(const char *path, uint64_t n, int nParts, uint64_t *cut, char *err, int errlen) {
+  if (nParts < 1 || !cut) return -1;
+  const int fd = open(path, O_RDONLY);
+  if (fd < 0) { if (err) snprintf(err, (size_t)errlen, "failed to open fqb file %s", path); return -1; }
+  cut[0] = 0; cut[nParts] = n;
+  for (int g = 1; g < nParts; ++g) {
+    uint64_t p = (uint64_t)(((__uint128_t)n * (unsigned)g) / (unsigned)nParts);
+    if (p < cut[g - 1]) p = cut[g - 1];
+    uint32_t prev = 0, here = 0;
+    if (p > 0 && p < n && pread(fd, &prev, 4, (off_t)((p - 1) * 120)) != 4) { close(fd); if (err) snprintf(err, (size_t)errlen, "file read problem"); return -1; }
+    while (p > 0 && p < n) {
+      if (pread(fd, &here, 4, (off_t)(p * 120)) != 4) { close(fd); if (err) snprintf(err, (size_t)errlen, "file read problem"); return -1; }
+      if (here != prev) break;
+      ++p;
+    }
+    cut[g] = p;
+  }
+  close(fd);
+  return 0;
+}
+
 static double now_ms(void) { struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return 1e3 * t.tv_sec + 1e-6 * t.tv_nsec; }
 static int hostprof(void) { static int v = -1; if (v < 0) v = getenv("H10X_HOSTPROF") != 0; return v; }
 
-static int fail_ctx(h10x_session *s);
 /* measurement / test knobs follow the context */
 static int apply_options(h10x_session *s) {
   h10x_timing_enable(s->ctx, s->timing);
-  h10x_set_option(s->ctx, "cluster_stamps", s->stamps);
-  h10x_set_option(s->ctx, "cluster_lds_budget", s->clusterLds);
-  h10x_set_option(s->ctx, "cluster_first_global", s->firstGlobal);
-  h10x_set_option(s->ctx, "cluster_first_cap", s->firstCap);
-  h10x_set_option(s->ctx, "cluster_dbg_skip", s->dbgSkip);
-  h10x_set_option(s->ctx, "cluster_big_ranks", s->bigRanks);
-  h10x_set_option(s->ctx, "cluster_threads0", s->threads0);
-  h10x_set_option(s->ctx, "cluster_budget0", s->budget0);
-  if (h10x_set_option(s->ctx, "stage_a_max_slots", s->maxSlots)) return fail_ctx(s);
+  for (int i = 0; i < N_KNOBS; ++i) if (h10x_set_option(s->ctx, knobName[i], s->knob[i])) return fail_ctx(s);
+  if (h10x_set_option(s->ctx, "chunk_size", 0)) return fail_ctx(s);
   return 0;
 }
 
@@ -143,87 +140,123 @@ static int session_init(h10x_session *s) {
   double t0 = now_ms();
   /* same hasher/table/device as the live context: keep it (its stream and warm memory pool); the next
      read/load call resets every table, which is all initialise() does to the state */
-  if (s->ctx && s->ctxK == s->k && s->ctxW == s->w && s->ctxR == s->r && s->ctxB == s->B && s->ctxDev == s->device &&
-      s->k > 0 && s->w > 0) {
-    s->depthDim = 1 << 20; s->depthMax = 0;
-    free(s->depthTail); s->depthTail = 0;
-    h10x_timing_reset(s->ctx);                         /* timers are per initialise() */
-    return apply_options(s);
-  }
-  if (s->ctx) { h10x_destroy(s->ctx); s->ctx = 0; }
-  double t1 = now_ms();
-  h10x_params p; memset(&p, 0, sizeof p);
-  p.k = s->k; p.w = s->w; p.B = s->B;
-  if (s->k > 0 && s->w > 0) p.factor1 = h10x_factor1_from_seed(s->r);
-  if (h10x_create(&s->ctx, &p, s->device, 0, s->err, (int)sizeof s->err)) return -1;
-  s->ctxK = s->k; s->ctxW = s->w; s->ctxR = s->r; s->ctxB = s->B; s->ctxDev = s->device;
-  if (hostprof()) fprintf(stderr, "hostprof: destroy %.3f ms, create %.3f ms\n", t1 - t0, now_ms() - t1);
-  if (apply_options(s)) return -1;
+  const int reuse = s->ctx && s->ctxK == s->k && s->ctxW == s->w && s->ctxR == s->r && s->ctxB == s->B && s->ctxDev == s->device && s->k > 0 && s->w > 0;
+  if (!reuse) {
+    if (s->ctx) { h10x_destroy(s->ctx); s->ctx = 0; }
+    double t1 = now_ms();
+    h10x_params p; memset(&p, 0, sizeof p);
+    p.k = s->k; p.w = s->w; p.B = s->B;
+    if (s->k > 0 && s->w > 0) p.factor1 = h10x_factor1_from_seed(s->r);
+    if (h10x_create(&s->ctx, &p, s->device, 0, s->err, (int)sizeof s->err)) return -1;
+    s->ctxK = s->k; s->ctxW = s->w; s->ctxR = s->r; s->ctxB = s->B; s->ctxDev = s->device;
+    if (hostprof()) fprintf(stderr, "hostprof: destroy %.3f ms, create %.3f ms\n", t1 - t0, now_ms() - t1);
+  } else h10x_timing_reset(s->ctx);                    /* timers are per initialise() */
   s->depthDim = 1 << 20; s->depthMax = 0;             /* arrayCreate(1 << 20, U32), hash10x.c:1114 */
   free(s->depthTail); s->depthTail = 0;
-  return 0;
+  crib_free(s);
+  return apply_options(s);
 }
 
-static void after_readFQB(h10x_session *s) {
-  h10x_sizes z; h10x_get_sizes(s->ctx, &z);
+/* Array dims as --readFQB of the WHOLE file leaves them (global sizes on a sharded context) */
+static int after_readFQB(h10x_session *s) {
+  h10x_shard_info_t z; if (h10x_shard_info(s->ctx, &z)) return fail_ctx(s);
   /* hashDepth: touched at indices 1 .. hashNumber-1 in ascending order of first touch (hash10x.c:178) */
   if (z.hashNumber > 1) { s->depthDim = h10x_host_array_dim(1 << 20, 4, (int64_t)z.hashNumber - 1); s->depthMax = (int)z.hashNumber; }
   else { s->depthDim = 1 << 20; s->depthMax = 0; }
   /* clusterBlocks: arrayp(…,1) then one more per barcode (hash10x.c:200,218); main() creates it once */
-  s->blocksDim = h10x_host_array_dim(s->blocksDim > 0 ? s->blocksDim : 1200, 32, (int64_t)z.nBlocks - 1);
-  s->blocksMax = (int)z.nBlocks;
+  s->blocksDim = h10x_host_array_dim(s->blocksDim > 0 ? s->blocksDim : 1200, 32, (int64_t)z.nBlocksGlobal - 1);
+  s->blocksMax = (int)z.nBlocksGlobal;
+  return 0;
 }
 
+/* --readFQB on an image in host memory: -N truncates (hash10x.c:202,207); the chunk loop's two side effects (the
+   "chunkSize too small" death and the all-A-barcode quirk) are replayed inside the library from the run starts */
 int h10x_session_readFQB_mem(h10x_session *s, const uint32_t *rec, uint64_t n) {
   if (session_init(s)) return -1;
-  int64_t use = h10x_host_check_chunks(rec, n, s->N, s->chunk, s->err, (int)sizeof s->err);
-  if (use < 0) return -1;
-  if (h10x_read_fqb(s->ctx, rec, (uint64_t)use)) return fail_ctx(s);
-  after_readFQB(s);
-  return 0;
+  if (s->N > 0 && (uint64_t)s->N < n) n = (uint64_t)s->N;
+  if (h10x_set_option(s->ctx, "chunk_size", s->chunk)) return fail_ctx(s);
+  if (h10x_read_fqb(s->ctx, rec, n)) return fail_ctx(s);
+  return after_readFQB(s);
 }
 
+/* records already in HBM (pipelines, bench): -N only, no chunk semantics */
 int h10x_session_readFQB_dev(h10x_session *s, const uint32_t *devRec, uint64_t n) {
   if (session_init(s)) return -1;
-  if (s->N && (uint64_t)s->N < n) n = (uint64_t)s->N;
+  if (s->N > 0 && (uint64_t)s->N < n) n = (uint64_t)s->N;
   if (h10x_read_fqb_device(s->ctx, devRec, n)) return fail_ctx(s);
-  after_readFQB(s);
+  return after_readFQB(s);
+}
+
+/* records [first, first + n) of a file into a device buffer, 64 MiB at a time: the file never sits in host memory */
+static int stream_records(h10x_session *s, const char *path, uint64_t first, uint64_t n, void **devOut) {
+  enum { SLAB = 64 << 20 };
+  *devOut = 0;
+  const int fd = open(path, O_RDONLY);
+  if (fd < 0) return fail(s, "failed to open fqb file %s", path);                    /* hash10x.c:1201 */
+  void *dev = h10x_device_malloc(s->device, n ? n * 120 : 120);
+  char *slab = (char *)malloc(SLAB);
+  if (!dev || !slab) { close(fd); free(slab); if (dev) h10x_device_free(s->device, dev); return fail(s, "out of memory for %llu records", (unsigned long long)n); }
+  const uint64_t bytes = n * 120; uint64_t done = 0; int rc = 0;
+  while (done < bytes) {
+    const uint64_t want = bytes - done < SLAB ? bytes - done : SLAB;
+    uint64_t got = 0;
+    while (got < want) { const ssize_t r = pread(fd, slab + got, want - got, (off_t)(first * 120 + done + got)); if (r <= 0) break; got += (uint64_t)r; }
+    if (got != want) { rc = fail(s, "file read problem"); break; }                   /* hash10x.c:209 */
+    if (h10x_device_upload(s->device, (char *)dev + done, slab, want)) { rc = fail(s, "upload of %llu bytes to device %d failed", (unsigned long long)want, s->device); break; }
+    done += want;
+  }
+  close(fd); free(slab);
+  if (rc) { h10x_device_free(s->device, dev); return rc; }
+  *devOut = dev;
+  return 0;
+}
+static int file_records(h10x_session *s, const char *path, uint64_t *n) {
+  struct stat sb;
+  if (stat(path, &sb)) return fail(s, "failed to open fqb file %s", path);
+  *n = (uint64_t)sb.st_size / 120;                                                   /* fread(u,120,…) ignores a partial tail */
+  if (s->N > 0 && (uint64_t)s->N < *n) *n = (uint64_t)s->N;
   return 0;
 }
 
+int h10x_session_readFQB(h10x_session *s, const char *path) {
+  uint64_t n; void *dev;
+  if (file_records(s, path, &n)) return -1;
+  if (session_init(s)) return -1;
+  if (stream_records(s, path, 0, n, &dev)) return -1;
+  int rc = 0;
+  if (h10x_set_option(s->ctx, "chunk_size", s->chunk) || h10x_read_fqb_device(s->ctx, (const uint32_t *)dev, n)) rc = fail_ctx(s);
+  h10x_device_free(s->device, dev);
+  return rc ? rc : after_readFQB(s);
+}
+
+/* ---- sharded sessions: one per rank; every call below is collective ---- */
 int h10x_session_shardReadFQB_mem(h10x_session *s, h10x_comm *comm, const uint32_t *rec, uint64_t n) {
   if (session_init(s)) return -1;
   if (h10x_shard_attach(s->ctx, comm)) return fail(s, "h10x_shard_attach failed");
   if (h10x_shard_read_fqb(s->ctx, rec, n)) return fail_ctx(s);
-  return 0;
+  return after_readFQB(s);
 }
 int h10x_session_shardReadFQB_dev(h10x_session *s, h10x_comm *comm, const uint32_t *devRec, uint64_t n) {
   if (session_init(s)) return -1;
   if (h10x_shard_attach(s->ctx, comm)) return fail(s, "h10x_shard_attach failed");
   if (h10x_shard_read_fqb_device(s->ctx, devRec, n)) return fail_ctx(s);
-  return 0;
+  return after_readFQB(s);
+}
+/* this rank's records [first, first + n) of the (N-truncated) file, streamed into HBM; chunk semantics of the whole file */
+int h10x_session_shardReadFQB_file(h10x_session *s, h10x_comm *comm, const char *path, uint64_t first, uint64_t n) {
+  if (session_init(s)) return -1;
+  if (h10x_shard_attach(s->ctx, comm)) return fail(s, "h10x_shard_attach failed");
+  void *dev;
+  if (stream_records(s, path, first, n, &dev)) return -1;
+  int rc = 0;
+  if (h10x_set_option(s->ctx, "chunk_size", s->chunk) || h10x_shard_read_fqb_device(s->ctx, (const uint32_t *)dev, n)) rc = fail_ctx(s);
+  h10x_device_free(s->device, dev);
+  return rc ? rc : after_readFQB(s);
 }
 int h10x_session_shardGather(h10x_session *s) {
   if (!s->ctx) return fail(s, "no hash state loaded: use readFQB or readHash first");
   if (h10x_shard_gather(s->ctx)) return fail_ctx(s);
-  h10x_sizes z;
-  if (!h10x_get_sizes(s->ctx, &z) && z.nBlocks) after_readFQB(s);   /* Array dims as one --readFQB of the whole file would leave them */
   return 0;
-}
-
-int h10x_session_readFQB(h10x_session *s, const char *path) {
-  FILE *f = fopen(path, "rb");
-  if (!f) return fail(s, "failed to open fqb file %s", path);                      /* hash10x.c:1201 */
-  fseek(f, 0, SEEK_END); long long sz = ftell(f); fseek(f, 0, SEEK_SET);
-  uint64_t n = (uint64_t)sz / 120;                                                 /* fread(u,120,…) ignores a partial tail */
-  if (s->N && (uint64_t)s->N < n) n = (uint64_t)s->N;
-  uint32_t *rec = (uint32_t *)malloc(n ? n * 120 : 120);
-  if (!rec) { fclose(f); return fail(s, "myalloc failure requesting %lld bytes", sz); }
-  if (n && fread(rec, 120, n, f) != n) { fclose(f); free(rec); return fail(s, "file read problem"); }   /* hash10x.c:209 */
-  fclose(f);
-  int rc = h10x_session_readFQB_mem(s, rec, n);
-  free(rec);
-  return rc;
 }
 
 int h10x_session_hashDepthRange(h10x_session *s, int min, int max) {
@@ -237,106 +270,90 @@ int h10x_session_cluster(h10x_session *s, int codeMin, int codeMax) {
 int h10x_session_clusterSplit(h10x_session *s) {
   if (!s->ctx) return fail(s, "no hash state loaded: use readFQB or readHash first");
   if (h10x_cluster_split(s->ctx)) return fail_ctx(s);
-  h10x_sizes z; h10x_get_sizes(s->ctx, &z);
-  s->blocksDim = s->blocksMax = (int)z.nBlocks;                                    /* arrayCreate(n) + arrayMax = n, hash10x.c:961-962 */
+  h10x_shard_info_t z; if (h10x_shard_info(s->ctx, &z)) return fail_ctx(s);
+  s->blocksDim = s->blocksMax = (int)z.nBlocksGlobal;                                /* arrayCreate(n) + arrayMax = n, hash10x.c:961-962 */
   return 0;
 }
 
-/* histogramReport (hash10x.c:351-375), same arithmetic (ints and doubles) and text */
-static void histogram_report(FILE *f, const char *prefix, const int *a, int n) {
-  uint64_t sum = 0, total = 0;
-  for (int i = 0; i < n; ++i) { sum += (uint64_t)a[i]; total += (uint64_t)((int64_t)i * a[i]); }
-  uint64_t partSum = 0, partTotal = 0, max = 0, massMax = 0;
-  int median = 0, massMedian = 0, n99 = 0, nMass99 = 0, mode = 0, massMode = 0;
-  int t50 = (int)(sum * 0.5), tMass50 = (int)(total * 0.5), t99 = (int)(sum * 0.99), tMass99 = (int)(total * 0.99);
-  for (int i = 0; i < n; ++i) {
-    int v = a[i];
-    partSum += (uint64_t)v; partTotal += (uint64_t)((int64_t)i * v);
-    fprintf(f, "%s_HIST %6d %d %.4f %.4f\n", prefix, i, v, partSum / (double)sum, partTotal / (double)total);
-    if ((uint64_t)v > max) { mode = i; max = (uint64_t)v; }
-    if ((uint64_t)((int64_t)i * v) > massMax) { massMode = i; massMax = (uint64_t)((int64_t)i * v); }
-    if (partSum > (uint64_t)t50 && !median) median = i;
-    if (partTotal > (uint64_t)tMass50 && !massMedian) massMedian = i;
-    if (partSum > (uint64_t)t99 && !n99) n99 = i;
-    if (partTotal > (uint64_t)tMass99 && !nMass99) nMass99 = i;
-  }
-  fprintf(f, "%s_STATS MEAN %.1f", prefix, total / (double)sum);
-  fprintf(f, "  MODE %d  MEDIAN %d  PERCENT99 %d", mode, median, n99);
-  fprintf(f, "  MASS_MODE %d  N50 %d  N99 %d\n", massMode, massMedian, nMass99);
-}
-static int *hist_grow(int *h, int *cap, int need) {
-  if (need < *cap) return h;
-  int nc = *cap; while (nc <= need) nc *= 2;
-  h = (int *)realloc(h, (size_t)nc * sizeof(int)); memset(h + *cap, 0, (size_t)(nc - *cap) * sizeof(int)); *cap = nc;
-  return h;
-}
-
-int h10x_session_hashStats(h10x_session *s, FILE *f) {         /* hashDepthHist, hash10x.c:377-386 */
-  h10x_sizes z;
-  if (!s->ctx || h10x_get_sizes(s->ctx, &z) || !s->depthMax) { fprintf(stderr, "  no hash list to print stats for\n"); return 0; }
-  uint32_t *depth = (uint32_t *)calloc((size_t)z.hashNumber + 1, 4);
-  if (h10x_export(s->ctx, 0, 0, depth, 0, 0)) { free(depth); return fail_ctx(s); }
-  int cap = 1024, top = 0; int *h = (int *)calloc((size_t)cap, sizeof(int));
-  for (int i = 0; i < s->depthMax; ++i) {                      /* arrayMax(hashDepth) entries, index 0 included */
-    int d = (uint32_t)i < z.hashNumber ? (int)depth[i] : 0;
-    h = hist_grow(h, &cap, d); ++h[d]; if (d + 1 > top) top = d + 1;
-  }
-  histogram_report(f, "HASH_COUNT", h, top);
-  free(h); free(depth);
+/* ---------------------------------------------------------------------------------------------------------------------
+ * --writeHash (hash10x.c:244-267 + arrayWrite, array.c:213-218). The file's layout is known from the sizes alone
+ * (SURVEY App. B), so nothing is gathered: rank 0 creates the file at its final size and writes the headers, then every
+ * rank pwrites its share — a slice of each replicated table, and the blocks / ClusterHash records of its own segments at
+ * their place in file order. One rank (unsharded) is the same code. Heap-pointer fields are written as 0.
+ * ------------------------------------------------------------------------------------------------------------------- */
+static int put(int fd, const void *p, uint64_t n, uint64_t at) {
+  const char *c = (const char *)p;
+  while (n) { const ssize_t w = pwrite(fd, c, n > (1u << 30) ? (1u << 30) : n, (off_t)at); if (w <= 0) return -1; c += w; at += (uint64_t)w; n -= (uint64_t)w; }
   return 0;
 }
-
-int h10x_session_codeStats(h10x_session *s, FILE *f) {         /* codeSizeHist, hash10x.c:388-402 */
-  h10x_sizes z;
-  if (!s->ctx || h10x_get_sizes(s->ctx, &z) || !z.nBlocks) { fprintf(stderr, "  no barcodes to print stats for\n"); return 0; }
-  h10x_block *b = (h10x_block *)calloc((size_t)z.nBlocks, sizeof *b);
-  if (h10x_export(s->ctx, 0, 0, 0, b, 0)) { free(b); return fail_ctx(s); }
-  int capH = 1024, capC = 1024, topH = 0, topC = 0;
-  int *hh = (int *)calloc((size_t)capH, sizeof(int)), *hc = (int *)calloc((size_t)capC, sizeof(int));
-  for (uint32_t i = 0; i < z.nBlocks; ++i) {
-    int nh = (int)b[i].nHash, ns = (int)b[i].nSubCluster;
-    hh = hist_grow(hh, &capH, nh); ++hh[nh]; if (nh + 1 > topH) topH = nh + 1;
-    hc = hist_grow(hc, &capC, ns); ++hc[ns]; if (ns + 1 > topC) topC = ns + 1;
+/* elements [first, first + count) of a device table to the file at byte `at`, through a bounded host buffer */
+static int put_table(h10x_session *s, int fd, int table, size_t elem, uint64_t first, uint64_t count, uint64_t at, void *buf, size_t bufBytes, const char *what) {
+  const uint64_t step = bufBytes / elem;
+  for (uint64_t done = 0; done < count; ) {
+    const uint64_t n = count - done < step ? count - done : step;
+    if (h10x_export_slice(s->ctx, table, first + done, n, buf)) return fail_ctx(s);
+    if (table == H10X_TABLE_BLOCKS) for (uint64_t i = 0; i < n; ++i) ((h10x_block *)buf)[i].clusHash = 0;
+    if (put(fd, buf, n * elem, at + done * elem)) return fail(s, "%s", what);
+    done += n;
   }
-  histogram_report(f, "CODE_SIZE", hh, topH);
-  if (topC > 1) histogram_report(f, "CODE_CLUSTER", hc, topC);
-  free(hh); free(hc); free(b);
   return 0;
 }
-
-/* writeHashFile (hash10x.c:244-267) + arrayWrite (array.c:213-218); heap-pointer fields are written as 0 */
 int h10x_session_writeHash(h10x_session *s, const char *path) {
   if (!s->ctx) return fail(s, "no hash state loaded: use readFQB or readHash first");
-  h10x_sizes z; if (h10x_get_sizes(s->ctx, &z)) return fail_ctx(s);
+  h10x_shard_info_t z; if (h10x_shard_info(s->ctx, &z)) return fail_ctx(s);
+  if (h10x_shard_prepare_export(s->ctx)) return fail_ctx(s);                          /* collective: hashValue / hashIndex of the whole set */
   const uint64_t T = (uint64_t)1 << z.B;
-  uint32_t *hashIndex = (uint32_t *)malloc(T * 4);
-  uint64_t *hashValue = (uint64_t *)malloc((size_t)z.hashNumber * 8);
-  uint32_t *depth = (uint32_t *)calloc((size_t)s->depthDim > z.hashNumber ? (size_t)s->depthDim : z.hashNumber, 4);
-  h10x_block *blocks = (h10x_block *)calloc((size_t)s->blocksDim > z.nBlocks ? (size_t)s->blocksDim : z.nBlocks, sizeof(h10x_block));
-  h10x_clushash *ch = (h10x_clushash *)malloc(z.nClusHash ? z.nClusHash * 8 : 8);
-  int rc = 0; FILE *f = 0;
-  if (!hashIndex || !hashValue || !depth || !blocks || !ch) { rc = fail(s, "out of host memory for .hash export"); goto done; }
-  if (h10x_export(s->ctx, hashIndex, hashValue, depth, blocks, ch)) { rc = fail_ctx(s); goto done; }
-  if (s->depthTail)                                                                 /* bytes beyond max travel unchanged from --readHash */
-    for (int i = s->depthTailFrom; i < s->depthDim; ++i) depth[i] = s->depthTail[i - s->depthTailFrom];
-  for (uint32_t i = 0; i < z.nBlocks; ++i) blocks[i].clusHash = 0;
-  if (!(f = fopen(path, "wb"))) { rc = fail(s, "failed to open hash file %s", path); goto done; }
+  const uint64_t depthDim = (uint64_t)s->depthDim, blocksDim = (uint64_t)s->blocksDim > z.nBlocksGlobal ? (uint64_t)s->blocksDim : z.nBlocksGlobal;
+  const uint64_t oIndex = 16, oNumber = oIndex + 4 * T, oValue = oNumber + 4, oDepthHdr = oValue + 8 * (uint64_t)z.hashNumber, oDepth = oDepthHdr + 32,
+                 oBlocksHdr = oDepth + 4 * depthDim, oBlocks = oBlocksHdr + 32, oClus = oBlocks + 32 * blocksDim, total = oClus + 8 * z.nEntriesGlobal;
+  int fd = -1, rc = 0; enum { BUF = 32 << 20 }; void *buf = malloc(BUF);
+  h10x_shard_seg *segs = (h10x_shard_seg *)calloc((size_t)z.nSegs + 1, sizeof *segs);
+  if (!buf || !segs) { rc = fail(s, "out of host memory for .hash export"); goto done; }
+  if (h10x_shard_segments(s->ctx, segs, z.nSegs + 1)) { rc = fail_ctx(s); goto done; }
+  if (z.rank == 0) {
+    fd = open(path, O_WRONLY | O_CREAT | O_TRUNC, 0666);
+    if (fd < 0) rc = fail(s, "failed to open hash file %s", path);
+    else if (ftruncate(fd, (off_t)total)) rc = fail(s, "write fail 1");              /* unwritten parts read as zeros: Array tails beyond max */
+    else {
+      struct { char magic[4]; uint32_t version; uint16_t chs, cbs; int32_t B; } head = {{'1', '0', 'X', 'H'}, 2, 8, 32, z.B};
+      const array_hdr hd = {ARRAY_MAGIC, 0, 0, (int32_t)depthDim, 4, s->depthMax, 0}, hb = {ARRAY_MAGIC, 0, 0, (int32_t)blocksDim, 32, s->blocksMax, 0};
+      if (put(fd, &head, 16, 0)) rc = fail(s, "write fail 1");
+      else if (put(fd, &z.hashNumber, 4, oNumber)) rc = fail(s, "failed to write hashNumber");
+      else if (put(fd, &hd, 32, oDepthHdr)) rc = fail(s, "failed to write hashDepth array");
+      else if (put(fd, &hb, 32, oBlocksHdr)) rc = fail(s, "failed to write clusterBlocks array");
+      else if (s->depthTail && depthDim > (uint64_t)s->depthTailFrom &&              /* bytes beyond max travel unchanged from --readHash */
+               put(fd, s->depthTail, 4 * (depthDim - (uint64_t)s->depthTailFrom), oDepth + 4 * (uint64_t)s->depthTailFrom)) rc = fail(s, "failed to write hashDepth array");
+    }
+  }
+  {                                                                                  /* the file exists (or rank 0 failed) before anybody else opens it */
+    uint64_t bad = rc ? 1 : 0;
+    if (h10x_shard_allreduce_max_u64(s->ctx, &bad, 1)) { rc = fail_ctx(s); goto done; }
+    if (bad) { if (!rc) rc = fail(s, "rank 0 could not create %s", path); goto done; }
+  }
+  if (z.rank != 0 && (fd = open(path, O_WRONLY)) < 0) rc = fail(s, "failed to open hash file %s", path);
+  if (!rc) {                                                                         /* replicated tables: rank r writes the r-th part of each */
+    const uint64_t R = (uint64_t)z.nranks, me = (uint64_t)z.rank;
+    const uint64_t i0 = T * me / R, i1 = T * (me + 1) / R, v0 = (uint64_t)z.hashNumber * me / R, v1 = (uint64_t)z.hashNumber * (me + 1) / R;
+    const uint64_t dLimit = (uint64_t)z.hashNumber < depthDim ? z.hashNumber : depthDim, d0 = dLimit * me / R, d1 = dLimit * (me + 1) / R;
+    rc = put_table(s, fd, H10X_TABLE_HASHINDEX, 4, i0, i1 - i0, oIndex + 4 * i0, buf, BUF, "write fail 2");
+    if (!rc) rc = put_table(s, fd, H10X_TABLE_HASHVALUE, 8, v0, v1 - v0, oValue + 8 * v0, buf, BUF, "failed to write hashValue");
+    if (!rc) rc = put_table(s, fd, H10X_TABLE_HASHDEPTH, 4, d0, d1 - d0, oDepth + 4 * d0, buf, BUF, "failed to write hashDepth array");
+  }
+  for (uint32_t i = 0; !rc && i < z.nSegs; ++i) {                                    /* my blocks and their ClusterHash records */
+    if ((int)segs[i].rank != z.rank) continue;
+    rc = put_table(s, fd, H10X_TABLE_BLOCKS, 32, segs[i].localStart, segs[i].count, oBlocks + 32 * (uint64_t)segs[i].globalBase, buf, BUF, "failed to write clusterBlocks array");
+    if (!rc) rc = put_table(s, fd, H10X_TABLE_CLUSHASH, 8, segs[i].localEntryStart, segs[i].entries, oClus + 8 * segs[i].globalEntryStart, buf, BUF, "write fail 3");
+  }
+  if (fd >= 0 && close(fd) && !rc) rc = fail(s, "write fail 3");
+  fd = -1;
   {
-    uint32_t version = 2; uint16_t chs = 8, cbs = 32; int32_t B = z.B;
-    if (fwrite("10XH", 4, 1, f) != 1 || fwrite(&version, 4, 1, f) != 1 || fwrite(&chs, 2, 1, f) != 1 ||
-        fwrite(&cbs, 2, 1, f) != 1 || fwrite(&B, 4, 1, f) != 1) { rc = fail(s, "write fail 1"); goto done; }
-    if (fwrite(hashIndex, 4, T, f) != T) { rc = fail(s, "write fail 2"); goto done; }
-    if (fwrite(&z.hashNumber, 4, 1, f) != 1) { rc = fail(s, "failed to write hashNumber"); goto done; }
-    if (fwrite(hashValue, 8, z.hashNumber, f) != z.hashNumber) { rc = fail(s, "failed to write hashValue"); goto done; }
-    array_hdr h = {ARRAY_MAGIC, 0, 0, s->depthDim, 4, s->depthMax, 0};
-    if (fwrite(&h, 32, 1, f) != 1 || fwrite(depth, 4, (size_t)s->depthDim, f) != (size_t)s->depthDim) { rc = fail(s, "failed to write hashDepth array"); goto done; }
-    array_hdr hb = {ARRAY_MAGIC, 0, 0, s->blocksDim, 32, s->blocksMax, 0};
-    if (fwrite(&hb, 32, 1, f) != 1 || fwrite(blocks, 32, (size_t)s->blocksDim, f) != (size_t)s->blocksDim) { rc = fail(s, "failed to write clusterBlocks array"); goto done; }
-    if (z.nClusHash && fwrite(ch, 8, z.nClusHash, f) != z.nClusHash) { rc = fail(s, "write fail 3"); goto done; }
+    uint64_t bad = rc ? 1 : 0;
+    if (h10x_shard_allreduce_max_u64(s->ctx, &bad, 1)) { rc = fail_ctx(s); goto done; }
+    if (bad && !rc) rc = fail(s, "another rank failed to write %s", path);
   }
 done:
-  if (f) fclose(f);
-  free(hashIndex); free(hashValue); free(depth); free(blocks); free(ch);
+  if (fd >= 0) close(fd);
+  free(buf); free(segs);
   return rc;
 }
 
@@ -399,8 +416,96 @@ done:
 }
 
 /* ---------------------------------------------------------------------------------------------------------------------
+ * --hashStats / --codeStats (hash10x.c:351-402). The histograms are filled on the device (h10x_report_histogram) and
+ * summed over the ranks; what is left is the summary line and the table. The arithmetic keeps the reference's types so
+ * that the printed figures agree digit for digit: counts are ints in an Array of int, the running sums are U64, the four
+ * thresholds are doubles cut to int (hash10x.c:358), and i * count is an int product.
+ * ------------------------------------------------------------------------------------------------------------------- */
+static int cut_to_int(double v) { return v >= -2147483648.0 && v < 2147483648.0 ? (int)v : INT_MIN; }   /* what cvttsd2si leaves for an out-of-range value */
+typedef struct { uint64_t count, mass; } Running;
+/* smallest bin >= 1 whose running value exceeds the threshold (bin 0 cannot hold a median: `!median` stays true there) */
+static int first_over(const Running *run, int bins, int threshold, int useMass) {
+  for (int i = 1; i < bins; ++i) if ((useMass ? run[i].mass : run[i].count) > (uint64_t)(int64_t)threshold) return i;
+  return 0;
+}
+static void write_histogram(FILE *f, const char *prefix, const uint64_t *hist, int bins) {
+  Running *run = (Running *)calloc((size_t)bins + 1, sizeof *run);
+  uint64_t count = 0, mass = 0; int mode = 0, massMode = 0; uint64_t best = 0, bestMass = 0;
+  for (int i = 0; i < bins; ++i) {
+    const int n = (int)hist[i]; const int in = (int)((uint32_t)i * (uint32_t)n);      /* int product, as in the reference */
+    count += (uint64_t)(int64_t)n; mass += (uint64_t)(int64_t)in;
+    run[i].count = count; run[i].mass = mass;
+    if ((uint64_t)(int64_t)n > best) { best = (uint64_t)(int64_t)n; mode = i; }
+    if ((uint64_t)(int64_t)in > bestMass) { bestMass = (uint64_t)(int64_t)in; massMode = i; }
+  }
+  for (int i = 0; i < bins; ++i) fprintf(f, "%s_HIST %6d %d %.4f %.4f\n", prefix, i, (int)hist[i], run[i].count / (double)count, run[i].mass / (double)mass);
+  const int median = first_over(run, bins, cut_to_int(count * 0.5), 0), p99 = first_over(run, bins, cut_to_int(count * 0.99), 0);
+  const int n50 = first_over(run, bins, cut_to_int(mass * 0.5), 1), n99 = first_over(run, bins, cut_to_int(mass * 0.99), 1);
+  fprintf(f, "%s_STATS MEAN %.1f  MODE %d  MEDIAN %d  PERCENT99 %d  MASS_MODE %d  N50 %d  N99 %d\n", prefix, mass / (double)count, mode, median, p99, massMode, n50, n99);
+  free(run);
+}
+/* histogram of one source over this rank's part, summed over all ranks; *bins = largest value + 1 */
+static int gather_histogram(h10x_session *s, int which, uint64_t first, uint64_t count, uint64_t **hist, int *bins) {
+  uint32_t mx = 0;
+  if (h10x_report_max(s->ctx, which, first, count, &mx)) return fail_ctx(s);
+  uint64_t top = mx;
+  if (h10x_shard_allreduce_max_u64(s->ctx, &top, 1)) return fail_ctx(s);
+  *bins = (int)top + 1;
+  *hist = (uint64_t *)calloc((size_t)*bins, 8);
+  if (!*hist) return fail(s, "out of host memory for a histogram of %d bins", *bins);
+  if (h10x_report_histogram(s->ctx, which, first, count, (uint32_t)*bins, *hist) || h10x_shard_allreduce_sum_u64(s->ctx, *hist, (uint32_t)*bins)) { free(*hist); *hist = 0; return fail_ctx(s); }
+  return 0;
+}
+
+int h10x_session_hashStats(h10x_session *s, FILE *f) {         /* hashDepthHist: arrayMax(hashDepth) entries, index 0 included */
+  h10x_shard_info_t z;
+  if (!s->ctx || h10x_shard_info(s->ctx, &z) || !s->depthMax) { if (f) fprintf(stderr, "  no hash list to print stats for\n"); return 0; }
+  const uint64_t have = (uint64_t)s->depthMax < z.hashNumber ? (uint64_t)s->depthMax : z.hashNumber;
+  uint64_t *hist; int bins;
+  /* hashDepth is the same on every rank: rank 0's copy is the histogram, the others contribute nothing */
+  if (gather_histogram(s, 0, 0, z.rank == 0 ? have : 0, &hist, &bins)) return -1;
+  if ((uint64_t)s->depthMax > have) hist[0] += (uint64_t)s->depthMax - have;           /* entries of the Array beyond hashNumber are zeros */
+  if (f) write_histogram(f, "HASH_COUNT", hist, bins);
+  free(hist);
+  return 0;
+}
+
+int h10x_session_codeStats(h10x_session *s, FILE *f) {         /* codeSizeHist: every block of the Array, block 0 included */
+  h10x_shard_info_t z;
+  if (!s->ctx || h10x_shard_info(s->ctx, &z) || !z.nBlocksGlobal) { if (f) fprintf(stderr, "  no barcodes to print stats for\n"); return 0; }
+  h10x_shard_seg *segs = (h10x_shard_seg *)calloc((size_t)z.nSegs + 1, sizeof *segs);
+  if (!segs || h10x_shard_segments(s->ctx, segs, z.nSegs + 1)) { free(segs); return segs ? fail_ctx(s) : fail(s, "out of host memory"); }
+  int rc = 0;
+  for (int which = 1; which <= 2 && !rc; ++which) {
+    /* one pair of collectives per source: each rank histograms all its segments locally first */
+    uint64_t *sum = 0; int bins = 1; uint32_t mx = 0;
+    for (uint32_t i = 0; i < z.nSegs && !rc; ++i) if ((int)segs[i].rank == z.rank) { uint32_t m = 0; if (h10x_report_max(s->ctx, which, segs[i].localStart, segs[i].count, &m)) rc = fail_ctx(s); if (m > mx) mx = m; }
+    uint64_t top = mx;
+    if (!rc && h10x_shard_allreduce_max_u64(s->ctx, &top, 1)) rc = fail_ctx(s);
+    if (rc) break;
+    bins = (int)top + 1;
+    sum = (uint64_t *)calloc((size_t)bins, 8); uint64_t *part = (uint64_t *)calloc((size_t)bins, 8);
+    if (!sum || !part) { free(sum); free(part); rc = fail(s, "out of host memory for a histogram of %d bins", bins); break; }
+    for (uint32_t i = 0; i < z.nSegs && !rc; ++i) if ((int)segs[i].rank == z.rank) {
+      if (h10x_report_histogram(s->ctx, which, segs[i].localStart, segs[i].count, (uint32_t)bins, part)) rc = fail_ctx(s);
+      for (int b = 0; b < bins; ++b) sum[b] += part[b];
+    }
+    if (!rc && h10x_shard_allreduce_sum_u64(s->ctx, sum, (uint32_t)bins)) rc = fail_ctx(s);
+    if (!rc) {
+      sum[0] += 1;                                                                     /* block 0: nHash 0, nSubCluster 0 */
+      if (f && which == 1) write_histogram(f, "CODE_SIZE", sum, bins);
+      if (f && which == 2 && bins > 1) write_histogram(f, "CODE_CLUSTER", sum, bins);   /* arrayMax(clusterHist) > 1 */
+    }
+    free(sum); free(part);
+  }
+  free(segs);
+  return rc;
+}
+
+/* ---------------------------------------------------------------------------------------------------------------------
  * crib: --cribBuild, --clusterReport, --cribSummary (hash10x.c:406-521, 870-952, 1017-1061). The genomes are hashed and
- * looked up on the device (h10x_crib_genome / h10x_crib_finish); what is left here is the FASTA reader and the text.
+ * looked up on the device (h10x_crib_genome / h10x_crib_finish) and the per-cluster figures are reduced there
+ * (h10x_cluster_report); what is left here is the FASTA reader and the text.
  * ------------------------------------------------------------------------------------------------------------------- */
 static const char *const cribTypeName[5] = {"err", "htA", "htB", "hom", "mul"};     /* hash10x.c:417 */
 
@@ -453,8 +558,7 @@ static void crib_array_stats(FILE *f, const uint32_t *a, uint32_t arrayMax) {
   fprintf(f, "  %d mean %.1f min %d max %d\n", sum, total / sum, min, max);
 }
 
-static void crib_free(h10x_session *s) { free(s->cribChr); free(s->cribPos); free(s->cribType); s->cribChr = 0; s->cribPos = 0; s->cribType = 0; s->cribN = 0; }
-
+/* out = NULL: take part (collective on a sharded context) without printing */
 int h10x_session_cribBuild(h10x_session *s, const char *fa1, const char *fa2, FILE *out, int printTables) {
   if (!s->ctx) return fail(s, "no hash state loaded: use readFQB or readHash first");
   crib_free(s);
@@ -467,10 +571,11 @@ int h10x_session_cribBuild(h10x_session *s, const char *fa1, const char *fa2, FI
     const int rc = h10x_crib_genome(s->ctx, codes, start, nSeq, g, &nPresent, &nAbsent);
     free(codes); free(start);
     if (rc) return fail_ctx(s);
-    fprintf(out, "  read %d known and %d unknown hashes from %d sequences in crib genome\n", (int)nPresent, (int)nAbsent, (int)nSeq);
-    if (out != stdout) printf("  read %d known and %d unknown hashes from %d sequences in crib genome\n", (int)nPresent, (int)nAbsent, (int)nSeq);
+    if (out) fprintf(out, "  read %d known and %d unknown hashes from %d sequences in crib genome\n", (int)nPresent, (int)nAbsent, (int)nSeq);
+    if (out && out != stdout) printf("  read %d known and %d unknown hashes from %d sequences in crib genome\n", (int)nPresent, (int)nAbsent, (int)nSeq);
   }
   if (h10x_crib_finish(s->ctx)) return fail_ctx(s);
+  if (!out) return 0;
   uint32_t dim = 0, amax[4];
   if (h10x_crib_sizes(s->ctx, &dim, amax)) return fail_ctx(s);
   uint32_t *hist = (uint32_t *)calloc((size_t)4 * dim + 4, 4);
@@ -491,141 +596,188 @@ int h10x_session_cribBuild(h10x_session *s, const char *fa1, const char *fa2, FI
   return 0;
 }
 
-/* host copies of crib[] / cribType[] for the text reports, fetched once per crib */
-static int crib_fetch(h10x_session *s) {
-  h10x_sizes z; if (h10x_get_sizes(s->ctx, &z)) return fail_ctx(s);
-  if (s->cribChr && s->cribN == z.hashNumber) return 0;
+/* per-hash host copies for the report texts (crib[] / cribType[] / hashDepth[]: 9 bytes per distinct hash), fetched once per crib */
+static int crib_fetch(h10x_session *s, uint32_t hashNumber) {
+  if (s->cribChr && s->cribN == hashNumber) return 0;
   crib_free(s);
-  s->cribChr = (int16_t *)malloc((size_t)z.hashNumber * 2); s->cribPos = (uint16_t *)malloc((size_t)z.hashNumber * 2); s->cribType = (uint8_t *)malloc(z.hashNumber);
-  if (!s->cribChr || !s->cribPos || !s->cribType) { crib_free(s); return fail(s, "out of host memory for the crib"); }
-  if (h10x_crib_export(s->ctx, s->cribChr, s->cribPos, s->cribType, 0)) { crib_free(s); return fail_ctx(s); }
-  s->cribN = z.hashNumber;
+  s->cribChr = (int16_t *)malloc((size_t)hashNumber * 2); s->cribPos = (uint16_t *)malloc((size_t)hashNumber * 2);
+  s->cribType = (uint8_t *)malloc(hashNumber); s->cribDepth = (uint32_t *)malloc((size_t)hashNumber * 4);
+  if (!s->cribChr || !s->cribPos || !s->cribType || !s->cribDepth) { crib_free(s); return fail(s, "out of host memory for the crib"); }
+  if (h10x_crib_export(s->ctx, s->cribChr, s->cribPos, s->cribType, 0) || h10x_export_slice(s->ctx, H10X_TABLE_HASHDEPTH, 0, hashNumber, s->cribDepth)) { crib_free(s); return fail_ctx(s); }
+  s->cribN = hashNumber;
   return 0;
 }
 
-/* cribText (hash10x.c:511-521) */
-static const char *crib_text(const h10x_session *s, const uint32_t *depth, uint32_t x, char *text) {
-  char *t = text;
-  t += sprintf(t, "%d", (int)x);
-  if (s->cribChr) t += sprintf(t, ":%s", cribTypeName[s->cribType[x]]);
-  if (s->cribChr && s->cribType[x] > 0 && s->cribType[x] < 4) t += sprintf(t, "_%d.%d", (int)s->cribChr[x], (int)s->cribPos[x]);
-  sprintf(t, "-%d", (int)depth[x]);
-  return text;
+/* a growing text buffer */
+typedef struct { char *p; size_t n, cap; } Text;
+static int text_room(Text *t, size_t more) {
+  if (t->n + more <= t->cap) return 0;
+  size_t nc = t->cap ? t->cap : 1 << 16; while (nc < t->n + more) nc *= 2;
+  char *q = (char *)realloc(t->p, nc); if (!q) return -1;
+  t->p = q; t->cap = nc; return 0;
+}
+static int text_printf(Text *t, const char *fmt, ...) {
+  if (text_room(t, 512)) return -1;
+  va_list ap; va_start(ap, fmt); const int w = vsnprintf(t->p + t->n, t->cap - t->n, fmt, ap); va_end(ap);
+  if (w < 0) return -1;
+  t->n += (size_t)w; return 0;
+}
+static int text_bytes(Text *t, const void *p, size_t n) { if (text_room(t, n)) return -1; memcpy(t->p + t->n, p, n); t->n += n; return 0; }
+
+/* the lines of one block (hash10x.c:917-947) from its device-side figures */
+static int report_block_lines(const h10x_session *s, Text *t, uint32_t code, const h10x_block *b, const h10x_block_rep *br, const h10x_cluster_rep *cl, int haveCrib) {
+  if (text_printf(t, "  CLUSTER_SUMMARY %d nRead %d nHash %d nGoodHash %d nClusHash %d nClusRead %d nSubCluster %d\n",
+                  (int)code, (int)b->nRead, (int)(code ? b->nHash : 0), (int)br->nGood, (int)br->nClusHash, (int)br->nClusRead, (int)b->nSubCluster)) return -1;
+  const uint32_t nSub = b->nSubCluster > 255 ? 255 : b->nSubCluster;
+  for (uint32_t j = 1; j <= nSub; ++j) {
+    const h10x_cluster_rep *r = &cl[j - 1];
+    if (!r->n) continue;
+    if (text_printf(t, "    CODE_CLUSTER %d %d : %d reads %d hashes", (int)code, (int)j, (int)r->nRead, (int)r->n)) return -1;
+    if (haveCrib) {
+      if (text_printf(t, " %d hom, %d htA, %d htB, %d mul, %d err", (int)r->nt[3], (int)r->nt[1], (int)r->nt[2], (int)r->nt[4], (int)r->nt[0])) return -1;
+      if (r->chr && text_printf(t, "  chr %d pos %d %d", (int)r->chr, (int)r->pMin, (int)r->pMax - (int)r->pMin + 1)) return -1;
+      if (r->nBad) {
+        if (text_printf(t, "  OTHER %d", (int)r->nBad)) return -1;
+        for (uint32_t q = 0; q < r->nOtherListed && q < 10; ++q) {                   /* cribText (hash10x.c:511-521) */
+          const uint32_t x = r->other[q]; const int ty = s->cribType[x];
+          if (text_printf(t, " %d:%s", (int)x, cribTypeName[ty])) return -1;
+          if (ty > 0 && ty < 4 && text_printf(t, "_%d.%d", (int)s->cribChr[x], (int)s->cribPos[x])) return -1;
+          if (text_printf(t, "-%d", (int)s->cribDepth[x])) return -1;
+        }
+      }
+    }
+    if (text_bytes(t, "\n", 1)) return -1;
+  }
+  return 0;
 }
 
-/* codeClusterReport (hash10x.c:870-952): per barcode a CLUSTER_SUMMARY line and one CODE_CLUSTER line per sub-cluster
-   with its reads, hashes, crib composition, the chromosome / position span of its first located hash and the hashes
-   that disagree with it. With or without a crib, like the reference. */
+/* codeClusterReport (hash10x.c:870-952). Every rank turns its blocks of [codeMin, codeMax) into text (figures from
+   h10x_cluster_report, in runs of at most 64 k blocks) and hands rank 0 one package per run: {first global block, blocks,
+   text bytes} + text + the blocks' pointToMin and nGoodHash, which rank 0 adds up in file order for MIN_POINT_DENSITY (the
+   reference's double sum is order dependent). out = NULL on the other ranks. */
+typedef struct { uint32_t first, count; uint64_t textBytes; } RunHead;
 int h10x_session_clusterReport(h10x_session *s, int codeMin, int codeMax, FILE *out) {
   if (!s->ctx) return fail(s, "no hash state loaded: use readFQB or readHash first");
-  h10x_sizes z; if (h10x_get_sizes(s->ctx, &z)) return fail_ctx(s);
-  if (!codeMax) codeMax = (int)z.nBlocks;                                            /* hash10x.c:1263-1264: codeMin 0 stays 0 (block 0 is reported, empty) */
-  if (codeMin < 0 || codeMax > (int)z.nBlocks) return fail(s, "clusterReport code range %d..%d outside 0..%u", codeMin, codeMax, z.nBlocks);
-  uint32_t sizes_dim = 0; const int haveCrib = h10x_crib_sizes(s->ctx, &sizes_dim, 0) == 0;
-  if (haveCrib) { if (crib_fetch(s)) return -1; } else crib_free(s);
-  int rc = 0;
-  h10x_block *blocks = (h10x_block *)calloc((size_t)z.nBlocks + 1, sizeof *blocks);
-  h10x_clushash *ch = (h10x_clushash *)malloc(z.nClusHash ? z.nClusHash * 8 : 8);
-  uint32_t *depth = (uint32_t *)calloc((size_t)z.hashNumber + 1, 4), *nGood = (uint32_t *)calloc((size_t)z.nBlocks + 1, 4);
-  typedef struct { int n, nRead, nt[5]; int16_t chr; uint16_t pMin, pMax; int nBad, bad; } ReportInfo;
-  ReportInfo *info = 0; int *readClus = 0, *badLink = 0; size_t capInfo = 0, capRead = 0, capLink = 0;
-  if (!blocks || !ch || !depth || !nGood) { rc = fail(s, "out of host memory for clusterReport"); goto done; }
-  if (h10x_export(s->ctx, 0, 0, depth, blocks, ch)) { rc = fail_ctx(s); goto done; }
-  if (h10x_export_ngood(s->ctx, nGood)) { rc = fail_ctx(s); goto done; }
-  {
-    uint64_t off = 0, totalGoodHash = 0; double totalPointToMin = 0.0;
-    for (int c = 1; c < codeMin; ++c) off += blocks[c].nHash;
-    for (int code = codeMin; code < codeMax; ++code) {
-      const h10x_block *b = &blocks[code]; const h10x_clushash *e = ch + off; off += b->nHash;
-      const size_t nInfo = (size_t)b->nSubCluster + 1;
-      if (nInfo > capInfo) { capInfo = nInfo * 2; info = (ReportInfo *)realloc(info, capInfo * sizeof *info); }
-      if ((size_t)b->nRead + 1 > capRead) { capRead = ((size_t)b->nRead + 1) * 2; readClus = (int *)realloc(readClus, capRead * sizeof(int)); }
-      if ((size_t)b->nHash + 1 > capLink) { capLink = ((size_t)b->nHash + 1) * 2; badLink = (int *)realloc(badLink, capLink * sizeof(int)); }
-      memset(info, 0, nInfo * sizeof *info); memset(readClus, 0, ((size_t)b->nRead + 1) * sizeof(int)); memset(badLink, 0, ((size_t)b->nHash + 1) * sizeof(int));
-      int nClusHash = 0;
-      for (uint32_t i = 0; i < b->nHash; ++i) {
-        const int cl = e[i].subCluster; if (!cl) continue;
-        ++nClusHash;
-        if (e[i].read < b->nRead) readClus[e[i].read] = cl;
-        if ((size_t)cl >= nInfo) continue;                                           /* stale label beyond nSubCluster: out of bounds in the reference */
-        ReportInfo *r = &info[cl];
-        ++r->n;
-        const uint32_t bh = e[i].hash;
-        if (haveCrib) {
-          const int t = s->cribType[bh];
-          ++r->nt[t];
-          if (t > 0 && t < 4) {
-            const int16_t hc = s->cribChr[bh]; const uint16_t hp = s->cribPos[bh];
-            if (!r->chr) { r->chr = hc; r->pMin = r->pMax = hp; }
-            else if (hc == r->chr) { if (hp < r->pMin) r->pMin = hp; if (hp > r->pMax) r->pMax = hp; }
-            else { ++r->nBad; badLink[i] = r->bad; r->bad = (int)i; }
-          }
-        }
+  h10x_shard_info_t z; if (h10x_shard_info(s->ctx, &z)) return fail_ctx(s);
+  if (!codeMax) codeMax = (int)z.nBlocksGlobal;                                      /* hash10x.c:1263-1264: codeMin 0 stays 0 (block 0 is reported, empty) */
+  if (codeMin < 0 || codeMax > (int)z.nBlocksGlobal) return fail(s, "clusterReport code range %d..%d outside 0..%u", codeMin, codeMax, z.nBlocksGlobal);
+  uint32_t histDim = 0; const int haveCrib = h10x_crib_sizes(s->ctx, &histDim, 0) == 0;
+  if (haveCrib) { if (crib_fetch(s, z.hashNumber)) return -1; } else crib_free(s);
+  enum { RUN = 65536 };
+  int rc = 0; Text pack = {0, 0, 0}, lines = {0, 0, 0};
+  h10x_shard_seg *segs = (h10x_shard_seg *)calloc((size_t)z.nSegs + 1, sizeof *segs);
+  h10x_block *blocks = (h10x_block *)malloc((size_t)RUN * sizeof *blocks);
+  h10x_block_rep *brep = (h10x_block_rep *)malloc((size_t)RUN * sizeof *brep);
+  h10x_cluster_rep *crep = 0; uint64_t crepCap = 0;
+  double *p2m = (double *)malloc((size_t)RUN * 8); uint32_t *good = (uint32_t *)malloc((size_t)RUN * 4);
+  if (!segs || !blocks || !brep || !p2m || !good) { rc = fail(s, "out of host memory for clusterReport"); goto done; }
+  if (h10x_shard_segments(s->ctx, segs, z.nSegs + 1)) { rc = fail_ctx(s); goto done; }
+  if (z.rank == 0 && codeMin == 0 && codeMax > 0) {                                  /* block 0 belongs to no segment: all zeros */
+    const RunHead h = {0, 1, 0}; const double zero = 0.0; const uint32_t g0 = 0; Text one = {0, 0, 0};
+    h10x_block b0; memset(&b0, 0, sizeof b0); h10x_block_rep r0; memset(&r0, 0, sizeof r0);
+    if (report_block_lines(s, &one, 0, &b0, &r0, 0, haveCrib)) { free(one.p); rc = fail(s, "out of host memory for clusterReport"); goto done; }
+    RunHead hh = h; hh.textBytes = one.n;
+    if (text_bytes(&pack, &hh, sizeof hh) || text_bytes(&pack, one.p, one.n) || text_bytes(&pack, &zero, 8) || text_bytes(&pack, &g0, 4)) { free(one.p); rc = fail(s, "out of host memory for clusterReport"); goto done; }
+    free(one.p);
+  }
+  for (uint32_t i = 0; i < z.nSegs && !rc; ++i) {
+    if ((int)segs[i].rank != z.rank) continue;
+    int64_t g0 = segs[i].globalBase, g1 = (int64_t)segs[i].globalBase + segs[i].count;
+    if (g0 < codeMin) g0 = codeMin;
+    if (g1 > codeMax) g1 = codeMax;
+    for (int64_t g = g0; g < g1 && !rc; g += RUN) {
+      const uint32_t n = (uint32_t)(g1 - g < RUN ? g1 - g : RUN), local = segs[i].localStart + (uint32_t)(g - segs[i].globalBase);
+      if (h10x_export_slice(s->ctx, H10X_TABLE_BLOCKS, local, n, blocks)) { rc = fail_ctx(s); break; }
+      uint64_t nClus = 0; for (uint32_t b = 0; b < n; ++b) nClus += blocks[b].nSubCluster > 255 ? 255 : blocks[b].nSubCluster;
+      if (nClus + 1 > crepCap) { free(crep); crepCap = (nClus + 1) * 2; crep = (h10x_cluster_rep *)malloc(crepCap * sizeof *crep); if (!crep) { rc = fail(s, "out of host memory for clusterReport"); break; } }
+      uint64_t got = 0;
+      if (h10x_cluster_report(s->ctx, local, n, brep, crep, crepCap, &got)) { rc = fail_ctx(s); break; }
+      lines.n = 0; uint64_t at = 0;
+      for (uint32_t b = 0; b < n; ++b) {
+        if (report_block_lines(s, &lines, (uint32_t)g + b, &blocks[b], &brep[b], crep + at, haveCrib)) { rc = fail(s, "out of host memory for clusterReport"); break; }
+        at += blocks[b].nSubCluster > 255 ? 255 : blocks[b].nSubCluster;
+        p2m[b] = blocks[b].pointToMin; good[b] = brep[b].nGood;
       }
-      int nClusRead = 0;
-      for (uint32_t i = 0; i < b->nRead; ++i) { const int cl = readClus[i]; if (cl) { if ((size_t)cl < nInfo) ++info[cl].nRead; ++nClusRead; } }
-      fprintf(out, "  CLUSTER_SUMMARY %d nRead %d nHash %d nGoodHash %d nClusHash %d nClusRead %d nSubCluster %d\n",
-              code, (int)b->nRead, (int)b->nHash, (int)nGood[code], nClusHash, nClusRead, (int)b->nSubCluster);
-      for (uint32_t i = 1; i <= b->nSubCluster; ++i) {
-        const ReportInfo *r = &info[i]; if (!r->n) continue;
-        fprintf(out, "    CODE_CLUSTER %d %d : %d reads %d hashes", code, (int)i, r->nRead, r->n);
-        if (haveCrib) {
-          fprintf(out, " %d hom, %d htA, %d htB, %d mul, %d err", r->nt[3], r->nt[1], r->nt[2], r->nt[4], r->nt[0]);
-          if (r->chr) fprintf(out, "  chr %d pos %d %d", (int)r->chr, (int)r->pMin, (int)r->pMax - (int)r->pMin + 1);
-          if (r->nBad) {
-            fprintf(out, "  OTHER %d", r->nBad);
-            int x = r->bad, j = 10; char text[64];
-            while (x && j--) { fprintf(out, " %s", crib_text(s, depth, e[x].hash, text)); x = badLink[x]; }
-          }
-        }
-        fputc('\n', out);
-      }
-      totalGoodHash += nGood[code];
-      totalPointToMin += b->pointToMin;
+      const RunHead h = {(uint32_t)g, n, lines.n};
+      if (!rc && (text_bytes(&pack, &h, sizeof h) || text_bytes(&pack, lines.p, lines.n) || text_bytes(&pack, p2m, (size_t)n * 8) || text_bytes(&pack, good, (size_t)n * 4)))
+        rc = fail(s, "out of host memory for clusterReport");
     }
-    if (totalGoodHash) fprintf(out, "  MIN_POINT_DENSITY %.3f\n", totalPointToMin / totalGoodHash);
+  }
+  {                                                                                  /* to rank 0, in any order; printed by first block */
+    uint64_t bad = rc ? 1 : 0, total = pack.n;
+    if (h10x_shard_allreduce_max_u64(s->ctx, &bad, 1) || h10x_shard_allreduce_sum_u64(s->ctx, &total, 1)) { rc = fail_ctx(s); goto done; }
+    if (bad) { if (!rc) rc = fail(s, "clusterReport failed on another rank"); goto done; }
+    char *all = z.rank == 0 ? (char *)malloc(total + 1) : 0; uint64_t *counts = (uint64_t *)calloc((size_t)z.nranks, 8);
+    if ((z.rank == 0 && !all) || !counts) { free(all); free(counts); rc = fail(s, "out of host memory for clusterReport"); goto done; }
+    if (h10x_shard_gather_bytes(s->ctx, pack.p, pack.n, all, total, counts)) { free(all); free(counts); rc = fail_ctx(s); goto done; }
+    if (z.rank == 0 && out) {
+      size_t nRuns = 0, capRuns = 64; const char **runs = (const char **)malloc(capRuns * sizeof *runs);
+      for (uint64_t o = 0; o < total; ) {
+        const RunHead *h = (const RunHead *)(all + o);
+        if (nRuns == capRuns) { capRuns *= 2; runs = (const char **)realloc(runs, capRuns * sizeof *runs); }
+        runs[nRuns++] = all + o;
+        o += sizeof *h + h->textBytes + (uint64_t)h->count * 12;
+      }
+      for (size_t a = 1; a < nRuns; ++a) {                                           /* few runs: insertion sort by first block */
+        const char *r = runs[a]; size_t b = a;
+        while (b > 0 && ((const RunHead *)runs[b - 1])->first > ((const RunHead *)r)->first) { runs[b] = runs[b - 1]; --b; }
+        runs[b] = r;
+      }
+      uint64_t totalGood = 0; double totalPoint = 0.0;
+      for (size_t a = 0; a < nRuns; ++a) {
+        RunHead h; memcpy(&h, runs[a], sizeof h);
+        const char *text = runs[a] + sizeof h;
+        fwrite(text, 1, h.textBytes, out);
+        for (uint32_t b = 0; b < h.count; ++b) {
+          double p; uint32_t g; memcpy(&p, text + h.textBytes + (size_t)b * 8, 8); memcpy(&g, text + h.textBytes + (size_t)h.count * 8 + (size_t)b * 4, 4);
+          totalGood += g; totalPoint += p;
+        }
+      }
+      if (totalGood) fprintf(out, "  MIN_POINT_DENSITY %.3f\n", totalPoint / totalGood);
+      free(runs);
+    }
+    free(all); free(counts);
   }
 done:
-  free(blocks); free(ch); free(depth); free(nGood); free(info); free(readClus); free(badLink);
+  free(pack.p); free(lines.p); free(segs); free(blocks); free(brep); free(crep); free(p2m); free(good);
   return rc;
 }
 
 /* cribSummary (hash10x.c:1017-1061): per crib type, hash entries and distinct hashes in base barcodes and in the barcodes
-   --clusterSplit made (clusterParent != 0) */
+   --clusterSplit made (clusterParent != 0). Entries are counted on the device; which hashes occur where comes back as two
+   bitmaps per rank, OR-ed on rank 0 and counted by type. */
 int h10x_session_cribSummary(h10x_session *s, FILE *out) {
   if (!s->ctx) return fail(s, "no hash state loaded: use readFQB or readHash first");
   uint32_t dim = 0;
-  if (h10x_crib_sizes(s->ctx, &dim, 0)) { fprintf(stderr, "cribSummary requires crib\n"); return 0; }
-  if (crib_fetch(s)) return -1;
-  h10x_sizes z; if (h10x_get_sizes(s->ctx, &z)) return fail_ctx(s);
-  h10x_block *blocks = (h10x_block *)calloc((size_t)z.nBlocks + 1, sizeof *blocks);
-  h10x_clushash *ch = (h10x_clushash *)malloc(z.nClusHash ? z.nClusHash * 8 : 8);
-  uint8_t *seen = (uint8_t *)calloc((size_t)z.hashNumber + 1, 1);                     /* bit 0: in a base barcode, bit 1: in a cluster barcode */
-  if (!blocks || !ch || !seen) { free(blocks); free(ch); free(seen); return fail(s, "out of host memory for cribSummary"); }
-  if (h10x_export(s->ctx, 0, 0, 0, blocks, ch)) { free(blocks); free(ch); free(seen); return fail_ctx(s); }
-  fprintf(stderr, "made hash objects\n");
-  unsigned long long countBase[5] = {0}, countCluster[5] = {0}; int distinctBase[5] = {0}, distinctCluster[5] = {0};
-  int nBaseCode = 0, nSubClusterCode = 0; uint64_t off = 0;
-  for (uint32_t i = 0; i < z.nBlocks; ++i) {
-    const h10x_block *b = &blocks[i]; const int isCluster = b->clusterParent != 0;
-    if (isCluster) ++nSubClusterCode; else ++nBaseCode;
-    if (i == 0) continue;                                                            /* block 0 owns no hashes (hash10x.c:256) */
-    for (uint32_t j = 0; j < b->nHash; ++j) {
-      const uint32_t h = ch[off + j].hash; const int t = s->cribType[h]; const uint8_t bit = isCluster ? 2 : 1;
-      if (isCluster) ++countCluster[t]; else ++countBase[t];
-      if (!(seen[h] & bit)) { seen[h] |= bit; if (isCluster) ++distinctCluster[t]; else ++distinctBase[t]; }
-    }
-    off += b->nHash;
+  if (h10x_crib_sizes(s->ctx, &dim, 0)) { if (out) fprintf(stderr, "cribSummary requires crib\n"); return 0; }
+  h10x_shard_info_t z; if (h10x_shard_info(s->ctx, &z)) return fail_ctx(s);
+  if (crib_fetch(s, z.hashNumber)) return -1;
+  const size_t words = ((size_t)z.hashNumber + 31) / 32;
+  uint32_t *seen = (uint32_t *)calloc(2 * words + 1, 4); uint64_t counts[12]; int rc = 0;
+  if (!seen) return fail(s, "out of host memory for cribSummary");
+  if (h10x_crib_summary(s->ctx, counts, seen, seen + words)) { free(seen); return fail_ctx(s); }
+  if (out) fprintf(stderr, "made hash objects\n");
+  if (h10x_shard_allreduce_sum_u64(s->ctx, counts, 12)) { free(seen); return fail_ctx(s); }
+  uint32_t *all = z.rank == 0 ? (uint32_t *)malloc((size_t)z.nranks * 2 * words * 4 + 4) : 0; uint64_t *cnt = (uint64_t *)calloc((size_t)z.nranks, 8);
+  if ((z.rank == 0 && !all) || !cnt) { free(seen); free(all); free(cnt); return fail(s, "out of host memory for cribSummary"); }
+  if (h10x_shard_gather_bytes(s->ctx, seen, 2 * words * 4, all, (uint64_t)z.nranks * 2 * words * 4, cnt)) rc = fail_ctx(s);
+  if (!rc && z.rank == 0 && out) {
+    int distinct[2][5] = {{0}};
+    for (size_t w = 0; w < words; ++w)
+      for (int kind = 0; kind < 2; ++kind) {
+        uint32_t bits = 0;
+        for (int r = 0; r < z.nranks; ++r) bits |= all[(size_t)r * 2 * words + (size_t)kind * words + w];
+        while (bits) { const int b = __builtin_ctz(bits); bits &= bits - 1; const size_t h = w * 32 + (size_t)b; if (h < z.hashNumber) ++distinct[kind][s->cribType[h] < 5 ? s->cribType[h] : 0]; }
+      }
+    fprintf(out, "  %d base codes ", (int)counts[10] + 1);                           /* block 0 counts as a base code */
+    for (int i = 0; i < 5; ++i) fprintf(out, " %s %llu %d %.1f", cribTypeName[i], (unsigned long long)counts[i], distinct[0][i], counts[i] / (double)distinct[0][i]);
+    fprintf(out, "\n  %d cluster codes ", (int)counts[11]);
+    for (int i = 0; i < 5; ++i) fprintf(out, " %s %llu %d %.1f", cribTypeName[i], (unsigned long long)counts[5 + i], distinct[1][i], counts[5 + i] / (double)distinct[1][i]);
+    fputc('\n', out);
   }
-  fprintf(out, "  %d base codes ", nBaseCode);
-  for (int i = 0; i < 5; ++i) fprintf(out, " %s %llu %d %.1f", cribTypeName[i], countBase[i], distinctBase[i], countBase[i] / (double)distinctBase[i]);
-  fprintf(out, "\n  %d cluster codes ", nSubClusterCode);
-  for (int i = 0; i < 5; ++i) fprintf(out, " %s %llu %d %.1f", cribTypeName[i], countCluster[i], distinctCluster[i], countCluster[i] / (double)distinctCluster[i]);
-  fputc('\n', out);
-  free(blocks); free(ch); free(seen);
-  return 0;
+  free(seen); free(all); free(cnt);
+  return rc;
 }
-
 
 /* --sortFQB <in.fqb> <out.fqb>: the record sort between fq2b and --readFQB (README.md:26 shells out to
    `bsort -k 4 -r 120`), on the device. Needs a context only for its stream and allocator: created with the session's

@@ -36,15 +36,16 @@ int  h10x_session_hashDepthRange(h10x_session *s, int min, int max);            
 int  h10x_session_cluster(h10x_session *s, int codeMin, int codeMax);                 /* hash10x.c:1241-1261 */
 int  h10x_session_clusterSplit(h10x_session *s);                                      /* hash10x.c:1267 */
 
-/* --hashStats / --codeStats (hash10x.c:351-402): the reference's histogram reports, printed to f from host copies
-   of hashDepth / clusterBlocks (cheap host loops; same text as the reference, including its Array dim: hashDepth is
-   histogrammed over arrayMax entries, index 0 included) */
+/* --hashStats / --codeStats (hash10x.c:351-402): the reference's histogram reports; the histograms are filled on the
+   device (h10x_report_histogram), the text is the reference's, including its Array dim: hashDepth is histogrammed over
+   arrayMax entries, index 0 included. f = NULL: take part without printing (ranks > 0 of a sharded session). */
 int  h10x_session_hashStats(h10x_session *s, FILE *f);
 int  h10x_session_codeStats(h10x_session *s, FILE *f);
 
 /* --cribBuild <genome1.fa> <genome2.fa>, --clusterReport <codeMin> <codeMax>, --cribSummary (hash10x.c:470-521, 870-952,
    1017-1061): truth labels from two haplotype FASTAs (hashed and looked up on the device) and the reference's text
-   reports. printTables = the --tables flag (CRIB_TABLE lines). */
+   reports. printTables = the --tables flag (CRIB_TABLE lines). The per-cluster figures come from the device
+   (h10x_cluster_report); out = NULL: take part without printing (ranks > 0 of a sharded session). */
 int  h10x_session_cribBuild(h10x_session *s, const char *fa1, const char *fa2, FILE *out, int printTables);
 int  h10x_session_clusterReport(h10x_session *s, int codeMin, int codeMax, FILE *out);
 int  h10x_session_cribSummary(h10x_session *s, FILE *out);
@@ -53,11 +54,16 @@ int  h10x_session_cribSummary(h10x_session *s, FILE *out);
    on the device: records ordered by their first 4 bytes, stably */
 int  h10x_session_sortFQB(h10x_session *s, const char *inPath, const char *outPath);
 
-/* multi-GPU (include/h10x.h "multi-GPU"): this rank's contiguous barcode range of the sorted file, cut with
-   h10x_host_partition; -N and the chunkSize check are the launcher's business here. After shardGather rank 0's
-   session holds the whole state and --writeHash works as usual. */
+/* multi-GPU (include/h10x.h "multi-GPU"): one session per rank, each holding a contiguous barcode range of the sorted file
+   (cut with h10x_host_partition / _partition_file; -N is applied by the launcher before cutting). Every command of a
+   sharded session is collective: all ranks call it with the same arguments; the text commands print on the rank whose
+   FILE* is not NULL (rank 0) and only take part on the others. --writeHash, --clusterSplit, --cribBuild and the reports
+   work on the shards as they are (no gather): see h10x.h. _file streams this rank's records [first, first + n) of the
+   file into HBM and applies the reference's chunk semantics (-c) over the whole file. shardGather turns rank 0 into a
+   single-GPU session holding everything (for continuing on one GPU). */
 int  h10x_session_shardReadFQB_mem(h10x_session *s, h10x_comm *comm, const uint32_t *shardRecords, uint64_t nRecords);
 int  h10x_session_shardReadFQB_dev(h10x_session *s, h10x_comm *comm, const uint32_t *devShardRecords, uint64_t nRecords);
+int  h10x_session_shardReadFQB_file(h10x_session *s, h10x_comm *comm, const char *path, uint64_t firstRecord, uint64_t nRecords);
 int  h10x_session_shardGather(h10x_session *s);
 
 /* dimension the reference's Array reaches when elements are first touched in ascending order up to
@@ -70,6 +76,8 @@ int64_t h10x_host_check_chunks(const uint32_t *records, uint64_t nRecords, int N
 /* contiguous barcode-range shards for nParts GPUs: cut[g] = first record of shard g, always on a
    barcode-run boundary, balanced by record count; cut[nParts] = nRecords. Returns 0. */
 int  h10x_host_partition(const uint32_t *records, uint64_t nRecords, int nParts, uint64_t *cut);
+/* the same cuts for the first nRecords records of a file, reading only the barcode words around each cut */
+int  h10x_host_partition_file(const char *path, uint64_t nRecords, int nParts, uint64_t *cut, char *err, int errlen);
 
 #ifdef __cplusplus
 }

@@ -1,11 +1,14 @@
-/* hash10x_main.c — `hash10x-amd`: the reference's command loop (hash10x.c:1122-1305) for the
- * in-scope commands, running on one MI355X through libh10x_host / libh10x_hip.
+/* hash10x_main.c — `hash10x-amd`: the reference's command surface (hash10x.c:1122-1305) for the in-scope commands, on one
+ * MI355X or, with --gpus N, on N of them (one rank per GPU, ranks = threads of this process over the in-process
+ * communicator; barcodes sharded, see csrc/shard.hip).
  *
- * Same argv grammar: tokens are processed strictly left to right, every token starts with '-',
- * parameters (-k -w -r -B -N -c -ct) are latched and take effect at the next --readFQB/--readHash,
- * each command is echoed as "COMMAND ..." and followed by a resource line. Fatal conditions print
- * "FATAL ERROR: <the reference's message>" and exit(-1) like die() (utils.c:18-29).
- * Additions: --device <n>; the resource line also carries wall-clock seconds.
+ * The argv grammar IS the drop-in boundary and is the reference's: tokens are taken strictly left to right, every token
+ * starts with '-', a command consumes a fixed number of arguments and is skipped as "unknown" when fewer are left
+ * (the reference's ARGMATCH(x, n) test, hash10x.c:1173), parameters (-k -w -r -B -N -c -ct) are latched until the next
+ * --readFQB / --readHash, each command is echoed as "COMMAND ..." and followed by a resource line. Fatal conditions
+ * print "FATAL ERROR: <the reference's message>" and exit(-1) like die() (utils.c:18-29). The dispatch itself is a
+ * table of commands, not the reference's if-chain.
+ * Additions: --device <n>, --gpus <n>, --sortFQB; the resource line also carries wall-clock seconds.
  */
 #define _GNU_SOURCE
 #include <stdio.h>
@@ -13,10 +16,13 @@
 #include <string.h>
 #include <stdarg.h>
 #include <time.h>
+#include <pthread.h>
+#include <sys/stat.h>
 #include <sys/resource.h>
 #include "h10x_host.h"
 
 static FILE *outFile;
+static int printTables;
 
 static void die(const char *fmt, ...) {
   va_list ap; va_start(ap, fmt);
@@ -24,10 +30,13 @@ static void die(const char *fmt, ...) {
   va_end(ap);
   exit(-1);
 }
-
-static double wallNow(void) { struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return t.tv_sec + 1e-9 * t.tv_nsec; }
+static void say(const char *fmt, ...) {                      /* outFile, and stdout too when -o names a file */
+  va_list ap; va_start(ap, fmt); vfprintf(outFile, fmt, ap); va_end(ap);
+  if (outFile != stdout) { va_start(ap, fmt); vprintf(fmt, ap); va_end(ap); }
+}
 
 /* utils.c:122-148 format (user/system are CPU seconds from getrusage) + wall seconds */
+static double wallNow(void) { struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return t.tv_sec + 1e-9 * t.tv_nsec; }
 static void timeUpdate(FILE *f, int total) {
   static int first = 1; static struct rusage rOld, rFirst; static double wOld, wFirst;
   struct rusage rNew; getrusage(RUSAGE_SELF, &rNew); double wNew = wallNow();
@@ -40,7 +49,44 @@ static void timeUpdate(FILE *f, int total) {
   rOld = rNew; wOld = wNew;
 }
 
-static void usage(h10x_session *s) {
+/* ---- the ranks: one session each; rank 0 is also the unsharded session when --gpus is 1 ---- */
+enum { MAX_RANKS = 64 };
+static struct { int n; h10x_session *s[MAX_RANKS]; h10x_comm *comm[MAX_RANKS]; } team = {1, {0}, {0}};
+typedef int (*rank_fn)(h10x_session *s, int rank, void *arg);
+typedef struct { rank_fn fn; void *arg; int rank, rc; } RankCall;
+static void *rank_thread(void *p) { RankCall *c = (RankCall *)p; c->rc = c->fn(team.s[c->rank], c->rank, c->arg); return 0; }
+/* every rank runs fn (a collective command); returns the lowest failing rank + 1, 0 if none failed */
+static int on_all_ranks(rank_fn fn, void *arg) {
+  if (team.n == 1) return fn(team.s[0], 0, arg) ? 1 : 0;
+  pthread_t th[MAX_RANKS]; RankCall call[MAX_RANKS];
+  for (int r = 0; r < team.n; ++r) { call[r].fn = fn; call[r].arg = arg; call[r].rank = r; call[r].rc = 0; if (pthread_create(&th[r], 0, rank_thread, &call[r])) die("pthread_create failed"); }
+  int bad = 0;
+  for (int r = 0; r < team.n; ++r) { pthread_join(th[r], 0); if (call[r].rc && !bad) bad = r + 1; }
+  return bad;
+}
+static void die_of(int bad) { die("%s", h10x_session_error(team.s[bad - 1])); }
+static void set_all(const char *name, int v) { for (int r = 0; r < team.n; ++r) h10x_session_set(team.s[r], name, v); }
+
+static void set_gpus(int n) {
+  if (n < 1 || n > MAX_RANKS) die("--gpus %d: must be 1..%d", n, MAX_RANKS);
+  if (n == team.n) return;
+  int nDev = h10x_device_count(); if (nDev < 1) nDev = 1;
+  const char *copy[] = {"k", "w", "r", "B", "N", "c", "ct", 0};
+  const int dev0 = h10x_session_get(team.s[0], "device");
+  for (int r = 1; r < team.n; ++r) { h10x_session_free(team.s[r]); team.s[r] = 0; }
+  for (int r = 0; r < team.n; ++r) if (team.comm[r]) { h10x_comm_destroy(team.comm[r]); team.comm[r] = 0; }
+  for (int r = 1; r < n; ++r) {
+    if (!(team.s[r] = h10x_session_new())) die("out of memory");
+    for (int i = 0; copy[i]; ++i) h10x_session_set(team.s[r], copy[i], h10x_session_get(team.s[0], copy[i]));
+    h10x_session_set(team.s[r], "device", (dev0 + r) % nDev);                          /* more ranks than devices: they share (tests on a 1-GPU box) */
+  }
+  team.n = n;
+  if (n > 1 && h10x_comm_create_local(team.comm, n)) die("h10x_comm_create_local failed");
+}
+
+/* ---- commands ---- */
+static void usage(void) {
+  h10x_session *s = team.s[0];
   fprintf(stderr, "Usage: hash10x-amd <commands>\n");
   fprintf(stderr, "Commands can be parameter settings with -x, or operations:\n");
   fprintf(stderr, "Be sure to set relevant parameters before invoking an operation!\n");
@@ -54,6 +100,7 @@ static void usage(h10x_session *s) {
   fprintf(stderr, "   -t | --threads <n> : accepted and ignored (clustering runs on the GPU)\n");
   fprintf(stderr, "   -o | --output <output filename> : '-' for stdout\n");
   fprintf(stderr, "   --device <HIP device ordinal> [0]\n");
+  fprintf(stderr, "   --gpus <n> [1]: shard the barcodes of the next --readFQB over n GPUs (devices device, device+1, ...)\n");
   fprintf(stderr, "   --sortFQB <fqb from fq2b> <sorted fqb output>: sort records by barcode on the GPU (instead of bsort -k 4 -r 120)\n");
   fprintf(stderr, "   --readFQB <sorted fqb input file name>: must have this or readHash\n");
   fprintf(stderr, "   --readHash <hash input file name>\n");
@@ -69,105 +116,138 @@ static void usage(h10x_session *s) {
   fprintf(stderr, "   --codeStats : distribution of barcode/cluster sizes and summary info\n");
   fprintf(stderr, "   --help : print this usage message\n");
 }
-
-static void say(const char *fmt, ...) {                      /* outFile, and stdout too when -o names a file */
-  va_list ap; va_start(ap, fmt); vfprintf(outFile, fmt, ap); va_end(ap);
-  if (outFile != stdout) { va_start(ap, fmt); vprintf(fmt, ap); va_end(ap); }
+static void say_initialised(void) {
+  h10x_session *s = team.s[0];
+  fprintf(outFile, "hash10x initialised with k = %d, w = %d, random seed = %d, hashtable bits = %d\n",
+          h10x_session_get(s, "k"), h10x_session_get(s, "w"), h10x_session_get(s, "r"), h10x_session_get(s, "B"));
 }
+static h10x_shard_info_t sizes_now(void) {
+  h10x_shard_info_t z; memset(&z, 0, sizeof z);
+  if (h10x_session_ctx(team.s[0])) h10x_shard_info(h10x_session_ctx(team.s[0]), &z);
+  return z;
+}
+static void say_filled(const h10x_shard_info_t *z) {
+  fprintf(outFile, "  filled hash table: %llu hashes from %u barcodes in %u bins\n", (unsigned long long)z->nEntriesGlobal, z->nBlocksGlobal, z->hashNumber);
+}
+
+typedef struct { const char *path; uint64_t cut[MAX_RANKS + 1]; } ReadArg;
+static int rank_readFQB(h10x_session *s, int r, void *a) {
+  ReadArg *ra = (ReadArg *)a;
+  return team.n == 1 ? h10x_session_readFQB(s, ra->path) : h10x_session_shardReadFQB_file(s, team.comm[r], ra->path, ra->cut[r], ra->cut[r + 1] - ra->cut[r]);
+}
+static void cmd_readFQB(char **a) {
+  say_initialised();
+  ReadArg ra; ra.path = a[0];
+  if (team.n > 1) {
+    struct stat sb; char err[256];
+    if (stat(a[0], &sb)) die("failed to open fqb file %s", a[0]);
+    uint64_t n = (uint64_t)sb.st_size / 120; const int N = h10x_session_get(team.s[0], "N");
+    if (N > 0 && (uint64_t)N < n) n = (uint64_t)N;
+    if (h10x_host_partition_file(a[0], n, team.n, ra.cut, err, (int)sizeof err)) die("%s", err);
+  }
+  const int bad = on_all_ranks(rank_readFQB, &ra); if (bad) die_of(bad);
+  const h10x_shard_info_t z = sizes_now(); const double nb = (double)z.nBlocksGlobal - 1;
+  say("  read %llu read pair records for %u barcodes, mean %.2f read pairs per barcode\n", (unsigned long long)z.nRecordsGlobal, z.nBlocksGlobal - 1, z.nRecordsGlobal / nb);
+  say("  created %llu hashes, mean %.2f hashes per read pair, %.2f per barcode\n", (unsigned long long)z.nEntriesGlobal, z.nEntriesGlobal / (double)z.nRecordsGlobal, z.nEntriesGlobal / nb);
+  say_filled(&z);
+}
+static void cmd_readHash(char **a) {
+  if (team.n > 1) die("--readHash after --gpus %d: a .hash file is loaded on one GPU in this build (give --gpus 1, or start from --readFQB)", team.n);
+  say_initialised();
+  if (h10x_session_readHash(team.s[0], a[0])) die_of(1);
+  const h10x_shard_info_t z = sizes_now();
+  say("  read %llu hashes in %u barcode blocks\n", (unsigned long long)z.nEntriesGlobal, z.nBlocksGlobal);
+  say_filled(&z);
+}
+static int rank_writeHash(h10x_session *s, int r, void *a) { (void)r; return h10x_session_writeHash(s, (const char *)a); }
+static void cmd_writeHash(char **a) {
+  const int bad = on_all_ranks(rank_writeHash, a[0]); if (bad) die_of(bad);
+  const h10x_shard_info_t z = sizes_now();
+  say("  wrote %llu hash table entries and %u barcode blocks\n", 1ULL << z.B, z.nBlocksGlobal);
+}
+static int rank_range(h10x_session *s, int r, void *a) { (void)r; const int *v = (const int *)a; return h10x_session_hashDepthRange(s, v[0], v[1]); }
+static void cmd_hashDepthRange(char **a) {
+  int v[2] = {atoi(a[0]), atoi(a[1])};
+  const int bad = on_all_ranks(rank_range, v); if (bad) die_of(bad);
+  printf("  made goodHashes arrays for hash range %d to %d\n", v[0], v[1]);
+}
+/* "!! ..." is the reference's soft error: print and carry on (hash10x.c:1257-1260) */
+static int soft_or_die(int bad) {
+  if (!bad) return 0;
+  const char *e = h10x_session_error(team.s[bad - 1]);
+  if (strncmp(e, "!!", 2)) die("%s", e);
+  fprintf(outFile, "%s\n", e); if (outFile != stdout) fprintf(stderr, "%s\n", e);
+  return 1;
+}
+static int rank_cluster(h10x_session *s, int r, void *a) { (void)r; const int *v = (const int *)a; return h10x_session_cluster(s, v[0], v[1]); }
+static void cmd_cluster(char **a) {
+  int v[2] = {atoi(a[0]), atoi(a[1])};
+  if (soft_or_die(on_all_ranks(rank_cluster, v))) return;
+  say("  clustered codes %d to %d\n", v[0] ? v[0] : 1, v[1] ? v[1] : (int)sizes_now().nBlocksGlobal);
+}
+static int rank_split(h10x_session *s, int r, void *a) { (void)r; (void)a; return h10x_session_clusterSplit(s); }
+static void cmd_clusterSplit(char **a) { (void)a; const int bad = on_all_ranks(rank_split, 0); if (bad) die_of(bad); }
+static int rank_crib(h10x_session *s, int r, void *a) { char **f = (char **)a; return h10x_session_cribBuild(s, f[0], f[1], r == 0 ? outFile : 0, printTables); }
+static void cmd_cribBuild(char **a) { const int bad = on_all_ranks(rank_crib, a); if (bad) die_of(bad); }
+static int rank_report(h10x_session *s, int r, void *a) { const int *v = (const int *)a; return h10x_session_clusterReport(s, v[0], v[1], r == 0 ? outFile : 0); }
+static void cmd_clusterReport(char **a) { int v[2] = {atoi(a[0]), atoi(a[1])}; soft_or_die(on_all_ranks(rank_report, v)); }
+static int rank_summary(h10x_session *s, int r, void *a) { (void)a; return h10x_session_cribSummary(s, r == 0 ? outFile : 0); }
+static void cmd_cribSummary(char **a) { (void)a; const int bad = on_all_ranks(rank_summary, 0); if (bad) die_of(bad); }
+static int rank_hashStats(h10x_session *s, int r, void *a) { (void)a; return h10x_session_hashStats(s, r == 0 ? outFile : 0); }
+static void cmd_hashStats(char **a) { (void)a; const int bad = on_all_ranks(rank_hashStats, 0); if (bad) die_of(bad); }
+static int rank_codeStats(h10x_session *s, int r, void *a) { (void)a; return h10x_session_codeStats(s, r == 0 ? outFile : 0); }
+static void cmd_codeStats(char **a) { (void)a; const int bad = on_all_ranks(rank_codeStats, 0); if (bad) die_of(bad); }
+static void cmd_sortFQB(char **a) { if (h10x_session_sortFQB(team.s[0], a[0], a[1])) die_of(1); }
+static void cmd_output(char **a) {
+  if (!strcmp(a[0], "-")) outFile = stdout;
+  else if (!(outFile = fopen(a[0], "w"))) { fprintf(stderr, "can't open output file %s\n", a[0]); outFile = stdout; }
+}
+static void cmd_threads(char **a) { (void)a; fprintf(stderr, "  can't set thread number - clustering runs on the GPU\n"); }
+static void cmd_tables(char **a) { (void)a; printTables = !printTables; }                 /* hash10x.c:1198 */
+static void cmd_nothing(char **a) { (void)a; }
+static void cmd_help(char **a) { (void)a; usage(); }
+static void cmd_gpus(char **a) { set_gpus(atoi(a[0])); }
+static void cmd_device(char **a) {
+  int nDev = h10x_device_count(); if (nDev < 1) nDev = 1;
+  for (int r = 0; r < team.n; ++r) h10x_session_set(team.s[r], "device", (atoi(a[0]) + r) % nDev);
+}
+
+typedef struct { const char *name; int nArgs; void (*run)(char **args); const char *param; } Command;
+static const Command commands[] = {
+  {"-k", 1, 0, "k"}, {"-w", 1, 0, "w"}, {"-r", 1, 0, "r"}, {"-B", 1, 0, "B"}, {"-N", 1, 0, "N"}, {"-c", 1, 0, "c"},
+  {"-ct", 1, 0, "ct"}, {"--clusterThreshold", 1, 0, "ct"},
+  {"--device", 1, cmd_device, 0}, {"--gpus", 1, cmd_gpus, 0},
+  {"-t", 1, cmd_threads, 0}, {"--threads", 1, cmd_threads, 0}, {"-o", 1, cmd_output, 0}, {"--output", 1, cmd_output, 0},
+  {"--tables", 0, cmd_tables, 0}, {"--verbose", 0, cmd_nothing, 0},                      /* --verbose: accepted, no per-barcode text on the device path */
+  {"--readFQB", 1, cmd_readFQB, 0}, {"--readHash", 1, cmd_readHash, 0}, {"--writeHash", 1, cmd_writeHash, 0},
+  {"--hashDepthRange", 2, cmd_hashDepthRange, 0}, {"--cluster", 2, cmd_cluster, 0}, {"--clusterSplit", 0, cmd_clusterSplit, 0},
+  {"--sortFQB", 2, cmd_sortFQB, 0}, {"--cribBuild", 2, cmd_cribBuild, 0}, {"--clusterReport", 2, cmd_clusterReport, 0},
+  {"--cribSummary", 0, cmd_cribSummary, 0}, {"--hashStats", 0, cmd_hashStats, 0}, {"--codeStats", 0, cmd_codeStats, 0},
+  {"--help", 0, cmd_help, 0},
+  {0, 0, 0, 0}};
 
 int main(int argc, char **argv) {
   --argc; ++argv;
   outFile = stdout;
-  int printTables = 0;
   timeUpdate(stdout, 0);
-  h10x_session *s = h10x_session_new();
-  if (!s) die("out of memory");
-  if (!argc) usage(s);
+  if (!(team.s[0] = h10x_session_new())) die("out of memory");
+  if (!argc) usage();
 
   while (argc) {
     if (**argv != '-') die("option/command %s does not start with '-': run without arguments for usage", *argv);
     fprintf(outFile, "COMMAND %s", *argv);
     for (int i = 1; i < argc && *argv[i] != '-'; ++i) fprintf(outFile, " %s", argv[i]);
     fputc('\n', outFile);
-#define ARGMATCH(x, n) (!strcmp(*argv, x) && argc >= n && (argc -= n, argv += n))
-    if (ARGMATCH("-k", 2)) h10x_session_set(s, "k", atoi(argv[-1]));
-    else if (ARGMATCH("-w", 2)) h10x_session_set(s, "w", atoi(argv[-1]));
-    else if (ARGMATCH("-r", 2)) h10x_session_set(s, "r", atoi(argv[-1]));
-    else if (ARGMATCH("-B", 2)) h10x_session_set(s, "B", atoi(argv[-1]));
-    else if (ARGMATCH("-N", 2)) h10x_session_set(s, "N", atoi(argv[-1]));
-    else if (ARGMATCH("-c", 2)) h10x_session_set(s, "c", atoi(argv[-1]));
-    else if (ARGMATCH("--device", 2)) h10x_session_set(s, "device", atoi(argv[-1]));
-    else if (ARGMATCH("-t", 2) || ARGMATCH("--threads", 2))
-      fprintf(stderr, "  can't set thread number - clustering runs on the GPU\n");
-    else if (ARGMATCH("-o", 2) || ARGMATCH("--output", 2)) {
-      if (!strcmp(argv[-1], "-")) outFile = stdout;
-      else if (!(outFile = fopen(argv[-1], "w"))) { fprintf(stderr, "can't open output file %s\n", argv[-1]); outFile = stdout; }
-    }
-    else if (ARGMATCH("--tables", 1)) printTables = !printTables;                       /* hash10x.c:1198 */
-    else if (ARGMATCH("--verbose", 1)) { /* accepted: no per-barcode text on the device path */ }
-    else if (ARGMATCH("--readFQB", 2)) {
-      fprintf(outFile, "hash10x initialised with k = %d, w = %d, random seed = %d, hashtable bits = %d\n",
-              h10x_session_get(s, "k"), h10x_session_get(s, "w"), h10x_session_get(s, "r"), h10x_session_get(s, "B"));
-      if (h10x_session_readFQB(s, argv[-1])) die("%s", h10x_session_error(s));
-      h10x_sizes z; h10x_get_sizes(h10x_session_ctx(s), &z);
-      h10x_counters c; h10x_get_counters(h10x_session_ctx(s), &c);
-      double nb = (double)z.nBlocks - 1;
-      say("  read %llu read pair records for %u barcodes, mean %.2f read pairs per barcode\n",
-          (unsigned long long)z.nRecords, z.nBlocks - 1, z.nRecords / nb);
-      say("  created %llu hashes, mean %.2f hashes per read pair, %.2f per barcode\n",
-          (unsigned long long)z.nClusHash, z.nClusHash / (double)z.nRecords, z.nClusHash / nb);
-      fprintf(outFile, "  filled hash table: %llu hashes from %u barcodes in %u bins\n", (unsigned long long)z.nClusHash, z.nBlocks, z.hashNumber);
-    }
-    else if (ARGMATCH("--readHash", 2)) {
-      fprintf(outFile, "hash10x initialised with k = %d, w = %d, random seed = %d, hashtable bits = %d\n",
-              h10x_session_get(s, "k"), h10x_session_get(s, "w"), h10x_session_get(s, "r"), h10x_session_get(s, "B"));
-      if (h10x_session_readHash(s, argv[-1])) die("%s", h10x_session_error(s));
-      h10x_sizes z; h10x_get_sizes(h10x_session_ctx(s), &z);
-      say("  read %llu hashes in %u barcode blocks\n", (unsigned long long)z.nClusHash, z.nBlocks);
-      fprintf(outFile, "  filled hash table: %llu hashes from %u barcodes in %u bins\n", (unsigned long long)z.nClusHash, z.nBlocks, z.hashNumber);
-    }
-    else if (ARGMATCH("--writeHash", 2)) {
-      if (h10x_session_writeHash(s, argv[-1])) die("%s", h10x_session_error(s));
-      h10x_sizes z; h10x_get_sizes(h10x_session_ctx(s), &z);
-      say("  wrote %llu hash table entries and %u barcode blocks\n", 1ULL << z.B, z.nBlocks);
-    }
-    else if (ARGMATCH("--hashDepthRange", 3)) {
-      if (h10x_session_hashDepthRange(s, atoi(argv[-2]), atoi(argv[-1]))) die("%s", h10x_session_error(s));
-      printf("  made goodHashes arrays for hash range %d to %d\n", atoi(argv[-2]), atoi(argv[-1]));
-    }
-    else if (ARGMATCH("-ct", 2) || ARGMATCH("--clusterThreshold", 2)) h10x_session_set(s, "ct", atoi(argv[-1]));
-    else if (ARGMATCH("--cluster", 3)) {
-      int codeMin = atoi(argv[-2]), codeMax = atoi(argv[-1]);
-      if (h10x_session_cluster(s, codeMin, codeMax)) {
-        const char *e = h10x_session_error(s);
-        if (!strncmp(e, "!!", 2)) {                          /* soft error: the reference prints and carries on (hash10x.c:1257-1260) */
-          fprintf(outFile, "%s\n", e); if (outFile != stdout) fprintf(stderr, "%s\n", e);
-        } else die("%s", e);
-      } else {
-        if (!codeMin) codeMin = 1;
-        if (!codeMax) { h10x_sizes z; h10x_get_sizes(h10x_session_ctx(s), &z); codeMax = (int)z.nBlocks; }
-        say("  clustered codes %d to %d\n", codeMin, codeMax);
-      }
-    }
-    else if (ARGMATCH("--clusterSplit", 1)) { if (h10x_session_clusterSplit(s)) die("%s", h10x_session_error(s)); }
-    else if (ARGMATCH("--sortFQB", 3)) { if (h10x_session_sortFQB(s, argv[-2], argv[-1])) die("%s", h10x_session_error(s)); }
-    else if (ARGMATCH("--cribBuild", 3)) { if (h10x_session_cribBuild(s, argv[-2], argv[-1], outFile, printTables)) die("%s", h10x_session_error(s)); }
-    else if (ARGMATCH("--clusterReport", 3)) {
-      if (h10x_session_clusterReport(s, atoi(argv[-2]), atoi(argv[-1]), outFile)) {
-        const char *e = h10x_session_error(s);
-        if (!strncmp(e, "!!", 2)) { fprintf(outFile, "%s\n", e); if (outFile != stdout) fprintf(stderr, "%s\n", e); } else die("%s", e);
-      }
-    }
-    else if (ARGMATCH("--cribSummary", 1)) { if (h10x_session_cribSummary(s, outFile)) die("%s", h10x_session_error(s)); }
-    else if (ARGMATCH("--hashStats", 1)) { if (h10x_session_hashStats(s, outFile)) die("%s", h10x_session_error(s)); }
-    else if (ARGMATCH("--codeStats", 1)) { if (h10x_session_codeStats(s, outFile)) die("%s", h10x_session_error(s)); }
-    else if (ARGMATCH("--help", 1)) usage(s);
-    else if (ARGMATCH("--quit", 1) || ARGMATCH("--exit", 1)) break;
-    else die("unknown option/command %s; run without arguments for usage", *argv);
-
+    if (!strcmp(*argv, "--quit") || !strcmp(*argv, "--exit")) break;
+    const Command *c = commands;
+    while (c->name && (strcmp(c->name, *argv) || argc < 1 + c->nArgs)) ++c;            /* too few arguments left: not a match, like ARGMATCH */
+    if (!c->name) die("unknown option/command %s; run without arguments for usage", *argv);
+    if (c->param) set_all(c->param, atoi(argv[1])); else c->run(argv + 1);
+    argc -= 1 + c->nArgs; argv += 1 + c->nArgs;
     printf("  "); timeUpdate(stdout, 0); fflush(stdout);
   }
   fprintf(outFile, "total resources used: "); timeUpdate(outFile, 1);
-  h10x_session_free(s);
+  for (int r = 0; r < team.n; ++r) h10x_session_free(team.s[r]);
+  for (int r = 0; r < team.n; ++r) if (team.comm[r]) h10x_comm_destroy(team.comm[r]);
   return 0;
 }

@@ -151,17 +151,73 @@ int  h10x_comm_size(const h10x_comm *comm);
 int  h10x_shard_attach(h10x_ctx *ctx, h10x_comm *comm);
 /* --readFQB on this rank's contiguous barcode range of the sorted file (cut with h10x_host_partition): stage A
    locally, then the hash-owner exchange; afterwards every rank holds hashDepth of the whole data set and
-   blocks/clusHash of its own barcodes. h10x_depth_range / h10x_cluster work as usual (global barcode numbers;
-   --hashDepthRange also allgathers the barcode lists of the in-range hashes). hashValue / hashIndex of the whole
+   blocks/clusHash of its own barcodes. h10x_depth_range / h10x_cluster / h10x_cluster_split / h10x_crib_* work as
+   usual and are collective on a sharded context (global barcode numbers; --hashDepthRange also allgathers the barcode
+   lists of the in-range hashes, --clusterSplit numbers the new blocks over all ranks and sends the entries' new block
+   numbers back to the hash owners, the crib is computed on every rank against the whole table). hashValue / hashIndex of the whole
    set (only --writeHash and the crib read them) are built by h10x_shard_gather, not here. */
 int  h10x_shard_read_fqb(h10x_ctx *ctx, const uint32_t *host_records, uint64_t n_records);
 int  h10x_shard_read_fqb_device(h10x_ctx *ctx, const uint32_t *dev_records, uint64_t n_records);
 /* collective: every rank builds hashValue / hashIndex of the whole set; rank 0 receives every rank's blocks and
-   clusHash and from then on exports like a single-GPU context */
+   clusHash (in file order), rebuilds the barcode lists and from then on IS a single-GPU context (for continuing on one
+   GPU; --writeHash and the reports work on the shards directly, see below) */
 int  h10x_shard_gather(h10x_ctx *ctx);
-/* collective plumbing for launchers: barrier, and max over ranks of a host double (timing) */
+/* ---- a sharded state without a gather ("each rank pwrites its slices") ----
+   After --readFQB every rank owns one contiguous range of the file's barcode blocks; every --clusterSplit appends, for
+   each range that held parents, a range of new blocks numbered behind ALL existing blocks (hash10x.c:961-1003). A
+   segment = one such range on one rank. h10x_shard_segments lists the segments of all ranks in file order (ascending
+   globalBase): blocks [localStart, localStart + count) of rank `rank` are blocks [globalBase, ...) of the data set and
+   their `entries` ClusterHash records start at localEntryStart in that rank's clusHash (filled in for the caller's own
+   segments) and at globalEntryStart in the file's. An unsharded context reports itself as one segment of rank 0.
+   h10x_shard_prepare_export (collective) builds hashValue[] / hashIndex[] of the whole set on every rank;
+   h10x_export_slice copies elements [first, first + count) of one table of THIS rank to the host. */
+typedef struct {
+  uint32_t rank, localStart, count, globalBase;
+  uint64_t entries, localEntryStart, globalEntryStart;
+} h10x_shard_seg;
+typedef struct {
+  int32_t  rank, nranks, B; uint32_t hashNumber;
+  uint32_t nBlocksGlobal;      /* arrayMax(clusterBlocks) of the whole data set */
+  uint32_t nSegs;              /* entries h10x_shard_segments will write */
+  uint64_t nEntriesGlobal, nRecordsGlobal;
+} h10x_shard_info_t;
+enum { H10X_TABLE_HASHINDEX = 0, H10X_TABLE_HASHVALUE = 1, H10X_TABLE_HASHDEPTH = 2, H10X_TABLE_BLOCKS = 3, H10X_TABLE_CLUSHASH = 4,
+       H10X_TABLE_NGOOD = 5 };
+int  h10x_shard_info(h10x_ctx *ctx, h10x_shard_info_t *out);
+int  h10x_shard_segments(h10x_ctx *ctx, h10x_shard_seg *out, uint32_t cap);
+int  h10x_shard_prepare_export(h10x_ctx *ctx);
+int  h10x_export_slice(h10x_ctx *ctx, int table, uint64_t first, uint64_t count, void *dst);
+/* collective plumbing for launchers: barrier, max over ranks of a host double (timing), sums / maxima of small host
+   arrays (in place), and a gather of byte strings to rank 0 (recv = the strings in rank order, counts[r] = bytes of
+   rank r; recv / cap are read on rank 0 only). On an unsharded context these are the identity. */
 int  h10x_shard_barrier(h10x_ctx *ctx);
 int  h10x_shard_allreduce_max(h10x_ctx *ctx, double *value);
+int  h10x_shard_allreduce_sum_u64(h10x_ctx *ctx, uint64_t *values, uint32_t n);
+int  h10x_shard_allreduce_max_u64(h10x_ctx *ctx, uint64_t *values, uint32_t n);
+int  h10x_shard_gather_bytes(h10x_ctx *ctx, const void *send, uint64_t nbytes, void *recv, uint64_t cap, uint64_t *counts);
+
+/* ---- the text reports, reduced on the device (csrc/stage_e.hip): only these results cross PCIe, never clusHash ----
+   h10x_report_max / h10x_report_histogram: what histogramReport() is fed with (hash10x.c:351-402): `which` = 0
+   hashDepth[first .. first+count) (hashDepthHist), 1 nHash and 2 nSubCluster of this rank's blocks [first, first+count)
+   (codeSizeHist); hist has `bins` entries, values >= bins are not counted.
+   h10x_cluster_report: codeClusterReport()'s per-barcode and per-sub-cluster figures (hash10x.c:870-952) for this
+   rank's blocks [firstBlock, firstBlock+nBlocks): one h10x_block_rep per block, and for block b its sub-clusters
+   1 .. min(nSubCluster, 255) consecutively in `clusters` (in block order). Without a crib the crib fields are 0.
+   h10x_crib_summary: cribSummary()'s tallies (hash10x.c:1017-1061) over this rank's blocks 1..: counts[0..4] entries
+   per crib type in base blocks, [5..9] in blocks made by --clusterSplit, [10] / [11] the number of such blocks; the two
+   bitmaps (bit = hash index, (hashNumber + 31) / 32 words) mark the hashes met in each kind. */
+typedef struct { uint32_t nGood, nClusHash, nClusRead, reserved; } h10x_block_rep;
+typedef struct {
+  uint32_t n, nRead, nt[5];      /* hashes, reads, hashes per crib type (err htA htB hom mul) */
+  uint32_t nBad;                 /* located hashes on another chromosome than the first located one ("OTHER") */
+  int16_t  chr; uint16_t pMin, pMax, nOtherListed;
+  uint32_t other[10];            /* hash indices of the last ten of those, in the reference's print order */
+} h10x_cluster_rep;
+int  h10x_report_max(h10x_ctx *ctx, int which, uint64_t first, uint64_t count, uint32_t *maxValue);
+int  h10x_report_histogram(h10x_ctx *ctx, int which, uint64_t first, uint64_t count, uint32_t bins, uint64_t *hist);
+int  h10x_cluster_report(h10x_ctx *ctx, uint32_t firstBlock, uint32_t nBlocks, h10x_block_rep *blocks,
+                         h10x_cluster_rep *clusters, uint64_t clusterCap, uint64_t *nClusters);
+int  h10x_crib_summary(h10x_ctx *ctx, uint64_t counts[12], uint32_t *seenBase, uint32_t *seenCluster);
 
 /* ---- device memory plumbing for callers that keep the input resident in HBM (bench, pipelines) ----
    plain hipMalloc / hipMemcpy / hipDeviceSynchronize on `device`; return NULL / non-zero on failure */

@@ -42,7 +42,7 @@ def gz_write(path, data):
 
 
 def ref(args, cwd):
-    r = orc.run_ref(args, cwd)
+    r = orc.run_ref(args, cwd, timeout=3600)
     if r.returncode != 0:
         raise RuntimeError("reference failed: %s\n%s" % (args, r.stderr.decode()))
     return r.stdout.decode(), r.stderr.decode()
@@ -245,6 +245,38 @@ def main():
     digest_case("big65k.c", dict(pairs=36000, barcodes=3, genome=3000000, err=0.01, seed=3, mol=12.0), 20,
                 ["--hashDepthRange", 1, 3, "--cluster", 1, 0])
 
+    # BASELINE configs[2] proportions (500 Mb x 2, 200 M pairs, 1 M barcodes, e = 0.1 %) at 1/10 and 1/4 scale: the ranked and the
+    # hashed placement of first[] at their natural sizes. The reference needs 4.5 and 12.5 minutes for them, so they are only
+    # regenerated on request (`make_golden.py --big`); otherwise the committed entries are carried over.
+    big = [("c3_20m.c", dict(pairs=20000000, barcodes=100000, genome=50000000, err=0.001, seed=2, mol=10.0), 26),
+           ("c3_50m.c", dict(pairs=50000000, barcodes=300000, genome=125000000, err=0.001, seed=2, mol=10.0), 27)]
+    if "--big" in sys.argv:
+        keep = man["digest_cases"]
+        man["digest_cases"] = []
+        for name, gen, B in big:
+            digest_case(name, gen, B, ["--hashDepthRange", 30, 100, "--cluster", 1, 0])
+            os.remove(os.path.join(tmp, name + ".fqb"))
+        man["big_digest_cases"], man["digest_cases"] = man["digest_cases"], keep
+        # the table size BASELINE configs[2] names is too small for its read count: the reference dies (1/10 set, proportional -B)
+        name, gen, B = big[0]
+        orc.gen_fqb(os.path.join(tmp, "die.fqb"), **gen)
+        r = orc.run_ref(["-B", B - 1, "--readFQB", "die.fqb"], tmp, timeout=3600)
+        os.remove(os.path.join(tmp, "die.fqb"))
+        assert r.returncode != 0 and b"hashTableSize is too small" in r.stderr, r.stderr
+        man["die_cases"] = [{"name": "c3_20m.B%d" % (B - 1), "gen": gen, "B": B - 1, "message": "hashTableSize is too small",
+                             "note": "reference binary: FATAL ERROR: hashTableSize is too small (the -B %d run of the same set counts %d hashes)"
+                                     % (B, man["big_digest_cases"][0]["hash_number"])}]
+    else:
+        try:
+            with open(os.path.join(HERE, "manifest.json")) as f:
+                old = json.load(f)
+            man["big_digest_cases"] = old.get("big_digest_cases", [])
+            man["die_cases"] = old.get("die_cases", [])
+        except OSError:
+            man["big_digest_cases"] = []
+            man["die_cases"] = []
+    man["big_note"] = ("big_digest_cases: BASELINE configs[2] proportions at 1/10 and 1/4 scale, generated by `make_golden.py --big` from "
+                       "oracle/_ref (4.5 and 12.5 minutes of the reference); only the GPU tests run them")
     with open(os.path.join(HERE, "manifest.json"), "w") as f:
         json.dump(man, f, indent=1)
     shutil.rmtree(tmp)

@@ -11,6 +11,57 @@ import orc
 from driver import run_commands
 
 
+class ShardEngine:
+    """One rank of a sharded run behind the engine interface of driver.run_commands: --readFQB takes this rank's barcode range
+    (after -N), everything else is the same collective call on every rank. gather=True: rank 0 collects the state before
+    --writeHash (h10x_shard_gather), else every rank writes its slices of the file."""
+
+    def __init__(self, h, comm, nranks, gather):
+        self.h, self.comm, self.nranks, self.gather = h, comm, nranks, gather
+
+    def read_fqb(self, records, N=0, chunk=100000):
+        import hash10x_amd
+        flat = np.ascontiguousarray(records, dtype=np.uint32).reshape(-1)
+        if N and N * 30 < flat.size:
+            flat = flat[: N * 30]
+        cut = hash10x_amd.partition(flat, self.nranks)
+        self.h.shard_read_fqb(self.comm, flat[30 * cut[self.comm.rank]: 30 * cut[self.comm.rank + 1]])
+
+    def depth_range(self, lo, hi): self.h.depth_range(lo, hi)
+    def cluster(self, a, b, ct): self.h.cluster(a, b, ct)
+    def cluster_split(self): self.h.cluster_split()
+
+    def write_hash(self, path):
+        if self.gather:
+            self.h.shard_gather()
+            if self.comm.rank == 0: self.h.write_hash(path)
+            self.gather = None                                # the state is rank 0's from here on: nothing sharded may follow
+        else:
+            self.h.write_hash(path)
+
+
+def run_sharded(args, cwd, nranks, k, w, r, B, opts=None, gather=False):
+    """the command line `args` on nranks ranks (threads of this process, in-process communicator)"""
+    import hash10x_amd
+    comms = hash10x_amd.Comm.local(nranks); errs = [None] * nranks
+
+    def work(rk):
+        try:
+            def make(k_, w_, r_, B_):
+                h = hash10x_amd.Hash10x(k=k_, w=w_, r=r_, B=B_)
+                for n, v in (opts or {}).items(): h.set_option(n, v)
+                return ShardEngine(h, comms[rk], nranks, gather)
+            eng = run_commands(make, args, cwd)
+            eng.h.close()
+        except Exception as e:                                # noqa: BLE001
+            errs[rk] = e
+    th = [threading.Thread(target=work, args=(rk,)) for rk in range(nranks)]
+    [x.start() for x in th]; [x.join() for x in th]
+    for cm in comms: cm.destroy()
+    for e in errs:
+        if e: raise e
+
+
 def run(n_cases, seed, verbose=False, scale=1):
     """scale > 1: pairs, barcodes and genome multiplied (launch classes, table overflows and multi-round lists at real sizes)"""
     import hash10x_amd
@@ -56,29 +107,15 @@ def run(n_cases, seed, verbose=False, scale=1):
             got = open(os.path.join(d, "hip.hash"), "rb").read(); exp = open(os.path.join(d, "orc.hash"), "rb").read()
             ok = got == exp
             nr = rng.choice([1, 2, 3, 4, 8])
-            if ok and simple and rng.random() < 0.6:          # the sharded form of the same commands, ranks as threads
-                flat = np.ascontiguousarray(recs, dtype=np.uint32).reshape(-1)
-                cut = hash10x_amd.partition(recs, nr); comms = hash10x_amd.Comm.local(nr); errs = [None] * nr
-
-                def work(rk):
-                    try:
-                        h = hash10x_amd.Hash10x(k=k, w=w, r=r, B=B)
-                        for n, v in opts.items(): h.set_option(n, v)
-                        h.shard_read_fqb(comms[rk], flat[30 * cut[rk]: 30 * cut[rk + 1]])
-                        h.depth_range(lo, hi); h.cluster(1, 0, ct)
-                        h.shard_gather()
-                        if rk == 0: h.write_hash(os.path.join(d, "sh.hash"))
-                        h.close()
-                    except Exception as e:                    # noqa: BLE001
-                        errs[rk] = e
-                th = [threading.Thread(target=work, args=(rk,)) for rk in range(nr)]
-                [x.start() for x in th]; [x.join() for x in th]
-                for cm in comms: cm.destroy()
-                for e in errs:
-                    if e: raise e
+            if ok and "--readHash" not in tail and rng.random() < 0.6:   # the same commands sharded, ranks as threads
+                sopts = dict(opts)
+                if rng.random() < 0.4: sopts["shard_row_shift"] = rng.choice([0, 1, 3])
+                if rng.random() < 0.3: sopts["shard_rows_fake_base"] = rng.choice([1 << 32, (5 << 32) + 24, 1 << 35])
+                gather = "--clusterSplit" not in tail and rng.random() < 0.3
+                run_sharded(base + ["--writeHash", "sh.hash"], d, nr, k, w, r, B, sopts, gather)
                 got = open(os.path.join(d, "sh.hash"), "rb").read()
                 ok = got == exp
-                desc["sharded_ranks"] = nr
+                desc["sharded_ranks"] = nr; desc["sharded_opts"] = sopts; desc["gather"] = gather
             if verbose: print("case %3d %s %s" % (case, "ok " if ok else "MISMATCH", desc if not ok else {x: desc[x] for x in ("k", "w", "barcodes")}), flush=True)
             if not ok:
                 desc["diff"] = orc.describe_diff(got, exp)[:400]; bad.append(desc)

@@ -26,6 +26,7 @@ def run(n_cases, seed, verbose=False):
         mol = rng.choice([2.0, 4.0]); mol_len = rng.choice([2500, 6000]); err = rng.choice([0.001, 0.003])
         lo = rng.choice([2, 3, 4]); hi = lo + rng.choice([3, 10, 30, 100]); ct = rng.choice([1, 2, 3, 5])
         B = 23 if w < 13 else 21
+        gpus = rng.choice([1, 1, 2, 3, 4])                    # > 1: the sharded form of every command (ranks share the one GPU of the test box)
         args = ["-k", k, "-w", w, "-r", r, "-B", B, "-ct", ct, "--readFQB", "x.fqb"]
         if rng.random() < 0.5: args += ["--hashStats"]
         args += ["--hashDepthRange", lo, hi, "--cluster", 1, 0]
@@ -41,7 +42,7 @@ def run(n_cases, seed, verbose=False):
             args += ["--hashDepthRange", lo, hi, "--cluster", 1, 0]
             if rng.random() < 0.5: args += ["--codeStats"]
         args = [str(a) for a in args] + ["--writeHash", "OUT"]
-        desc = dict(case=case, seed=2000 + case, pairs=pairs, barcodes=barcodes, genome=genome, mol=mol, mol_len=mol_len, err=err, args=" ".join(args))
+        desc = dict(case=case, gpus=gpus, seed=2000 + case, pairs=pairs, barcodes=barcodes, genome=genome, mol=mol, mol_len=mol_len, err=err, args=" ".join(args))
         try:
             orc.gen_fqb(os.path.join(d, "x.fqb"), pairs, barcodes, genome, err, 2000 + case, mol, 150, mol_len, fa=os.path.join(d, "x"))
             if crib and rng.random() < 0.5:                  # cut the haplotypes into several sequences
@@ -52,7 +53,7 @@ def run(n_cases, seed, verbose=False):
                         for i in range(0, len(lines), step):
                             f.write(">c%d\n%s\n" % (i // step + 1, "\n".join(lines[i:i + step])))
             ref = orc.run_ref([a if a != "OUT" else "ref.hash" for a in args], d)
-            hip = subprocess.run([exe] + [a if a != "OUT" else "hip.hash" for a in args], cwd=d, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+            hip = subprocess.run([exe] + (["--gpus", str(gpus)] if gpus > 1 else []) + [a if a != "OUT" else "hip.hash" for a in args], cwd=d, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
             why = None
             if ref.returncode != hip.returncode: why = "exit codes %d (ref) vs %d: %s | %s" % (ref.returncode, hip.returncode, ref.stderr.decode()[-200:], hip.stderr.decode()[-200:])
             elif ref.returncode == 0:

@@ -219,8 +219,10 @@ def test_context_reuse_is_deterministic(workdir):
     assert orc.HashFile(exp).blocks["nSubCluster"].sum() > 0
 
 
-def _run_sharded(recs, nranks, B, lo, hi, ct, out_path, split_after=False):
-    """N ranks as N threads on one GPU (in-process communicator): the whole sharded pipeline incl. gather."""
+def _run_sharded(recs, nranks, B, lo, hi, ct, out_path, gather=False, opts=None, after=None):
+    """N ranks as N threads on one GPU (in-process communicator): the whole sharded pipeline. Every rank writes its slices of
+    the .hash file (gather=True: rank 0 collects the state first, the round-1 way). after(h, rank): more collective commands
+    before the file is written."""
     import threading
     import hash10x_amd
     cut = hash10x_amd.partition(recs, nranks)
@@ -231,11 +233,18 @@ def _run_sharded(recs, nranks, B, lo, hi, ct, out_path, split_after=False):
     def work(r):
         try:
             h = hash10x_amd.Hash10x(B=B)
+            for n, v in (opts or {}).items():
+                h.set_option(n, v)
             h.shard_read_fqb(comms[r], flat[30 * cut[r]: 30 * cut[r + 1]])
             h.depth_range(lo, hi)
             h.cluster(1, 0, ct)
-            h.shard_gather()
-            if r == 0:
+            if after:
+                after(h, r)
+            if gather:
+                h.shard_gather()
+                if r == 0:
+                    h.write_hash(out_path)
+            else:
                 h.write_hash(out_path)
             h.close()
         except Exception as e:              # noqa: BLE001
@@ -267,6 +276,82 @@ def test_sharded_equals_single_gpu_and_oracle(workdir, nranks):
     got = open(workdir.file("hip.hash"), "rb").read()
     assert got == exp, orc.describe_diff(got, exp)
     assert orc.HashFile(exp).blocks["nSubCluster"].sum() > 0
+    if nranks in (2, 3):                                     # the gather to rank 0 gives the same file
+        _run_sharded(recs, nranks, 20, 4, 30, 3, workdir.file("hip2.hash"), gather=True)
+        assert open(workdir.file("hip2.hash"), "rb").read() == exp
+
+
+@pytest.mark.parametrize("shift,fake", [(0, 1 << 32), (3, 0), (2, (7 << 32) + 4), (1, 1 << 35)])
+def test_sharded_list_offsets_beyond_32_bits(workdir, shift, fake):
+    """BASELINE configs[3]/[4] hold more than 2^32 in-range list entries: cluster_kernel then keeps a list's offset as a 32-bit
+    count of 2^shift-entry units (lists padded to that alignment by the exchange). Exercised on a small set by forcing the
+    alignment and by letting the offsets start `fake` entries in front of the array (64-bit address arithmetic in the kernel)."""
+    recs = orc.gen_fqb(workdir.file("x.fqb"), 40000, 180, 300000, 0.003, 61, 4.0, 150, 6000)
+    o = orc.Oracle(B=20)
+    o.read_fqb(recs)
+    o.depth_range(4, 30)
+    o.cluster(1, 0, 3)
+    o.write_hash(workdir.file("orc.hash"))
+    exp = open(workdir.file("orc.hash"), "rb").read()
+    _run_sharded(recs, 3, 20, 4, 30, 3, workdir.file("hip.hash"), opts={"shard_row_shift": shift, "shard_rows_fake_base": fake})
+    got = open(workdir.file("hip.hash"), "rb").read()
+    assert got == exp, orc.describe_diff(got, exp)
+
+
+def test_gather_then_continue_on_one_gpu(workdir):
+    """h10x_shard_gather leaves rank 0 a complete single-GPU context: its barcode lists are rebuilt, so a new depth range and
+    another clustering on rank 0 alone give what one GPU gives from the start (the lists used to be stale)."""
+    import threading
+    import hash10x_amd
+    recs = orc.gen_fqb(workdir.file("x.fqb"), 40000, 180, 300000, 0.003, 61, 4.0, 150, 6000)
+    o = orc.Oracle(B=20)
+    o.read_fqb(recs); o.depth_range(4, 30); o.cluster(1, 0, 3); o.depth_range(2, 40); o.cluster(1, 0, 2)
+    o.write_hash(workdir.file("orc.hash"))
+    exp = open(workdir.file("orc.hash"), "rb").read()
+    nranks = 3
+    cut = hash10x_amd.partition(recs, nranks); comms = hash10x_amd.Comm.local(nranks)
+    flat = np.ascontiguousarray(recs, dtype=np.uint32).reshape(-1); errs = [None] * nranks
+
+    def work(r):
+        try:
+            h = hash10x_amd.Hash10x(B=20)
+            h.shard_read_fqb(comms[r], flat[30 * cut[r]: 30 * cut[r + 1]])
+            h.depth_range(4, 30); h.cluster(1, 0, 3)
+            h.shard_gather()
+            if r == 0:
+                h.depth_range(2, 40); h.cluster(1, 0, 2)
+                h.write_hash(workdir.file("hip.hash"))
+            h.close()
+        except Exception as e:              # noqa: BLE001
+            errs[r] = e
+    th = [threading.Thread(target=work, args=(r,)) for r in range(nranks)]
+    [t.start() for t in th]; [t.join(600) for t in th]
+    [c.destroy() for c in comms]
+    for e in errs:
+        if e is not None:
+            raise e
+    got = open(workdir.file("hip.hash"), "rb").read()
+    assert got == exp, orc.describe_diff(got, exp)
+
+
+@pytest.mark.parametrize("nranks", [2, 4])
+def test_sharded_split_recluster_and_second_split(workdir, nranks):
+    """--clusterSplit on shards: the new blocks are numbered behind the blocks of ALL ranks in the order of their parents, the
+    hash owners rebuild their barcode lists, and the split blocks cluster (and split) again like the reference's."""
+    recs = orc.gen_fqb(workdir.file("x.fqb"), 40000, 180, 300000, 0.003, 61, 4.0, 150, 6000)
+    o = orc.Oracle(B=20)
+    o.read_fqb(recs); o.depth_range(4, 30); o.cluster(1, 0, 3); o.cluster_split()
+    o.depth_range(3, 30); o.cluster(1, 0, 2); o.cluster_split(); o.depth_range(3, 30); o.cluster(1, 0, 2)
+    o.write_hash(workdir.file("orc.hash"))
+    exp = open(workdir.file("orc.hash"), "rb").read()
+
+    def after(h, r):
+        h.cluster_split(); h.depth_range(3, 30); h.cluster(1, 0, 2); h.cluster_split(); h.depth_range(3, 30); h.cluster(1, 0, 2)
+    _run_sharded(recs, nranks, 20, 4, 30, 3, workdir.file("hip.hash"), after=after)
+    got = open(workdir.file("hip.hash"), "rb").read()
+    assert got == exp, orc.describe_diff(got, exp)
+    hf = orc.HashFile(exp)
+    assert hf.blocks_max > 181 and hf.blocks["clusterParent"].max() > 181          # second-generation blocks exist
 
 
 @pytest.mark.parametrize("nranks", [2, 4, 8])
@@ -382,21 +467,27 @@ def test_cli_crib_reports_match_reference(workdir):
         f.write("\n".join(a) + "\n")
     args = ["-B", "20", "-ct", "3", "--readFQB", "x.fqb", "--hashDepthRange", "4", "30", "--cluster", "1", "0", "--tables",
             "--cribBuild", "x.A.fa", "x.B.fa", "--clusterReport", "0", "0", "--clusterReport", "3", "9", "--clusterSplit", "--cribSummary",
-            "--hashDepthRange", "4", "30", "--clusterReport", "140", "175"]
+            "--hashDepthRange", "4", "30", "--clusterReport", "140", "175", "--cluster", "1", "0", "--codeStats", "--hashStats", "--clusterReport", "150", "400",
+            "--writeHash", "ref.hash"]
     r = orc.run_ref(args, workdir.path)
     assert r.returncode == 0, r.stderr.decode()
-    g = subprocess.run([os.path.join(orc.REPO, "bin", "hash10x-amd")] + args, cwd=workdir.path, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
-    assert g.returncode == 0, g.stderr.decode()
-
     def report(txt):
         keep = ("  crib matches", "    hom", "    het", "    mul", "    err", "CRIB_TABLE", "  CLUSTER_SUMMARY", "    CODE_CLUSTER",
-                "  MIN_POINT_DENSITY")
+                "  MIN_POINT_DENSITY", "CODE_SIZE_", "CODE_CLUSTER_", "HASH_COUNT_")
         return [ln for ln in txt.decode().splitlines() if ln.startswith(keep) or " base codes " in ln or " cluster codes " in ln or " in crib genome" in ln]
-    got, exp = report(g.stdout), report(r.stdout)
-    for i, (a, b) in enumerate(zip(got, exp)):
-        assert a == b, "line %d differs:\n  hip: %s\n  ref: %s" % (i, a, b)
-    assert len(got) == len(exp) and len(got) > 400
-    assert any("OTHER" in ln for ln in got) and any(" mul," in ln for ln in got)
+    exp = report(r.stdout)
+    exp_hash = orc.canonical_hash_bytes(open(workdir.file("ref.hash"), "rb").read())
+    for gpus in (1, 4, 3):                                   # --gpus N: the same commands on N shards (ranks share this box's GPU), no gather
+        g = subprocess.run([os.path.join(orc.REPO, "bin", "hash10x-amd")] + (["--gpus", str(gpus)] if gpus > 1 else []) +
+                           [a if a != "ref.hash" else "hip%d.hash" % gpus for a in args], cwd=workdir.path, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+        assert g.returncode == 0, g.stderr.decode()
+        got = report(g.stdout)
+        for i, (a, b) in enumerate(zip(got, exp)):
+            assert a == b, "--gpus %d, line %d differs:\n  hip: %s\n  ref: %s" % (gpus, i, a, b)
+        assert len(got) == len(exp) and len(got) > 400
+        assert any("OTHER" in ln for ln in got) and any(" mul," in ln for ln in got)
+        got_hash = open(workdir.file("hip%d.hash" % gpus), "rb").read()
+        assert got_hash == exp_hash, "--gpus %d: %s" % (gpus, orc.describe_diff(got_hash, exp_hash))
 
 
 def test_sort_fqb_on_device(workdir):
@@ -459,3 +550,121 @@ def test_full_size_properties_and_round_trip(workdir):
     g.depth_range(wl["lo"], wl["hi"]); g.cluster(1, 0, wl["ct"]); g.write_hash(workdir.file("d.hash"))
     assert a == open(workdir.file("d.hash"), "rb").read()
     g.close()
+
+
+# ---------------------------------------------------------------------------------------- BASELINE configs[2] proportions
+_BIG = {}
+
+
+def _big_set(workdir_factory, case):
+    """the seeded input of a big digest case, generated once per test session"""
+    key = json.dumps(case["gen"], sort_keys=True)
+    if key not in _BIG:
+        d = workdir_factory.mktemp("big")
+        recs = orc.gen_fqb(str(d / "big.fqb"), **case["gen"])
+        os.remove(str(d / "big.fqb"))
+        _BIG.clear()                                         # one 2.4 - 6 GB image at a time
+        _BIG[key] = recs
+    return _BIG[key]
+
+
+@pytest.mark.parametrize("case", MAN.get("big_digest_cases", []), ids=[c["name"] for c in MAN.get("big_digest_cases", [])])
+def test_config3_proportions_match_reference_digests(case, tmp_path_factory, workdir):
+    """BASELINE configs[2] (500 Mb x 2 haplotypes, 200 M pairs, 1 M barcodes, e = 0.1 %) at 1/10 and 1/4 scale: 100 k barcodes
+    run the RANKED placement of first[], 300 k the HASHED one, both at their natural sizes (no test knob), several thousand
+    barcodes take the > 255 clusters abort path. Expected = sha256 of the reference binary's canonical .hash, generated in
+    the build container (tests/golden/make_golden.py --big: 4.5 and 12.5 minutes of the reference)."""
+    import hashlib
+    import hash10x_amd
+    recs = _big_set(tmp_path_factory, case)
+    assert orc.sha256(recs.tobytes()) == case["input_sha256"]
+    h = hash10x_amd.Hash10x(B=case["B"])
+    d = hash10x_amd.DeviceRecords(recs)
+    h.read_fqb_device(d.ptr, d.n_records)
+    d.free()
+    a = case["args"]
+    h.depth_range(int(a[1]), int(a[2]))
+    h.cluster(int(a[4]), int(a[5]), 5)
+    c = h.counters(); z = h.sizes()
+    assert z["hashNumber"] == case["hash_number"] and z["nBlocks"] == case["blocks_max"] and z["nClusHash"] == case["sum_nHash"]
+    assert c["cluster_first_mode"] == (1 if case["gen"]["barcodes"] <= 262144 else 3)
+    h.write_hash(workdir.file("big.hash"))
+    h.close()
+    sha = hashlib.sha256()
+    with open(workdir.file("big.hash"), "rb") as f:
+        for blk in iter(lambda: f.read(1 << 24), b""):
+            sha.update(blk)
+    os.remove(workdir.file("big.hash"))
+    assert sha.hexdigest() == case["sha256"]
+
+
+def test_config3_dies_at_the_table_size_of_BASELINE(tmp_path_factory):
+    """BASELINE configs[2] says -B 28 for 200 M pairs. At that scale the set holds ~104 M distinct hashes (the six padding
+    bases hashed at every read end, SURVEY F6, give ~0.3 new hashes per pair whatever the error rate) against the cap of
+    2^26 - 2 = 67.1 M: the reference dies with "hashTableSize is too small" — shown in the build container on the 1/10 set
+    at the proportional table size (-B 25: 10.43 M hashes against 8.39 M, tests/golden/manifest.json "die_cases"). The HIP
+    path must die the same way."""
+    import hash10x_amd
+    case = MAN["die_cases"][0]
+    recs = _big_set(tmp_path_factory, case)
+    h = hash10x_amd.Hash10x(B=case["B"])
+    d = hash10x_amd.DeviceRecords(recs)
+    with pytest.raises(hash10x_amd.Hash10xError, match=case["message"]):
+        h.read_fqb_device(d.ptr, d.n_records)
+    d.free(); h.close()
+
+
+# ---------------------------------------------------------------------------------------- chunk boundaries of readFQB
+def test_all_A_barcode_run_ending_at_a_chunk_boundary(workdir):
+    """hash10x.c:212 `if (!barcode) barcode = u[0]`: a run of the all-A barcode (word 0) that ends exactly
+    where a chunk ends swallows the next barcode's run. The chunk boundaries are replayed from the run starts; -c also gives
+    the reference's "chunkSize too small" for a barcode of chunkSize or more pairs."""
+    import hash10x_amd
+    recs = orc.gen_fqb(workdir.file("x.fqb"), 3000, 12, 40000, 0.003, 5, 3.0, 150, 3000).copy()
+    starts = [0] + [i for i in range(1, recs.shape[0]) if recs[i, 0] != recs[i - 1, 0]] + [recs.shape[0]]
+    chunk = 700
+    assert max(b - a for a, b in zip(starts, starts[1:])) < chunk
+    # replay the loop to find where chunks end, then give the barcode that holds a chunk end the word 0 and cut it there
+    ends, pos, head = [], 0, 0
+    while pos < recs.shape[0]:
+        end = min(head + chunk, recs.shape[0]); ends.append(end)
+        head = max(s for s in starts[:-1] if s <= end - 1); pos = end
+    e = next(x for x in ends if x not in starts and x < recs.shape[0] - 300)
+    run0 = max(s for s in starts if s < e)
+    run1 = min(s for s in starts if s > e)
+    # records run0 .. e-1 become the all-A barcode; e .. run1-1 keep their own: the zero run now ends at the chunk end e
+    recs[run0:e, 0] = 0
+    recs.tofile(workdir.file("q.fqb"))
+    for c, expect_merge in ((chunk, True), (chunk + 1, False)):
+        o = orc.Oracle(B=20); o.read_fqb(recs.reshape(-1), 0, c); o.write_hash(workdir.file("orc.hash"))
+        h = hash10x_amd.Hash10x(B=20); h.read_fqb(recs.reshape(-1), 0, c); h.write_hash(workdir.file("hip.hash"))
+        a, b = open(workdir.file("hip.hash"), "rb").read(), open(workdir.file("orc.hash"), "rb").read()
+        assert a == b, "-c %d: %s" % (c, orc.describe_diff(a, b))
+        assert (h.sizes()["nBlocks"] == len(starts) - 1 + 1) == expect_merge      # one barcode more (the cut), one less (the merge)
+        h.read_fqb_file(workdir.file("q.fqb"), 0, c); h.write_hash(workdir.file("hip2.hash"))     # the file path streams and replays alike
+        assert open(workdir.file("hip2.hash"), "rb").read() == b
+        h.close()
+    if orc.have_ref():
+        r = orc.run_ref(["-B", 20, "-c", chunk, "--readFQB", "q.fqb", "--writeHash", "ref.hash"], workdir.path)
+        assert r.returncode == 0, r.stderr.decode()
+        h = hash10x_amd.Hash10x(B=20); h.read_fqb(recs.reshape(-1), 0, chunk); h.write_hash(workdir.file("hip.hash")); h.close()
+        assert orc.canonical_hash_bytes(open(workdir.file("ref.hash"), "rb").read()) == open(workdir.file("hip.hash"), "rb").read()
+    with pytest.raises(hash10x_amd.Hash10xError, match="chunkSize too small"):
+        h = hash10x_amd.Hash10x(B=20); h.read_fqb(recs.reshape(-1), 0, 100)
+
+
+def test_corrupt_hash_file_is_refused(workdir):
+    """--readHash checks what it later uses as an index: a hash index beyond hashNumber in clusHash or in
+    hashIndex[] gives an error message, not a device fault."""
+    import hash10x_amd
+    data = bytearray(orc.read_maybe_gz(os.path.join(orc.GOLDEN, "small.c_3_14_2.hash.gz")))
+    hf = orc.HashFile(bytes(data))
+    bad = bytearray(data); bad[-8:-4] = (hf.hash_number + 5).to_bytes(4, "little")         # last ClusterHash.hash
+    open(workdir.file("bad1.hash"), "wb").write(bad)
+    bad = bytearray(data); bad[16:20] = (hf.hash_number + 1000).to_bytes(4, "little")       # hashIndex[0]
+    open(workdir.file("bad2.hash"), "wb").write(bad)
+    for f in ("bad1.hash", "bad2.hash"):
+        h = hash10x_amd.Hash10x(B=20)
+        with pytest.raises(hash10x_amd.Hash10xError, match="corrupt hash file"):
+            h.read_hash(workdir.file(f))
+        h.close()
