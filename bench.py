@@ -42,6 +42,11 @@ WORKLOADS = {
                             B=24, lo=30, hi=100, ct=5),
     "small-0.25M": dict(pairs=250000, barcodes=1000, genome=1200000, err=0.005, mol=10.0, snp=150, mol_len=50000.0,
                         B=22, lo=30, hi=100, ct=5),
+    # BASELINE configs[2] (500 Mb x 2, 200 M pairs, 1 M barcodes, e = 0.1 %) at 1/10 scale: the `secondary` block of the bench
+    # line (ranked placement of first[], several thousand barcodes on the > 255 clusters path). -B 26: the table size that
+    # holds its 10.4 M hashes (BASELINE's -B 28 for the full set is too small, see tests "config3_dies...").
+    "config3-tenth-20M": dict(pairs=20000000, barcodes=100000, genome=50000000, err=0.001, mol=10.0, snp=150, mol_len=50000.0,
+                              B=26, lo=30, hi=100, ct=5, seed=2),
 }
 
 
@@ -125,41 +130,75 @@ def rendezvous_unique_id(rank, world, hash10x_amd):
     raise RuntimeError("rendezvous: rank 0 did not answer on %s:%r" % (addr, ports))
 
 
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
 def cpu_baseline(wl, recs, workdir, gpu_hash_path):
-    """Reference binary (oracle/_ref, compiled -O3 from /root/reference) or the oracle port on this box's
-    host cores, single thread, same input, same commands. Returns (dict, parity string)."""
+    """The reference binary (oracle/_ref, compiled -O3 from /root/reference) — or the oracle port where it is absent — on
+    this box's host cores, same input, same commands, timed by WALL CLOCK (the reference's own lines are getrusage CPU
+    seconds): SURVEY 8d's two invocations, `--readFQB .. --writeHash` and `--readHash .. --hashDepthRange ..
+    --cluster 1 0 --writeHash`, each bracketed with perf_counter; once single-threaded and once with the OpenMP build on all
+    cores. Returns (cpu_baseline, cpu_baseline_omp, parity string)."""
     sys.path.insert(0, os.path.join(REPO, "tests"))
     import orc
     fqb = os.path.join(workdir, "bench.fqb")
     recs.tofile(fqb)
     pairs = recs.size // 30
     gpu_canon = open(gpu_hash_path, "rb").read()
+    cores = os.cpu_count() or 1
+    model = cpu_model()
     if orc.have_ref():
-        t0 = time.perf_counter()
-        r = orc.run_ref(["-B", wl["B"], "-ct", wl["ct"], "--readFQB", "bench.fqb", "--hashDepthRange", wl["lo"], wl["hi"],
-                         "--cluster", 1, 0, "--writeHash", "ref.hash"], workdir, timeout=3000)
-        wall = time.perf_counter() - t0
-        if r.returncode != 0:
-            raise RuntimeError("reference failed: " + r.stderr.decode())
-        # per-command CPU seconds printed by the reference (single thread => ~ wall)
-        cmd, tm = None, {}
-        for line in r.stdout.decode().splitlines():
-            if line.startswith("COMMAND "):
-                cmd = line.split()[1]
-            elif line.strip().startswith("user") and cmd:
-                f = line.split()
-                tm[cmd] = tm.get(cmd, 0.0) + float(f[1]) + float(f[3])
-        t_read, t_range, t_clu = tm.get("--readFQB", 0.0), tm.get("--hashDepthRange", 0.0), tm.get("--cluster", 0.0)
+        def two_runs(binary, threads):
+            t0 = time.perf_counter()
+            r = orc.run_ref(["-B", wl["B"], "--readFQB", "bench.fqb", "--writeHash", "a.hash"], workdir, binary=binary, timeout=3000)
+            t1 = time.perf_counter()
+            if r.returncode != 0:
+                raise RuntimeError("reference failed: " + r.stderr.decode())
+            r = orc.run_ref((["-t", threads] if threads > 1 else []) + ["-B", wl["B"], "-ct", wl["ct"], "--readHash", "a.hash", "--hashDepthRange", wl["lo"], wl["hi"],
+                            "--cluster", 1, 0, "--writeHash", "ref.hash"], workdir, binary=binary, timeout=3000)
+            t2 = time.perf_counter()
+            if r.returncode != 0:
+                raise RuntimeError("reference failed: " + r.stderr.decode())
+            # the reference's own per-command CPU seconds, to split the second process into load / range / cluster
+            cmd, tm = None, {}
+            for line in r.stdout.decode().splitlines():
+                if line.startswith("COMMAND "):
+                    cmd = line.split()[1]
+                elif line.strip().startswith("user") and cmd:
+                    f = line.split()
+                    tm[cmd] = tm.get(cmd, 0.0) + float(f[1]) + float(f[3])
+            os.remove(os.path.join(workdir, "a.hash"))
+            return t1 - t0, t2 - t1, tm
+        w_read, w_clu, tm = two_runs("hash10x", 1)
         ref_canon = orc.canonical_hash_bytes(open(os.path.join(workdir, "ref.hash"), "rb").read())
         parity = "identical" if ref_canon == gpu_canon else "DIFFERENT: " + orc.describe_diff(gpu_canon, ref_canon)
         os.remove(os.path.join(workdir, "ref.hash"))
-        t_path = t_read + t_range + t_clu
-        return ({"value": pairs / t_path, "unit": "read-pairs/s", "cores": 1, "kind": "reference",
-                 "sample": "full workload (%d read pairs): reference hash10x -O3, 1 thread; readFQB %.2fs + hashDepthRange %.2fs + cluster %.2fs "
-                           "(its own per-command CPU times; whole process %.2fs wall incl. file I/O)" % (pairs, t_read, t_range, t_clu, wall),
-                 "read_pairs_per_s_hashed": pairs / t_read if t_read else None,
-                 "barcodes_per_s_clustered": (wl["barcodes"] / t_clu) if t_clu else None,
-                 "cluster_seconds": t_clu}, parity)
+        cpu_clu = tm.get("--cluster", 0.0)                    # CPU seconds = wall for one thread
+        one = {"value": pairs / (w_read + w_clu), "unit": "read-pairs/s", "cores": 1, "kind": "reference", "cpu_model": model, "timer": "wall clock (perf_counter around each process)",
+               "sample": "full workload (%d read pairs): reference hash10x -O3, 1 thread; process 1 (--readFQB --writeHash) %.2fs, process 2 (--readHash --hashDepthRange --cluster 1 0 "
+                         "--writeHash) %.2fs of which --cluster %.2fs by the reference's own timer" % (pairs, w_read, w_clu, cpu_clu),
+               "read_pairs_per_s_hashed": pairs / w_read, "barcodes_per_s_clustered": (wl["barcodes"] / cpu_clu) if cpu_clu else None,
+               "cluster_seconds": cpu_clu, "second_process_seconds": w_clu}
+        omp = None
+        if os.path.exists(os.path.join(orc.REF_DIR, "hash10x_omp")):
+            o_read, o_clu, otm = two_runs("hash10x_omp", cores)
+            omp_canon = orc.canonical_hash_bytes(open(os.path.join(workdir, "ref.hash"), "rb").read())
+            os.remove(os.path.join(workdir, "ref.hash"))
+            # wall seconds of --cluster alone = second process minus what its other commands took single-threaded above
+            other = w_clu - cpu_clu
+            omp = {"value": pairs / (o_read + o_clu), "unit": "read-pairs/s", "cores": cores, "kind": "reference", "cpu_model": model, "timer": "wall clock (perf_counter around each process)",
+                   "sample": "full workload: reference hash10x -O3 -DOMP -fopenmp, -t %d; process 1 %.2fs (readFQB is serial in the reference), process 2 %.2fs "
+                             "(of which ~%.2fs are --readHash / fillHashTable / goodHashes / --writeHash, serial)" % (cores, o_read, o_clu, other),
+                   "read_pairs_per_s_hashed": pairs / o_read, "second_process_seconds": o_clu,
+                   "cluster_seconds_estimate": max(o_clu - other, 1e-9), "parity_with_1_thread": "identical" if omp_canon == ref_canon else "DIFFERENT"}
+        return one, omp, parity
     o = orc.Oracle(B=wl["B"])
     t0 = time.perf_counter(); o.read_fqb(recs); t1 = time.perf_counter()
     o.depth_range(wl["lo"], wl["hi"]); t2 = time.perf_counter()
@@ -167,11 +206,58 @@ def cpu_baseline(wl, recs, workdir, gpu_hash_path):
     o.write_hash(os.path.join(workdir, "orc.hash"))
     ref_canon = open(os.path.join(workdir, "orc.hash"), "rb").read()
     parity = "identical" if ref_canon == gpu_canon else "DIFFERENT: " + orc.describe_diff(gpu_canon, ref_canon)
-    return ({"value": pairs / (t3 - t0), "unit": "read-pairs/s", "cores": 1, "kind": "port",
-             "sample": "full workload (%d read pairs): oracle C restatement, 1 thread; readFQB %.2fs + hashDepthRange %.2fs + cluster %.2fs"
-                       % (pairs, t1 - t0, t2 - t1, t3 - t2),
-             "read_pairs_per_s_hashed": pairs / (t1 - t0), "barcodes_per_s_clustered": wl["barcodes"] / (t3 - t2),
-             "cluster_seconds": t3 - t2}, parity)
+    one = {"value": pairs / (t3 - t0), "unit": "read-pairs/s", "cores": 1, "kind": "port", "cpu_model": model, "timer": "wall clock",
+           "sample": "full workload (%d read pairs): oracle C restatement, 1 thread; readFQB %.2fs + hashDepthRange %.2fs + cluster %.2fs" % (pairs, t1 - t0, t2 - t1, t3 - t2),
+           "read_pairs_per_s_hashed": pairs / (t1 - t0), "barcodes_per_s_clustered": wl["barcodes"] / (t3 - t2), "cluster_seconds": t3 - t2}
+    o2 = orc.Oracle(B=wl["B"]); o2.read_fqb(recs); o2.depth_range(wl["lo"], wl["hi"])
+    t4 = time.perf_counter(); o2.cluster(1, 0, wl["ct"], cores); t5 = time.perf_counter()
+    omp = {"value": pairs / ((t2 - t0) + (t5 - t4)), "unit": "read-pairs/s", "cores": cores, "kind": "port", "cpu_model": model, "timer": "wall clock",
+           "sample": "oracle C restatement, OpenMP over barcodes with %d threads in --cluster (%.2fs); readFQB / hashDepthRange serial as above" % (cores, t5 - t4),
+           "cluster_seconds_estimate": t5 - t4}
+    return one, omp, parity
+
+
+def secondary_block(hash10x_amd, local_rank):
+    """The 1/10-scale BASELINE configs[2] set in the same process (single GPU): ms per step and the roofline of the main
+    cluster launch in the ranked placement — the regime real data sets are in, next to the yeast-scale headline."""
+    wl = dict(WORKLOADS["config3-tenth-20M"])
+    t0 = time.perf_counter()
+    recs = generate(wl, seed=wl["seed"])
+    gen_s = time.perf_counter() - t0
+    d = hash10x_amd.DeviceRecords(recs, device=local_rank)
+    pairs = recs.size // 30
+    del recs
+    h = hash10x_amd.Hash10x(B=wl["B"], device=local_rank)
+    h.enable_timing(True)
+    steps, wall = 2, []
+    for it in range(steps + 1):                             # one warm-up
+        if it == 1:
+            h.reset_timings()
+        hash10x_amd.synchronize(local_rank)
+        t = time.perf_counter()
+        h.read_fqb_device(d.ptr, pairs); h.depth_range(wl["lo"], wl["hi"]); h.cluster(1, 0, wl["ct"])
+        hash10x_amd.synchronize(local_rank)
+        if it:
+            wall.append(time.perf_counter() - t)
+    tm = h.timings(); c = h.counters(); z = h.sizes()
+    main_ms = tm["cluster_main"][0] / max(tm["cluster_main"][1], 1)
+    alg = 4.0 * c["cluster_main"][1] + 14.0 * c["cluster_main"][0] + 16.0 * c["cluster_main"][2]
+    clu_all_ms = tm["cluster_kernel"][0] / steps
+    alg_all = 4.0 * c["sum_good_depth"] + 14.0 * c["sum_good"] + 16.0 * c["sum_hash_clustered"]
+    out = {"workload": "config3-tenth-20M (BASELINE configs[2] proportions at 1/10: 20 M pairs, 100 k barcodes, 50 Mb x 2, e = 0.1 %, -B 26)",
+           "ms_per_step": 1e3 * sum(wall) / len(wall), "read_pairs_per_s": pairs * len(wall) / sum(wall), "steps": steps,
+           "device_ms_per_step": {k: round(v[0] / steps, 3) for k, v in tm.items() if v[0] > 0},
+           "entries_H": c["entries"], "distinct_U": c["distinct"], "hashNumber": z["hashNumber"],
+           "first_placement": {0: "dense", 1: "ranked", 2: "hbm-slot", 3: "hashed"}.get(c["cluster_first_mode"]),
+           "cluster_class_counts": c["cluster_class_counts"], "cluster_overflow_blocks": c["cluster_overflow_blocks"],
+           "roofline": {"bound": "hbm", "kernel": "cluster_main", "achieved": alg / (main_ms * 1e-3) / 1e9 if main_ms else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": alg / (main_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if main_ms else None, "algorithmic_bytes_per_launch": alg, "avg_launch_ms": main_ms,
+                        "barcodes_in_launch": c["cluster_main"][3],
+                        "all_cluster_launches": {"GB/s": alg_all / (clu_all_ms * 1e-3) / 1e9 if clu_all_ms else None, "ms_per_step": clu_all_ms, "algorithmic_bytes": alg_all}},
+           "generate_seconds": gen_s,
+           "parity": "tests/test_gpu_parity.py::test_config3_proportions_match_reference_digests pins this exact set (sha256 of the reference binary's .hash)"}
+    h.close(); d.free()
+    return out
 
 
 def main():
@@ -181,6 +267,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="yeast-like-2.5M", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the config-3-scale block (20 M pairs: ~40 s of generation + 3 passes)")
+    ap.add_argument("--comm", default="auto", choices=["auto", "rccl", "socket"], help="multi-process backend: RCCL over xGMI (one GPU per rank), or the "
+                    "host-staged socket backend where ranks share a GPU (test boxes); auto = socket when there are fewer devices than ranks")
     ap.add_argument("--sharded", action="store_true", help="use the multi-GPU code path (RCCL communicator, shard exchange) even with one rank")
     args = ap.parse_args()
 
@@ -209,7 +298,14 @@ def main():
         wl["barcodes"] *= world
         wl["genome"] *= world
         wl["B"] += (world - 1).bit_length()
-        comm = hash10x_amd.Comm.rccl(rank, world, rendezvous_unique_id(rank, world, hash10x_amd), local_rank)
+        ndev = hash10x_amd.device_count()
+        backend = args.comm if args.comm != "auto" else ("socket" if world > max(ndev, 1) else "rccl")
+        if backend == "socket":
+            local_rank = local_rank % max(ndev, 1)          # ranks share the devices there are
+            comm = hash10x_amd.Comm.socket(rank, world, os.environ.get("MASTER_ADDR", "127.0.0.1").replace("localhost", "127.0.0.1"),
+                                           int(os.environ.get("MASTER_PORT", "29500")) + 61)
+        else:
+            comm = hash10x_amd.Comm.rccl(rank, world, rendezvous_unique_id(rank, world, hash10x_amd), local_rank)
     recs = generate(wl, seed=1)                              # every rank builds the same seeded set and keeps its shard
     total_pairs = recs.size // 30
     if comm is not None:
@@ -276,15 +372,20 @@ def main():
 
     per = {k: (v[0] / max(v[1], 1), v[1] // steps if steps else 0, v[0] / steps) for k, v in acc.items()}   # avg ms/launch, launches/step, ms/step
     H, U = ctr["entries"], ctr["distinct"]
+    T = float(1 << wl["B"])
     alg = {
-        # SURVEY §8d algorithmic bytes per launch
+        # SURVEY §8d algorithmic bytes per launch. The index build's 28 H + 16 U + 4 2^B is split over its four timers by what each
+        # of them produces: the sort reads the 16-byte entries and yields the 4-byte barcode lists, index_rank the 12 bytes of
+        # hashValue + hashDepth per distinct hash, probe_table the 4-byte slots (U filled, 2^B written), clushash_build the 8-byte records
         "mosh_extract": 120.0 * pairs + 16.0 * H,
-        "sort_by_hash": 28.0 * H + 16.0 * U + 4.0 * (1 << wl["B"]),         # whole index build; reported against the sort, its dominant kernel
+        "sort_by_hash": 20.0 * H, "index_rank": 12.0 * U, "probe_table": 4.0 * U + 4.0 * T, "clushash_build": 8.0 * H,
         # the main cluster_kernel launch alone (its own hipEvent bracket and its own work counters: what rocprofv3 lists as
         # cluster_kernel<true, *, 1024, 0>); the few largest barcodes run beside it in a launch of their own
         "cluster_main": 4.0 * ctr["cluster_main"][1] + 14.0 * ctr["cluster_main"][0] + 16.0 * ctr["cluster_main"][2],
     }
-    dom = max(alg, key=lambda k: per.get(k, (0, 0, 0))[2])
+    index_ms = sum(per.get(k, (0, 0, 0))[2] for k in ("sort_by_hash", "index_rank", "probe_table", "clushash_build"))
+    index_alg = 28.0 * H + 16.0 * U + 4.0 * T
+    dom = max(("mosh_extract", "sort_by_hash", "cluster_main"), key=lambda k: per.get(k, (0, 0, 0))[2])
     dom_ms = per[dom][2]                                    # one launch (bracket) of each of these per step
     achieved = alg[dom] / (dom_ms * 1e-3) / 1e9
     stage_ms = {k: round(v[2], 4) for k, v in per.items() if v[2] > 0}
@@ -322,23 +423,40 @@ def main():
         "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                      "algorithmic_bytes_per_launch": alg[dom], "avg_launch_ms": dom_ms, "barcodes_in_launch": ctr["cluster_main"][3] if dom == "cluster_main" else None,
-                     "other_kernels": {k: {"GB/s": alg[k] / (per[k][2] * 1e-3) / 1e9, "ms_per_step": per[k][2]} for k in alg if k in per and per[k][2] > 0}},
+                     "other_kernels": {k: {"GB/s": alg[k] / (per[k][2] * 1e-3) / 1e9, "frac": alg[k] / (per[k][2] * 1e-3) / 1e9 / HBM_PEAK_GBS, "ms_per_step": per[k][2],
+                                           "algorithmic_bytes": alg[k]} for k in alg if k in per and per[k][2] > 0},
+                     "index_build": {"GB/s": index_alg / (index_ms * 1e-3) / 1e9 if index_ms else None, "frac": index_alg / (index_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if index_ms else None,
+                                     "ms_per_step": index_ms, "algorithmic_bytes": index_alg, "timers": "sort_by_hash + index_rank + probe_table + clushash_build"},
+                     # K1 is bounded by integer ALU, not HBM: 2 x 64-bit multiplies per k-mer (seqhash.c:58-59), 237 k-mers per pair at k = 21;
+                     # SQ_INSTS_VALU per launch is in profiles/*_pmc_sq.json (collected by rocprofv3 in passes of their own)
+                     "mosh_extract_int_ops": {"u64_multiplies_per_s": 2.0 * ctr["kmers"] / (per["mosh_extract"][2] * 1e-3) if per.get("mosh_extract", (0, 0, 0))[2] else None,
+                                              "kmers_per_step": ctr["kmers"]}},
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         with tempfile.TemporaryDirectory() as d:
             gp = os.path.join(d, "gpu.hash")
             h.write_hash(gp)
             try:
-                cb, parity = cpu_baseline(wl, recs, d, gp)
+                cb, omp, parity = cpu_baseline(wl, recs, d, gp)
                 out["cpu_baseline"] = cb
+                if omp:
+                    out["cpu_baseline_omp"] = omp
                 out["parity_vs_cpu_on_bench_input"] = parity
                 if cb.get("cluster_seconds") and clu_ms:
                     out["cluster_speedup_vs_cpu_1thread"] = cb["cluster_seconds"] / (clu_ms * 1e-3)
+                if omp and omp.get("cluster_seconds_estimate") and clu_ms:
+                    out["cluster_speedup_vs_cpu_all_cores"] = omp["cluster_seconds_estimate"] / (clu_ms * 1e-3)
             except Exception as e:                       # the baseline is reporting only; never lose the GPU number
                 out["cpu_baseline"] = {"value": None, "unit": "read-pairs/s", "cores": 1, "kind": "error", "sample": str(e)[:300]}
+    h.close()
+    d_recs.free()
+    if rank == 0 and world == 1 and not args.no_secondary and args.workload == "yeast-like-2.5M":
+        try:
+            out["secondary"] = secondary_block(hash10x_amd, local_rank)
+        except Exception as e:                           # never lose the headline over the side block
+            out["secondary"] = {"error": str(e)[:300]}
     if rank == 0:
         os.write(json_fd, (json.dumps(out) + "\n").encode())
-    h.close()
     if comm is not None:
         comm.destroy()
 

@@ -98,6 +98,7 @@ def load_native():
     hip.h10x_comm_unique_id.argtypes = [vp]
     hip.h10x_comm_create_rccl.argtypes = [ctypes.POINTER(vp), ci, ci, vp, ci, cs, ci]
     hip.h10x_comm_create_local.argtypes = [ctypes.POINTER(vp), ci]
+    hip.h10x_comm_create_socket.argtypes = [ctypes.POINTER(vp), ci, ci, cs, ci, cs, ci]
     hip.h10x_comm_destroy.argtypes = [vp]
     hip.h10x_shard_barrier.argtypes = [vp]
     hip.h10x_shard_allreduce_max.argtypes = [vp, ctypes.POINTER(ctypes.c_double)]
@@ -177,6 +178,15 @@ class Comm:
         h = ctypes.c_void_p()
         err = ctypes.create_string_buffer(512)
         if load_native()[0].h10x_comm_create_rccl(ctypes.byref(h), rank, size, unique_id, device, err, 512):
+            raise Hash10xError(err.value.decode())
+        return Comm(h, rank, size)
+
+    @staticmethod
+    def socket(rank, size, addr="127.0.0.1", base_port=29700):
+        """One process per rank, host-staged over TCP: the multi-process path where RCCL cannot run (ranks sharing a GPU)."""
+        h = ctypes.c_void_p()
+        err = ctypes.create_string_buffer(512)
+        if load_native()[0].h10x_comm_create_socket(ctypes.byref(h), rank, size, addr.encode(), int(base_port), err, 512):
             raise Hash10xError(err.value.decode())
         return Comm(h, rank, size)
 

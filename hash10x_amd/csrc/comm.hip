@@ -18,13 +18,15 @@ struct RcclComm : Comm {
     if (sendCnt[rank]) H10X_HIP(c, hipMemcpyAsync((char *)dRecv + recvOff[rank] * eb, (const char *)dSend + sendOff[rank] * eb, sendCnt[rank] * eb,
                                                    hipMemcpyDeviceToDevice, c->stream));
     H10X_TRY(chk(c, ncclGroupStart(), "GroupStart"));
-    for (int p = 0; p < n; ++p) {
+    ncclResult_t bad = ncclSuccess; const char *what = "";
+    for (int p = 0; p < n && bad == ncclSuccess; ++p) {
       if (p == rank) continue;
-      if (sendCnt[p]) H10X_TRY(chk(c, ncclSend((const char *)dSend + sendOff[p] * eb, sendCnt[p] * eb, ncclChar, p, nc, c->stream), "Send"));
-      if (recvCnt[p]) H10X_TRY(chk(c, ncclRecv((char *)dRecv + recvOff[p] * eb, recvCnt[p] * eb, ncclChar, p, nc, c->stream), "Recv"));
+      if (sendCnt[p] && (bad = ncclSend((const char *)dSend + sendOff[p] * eb, sendCnt[p] * eb, ncclChar, p, nc, c->stream)) != ncclSuccess) { what = "Send"; break; }
+      if (recvCnt[p] && (bad = ncclRecv((char *)dRecv + recvOff[p] * eb, recvCnt[p] * eb, ncclChar, p, nc, c->stream)) != ncclSuccess) { what = "Recv"; break; }
     }
-    H10X_TRY(chk(c, ncclGroupEnd(), "GroupEnd"));
-    return 0;
+    const ncclResult_t end = ncclGroupEnd();                 // always closed, also after a failed call inside the group
+    if (bad != ncclSuccess) return chk(c, bad, what);
+    return chk(c, end, "GroupEnd");
   }
   int allgatherHost(Ctx *c, const void *send, void *recv, size_t bytes) override {
     if (small.n < bytes * (size_t)(n + 1)) H10X_HIP(c, small.alloc(bytes * (size_t)(n + 1)));
@@ -49,14 +51,18 @@ struct RcclComm : Comm {
 // ------------------------------------------------------------------------------------------ in-process group
 struct LocalGroup {
   int n; std::mutex mu; std::condition_variable cv; int arrived = 0; unsigned long gen = 0;
+  int failed = 0, failedPrev = 0;                            // a rank's failure in a collective is seen by every rank at the closing barrier
   std::vector<const void *> sendPtr; std::vector<const u64 *> sendCnt, sendOff; std::vector<std::vector<unsigned char>> host;
   std::vector<double> dbl;
   explicit LocalGroup(int n_) : n(n_), sendPtr(n_), sendCnt(n_), sendOff(n_), host(n_), dbl(n_) {}
-  void wait() {
+  // returns whether any rank reported a failure since the previous rendezvous
+  bool wait(bool iFailed = false) {
     std::unique_lock<std::mutex> lk(mu);
     const unsigned long g = gen;
-    if (++arrived == n) { arrived = 0; ++gen; cv.notify_all(); }
+    if (iFailed) failed = 1;
+    if (++arrived == n) { arrived = 0; failedPrev = failed; failed = 0; ++gen; cv.notify_all(); }
     else cv.wait(lk, [&] { return gen != g; });
+    return failedPrev != 0;
   }
 };
 struct LocalComm : Comm {
@@ -66,15 +72,18 @@ struct LocalComm : Comm {
     H10X_HIP(c, hipStreamSynchronize(c->stream));            // my send buffer is complete
     g->sendPtr[rank] = dSend; g->sendCnt[rank] = sendCnt; g->sendOff[rank] = sendOff;
     g->wait();
-    for (int p = 0; p < n; ++p) {                            // pull my part from every rank (may live on another device)
+    int rc = 0;
+    for (int p = 0; p < n && !rc; ++p) {                     // pull my part from every rank (may live on another device)
       const u64 cnt = g->sendCnt[p][rank];
-      if (cnt != recvCnt[p]) return c->fail("alltoallv: rank %d sends %llu elements to rank %d which expects %llu", p, (u64)cnt, rank, (u64)recvCnt[p]);
-      if (cnt) H10X_HIP(c, hipMemcpyAsync((char *)dRecv + recvOff[p] * eb, (const char *)g->sendPtr[p] + g->sendOff[p][rank] * eb, cnt * eb,
-                                          hipMemcpyDefault, c->stream));
+      if (cnt != recvCnt[p]) rc = c->fail("alltoallv: rank %d sends %llu elements to rank %d which expects %llu", p, (u64)cnt, rank, (u64)recvCnt[p]);
+      else if (cnt && hipMemcpyAsync((char *)dRecv + recvOff[p] * eb, (const char *)g->sendPtr[p] + g->sendOff[p][rank] * eb, cnt * eb, hipMemcpyDefault, c->stream) != hipSuccess)
+        rc = c->fail("alltoallv: device copy from rank %d failed", p);
     }
-    H10X_HIP(c, hipStreamSynchronize(c->stream));
-    g->wait();                                               // nobody reuses a send buffer before everyone has pulled
-    return 0;
+    if (!rc && hipStreamSynchronize(c->stream) != hipSuccess) rc = c->fail("alltoallv: stream synchronisation failed");
+    // nobody reuses a send buffer before everyone has pulled — and everybody leaves with the same verdict (a rank that
+    // returned early would leave the others waiting here for ever)
+    if (g->wait(rc != 0) && !rc) rc = c->fail("alltoallv failed on another rank");
+    return rc;
   }
   int allgatherHost(Ctx *, const void *send, void *recv, size_t bytes) override {
     g->host[rank].assign((const unsigned char *)send, (const unsigned char *)send + bytes);
@@ -91,6 +100,70 @@ struct LocalComm : Comm {
   }
 };
 
+// ------------------------------------------------------------------------------------------ host-staged over TCP
+// One process per rank like RCCL, but every exchange goes device -> host -> socket -> host -> device. Not a data path for
+// production (PCIe + loopback); it exists so that the multi-PROCESS launch path (rendezvous, one context per process,
+// bench.py under torch.distributed.run) can run where RCCL cannot: several ranks on ONE GPU (RCCL refuses two ranks per
+// device), i.e. on a 1-GPU test box. Full mesh: rank r listens on port base + r, connects to the lower ranks.
+}  // namespace h10x
+#include <sys/socket.h>
+#include <netinet/in.h>
+#include <netinet/tcp.h>
+#include <arpa/inet.h>
+#include <poll.h>
+#include <fcntl.h>
+#include <unistd.h>
+#include <cerrno>
+namespace h10x {
+struct SockComm : Comm {
+  std::vector<int> fd;                                       // fd[p] = connection to rank p (-1 for myself)
+  ~SockComm() override { for (int f : fd) if (f >= 0) close(f); }
+  // send nOut bytes to fdOut while receiving nIn bytes from fdIn (either may be -1 / 0): never blocks on one direction
+  static int duplex(int fdOut, const char *out, size_t nOut, int fdIn, char *in, size_t nIn) {
+    while (nOut || nIn) {
+      pollfd pf[2]; int k = 0, io = -1, ii = -1;
+      if (nOut) { pf[k] = pollfd{fdOut, POLLOUT, 0}; io = k++; }
+      if (nIn) { pf[k] = pollfd{fdIn, POLLIN, 0}; ii = k++; }
+      if (poll(pf, (nfds_t)k, 60000) <= 0) return -1;
+      if (io >= 0 && (pf[io].revents & (POLLOUT | POLLERR | POLLHUP))) { const ssize_t w = send(fdOut, out, nOut > (1u << 20) ? (1u << 20) : nOut, MSG_DONTWAIT | MSG_NOSIGNAL); if (w < 0 && errno != EAGAIN && errno != EWOULDBLOCK) return -1; if (w > 0) { out += w; nOut -= (size_t)w; } }
+      if (ii >= 0 && (pf[ii].revents & (POLLIN | POLLERR | POLLHUP))) { const ssize_t r = recv(fdIn, in, nIn, MSG_DONTWAIT); if (r == 0 || (r < 0 && errno != EAGAIN && errno != EWOULDBLOCK)) return -1; if (r > 0) { in += r; nIn -= (size_t)r; } }
+    }
+    return 0;
+  }
+  // host bytes: part p of `send` (sendOff / sendCnt in bytes) goes to rank p; n - 1 rounds, in round s I send to rank + s and receive from rank - s
+  int exchange(Ctx *c, const char *send, const u64 *sendCnt, const u64 *sendOff, char *recv, const u64 *recvCnt, const u64 *recvOff) {
+    if (sendCnt[rank] != recvCnt[rank]) return c->fail("socket alltoallv: self part %llu != %llu", (u64)sendCnt[rank], (u64)recvCnt[rank]);
+    if (sendCnt[rank]) memcpy(recv + recvOff[rank], send + sendOff[rank], sendCnt[rank]);
+    for (int s = 1; s < n; ++s) {
+      const int to = (rank + s) % n, from = (rank - s + n) % n;
+      if (duplex(fd[to], send + sendOff[to], sendCnt[to], fd[from], recv + recvOff[from], recvCnt[from])) return c->fail("socket exchange with ranks %d / %d failed: %s", to, from, strerror(errno));
+    }
+    return 0;
+  }
+  int alltoallv(Ctx *c, const void *dSend, const u64 *sendCnt, const u64 *sendOff, void *dRecv, const u64 *recvCnt, const u64 *recvOff, size_t eb) override {
+    std::vector<u64> sc((size_t)n), so((size_t)n), rc((size_t)n), ro((size_t)n); u64 ts = 0, tr = 0;
+    for (int p = 0; p < n; ++p) { sc[p] = sendCnt[p] * eb; so[p] = ts; ts += sc[p]; rc[p] = recvCnt[p] * eb; ro[p] = tr; tr += rc[p]; }
+    std::vector<char> hs(ts ? ts : 1), hr(tr ? tr : 1);
+    for (int p = 0; p < n; ++p) if (sc[p]) H10X_HIP(c, hipMemcpyAsync(hs.data() + so[p], (const char *)dSend + sendOff[p] * eb, sc[p], hipMemcpyDeviceToHost, c->stream));
+    H10X_HIP(c, hipStreamSynchronize(c->stream));
+    H10X_TRY(exchange(c, hs.data(), sc.data(), so.data(), hr.data(), rc.data(), ro.data()));
+    for (int p = 0; p < n; ++p) if (rc[p]) H10X_HIP(c, hipMemcpyAsync((char *)dRecv + recvOff[p] * eb, hr.data() + ro[p], rc[p], hipMemcpyHostToDevice, c->stream));
+    H10X_HIP(c, hipStreamSynchronize(c->stream));
+    return 0;
+  }
+  int allgatherHost(Ctx *c, const void *send, void *recv, size_t bytes) override {
+    std::vector<u64> sc((size_t)n, bytes), so((size_t)n, 0), ro((size_t)n);
+    for (int p = 0; p < n; ++p) ro[p] = (u64)p * bytes;
+    return exchange(c, (const char *)send, sc.data(), so.data(), (char *)recv, sc.data(), ro.data());
+  }
+  int barrier(Ctx *c) override { double v = 0; return allreduceMaxHost(c, &v); }
+  int allreduceMaxHost(Ctx *c, double *v) override {
+    std::vector<double> all((size_t)n);
+    H10X_TRY(allgatherHost(c, v, all.data(), 8));
+    double m = all[0]; for (int p = 1; p < n; ++p) m = all[p] > m ? all[p] : m;
+    *v = m; return 0;
+  }
+};
 }  // namespace h10x
 
 using namespace h10x;
@@ -114,6 +187,45 @@ int h10x_comm_create_rccl(h10x_comm **out, int rank, int nranks, const void *id1
   const ncclResult_t rc = ncclCommInitRank(&r->nc, nranks, id, rank);
   if (rc != ncclSuccess) { if (err) snprintf(err, (size_t)errlen, "ncclCommInitRank failed: %s", ncclGetErrorString(rc)); r->nc = nullptr; delete r; return -1; }
   *out = new h10x_comm{r};
+  return 0;
+}
+
+int h10x_comm_create_socket(h10x_comm **out, int rank, int nranks, const char *addr, int basePort, char *err, int errlen) {
+  *out = nullptr;
+  auto bad = [&](const char *what) { if (err) snprintf(err, (size_t)errlen, "socket communicator, rank %d: %s: %s", rank, what, strerror(errno)); return -1; };
+  SockComm *sc = new SockComm(); sc->rank = rank; sc->n = nranks; sc->fd.assign((size_t)nranks, -1);
+  sockaddr_in a; memset(&a, 0, sizeof a); a.sin_family = AF_INET;
+  if (inet_pton(AF_INET, addr && *addr ? addr : "127.0.0.1", &a.sin_addr) != 1) { delete sc; errno = EINVAL; return bad("address"); }
+  int srv = -1; const int one = 1;
+  if (rank < nranks - 1) {                                   // the higher ranks connect to me
+    srv = socket(AF_INET, SOCK_STREAM, 0);
+    setsockopt(srv, SOL_SOCKET, SO_REUSEADDR, &one, sizeof one);
+    a.sin_port = htons((uint16_t)(basePort + rank));
+    if (srv < 0 || bind(srv, (sockaddr *)&a, sizeof a) || listen(srv, nranks)) { if (srv >= 0) close(srv); delete sc; return bad("listen"); }
+  }
+  for (int p = 0; p < rank; ++p) {                           // I connect to the lower ranks (they may not be up yet: retry for a while)
+    int f = -1;
+    for (int attempt = 0; attempt < 3000; ++attempt) {
+      f = socket(AF_INET, SOCK_STREAM, 0); a.sin_port = htons((uint16_t)(basePort + p));
+      if (f >= 0 && connect(f, (sockaddr *)&a, sizeof a) == 0) break;
+      if (f >= 0) close(f);
+      f = -1; usleep(100000);
+    }
+    if (f < 0) { if (srv >= 0) close(srv); delete sc; return bad("connect"); }
+    setsockopt(f, IPPROTO_TCP, TCP_NODELAY, &one, sizeof one);
+    const int32_t me = rank; if (send(f, &me, 4, MSG_NOSIGNAL) != 4) { close(f); if (srv >= 0) close(srv); delete sc; return bad("hello"); }
+    sc->fd[p] = f;
+  }
+  for (int k = rank + 1; k < nranks; ++k) {
+    pollfd pf{srv, POLLIN, 0};
+    if (poll(&pf, 1, 300000) <= 0) { close(srv); delete sc; errno = ETIMEDOUT; return bad("accept"); }
+    const int f = accept(srv, nullptr, nullptr); int32_t who = -1;
+    if (f < 0 || recv(f, &who, 4, MSG_WAITALL) != 4 || who <= rank || who >= nranks || sc->fd[who] >= 0) { if (f >= 0) close(f); close(srv); delete sc; return bad("accept"); }
+    setsockopt(f, IPPROTO_TCP, TCP_NODELAY, &one, sizeof one);
+    sc->fd[who] = f;
+  }
+  if (srv >= 0) close(srv);
+  *out = new h10x_comm{sc};
   return 0;
 }
 

@@ -29,10 +29,13 @@ int h10x_device_count(void) {
 
 uint64_t h10x_factor1_from_seed(int32_t seed) {
   // hash10x.c:1101 srandom(r); seqhash.c:29 (random() << 32) | random() | 0x01 — first draw is the high word
-  srandom((unsigned)seed);
-  const uint64_t hi = (uint64_t)random();
-  const uint64_t lo = (uint64_t)random();
-  return (hi << 32) | lo | 1;
+  // glibc's srandom() / random() share one process-wide state: rank threads initialising at the same time would draw from
+  // each other's sequence. random_r on a private state of the default size (128 bytes = TYPE_3) yields the same numbers.
+  struct random_data rd; char state[128]; int32_t a = 0, b = 0;
+  memset(&rd, 0, sizeof rd); memset(state, 0, sizeof state);
+  initstate_r((unsigned)seed, state, sizeof state, &rd);
+  random_r(&rd, &a); random_r(&rd, &b);
+  return ((uint64_t)(uint32_t)a << 32) | (uint64_t)(uint32_t)b | 1;
 }
 
 static int create_fail(char *err, int errlen, const char *fmt, ...) {
@@ -262,7 +265,10 @@ void *h10x_device_malloc(int device, uint64_t bytes) {
 }
 int h10x_device_free(int device, void *ptr) { return (hipSetDevice(device) == hipSuccess && hipFree(ptr) == hipSuccess) ? 0 : -1; }
 int h10x_device_upload(int device, void *dst, const void *src, uint64_t bytes) {
-  return (hipSetDevice(device) == hipSuccess && hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice) == hipSuccess) ? 0 : -1;
+  // hipMemcpy from pageable memory may return once the bytes are STAGED, before the DMA has landed; the contexts of this
+  // library run on non-blocking streams that do not wait for the default stream, so wait here (seen as rare wrong records
+  // at the end of an upload when several rank threads shared one device)
+  return (hipSetDevice(device) == hipSuccess && hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice) == hipSuccess && hipDeviceSynchronize() == hipSuccess) ? 0 : -1;
 }
 int h10x_device_synchronize(int device) { return (hipSetDevice(device) == hipSuccess && hipDeviceSynchronize() == hipSuccess) ? 0 : -1; }
 

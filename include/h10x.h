@@ -144,6 +144,9 @@ typedef struct h10x_comm h10x_comm;
 int  h10x_comm_unique_id(void *id128);
 int  h10x_comm_create_rccl(h10x_comm **comm, int rank, int nranks, const void *id128, int device, char *err, int errlen);
 int  h10x_comm_create_local(h10x_comm **comms /* nranks outputs */, int nranks);
+/* one process per rank like RCCL, but host-staged over TCP (rank r listens on basePort + r at addr): for exercising the
+   multi-process launch path where RCCL cannot run — several ranks sharing one GPU on a test box. Not a production path. */
+int  h10x_comm_create_socket(h10x_comm **comm, int rank, int nranks, const char *addr, int basePort, char *err, int errlen);
 void h10x_comm_destroy(h10x_comm *comm);
 int  h10x_comm_rank(const h10x_comm *comm);
 int  h10x_comm_size(const h10x_comm *comm);

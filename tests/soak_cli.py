@@ -65,7 +65,14 @@ def run(n_cases, seed, verbose=False):
                         i = next((i for i, (x, y) in enumerate(zip(a, b)) if x != y), min(len(a), len(b)))
                         why = "report line %d of %d/%d:\n  hip: %s\n  ref: %s" % (i, len(a), len(b), a[i] if i < len(a) else None, b[i] if i < len(b) else None)
             if verbose: print("case %3d %s %s" % (case, "ok " if not why else "MISMATCH", desc["args"] if why else ""), flush=True)
-            if why: desc["why"] = why; bad.append(desc)
+            if why:
+                desc["why"] = why; bad.append(desc)
+                keep = os.environ.get("H10X_SOAK_KEEP")
+                if keep:                                      # leave the evidence behind (a directory under gpurun_out/, say)
+                    os.makedirs(keep, exist_ok=True)
+                    for fn in ("hip.hash", "ref.hash"):
+                        if os.path.exists(os.path.join(d, fn)): shutil.copy(os.path.join(d, fn), os.path.join(keep, "case%d.%s" % (case, fn)))
+                    open(os.path.join(keep, "case%d.hip.out" % case), "wb").write(hip.stdout + b"\n--stderr--\n" + hip.stderr)
         except Exception as e:                                # noqa: BLE001
             desc["exception"] = repr(e); bad.append(desc)
             if verbose: print("case %3d EXCEPTION %r" % (case, e), flush=True)
