@@ -466,7 +466,6 @@ __device__ void cluster_one_block(const ClusterArgs &a, u32 code, unsigned char 
   const u32 n = a.nGood[code];
   if (n == 0) return;                                        // hash10x.c:780: block left untouched
   const u64 o = a.blockOff[code];
-  const u32 nHash = a.blocks[code].nHash;
   constexpr bool FIRST_LDS = IN_LDS && FIRST_MODE != 2;
   constexpr bool RANKED = IN_LDS && FIRST_MODE == 1;
   constexpr bool HASHED = IN_LDS && FIRST_MODE == 3;
@@ -754,7 +753,7 @@ __device__ void cluster_one_block(const ClusterArgs &a, u32 code, unsigned char 
   // work counters: kept per lane over the barcodes of the workgroup, posted once when the kernel ends (19 atomics per
   // barcode on four shared words would queue up in L2 behind those of every other workgroup)
   acc[1] += myDepth;
-  if (tid == 0) { acc[0] += n; acc[2] += nHash; acc[3] += 1; }
+  if (tid == 0) { acc[0] += n; acc[2] += a.blocks[lcode].nHash; acc[3] += 1; }
   if (!FIRST_LDS) {                                          // leave first[] clean for the next barcode of this workgroup
     SYNC();
     for (u32 i = 1 + wave; i < n; i += CL_WAVES) {

@@ -668,3 +668,25 @@ def test_corrupt_hash_file_is_refused(workdir):
         with pytest.raises(hash10x_amd.Hash10xError, match="corrupt hash file"):
             h.read_hash(workdir.file(f))
         h.close()
+
+
+def test_two_processes_over_the_socket_communicator(workdir):
+    """One process per rank, as under torch.distributed.run / a C launcher: rendezvous, one context per process, every
+    collective of the sharded path between PROCESSES (host-staged over TCP: RCCL will not put two ranks on this box's one
+    GPU), incl. --clusterSplit and the slice-wise --writeHash into one file."""
+    import subprocess, sys
+    recs = orc.gen_fqb(workdir.file("x.fqb"), 40000, 180, 300000, 0.003, 61, 4.0, 150, 6000)
+    o = orc.Oracle(B=20)
+    o.read_fqb(recs); o.depth_range(4, 30); o.cluster(1, 0, 3); o.cluster_split(); o.depth_range(4, 30); o.cluster(1, 0, 3)
+    o.write_hash(workdir.file("orc.hash"))
+    exp = open(workdir.file("orc.hash"), "rb").read()
+    port = 31000 + os.getpid() % 2000
+    worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), "shard_worker.py")
+    for n in (2, 3):
+        ps = [subprocess.Popen([sys.executable, worker, str(r), str(n), str(port + 10 * n), workdir.file("x.fqb"), "20", "4", "30", "3", workdir.file("p%d.hash" % n)],
+                               stdout=subprocess.PIPE, stderr=subprocess.PIPE) for r in range(n)]
+        outs = [p.communicate(timeout=300) for p in ps]
+        for p, (so, se) in zip(ps, outs):
+            assert p.returncode == 0, se.decode()[-1500:]
+        got = open(workdir.file("p%d.hash" % n), "rb").read()
+        assert got == exp, orc.describe_diff(got, exp)
