@@ -787,6 +787,8 @@ void cluster_kernel(ClusterArgs a) {
     __syncthreads();
     const u32 wi = sh[3];
     if (wi >= a.nFront + a.nList) break;                     // every wave of the workgroup leaves together
+    // (making the block number scalar with readfirstlane — and with it the rank count and every loop bound — removes a third
+    // of the spills and 170 of 6900 instructions, and is 3-4 % SLOWER: 2.49 against 2.41 ms, measured round 2)
     cluster_one_block<IN_LDS, FIRST_MODE, CL_THREADS, KLASS>(a, wi < a.nFront ? a.front[wi] : a.list[wi - a.nFront], region, firstGlobal, sh, acc);
   }
   u64 depth = acc[1];

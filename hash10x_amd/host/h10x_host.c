@@ -219,7 +219,7 @@ static int file_records(h10x_session *s, const char *path, uint64_t *n) {
 }
 
 int h10x_session_readFQB(h10x_session *s, const char *path) {
-  uint64_t n; void *dev;
+  uint64_t n = 0; void *dev;
   if (file_records(s, path, &n)) return -1;
   if (session_init(s)) return -1;
   if (stream_records(s, path, 0, n, &dev)) return -1;
@@ -656,6 +656,7 @@ static int report_block_lines(const h10x_session *s, Text *t, uint32_t code, con
    text bytes} + text + the blocks' pointToMin and nGoodHash, which rank 0 adds up in file order for MIN_POINT_DENSITY (the
    reference's double sum is order dependent). out = NULL on the other ranks. */
 typedef struct { uint32_t first, count; uint64_t textBytes; } RunHead;
+static RunHead run_head(const char *p) { RunHead h; memcpy(&h, p, sizeof h); return h; }   /* packages sit at any byte offset */
 int h10x_session_clusterReport(h10x_session *s, int codeMin, int codeMax, FILE *out) {
   if (!s->ctx) return fail(s, "no hash state loaded: use readFQB or readHash first");
   h10x_shard_info_t z; if (h10x_shard_info(s->ctx, &z)) return fail_ctx(s);
@@ -713,19 +714,19 @@ int h10x_session_clusterReport(h10x_session *s, int codeMin, int codeMax, FILE *
     if (z.rank == 0 && out) {
       size_t nRuns = 0, capRuns = 64; const char **runs = (const char **)malloc(capRuns * sizeof *runs);
       for (uint64_t o = 0; o < total; ) {
-        const RunHead *h = (const RunHead *)(all + o);
+        const RunHead h = run_head(all + o);
         if (nRuns == capRuns) { capRuns *= 2; runs = (const char **)realloc(runs, capRuns * sizeof *runs); }
         runs[nRuns++] = all + o;
-        o += sizeof *h + h->textBytes + (uint64_t)h->count * 12;
+        o += sizeof h + h.textBytes + (uint64_t)h.count * 12;
       }
       for (size_t a = 1; a < nRuns; ++a) {                                           /* few runs: insertion sort by first block */
         const char *r = runs[a]; size_t b = a;
-        while (b > 0 && ((const RunHead *)runs[b - 1])->first > ((const RunHead *)r)->first) { runs[b] = runs[b - 1]; --b; }
+        while (b > 0 && run_head(runs[b - 1]).first > run_head(r).first) { runs[b] = runs[b - 1]; --b; }
         runs[b] = r;
       }
       uint64_t totalGood = 0; double totalPoint = 0.0;
       for (size_t a = 0; a < nRuns; ++a) {
-        RunHead h; memcpy(&h, runs[a], sizeof h);
+        const RunHead h = run_head(runs[a]);
         const char *text = runs[a] + sizeof h;
         fwrite(text, 1, h.textBytes, out);
         for (uint32_t b = 0; b < h.count; ++b) {
