@@ -154,6 +154,7 @@ struct Ctx {
   DevBuf<u64> blockOff;       // nBlocks+1 : clusHash offset of each block
   DevBuf<h10x_clushash> clusHash;  // H
   u32 hashNumber = 1, nBlocks = 0;
+  u32 maxBlockHashes = 0xFFFFFFFFu;   // no block of this context holds more entries (0xFFFFFFFF = unknown): blocks up to 8192 entries are sorted in LDS
   u64 nEntries = 0, nRecords = 0;
   bool haveState = false;
 
@@ -163,6 +164,7 @@ struct Ctx {
   DevBuf<u32> nGood;          // nBlocks
   DevBuf<u32> goodEntries;    // nBlocks : sum of the depths of a block's good hashes = entries of its barcode lists
   bool haveRange = false, haveGood = false; int rangeMin = 0, rangeMax = 0;
+  u32 rangeHiMax = 0;             // largest upper limit of the ranges set so far: an in-range depth is below it
   u32 depthBound = 0xFFFFFFFFu;   // no hashDepth[] value exceeds this: barcodes of the data set after --readFQB, the largest value read after --readHash
   u32 maxGoodDepth = 0, maxGood = 0, meanGood = 0;
 
@@ -298,6 +300,9 @@ int replayChunks(const std::vector<u64> &starts, const std::vector<u32> &zeroRun
 int stageB_run(Ctx *c, DevBuf<u64> &entHash, DevBuf<u32> &entCode, DevBuf<u32> &entRead);
 int stageB_buildCSR(Ctx *c);                   // rows/rowStart from clusHash + hashDepth (fillHashTable)
 int stageB_finishClusHash(Ctx *c, DevBuf<u64> &key);   // key[e] = index << 32 | read16 in block order -> clusHash sorted per block
+// workgroup-local sorts of a block's entries (clushash_block_kernel, good_block_kernel): three launch classes, side by side on
+// forked streams — 256 lanes x 12 items (blocks up to 3072 entries: 98 % of them at 250 read pairs per barcode), 512 x 12, 1024 x 8
+constexpr u32 BLOCK_SORT_CAP0 = 3072, BLOCK_SORT_CAP1 = 6144, BLOCK_SORT_MAX = 8192;
 int stageB_buildProbeTable(Ctx *c);            // hashIndex[] from hashValue[1..hashNumber)
 int stageC_depthRange(Ctx *c, int min, int max);
 int stageC_cluster(Ctx *c, int codeMin, int codeMax, int threshold);

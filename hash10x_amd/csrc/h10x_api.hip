@@ -96,9 +96,9 @@ void h10x_destroy(h10x_ctx *h) {
 const char *h10x_last_error(const h10x_ctx *h) { return h ? h->c.err.c_str() : "null context"; }
 
 static void reset_state(Ctx &c) {
-  c.haveState = false; c.haveRange = false; c.haveGood = false; c.rangeMin = c.rangeMax = 0; c.depthBound = 0xFFFFFFFFu;
+  c.haveState = false; c.haveRange = false; c.haveGood = false; c.rangeMin = c.rangeMax = 0; c.depthBound = 0xFFFFFFFFu; c.rangeHiMax = 0;
   c.within.release(); c.goodPos.release(); c.nGood.release(); c.goodEntries.release();
-  c.hashNumber = 1; c.nBlocks = 0; c.nEntries = 0; c.nRecords = 0;
+  c.hashNumber = 1; c.nBlocks = 0; c.nEntries = 0; c.nRecords = 0; c.maxBlockHashes = 0xFFFFFFFFu;
   c.sharded = false; c.codeBase = 0; c.nBlocksGlobal = 0; c.oRows.release(); c.oSegStart.release(); c.oIndex.release(); c.oU = 0; c.oM = 0;
   c.oHash.release(); c.tablesPending = false;
   c.segs.n = 1; c.segs.s[0] = BlockSeg{0, 0, 0}; c.allSegs.clear(); c.nEntriesGlobal = c.nRecordsGlobal = 0; c.rowShift = 0; c.ownerListsStale = false;
@@ -181,10 +181,11 @@ int h10x_load_state(h10x_ctx *h, const uint32_t *hashIndex, uint32_t hashNumber,
   hipStream_t st = c.stream;
   const u64 tableSize = (u64)1 << c.prm.B;
   u64 H = 0;
-  for (u32 i = 1; i < nBlocks; ++i) H += blocks[i].nHash;
+  u32 maxHash = 0;
+  for (u32 i = 1; i < nBlocks; ++i) { H += blocks[i].nHash; maxHash = blocks[i].nHash > maxHash ? blocks[i].nHash : maxHash; }
   if (H >= (1ULL << 32)) return c.fail("%llu (barcode,hash) entries exceed this build's 2^32 per-GPU limit", (u64)H);
   if (H && !clusHash) return c.fail("h10x_load_state: null clusHash");
-  c.hashNumber = hashNumber; c.nBlocks = nBlocks; c.nEntries = H;
+  c.hashNumber = hashNumber; c.nBlocks = nBlocks; c.nEntries = H; c.maxBlockHashes = maxHash;
   H10X_HIP(&c, c.hashIndex.alloc(tableSize)); H10X_HIP(&c, c.hashValue.alloc(hashNumber)); H10X_HIP(&c, c.hashDepth.alloc(hashNumber));
   H10X_HIP(&c, c.blocks.alloc(nBlocks)); H10X_HIP(&c, c.clusHash.alloc(H)); H10X_HIP(&c, c.blockOff.alloc((size_t)nBlocks + 1));
   H10X_HIP(&c, hipMemcpyAsync(c.hashIndex.p, hashIndex, tableSize * 4, hipMemcpyHostToDevice, st));

@@ -506,7 +506,10 @@ int stageA_run(Ctx *c, const u32 *dRec, u64 nRec, DevBuf<u64> &entHash, DevBuf<u
   count_overflow_kernel<<<divUp(nBlocks, 256), 256, 0, st>>>(nHash.p, nBlocks, nOverflow.p);
   H10X_HIP(c, c->blockOff.alloc((size_t)nBlocks + 1));
   H10X_TRY(prim_exclusive_scan_u32_u64(c, pt, nHash.p, c->blockOff.p, (size_t)nBlocks + 1));
-  u64 H = 0, lastStart = 0; u32 hOverflow = 0;
+  u64 H = 0, lastStart = 0; u32 hOverflow = 0, hMaxHash = 0xFFFFFFFFu;
+  DevBuf<u32> dMaxHash; H10X_HIP(c, dMaxHash.alloc(1));
+  H10X_TRY(prim_reduce_max_u32(c, pt, nHash.p, dMaxHash.p, nBlocks));       // an overflowed block reads as the largest value: "unknown" until repaired
+  H10X_TRY(c->readback(&hMaxHash, dMaxHash.p, 4));
   H10X_TRY(c->readback(&H, c->blockOff.p + nBlocks, 8));
   H10X_TRY(c->readback(&lastStart, startRec.p + (nBlocks - 1), 8));
   H10X_TRY(c->readback(&hOverflow, nOverflow.p, 4));
@@ -574,6 +577,8 @@ int stageA_run(Ctx *c, const u32 *dRec, u64 nRec, DevBuf<u64> &entHash, DevBuf<u
   }
   if (H >= (1ULL << 32)) return c->fail("%llu (barcode,hash) entries exceed this build's 2^32 per-GPU limit", (u64)H);
   c->nEntries = H;
+  if (!hNHash.empty()) { hMaxHash = 0; for (u32 b = 0; b < nBlocks; ++b) hMaxHash = hNHash[b] > hMaxHash ? hNHash[b] : hMaxHash; }   // fallback path: the repaired counts
+  c->maxBlockHashes = hMaxHash;
   set_nhash_kernel<<<divUp(nBlocks, 256), 256, 0, st>>>(c->blocks.p, nHash.p, nBlocks);
   H10X_HIP(c, entHash.alloc(H)); H10X_HIP(c, entCode.alloc(H)); H10X_HIP(c, entRead.alloc(H));
   {                                                          // sort key = hash / w (common.hpp, Ctx::keyInv)

@@ -12,6 +12,7 @@
 // Device-wide radix sorts/scans come from rocPRIM (prim.hip); everything else is hand-written.
 #include "common.hpp"
 #include "prim.hpp"
+#include <rocprim/block/block_radix_sort.hpp>
 
 namespace h10x {
 
@@ -140,6 +141,71 @@ __global__ void write_clushash_kernel(const u64 *__restrict__ key, u64 n, h10x_c
 }
 
 
+// ------------------------------------------------------------------------------------------ clusHash, one workgroup per block
+// A block's entries (1500-2000 at 200-250 read pairs per barcode) fit a workgroup: look every entry up (THREADS x IPT probes
+// in flight per workgroup, IPT independent ones per lane), sort the block by index in LDS (rocPRIM block radix sort: 8 bits
+// per pass) and write the ClusterHash records — one kernel and one pass over the entries instead of look-up kernel, key
+// array, device-wide segmented sort and record kernel. Three launch classes by block size (2048 / 4096 / 8192 entries);
+// a data set with a larger block takes the device-wide path for everything.
+template <int THREADS, int IPT, bool LOOKUP>
+__global__ __launch_bounds__(THREADS)
+void clushash_block_kernel(const u64 *__restrict__ entHash /* hash / w */, const u32 *__restrict__ entRead, const u64 *__restrict__ key /* !LOOKUP: index << 32 | read */,
+                           const u64 *__restrict__ blockOff, u32 nBlocks, const u64 *__restrict__ table64, int B, u64 w, int qBits, int sortBits,
+                           h10x_clushash *__restrict__ out) {
+  using Sort = rocprim::block_radix_sort<u32, THREADS, IPT, u32>;
+  __shared__ typename Sort::storage_type storage;
+  constexpr u32 CAP = THREADS * IPT, LOWER = CAP == BLOCK_SORT_CAP0 ? 0 : (CAP == BLOCK_SORT_CAP1 ? BLOCK_SORT_CAP0 : BLOCK_SORT_CAP1);
+  for (u32 c = blockIdx.x + 1; c < nBlocks; c += gridDim.x) {
+    const u64 o = blockOff[c]; const u64 n64 = blockOff[c + 1] - o;
+    if (n64 > CAP || n64 <= LOWER) continue;                 // another class's block (uniform)
+    const u32 n = (u32)n64;
+    u32 k[IPT], v[IPT];
+    const u64 mask = ((u64)1 << B) - 1, qmask = qBits >= 64 ? ~0ULL : ((u64)1 << qBits) - 1;
+#pragma unroll
+    for (int j = 0; j < IPT; ++j) {
+      const u32 e = (u32)j * THREADS + threadIdx.x;
+      k[j] = 0xFFFFFFFFu; v[j] = 0;
+      if (e < n) {
+        if (LOOKUP) {
+          const u64 q = entHash[o + e], h = q * w;
+          u64 slot = h & mask; const u64 step = ((h >> B) & mask) | 1;
+          u64 t;
+          while ((t = table64[slot]) != SLOT_EMPTY64 && (t & qmask) != q) slot = (slot + step) & mask;
+          k[j] = t == SLOT_EMPTY64 ? 0u : (u32)(t >> qBits);
+          v[j] = entRead[o + e] & 0xFFFFu;                   // ClusterHash.read is U16 (hash10x.c:37,180)
+        } else { const u64 t = key[o + e]; k[j] = (u32)(t >> 32); v[j] = (u32)t & 0xFFFFu; }
+      }
+    }
+    __syncthreads();                                         // the storage of the previous block's sort is free again
+    Sort().sort(k, v, storage, 0, sortBits);                 // padding keys are all ones in sortBits bits: behind every index
+#pragma unroll
+    for (int j = 0; j < IPT; ++j) {
+      const u32 e = threadIdx.x * IPT + j;                   // sorted: blocked arrangement
+      if (e < n) { h10x_clushash r; r.hash = k[j]; r.read = (u16)v[j]; r.subCluster = 0; r.flags = 0; out[o + e] = r; }   // zeroed: SURVEY F4
+    }
+  }
+}
+
+// clusHash of every block by workgroup-local sorts; needs maxBlockHashes <= BLOCK_SORT_MAX. key = nullptr: look the entries up in table64
+static int clusHashByBlocks(Ctx *c, const u64 *entHash, const u32 *entRead, const u64 *key, const u64 *table64) {
+  hipStream_t st = c->stream; const u32 nBlocks = c->nBlocks;
+  H10X_HIP(c, c->clusHash.alloc(c->nEntries));
+  if (!c->nEntries || nBlocks < 2) return 0;
+  const int sortBits = bitsFor(c->hashNumber) + 1 > 32 ? 32 : bitsFor(c->hashNumber) + 1;
+  const unsigned grid = hmin<u32>(nBlocks - 1, 65535u * 4);
+  const int B = c->prm.B; const u64 w = (u64)c->prm.w; const int qBits = c->keyBits;
+#define H10X_CH_LAUNCH(T, I, LOOK, STREAM) clushash_block_kernel<T, I, LOOK><<<grid, T, 0, STREAM>>>(entHash, entRead, key, c->blockOff.p, nBlocks, table64, B, w, qBits, sortBits, c->clusHash.p)
+  const int side = c->maxBlockHashes > BLOCK_SORT_CAP1 ? 2 : (c->maxBlockHashes > BLOCK_SORT_CAP0 ? 1 : 0);
+  if (side) H10X_TRY(c->forkStreams(side));                  // the few large blocks beside the many small ones
+  if (key) { H10X_CH_LAUNCH(256, 12, false, st); if (side >= 1) H10X_CH_LAUNCH(512, 12, false, c->aux[0]); if (side >= 2) H10X_CH_LAUNCH(1024, 8, false, c->aux[1]); }
+  else { H10X_CH_LAUNCH(256, 12, true, st); if (side >= 1) H10X_CH_LAUNCH(512, 12, true, c->aux[0]); if (side >= 2) H10X_CH_LAUNCH(1024, 8, true, c->aux[1]); }
+#undef H10X_CH_LAUNCH
+  if (side) H10X_TRY(c->joinStreams(side));
+  H10X_HIP(c, hipGetLastError());
+  H10X_HIP(c, hipStreamSynchronize(st));
+  return 0;
+}
+
 int stageB_run(Ctx *c, DevBuf<u64> &entHash, DevBuf<u32> &entCode, DevBuf<u32> &entRead) {
   hipStream_t st = c->stream; PrimTemp pt;
   const u64 H = c->nEntries; const int B = c->prm.B; const u32 nBlocks = c->nBlocks;
@@ -195,7 +261,10 @@ int stageB_run(Ctx *c, DevBuf<u64> &entHash, DevBuf<u32> &entCode, DevBuf<u32> &
 
   // ---- clusHash: look every entry up, order each block by index (hash10x.c:177-183)
   c->tstart(T_CLUSHASH);
-  if (H) {
+  if (H && wideTable && c->maxBlockHashes <= BLOCK_SORT_MAX) {
+    H10X_TRY(clusHashByBlocks(c, entHash.p, entRead.p, nullptr, table64.p));
+    table64.release();
+  } else if (H) {
     DevBuf<u64> key; H10X_HIP(c, key.alloc(H));
     if (wideTable) lookup_pack64_kernel<<<gH, 256, 0, st>>>(entHash.p, entRead.p, H, table64.p, B, (u64)c->prm.w, c->keyBits, key.p);
     else lookup_pack_kernel<<<gH, 256, 0, st>>>(entHash.p, entRead.p, H, c->hashIndex.p, c->hashValue.p, B, (u64)c->prm.w, key.p);
@@ -223,6 +292,7 @@ int stageB_buildProbeTable(Ctx *c) {
 int stageB_finishClusHash(Ctx *c, DevBuf<u64> &key) {
   hipStream_t st = c->stream; PrimTemp pt; const u64 H = c->nEntries; const u32 nBlocks = c->nBlocks;
   const unsigned gH = (unsigned)hmin<u64>(divUp(H ? H : 1, 256), 65535u * 2);
+  if (c->maxBlockHashes <= BLOCK_SORT_MAX) return clusHashByBlocks(c, nullptr, nullptr, key.p, nullptr);
   H10X_HIP(c, c->clusHash.alloc(H));
   if (!H) return 0;
   DevBuf<u64> keyS; DevBuf<u32> off32;

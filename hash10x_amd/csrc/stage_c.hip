@@ -25,6 +25,7 @@
 #include <chrono>
 #include "prim.hpp"
 #include <type_traits>
+#include <rocprim/block/block_radix_sort.hpp>
 
 namespace h10x {
 
@@ -94,6 +95,43 @@ __global__ void offsets32c_kernel(const u64 *__restrict__ off, u32 n, u32 *__res
   if (i < n) out[i] = (u32)off[i];
 }
 
+// The good list of a block in one workgroup: keys (depth << 16 | position) of the in-range hashes, sorted in LDS (rocPRIM block
+// radix sort), positions written out — instead of key kernel + device-wide segmented sort + position kernel. Blocks up to
+// BLOCK_SORT_MAX entries, depths below 2^16 (32-bit keys); three launch classes by block size like clushash_block_kernel.
+template <int THREADS, int IPT>
+__global__ __launch_bounds__(THREADS)
+void good_block_kernel(const h10x_clushash *__restrict__ ch, const u64 *__restrict__ blockOff, const h10x_block *__restrict__ blocks, u32 nBlocks,
+                       const u32 *__restrict__ wdepth /* 0 = not in range, else depth + 1 */, int sortBits,
+                       u16 *__restrict__ goodPos, u32 *__restrict__ nGood, u32 *__restrict__ entries /* sum of depths, saturating */) {
+  using Sort = rocprim::block_radix_sort<u32, THREADS, IPT>;
+  __shared__ typename Sort::storage_type storage;
+  __shared__ u32 sCount; __shared__ unsigned long long sDepth;
+  constexpr u32 CAP = THREADS * IPT, LOWER = CAP == BLOCK_SORT_CAP0 ? 0 : (CAP == BLOCK_SORT_CAP1 ? BLOCK_SORT_CAP0 : BLOCK_SORT_CAP1);
+  for (u32 c = blockIdx.x; c < nBlocks; c += gridDim.x) {
+    const u32 nHash = blocks[c].nHash;
+    if (nHash > CAP || (nHash <= LOWER && LOWER)) continue;  // another class's block (uniform); the smallest class also takes the empty blocks
+    const u64 o = blockOff[c];
+    __syncthreads();
+    if (threadIdx.x == 0) { sCount = 0; sDepth = 0; }
+    __syncthreads();
+    u32 k[IPT]; u32 mine = 0; unsigned long long myDepth = 0;
+#pragma unroll
+    for (int j = 0; j < IPT; ++j) {
+      const u32 p = (u32)j * THREADS + threadIdx.x;
+      k[j] = 0xFFFFFFFFu;
+      if (p < nHash) { const u32 wd = wdepth[ch[o + p].hash]; if (wd) { k[j] = ((wd - 1) << 16) | p; ++mine; myDepth += wd - 1; } }
+    }
+    for (int sft = 32; sft; sft >>= 1) { mine += (u32)__shfl_down((int)mine, sft); myDepth += __shfl_down(myDepth, sft); }
+    if ((threadIdx.x & (WAVE - 1)) == 0 && mine) { atomicAdd(&sCount, mine); atomicAdd(&sDepth, myDepth); }
+    Sort().sort(k, storage, 0, sortBits);                    // ascending (depth, position): hash10x.c:726-730,758; padding keys last
+    __syncthreads();
+    const u32 nG = sCount;
+#pragma unroll
+    for (int j = 0; j < IPT; ++j) { const u32 e = threadIdx.x * IPT + j; if (e < nG) goodPos[o + e] = (u16)(k[j] & 0xFFFFu); }
+    if (threadIdx.x == 0) { nGood[c] = nG; entries[c] = sDepth > 0xFFFFFFFFull ? 0xFFFFFFFFu : (u32)sDepth; }
+  }
+}
+
 static int bitsForC(u64 maxValue) { int b = 1; while (b < 64 && (maxValue >> b)) ++b; return b; }
 
 int stageC_depthRange(Ctx *c, int lo, int hi) {
@@ -105,6 +143,7 @@ int stageC_depthRange(Ctx *c, int lo, int hi) {
     if (!c->haveRange) { H10X_HIP(c, c->within.alloc(U1)); H10X_HIP(c, hipMemsetAsync(c->within.p, 0, U1, st)); }
     within_kernel<<<divUp(U1, 256), 256, 0, st>>>(c->hashDepth.p, U1, lo, hi, c->within.p);
     c->haveRange = true; c->rangeMin = lo; c->rangeMax = hi;
+    if (hi > 0 && (u32)hi > c->rangeHiMax) c->rangeHiMax = (u32)hi;
   }
   // goodHashesBuild (hash10x.c:738-766)
   DevBuf<u64> key, keyS; DevBuf<u32> key32, keyS32, off32, segEnd, wdepth, red;
@@ -113,9 +152,24 @@ int stageC_depthRange(Ctx *c, int lo, int hi) {
   H10X_HIP(c, c->nGood.alloc(nBlocks)); H10X_HIP(c, c->goodPos.alloc(H)); H10X_HIP(c, c->goodEntries.alloc(nBlocks));
   within_depth_kernel<<<divUp(U1, 256), 256, 0, st>>>(c->hashDepth.p, c->within.p, U1, wdepth.p);
   H10X_TRY(prim_reduce_max_u32(c, pt, wdepth.p, red.p, U1));
-  const bool narrow = c->depthBound <= 65535u;                // known without a round trip (Ctx::depthBound)
-  if (narrow) { H10X_HIP(c, key32.alloc(H)); H10X_HIP(c, keyS32.alloc(H)); } else { H10X_HIP(c, key.alloc(H)); H10X_HIP(c, keyS.alloc(H)); }
-  if (narrow) good_keys_kernel<u32><<<hmin<u32>(nBlocks, 16384), 256, 0, st>>>(c->clusHash.p, c->blockOff.p, c->blocks.p, nBlocks, wdepth.p,
+  // no in-range depth exceeds this, known without a round trip: the data set's barcode count (Ctx::depthBound) or the ranges' limit
+  const u32 goodDepthBound = hmin<u32>(c->depthBound, c->rangeHiMax ? c->rangeHiMax - 1 : 0);
+  const bool narrow = goodDepthBound <= 65535u;
+  const bool byBlocks = narrow && c->maxBlockHashes <= BLOCK_SORT_MAX;       // every block's list is built and sorted by one workgroup
+  if (byBlocks) {
+    int db = 1; while (db < 16 && (goodDepthBound >> db)) ++db;
+    const int sortBits = 16 + db + 1 > 32 ? 32 : 16 + db + 1;                 // one bit more than the largest key: padding keys sort last
+    const unsigned grid = hmin<u32>(nBlocks, 65535u * 4);
+    const int side = c->maxBlockHashes > BLOCK_SORT_CAP1 ? 2 : (c->maxBlockHashes > BLOCK_SORT_CAP0 ? 1 : 0);
+    if (side) H10X_TRY(c->forkStreams(side));
+    good_block_kernel<256, 12><<<grid, 256, 0, st>>>(c->clusHash.p, c->blockOff.p, c->blocks.p, nBlocks, wdepth.p, sortBits, c->goodPos.p, c->nGood.p, c->goodEntries.p);
+    if (side >= 1) good_block_kernel<512, 12><<<grid, 512, 0, c->aux[0]>>>(c->clusHash.p, c->blockOff.p, c->blocks.p, nBlocks, wdepth.p, sortBits, c->goodPos.p, c->nGood.p, c->goodEntries.p);
+    if (side >= 2) good_block_kernel<1024, 8><<<grid, 1024, 0, c->aux[1]>>>(c->clusHash.p, c->blockOff.p, c->blocks.p, nBlocks, wdepth.p, sortBits, c->goodPos.p, c->nGood.p, c->goodEntries.p);
+    if (side) H10X_TRY(c->joinStreams(side));
+  }
+  else if (narrow) { H10X_HIP(c, key32.alloc(H)); H10X_HIP(c, keyS32.alloc(H)); } else { H10X_HIP(c, key.alloc(H)); H10X_HIP(c, keyS.alloc(H)); }
+  if (byBlocks) {}
+  else if (narrow) good_keys_kernel<u32><<<hmin<u32>(nBlocks, 16384), 256, 0, st>>>(c->clusHash.p, c->blockOff.p, c->blocks.p, nBlocks, wdepth.p,
                                                                              key32.p, c->nGood.p, segEnd.p, c->goodEntries.p);
   else good_keys_kernel<u64><<<hmin<u32>(nBlocks, 16384), 256, 0, st>>>(c->clusHash.p, c->blockOff.p, c->blocks.p, nBlocks, wdepth.p,
                                                                       key.p, c->nGood.p, segEnd.p, c->goodEntries.p);
@@ -130,7 +184,7 @@ int stageC_depthRange(Ctx *c, int lo, int hi) {
   c->maxGoodDepth = hr[0]; c->maxGood = hr[1]; c->meanGood = nBlocks > 1 ? (u32)(sumGood / (nBlocks - 1)) : 0;
   offsets32c_kernel<<<divUp((u64)nBlocks + 1, 256), 256, 0, st>>>(c->blockOff.p, nBlocks + 1, off32.p);
   // ascending (depth, position): qsort by depth, stable => ties by position (hash10x.c:726-730,758)
-  if (H) {
+  if (H && !byBlocks) {
     if (narrow) {
       H10X_TRY(prim_seg_sort_keys_u32(c, pt, key32.p, keyS32.p, (u32)H, nBlocks, off32.p, segEnd.p, 0, 16 + bitsForC(hr[0])));
       good_pos_kernel<u32><<<(unsigned)hmin<u64>(divUp(H, 256), 65535u * 2), 256, 0, st>>>(keyS32.p, H, c->goodPos.p);
