@@ -535,16 +535,12 @@ __device__ void cluster_one_block(const ClusterArgs &a, u32 code, unsigned char 
       if (tid == 0) a.overflow[atomicAdd(a.overflowCount, 1u)] = code;
       return;
     }
-  } else nW = IN_LDS ? histWaves(RANKED ? rankedFirstEstimate(a.nBlocksFirst, n) : (FIRST_LDS ? a.nBlocksFirst : 0), n, CL_WAVES, bmWords, sizeof(CT), a.ldsBudget) : (u32)CL_WAVES;
-  if (!nW) return;                                           // cannot happen: the classification sends such a barcode to the HBM-scratch class
-  u32 firstCap = 0;                                          // ranked placement: first[] gets every byte the budget leaves
-  if constexpr (RANKED) {
-    const size_t used = workBytes(0, n, nW, bmWords, sizeof(CT));
-    const size_t room = a.ldsBudget > used + 32 ? (a.ldsBudget - used - 32) / 2 : 0;
-    firstCap = (u32)(room < 65535 ? room : 65535); if (firstCap > a.nBlocksFirst) firstCap = a.nBlocksFirst;
-    if (a.firstCap && firstCap > a.firstCap) firstCap = a.firstCap;          // test knob
-  }
-  Work<CT> w = carve<CT>(region, HASHED ? 2 * slots : (RANKED ? firstCap : (FIRST_LDS || !IN_LDS ? a.nBlocksFirst : 0)), n, bmWords);
+  } else if constexpr (RANKED) nW = 0;                       // ranked placement: decided once the bitmap pass has counted the barcodes present
+  else nW = IN_LDS ? histWaves(FIRST_LDS ? a.nBlocksFirst : 0, n, CL_WAVES, bmWords, sizeof(CT), a.ldsBudget) : (u32)CL_WAVES;
+  if (!RANKED && !nW) return;                                // cannot happen: the classification sends such a barcode to the HBM-scratch class
+  // ranked placement: first[] lies BEHIND the histograms and both are laid out after the bitmap pass, when the number of
+  // barcodes present is known: the list loop then runs on as many waves as what is left of the budget has room for
+  Work<CT> w = carve<CT>(region, HASHED ? 2 * slots : (RANKED ? 0 : (FIRST_LDS || !IN_LDS ? a.nBlocksFirst : 0)), n, bmWords);
   if (IN_LDS && FIRST_MODE == 2) w.first = firstGlobal;      // hybrid: first[] on this workgroup's HBM slot, the rest in LDS
   typename std::conditional<HASHED, FirstHashed, typename std::conditional<RANKED, FirstRanked, FirstDense<FIRST_LDS>>::type>::type ft{};
   if constexpr (HASHED) { slots &= ~3u; ft.tab = (u32 *)w.first; ft.NB = slots / 4; ft.recip = (u32)((0x100000000ULL + ft.NB - 1) / ft.NB); ft.bmask = a.hashMask; ft.ovf = &sh[2]; }
@@ -560,7 +556,7 @@ __device__ void cluster_one_block(const ClusterArgs &a, u32 code, unsigned char 
   if (FIRST_LDS && !RANKED) for (u32 i = tid; i < (HASHED ? slots : (a.nBlocksFirst + 1) / 2); i += CL_THREADS) ((u32 *)w.first)[i] = 0xFFFFFFFFu;
   if (HASHED && tid == 0) sh[2] = 0;
   if (RANKED) for (u32 i = tid; i < bmWords; i += CL_THREADS) w.bm[i] = 0;
-  for (u32 i = tid; i < nW * w.histWords; i += CL_THREADS) w.hist[i] = 0;
+  if (!RANKED) for (u32 i = tid; i < nW * w.histWords; i += CL_THREADS) w.hist[i] = 0;
   u64 myDepth = 0;
   for (u32 i = tid; i < n; i += CL_THREADS) {
     const u32 x = ch[g[i]].hash; const u32 d = a.hashDepth[x];
@@ -596,11 +592,20 @@ __device__ void cluster_one_block(const ClusterArgs &a, u32 code, unsigned char 
     u32 run = inc - mine, total = 0;
     for (int q = 0; q < CL_WAVES; ++q) { if (q < wave) run += sh[4 + q]; total += sh[4 + q]; }
     for (u32 q = s0; q < s1; ++q) { w.pre[q] = (u16)run; run += (u32)__popc(w.bm[q]); }
-    if (total > firstCap) {                                   // uniform: every thread sees the same total
-      if (tid == 0) a.overflow[atomicAdd(a.overflowCount, 1u)] = lcode;
-      SYNC();
-      return;
+    {                                                         // uniform: every thread sees the same total
+      const size_t fixed = workBytes(0, n, 0, bmWords, sizeof(CT)), per = (size_t)w.histWords * 4, need = (((size_t)total * 2 + 15) & ~(size_t)15) + 32;
+      const bool fits = total <= 65535u && fixed + need + MIN_HIST_WAVES * per <= a.ldsBudget && !(a.firstCap && total > a.firstCap);   // (firstCap: test knob)
+      if (!fits) {                                             // more barcodes present than this class has room for: the next larger class takes the block
+        if (tid == 0) a.overflow[atomicAdd(a.overflowCount, 1u)] = lcode;
+        SYNC();
+        return;
+      }
+      const size_t wv = (a.ldsBudget - fixed - need) / (per ? per : 1);
+      nW = wv < (size_t)CL_WAVES ? (u32)wv : (u32)CL_WAVES;
+      w.first = (u16 *)((unsigned char *)w.hist + (((size_t)nW * per + 15) & ~(size_t)15));
+      ft.first = w.first;
     }
+    for (u32 i = tid; i < nW * w.histWords; i += CL_THREADS) w.hist[i] = 0;
     for (u32 q = tid; q < (total + 1) / 2; q += CL_THREADS) ((u32 *)w.first)[q] = 0xFFFFFFFFu;
     SYNC();
   }

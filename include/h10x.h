@@ -78,7 +78,10 @@ const char *h10x_last_error(const h10x_ctx *ctx);
 /* replaces readFQB() + fillHashTable() (hash10x.c:188-236, 317-347) for a whole sorted .fqb image:
    n_records records of 30 uint32 (fq2b.c:142-160). Barcode blocks are runs of equal word 0; the
    block still open at the end is kept with nHash = 0 (hash10x.c:209). The caller applies
-   -N (pass only the first N records) and the reference's chunkSize check (h10x_host_check_chunks).
+   -N (pass only the first N records). The side effects of the reference's chunked fread loop (hash10x.c:202-223:
+   die("chunkSize too small") for a barcode of chunkSize or more pairs, and the all-A barcode swallowing the next run
+   when its own run ends at a chunk boundary, hash10x.c:212) are replayed from the barcode run starts when
+   h10x_set_option(ctx, "chunk_size", c) was called with c > 0 (the session layer passes -c); 0 = no chunk semantics.
    _device: records already resident in device memory (HBM). */
 int  h10x_read_fqb(h10x_ctx *ctx, const uint32_t *host_records, uint64_t n_records);
 int  h10x_read_fqb_device(h10x_ctx *ctx, const uint32_t *dev_records, uint64_t n_records);
