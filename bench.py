@@ -244,6 +244,17 @@ def secondary_block(hash10x_amd, local_rank):
     alg = 4.0 * c["cluster_main"][1] + 14.0 * c["cluster_main"][0] + 16.0 * c["cluster_main"][2]
     clu_all_ms = tm["cluster_kernel"][0] / steps
     alg_all = 4.0 * c["sum_good_depth"] + 14.0 * c["sum_good"] + 16.0 * c["sum_hash_clustered"]
+    c3_traffic = c3_src = None                              # rocprofv3 --pmc passes of this workload, committed under profiles/
+    try:
+        import glob
+        cands = sorted(glob.glob(os.path.join(REPO, "profiles", "*config3*_pmc_traffic.json")))
+        if cands:
+            pm = json.load(open(cands[-1]))
+            tb = sum(sum(x["bytes_per_step"] for x in v.values()) for k, v in pm["kernels"].items() if pm.get("dominant", "cluster_kernel") in k)
+            if tb:
+                c3_traffic, c3_src = tb, os.path.basename(cands[-1])
+    except Exception:
+        pass
     out = {"workload": "config3-tenth-20M (BASELINE configs[2] proportions at 1/10: 20 M pairs, 100 k barcodes, 50 Mb x 2, e = 0.1 %, -B 26)",
            "ms_per_step": 1e3 * sum(wall) / len(wall), "read_pairs_per_s": pairs * len(wall) / sum(wall), "steps": steps,
            "device_ms_per_step": {k: round(v[0] / steps, 3) for k, v in tm.items() if v[0] > 0},
@@ -254,7 +265,7 @@ def secondary_block(hash10x_amd, local_rank):
                         "frac": alg / (main_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if main_ms else None, "algorithmic_bytes_per_launch": alg, "avg_launch_ms": main_ms,
                         "barcodes_in_launch": c["cluster_main"][3],
                         "all_cluster_launches": {"GB/s": alg_all / (clu_all_ms * 1e-3) / 1e9 if clu_all_ms else None, "ms_per_step": clu_all_ms, "algorithmic_bytes": alg_all}},
-           "generate_seconds": gen_s,
+           "generate_seconds": gen_s, "traffic": c3_traffic, "traffic_source": c3_src,
            "parity": "tests/test_gpu_parity.py::test_config3_proportions_match_reference_digests pins this exact set (sha256 of the reference binary's .hash)"}
     h.close(); d.free()
     return out
@@ -399,7 +410,7 @@ def main():
     traffic = traffic_src = None
     try:
         import glob
-        cands = sorted(glob.glob(os.path.join(REPO, "profiles", "*_pmc_traffic.json")))
+        cands = sorted(f for f in glob.glob(os.path.join(REPO, "profiles", "*_pmc_traffic.json")) if "config3" not in os.path.basename(f))
         if cands and args.workload == "yeast-like-2.5M" and world == 1:
             pm = json.load(open(cands[-1]))
             tb = sum(sum(c["bytes_per_step"] for c in v.values()) for k, v in pm["kernels"].items() if (pm.get("dominant") or dom.split("_")[0]) in k)

@@ -53,7 +53,7 @@ interesting = ("h10x::", "radix_sort", "segmented", "onesweep")
 traffic = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, no trace flags) -- python3 <script>; dispatches of the last step",
            "unit": "bytes (counter value x 1024)",
            "note": "raw counters; MI355X_MICROARCH.md: on gfx950 FETCH_SIZE reads 1/2 of wide (16 B/lane) coalesced reads; 4-8 B/lane gathers are uncalibrated",
-           "dominant": "cluster_kernel<true, 0, 1024, 0>", "kernels": {}}
+           "dominant": "cluster_kernel<true, 1, 1024, 0>" if "config3" in tag else "cluster_kernel<true, 0, 1024, 0>", "kernels": {}}
 for counter, sub in (("FETCH_SIZE", "fetch"), ("WRITE_SIZE", "write")):
     per, _ = load(os.path.join(G, "%s_%s" % (tag, sub)))
     for k, cs in per.items():

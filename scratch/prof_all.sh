@@ -8,9 +8,13 @@ TAG=$1; SCRIPT=${2:-scratch/one_step.py}
 export TMPDIR=/tmp
 O=gpurun_out
 mkdir -p $O
-python3 bench.py --steps 10 --warmup 2 > $O/${TAG}_bench.json 2> $O/${TAG}_bench.err
-echo "bench done"
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/${TAG}_stats -o runc -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline > $O/${TAG}_bench_under_rocprof.json 2> $O/${TAG}_rocprof.err
+if [ -z "$SKIP_BENCH" ]; then
+  python3 bench.py --steps 10 --warmup 2 > $O/${TAG}_bench.json 2> $O/${TAG}_bench.err
+  echo "bench done"
+  rocprofv3 --kernel-trace --stats --output-format csv -d $O/${TAG}_stats -o runc -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-secondary > $O/${TAG}_bench_under_rocprof.json 2> $O/${TAG}_rocprof.err
+else                                            # another workload than the bench's: trace the script itself
+  rocprofv3 --kernel-trace --stats --output-format csv -d $O/${TAG}_stats -o runc -- python3 $SCRIPT > $O/${TAG}_trace.log 2> $O/${TAG}_rocprof.err
+fi
 echo "kernel trace done"
 pass() { rocprofv3 --pmc $2 --output-format csv -d $O/${TAG}_$1 -o runc -- python3 $SCRIPT > $O/${TAG}_$1.log 2>&1; echo "pass $1 done"; }
 pass fetch "FETCH_SIZE"
