@@ -84,6 +84,7 @@ def load_native():
     host.h10x_session_shardReadFQB_mem.argtypes = [vp, vp, vp, cu64]
     host.h10x_session_shardReadFQB_dev.argtypes = [vp, vp, vp, cu64]
     host.h10x_session_shardGather.argtypes = [vp]
+    host.h10x_session_shardReadHash.argtypes = [vp, vp, cs]
     host.h10x_session_shardReadFQB_file.argtypes = [vp, vp, cs, cu64, cu64]
     host.h10x_host_partition_file.argtypes = [cs, cu64, ci, vp, cs, ci]
     host.h10x_session_cribBuild.argtypes = [vp, cs, cs, vp, ci]
@@ -279,6 +280,11 @@ class Hash10x:
 
     def shard_read_fqb_device(self, comm, dev_ptr, n_records):
         self._chk(self._host.h10x_session_shardReadFQB_dev(self._s, comm.handle, ctypes.c_void_p(dev_ptr), int(n_records)))
+        self._after_init()
+
+    def shard_read_hash(self, comm, path):
+        """Sharded --readHash (collective): every rank loads the replicated tables and its own cut of the file's blocks."""
+        self._chk(self._host.h10x_session_shardReadHash(self._s, comm.handle, os.fsencode(path)))
         self._after_init()
 
     def shard_gather(self):

@@ -171,11 +171,11 @@ __global__ void validate_table_kernel(const u32 *__restrict__ table, u64 n, u32 
 
 extern "C" {
 
-int h10x_load_state(h10x_ctx *h, const uint32_t *hashIndex, uint32_t hashNumber, const uint64_t *hashValue,
-                    const uint32_t *hashDepth, const h10x_block *blocks, uint32_t nBlocks, const h10x_clushash *clusHash) {
-  if (!h) return -1;
-  Ctx &c = h->c;
-  H10X_TRY(enter(c));
+}  // extern "C"
+namespace h10x { int shard_adoptLoadedState(Ctx *c, Comm *cm, u32 codeBase, u32 nBlocksGlobal); }
+// the tables of a parsed .hash file (or of one rank's share of it: blocks = slot 0 + the rank's blocks) onto the device, validated
+static int upload_state(Ctx &c, const uint32_t *hashIndex, uint32_t hashNumber, const uint64_t *hashValue,
+                        const uint32_t *hashDepth, const h10x_block *blocks, uint32_t nBlocks, const h10x_clushash *clusHash) {
   if (!hashIndex || !hashValue || !hashDepth || !blocks || nBlocks < 1 || hashNumber < 1) return c.fail("h10x_load_state: bad argument");
   reset_state(c);
   hipStream_t st = c.stream;
@@ -208,11 +208,31 @@ int h10x_load_state(h10x_ctx *h, const uint32_t *hashIndex, uint32_t hashNumber,
     if (hb[2]) return c.fail("corrupt hash file: %u blocks with more than 255 sub-clusters", hb[2]);
     // (a label above its block's nSubCluster is what re-clustering a clustered file can leave behind in the reference too: tolerated, see DESIGN)
   }
+  c.ctr.entries = H; c.ctr.distinct = hashNumber - 1;
+  return 0;
+}
+extern "C" {
+int h10x_load_state(h10x_ctx *h, const uint32_t *hashIndex, uint32_t hashNumber, const uint64_t *hashValue,
+                    const uint32_t *hashDepth, const h10x_block *blocks, uint32_t nBlocks, const h10x_clushash *clusHash) {
+  if (!h) return -1;
+  Ctx &c = h->c;
+  H10X_TRY(enter(c));
+  H10X_TRY(upload_state(c, hashIndex, hashNumber, hashValue, hashDepth, blocks, nBlocks, clusHash));
   c.segs.n = 1; c.segs.s[0] = BlockSeg{0, nBlocks, 0};
   H10X_TRY(stageB_buildCSR(&c));                              // fillHashTable (hash10x.c:1210)
-  c.ctr.entries = H; c.ctr.distinct = hashNumber - 1;
   c.haveState = true;
   return 0;
+}
+int h10x_shard_load_state(h10x_ctx *h, const uint32_t *hashIndex, uint32_t hashNumber, const uint64_t *hashValue, const uint32_t *hashDepth,
+                          const h10x_block *localBlocks, uint32_t nLocalBlocks, const h10x_clushash *localClusHash, uint32_t codeBase, uint32_t nBlocksGlobal) {
+  if (!h) return -1;
+  Ctx &c = h->c;
+  H10X_TRY(enter(c));
+  if (!c.comm) return c.fail("h10x_shard_load_state: no communicator attached");
+  Comm *cm = c.comm;
+  H10X_TRY(upload_state(c, hashIndex, hashNumber, hashValue, hashDepth, localBlocks, nLocalBlocks, localClusHash));
+  c.comm = cm;
+  return shard_adoptLoadedState(&c, cm, codeBase, nBlocksGlobal);
 }
 
 int h10x_depth_range(h10x_ctx *h, int32_t lo, int32_t hi) {

@@ -634,6 +634,41 @@ int shard_split(Ctx *c, const u32 *dSubBefore, u32 totalSubLocal) {
   return shard_rebuildOwnerLists(c);
 }
 
+// ---------------------------------------------------------------------------------------- --readHash onto shards
+// The tables of a .hash file are on this rank's device (h10x_api.hip upload_state): hashIndex / hashValue / hashDepth of the
+// whole set, and the blocks [codeBase + 1, codeBase + nBlocks) of the file with their ClusterHash records (any contiguous cut of
+// the file's block order will do — blocks made by an earlier --clusterSplit are blocks like any other). What is missing are the
+// hash owners' barcode lists: ownership is by INDEX range here (rank r owns indices 1 + U r / N ...), the list lengths are the
+// depths, and the lists are filled by the same exchange that follows a --clusterSplit.
+__global__ void iota_from_kernel(u32 *__restrict__ p, u32 n, u32 from) { const u32 i = blockIdx.x * blockDim.x + threadIdx.x; if (i < n) p[i] = from + i; }
+__global__ void add_base_kernel(const u64 *__restrict__ in, u32 n, u32 *__restrict__ out) { const u32 i = blockIdx.x * blockDim.x + threadIdx.x; if (i < n) out[i] = (u32)in[i]; }
+int shard_adoptLoadedState(Ctx *c, Comm *cm, u32 codeBase, u32 nBlocksGlobal) {
+  hipStream_t st = c->stream; PrimTemp pt;
+  const int N = cm->n, me = cm->rank; const u32 U = c->hashNumber - 1;
+  c->comm = cm; c->sharded = true; c->codeBase = codeBase; c->nBlocksGlobal = nBlocksGlobal;
+  c->segs.n = 1; c->segs.s[0] = BlockSeg{0, c->nBlocks, codeBase};
+  c->tablesPending = false; c->rowShift = 0;
+  const u32 lo = 1 + (u32)((u64)U * (u64)me / (u64)N), hi = 1 + (u32)((u64)U * ((u64)me + 1) / (u64)N), Uo = hi - lo;
+  H10X_HIP(c, c->oIndex.alloc(Uo)); H10X_HIP(c, c->oSegStart.alloc((size_t)Uo + 1));
+  if (Uo) iota_from_kernel<<<divUp(Uo, 256), 256, 0, st>>>(c->oIndex.p, Uo, lo);
+  DevBuf<u64> off; DevBuf<u32> dep; H10X_HIP(c, off.alloc((size_t)Uo + 1)); H10X_HIP(c, dep.alloc((size_t)Uo + 1));
+  if (Uo) H10X_HIP(c, hipMemcpyAsync(dep.p, c->hashDepth.p + lo, (size_t)Uo * 4, hipMemcpyDeviceToDevice, st));
+  H10X_HIP(c, hipMemsetAsync(dep.p + Uo, 0, 4, st));
+  H10X_TRY(prim_exclusive_scan_u32_u64(c, pt, dep.p, off.p, (size_t)Uo + 1));
+  u64 M = 0;
+  H10X_TRY(c->readback(&M, off.p + Uo, 8));
+  H10X_TRY(c->syncReadbacks());
+  u64 worst = M; { std::vector<u64> all((size_t)N); H10X_TRY(cm->allgatherHost(c, &M, all.data(), 8)); for (u64 x : all) worst = x > worst ? x : worst; }
+  if (worst >= (1ULL << 32)) return c->fail("more than 2^32 entries land on one hash owner: over this build's per-GPU limit");   // the same verdict on every rank
+  add_base_kernel<<<divUp((u64)Uo + 1, 256), 256, 0, st>>>(off.p, Uo + 1, c->oSegStart.p);
+  c->oU = Uo; c->oM = M;
+  H10X_TRY(shard_refreshLayout(c));
+  if (c->nBlocksGlobal != nBlocksGlobal) return c->fail("sharded --readHash: %u blocks laid out, the file holds %u", c->nBlocksGlobal, nBlocksGlobal);
+  c->haveState = true;
+  c->ownerListsStale = true;
+  return shard_rebuildOwnerLists(c);                         // also the consistency check: every owner must receive exactly its depths' worth of entries
+}
+
 // ---------------------------------------------------------------------------------------- gather for a single-GPU continuation
 __global__ void blocks_nhash_kernel(const h10x_block *__restrict__ blocks, u32 nBlocks, u32 *__restrict__ nHash) {
   const u32 i = blockIdx.x * blockDim.x + threadIdx.x;

@@ -415,6 +415,75 @@ done:
   return rc;
 }
 
+/* --readHash onto N ranks (collective): every rank reads the replicated tables and the block array, takes a contiguous cut of the
+   blocks balanced by ClusterHash records, and preads its own records. Same checks and messages as the single-GPU reader. */
+int h10x_session_shardReadHash(h10x_session *s, h10x_comm *comm, const char *path) {
+  const int rank = h10x_comm_rank(comm), nranks = h10x_comm_size(comm);
+  FILE *f = fopen(path, "rb");
+  if (!f) return fail(s, "failed to open hash file %s", path);
+  if (session_init(s)) { fclose(f); return -1; }
+  if (h10x_shard_attach(s->ctx, comm)) { fclose(f); return fail(s, "h10x_shard_attach failed"); }
+  int rc = 0;
+  struct { char magic[4]; uint32_t version; uint16_t chs, cbs; int32_t B; } head;
+  uint32_t *hashIndex = 0, *depth = 0; uint64_t *hashValue = 0; h10x_block *blocks = 0; h10x_clushash *ch = 0;
+  uint32_t hashNumber = 0; array_hdr h, hb;
+  const uint64_t T = (uint64_t)1 << s->B;
+  if (fread(&head, 16, 1, f) != 1) { rc = fail(s, "read fail 0"); goto done; }
+  if (memcmp(head.magic, "10XH", 4)) { rc = fail(s, "not a 10X hash file"); goto done; }
+  if (head.version != 2) { rc = fail(s, "hash file version %d: only version 2 files can be read onto several GPUs", (int)head.version); goto done; }
+  if (head.chs != 8) { rc = fail(s, "ClusterHash structure size mismatch: file %d != code %d", head.chs, 8); goto done; }
+  if (head.cbs != 32) { rc = fail(s, "ClusterBlock structure size mismatch: file %d != code %d", head.cbs, 32); goto done; }
+  if (head.B != s->B) { rc = fail(s, "incompatible hash table size: rerun with -B %d", head.B); goto done; }
+  hashIndex = (uint32_t *)malloc(T * 4);
+  if (!hashIndex || fread(hashIndex, 4, T, f) != T) { rc = fail(s, "read fail 2"); goto done; }
+  if (fread(&hashNumber, 4, 1, f) != 1) { rc = fail(s, "failed to read hashNumber"); goto done; }
+  if (hashNumber > (T >> 2)) { rc = fail(s, "failed to read hashValue"); goto done; }
+  hashValue = (uint64_t *)malloc((size_t)hashNumber * 8 + 8);
+  if (!hashValue || fread(hashValue, 8, hashNumber, f) != hashNumber) { rc = fail(s, "failed to read hashValue"); goto done; }
+  if (fread(&h, 32, 1, f) != 1 || h.size != 4 || h.dim < 0) { rc = fail(s, "failed to read hashDepth array"); goto done; }
+  depth = (uint32_t *)calloc((size_t)(h.dim > (int)hashNumber ? h.dim : (int)hashNumber) + 1, 4);
+  if (!depth || fread(depth, 4, (size_t)h.dim, f) != (size_t)h.dim) { rc = fail(s, "failed to read hashDepth array"); goto done; }
+  if (fread(&hb, 32, 1, f) != 1 || hb.size != 32 || hb.dim < hb.max || hb.max < 1) { rc = fail(s, "failed to read clusterBlocks array"); goto done; }
+  blocks = (h10x_block *)calloc((size_t)hb.dim + 1, 32);
+  if (!blocks || fread(blocks, 32, (size_t)hb.dim, f) != (size_t)hb.dim) { rc = fail(s, "failed to read clusterBlocks array"); goto done; }
+  {
+    const off_t chBase = ftello(f);
+    uint64_t total = 0; for (int i = 1; i < hb.max; ++i) total += blocks[i].nHash;
+    /* cut b_r = first block of rank r: the first block at which the records before it reach r / nranks of the total */
+    uint32_t b0 = 1, b1 = (uint32_t)hb.max; uint64_t e0 = 0, e1 = total, acc = 0; int next = 1;
+    if (rank == 0) { b0 = 1; e0 = 0; }
+    for (int i = 1; i <= hb.max; ++i) {
+      while (next <= nranks - 1 && (i == hb.max || acc >= (uint64_t)(((__uint128_t)total * (unsigned)next) / (unsigned)nranks))) {
+        if (next == rank) { b0 = (uint32_t)i; e0 = acc; }
+        if (next == rank + 1) { b1 = (uint32_t)i; e1 = acc; }
+        ++next;
+      }
+      if (i < hb.max) acc += blocks[i].nHash;
+    }
+    const uint32_t nLocal = b1 - b0 + 1;                                             /* slot 0 + my blocks */
+    h10x_block *mine = (h10x_block *)calloc((size_t)nLocal, 32);
+    ch = (h10x_clushash *)malloc(e1 > e0 ? (e1 - e0) * 8 : 8);
+    if (!mine || !ch) { free(mine); rc = fail(s, "out of host memory for the blocks of rank %d", rank); goto done; }
+    memcpy(mine + 1, blocks + b0, (size_t)(b1 - b0) * 32);
+    if (e1 > e0 && (fseeko(f, chBase + (off_t)(e0 * 8), SEEK_SET) || fread(ch, 8, e1 - e0, f) != e1 - e0)) { free(mine); rc = fail(s, "read fail 3"); goto done; }
+    if (hashNumber < 1) hashNumber = 1;
+    if (h10x_shard_load_state(s->ctx, hashIndex, hashNumber, hashValue, depth, mine, nLocal, ch, b0 - 1, (uint32_t)hb.max)) rc = fail_ctx(s);
+    free(mine);
+    if (rc) goto done;
+  }
+  s->depthDim = h.dim; s->depthMax = h.max; s->blocksDim = hb.dim; s->blocksMax = hb.max;
+  free(s->depthTail); s->depthTail = 0;
+  if (h.dim > (int)hashNumber) {                                                    /* keep the bytes the file carries beyond hashNumber */
+    s->depthTailFrom = (int)hashNumber;
+    s->depthTail = (uint32_t *)malloc((size_t)(h.dim - (int)hashNumber) * 4);
+    memcpy(s->depthTail, depth + hashNumber, (size_t)(h.dim - (int)hashNumber) * 4);
+  }
+done:
+  fclose(f);
+  free(hashIndex); free(hashValue); free(depth); free(blocks); free(ch);
+  return rc;
+}
+
 /* ---------------------------------------------------------------------------------------------------------------------
  * --hashStats / --codeStats (hash10x.c:351-402). The histograms are filled on the device (h10x_report_histogram) and
  * summed over the ranks; what is left is the summary line and the table. The arithmetic keeps the reference's types so

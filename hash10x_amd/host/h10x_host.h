@@ -64,6 +64,7 @@ int  h10x_session_sortFQB(h10x_session *s, const char *inPath, const char *outPa
 int  h10x_session_shardReadFQB_mem(h10x_session *s, h10x_comm *comm, const uint32_t *shardRecords, uint64_t nRecords);
 int  h10x_session_shardReadFQB_dev(h10x_session *s, h10x_comm *comm, const uint32_t *devShardRecords, uint64_t nRecords);
 int  h10x_session_shardReadFQB_file(h10x_session *s, h10x_comm *comm, const char *path, uint64_t firstRecord, uint64_t nRecords);
+int  h10x_session_shardReadHash(h10x_session *s, h10x_comm *comm, const char *path);      /* --readHash: every rank reads its cut of the blocks */
 int  h10x_session_shardGather(h10x_session *s);
 
 /* dimension the reference's Array reaches when elements are first touched in ascending order up to

@@ -100,7 +100,7 @@ static void usage(void) {
   fprintf(stderr, "   -t | --threads <n> : accepted and ignored (clustering runs on the GPU)\n");
   fprintf(stderr, "   -o | --output <output filename> : '-' for stdout\n");
   fprintf(stderr, "   --device <HIP device ordinal> [0]\n");
-  fprintf(stderr, "   --gpus <n> [1]: shard the barcodes of the next --readFQB over n GPUs (devices device, device+1, ...)\n");
+  fprintf(stderr, "   --gpus <n> [1]: shard the barcodes of the next --readFQB / --readHash over n GPUs (devices device, device+1, ...)\n");
   fprintf(stderr, "   --sortFQB <fqb from fq2b> <sorted fqb output>: sort records by barcode on the GPU (instead of bsort -k 4 -r 120)\n");
   fprintf(stderr, "   --readFQB <sorted fqb input file name>: must have this or readHash\n");
   fprintf(stderr, "   --readHash <hash input file name>\n");
@@ -151,10 +151,10 @@ static void cmd_readFQB(char **a) {
   say("  created %llu hashes, mean %.2f hashes per read pair, %.2f per barcode\n", (unsigned long long)z.nEntriesGlobal, z.nEntriesGlobal / (double)z.nRecordsGlobal, z.nEntriesGlobal / nb);
   say_filled(&z);
 }
+static int rank_readHash(h10x_session *s, int r, void *a) { return team.n == 1 ? h10x_session_readHash(s, (const char *)a) : h10x_session_shardReadHash(s, team.comm[r], (const char *)a); }
 static void cmd_readHash(char **a) {
-  if (team.n > 1) die("--readHash after --gpus %d: a .hash file is loaded on one GPU in this build (give --gpus 1, or start from --readFQB)", team.n);
   say_initialised();
-  if (h10x_session_readHash(team.s[0], a[0])) die_of(1);
+  const int bad = on_all_ranks(rank_readHash, a[0]); if (bad) die_of(bad);
   const h10x_shard_info_t z = sizes_now();
   say("  read %llu hashes in %u barcode blocks\n", (unsigned long long)z.nEntriesGlobal, z.nBlocksGlobal);
   say_filled(&z);

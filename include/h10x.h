@@ -164,6 +164,13 @@ int  h10x_shard_attach(h10x_ctx *ctx, h10x_comm *comm);
    set (only --writeHash and the crib read them) are built by h10x_shard_gather, not here. */
 int  h10x_shard_read_fqb(h10x_ctx *ctx, const uint32_t *host_records, uint64_t n_records);
 int  h10x_shard_read_fqb_device(h10x_ctx *ctx, const uint32_t *dev_records, uint64_t n_records);
+/* --readHash onto shards (collective): the replicated tables of the file (hashIndex, hashValue, hashDepth: whole data set) plus THIS
+   rank's contiguous cut of the file's blocks — localBlocks[0] unused, localBlocks[1 ..] = blocks codeBase + 1 .. of the file, with
+   their ClusterHash records concatenated. The hash owners' barcode lists are rebuilt by an exchange (ownership by index range);
+   inconsistent files (entries of a hash != its depth) are refused there. */
+int  h10x_shard_load_state(h10x_ctx *ctx, const uint32_t *hashIndex, uint32_t hashNumber, const uint64_t *hashValue,
+                           const uint32_t *hashDepth, const h10x_block *localBlocks, uint32_t nLocalBlocks,
+                           const h10x_clushash *localClusHash, uint32_t codeBase, uint32_t nBlocksGlobal);
 /* collective: every rank builds hashValue / hashIndex of the whole set; rank 0 receives every rank's blocks and
    clusHash (in file order), rebuilds the barcode lists and from then on IS a single-GPU context (for continuing on one
    GPU; --writeHash and the reports work on the shards directly, see below) */

@@ -31,6 +31,8 @@ def run(n_cases, seed, verbose=False):
         if rng.random() < 0.5: args += ["--hashStats"]
         args += ["--hashDepthRange", lo, hi, "--cluster", 1, 0]
         if rng.random() < 0.5: args += ["--codeStats"]
+        if rng.random() < 0.3:                                 # through a .hash file, read back on the same number of GPUs
+            args += ["--writeHash", "mid.hash", "--readHash", "mid.hash", "--hashDepthRange", lo, hi]
         crib = rng.random() < 0.6
         if crib:
             if rng.random() < 0.5: args += ["--tables"]

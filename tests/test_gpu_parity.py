@@ -690,3 +690,33 @@ def test_two_processes_over_the_socket_communicator(workdir):
             assert p.returncode == 0, se.decode()[-1500:]
         got = open(workdir.file("p%d.hash" % n), "rb").read()
         assert got == exp, orc.describe_diff(got, exp)
+
+
+@pytest.mark.parametrize("gpus", [2, 3])
+def test_cli_read_hash_onto_several_gpus(workdir, gpus):
+    """The README's main recipe (`--readHash x.hash --hashDepthRange .. --cluster 1 0 --clusterSplit --writeHash`, README.md:29) under
+    --gpus N: every rank loads the replicated tables and its own cut of the file's blocks, the hash owners' barcode lists are
+    rebuilt by an exchange, and the result is the single-GPU / oracle file. Also a file that already holds split blocks."""
+    import subprocess
+    workdir.need("small.hash.gz")
+    exe = os.path.join(orc.REPO, "bin", "hash10x-amd")
+    tail = ["-B", "20", "-ct", "2", "--readHash", "small.hash", "--hashDepthRange", "3", "14", "--cluster", "1", "0", "--clusterSplit", "--writeHash", "OUT"]
+    o = orc.Oracle(B=20); o.read_hash(workdir.file("small.hash")); o.depth_range(3, 14); o.cluster(1, 0, 2); o.cluster_split(); o.write_hash(workdir.file("orc.hash"))
+    exp = open(workdir.file("orc.hash"), "rb").read()
+    g = subprocess.run([exe, "--gpus", str(gpus)] + [a if a != "OUT" else "hip.hash" for a in tail], cwd=workdir.path, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert g.returncode == 0, g.stderr.decode()
+    got = open(workdir.file("hip.hash"), "rb").read()
+    assert got == exp, orc.describe_diff(got, exp)
+    # second generation: read the split file back onto the GPUs, cluster the split blocks, split again
+    tail2 = ["-B", "20", "-ct", "2", "--readHash", "hip.hash", "--hashDepthRange", "3", "14", "--cluster", "1", "0", "--clusterSplit", "--codeStats", "--writeHash", "OUT"]
+    o = orc.Oracle(B=20); o.read_hash(workdir.file("orc.hash")); o.depth_range(3, 14); o.cluster(1, 0, 2); o.cluster_split(); o.write_hash(workdir.file("orc2.hash"))
+    g = subprocess.run([exe, "--gpus", str(gpus)] + [a if a != "OUT" else "hip2.hash" for a in tail2], cwd=workdir.path, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert g.returncode == 0, g.stderr.decode()
+    got, exp = open(workdir.file("hip2.hash"), "rb").read(), open(workdir.file("orc2.hash"), "rb").read()
+    assert got == exp, orc.describe_diff(got, exp)
+    # a file whose entries do not add up to its depths is refused by every rank together
+    bad = bytearray(open(workdir.file("small.hash"), "rb").read()); hf = orc.HashFile(bytes(bad))
+    bad[-8:-4] = (1).to_bytes(4, "little") if hf.clushash["hash"][-1] != 1 else (2).to_bytes(4, "little")
+    open(workdir.file("bad.hash"), "wb").write(bad)
+    g = subprocess.run([exe, "--gpus", str(gpus), "-B", "20", "--readHash", "bad.hash"], cwd=workdir.path, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert g.returncode == 255 and b"FATAL ERROR" in g.stderr

