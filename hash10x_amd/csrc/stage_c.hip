@@ -449,7 +449,9 @@ __device__ __forceinline__ void row_mode_hist(const u32 *__restrict__ row, u32 h
     }
   }
   best = NONE16; bcnt = 0;
-  if (tot < thr) return;
+  // lists of up to two chunks (nearly all) run straight through: a list with fewer usable entries than the threshold then
+  // counts and clears its few values for nothing, which is cheaper than two branches per list (2.41 -> 2.36 ms)
+  if (RCHUNK > 2 && tot < thr) return;
   u32 key = 0;
 #pragma unroll
   for (int r = 0; r < RCHUNK; ++r)
@@ -467,7 +469,7 @@ __device__ __forceinline__ void row_mode_hist(const u32 *__restrict__ row, u32 h
     }
   // no value reached the threshold (most lists): the caller only tests msMax >= threshold (hash10x.c:807), so the
   // wave reduction is skipped and the rank is reported inactive
-  if (!__builtin_amdgcn_ballot_w64((key >> 16) >= thr)) return;
+  if (RCHUNK > 2 && !__builtin_amdgcn_ballot_w64((key >> 16) >= thr)) return;
   key = wave_max_u32(key);
   bcnt = key >> 16;
   best = key ? 0xFFFFu - (key & 0xFFFFu) : NONE16;
@@ -497,6 +499,13 @@ __device__ void row_mode_long(const u32 *__restrict__ row, u32 d, u32 code, u32 
     }
   }
 }
+// what-if switches of scratch/skip_floor.py (option "cluster_dbg_skip"): compiled in only with -DH10X_DBG_SKIP — a runtime test per list
+// in the loop costs more than the phases they were built to weigh (2.29 -> 2.22 ms without them)
+#ifdef H10X_DBG_SKIP
+#define H10X_DBGSKIP(bit) (a.dbgSkip & (bit))
+#else
+#define H10X_DBGSKIP(bit) false
+#endif
 #define STAMP(k) do { if (a.phase && threadIdx.x == 0) { const u64 t__ = wall_clock64(); atomicAdd((u64 *)&a.phase[k], t__ - tPrev); tPrev = t__; } } while (0)
 
 // Workgroup barrier. In the HBM-scratch instantiation the working set lives in global memory and is re-used
@@ -632,7 +641,7 @@ __device__ void cluster_one_block(const ClusterArgs &a, u32 code, unsigned char 
     else { _Pragma("unroll") for (int t = 0; t < RIF; ++t) { const u32 i = ib + t; dv[t] = i < n ? (u32)w.dd[i] : 0; rv[t] = w.rs[i < n ? i : 0]; } } \
     _Pragma("unroll") for (int t = 0; t < RIF; ++t) {                                                         \
       const u32 i = ib + t;                                                                                   \
-      DL[t] = (i >= 1 && i < n) ? (u32)__builtin_amdgcn_readfirstlane((int)dv[t]) : 0;                        \
+      DL[t] = (u32)__builtin_amdgcn_readfirstlane((int)((i >= 1 && i < n) ? dv[t] : 0u));                     \
       RS[t] = (u32)__builtin_amdgcn_readfirstlane((int)rv[t]);                                                \
       CJ[t] = (u32)lane < DL[t] ? ROWP(RS[t])[lane] : code;                                                   \
     } }
@@ -656,26 +665,27 @@ __device__ void cluster_one_block(const ClusterArgs &a, u32 code, unsigned char 
 #pragma unroll
     for (int t = 0; t < RIF; ++t) {
       const u32 i = i0 + t;
-      if (a.dbgSkip & 1) { cj[t] = cj[t] != code ? cj[t] : NOHANDLE; continue; }
+      if (H10X_DBGSKIP(1)) { cj[t] = cj[t] != code ? cj[t] : NOHANDLE; continue; }
       cj[t] = cj[t] != code ? ft.update(cj[t], i) : NOHANDLE;          // from here on cj / cj2 hold handles
       if (dl[t] > WAVE) {
         cj2[t] = cj2[t] != code ? ft.update(cj2[t], i) : NOHANDLE;
         if (dl[t] > 2 * WAVE) { const u32 *row = ROWP(w.rs[i]); for (u32 j = 2 * WAVE + lane; j < dl[t]; j += WAVE) { const u32 c2 = row[j]; if (c2 != code) ft.update(c2, i); } }
       }
     }
-    if (!(a.dbgSkip & 8)) SYNC_LDS();
+    if (!H10X_DBGSKIP(8)) SYNC_LDS();
     if (HASHED && sh[2]) break;                              // the table filled up (uniform: read after the barrier)
-    if (a.dbgSkip & 2) continue;
+    if (H10X_DBGSKIP(2)) continue;
 #pragma unroll
     for (int t = 0; t < RIF; ++t) {
       const u32 i = i0 + t;
-      if (i >= 1 && i < n) {
-        const u32 d = dl[t]; const u32 *row = ROWP(w.rs[i]);
+      if (dl[t]) {                                           // 0 for rank 0 and past the last rank; a list of the depth range holds at least one barcode
+        const u32 d = dl[t];
         u32 best, bcnt, tot;
-        if (d <= WAVE) row_mode_hist<IN_LDS, 1>(row, cj[t], NOHANDLE, d, code, i, ft, w.hist + wave * w.histWords, (u32)a.threshold, best, bcnt, tot);
-        else if (d <= 2 * WAVE) row_mode_hist<IN_LDS, 2>(row, cj[t], cj2[t], d, code, i, ft, w.hist + wave * w.histWords, (u32)a.threshold, best, bcnt, tot);
-        else if (d < RCHUNK * WAVE) row_mode_hist<IN_LDS, RCHUNK>(row, cj[t], cj2[t], d, code, i, ft, w.hist + wave * w.histWords, (u32)a.threshold, best, bcnt, tot);
-        else row_mode_long(row, d, code, i, ft, best, bcnt, tot);
+        // (the list's address is only formed where entries beyond the two chunks held in registers are read)
+        if (d <= WAVE) row_mode_hist<IN_LDS, 1>(nullptr, cj[t], NOHANDLE, d, code, i, ft, w.hist + wave * w.histWords, (u32)a.threshold, best, bcnt, tot);
+        else if (d <= 2 * WAVE) row_mode_hist<IN_LDS, 2>(nullptr, cj[t], cj2[t], d, code, i, ft, w.hist + wave * w.histWords, (u32)a.threshold, best, bcnt, tot);
+        else if (d < RCHUNK * WAVE) row_mode_hist<IN_LDS, RCHUNK>(ROWP(w.rs[i]), cj[t], cj2[t], d, code, i, ft, w.hist + wave * w.histWords, (u32)a.threshold, best, bcnt, tot);
+        else row_mode_long(ROWP(w.rs[i]), d, code, i, ft, best, bcnt, tot);
         if (lane == 0) { w.best[i] = (u16)best; w.cnt[i] = (CT)bcnt; w.tot[i] = (CT)tot; }
       }
     }
@@ -761,7 +771,7 @@ __device__ void cluster_one_block(const ClusterArgs &a, u32 code, unsigned char 
     u16 *todo = (u16 *)w.hist;                               // the histograms are idle from here on
     if (tid == 0) sh[2] = 0;
     SYNC();
-    if (!(a.dbgSkip & 4))
+    if (!H10X_DBGSKIP(4))
       for (u32 i0 = 0; i0 < stop; i0 += CL_THREADS) {
         const u32 i = i0 + tid;
         bool need = false;
