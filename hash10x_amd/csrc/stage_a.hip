@@ -32,7 +32,13 @@ struct MoshConst {
   int n1, n2;            // k-mers per read 1 (127 bases from base 23) and read 2 (150 bases)
   int run;               // consecutive k-mer slots per lane in mosh_lds_kernel: ceil(n1/run) + ceil(n2/run) <= 32
   u64 factor1;
+  int dbg;               // what-if timing switches (results WRONG), honoured only by builds with -DH10X_DBG_SKIP: 16 queue never drained, 32 no survivors, 64 no compaction
 };
+#ifdef H10X_DBG_SKIP
+#define H10X_MOSH_DBG(bit) (mc.dbg & (bit))
+#else
+#define H10X_MOSH_DBG(bit) false
+#endif
 
 // ------------------------------------------------------------------------------------------ helpers
 // 2k-bit big-endian word of bases [p, p+k) from MSB-first packed dwords (fq2b.c:33-42 layout;
@@ -144,38 +150,86 @@ __global__ void classify_kernel(const u64 *__restrict__ startRec, u32 nBlocks, h
 
 // ------------------------------------------------------------------------------------------ LDS path
 // packed entry: hash << 16 | read   (needs 2k + 16 <= 64 and read <= 65535)
-__device__ __forceinline__ bool lds_set_insert(u64 *table, u32 mask, u64 hash, u32 read) {
-  const u64 packed = (hash << 16) | (u64)read;
-  u32 slot = (u32)((hash * 0x9E3779B97F4A7C15ULL) >> 40) & mask;
-  for (u32 probe = 0; probe <= mask; ++probe) {
-    u64 cur = *(volatile u64 *)&table[slot];
-    if (cur == EMPTY64) {
-      cur = atomicCAS((u64 *)&table[slot], EMPTY64, packed);
-      if (cur == EMPTY64) return true;
+// 64-bit shifts and compares cost four times a 32-bit one on gfx950 (scratch/valu_rate64.hip: 8 SIMD cycles against 2), so the
+// set works on the two halves of an entry: empty = both halves all ones, same hash = high halves equal and low halves equal
+// above the 16 read bits.
+__device__ __forceinline__ u32 lo32(u64 x) { return (u32)x; }
+__device__ __forceinline__ u32 hi32(u64 x) { return (u32)(x >> 32); }
+__device__ __forceinline__ u64 mk64(u32 hi, u32 lo) { return ((u64)hi << 32) | lo; }
+__device__ __forceinline__ bool entry_empty(u64 v) {
+  u32 t = lo32(v) & hi32(v);
+  asm("" : "+v"(t));                                         // or the compiler folds this back into one 64-bit compare
+  return t == 0xFFFFFFFFu;
+}
+// One probe = one compare-and-swap against the empty pattern: the returned word says everything (was empty: ours now; same
+// hash: keep the lower read with a fire-and-forget min; another hash: next slot) — no look before the swap, one LDS round trip.
+__device__ __forceinline__ u32 set_slot_of(u32 hLo, u32 hHi, u32 mask) {
+  return (((hLo ^ (hHi * 0x9E3779B1u)) * 0x85EBCA6Bu) >> 15) & mask;   // any spread will do: the order inside a block is not kept
+}
+__device__ __forceinline__ bool probe_done(u64 *table, u32 slot, u64 cur, u32 pLo, u32 pHi) {
+  if (entry_empty(cur)) return true;
+  if (hi32(cur) == pHi && ((lo32(cur) ^ pLo) >> 16) == 0) { atomicMin((u64 *)&table[slot], mk64(pHi, pLo)); return true; }
+  return false;
+}
+// Survivors are 1 in w of the slots: inserting them where they turn up would run the probe loop with a quarter of the lanes
+// (measured: a third of the launch). Each wave parks them, packed, in a small LDS queue of its own instead — one ballot and
+// one write per slot — and empties it 64 at a time with every lane probing for one entry.
+constexpr u32 MOSH_QCAP = 96, MOSH_QKEEP = MOSH_QCAP - WAVE;      // entries per wave; at most QKEEP may stay behind before a slot's push of up to 64
+typedef __attribute__((address_space(3))) volatile u64 lds_queue_t;   // typed as LDS: a volatile generic pointer compiles to flat accesses, each waited for
+__device__ __forceinline__ void queue_push(lds_queue_t *q, u32 &qn /* wave-uniform */, bool ok, u32 hLo, u32 hHi, u32 read) {
+  const u64 bal = __builtin_amdgcn_ballot_w64(ok);
+  if (!bal) return;
+  const u32 pre = __builtin_amdgcn_mbcnt_hi((u32)(bal >> 32), __builtin_amdgcn_mbcnt_lo((u32)bal, 0u));
+  if (ok) q[qn + pre] = mk64(__builtin_amdgcn_alignbit(hHi, hLo, 16), (hLo << 16) | read);
+  qn += (u32)__popcll(bal);
+}
+// takes up to 64 entries off the top of the queue; false = the table is full
+__device__ __forceinline__ bool queue_drain(u64 *table, u32 mask, lds_queue_t *q, u32 &qn, int lane) {
+  const u32 n = qn < (u32)WAVE ? qn : (u32)WAVE;
+  qn -= n;
+  bool go = (u32)lane < n;
+  u64 packed = EMPTY64;
+  if (go) packed = q[qn + lane];
+  const u32 pLo = lo32(packed), pHi = hi32(packed);
+  u32 slot = set_slot_of(__builtin_amdgcn_alignbit(pHi, pLo, 16), pHi >> 16, mask);
+  for (u32 probes = 0; __builtin_amdgcn_ballot_w64(go); ++probes) {
+    if (probes > mask) return false;
+    if (go) {
+      const u64 cur = atomicCAS((u64 *)&table[slot], EMPTY64, packed);
+      if (probe_done(table, slot, cur, pLo, pHi)) go = false; else slot = (slot + 1) & mask;
     }
-    if ((cur >> 16) == hash) { atomicMin((u64 *)&table[slot], packed); return true; }
-    slot = (slot + 1) & mask;
   }
-  return false;                                              // table full
+  return true;
+}
+
+// low 64 bits of x * f from 32-bit halves: one 32 x 32 -> 64 multiply-add and two low multiplies
+__device__ __forceinline__ void mul64_lo(u32 xLo, u32 xHi, u32 fLo, u32 fHi, u32 &pLo, u32 &pHi) {
+  const u64 p = (u64)xLo * fLo;
+  pLo = lo32(p); pHi = hi32(p) + xLo * fHi + xHi * fLo;
 }
 
 // One workgroup per barcode block, no staging tile and no barrier in the main loop: 32 lanes share a read pair, each
 // lane owns a run of L (8 or 9) consecutive k-mer slots of one read. It fetches the 4 packed dwords that cover its run
-// straight from HBM (the next pair's are requested before the current pair is hashed), keeps them as a 128-bit shift
-// register, and ROLLS the forward word (2 bits in per step) and the reverse-complement word (seqhash.c:75: shift
-// right, complement of the new base in at the top) instead of re-extracting a window per slot; what is left per slot
-// is the two 64-bit multiplies of hashFunc, the min and the divisibility test. Survivors (1 in w) are parked, two
-// per lane, and inserted into the LDS hash set once per pair.
-template <bool W31, int L /* slots per lane: mc.run */, int THREADS /* 256 / 512 / 1024 for the 32 / 64 / 128 KB table classes */>
-__global__ __launch_bounds__(THREADS)
+// straight from HBM (the next pair's are requested before the current pair is hashed) and ROLLS the forward word (2 bits in
+// per step) and the reverse-complement word (seqhash.c:75: shift right, complement of the new base in at the top) instead
+// of re-extracting a window per slot; what is left per slot is the two 64-bit multiplies of hashFunc, the min and the
+// divisibility test. Survivors (1 in w) are parked, two per lane, and inserted into the LDS hash set once per pair.
+// FAST (17 <= k <= 30, the usual range): everything on 32-bit halves — the two words roll by funnel shifts, the bases still
+// to come sit in one dword (2 L <= 32 bits) whose fields are picked with constant offsets, min(hf, hr) is taken before the
+// one shift both share; the general form keeps 64-bit arithmetic.
+template <bool W31, int L /* slots per lane: mc.run */, bool FAST>
+__global__ __launch_bounds__(1024)
 void mosh_lds_kernel(const u32 *__restrict__ rec, const u32 *__restrict__ list, u32 nList,
                      const u64 *__restrict__ startRec, const u32 *__restrict__ slots, const u64 *__restrict__ capOff,
-                     MoshConst mc, u64 *__restrict__ stHash, u32 *__restrict__ stRead, u32 *__restrict__ nHashOut) {
+                     MoshConst mc, u32 tableBytes /* of the launch's table class; the waves' queues lie behind */,
+                     u64 *__restrict__ stHash, u32 *__restrict__ stRead, u32 *__restrict__ nHashOut) {
   extern __shared__ __align__(16) unsigned char smem[];
   if (blockIdx.x >= nList) return;
   const u32 code = list[blockIdx.x];
   const u32 S = slots[code], mask = S - 1;
   u64 *table = (u64 *)smem;
+  lds_queue_t *queue = (lds_queue_t *)(smem + tableBytes) + (threadIdx.x / WAVE) * MOSH_QCAP;
+  u32 qn = 0;
   __shared__ u32 sOverflow, sCount;
   const u64 rec0 = startRec[code];
   const u32 nRead = (u32)(startRec[code + 1] - rec0);
@@ -192,47 +246,70 @@ void mosh_lds_kernel(const u32 *__restrict__ rec, const u32 *__restrict__ list, 
   else if (sub < lanes1 + lanes2) { const int t0 = (sub - lanes1) * L; cnt = min(L, mc.n2 - t0); pos0 = t0; wordBase = 15; }   // hash10x.c:163  s2, 150 bases
   const int wi = wordBase + (pos0 >> 4), sh = (pos0 & 15) * 2;
   const int k2 = 2 * mc.k, down = 64 - k2;
-  constexpr u32 PAIRS_PER_ROUND = (THREADS / WAVE) * 2;
+  const u32 pairsPerRound = (blockDim.x / WAVE) * 2;
+  const u32 fLo = lo32(mc.factor1), fHi = hi32(mc.factor1);
+  const u32 maskHi = 0xFFFFFFFFu >> (down & 31);            // FAST: the 2k - 32 bits of the forward word's high half
   u32 r = (u32)wv * 2 + (u32)(lane >> 5);
   uint4 nx = make_uint4(0, 0, 0, 0);
   if (r < nRead && cnt > 0) { const u32 *p = rec + (rec0 + r) * 30 + wi; nx = make_uint4(p[0], p[1], p[2], p[3]); }
-  for (; __builtin_amdgcn_ballot_w64(r < nRead); r += PAIRS_PER_ROUND) {
+  for (; __builtin_amdgcn_ballot_w64(r < nRead); r += pairsPerRound) {
     const uint4 cw = nx;
-    const u32 rn = r + PAIRS_PER_ROUND;
-    if (rn < nRead && cnt > 0) { const u32 *p = rec + (rec0 + rn) * 30 + wi; nx = make_uint4(p[0], p[1], p[2], p[3]); }
+    const u32 rn = r + pairsPerRound;
+    if (rn < nRead && cnt > 0 && !H10X_MOSH_DBG(512)) { const u32 *p = rec + (rec0 + rn) * 30 + wi; nx = make_uint4(p[0], p[1], p[2], p[3]); }
+    if (H10X_MOSH_DBG(512)) nx = make_uint4(cw.y * 0x9E3779B1u + r, cw.x ^ 0x85EBCA6Bu, cw.w + cw.x, cw.z * 5u + 1u);
     // 128-bit shift register, bases MSB first (fq2b.c:33-42; the un-justified tail word is consumed as is: SURVEY F6)
     u64 hi = ((u64)cw.x << 32) | cw.y, lo = ((u64)cw.z << 32) | cw.w;
     if (sh) { hi = (hi << sh) | (lo >> (64 - sh)); lo <<= sh; }
     u64 f = hi >> down;
     u64 rc = revcomp_word(f, mc.k);
-    const bool live = r < nRead;
-    u64 pendA = EMPTY64, pendB = EMPTY64;
+    const bool live = r < nRead && !H10X_MOSH_DBG(32);
+    if (FAST) {
+      u32 fl = lo32(f), fh = hi32(f), rl = lo32(rc), rh = hi32(rc);
+      const u32 inw = hi32((hi << k2) | (lo >> down));       // the bases after the first window: base j + 1 at bits [31 - 2j, 30 - 2j]
+      const u32 cinw = ~inw;
 #pragma unroll
-    for (int j = 0; j < L; ++j) {
-      const u64 hf = (f * mc.factor1) >> mc.shift1;          // seqhash.c:58-59
-      const u64 hr = (rc * mc.factor1) >> mc.shift1;
-      const u64 h = hf < hr ? hf : hr;                       // seqhash.c:67-68
-      if (live && j < cnt && divisible<W31>(h, mc.w)) {
-        if (pendA == EMPTY64) pendA = h;
-        else if (pendB == EMPTY64) pendB = h;
-        else { if (!lds_set_insert(table, mask, pendA, r)) sOverflow = 1; pendA = h; }
+      for (int j = 0; j < L; ++j) {
+        u32 pfL, pfH, prL, prH;
+        mul64_lo(fl, fh, fLo, fHi, pfL, pfH);                // seqhash.c:58-59, the shift comes after the min: it is monotone
+        mul64_lo(rl, rh, fLo, fHi, prL, prH);
+        const bool flt = mk64(pfH, pfL) < mk64(prH, prL);    // seqhash.c:67-68
+        const u32 mL = flt ? pfL : prL, mH = flt ? pfH : prH;
+        const u32 hL = __builtin_amdgcn_alignbit(mH, mL, (u32)down), hH = mH >> down;
+        bool ok;
+        if (W31) ok = (((hL & 0x3FFFFFFFu) + __builtin_amdgcn_alignbit(hH, hL, 30)) % 31u) == 0;   // 2^30 == 1 (mod 31); h < 2^60
+        else ok = (mk64(hH, hL) % (u64)mc.w) == 0;
+        queue_push(queue, qn, ok && live && j < cnt, hL, hH, r);
+        if (H10X_MOSH_DBG(16)) { if (qn > MOSH_QKEEP) qn = 0; }
+        else if (qn > MOSH_QKEEP && !queue_drain(table, mask, queue, qn, lane)) sOverflow = 1;
+        // next base in
+        const u32 nb = (inw >> (30 - 2 * j)) & 3u, cb = (cinw >> (30 - 2 * j)) & 3u;
+        fh = __builtin_amdgcn_alignbit(fh, fl, 30) & maskHi; fl = (fl << 2) | nb;
+        rl = __builtin_amdgcn_alignbit(rh, rl, 2); rh = (rh >> 2) | (cb << (k2 - 34));
       }
-      hi = (hi << 2) | (lo >> 62); lo <<= 2;                 // next base in
-      f = hi >> down;
-      rc = (rc >> 2) | ((u64)(3u - ((u32)f & 3u)) << (k2 - 2));
+    } else {
+#pragma unroll
+      for (int j = 0; j < L; ++j) {
+        const u64 hf = (f * mc.factor1) >> mc.shift1;          // seqhash.c:58-59
+        const u64 hr = (rc * mc.factor1) >> mc.shift1;
+        const u64 h = hf < hr ? hf : hr;                       // seqhash.c:67-68
+        queue_push(queue, qn, divisible<W31>(h, mc.w) && live && j < cnt, lo32(h), hi32(h), r);
+        if (qn > MOSH_QKEEP && !queue_drain(table, mask, queue, qn, lane)) sOverflow = 1;
+        hi = (hi << 2) | (lo >> 62); lo <<= 2;                 // next base in
+        f = hi >> down;
+        rc = (rc >> 2) | ((u64)(3u - ((u32)f & 3u)) << (k2 - 2));
+      }
     }
-    if (pendA != EMPTY64 && !lds_set_insert(table, mask, pendA, r)) sOverflow = 1;
-    if (pendB != EMPTY64 && !lds_set_insert(table, mask, pendB, r)) sOverflow = 1;
   }
+  while (qn) if (!queue_drain(table, mask, queue, qn, lane)) { sOverflow = 1; break; }
   __syncthreads();
 
   // compact the set to this block's staging slice (order inside a block is irrelevant downstream)
   const u64 out0 = capOff[code];
   const u32 cap = S - (S >> 3);                              // > 87.5 % full => treat as overflow
-  for (u32 base = 0; base < S; base += blockDim.x) {
+  for (u32 base = 0; base < (H10X_MOSH_DBG(64) ? 0u : S); base += blockDim.x) {
     const u32 i = base + threadIdx.x;
     const u64 v = i < S ? table[i] : EMPTY64;
-    const bool valid = v != EMPTY64;
+    const bool valid = !entry_empty(v);
     const u64 bal = __ballot(valid);
     const int lane = threadIdx.x & (WAVE - 1);
     u32 wbase = 0;
@@ -240,7 +317,7 @@ void mosh_lds_kernel(const u32 *__restrict__ rec, const u32 *__restrict__ list, 
     wbase = __shfl(wbase, 0);
     if (valid) {
       const u32 pos = wbase + (u32)__popcll(bal & ((1ULL << lane) - 1));
-      if (pos < cap) { stHash[out0 + pos] = v >> 16; stRead[out0 + pos] = (u32)(v & 0xFFFF); }
+      if (pos < cap) { stHash[out0 + pos] = mk64(hi32(v) >> 16, __builtin_amdgcn_alignbit(hi32(v), lo32(v), 16)); stRead[out0 + pos] = lo32(v) & 0xFFFFu; }
     }
   }
   __syncthreads();
@@ -411,7 +488,7 @@ int stageA_run(Ctx *c, const u32 *dRec, u64 nRec, DevBuf<u64> &entHash, DevBuf<u
   hipStream_t st = c->stream;
   PrimTemp pt;
   const int k = c->prm.k;
-  MoshConst mc; mc.k = k; mc.w = c->prm.w; mc.shift1 = 64 - 2 * k; mc.factor1 = c->prm.factor1;
+  MoshConst mc; mc.k = k; mc.w = c->prm.w; mc.shift1 = 64 - 2 * k; mc.factor1 = c->prm.factor1; mc.dbg = (int)c->optDbgSkip;
   mc.n1 = 127 - k + 1 > 0 ? 127 - k + 1 : 0;               // len < k => no k-mer (seqhash.c:162)
   mc.n2 = 150 - k + 1 > 0 ? 150 - k + 1 : 0;
   mc.run = 8; while ((mc.n1 + mc.run - 1) / mc.run + (mc.n2 + mc.run - 1) / mc.run > 32) ++mc.run;   // 8 at k = 21, 9 for k <= 7
@@ -482,17 +559,22 @@ int stageA_run(Ctx *c, const u32 *dRec, u64 nRec, DevBuf<u64> &entHash, DevBuf<u
   // the three table classes are independent: side by side on forked streams, the few blocks with many read pairs
   // (largest tables, most lanes per workgroup) first
   H10X_TRY(c->forkStreams(2));
-#define H10X_MOSH_LAUNCH(W, LL, TH, STREAM)                                                                                        \
-    { if (lds > 48 * 1024) H10X_HIP(c, hipFuncSetAttribute((const void *)mosh_lds_kernel<W, LL, TH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
-      mosh_lds_kernel<W, LL, TH><<<n, TH, lds, STREAM>>>(dRec, list, n, startRec.p, slots.p, capOff.p, mc, stHash.p, stRead.p, nHash.p); }
+#define H10X_MOSH_LAUNCH(W, LL, FK, TH, STREAM)                                                                                    \
+    { if (lds > 48 * 1024) H10X_HIP(c, hipFuncSetAttribute((const void *)mosh_lds_kernel<W, LL, FK>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+      mosh_lds_kernel<W, LL, FK><<<n, TH, lds, STREAM>>>(dRec, list, n, startRec.p, slots.p, capOff.p, mc, (u32)tableBytes, stHash.p, stRead.p, nHash.p); }
 #define H10X_MOSH_CLASS(TH, STREAM)                                                                                                \
-    { if (w31 && mc.run == 8) H10X_MOSH_LAUNCH(true, 8, TH, STREAM) else if (w31) H10X_MOSH_LAUNCH(true, 9, TH, STREAM)           \
-      else if (mc.run == 8) H10X_MOSH_LAUNCH(false, 8, TH, STREAM) else H10X_MOSH_LAUNCH(false, 9, TH, STREAM) }
+    { if (fastK && w31) H10X_MOSH_LAUNCH(true, 8, true, TH, STREAM) else if (fastK) H10X_MOSH_LAUNCH(false, 8, true, TH, STREAM)   \
+      else if (w31 && mc.run == 8) H10X_MOSH_LAUNCH(true, 8, false, TH, STREAM) else if (w31) H10X_MOSH_LAUNCH(true, 9, false, TH, STREAM) \
+      else if (mc.run == 8) H10X_MOSH_LAUNCH(false, 8, false, TH, STREAM) else H10X_MOSH_LAUNCH(false, 9, false, TH, STREAM) }
+  // workgroups of 512 lanes for the 32 KB tables too: four of them fill a CU's 32 wave slots (256-lane ones left half empty:
+  // 1.20 -> 1.06 ms on the yeast-scale set); the 64 KB class gains nothing from 1024 lanes (measured)
+  const bool fastK = k >= 17 && k <= 30 && mc.run == 8;
   for (int cls = 2; cls >= 0; --cls) {
     const u32 n = hc[cls]; if (!n) continue;
     const u32 *list = cls == 0 ? list0.p : cls == 1 ? list1.p : list2.p;
-    const size_t lds = (size_t)hmin<u32>(4096u << cls, maxSlots) * 8;
-    if (cls == 2) H10X_MOSH_CLASS(1024, c->aux[0]) else if (cls == 1) H10X_MOSH_CLASS(512, c->aux[1]) else H10X_MOSH_CLASS(256, st)
+    const size_t tableBytes = (size_t)hmin<u32>(4096u << cls, maxSlots) * 8;
+    const size_t lds = tableBytes + (size_t)((cls == 2 ? 1024 : 512) / WAVE) * MOSH_QCAP * 8;        // the table, then one survivor queue per wave
+    if (cls == 2) H10X_MOSH_CLASS(1024, c->aux[0]) else if (cls == 1) H10X_MOSH_CLASS(512, c->aux[1]) else H10X_MOSH_CLASS(512, st)
     H10X_HIP(c, hipGetLastError());
   }
 #undef H10X_MOSH_CLASS
