@@ -136,6 +136,10 @@ struct Ctx {
   // multiplied back where hashValue[] is written or the probe table is searched. Exact division: w = 2^keyShift * m,
   // q = (hash >> keyShift) * keyInv with keyInv = m^-1 mod 2^64. Set by stageA_run.
   u64 keyInv = 1; int keyShift = 0; int keyBits = 64;
+  // Single-GPU index build: an entry's key and block number travel in ONE word, (hash / w) << entCodeBits | block, so the
+  // device-wide sort moves 8 bytes per entry and pass instead of 12 (keys only, on bits [entCodeBits, entCodeBits + keyBits)).
+  // 0 = separate arrays (sharded path, or the two do not fit 64 bits). wantPacked is set by the caller of stageA_run.
+  bool wantPacked = false; int entCodeBits = 0;
   int device = 0;
   hipStream_t stream = nullptr;
   hipStream_t aux[3] = {nullptr, nullptr, nullptr};   // side streams for independent launches (fork/join around them)
@@ -195,6 +199,8 @@ struct Ctx {
   int64_t optFirstCap = 0;    // testing knob: entries of the ranked first[]
   int64_t optClusterThreads0 = 0, optClusterBudget0 = 0;   // tuning knobs: lanes and LDS bytes of the first cluster class
   int64_t optBigRanks = 0;    // tuning knob: rank count above which a barcode goes to the front of the main work queue (0 = 1.5 x the mean)
+  int64_t optNoPack = 0;      // index build with separate key / block arrays even where the packed form fits (A/B, tests)
+  int64_t optNarrowFirst = 0; // first[] of the cluster kernel at 2 bytes per entry in every block (default: 4 where the block's working set leaves room)
   int64_t optDbgSkip = 0;     // diagnostic: what-if timing of cluster_kernel with phases switched off (results wrong)
   int64_t optStamps = 0;      // diagnostic: per-phase wall-clock stamps in cluster_kernel
   int64_t optChunk = 0;       // -c <chunkSize> of the reference's readFQB loop (hash10x.c:202-223): 0 = no chunk semantics (no "chunkSize too small", no

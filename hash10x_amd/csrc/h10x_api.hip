@@ -116,7 +116,9 @@ int h10x_read_fqb_device(h10x_ctx *h, const uint32_t *dRec, uint64_t n) {
   static const bool prof = getenv("H10X_HOSTPROF") != nullptr;
   timespec t0, t1, t2; clock_gettime(CLOCK_MONOTONIC, &t0);
   DevBuf<u64> entHash; DevBuf<u32> entCode, entRead;
+  c.wantPacked = !c.optNoPack;
   H10X_TRY(stageA_run(&c, dRec, n, entHash, entCode, entRead));
+  c.wantPacked = false;
   c.segs.n = 1; c.segs.s[0] = BlockSeg{0, c.nBlocks, 0};
   clock_gettime(CLOCK_MONOTONIC, &t1);
   H10X_TRY(stageB_run(&c, entHash, entCode, entRead));
@@ -494,6 +496,8 @@ int h10x_set_option(h10x_ctx *h, const char *name, int64_t value) {
   if (!strcmp(name, "cluster_budget0")) { h->c.optClusterBudget0 = value; return 0; }
   if (!strcmp(name, "cluster_big_ranks")) { h->c.optBigRanks = value; return 0; }
   if (!strcmp(name, "cluster_dbg_skip")) { h->c.optDbgSkip = value; return 0; }
+  if (!strcmp(name, "cluster_narrow_first")) { h->c.optNarrowFirst = value; return 0; }
+  if (!strcmp(name, "index_no_pack")) { h->c.optNoPack = value; return 0; }
   if (!strcmp(name, "cluster_stamps")) { h->c.optStamps = value; return 0; }
   if (!strcmp(name, "chunk_size")) { if (value < 0) return h->c.fail("chunk_size must be >= 0"); h->c.optChunk = value; return 0; }
   if (!strcmp(name, "shard_row_shift")) { if (value < -1 || value > 8) return h->c.fail("shard_row_shift must be -1..8"); h->c.optRowShift = value; return 0; }

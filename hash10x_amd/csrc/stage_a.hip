@@ -381,13 +381,15 @@ __global__ void count_overflow_kernel(const u32 *__restrict__ nHash, u32 nBlocks
 __global__ void compact_entries_kernel(const u64 *__restrict__ stHash, const u32 *__restrict__ stRead, const u64 *__restrict__ capOff,
                                        const SrcPtr *__restrict__ fb /* per block, null hash = staging */,
                                        const u32 *__restrict__ nHash, const u64 *__restrict__ blockOff, u32 nBlocks,
-                                       u64 keyInv, int keyShift, u64 *__restrict__ entHash, u32 *__restrict__ entCode, u32 *__restrict__ entRead) {
+                                       u64 keyInv, int keyShift, int codeBits /* > 0: packed entries (Ctx::entCodeBits), entCode unused */,
+                                       u64 *__restrict__ entHash, u32 *__restrict__ entCode, u32 *__restrict__ entRead) {
   for (u32 c = blockIdx.x + 1; c < nBlocks; c += gridDim.x) {
     const u32 n = nHash[c]; if (!n) continue;
     const u64 *sh; const u32 *sr;
     if (fb[c].hash) { sh = fb[c].hash; sr = fb[c].read; } else { sh = stHash + capOff[c]; sr = stRead + capOff[c]; }
     const u64 o = blockOff[c];
-    for (u32 i = threadIdx.x; i < n; i += blockDim.x) { entHash[o + i] = (sh[i] >> keyShift) * keyInv; entCode[o + i] = c; entRead[o + i] = sr[i]; }   // hash / w (Ctx::keyInv)
+    if (codeBits) for (u32 i = threadIdx.x; i < n; i += blockDim.x) { entHash[o + i] = (((sh[i] >> keyShift) * keyInv) << codeBits) | c; entRead[o + i] = sr[i]; }
+    else for (u32 i = threadIdx.x; i < n; i += blockDim.x) { entHash[o + i] = (sh[i] >> keyShift) * keyInv; entCode[o + i] = c; entRead[o + i] = sr[i]; }   // hash / w (Ctx::keyInv)
   }
 }
 
@@ -662,16 +664,19 @@ int stageA_run(Ctx *c, const u32 *dRec, u64 nRec, DevBuf<u64> &entHash, DevBuf<u
   if (!hNHash.empty()) { hMaxHash = 0; for (u32 b = 0; b < nBlocks; ++b) hMaxHash = hNHash[b] > hMaxHash ? hNHash[b] : hMaxHash; }   // fallback path: the repaired counts
   c->maxBlockHashes = hMaxHash;
   set_nhash_kernel<<<divUp(nBlocks, 256), 256, 0, st>>>(c->blocks.p, nHash.p, nBlocks);
-  H10X_HIP(c, entHash.alloc(H)); H10X_HIP(c, entCode.alloc(H)); H10X_HIP(c, entRead.alloc(H));
+  H10X_HIP(c, entHash.alloc(H)); H10X_HIP(c, entRead.alloc(H));
   {                                                          // sort key = hash / w (common.hpp, Ctx::keyInv)
     u64 m = (u64)c->prm.w; int s = 0; while (!(m & 1)) { m >>= 1; ++s; }
     u64 inv = m; for (int it = 0; it < 6; ++it) inv *= 2 - m * inv;          // Newton: m^-1 mod 2^64 (m odd: 3 correct bits double each step)
     const int k2 = 2 * c->prm.k; const u64 maxH = k2 >= 64 ? ~0ULL : ((u64)1 << k2) - 1, maxQ = maxH / (u64)c->prm.w;
     int b = 1; while (b < 64 && (maxQ >> b)) ++b;
     c->keyInv = inv; c->keyShift = s; c->keyBits = b;
+    int cb = 1; while (cb < 32 && ((nBlocks - 1) >> cb)) ++cb;
+    c->entCodeBits = (c->wantPacked && b + cb <= 64) ? cb : 0;
   }
+  if (!c->entCodeBits) H10X_HIP(c, entCode.alloc(H));
   if (H) compact_entries_kernel<<<hmin<u32>(nBlocks, 8192), 256, 0, st>>>(stHash.p, stRead.p, capOff.p, dFb.p, nHash.p, c->blockOff.p, nBlocks,
-                                                                        c->keyInv, c->keyShift, entHash.p, entCode.p, entRead.p);
+                                                                        c->keyInv, c->keyShift, c->entCodeBits, entHash.p, entCode.p, entRead.p);
   H10X_HIP(c, hipGetLastError());
   if (!hFb.empty()) H10X_HIP(c, hipStreamSynchronize(st));   // the host copy of the fallback pointers is still being read
   c->tstop(T_COMPACT);

@@ -20,10 +20,10 @@ constexpr u32 SLOT_EMPTY = 0xFFFFFFFFu;
 static int bitsFor(u64 maxValue) { int b = 1; while (b < 64 && (maxValue >> b)) ++b; return b; }
 
 // ------------------------------------------------------------------------------------------ distinct hashes
-__global__ void seg_head_flags_kernel(const u64 *__restrict__ sHash, u64 n, u32 *__restrict__ flags) {
+__global__ void seg_head_flags_kernel(const u64 *__restrict__ sHash, u64 n, int cb /* packed entries: block number in the low cb bits */, u32 *__restrict__ flags) {
   u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
   const u64 stride = (u64)gridDim.x * blockDim.x;
-  for (; i < n; i += stride) flags[i] = (i == 0 || sHash[i] != sHash[i - 1]) ? 1u : 0u;
+  for (; i < n; i += stride) flags[i] = (i == 0 || (sHash[i] >> cb) != (sHash[i - 1] >> cb)) ? 1u : 0u;
 }
 
 __global__ void seg_scatter_kernel(const u64 *__restrict__ sHash, const u32 *__restrict__ sCode, const u32 *__restrict__ flags,
@@ -34,6 +34,19 @@ __global__ void seg_scatter_kernel(const u64 *__restrict__ sHash, const u32 *__r
   for (; i < n; i += stride) if (flags[i]) {
     const u32 d = ord[i];
     dHash[d] = sHash[i]; dFirst[d] = sCode[i]; segStart[d] = (u32)i; iota[d] = d;
+  }
+}
+// the same from packed entries, which also leaves the barcode lists (the block numbers in sorted order) behind
+__global__ void seg_scatter_packed_kernel(const u64 *__restrict__ sKey, int cb, const u32 *__restrict__ flags,
+                                          const u32 *__restrict__ ord, u64 n, u64 *__restrict__ dHash, u32 *__restrict__ dFirst,
+                                          u32 *__restrict__ segStart, u32 *__restrict__ iota, u32 *__restrict__ rows) {
+  u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  const u64 stride = (u64)gridDim.x * blockDim.x;
+  const u64 cmask = ((u64)1 << cb) - 1;
+  for (; i < n; i += stride) {
+    const u64 k = sKey[i]; const u32 code = (u32)(k & cmask);
+    rows[i] = code;
+    if (flags[i]) { const u32 d = ord[i]; dHash[d] = k >> cb; dFirst[d] = code; segStart[d] = (u32)i; iota[d] = d; }
   }
 }
 
@@ -101,13 +114,13 @@ __global__ void probe_finish64_kernel(const u64 *__restrict__ table64, u64 n, in
   const u64 stride = (u64)gridDim.x * blockDim.x;
   for (; i < n; i += stride) { const u64 e = table64[i]; table[i] = e == SLOT_EMPTY64 ? 0u : (u32)(e >> qBits); }
 }
-__global__ void lookup_pack64_kernel(const u64 *__restrict__ entHash /* hash / w */, const u32 *__restrict__ entRead, u64 n,
-                                     const u64 *__restrict__ table64, int B, u64 w, int qBits, u64 *__restrict__ key) {
+__global__ void lookup_pack64_kernel(const u64 *__restrict__ entHash /* hash / w, << cb if packed */, const u32 *__restrict__ entRead, u64 n,
+                                     const u64 *__restrict__ table64, int B, u64 w, int qBits, int cb, u64 *__restrict__ key) {
   u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
   const u64 stride = (u64)gridDim.x * blockDim.x;
   const u64 mask = ((u64)1 << B) - 1, qmask = ((u64)1 << qBits) - 1;
   for (; i < n; i += stride) {
-    const u64 q = entHash[i], h = q * w;
+    const u64 q = entHash[i] >> cb, h = q * w;
     u64 slot = h & mask; const u64 step = ((h >> B) & mask) | 1;
     u64 e;
     while ((e = table64[slot]) != SLOT_EMPTY64 && (e & qmask) != q) slot = (slot + step) & mask;
@@ -118,11 +131,11 @@ __global__ void lookup_pack64_kernel(const u64 *__restrict__ entHash /* hash / w
 
 // ------------------------------------------------------------------------------------------ clusHash
 __global__ void lookup_pack_kernel(const u64 *__restrict__ entHash, const u32 *__restrict__ entRead, u64 n,
-                                   const u32 *__restrict__ table, const u64 *__restrict__ hashValue, int B, u64 w /* entHash holds hash / w */, u64 *__restrict__ key) {
+                                   const u32 *__restrict__ table, const u64 *__restrict__ hashValue, int B, u64 w /* entHash holds hash / w */, int cb, u64 *__restrict__ key) {
   u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
   const u64 stride = (u64)gridDim.x * blockDim.x;
   for (; i < n; i += stride) {
-    const u32 ix = probe_find(table, hashValue, B, entHash[i] * w);
+    const u32 ix = probe_find(table, hashValue, B, (entHash[i] >> cb) * w);
     key[i] = ((u64)ix << 32) | (u64)(entRead[i] & 0xFFFFu);  // ClusterHash.read is U16 (hash10x.c:37,180)
   }
 }
@@ -150,7 +163,7 @@ __global__ void write_clushash_kernel(const u64 *__restrict__ key, u64 n, h10x_c
 template <int THREADS, int IPT, bool LOOKUP>
 __global__ __launch_bounds__(THREADS)
 void clushash_block_kernel(const u64 *__restrict__ entHash /* hash / w */, const u32 *__restrict__ entRead, const u64 *__restrict__ key /* !LOOKUP: index << 32 | read */,
-                           const u64 *__restrict__ blockOff, u32 nBlocks, const u64 *__restrict__ table64, int B, u64 w, int qBits, int sortBits,
+                           const u64 *__restrict__ blockOff, u32 nBlocks, const u64 *__restrict__ table64, int B, u64 w, int qBits, int cb /* packed entries */, int sortBits,
                            h10x_clushash *__restrict__ out) {
   using Sort = rocprim::block_radix_sort<u32, THREADS, IPT, u32>;
   __shared__ typename Sort::storage_type storage;
@@ -167,7 +180,7 @@ void clushash_block_kernel(const u64 *__restrict__ entHash /* hash / w */, const
       k[j] = 0xFFFFFFFFu; v[j] = 0;
       if (e < n) {
         if (LOOKUP) {
-          const u64 q = entHash[o + e], h = q * w;
+          const u64 q = entHash[o + e] >> cb, h = q * w;
           u64 slot = h & mask; const u64 step = ((h >> B) & mask) | 1;
           u64 t;
           while ((t = table64[slot]) != SLOT_EMPTY64 && (t & qmask) != q) slot = (slot + step) & mask;
@@ -194,7 +207,7 @@ static int clusHashByBlocks(Ctx *c, const u64 *entHash, const u32 *entRead, cons
   const int sortBits = bitsFor(c->hashNumber) + 1 > 32 ? 32 : bitsFor(c->hashNumber) + 1;
   const unsigned grid = hmin<u32>(nBlocks - 1, 65535u * 4);
   const int B = c->prm.B; const u64 w = (u64)c->prm.w; const int qBits = c->keyBits;
-#define H10X_CH_LAUNCH(T, I, LOOK, STREAM) clushash_block_kernel<T, I, LOOK><<<grid, T, 0, STREAM>>>(entHash, entRead, key, c->blockOff.p, nBlocks, table64, B, w, qBits, sortBits, c->clusHash.p)
+#define H10X_CH_LAUNCH(T, I, LOOK, STREAM) clushash_block_kernel<T, I, LOOK><<<grid, T, 0, STREAM>>>(entHash, entRead, key, c->blockOff.p, nBlocks, table64, B, w, qBits, key ? 0 : c->entCodeBits, sortBits, c->clusHash.p)
   const int side = c->maxBlockHashes > BLOCK_SORT_CAP1 ? 2 : (c->maxBlockHashes > BLOCK_SORT_CAP0 ? 1 : 0);
   if (side) H10X_TRY(c->forkStreams(side));                  // the few large blocks beside the many small ones
   if (key) { H10X_CH_LAUNCH(256, 12, false, st); if (side >= 1) H10X_CH_LAUNCH(512, 12, false, c->aux[0]); if (side >= 2) H10X_CH_LAUNCH(1024, 8, false, c->aux[1]); }
@@ -215,8 +228,10 @@ int stageB_run(Ctx *c, DevBuf<u64> &entHash, DevBuf<u32> &entCode, DevBuf<u32> &
   // ---- sort all (hash, barcode) entries by hash; stable => barcodes ascending inside a hash
   c->tstart(T_SORT_HASH);
   DevBuf<u64> sHash; DevBuf<u32> sCode;
+  const int cb = c->entCodeBits;                             // > 0: packed entries (common.hpp), keys-only sort
   H10X_HIP(c, sHash.alloc(H)); H10X_HIP(c, sCode.alloc(H));
-  H10X_TRY(prim_sort_pairs_u64_u32(c, pt, entHash.p, sHash.p, entCode.p, sCode.p, H, 0, c->keyBits));
+  if (cb) H10X_TRY(prim_sort_keys_u64(c, pt, entHash.p, sHash.p, H, cb, cb + c->keyBits));
+  else H10X_TRY(prim_sort_pairs_u64_u32(c, pt, entHash.p, sHash.p, entCode.p, sCode.p, H, 0, c->keyBits));
   c->tstop(T_SORT_HASH);
 
   // ---- distinct hashes, first barcode, depth
@@ -226,7 +241,7 @@ int stageB_run(Ctx *c, DevBuf<u64> &entHash, DevBuf<u32> &entCode, DevBuf<u32> &
   {
     DevBuf<u32> flags, ord;
     H10X_HIP(c, flags.alloc(H + 1)); H10X_HIP(c, ord.alloc(H + 1));
-    if (H) seg_head_flags_kernel<<<gH, 256, 0, st>>>(sHash.p, H, flags.p);
+    if (H) seg_head_flags_kernel<<<gH, 256, 0, st>>>(sHash.p, H, cb, flags.p);
     H10X_HIP(c, hipMemsetAsync(flags.p + H, 0, 4, st));
     H10X_TRY(prim_exclusive_scan_u32(c, pt, flags.p, ord.p, H + 1));
     H10X_TRY(c->readback(&U, ord.p + H, 4));
@@ -235,7 +250,8 @@ int stageB_run(Ctx *c, DevBuf<u64> &entHash, DevBuf<u32> &entCode, DevBuf<u32> &
     if ((u64)U + 1 > (tableSize >> 2) - 2) return c->fail("hashTableSize is too small");
     H10X_HIP(c, dHash.alloc(U)); H10X_HIP(c, dFirst.alloc(U)); H10X_HIP(c, segStart.alloc((size_t)U + 1));
     H10X_HIP(c, iota.alloc(U)); H10X_HIP(c, order.alloc(U)); H10X_HIP(c, dFirstSorted.alloc(U));
-    if (H) seg_scatter_kernel<<<gH, 256, 0, st>>>(sHash.p, sCode.p, flags.p, ord.p, H, dHash.p, dFirst.p, segStart.p, iota.p);
+    if (H && cb) seg_scatter_packed_kernel<<<gH, 256, 0, st>>>(sHash.p, cb, flags.p, ord.p, H, dHash.p, dFirst.p, segStart.p, iota.p, sCode.p);
+    else if (H) seg_scatter_kernel<<<gH, 256, 0, st>>>(sHash.p, sCode.p, flags.p, ord.p, H, dHash.p, dFirst.p, segStart.p, iota.p);
     H10X_HIP(c, hipMemsetD32Async((hipDeviceptr_t)(segStart.p + U), (int)(u32)H, 1, st));      // end of the last segment
   }
   // distinct hashes are in ascending hash order; a stable sort by first barcode gives (first, hash) order
@@ -266,8 +282,8 @@ int stageB_run(Ctx *c, DevBuf<u64> &entHash, DevBuf<u32> &entCode, DevBuf<u32> &
     table64.release();
   } else if (H) {
     DevBuf<u64> key; H10X_HIP(c, key.alloc(H));
-    if (wideTable) lookup_pack64_kernel<<<gH, 256, 0, st>>>(entHash.p, entRead.p, H, table64.p, B, (u64)c->prm.w, c->keyBits, key.p);
-    else lookup_pack_kernel<<<gH, 256, 0, st>>>(entHash.p, entRead.p, H, c->hashIndex.p, c->hashValue.p, B, (u64)c->prm.w, key.p);
+    if (wideTable) lookup_pack64_kernel<<<gH, 256, 0, st>>>(entHash.p, entRead.p, H, table64.p, B, (u64)c->prm.w, c->keyBits, cb, key.p);
+    else lookup_pack_kernel<<<gH, 256, 0, st>>>(entHash.p, entRead.p, H, c->hashIndex.p, c->hashValue.p, B, (u64)c->prm.w, cb, key.p);
     table64.release();
     H10X_TRY(stageB_finishClusHash(c, key));
   } else H10X_HIP(c, c->clusHash.alloc(0));

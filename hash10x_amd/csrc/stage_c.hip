@@ -222,6 +222,7 @@ struct ClusterArgs {
   double *term;                                             // per rank (slice of block c at blockOff[c]): its pointToMin term, 0.0 if none
   u64 *stats;                                               // [0] sum good, [1] sum good depth, [2] sum nHash, [3] codes
   u64 *phase;                                               // diagnostic per-phase ticks (null = off)
+  u32 narrowFirst;                                          // test / A-B knob: keep first[] at 2 bytes per entry in every block
   u32 dbgSkip;                                              // diagnostic what-if timing (results are WRONG): 1 no first[] update, 2 no mode, 4 no phase (d), 8 no barrier
 };
 
@@ -349,18 +350,27 @@ __device__ __forceinline__ void min_u16(u16 *arr, u32 idx, u32 val) {
 //    is then re-run in a larger placement.
 // update() returns a handle under which peek() finds the entry again without repeating the search: the list loop reads
 // every entry twice (before and after the round's barrier).
+// Dense and ranked placements in LDS come in two widths, chosen per block: a u32 per entry where the block's working set
+// leaves the room (minimum = one fire-and-forget ds_min_u32, no loop), the u16 of the CAS-min otherwise. The list loop is
+// bound by scalar and branch instructions (0.8 per CU cycle), and the CAS loop is mostly those.
 template <bool FIRST_LDS> struct FirstDense {
-  u16 *first;
-  __device__ __forceinline__ u32 update(u32 cj, u32 i) const { min_u16<FIRST_LDS>(first, cj, i); return cj; }
-  __device__ __forceinline__ u32 peek(u32 h) const { return ld_shared<FIRST_LDS>(&first[h]); }
-  __device__ __forceinline__ u32 lookup(u32 cj) const { return ld_shared<FIRST_LDS>(&first[cj]); }
+  u16 *first; u32 wide;                                      // wide: 1 = 4-byte entries (their low half, at the same address, is the value), else 0
+  __device__ __forceinline__ u32 update(u32 cj, u32 i) const {
+    if (FIRST_LDS && wide) atomicMin(&((u32 *)first)[cj], i); else min_u16<FIRST_LDS>(first, cj, i);
+    return cj;
+  }
+  __device__ __forceinline__ u32 peek(u32 h) const {         // one read for both widths, no branch
+    if (FIRST_LDS) return *(const u16 *)((const unsigned char *)first + ((size_t)h << (1 + wide)));
+    return ld_shared<FIRST_LDS>(&first[h]);
+  }
+  __device__ __forceinline__ u32 lookup(u32 cj) const { return peek(cj); }
 };
 struct FirstRanked {
-  u16 *first; const u32 *bm; const u16 *pre;
+  u16 *first; const u32 *bm; const u16 *pre; u32 wide;
   __device__ __forceinline__ u32 at(u32 cj) const { const u32 w = cj >> 5; return pre[w] + (u32)__popc(bm[w] & ((1u << (cj & 31)) - 1u)); }
-  __device__ __forceinline__ u32 update(u32 cj, u32 i) const { const u32 h = at(cj); min_u16<true>(first, h, i); return h; }
-  __device__ __forceinline__ u32 peek(u32 h) const { return first[h]; }
-  __device__ __forceinline__ u32 lookup(u32 cj) const { return first[at(cj)]; }
+  __device__ __forceinline__ u32 update(u32 cj, u32 i) const { const u32 h = at(cj); if (wide) atomicMin(&((u32 *)first)[h], i); else min_u16<true>(first, h, i); return h; }
+  __device__ __forceinline__ u32 peek(u32 h) const { return *(const u16 *)((const unsigned char *)first + ((size_t)h << (1 + wide))); }
+  __device__ __forceinline__ u32 lookup(u32 cj) const { return peek(at(cj)); }
 };
 struct FirstHashed {
   // Buckets of 4 entries (one ds_read_b128 shows a whole bucket: at 2/3 load nearly every search ends in its home bucket).
@@ -547,14 +557,21 @@ __device__ void cluster_one_block(const ClusterArgs &a, u32 code, unsigned char 
   } else if constexpr (RANKED) nW = 0;                       // ranked placement: decided once the bitmap pass has counted the barcodes present
   else nW = IN_LDS ? histWaves(FIRST_LDS ? a.nBlocksFirst : 0, n, CL_WAVES, bmWords, sizeof(CT), a.ldsBudget) : (u32)CL_WAVES;
   if (!RANKED && !nW) return;                                // cannot happen: the classification sends such a barcode to the HBM-scratch class
+  // dense placement in LDS: 4-byte entries where that costs the list loop no wave (see FirstDense)
+  bool wideFirst = false;
+  if (FIRST_LDS && !RANKED && !HASHED && a.narrowFirst != 1) {
+    const u32 nW4 = histWaves(2 * a.nBlocksFirst, n, CL_WAVES, bmWords, sizeof(CT), a.ldsBudget);
+    wideFirst = nW4 >= nW || (a.narrowFirst >= 2 && nW4 >= a.narrowFirst);   // (A/B: accept down to narrowFirst waves)
+    if (wideFirst) nW = nW4;
+  }
   // ranked placement: first[] lies BEHIND the histograms and both are laid out after the bitmap pass, when the number of
   // barcodes present is known: the list loop then runs on as many waves as what is left of the budget has room for
-  Work<CT> w = carve<CT>(region, HASHED ? 2 * slots : (RANKED ? 0 : (FIRST_LDS || !IN_LDS ? a.nBlocksFirst : 0)), n, bmWords);
+  Work<CT> w = carve<CT>(region, HASHED ? 2 * slots : (RANKED ? 0 : (FIRST_LDS || !IN_LDS ? (wideFirst ? 2 * a.nBlocksFirst : a.nBlocksFirst) : 0)), n, bmWords);
   if (IN_LDS && FIRST_MODE == 2) w.first = firstGlobal;      // hybrid: first[] on this workgroup's HBM slot, the rest in LDS
   typename std::conditional<HASHED, FirstHashed, typename std::conditional<RANKED, FirstRanked, FirstDense<FIRST_LDS>>::type>::type ft{};
   if constexpr (HASHED) { slots &= ~3u; ft.tab = (u32 *)w.first; ft.NB = slots / 4; ft.recip = (u32)((0x100000000ULL + ft.NB - 1) / ft.NB); ft.bmask = a.hashMask; ft.ovf = &sh[2]; }
-  else if constexpr (RANKED) { ft.first = w.first; ft.bm = w.bm; ft.pre = w.pre; }
-  else ft.first = w.first;
+  else if constexpr (RANKED) { ft.first = w.first; ft.bm = w.bm; ft.pre = w.pre; ft.wide = 0; }
+  else { ft.first = w.first; ft.wide = wideFirst ? 1u : 0u; }
   const u32 lcode = code; code = a.segs.globalOf(lcode);     // from here on `code` is the global barcode number (what the lists hold)
   const u32 rsh = a.rowShift;
 #define ROWP(rs) (a.rows + ((size_t)(rs) << rsh))
@@ -562,7 +579,10 @@ __device__ void cluster_one_block(const ClusterArgs &a, u32 code, unsigned char 
 
   u64 tPrev = a.phase ? wall_clock64() : 0;
   // ---- init: prefetch every rank's list offset/length once
-  if (FIRST_LDS && !RANKED) for (u32 i = tid; i < (HASHED ? slots : (a.nBlocksFirst + 1) / 2); i += CL_THREADS) ((u32 *)w.first)[i] = 0xFFFFFFFFu;
+  if (FIRST_LDS && !RANKED) {
+    if (wideFirst) for (u32 i = tid; i < a.nBlocksFirst; i += CL_THREADS) ((u32 *)w.first)[i] = NONE16;
+    else for (u32 i = tid; i < (HASHED ? slots : (a.nBlocksFirst + 1) / 2); i += CL_THREADS) ((u32 *)w.first)[i] = 0xFFFFFFFFu;
+  }
   if (HASHED && tid == 0) sh[2] = 0;
   if (RANKED) for (u32 i = tid; i < bmWords; i += CL_THREADS) w.bm[i] = 0;
   if (!RANKED) for (u32 i = tid; i < nW * w.histWords; i += CL_THREADS) w.hist[i] = 0;
@@ -611,11 +631,14 @@ __device__ void cluster_one_block(const ClusterArgs &a, u32 code, unsigned char 
       }
       const size_t wv = (a.ldsBudget - fixed - need) / (per ? per : 1);
       nW = wv < (size_t)CL_WAVES ? (u32)wv : (u32)CL_WAVES;
+      const size_t need4 = (((size_t)total * 4 + 15) & ~(size_t)15) + 32;      // 4-byte entries where that costs the list loop no wave
+      ft.wide = (a.narrowFirst != 1 && fixed + need4 + (size_t)nW * per <= a.ldsBudget) ? 1u : 0u;
       w.first = (u16 *)((unsigned char *)w.hist + (((size_t)nW * per + 15) & ~(size_t)15));
       ft.first = w.first;
     }
     for (u32 i = tid; i < nW * w.histWords; i += CL_THREADS) w.hist[i] = 0;
-    for (u32 q = tid; q < (total + 1) / 2; q += CL_THREADS) ((u32 *)w.first)[q] = 0xFFFFFFFFu;
+    if (ft.wide) for (u32 q = tid; q < total; q += CL_THREADS) ((u32 *)w.first)[q] = NONE16;
+    else for (u32 q = tid; q < (total + 1) / 2; q += CL_THREADS) ((u32 *)w.first)[q] = 0xFFFFFFFFu;
     SYNC();
   }
   STAMP(0);
@@ -1064,7 +1087,7 @@ static int cluster_local_range(Ctx *c, int codeMin, int codeMax, int threshold, 
   a.hashDepth = c->hashDepth.p; a.rowStart = c->rowStart.p; a.rows = c->rows.p; a.nBlocks = c->nBlocks; a.threshold = threshold;
   a.segs = c->segs; a.nBlocksFirst = nGlobal; a.rowShift = (u32)c->rowShift;
   if (c->sharded && c->optRowsFakeBase) a.rows = c->rows.p - (size_t)c->optRowsFakeBase;   // test knob: rowStart[] carries the same offset (shard_exchangeRows)
-  a.dbgSkip = (u32)c->optDbgSkip;
+  a.dbgSkip = (u32)c->optDbgSkip; a.narrowFirst = (u32)c->optNarrowFirst;
   a.maxGood = c->maxGood; a.stats = stats.p; a.term = term.p; a.entries = c->goodEntries.p;
   a.firstCap = firstCap; a.hashMask = hashBits >= 32 ? 0xFFFFFFFFu : (1u << hashBits) - 1u; a.hashMinSlots = hashMinSlots;
   // ranked / hashed placement: blocks whose table was too small are re-run — those of the half-CU class (list A) with the

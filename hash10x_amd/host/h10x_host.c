@@ -15,10 +15,11 @@
 #define ARRAY_MAGIC 8918274                            /* array.h:56 */
 typedef struct { int32_t magic, pad0; uint64_t base; int32_t dim, size, max, pad1; } array_hdr;   /* array.h:41-50 */
 
+enum { N_KNOBS = 13 };
 struct h10x_session {
   int k, w, r, B, N, chunk, ct, device;                /* params (hash10x.c:25-33) */
   int timing;                                          /* measurement hook: enable hipEvent timers on every new context */
-  int knob[11];                                        /* test / tuning knobs forwarded to h10x_set_option (names in knobName[]) */
+  int knob[N_KNOBS];                                        /* test / tuning knobs forwarded to h10x_set_option (names in knobName[]) */
   int16_t *cribChr; uint16_t *cribPos; uint8_t *cribType; uint32_t *cribDepth; uint32_t cribN;   /* per-hash host copies for the report texts */
   h10x_ctx *ctx;
   int ctxK, ctxW, ctxR, ctxB, ctxDev;                   /* parameters the live context was created with */
@@ -27,9 +28,8 @@ struct h10x_session {
   uint32_t *depthTail; int depthTailFrom;              /* entries [hashNumber, dim) as read from a file (normally zero) */
   char err[1024];
 };
-enum { N_KNOBS = 11 };
 static const char *const knobName[N_KNOBS] = {"cluster_stamps", "cluster_lds_budget", "cluster_first_global", "cluster_first_cap", "cluster_dbg_skip",
-                                              "cluster_big_ranks", "cluster_threads0", "cluster_budget0", "shard_row_shift", "shard_rows_fake_base", "stage_a_max_slots"};
+                                              "cluster_big_ranks", "cluster_threads0", "cluster_budget0", "shard_row_shift", "shard_rows_fake_base", "stage_a_max_slots", "cluster_narrow_first", "index_no_pack"};
 
 static int fail(h10x_session *s, const char *fmt, ...) {
   va_list ap; va_start(ap, fmt); vsnprintf(s->err, sizeof s->err, fmt, ap); va_end(ap);
