@@ -46,9 +46,13 @@ __global__ void within_kernel(const u32 *__restrict__ depth, u32 hashNumber, int
   const int n = (int)depth[i];
   if (n >= lo && n < hi) within[i] = 1;                     // only ever set (hash10x.c:535)
 }
-__global__ void within_depth_kernel(const u32 *__restrict__ depth, const u8 *__restrict__ within, u32 hashNumber, u32 *__restrict__ out) {
+__global__ void within_depth_kernel(const u32 *__restrict__ depth, const u8 *__restrict__ within, u32 hashNumber, u32 *__restrict__ out,
+                                    u8 *__restrict__ out8 /* the same in a byte where every in-range depth is below 255, else null */) {
   const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < hashNumber) out[i] = within[i] ? depth[i] + 1 : 0;   // 0 = outside the range(s); depth + 1 otherwise (one word tells both)
+  if (i < hashNumber) {
+    const u32 wd = within[i] ? depth[i] + 1 : 0;             // 0 = outside the range(s); depth + 1 otherwise (one word tells both)
+    out[i] = wd; if (out8) out8[i] = (u8)wd;
+  }
 }
 
 // per block: keys (depth << 16 | position) of its in-range hashes, appended in any order; KT = u32 while the largest
@@ -95,15 +99,17 @@ __global__ void offsets32c_kernel(const u64 *__restrict__ off, u32 n, u32 *__res
   if (i < n) out[i] = (u32)off[i];
 }
 
-// The good list of a block in one workgroup: keys (depth << 16 | position) of the in-range hashes, sorted in LDS (rocPRIM block
-// radix sort), positions written out — instead of key kernel + device-wide segmented sort + position kernel. Blocks up to
-// BLOCK_SORT_MAX entries, depths below 2^16 (32-bit keys); three launch classes by block size like clushash_block_kernel.
-template <int THREADS, int IPT>
+// The good list of a block in one workgroup: the in-range hashes' depths as keys, their positions as values, sorted in LDS
+// (rocPRIM block radix sort, stable), positions written out — instead of key kernel + device-wide segmented sort + position
+// kernel. Blocks up to BLOCK_SORT_MAX entries, depths below 2^16; three launch classes by block size like clushash_block_kernel.
+// (WT = u8 where the depths allow: the table every entry looks its hash up in is then a quarter the size — 7.6 MB instead of
+// 30 MB at yeast scale, against 4 MB of L2 per XCD)
+template <int THREADS, int IPT, typename WT>
 __global__ __launch_bounds__(THREADS)
 void good_block_kernel(const h10x_clushash *__restrict__ ch, const u64 *__restrict__ blockOff, const h10x_block *__restrict__ blocks, u32 nBlocks,
-                       const u32 *__restrict__ wdepth /* 0 = not in range, else depth + 1 */, int sortBits,
+                       const WT *__restrict__ wdepth /* 0 = not in range, else depth + 1 */, int sortBits,
                        u16 *__restrict__ goodPos, u32 *__restrict__ nGood, u32 *__restrict__ entries /* sum of depths, saturating */) {
-  using Sort = rocprim::block_radix_sort<u32, THREADS, IPT>;
+  using Sort = rocprim::block_radix_sort<u32, THREADS, IPT, u32>;
   __shared__ typename Sort::storage_type storage;
   __shared__ u32 sCount; __shared__ unsigned long long sDepth;
   constexpr u32 CAP = THREADS * IPT, LOWER = CAP == BLOCK_SORT_CAP0 ? 0 : (CAP == BLOCK_SORT_CAP1 ? BLOCK_SORT_CAP0 : BLOCK_SORT_CAP1);
@@ -114,20 +120,23 @@ void good_block_kernel(const h10x_clushash *__restrict__ ch, const u64 *__restri
     __syncthreads();
     if (threadIdx.x == 0) { sCount = 0; sDepth = 0; }
     __syncthreads();
-    u32 k[IPT]; u32 mine = 0; unsigned long long myDepth = 0;
+    // blocked arrangement: a thread holds IPT consecutive positions, so the positions are ascending in the order the sort
+    // takes as given, and a STABLE sort on the depth bits alone (one 8-bit pass for depths below 128, where depth and
+    // position in one key needed three) leaves equal depths in ascending position
+    u32 k[IPT], v[IPT]; u32 mine = 0; unsigned long long myDepth = 0;
 #pragma unroll
     for (int j = 0; j < IPT; ++j) {
-      const u32 p = (u32)j * THREADS + threadIdx.x;
-      k[j] = 0xFFFFFFFFu;
-      if (p < nHash) { const u32 wd = wdepth[ch[o + p].hash]; if (wd) { k[j] = ((wd - 1) << 16) | p; ++mine; myDepth += wd - 1; } }
+      const u32 p = threadIdx.x * IPT + (u32)j;
+      k[j] = 0xFFFFFFFFu; v[j] = p;
+      if (p < nHash) { const u32 wd = wdepth[ch[o + p].hash]; if (wd) { k[j] = wd - 1; ++mine; myDepth += wd - 1; } }
     }
     for (int sft = 32; sft; sft >>= 1) { mine += (u32)__shfl_down((int)mine, sft); myDepth += __shfl_down(myDepth, sft); }
     if ((threadIdx.x & (WAVE - 1)) == 0 && mine) { atomicAdd(&sCount, mine); atomicAdd(&sDepth, myDepth); }
-    Sort().sort(k, storage, 0, sortBits);                    // ascending (depth, position): hash10x.c:726-730,758; padding keys last
+    Sort().sort(k, v, storage, 0, sortBits);                 // ascending (depth, position): hash10x.c:726-730,758; padding keys last
     __syncthreads();
     const u32 nG = sCount;
 #pragma unroll
-    for (int j = 0; j < IPT; ++j) { const u32 e = threadIdx.x * IPT + j; if (e < nG) goodPos[o + e] = (u16)(k[j] & 0xFFFFu); }
+    for (int j = 0; j < IPT; ++j) { const u32 e = threadIdx.x * IPT + j; if (e < nG) goodPos[o + e] = (u16)v[j]; }
     if (threadIdx.x == 0) { nGood[c] = nG; entries[c] = sDepth > 0xFFFFFFFFull ? 0xFFFFFFFFu : (u32)sDepth; }
   }
 }
@@ -150,21 +159,26 @@ int stageC_depthRange(Ctx *c, int lo, int hi) {
   H10X_HIP(c, off32.alloc((size_t)nBlocks + 1));
   H10X_HIP(c, segEnd.alloc(nBlocks)); H10X_HIP(c, wdepth.alloc(U1)); H10X_HIP(c, red.alloc(2));
   H10X_HIP(c, c->nGood.alloc(nBlocks)); H10X_HIP(c, c->goodPos.alloc(H)); H10X_HIP(c, c->goodEntries.alloc(nBlocks));
-  within_depth_kernel<<<divUp(U1, 256), 256, 0, st>>>(c->hashDepth.p, c->within.p, U1, wdepth.p);
-  H10X_TRY(prim_reduce_max_u32(c, pt, wdepth.p, red.p, U1));
   // no in-range depth exceeds this, known without a round trip: the data set's barcode count (Ctx::depthBound) or the ranges' limit
   const u32 goodDepthBound = hmin<u32>(c->depthBound, c->rangeHiMax ? c->rangeHiMax - 1 : 0);
   const bool narrow = goodDepthBound <= 65535u;
   const bool byBlocks = narrow && c->maxBlockHashes <= BLOCK_SORT_MAX;       // every block's list is built and sorted by one workgroup
+  DevBuf<u8> wdepth8; if (byBlocks && goodDepthBound <= 254u) H10X_HIP(c, wdepth8.alloc(U1));
+  within_depth_kernel<<<divUp(U1, 256), 256, 0, st>>>(c->hashDepth.p, c->within.p, U1, wdepth.p, wdepth8.p);
+  H10X_TRY(prim_reduce_max_u32(c, pt, wdepth.p, red.p, U1));
   if (byBlocks) {
     int db = 1; while (db < 16 && (goodDepthBound >> db)) ++db;
-    const int sortBits = 16 + db + 1 > 32 ? 32 : 16 + db + 1;                 // one bit more than the largest key: padding keys sort last
+    const int sortBits = db + 1;                                              // one bit more than the largest depth: padding keys sort last
     const unsigned grid = hmin<u32>(nBlocks, 65535u * 4);
     const int side = c->maxBlockHashes > BLOCK_SORT_CAP1 ? 2 : (c->maxBlockHashes > BLOCK_SORT_CAP0 ? 1 : 0);
     if (side) H10X_TRY(c->forkStreams(side));
-    good_block_kernel<256, 12><<<grid, 256, 0, st>>>(c->clusHash.p, c->blockOff.p, c->blocks.p, nBlocks, wdepth.p, sortBits, c->goodPos.p, c->nGood.p, c->goodEntries.p);
-    if (side >= 1) good_block_kernel<512, 12><<<grid, 512, 0, c->aux[0]>>>(c->clusHash.p, c->blockOff.p, c->blocks.p, nBlocks, wdepth.p, sortBits, c->goodPos.p, c->nGood.p, c->goodEntries.p);
-    if (side >= 2) good_block_kernel<1024, 8><<<grid, 1024, 0, c->aux[1]>>>(c->clusHash.p, c->blockOff.p, c->blocks.p, nBlocks, wdepth.p, sortBits, c->goodPos.p, c->nGood.p, c->goodEntries.p);
+#define H10X_GOOD_LAUNCH(T, I, STREAM)                                                                                              \
+    { if (wdepth8.p) good_block_kernel<T, I, u8><<<grid, T, 0, STREAM>>>(c->clusHash.p, c->blockOff.p, c->blocks.p, nBlocks, wdepth8.p, sortBits, c->goodPos.p, c->nGood.p, c->goodEntries.p); \
+      else good_block_kernel<T, I, u32><<<grid, T, 0, STREAM>>>(c->clusHash.p, c->blockOff.p, c->blocks.p, nBlocks, wdepth.p, sortBits, c->goodPos.p, c->nGood.p, c->goodEntries.p); }
+    H10X_GOOD_LAUNCH(256, 12, st)
+    if (side >= 1) H10X_GOOD_LAUNCH(512, 12, c->aux[0])
+    if (side >= 2) H10X_GOOD_LAUNCH(1024, 8, c->aux[1])
+#undef H10X_GOOD_LAUNCH
     if (side) H10X_TRY(c->joinStreams(side));
   }
   else if (narrow) { H10X_HIP(c, key32.alloc(H)); H10X_HIP(c, keyS32.alloc(H)); } else { H10X_HIP(c, key.alloc(H)); H10X_HIP(c, keyS.alloc(H)); }
