@@ -183,6 +183,9 @@ void clushash_block_kernel(const u64 *__restrict__ entHash /* hash / w */, const
           const u64 q = entHash[o + e] >> cb, h = q * w;
           u64 slot = h & mask; const u64 step = ((h >> B) & mask) | 1;
           u64 t;
+#ifdef H10X_DBG_SKIP
+          if (sortBits & 64) { t = (q * 0x9E3779B97F4A7C15ULL) << qBits | q; } else                   // what-if: no table look-up
+#endif
           while ((t = table64[slot]) != SLOT_EMPTY64 && (t & qmask) != q) slot = (slot + step) & mask;
           k[j] = t == SLOT_EMPTY64 ? 0u : (u32)(t >> qBits);
           v[j] = entRead[o + e] & 0xFFFFu;                   // ClusterHash.read is U16 (hash10x.c:37,180)
@@ -190,10 +193,13 @@ void clushash_block_kernel(const u64 *__restrict__ entHash /* hash / w */, const
       }
     }
     __syncthreads();                                         // the storage of the previous block's sort is free again
-    Sort().sort(k, v, storage, 0, sortBits);                 // padding keys are all ones in sortBits bits: behind every index
+#ifdef H10X_DBG_SKIP
+    if (!(sortBits & 128))                                   // what-if: no sort
+#endif
+    Sort().sort_to_striped(k, v, storage, 0, sortBits & 63); // padding keys are all ones in sortBits bits: behind every index
 #pragma unroll
     for (int j = 0; j < IPT; ++j) {
-      const u32 e = threadIdx.x * IPT + j;                   // sorted: blocked arrangement
+      const u32 e = (u32)j * THREADS + threadIdx.x;          // sorted, striped arrangement: a wave's store covers 512 contiguous bytes
       if (e < n) { h10x_clushash r; r.hash = k[j]; r.read = (u16)v[j]; r.subCluster = 0; r.flags = 0; out[o + e] = r; }   // zeroed: SURVEY F4
     }
   }
@@ -204,7 +210,10 @@ static int clusHashByBlocks(Ctx *c, const u64 *entHash, const u32 *entRead, cons
   hipStream_t st = c->stream; const u32 nBlocks = c->nBlocks;
   H10X_HIP(c, c->clusHash.alloc(c->nEntries));
   if (!c->nEntries || nBlocks < 2) return 0;
-  const int sortBits = bitsFor(c->hashNumber) + 1 > 32 ? 32 : bitsFor(c->hashNumber) + 1;
+  int sortBits = bitsFor(c->hashNumber) + 1 > 32 ? 32 : bitsFor(c->hashNumber) + 1;
+#ifdef H10X_DBG_SKIP
+  sortBits |= (int)(c->optDbgSkip & (1024 | 2048)) >> 4;     // what-if timing (results wrong): 1024 no look-up, 2048 no sort
+#endif
   const unsigned grid = hmin<u32>(nBlocks - 1, 65535u * 4);
   const int B = c->prm.B; const u64 w = (u64)c->prm.w; const int qBits = c->keyBits;
 #define H10X_CH_LAUNCH(T, I, LOOK, STREAM) clushash_block_kernel<T, I, LOOK><<<grid, T, 0, STREAM>>>(entHash, entRead, key, c->blockOff.p, nBlocks, table64, B, w, qBits, key ? 0 : c->entCodeBits, sortBits, c->clusHash.p)

@@ -132,11 +132,11 @@ void good_block_kernel(const h10x_clushash *__restrict__ ch, const u64 *__restri
     }
     for (int sft = 32; sft; sft >>= 1) { mine += (u32)__shfl_down((int)mine, sft); myDepth += __shfl_down(myDepth, sft); }
     if ((threadIdx.x & (WAVE - 1)) == 0 && mine) { atomicAdd(&sCount, mine); atomicAdd(&sDepth, myDepth); }
-    Sort().sort(k, v, storage, 0, sortBits);                 // ascending (depth, position): hash10x.c:726-730,758; padding keys last
+    Sort().sort_to_striped(k, v, storage, 0, sortBits);      // ascending (depth, position): hash10x.c:726-730,758; padding keys last
     __syncthreads();
     const u32 nG = sCount;
 #pragma unroll
-    for (int j = 0; j < IPT; ++j) { const u32 e = threadIdx.x * IPT + j; if (e < nG) goodPos[o + e] = (u16)v[j]; }
+    for (int j = 0; j < IPT; ++j) { const u32 e = (u32)j * THREADS + threadIdx.x; if (e < nG) goodPos[o + e] = (u16)v[j]; }   // striped: coalesced stores
     if (threadIdx.x == 0) { nGood[c] = nG; entries[c] = sDepth > 0xFFFFFFFFull ? 0xFFFFFFFFu : (u32)sDepth; }
   }
 }
