@@ -224,8 +224,7 @@ static int clusHashByBlocks(Ctx *c, const u64 *entHash, const u32 *entRead, cons
 #undef H10X_CH_LAUNCH
   if (side) H10X_TRY(c->joinStreams(side));
   H10X_HIP(c, hipGetLastError());
-  H10X_HIP(c, hipStreamSynchronize(st));
-  return 0;
+  return 0;                                                  // no round trip: the buffers go back to the stream-ordered block cache, the next command queues behind
 }
 
 int stageB_run(Ctx *c, DevBuf<u64> &entHash, DevBuf<u32> &entCode, DevBuf<u32> &entRead) {
