@@ -19,6 +19,17 @@ int prim_exclusive_scan_u32(Ctx *c, PrimTemp &t, const u32 *in, u32 *out, size_t
   PRIM_TWO_PHASE(c, t, rocprim::exclusive_scan(tmp, bytes, in, out, (u32)0, n, rocprim::plus<u32>(), c->stream));
   return 0;
 }
+// ord[i] = number of runs of equal keys (compared above their low `cb` bits) that start before position i, for i in [0, n]:
+// the head flags are formed inside the scan's loads instead of by a kernel of their own
+struct RunHead {
+  const u64 *key; size_t n; int cb;
+  __device__ u32 operator()(size_t i) const { return (i < n && (i == 0 || (key[i] >> cb) != (key[i - 1] >> cb))) ? 1u : 0u; }
+};
+int prim_run_ordinals_u64(Ctx *c, PrimTemp &t, const u64 *key, int cb, u32 *ord, size_t n) {
+  auto flags = rocprim::make_transform_iterator(rocprim::counting_iterator<size_t>(0), RunHead{key, n, cb});
+  PRIM_TWO_PHASE(c, t, rocprim::exclusive_scan(tmp, bytes, flags, ord, (u32)0, n + 1, rocprim::plus<u32>(), c->stream));
+  return 0;
+}
 int prim_exclusive_scan_u32_u64(Ctx *c, PrimTemp &t, const u32 *in, u64 *out, size_t n) {
   if (!n) return 0;
   auto in64 = rocprim::make_transform_iterator(in, [] __device__(u32 v) -> u64 { return (u64)v; });

@@ -8,6 +8,7 @@ namespace h10x {
 // scratch for rocPRIM temporary storage, grown on demand, owned by the caller
 struct PrimTemp { DevBuf<char> buf; };
 
+int prim_run_ordinals_u64(Ctx *c, PrimTemp &t, const u64 *key, int cb, u32 *ord /* n + 1 */, size_t n);   // runs of equal key >> cb that start before i
 int prim_exclusive_scan_u32(Ctx *c, PrimTemp &t, const u32 *in, u32 *out, size_t n);              // out[i] = sum in[0..i)
 int prim_exclusive_scan_u32_u64(Ctx *c, PrimTemp &t, const u32 *in, u64 *out, size_t n);          // 64-bit accumulation
 int prim_inclusive_scan_u32(Ctx *c, PrimTemp &t, const u32 *in, u32 *out, size_t n);

@@ -20,24 +20,19 @@ constexpr u32 SLOT_EMPTY = 0xFFFFFFFFu;
 static int bitsFor(u64 maxValue) { int b = 1; while (b < 64 && (maxValue >> b)) ++b; return b; }
 
 // ------------------------------------------------------------------------------------------ distinct hashes
-__global__ void seg_head_flags_kernel(const u64 *__restrict__ sHash, u64 n, int cb /* packed entries: block number in the low cb bits */, u32 *__restrict__ flags) {
-  u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-  const u64 stride = (u64)gridDim.x * blockDim.x;
-  for (; i < n; i += stride) flags[i] = (i == 0 || (sHash[i] >> cb) != (sHash[i - 1] >> cb)) ? 1u : 0u;
-}
-
-__global__ void seg_scatter_kernel(const u64 *__restrict__ sHash, const u32 *__restrict__ sCode, const u32 *__restrict__ flags,
+// (position i starts a run iff the ordinal steps there: ord has n + 1 entries)
+__global__ void seg_scatter_kernel(const u64 *__restrict__ sHash, const u32 *__restrict__ sCode,
                                    const u32 *__restrict__ ord, u64 n, u64 *__restrict__ dHash, u32 *__restrict__ dFirst,
                                    u32 *__restrict__ segStart, u32 *__restrict__ iota) {
   u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
   const u64 stride = (u64)gridDim.x * blockDim.x;
-  for (; i < n; i += stride) if (flags[i]) {
+  for (; i < n; i += stride) if (ord[i + 1] != ord[i]) {
     const u32 d = ord[i];
     dHash[d] = sHash[i]; dFirst[d] = sCode[i]; segStart[d] = (u32)i; iota[d] = d;
   }
 }
 // the same from packed entries, which also leaves the barcode lists (the block numbers in sorted order) behind
-__global__ void seg_scatter_packed_kernel(const u64 *__restrict__ sKey, int cb, const u32 *__restrict__ flags,
+__global__ void seg_scatter_packed_kernel(const u64 *__restrict__ sKey, int cb,
                                           const u32 *__restrict__ ord, u64 n, u64 *__restrict__ dHash, u32 *__restrict__ dFirst,
                                           u32 *__restrict__ segStart, u32 *__restrict__ iota, u32 *__restrict__ rows) {
   u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
@@ -46,7 +41,8 @@ __global__ void seg_scatter_packed_kernel(const u64 *__restrict__ sKey, int cb, 
   for (; i < n; i += stride) {
     const u64 k = sKey[i]; const u32 code = (u32)(k & cmask);
     rows[i] = code;
-    if (flags[i]) { const u32 d = ord[i]; dHash[d] = k >> cb; dFirst[d] = code; segStart[d] = (u32)i; iota[d] = d; }
+    const u32 d = ord[i];
+    if (ord[i + 1] != d) { dHash[d] = k >> cb; dFirst[d] = code; segStart[d] = (u32)i; iota[d] = d; }
   }
 }
 
@@ -247,19 +243,17 @@ int stageB_run(Ctx *c, DevBuf<u64> &entHash, DevBuf<u32> &entCode, DevBuf<u32> &
   u32 U = 0;
   DevBuf<u64> dHash; DevBuf<u32> dFirst, segStart, iota, order, dFirstSorted;
   {
-    DevBuf<u32> flags, ord;
-    H10X_HIP(c, flags.alloc(H + 1)); H10X_HIP(c, ord.alloc(H + 1));
-    if (H) seg_head_flags_kernel<<<gH, 256, 0, st>>>(sHash.p, H, cb, flags.p);
-    H10X_HIP(c, hipMemsetAsync(flags.p + H, 0, 4, st));
-    H10X_TRY(prim_exclusive_scan_u32(c, pt, flags.p, ord.p, H + 1));
+    DevBuf<u32> ord;
+    H10X_HIP(c, ord.alloc(H + 1));
+    H10X_TRY(prim_run_ordinals_u64(c, pt, sHash.p, cb, ord.p, H));          // (head flags formed inside the scan)
     H10X_TRY(c->readback(&U, ord.p + H, 4));
     H10X_TRY(c->syncReadbacks());
     // hash10x.c:149: die once hashNumber exceeds 2^(B-2) - 2; hashNumber ends at U + 1
     if ((u64)U + 1 > (tableSize >> 2) - 2) return c->fail("hashTableSize is too small");
     H10X_HIP(c, dHash.alloc(U)); H10X_HIP(c, dFirst.alloc(U)); H10X_HIP(c, segStart.alloc((size_t)U + 1));
     H10X_HIP(c, iota.alloc(U)); H10X_HIP(c, order.alloc(U)); H10X_HIP(c, dFirstSorted.alloc(U));
-    if (H && cb) seg_scatter_packed_kernel<<<gH, 256, 0, st>>>(sHash.p, cb, flags.p, ord.p, H, dHash.p, dFirst.p, segStart.p, iota.p, sCode.p);
-    else if (H) seg_scatter_kernel<<<gH, 256, 0, st>>>(sHash.p, sCode.p, flags.p, ord.p, H, dHash.p, dFirst.p, segStart.p, iota.p);
+    if (H && cb) seg_scatter_packed_kernel<<<gH, 256, 0, st>>>(sHash.p, cb, ord.p, H, dHash.p, dFirst.p, segStart.p, iota.p, sCode.p);
+    else if (H) seg_scatter_kernel<<<gH, 256, 0, st>>>(sHash.p, sCode.p, ord.p, H, dHash.p, dFirst.p, segStart.p, iota.p);
     H10X_HIP(c, hipMemsetD32Async((hipDeviceptr_t)(segStart.p + U), (int)(u32)H, 1, st));      // end of the last segment
   }
   // distinct hashes are in ascending hash order; a stable sort by first barcode gives (first, hash) order
