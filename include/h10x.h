@@ -83,6 +83,8 @@ const char *h10x_last_error(const h10x_ctx *ctx);
    when its own run ends at a chunk boundary, hash10x.c:212) are replayed from the barcode run starts when
    h10x_set_option(ctx, "chunk_size", c) was called with c > 0 (the session layer passes -c); 0 = no chunk semantics.
    _device: records already resident in device memory (HBM). */
+/* Both return once the last launches are queued (every size the host needs has been read back by then): the next call on the
+   context waits for them, and a device fault in them is reported there. */
 int  h10x_read_fqb(h10x_ctx *ctx, const uint32_t *host_records, uint64_t n_records);
 int  h10x_read_fqb_device(h10x_ctx *ctx, const uint32_t *dev_records, uint64_t n_records);
 
@@ -267,8 +269,14 @@ typedef struct {
                                       [0] init (+ bitmap), [1] list loop, [2] barrier, [3] replay, [4] quotient, [5] output */
 } h10x_counters;
 int  h10x_get_counters(h10x_ctx *ctx, h10x_counters *out);
-/* testing knob: cap the LDS hash-set slots per barcode in stage A (0 = default) so that the
-   global-memory fallback can be exercised on small inputs */
+/* test / tuning knobs (none changes a result): "stage_a_max_slots" caps the LDS hash-set slots per barcode in stage A (0 =
+   default) so that the global-memory fallback can be exercised on small inputs; "chunk_size" (above); "index_no_pack" 1 = index
+   build with separate key / block arrays even where the packed one-word entries fit; "cluster_narrow_first" 1 = first[] of the
+   cluster kernel at 2 bytes per entry in every block, w >= 2 = 4 bytes down to w list-loop waves (default 0: 4 bytes where that
+   costs no wave); "cluster_lds_budget", "cluster_first_global", "cluster_first_cap", "cluster_big_ranks", "cluster_threads0",
+   "cluster_budget0" (placement and launch-class overrides of the tests), "cluster_stamps" (phase stamps into h10x_counters),
+   "cluster_dbg_skip" (what-if timing switches, honoured only by a library built with -DH10X_DBG_SKIP: results are then wrong),
+   "shard_row_shift", "shard_rows_fake_base" (sharded list offsets beyond 32 bits on small inputs). Unknown name: -1. */
 int  h10x_set_option(h10x_ctx *ctx, const char *name, int64_t value);
 
 #ifdef __cplusplus
