@@ -142,9 +142,11 @@ def test_cluster_tiny_set_front_queue_only(workdir):
                         k=24, w=32, r=9, B=21, cluster_first_global=mode)
 
 
-@pytest.mark.parametrize("k,w,r", [(21, 31, 17), (16, 5, 3), (24, 31, 5), (25, 31, 17), (31, 7, 1), (11, 32, 9)])
+@pytest.mark.parametrize("k,w,r", [(21, 31, 17), (16, 5, 3), (24, 31, 5), (25, 31, 17), (31, 7, 1), (11, 32, 9), (21, 1, 3), (19, 29, 7), (17, 2, 5), (30, 31, 2)])
 def test_other_hashers(workdir, k, w, r):
-    """k > 24 cannot pack (hash, read) into 64 bits and takes the global path; w != 31 the generic modulo."""
+    """k > 24 cannot pack (hash, read) into 64 bits and takes the global path; w != 31 the generic modulo. w = 1 / 2: every (other)
+    k-mer is a mosh — each wave's survivor queue is emptied after every slot and the LDS set overflows into the global path; w = 29: as
+    many survivors as the table still holds; k = 17 and 30: the ends of the range that hashes on 32-bit halves."""
     orc.gen_fqb(workdir.file("x.fqb"), 3000, 20, 40000, 0.004, 100 + k, 3.0, 150, 2500)
     _against_oracle(workdir, "x.fqb", ["--readFQB", "x.fqb"], k=k, w=w, r=r, B=21)
 
@@ -162,6 +164,17 @@ def test_random_sets_end_to_end(workdir, seed, pairs, barcodes, genome, mol, mol
     hf2 = _against_oracle(workdir, "x.fqb", ["-ct", ct, "--readFQB", "x.fqb", "--hashDepthRange", lo, hi, "--cluster", 1, 0, "--clusterSplit",
                                              "--hashDepthRange", lo, hi, "--cluster", 1, 0])
     assert hf2.blocks_max > hf.blocks_max
+
+
+@pytest.mark.parametrize("opts", [dict(index_no_pack=1), dict(cluster_narrow_first=1), dict(cluster_narrow_first=5),
+                                  dict(cluster_first_global=2, cluster_narrow_first=1), dict(cluster_first_global=2, cluster_lds_budget=40 * 1024)])
+def test_alternative_layouts_give_the_same_bytes(workdir, opts):
+    """The forms the default build does not take on a small set: index build with separate key / block arrays (default: one packed
+    word per entry), first[] of the cluster kernel at 2 bytes per entry everywhere / at 4 bytes even where that costs list-loop
+    waves (default: 4 bytes where free), in the dense and in the ranked placement."""
+    orc.gen_fqb(workdir.file("x.fqb"), 40000, 120, 250000, 0.003, 77, 4.0, 150, 6000)
+    hf = _against_oracle(workdir, "x.fqb", ["-ct", 3, "--readFQB", "x.fqb", "--hashDepthRange", 4, 40, "--cluster", 1, 0], **opts)
+    assert hf.blocks["nSubCluster"].sum() > 0
 
 
 def test_big_barcode_uses_medium_lds_class_and_wide_lists(workdir):
