@@ -138,7 +138,7 @@ struct Ctx {
   u64 keyInv = 1; int keyShift = 0; int keyBits = 64;
   // Single-GPU index build: an entry's key and block number travel in ONE word, (hash / w) << entCodeBits | block, so the
   // device-wide sort moves 8 bytes per entry and pass instead of 12 (keys only, on bits [entCodeBits, entCodeBits + keyBits)).
-  // 0 = separate arrays (sharded path, or the two do not fit 64 bits). wantPacked is set by the caller of stageA_run.
+  // 0 = separate arrays (sharded path, or the two do not fit 63 bits). wantPacked is set by the caller of stageA_run.
   bool wantPacked = false; int entCodeBits = 0;
   int device = 0;
   hipStream_t stream = nullptr;

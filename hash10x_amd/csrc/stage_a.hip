@@ -672,7 +672,9 @@ int stageA_run(Ctx *c, const u32 *dRec, u64 nRec, DevBuf<u64> &entHash, DevBuf<u
     int b = 1; while (b < 64 && (maxQ >> b)) ++b;
     c->keyInv = inv; c->keyShift = s; c->keyBits = b;
     int cb = 1; while (cb < 32 && ((nBlocks - 1) >> cb)) ++cb;
-    c->entCodeBits = (c->wantPacked && b + cb <= 64) ? cb : 0;
+    // (63, not 64: rocPRIM 4.2's radix_sort_keys mis-sorts inputs of some thousand to a million keys when the bit range starts above
+    // bit 0 and ends at bit 64 — scratch/sort_bits_check.hip; found by tests/soak.py at k = 31, w = 5 with 15 barcodes)
+    c->entCodeBits = (c->wantPacked && b + cb <= 63) ? cb : 0;
   }
   if (!c->entCodeBits) H10X_HIP(c, entCode.alloc(H));
   if (H) compact_entries_kernel<<<hmin<u32>(nBlocks, 8192), 256, 0, st>>>(stHash.p, stRead.p, capOff.p, dFb.p, nHash.p, c->blockOff.p, nBlocks,

@@ -151,6 +151,17 @@ def test_other_hashers(workdir, k, w, r):
     _against_oracle(workdir, "x.fqb", ["--readFQB", "x.fqb"], k=k, w=w, r=r, B=21)
 
 
+@pytest.mark.parametrize("barcodes", [7, 15])
+def test_packed_entries_at_the_width_limit(workdir, barcodes):
+    """k = 31, w = 5: 60 key bits. With 7 barcodes key and block number fill 63 bits (packed one-word entries, the widest the index
+    build packs), with 15 they would fill 64 and the build must take separate arrays: rocPRIM's keys-only sort mis-sorts a bit range
+    that starts above bit 0 and ends at bit 64 (tests/soak.py case; scratch/sort_bits_check.hip)."""
+    orc.gen_fqb(workdir.file("x.fqb"), 60 * barcodes // 15 + 40, barcodes, 100000, 0.003, 1076, 3.0, 150, 8000)
+    _against_oracle(workdir, "x.fqb", ["-ct", 2, "--readFQB", "x.fqb", "--hashDepthRange", 3, 33, "--cluster", 1, 0], k=31, w=5, r=17, B=23)
+    orc.gen_fqb(workdir.file("y.fqb"), 30000, barcodes, 200000, 0.003, 1077, 3.0, 150, 8000)          # enough entries for the merge-sort sizes
+    _against_oracle(workdir, "y.fqb", ["-ct", 2, "--readFQB", "y.fqb", "--hashDepthRange", 3, 33, "--cluster", 1, 0], k=31, w=5, r=17, B=25)
+
+
 @pytest.mark.parametrize("seed,pairs,barcodes,genome,mol,mol_len,lo,hi,ct", [
     (41, 30000, 150, 300000, 4.0, 6000, 4, 30, 3),
     (42, 50000, 60, 150000, 3.0, 5000, 6, 60, 5),
