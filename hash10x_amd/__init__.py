@@ -28,7 +28,7 @@ class Hash10xError(RuntimeError):
 class _Counters(ctypes.Structure):
     _fields_ = [(n, ctypes.c_uint64) for n in (
         "pairs", "kmers", "entries", "distinct", "clustered_codes", "sum_good", "sum_good_depth",
-        "sum_hash_clustered", "fallback_blocks")] + [("cluster_class_counts", ctypes.c_uint64 * 4), ("cluster_first_mode", ctypes.c_uint64), ("cluster_overflow_blocks", ctypes.c_uint64), ("cluster_main", ctypes.c_uint64 * 4), ("cluster_phase_ticks", ctypes.c_uint64 * 8)]
+        "sum_hash_clustered", "fallback_blocks")] + [("cluster_class_counts", ctypes.c_uint64 * 4), ("cluster_first_mode", ctypes.c_uint64), ("cluster_overflow_blocks", ctypes.c_uint64), ("cluster_main", ctypes.c_uint64 * 4), ("cluster_phase_ticks", ctypes.c_uint64 * 8), ("list_words", ctypes.c_uint64 * 2)]
 
 
 class _Sizes(ctypes.Structure):
@@ -397,7 +397,8 @@ class Hash10x:
         c = _Counters()
         if self._ctx():
             self._hip.h10x_get_counters(self._ctx(), ctypes.byref(c))
-        out = {n: int(getattr(c, n)) for n, _ in _Counters._fields_ if n not in ("cluster_phase_ticks", "cluster_class_counts", "cluster_main")}
+        out = {n: int(getattr(c, n)) for n, _ in _Counters._fields_ if n not in ("cluster_phase_ticks", "cluster_class_counts", "cluster_main", "list_words")}
+        out["list_words"] = [int(x) for x in c.list_words]
         out["cluster_main"] = [int(x) for x in c.cluster_main]
         out["cluster_class_counts"] = [int(x) for x in c.cluster_class_counts]
         out["cluster_phase_ticks"] = [int(x) for x in c.cluster_phase_ticks]

@@ -207,6 +207,7 @@ struct Ctx {
                               // all-A-barcode quirk); set by the session layer for --readFQB
   std::vector<u64> mergePoints; bool replayDone = false;     // records whose barcode change does NOT start a block (chunk replay; consumed by stageA_run)
   int64_t optRowShift = -1;   // testing knob: force the list alignment of the sharded rows[] (-1 = as small as the offsets allow)
+  int64_t optDeltaLists = -1; // in-range barcode lists travel delta-coded between ranks: -1 = when there is more than one rank, 0 never, 1 always (tests)
   int64_t optRowsFakeBase = 0; // testing knob: list offsets start at this many entries (multiple of 2^rowShift) in front of the real array: 64-bit offsets on small inputs
   bool timing = false;
   u32 *startFlags = nullptr;   // pinned host words a side-stream kernel's workgroups set when they start (stageC_cluster)

@@ -425,6 +425,67 @@ __global__ void good_pack_kernel(const u32 *__restrict__ oIndex, const u32 *__re
     for (u32 j = threadIdx.x; j < n; j += blockDim.x) gRows[o + j] = oRows[s + j];
   }
 }
+// ---- delta-coded lists. A list is ascending global block numbers; between ranks it travels as 16-bit units: the first number in
+// two units, then one unit per further entry holding the step from its predecessor — n + 1 units instead of 2 n — unless some
+// step of the list does not fit 16 bits, in which case the list goes as it is. The mode is decided per list (no escape codes
+// inside a list: the receiver rebuilds the numbers with a wave-wide prefix sum), a list's coded length is rounded up to whole
+// 32-bit words, and (coded words | raw << 31) travels beside the list's index and padded length.
+__global__ __launch_bounds__(WAVE) void delta_len_kernel(const u32 *__restrict__ segStart, const u32 *__restrict__ oRows, const u32 *__restrict__ isGood, const u32 *__restrict__ pos, u32 U,
+                                                          u32 *__restrict__ encLen /* per distinct hash, 0 if not in range */, u32 *__restrict__ gEnc /* per in-range hash */) {
+  const int lane = threadIdx.x;
+  for (u32 d = blockIdx.x; d < U; d += gridDim.x) {
+    if (!isGood[d]) { if (lane == 0) encLen[d] = 0; continue; }
+    const u32 s = segStart[d], n = segStart[d + 1] - s;
+    bool wide = false;
+    for (u32 j = 1 + lane; j < n; j += WAVE) wide |= oRows[s + j] - oRows[s + j - 1] > 0xFFFFu;
+    const u32 raw = __builtin_amdgcn_ballot_w64(wide) ? 1u : 0u;
+    const u32 words = raw ? n : (n + 2) / 2;                 // n + 1 units of 16 bits
+    if (lane == 0) { encLen[d] = words; gEnc[pos[d]] = words | (raw << 31); }
+  }
+  if (blockIdx.x == 0 && lane == 0) encLen[U] = 0;
+}
+__global__ __launch_bounds__(WAVE) void delta_pack_kernel(const u32 *__restrict__ segStart, const u32 *__restrict__ oRows, const u32 *__restrict__ isGood, const u32 *__restrict__ pos,
+                                                           const u64 *__restrict__ encOff, const u32 *__restrict__ gEnc, u32 U, u32 *__restrict__ enc) {
+  const int lane = threadIdx.x;
+  for (u32 d = blockIdx.x; d < U; d += gridDim.x) {
+    if (!isGood[d]) continue;
+    const u32 s = segStart[d], n = segStart[d + 1] - s; u32 *out = enc + encOff[d];
+    if (gEnc[pos[d]] >> 31) { for (u32 j = lane; j < n; j += WAVE) out[j] = oRows[s + j]; continue; }
+    // word 0 = the first number; word m >= 1 = steps of entries 2m - 1 (low half) and 2m (high half, 0 past the end)
+    const u32 words = (n + 2) / 2;
+    for (u32 m = lane; m < words; m += WAVE) {
+      if (m == 0) { out[0] = oRows[s]; continue; }
+      const u32 j = 2 * m - 1;
+      const u32 lo = oRows[s + j] - oRows[s + j - 1], hi = j + 1 < n ? oRows[s + j + 1] - oRows[s + j] : 0u;
+      out[m] = lo | (hi << 16);
+    }
+  }
+}
+// receiver: list i of the concatenated streams -> rows at its (padded) offset
+__global__ __launch_bounds__(WAVE) void delta_unpack_kernel(const u32 *__restrict__ aIdx, const u32 *__restrict__ aEnc, const u64 *__restrict__ eOff, const u64 *__restrict__ aOff,
+                                                             const u32 *__restrict__ hashDepth, u64 nLists, const u32 *__restrict__ enc, u32 *__restrict__ rows) {
+  const int lane = threadIdx.x;
+  for (u64 i = blockIdx.x; i < nLists; i += gridDim.x) {
+    const u32 n = hashDepth[aIdx[i]]; const u32 *in = enc + eOff[i]; u32 *out = rows + aOff[i];
+    if (aEnc[i] >> 31) { for (u32 j = lane; j < n; j += WAVE) out[j] = in[j]; continue; }
+    u32 carry = in[0];                                       // value of the entry before this chunk's first step
+    if (lane == 0) out[0] = carry;
+    for (u32 j0 = 1; j0 < n; j0 += WAVE) {                  // entries j0 .. j0 + 63: step of entry j in unit j + 1
+      const u32 j = j0 + lane;
+      u32 step = 0;
+      if (j < n) { const u32 w = in[(j + 1) >> 1]; step = ((j + 1) & 1) ? (w >> 16) : (w & 0xFFFFu); }
+      u32 inc = step;
+#pragma unroll
+      for (int dd = 1; dd < WAVE; dd <<= 1) { const u32 o = (u32)__shfl_up((int)inc, dd); if (lane >= dd) inc += o; }
+      if (j < n) out[j] = carry + inc;
+      carry += (u32)__shfl((int)inc, WAVE - 1);
+    }
+  }
+}
+__global__ void coded_words_kernel(const u32 *__restrict__ aEnc, u64 n, u32 *__restrict__ words) {
+  u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; const u64 stride = (u64)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) words[i] = aEnc[i] & 0x7FFFFFFFu;
+}
 __global__ void row_start_kernel(const u32 *__restrict__ gIdx, const u64 *__restrict__ gOff, u64 n, u64 base, u64 *__restrict__ rowStart) {
   u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; const u64 stride = (u64)gridDim.x * blockDim.x;
   for (; i < n; i += stride) rowStart[gIdx[i]] = base + gOff[i];
@@ -472,12 +533,40 @@ int shard_exchangeRows(Ctx *c) {
   DevBuf<u32> aIdx, aLen; H10X_HIP(c, aIdx.alloc(nG)); H10X_HIP(c, aLen.alloc(nG + 1));
   H10X_TRY(cm->alltoallv(c, gIdx.p, sc.data(), so.data(), aIdx.p, rc.data(), ro.data(), 4));
   H10X_TRY(cm->alltoallv(c, gLen.p, sc.data(), so.data(), aLen.p, rc.data(), ro.data(), 4));
-  for (int r = 0; r < N; ++r) { sc[r] = mine[1]; rc[r] = all[2 * r + 1]; ro[r] = nR; nR += rc[r]; }
+  for (int r = 0; r < N; ++r) { rc[r] = all[2 * r + 1]; nR += rc[r]; }
   H10X_HIP(c, c->rows.alloc(nR));
-  H10X_TRY(cm->alltoallv(c, gRows.p, sc.data(), so.data(), c->rows.p, rc.data(), ro.data(), 4));
   DevBuf<u64> aOff; H10X_HIP(c, aOff.alloc(nG + 1));
   H10X_HIP(c, hipMemsetAsync(aLen.p + nG, 0, 4, st));
   H10X_TRY(prim_exclusive_scan_u32_u64(c, pt, aLen.p, aOff.p, nG + 1));
+  const bool delta = c->optDeltaLists > 0 || (c->optDeltaLists < 0 && N > 1);
+  if (!delta) {
+    nR = 0; for (int r = 0; r < N; ++r) { sc[r] = mine[1]; ro[r] = nR; nR += rc[r]; }
+    H10X_TRY(cm->alltoallv(c, gRows.p, sc.data(), so.data(), c->rows.p, rc.data(), ro.data(), 4));
+  } else {
+    // coded lengths, coded stream, the same allgather-shaped exchange, decode into the padded layout (see delta_len_kernel)
+    DevBuf<u32> encLen, gEnc, enc, aEnc, encAll, aWords; DevBuf<u64> encOff, eOff;
+    H10X_HIP(c, encLen.alloc((size_t)Uo + 1)); H10X_HIP(c, gEnc.alloc(mine[0])); H10X_HIP(c, encOff.alloc((size_t)Uo + 1));
+    delta_len_kernel<<<hmin<u32>(Uo + 1, 32768), WAVE, 0, st>>>(c->oSegStart.p, c->oRows.p, isGood.p, pos.p, Uo, encLen.p, gEnc.p);
+    H10X_TRY(prim_exclusive_scan_u32_u64(c, pt, encLen.p, encOff.p, (size_t)Uo + 1));
+    u64 encMine = 0; H10X_TRY(c->readback(&encMine, encOff.p + Uo, 8)); H10X_TRY(c->syncReadbacks());
+    std::vector<u64> encTot((size_t)N); H10X_TRY(cm->allgatherHost(c, &encMine, encTot.data(), 8));
+    H10X_HIP(c, enc.alloc(encMine));
+    if (Uo) delta_pack_kernel<<<hmin<u32>(Uo, 32768), WAVE, 0, st>>>(c->oSegStart.p, c->oRows.p, isGood.p, pos.p, encOff.p, gEnc.p, Uo, enc.p);
+    H10X_HIP(c, aEnc.alloc(nG + 1));
+    { u64 o = 0; for (int r = 0; r < N; ++r) { sc[r] = mine[0]; rc[r] = all[2 * r]; ro[r] = o; o += rc[r]; } }
+    H10X_TRY(cm->alltoallv(c, gEnc.p, sc.data(), so.data(), aEnc.p, rc.data(), ro.data(), 4));
+    u64 nE = 0; for (int r = 0; r < N; ++r) { sc[r] = encMine; rc[r] = encTot[r]; ro[r] = nE; nE += rc[r]; }
+    H10X_HIP(c, encAll.alloc(nE));
+    H10X_TRY(cm->alltoallv(c, enc.p, sc.data(), so.data(), encAll.p, rc.data(), ro.data(), 4));
+    H10X_HIP(c, eOff.alloc(nG + 1));
+    H10X_HIP(c, hipMemsetAsync(aEnc.p + nG, 0, 4, st));
+    H10X_HIP(c, aWords.alloc(nG + 1));
+    coded_words_kernel<<<gridFor(nG + 1), 256, 0, st>>>(aEnc.p, nG + 1, aWords.p);
+    H10X_TRY(prim_exclusive_scan_u32_u64(c, pt, aWords.p, eOff.p, nG + 1));
+    if (nG) delta_unpack_kernel<<<(unsigned)hmin<u64>(nG, 65535u * 2), WAVE, 0, st>>>(aIdx.p, aEnc.p, eOff.p, aOff.p, c->hashDepth.p, nG, encAll.p, c->rows.p);
+    c->ctr.list_words[0] = nR; c->ctr.list_words[1] = nE;
+    H10X_HIP(c, hipStreamSynchronize(st));                   // the coded buffers go out of scope
+  }
   H10X_HIP(c, c->rowStart.alloc((size_t)c->hashNumber + 1));
   H10X_HIP(c, hipMemsetAsync(c->rowStart.p, 0, ((size_t)c->hashNumber + 1) * 8, st));
   const u64 fakeAligned = (fake + pad) & ~(u64)pad;

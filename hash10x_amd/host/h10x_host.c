@@ -15,7 +15,7 @@
 #define ARRAY_MAGIC 8918274                            /* array.h:56 */
 typedef struct { int32_t magic, pad0; uint64_t base; int32_t dim, size, max, pad1; } array_hdr;   /* array.h:41-50 */
 
-enum { N_KNOBS = 13 };
+enum { N_KNOBS = 14 };
 struct h10x_session {
   int k, w, r, B, N, chunk, ct, device;                /* params (hash10x.c:25-33) */
   int timing;                                          /* measurement hook: enable hipEvent timers on every new context */
@@ -29,7 +29,7 @@ struct h10x_session {
   char err[1024];
 };
 static const char *const knobName[N_KNOBS] = {"cluster_stamps", "cluster_lds_budget", "cluster_first_global", "cluster_first_cap", "cluster_dbg_skip",
-                                              "cluster_big_ranks", "cluster_threads0", "cluster_budget0", "shard_row_shift", "shard_rows_fake_base", "stage_a_max_slots", "cluster_narrow_first", "index_no_pack"};
+                                              "cluster_big_ranks", "cluster_threads0", "cluster_budget0", "shard_row_shift", "shard_rows_fake_base", "stage_a_max_slots", "cluster_narrow_first", "index_no_pack", "shard_delta_lists"};
 
 static int fail(h10x_session *s, const char *fmt, ...) {
   va_list ap; va_start(ap, fmt); vsnprintf(s->err, sizeof s->err, fmt, ap); va_end(ap);
@@ -41,6 +41,7 @@ h10x_session *h10x_session_new(void) {
   h10x_session *s = (h10x_session *)calloc(1, sizeof *s);
   if (!s) return 0;
   s->k = 21; s->w = 31; s->r = 17; s->B = 28; s->N = 0; s->chunk = 100000; s->ct = 5; s->device = 0;
+  s->knob[13] = -1;                                    /* shard_delta_lists: delta-coded list exchange when there is more than one rank */
   s->knob[8] = -1;                                     /* shard_row_shift: as small as the offsets allow */
   s->blocksDim = 1200;                                 /* arrayCreate(1200, ClusterBlock), hash10x.c:1151 */
   return s;

@@ -267,6 +267,8 @@ typedef struct {
   uint64_t cluster_main[4];        /* work of the main cluster launch alone (timer "cluster_main"): good hashes, gathered list entries, nHash, barcodes */
   uint64_t cluster_phase_ticks[8]; /* diagnostic (option "cluster_stamps"): 100 MHz ticks per phase summed over workgroups:
                                       [0] init (+ bitmap), [1] list loop, [2] barrier, [3] replay, [4] quotient, [5] output */
+  uint64_t list_words[2];          /* sharded --hashDepthRange: 32-bit words of in-range barcode lists this rank received, [0] as plain
+                                      numbers, [1] as they travelled (delta-coded: option "shard_delta_lists"); 0 0 if sent plain */
 } h10x_counters;
 int  h10x_get_counters(h10x_ctx *ctx, h10x_counters *out);
 /* test / tuning knobs (none changes a result): "stage_a_max_slots" caps the LDS hash-set slots per barcode in stage A (0 =
@@ -276,7 +278,8 @@ int  h10x_get_counters(h10x_ctx *ctx, h10x_counters *out);
    costs no wave); "cluster_lds_budget", "cluster_first_global", "cluster_first_cap", "cluster_big_ranks", "cluster_threads0",
    "cluster_budget0" (placement and launch-class overrides of the tests), "cluster_stamps" (phase stamps into h10x_counters),
    "cluster_dbg_skip" (what-if timing switches, honoured only by a library built with -DH10X_DBG_SKIP: results are then wrong),
-   "shard_row_shift", "shard_rows_fake_base" (sharded list offsets beyond 32 bits on small inputs). Unknown name: -1. */
+   "shard_row_shift", "shard_rows_fake_base" (sharded list offsets beyond 32 bits on small inputs), "shard_delta_lists" (-1 default:
+   the in-range barcode lists travel delta-coded when there is more than one rank; 0 never; 1 always). Unknown name: -1. */
 int  h10x_set_option(h10x_ctx *ctx, const char *name, int64_t value);
 
 #ifdef __cplusplus

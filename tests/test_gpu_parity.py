@@ -305,6 +305,27 @@ def test_sharded_equals_single_gpu_and_oracle(workdir, nranks):
         assert open(workdir.file("hip2.hash"), "rb").read() == exp
 
 
+@pytest.mark.parametrize("nranks,delta", [(1, 1), (3, 0), (3, 1), (4, -1)])
+def test_sharded_lists_travel_delta_coded(workdir, nranks, delta):
+    """The in-range barcode lists go between ranks as 16-bit steps (a list with a step beyond 16 bits goes as it is): forced on one
+    rank, off and on with three, by default with four; the words received must be about half the plain ones where it is on."""
+    import hash10x_amd
+    orc.gen_fqb(workdir.file("x.fqb"), 60000, 300, 400000, 0.003, 43, 4.0, 150, 6000)
+    run_commands(lambda k, w, r, B: orc.Oracle(k, w, r, B), ["-B", 22, "-ct", 3, "--readFQB", "x.fqb", "--hashDepthRange", 4, 40, "--cluster", 1, 0, "--writeHash", "orc.hash"], workdir.path)
+    exp = open(workdir.file("orc.hash"), "rb").read()
+    recs = np.fromfile(workdir.file("x.fqb"), dtype=np.uint32)
+    words = {}
+    _run_sharded(recs, nranks, 22, 4, 40, 3, workdir.file("sh.hash"), opts=dict(shard_delta_lists=delta),
+                 after=lambda h, r: words.__setitem__(r, h.counters()["list_words"]))
+    got = open(workdir.file("sh.hash"), "rb").read()
+    assert got == exp, orc.describe_diff(got, exp)
+    plain, coded = words[0]
+    if delta == 0:
+        assert plain == 0 and coded == 0
+    else:
+        assert plain > 0 and 0.5 * plain <= coded <= 0.62 * plain, (plain, coded)
+
+
 @pytest.mark.parametrize("shift,fake", [(0, 1 << 32), (3, 0), (2, (7 << 32) + 4), (1, 1 << 35)])
 def test_sharded_list_offsets_beyond_32_bits(workdir, shift, fake):
     """BASELINE configs[3]/[4] hold more than 2^32 in-range list entries: cluster_kernel then keeps a list's offset as a 32-bit
