@@ -59,7 +59,7 @@ template <int PASS>
 __global__ __launch_bounds__(256)
 void owner_partition_kernel(const u64 *__restrict__ entHash, const u32 *__restrict__ entCode, const u64 *__restrict__ blockOff, u32 nBlocks,
                             const u64 *__restrict__ lowHash /* N+1 */, int N, u32 codeBase, u32 *__restrict__ cnt /* N x nBlocks: counts, then offsets */,
-                            u64 *__restrict__ sHash, u32 *__restrict__ sCode, u32 *__restrict__ perm) {
+                            u64 *__restrict__ sHash, u32 *__restrict__ sCode, u32 *__restrict__ perm, int cb /* > 0: key << cb | global block in sHash, no sCode */) {
   __shared__ u64 low[PART_MAX_OWNERS + 1];
   __shared__ u32 fill[PART_MAX_OWNERS];
   for (int o = threadIdx.x; o <= N; o += blockDim.x) low[o] = lowHash[o];
@@ -73,7 +73,7 @@ void owner_partition_kernel(const u64 *__restrict__ entHash, const u32 *__restri
       int lo = 0, hi = N;                                    // largest o with low[o] <= h
       while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (low[mid] <= h) lo = mid; else hi = mid; }
       const u32 pos = atomicAdd(&fill[lo], 1u);
-      if (PASS) { sHash[pos] = h; sCode[pos] = entCode[e] + codeBase; perm[pos] = (u32)e; }
+      if (PASS) { if (cb) sHash[pos] = (h << cb) | (u64)(entCode[e] + codeBase); else { sHash[pos] = h; sCode[pos] = entCode[e] + codeBase; } perm[pos] = (u32)e; }
     }
     if (!PASS) { __syncthreads(); for (int o = threadIdx.x; o < N; o += blockDim.x) cnt[(size_t)o * nBlocks + b] = fill[o]; }
   }
@@ -100,12 +100,18 @@ __global__ void heads_kernel(const u64 *__restrict__ sHash, u64 n, u32 *__restri
   u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; const u64 stride = (u64)gridDim.x * blockDim.x;
   for (; i < n; i += stride) flags[i] = (i == 0 || sHash[i] != sHash[i - 1]) ? 1u : 0u;
 }
+// the same from packed entries (key << cb | global block), which also yields the owner's barcode lists
+__global__ void heads_packed_kernel(const u64 *__restrict__ sKey, int cb, u64 n, u32 *__restrict__ flags, u32 *__restrict__ rows) {
+  u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; const u64 stride = (u64)gridDim.x * blockDim.x;
+  const u64 cmask = ((u64)1 << cb) - 1;
+  for (; i < n; i += stride) { const u64 k = sKey[i]; flags[i] = (i == 0 || (k >> cb) != (sKey[i - 1] >> cb)) ? 1u : 0u; rows[i] = (u32)(k & cmask); }
+}
 __global__ void owner_distinct_kernel(const u64 *__restrict__ sHash, const u32 *__restrict__ rows, const u32 *__restrict__ flags, const u32 *__restrict__ ord,
-                                      u64 n, u64 *__restrict__ dHash, u32 *__restrict__ dFirst, u32 *__restrict__ segStart, u32 *__restrict__ iota) {
+                                      u64 n, u64 *__restrict__ dHash, u32 *__restrict__ dFirst, u32 *__restrict__ segStart, u32 *__restrict__ iota, int cb /* packed entries */) {
   u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; const u64 stride = (u64)gridDim.x * blockDim.x;
   for (; i < n; i += stride) if (flags[i]) {
     const u32 d = ord[i];
-    dHash[d] = sHash[i]; dFirst[d] = rows[i]; segStart[d] = (u32)i; iota[d] = d;   // stable sort => rows[i] is the lowest barcode of the hash
+    dHash[d] = sHash[i] >> cb; dFirst[d] = rows[i]; segStart[d] = (u32)i; iota[d] = d;   // stable sort => rows[i] is the lowest barcode of the hash
   }
 }
 // per barcode f: where its run starts in the distinct hashes sorted by first barcode, and how long it is (counting the
@@ -215,8 +221,12 @@ int shard_readFqb(Ctx *c, Comm *cm, const u32 *dRec, u64 nRec) {
   // ---- 2. my entries by hash owner, each owner's part in block = barcode order (owner_partition_kernel; the owners sort by
   //         hash anyway)
   c->tstart(T_SORT_HASH);
+  // key and global block number of an entry in ONE word where they fit (as in the single-GPU index build, common.hpp: 63 bits): 8
+  // instead of 12 bytes per entry on the wire, and the owner's barcode lists fall out of the sorted keys without a gather
+  int cbG = 1; while (cbG < 32 && ((nB - 1) >> cbG)) ++cbG;
+  const int pk = (!c->optNoPack && N <= PART_MAX_OWNERS && c->keyBits + cbG <= 63) ? cbG : 0;
   DevBuf<u64> sHash; DevBuf<u32> perm, sCodeG;
-  H10X_HIP(c, sHash.alloc(H)); H10X_HIP(c, perm.alloc(H)); H10X_HIP(c, sCodeG.alloc(H));
+  H10X_HIP(c, sHash.alloc(H)); H10X_HIP(c, perm.alloc(H)); if (!pk) H10X_HIP(c, sCodeG.alloc(H));
   std::vector<u64> lowHash((size_t)N + 1), bound((size_t)N + 1);
   // (the entries hold hash / w, Ctx::keyInv: the owner ranges are cut in that space)
   const u64 nKeys = ((2 * k >= 64 ? ~0ULL : ((u64)1 << (2 * k)) - 1) / (u64)c->prm.w) + 1;
@@ -228,9 +238,9 @@ int shard_readFqb(Ctx *c, Comm *cm, const u32 *dRec, u64 nRec) {
     DevBuf<u32> cnt, off; H10X_HIP(c, cnt.alloc(cells + 1)); H10X_HIP(c, off.alloc(cells + 1));
     H10X_HIP(c, hipMemsetAsync(cnt.p, 0, (cells + 1) * 4, st));                  // block 0 (unused) and the sentinel stay 0
     const unsigned grid = hmin<u32>(nBl, 16384);
-    if (H) owner_partition_kernel<0><<<grid, 256, 0, st>>>(entHash.p, entCode.p, c->blockOff.p, nBl, dLow.p, N, c->codeBase, cnt.p, nullptr, nullptr, nullptr);
+    if (H) owner_partition_kernel<0><<<grid, 256, 0, st>>>(entHash.p, entCode.p, c->blockOff.p, nBl, dLow.p, N, c->codeBase, cnt.p, nullptr, nullptr, nullptr, 0);
     H10X_TRY(prim_exclusive_scan_u32(c, pt, cnt.p, off.p, cells + 1));
-    if (H) owner_partition_kernel<1><<<grid, 256, 0, st>>>(entHash.p, entCode.p, c->blockOff.p, nBl, dLow.p, N, c->codeBase, off.p, sHash.p, sCodeG.p, perm.p);
+    if (H) owner_partition_kernel<1><<<grid, 256, 0, st>>>(entHash.p, entCode.p, c->blockOff.p, nBl, dLow.p, N, c->codeBase, off.p, sHash.p, sCodeG.p, perm.p, pk);
     partition_bounds_kernel<<<divUp((u64)N + 1, 256), 256, 0, st>>>(off.p, nBl, N, H, dBound.p);
     H10X_TRY(c->readback(bound.data(), dBound.p, ((size_t)N + 1) * 8));
     H10X_TRY(c->syncReadbacks());
@@ -250,21 +260,22 @@ int shard_readFqb(Ctx *c, Comm *cm, const u32 *dRec, u64 nRec) {
   for (int r = 0; r < N; ++r) { recvCnt[r] = matrix[(size_t)r * N + me]; recvOff[r] = M; M += recvCnt[r]; }
   if (M >= (1ULL << 32)) return c->fail("%llu entries land on hash owner %d: over this build's 2^32 limit", (u64)M, me);
   DevBuf<u64> rHash; DevBuf<u32> rCode;
-  H10X_HIP(c, rHash.alloc(M)); H10X_HIP(c, rCode.alloc(M));
+  H10X_HIP(c, rHash.alloc(M)); if (!pk) H10X_HIP(c, rCode.alloc(M));
   H10X_TRY(cm->alltoallv(c, sHash.p, sendCnt.data(), sendOff.data(), rHash.p, recvCnt.data(), recvOff.data(), 8));
-  H10X_TRY(cm->alltoallv(c, sCodeG.p, sendCnt.data(), sendOff.data(), rCode.p, recvCnt.data(), recvOff.data(), 4));
+  if (!pk) H10X_TRY(cm->alltoallv(c, sCodeG.p, sendCnt.data(), sendOff.data(), rCode.p, recvCnt.data(), recvOff.data(), 4));
   sHash.release(); sCodeG.release();
 
   // ---- 3. owner side: received runs are in rank (= barcode) order, a stable sort by hash keeps barcodes ascending
   DevBuf<u64> oHash; DevBuf<u32> oQ; H10X_HIP(c, oHash.alloc(M)); H10X_HIP(c, oQ.alloc(M));
   { DevBuf<u32> qio; H10X_HIP(c, qio.alloc(M)); if (M) iota_kernel<<<gridFor(M), 256, 0, st>>>(qio.p, M);
-    H10X_TRY(prim_sort_pairs_u64_u32(c, pt, rHash.p, oHash.p, qio.p, oQ.p, M, 0, c->keyBits)); H10X_HIP(c, hipStreamSynchronize(st)); }
+    H10X_TRY(prim_sort_pairs_u64_u32(c, pt, rHash.p, oHash.p, qio.p, oQ.p, M, pk, pk + c->keyBits)); H10X_HIP(c, hipStreamSynchronize(st)); }
   H10X_HIP(c, c->oRows.alloc(M));
-  if (M) gather_u32_kernel<<<gridFor(M), 256, 0, st>>>(rCode.p, oQ.p, M, c->oRows.p);
+  if (M && !pk) gather_u32_kernel<<<gridFor(M), 256, 0, st>>>(rCode.p, oQ.p, M, c->oRows.p);
   c->tstop(T_SORT_HASH);
   c->tstart(T_RANK);
   DevBuf<u32> flags, ord; H10X_HIP(c, flags.alloc(M + 1)); H10X_HIP(c, ord.alloc(M + 1));
-  if (M) heads_kernel<<<gridFor(M), 256, 0, st>>>(oHash.p, M, flags.p);
+  if (M && pk) heads_packed_kernel<<<gridFor(M), 256, 0, st>>>(oHash.p, pk, M, flags.p, c->oRows.p);
+  else if (M) heads_kernel<<<gridFor(M), 256, 0, st>>>(oHash.p, M, flags.p);
   H10X_HIP(c, hipMemsetAsync(flags.p + M, 0, 4, st));
   H10X_TRY(prim_exclusive_scan_u32(c, pt, flags.p, ord.p, M + 1));
   u32 Uo = 0;
@@ -273,7 +284,7 @@ int shard_readFqb(Ctx *c, Comm *cm, const u32 *dRec, u64 nRec) {
   DevBuf<u64> dHash; DevBuf<u32> dFirst, dio, cntFirst;
   H10X_HIP(c, dHash.alloc(Uo)); H10X_HIP(c, dFirst.alloc(Uo)); H10X_HIP(c, c->oSegStart.alloc((size_t)Uo + 1)); H10X_HIP(c, dio.alloc(Uo));
   H10X_HIP(c, cntFirst.alloc(nB));
-  if (M) owner_distinct_kernel<<<gridFor(M), 256, 0, st>>>(oHash.p, c->oRows.p, flags.p, ord.p, M, dHash.p, dFirst.p, c->oSegStart.p, dio.p);
+  if (M) owner_distinct_kernel<<<gridFor(M), 256, 0, st>>>(oHash.p, c->oRows.p, flags.p, ord.p, M, dHash.p, dFirst.p, c->oSegStart.p, dio.p, pk);
   H10X_HIP(c, hipMemsetD32Async((hipDeviceptr_t)(c->oSegStart.p + Uo), (int)(u32)M, 1, st));          // end of the last segment
 
   // ---- 4. numbering: index = 1 + #(hashes first seen in an earlier barcode) + #(same barcode, smaller hash);
@@ -415,14 +426,20 @@ __global__ void pad_len_kernel(u32 *__restrict__ len, u32 n, u32 pad) {
   const u32 d = blockIdx.x * blockDim.x + threadIdx.x;
   if (d < n) len[d] = (len[d] + pad) & ~pad;
 }
-__global__ void good_pack_kernel(const u32 *__restrict__ oIndex, const u32 *__restrict__ segStart, const u32 *__restrict__ oRows, const u32 *__restrict__ isGood,
-                                 const u32 *__restrict__ pos, const u64 *__restrict__ off, const u32 *__restrict__ padLen, u32 U,
+// (the in-range hashes are a small part of an owner's distinct hashes — one in ten at yeast scale: the kernels that handle their
+// lists walk goodId[], the in-range ordinals in ascending order, not all U hashes)
+__global__ void good_ids_kernel(const u32 *__restrict__ isGood, const u32 *__restrict__ pos, u32 U, u32 *__restrict__ goodId) {
+  const u32 d = blockIdx.x * blockDim.x + threadIdx.x;
+  if (d < U && isGood[d]) goodId[pos[d]] = d;
+}
+__global__ void good_pack_kernel(const u32 *__restrict__ oIndex, const u32 *__restrict__ segStart, const u32 *__restrict__ oRows, const u32 *__restrict__ goodId, u32 nGood,
+                                 const u64 *__restrict__ off, const u32 *__restrict__ padLen, bool copyRows,
                                  u32 *__restrict__ gIdx, u32 *__restrict__ gLen, u32 *__restrict__ gRows) {
-  for (u32 d = blockIdx.x; d < U; d += gridDim.x) {
-    if (!isGood[d]) continue;
+  for (u32 g = blockIdx.x; g < nGood; g += gridDim.x) {
+    const u32 d = goodId[g];
     const u32 s = segStart[d], n = segStart[d + 1] - s; const u64 o = off[d];
-    if (threadIdx.x == 0) { gIdx[pos[d]] = oIndex[d]; gLen[pos[d]] = padLen[d]; }
-    for (u32 j = threadIdx.x; j < n; j += blockDim.x) gRows[o + j] = oRows[s + j];
+    if (threadIdx.x == 0) { gIdx[g] = oIndex[d]; gLen[g] = padLen[d]; }
+    if (copyRows) for (u32 j = threadIdx.x; j < n; j += blockDim.x) gRows[o + j] = oRows[s + j];
   }
 }
 // ---- delta-coded lists. A list is ascending global block numbers; between ranks it travels as 16-bit units: the first number in
@@ -430,27 +447,27 @@ __global__ void good_pack_kernel(const u32 *__restrict__ oIndex, const u32 *__re
 // step of the list does not fit 16 bits, in which case the list goes as it is. The mode is decided per list (no escape codes
 // inside a list: the receiver rebuilds the numbers with a wave-wide prefix sum), a list's coded length is rounded up to whole
 // 32-bit words, and (coded words | raw << 31) travels beside the list's index and padded length.
-__global__ __launch_bounds__(WAVE) void delta_len_kernel(const u32 *__restrict__ segStart, const u32 *__restrict__ oRows, const u32 *__restrict__ isGood, const u32 *__restrict__ pos, u32 U,
-                                                          u32 *__restrict__ encLen /* per distinct hash, 0 if not in range */, u32 *__restrict__ gEnc /* per in-range hash */) {
+__global__ __launch_bounds__(WAVE) void delta_len_kernel(const u32 *__restrict__ segStart, const u32 *__restrict__ oRows, const u32 *__restrict__ goodId, u32 nGood,
+                                                          u32 *__restrict__ encLen /* per in-range hash, + a closing 0 */, u32 *__restrict__ gEnc /* the same | raw << 31 */) {
   const int lane = threadIdx.x;
-  for (u32 d = blockIdx.x; d < U; d += gridDim.x) {
-    if (!isGood[d]) { if (lane == 0) encLen[d] = 0; continue; }
+  for (u32 g = blockIdx.x; g < nGood; g += gridDim.x) {
+    const u32 d = goodId[g];
     const u32 s = segStart[d], n = segStart[d + 1] - s;
     bool wide = false;
     for (u32 j = 1 + lane; j < n; j += WAVE) wide |= oRows[s + j] - oRows[s + j - 1] > 0xFFFFu;
     const u32 raw = __builtin_amdgcn_ballot_w64(wide) ? 1u : 0u;
     const u32 words = raw ? n : (n + 2) / 2;                 // n + 1 units of 16 bits
-    if (lane == 0) { encLen[d] = words; gEnc[pos[d]] = words | (raw << 31); }
+    if (lane == 0) { encLen[g] = words; gEnc[g] = words | (raw << 31); }
   }
-  if (blockIdx.x == 0 && lane == 0) encLen[U] = 0;
+  if (blockIdx.x == 0 && lane == 0) encLen[nGood] = 0;
 }
-__global__ __launch_bounds__(WAVE) void delta_pack_kernel(const u32 *__restrict__ segStart, const u32 *__restrict__ oRows, const u32 *__restrict__ isGood, const u32 *__restrict__ pos,
-                                                           const u64 *__restrict__ encOff, const u32 *__restrict__ gEnc, u32 U, u32 *__restrict__ enc) {
+__global__ __launch_bounds__(WAVE) void delta_pack_kernel(const u32 *__restrict__ segStart, const u32 *__restrict__ oRows, const u32 *__restrict__ goodId, u32 nGood,
+                                                           const u64 *__restrict__ encOff, const u32 *__restrict__ gEnc, u32 *__restrict__ enc) {
   const int lane = threadIdx.x;
-  for (u32 d = blockIdx.x; d < U; d += gridDim.x) {
-    if (!isGood[d]) continue;
-    const u32 s = segStart[d], n = segStart[d + 1] - s; u32 *out = enc + encOff[d];
-    if (gEnc[pos[d]] >> 31) { for (u32 j = lane; j < n; j += WAVE) out[j] = oRows[s + j]; continue; }
+  for (u32 g = blockIdx.x; g < nGood; g += gridDim.x) {
+    const u32 d = goodId[g];
+    const u32 s = segStart[d], n = segStart[d + 1] - s; u32 *out = enc + encOff[g];
+    if (gEnc[g] >> 31) { for (u32 j = lane; j < n; j += WAVE) out[j] = oRows[s + j]; continue; }
     // word 0 = the first number; word m >= 1 = steps of entries 2m - 1 (low half) and 2m (high half, 0 past the end)
     const u32 words = (n + 2) / 2;
     for (u32 m = lane; m < words; m += WAVE) {
@@ -525,9 +542,12 @@ int shard_exchangeRows(Ctx *c) {
     H10X_TRY(c->syncReadbacks());
     H10X_TRY(cm->allgatherHost(c, mine, all.data(), 16));
   }
-  DevBuf<u32> gIdx, gLen, gRows;
-  H10X_HIP(c, gIdx.alloc(mine[0])); H10X_HIP(c, gLen.alloc(mine[0])); H10X_HIP(c, gRows.alloc(mine[1]));
-  if (Uo) good_pack_kernel<<<hmin<u32>(Uo, 16384), 64, 0, st>>>(c->oIndex.p, c->oSegStart.p, c->oRows.p, isGood.p, pos.p, off.p, len.p, Uo, gIdx.p, gLen.p, gRows.p);
+  const bool delta = c->optDeltaLists > 0 || (c->optDeltaLists < 0 && N > 1);
+  const u32 nGoodU = (u32)mine[0];
+  DevBuf<u32> gIdx, gLen, gRows, goodId;
+  H10X_HIP(c, gIdx.alloc(mine[0])); H10X_HIP(c, gLen.alloc(mine[0])); H10X_HIP(c, goodId.alloc(mine[0])); if (!delta) H10X_HIP(c, gRows.alloc(mine[1]));
+  if (Uo) good_ids_kernel<<<divUp(Uo, 256), 256, 0, st>>>(isGood.p, pos.p, Uo, goodId.p);
+  if (nGoodU) good_pack_kernel<<<hmin<u32>(nGoodU, 65535u * 2), 64, 0, st>>>(c->oIndex.p, c->oSegStart.p, c->oRows.p, goodId.p, nGoodU, off.p, len.p, !delta, gIdx.p, gLen.p, gRows.p);
   std::vector<u64> sc((size_t)N), so((size_t)N, 0), rc((size_t)N), ro((size_t)N); u64 nG = 0, nR = 0;
   for (int r = 0; r < N; ++r) { sc[r] = mine[0]; rc[r] = all[2 * r]; ro[r] = nG; nG += rc[r]; }
   DevBuf<u32> aIdx, aLen; H10X_HIP(c, aIdx.alloc(nG)); H10X_HIP(c, aLen.alloc(nG + 1));
@@ -538,20 +558,19 @@ int shard_exchangeRows(Ctx *c) {
   DevBuf<u64> aOff; H10X_HIP(c, aOff.alloc(nG + 1));
   H10X_HIP(c, hipMemsetAsync(aLen.p + nG, 0, 4, st));
   H10X_TRY(prim_exclusive_scan_u32_u64(c, pt, aLen.p, aOff.p, nG + 1));
-  const bool delta = c->optDeltaLists > 0 || (c->optDeltaLists < 0 && N > 1);
   if (!delta) {
     nR = 0; for (int r = 0; r < N; ++r) { sc[r] = mine[1]; ro[r] = nR; nR += rc[r]; }
     H10X_TRY(cm->alltoallv(c, gRows.p, sc.data(), so.data(), c->rows.p, rc.data(), ro.data(), 4));
   } else {
     // coded lengths, coded stream, the same allgather-shaped exchange, decode into the padded layout (see delta_len_kernel)
     DevBuf<u32> encLen, gEnc, enc, aEnc, encAll, aWords; DevBuf<u64> encOff, eOff;
-    H10X_HIP(c, encLen.alloc((size_t)Uo + 1)); H10X_HIP(c, gEnc.alloc(mine[0])); H10X_HIP(c, encOff.alloc((size_t)Uo + 1));
-    delta_len_kernel<<<hmin<u32>(Uo + 1, 32768), WAVE, 0, st>>>(c->oSegStart.p, c->oRows.p, isGood.p, pos.p, Uo, encLen.p, gEnc.p);
-    H10X_TRY(prim_exclusive_scan_u32_u64(c, pt, encLen.p, encOff.p, (size_t)Uo + 1));
-    u64 encMine = 0; H10X_TRY(c->readback(&encMine, encOff.p + Uo, 8)); H10X_TRY(c->syncReadbacks());
+    H10X_HIP(c, encLen.alloc((size_t)nGoodU + 1)); H10X_HIP(c, gEnc.alloc(mine[0])); H10X_HIP(c, encOff.alloc((size_t)nGoodU + 1));
+    delta_len_kernel<<<hmin<u32>(nGoodU + 1, 65535u * 2), WAVE, 0, st>>>(c->oSegStart.p, c->oRows.p, goodId.p, nGoodU, encLen.p, gEnc.p);
+    H10X_TRY(prim_exclusive_scan_u32_u64(c, pt, encLen.p, encOff.p, (size_t)nGoodU + 1));
+    u64 encMine = 0; H10X_TRY(c->readback(&encMine, encOff.p + nGoodU, 8)); H10X_TRY(c->syncReadbacks());
     std::vector<u64> encTot((size_t)N); H10X_TRY(cm->allgatherHost(c, &encMine, encTot.data(), 8));
     H10X_HIP(c, enc.alloc(encMine));
-    if (Uo) delta_pack_kernel<<<hmin<u32>(Uo, 32768), WAVE, 0, st>>>(c->oSegStart.p, c->oRows.p, isGood.p, pos.p, encOff.p, gEnc.p, Uo, enc.p);
+    if (nGoodU) delta_pack_kernel<<<hmin<u32>(nGoodU, 65535u * 2), WAVE, 0, st>>>(c->oSegStart.p, c->oRows.p, goodId.p, nGoodU, encOff.p, gEnc.p, enc.p);
     H10X_HIP(c, aEnc.alloc(nG + 1));
     { u64 o = 0; for (int r = 0; r < N; ++r) { sc[r] = mine[0]; rc[r] = all[2 * r]; ro[r] = o; o += rc[r]; } }
     H10X_TRY(cm->alltoallv(c, gEnc.p, sc.data(), so.data(), aEnc.p, rc.data(), ro.data(), 4));
