@@ -610,17 +610,27 @@ __device__ void cluster_one_block(const ClusterArgs &a, u32 code, unsigned char 
   if constexpr (RANKED) {
     // ---- (0) which barcodes occur in this block's lists: presence bitmap, per-word popcount prefix, and a first[] sized by
     // the number present. More present than the table holds => the block is handed to the HBM-slot variant.
-    // four lists per wave in flight (their first chunks are requested together); most entries meet a bit that is already
+    // eight lists per wave in flight (their chunks are requested together); most entries meet a bit that is already
     // set: look before the atomic (LDS atomics cost per active lane)
     auto mark = [&](u32 cj) { if (cj != code) { const u32 bit = 1u << (cj & 31); if (!(*(volatile u32 *)&w.bm[cj >> 5] & bit)) atomicOr(&w.bm[cj >> 5], bit); } };
-    for (u32 i0 = 1 + wave * 4; i0 < n; i0 += CL_WAVES * 4) {
-      u32 c0[4], d4[4];
+    // (both chunks of the four lists are requested together: met one list at a time, the second chunk — most lists have one where the
+    // depth range reaches 100 and the lists are long — was a load waited for per list: a third of the launch on the 1/10 config-3 set)
+    constexpr int BIF = 8;                                   // lists in flight per wave in this pass (few live registers here)
+    for (u32 i0 = 1 + wave * BIF; i0 < n; i0 += CL_WAVES * BIF) {
+      u32 c0[BIF], c1[BIF], d4[BIF];
 #pragma unroll
-      for (int t = 0; t < 4; ++t) { const u32 i = i0 + t; d4[t] = i < n ? (u32)w.dd[i] : 0; c0[t] = (u32)lane < d4[t] ? ROWP(w.rs[i < n ? i : n - 1])[lane] : code; }
+      for (int t = 0; t < BIF; ++t) {
+        const u32 i = i0 + t; d4[t] = i < n ? (u32)w.dd[i] : 0;
+        const u32 *row = ROWP(w.rs[i < n ? i : n - 1]);
+        c0[t] = (u32)lane < d4[t] ? row[lane] : code; c1[t] = (u32)(WAVE + lane) < d4[t] ? row[WAVE + lane] : code;
+      }
 #pragma unroll
-      for (int t = 0; t < 4; ++t) {
+      for (int t = 0; t < BIF; ++t) {
         mark(c0[t]);
-        if (d4[t] > WAVE) { const u32 *row = ROWP(w.rs[i0 + t]); for (u32 j = WAVE + lane; j < d4[t]; j += WAVE) mark(row[j]); }
+        if (d4[t] > WAVE) {
+          mark(c1[t]);
+          if (d4[t] > 2 * WAVE) { const u32 *row = ROWP(w.rs[i0 + t]); for (u32 j = 2 * WAVE + lane; j < d4[t]; j += WAVE) mark(row[j]); }
+        }
       }
     }
     SYNC();
@@ -824,20 +834,22 @@ __device__ void cluster_one_block(const ClusterArgs &a, u32 code, unsigned char 
     SYNC();
     const u32 nTodo = sh[2];
     for (u32 k0 = wave * RIF; k0 < nTodo; k0 += CL_WAVES * RIF) {
-      u32 ii[RIF], cj[RIF], dl[RIF], qv[RIF];
+      u32 ii[RIF], cj[RIF], cjB[RIF], dl[RIF], qv[RIF];
 #pragma unroll
       for (int t = 0; t < RIF; ++t) {
         const bool on = k0 + t < nTodo;
         ii[t] = on ? (u32)ld_shared<IN_LDS>(&todo[k0 + t]) : 0u;
         qv[t] = on ? (u32)w.qj[ii[t]] : NONE16; dl[t] = on ? (u32)w.dd[ii[t]] : 0u;
-        cj[t] = (u32)lane < dl[t] ? ROWP(w.rs[ii[t]])[lane] : code;
+        const u32 *row = ROWP(w.rs[ii[t]]);
+        cj[t] = (u32)lane < dl[t] ? row[lane] : code; cjB[t] = (u32)(WAVE + lane) < dl[t] ? row[WAVE + lane] : code;   // both chunks up front
       }
 #pragma unroll
       for (int t = 0; t < RIF; ++t) {
         if (dl[t] == 0) continue;
         const u32 i = ii[t];
         u32 q = (u32)__popcll(__ballot(cj[t] != code && ft.lookup(cj[t]) == qv[t]));
-        if (dl[t] > WAVE) { const u32 *row = ROWP(w.rs[i]); for (u32 b0 = WAVE; b0 < dl[t]; b0 += WAVE) { bool m = false; if (b0 + lane < dl[t]) { const u32 c2 = row[b0 + lane]; m = c2 != code && ft.lookup(c2) == qv[t]; } q += (u32)__popcll(__ballot(m)); } }
+        if (dl[t] > WAVE) q += (u32)__popcll(__ballot(cjB[t] != code && ft.lookup(cjB[t]) == qv[t]));
+        if (dl[t] > 2 * WAVE) { const u32 *row = ROWP(w.rs[i]); for (u32 b0 = 2 * WAVE; b0 < dl[t]; b0 += WAVE) { bool m = false; if (b0 + lane < dl[t]) { const u32 c2 = row[b0 + lane]; m = c2 != code && ft.lookup(c2) == qv[t]; } q += (u32)__popcll(__ballot(m)); } }
         if (lane == 0) w.cnt[i] = (CT)q;
       }
     }
