@@ -395,7 +395,8 @@ struct FirstHashed {
   __device__ __forceinline__ void split(u32 cj, u32 &home, u32 &tag) const {
     const u32 q = (cj * SCRAMBLE) & bmask;
     tag = __umulhi(q, recip); home = q - tag * NB;
-    if (home >= NB) { if ((int)home < 0) { --tag; home += NB; } else { ++tag; home -= NB; } }   // recip is rounded up: off by one at most
+    const bool neg = (int)home < 0, big = !neg && home >= NB;                                     // recip is rounded up: off by one at most; no branch
+    tag += big ? 1u : (neg ? ~0u : 0u); home += neg ? NB : (big ? 0u - NB : 0u);
   }
   __device__ __forceinline__ u32 update(u32 cj, u32 i) const {
     u32 home, tag; split(cj, home, tag);
@@ -404,9 +405,12 @@ struct FirstHashed {
       const u32 key = (d << 10) | tag, mine = (i << 16) | key;
       const uint4 e4 = *(const uint4 *)&tab[4 * b];
       const u32 e[4] = {e4.x, e4.y, e4.z, e4.w};
+      // already here? (the usual case after a barcode's first list: no branch per word — an empty word's low half, displacement 63 with
+      // tag 1023, is no key)
+      u32 hit = 4, eh = 0;
 #pragma unroll
-      for (int w = 0; w < 4; ++w)                            // already here?
-        if ((e[w] & 0xFFFFu) == key && e[w] != 0xFFFFFFFFu) { if ((e[w] >> 16) > i) atomicMin(&tab[4 * b + w], mine); return 4 * b + w; }
+      for (int w = 3; w >= 0; --w) { const bool m = (e[w] & 0xFFFFu) == key; hit = m ? (u32)w : hit; eh = m ? e[w] : eh; }
+      if (hit < 4) { if ((eh >> 16) > i) atomicMin(&tab[4 * b + hit], mine); return 4 * b + hit; }
 #pragma unroll
       for (int w = 0; w < 4; ++w)                            // first empty word, in order: every inserter of a barcode walks the same words
         if (e[w] == 0xFFFFFFFFu) {
@@ -429,7 +433,7 @@ struct FirstHashed {
       const u32 e[4] = {e4.x, e4.y, e4.z, e4.w};
       bool hole = false; u32 r = NONE16;
 #pragma unroll
-      for (int w = 0; w < 4; ++w) { if (e[w] == 0xFFFFFFFFu) hole = true; else if ((e[w] & 0xFFFFu) == key) r = e[w] >> 16; }
+      for (int w = 0; w < 4; ++w) { hole |= e[w] == 0xFFFFFFFFu; r = (e[w] & 0xFFFFu) == key ? e[w] >> 16 : r; }   // (an empty word's low half is no key)
       if (r != NONE16 || hole) return r;                     // a bucket with a hole ends every search that reaches it
       if (++b == NB) b = 0;
     }
@@ -547,7 +551,7 @@ __device__ void cluster_one_block(const ClusterArgs &a, u32 code, unsigned char 
   // the ranked / hashed lookup: fewer registers spilled is worth more there than the deeper prefetch (8x set: 52.8 -> 41.4 ms);
   // and 2 for the hashed placement in every class: with 4 its list loop unrolls to 61 KB of code (the compiler then keeps
   // the block function out of line) against 42 KB — 300 k-barcode set: 0.533 -> 0.507 s
-  constexpr int RIF = ((KLASS == 0 && CL_THREADS == 1024 && FIRST_MODE == 1) || FIRST_MODE == 3) ? 2 : ROWS_IN_FLIGHT;
+  constexpr int RIF = ((KLASS == 0 && CL_THREADS == 1024 && FIRST_MODE == 1) || (FIRST_MODE == 3 && KLASS == 0)) ? 2 : ROWS_IN_FLIGHT;
   typedef typename std::conditional<IN_LDS, u16, u32>::type CT;
   const int tid = threadIdx.x, lane = tid & (WAVE - 1), wave = tid / WAVE;
   const u32 n = a.nGood[code];
