@@ -64,7 +64,9 @@ static int *param_slot(h10x_session *s, const char *n) {
 }
 int h10x_session_set(h10x_session *s, const char *name, int value) {
   int *p = param_slot(s, name); if (!p) return fail(s, "unknown parameter %s", name);
-  *p = value; return 0;
+  *p = value;
+  if (s->ctx && p >= s->knob && p < s->knob + N_KNOBS && h10x_set_option(s->ctx, name, value)) return fail_ctx(s);   /* a knob reaches a live context at once */
+  return 0;
 }
 int h10x_session_get(const h10x_session *s, const char *name) {
   int *p = param_slot((h10x_session *)s, name); return p ? *p : 0;

@@ -18,6 +18,7 @@ def _beat():                                                  # gpurun kills a r
 threading.Thread(target=_beat, daemon=True).start()
 t = time.time(); recs = bench.generate(wl, 2); print("generated %d pairs in %.1fs" % (recs.size // 30, time.time() - t), flush=True)
 h = hash10x_amd.Hash10x(B=wl["B"]); h.enable_timing(True)
+if os.environ.get("H10X_FIRST_GLOBAL"): h.set_option("cluster_first_global", int(os.environ["H10X_FIRST_GLOBAL"]))   # placement override (2 ranked, 3 hashed)
 t = time.time(); dr = hash10x_amd.DeviceRecords(recs); print("uploaded %.1f GB in %.1fs" % (recs.nbytes / 1e9, time.time() - t), flush=True)
 del recs
 digests = []
