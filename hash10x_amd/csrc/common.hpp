@@ -166,6 +166,7 @@ struct Ctx {
   DevBuf<u8>  within;         // hashNumber
   DevBuf<u16> goodPos;        // H : per block [blockOff[c], blockOff[c]+nGood[c])
   DevBuf<u32> nGood;          // nBlocks
+  DevBuf<u64> goodRow;        // H : per good hash of a block, in rank order: (offset of its barcode list in rows[] >> rowShift, its length) — stage_c.hip good_rows_kernel
   DevBuf<u32> goodEntries;    // nBlocks : sum of the depths of a block's good hashes = entries of its barcode lists
   bool haveRange = false, haveGood = false; int rangeMin = 0, rangeMax = 0;
   u32 rangeHiMax = 0;             // largest upper limit of the ranges set so far: an in-range depth is below it

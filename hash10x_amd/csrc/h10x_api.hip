@@ -97,7 +97,7 @@ const char *h10x_last_error(const h10x_ctx *h) { return h ? h->c.err.c_str() : "
 
 static void reset_state(Ctx &c) {
   c.haveState = false; c.haveRange = false; c.haveGood = false; c.rangeMin = c.rangeMax = 0; c.depthBound = 0xFFFFFFFFu; c.rangeHiMax = 0;
-  c.within.release(); c.goodPos.release(); c.nGood.release(); c.goodEntries.release();
+  c.within.release(); c.goodPos.release(); c.nGood.release(); c.goodEntries.release(); c.goodRow.release();
   c.hashNumber = 1; c.nBlocks = 0; c.nEntries = 0; c.nRecords = 0; c.maxBlockHashes = 0xFFFFFFFFu;
   c.sharded = false; c.codeBase = 0; c.nBlocksGlobal = 0; c.oRows.release(); c.oSegStart.release(); c.oIndex.release(); c.oU = 0; c.oM = 0;
   c.oHash.release(); c.tablesPending = false;

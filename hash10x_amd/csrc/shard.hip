@@ -833,7 +833,7 @@ int shard_gather(Ctx *c) {
     H10X_HIP(c, hipStreamSynchronize(st));
     c->sharded = false; c->codeBase = 0; c->haveGood = false;  // a full, unsharded state from here on (good lists were per shard)
     c->maxBlockHashes = 0xFFFFFFFFu;                           // other ranks' blocks: unknown
-    c->goodPos.release(); c->nGood.release(); c->goodEntries.release();
+    c->goodPos.release(); c->nGood.release(); c->goodEntries.release(); c->goodRow.release();
     c->segs.n = 1; c->segs.s[0] = BlockSeg{0, c->nBlocks, 0}; c->rowShift = 0; c->optRowsFakeBase = 0; c->allSegs.clear();
     c->oRows.release(); c->oSegStart.release(); c->oIndex.release(); c->oU = 0; c->oM = 0;
     H10X_TRY(stageB_buildCSR(c));                            // the barcode lists of the gathered state (fillHashTable)

@@ -108,7 +108,8 @@ template <int THREADS, int IPT, typename WT>
 __global__ __launch_bounds__(THREADS)
 void good_block_kernel(const h10x_clushash *__restrict__ ch, const u64 *__restrict__ blockOff, const h10x_block *__restrict__ blocks, u32 nBlocks,
                        const WT *__restrict__ wdepth /* 0 = not in range, else depth + 1 */, int sortBits,
-                       u16 *__restrict__ goodPos, u32 *__restrict__ nGood, u32 *__restrict__ entries /* sum of depths, saturating */) {
+                       u16 *__restrict__ goodPos, u32 *__restrict__ nGood, u32 *__restrict__ entries /* sum of depths, saturating */,
+                       const u64 *__restrict__ rowStart, u32 rowShift, u64 *__restrict__ goodRow /* list descriptor per rank: see good_rows_kernel */) {
   using Sort = rocprim::block_radix_sort<u32, THREADS, IPT, u32>;
   __shared__ typename Sort::storage_type storage;
   __shared__ u32 sCount; __shared__ unsigned long long sDepth;
@@ -136,11 +137,21 @@ void good_block_kernel(const h10x_clushash *__restrict__ ch, const u64 *__restri
     __syncthreads();
     const u32 nG = sCount;
 #pragma unroll
-    for (int j = 0; j < IPT; ++j) { const u32 e = (u32)j * THREADS + threadIdx.x; if (e < nG) goodPos[o + e] = (u16)v[j]; }   // striped: coalesced stores
+    for (int j = 0; j < IPT; ++j) {                          // striped: coalesced stores
+      const u32 e = (u32)j * THREADS + threadIdx.x;
+      if (e < nG) {
+        goodPos[o + e] = (u16)v[j];
+        // where the rank's barcode list lies and how long it is (the sort key IS the depth): the cluster kernel streams these
+        // instead of gathering position -> hash index -> offset, depth per barcode
+        goodRow[o + e] = (u64)(u32)(rowStart[ch[o + v[j]].hash] >> rowShift) | ((u64)k[j] << 32);
+      }
+    }
     if (threadIdx.x == 0) { nGood[c] = nG; entries[c] = sDepth > 0xFFFFFFFFull ? 0xFFFFFFFFu : (u32)sDepth; }
   }
 }
 
+__global__ void good_rows_kernel(const h10x_clushash *__restrict__ ch, const u64 *__restrict__ blockOff, const u32 *__restrict__ nGood, const u16 *__restrict__ goodPos, u32 nBlocks,
+                                 const u32 *__restrict__ hashDepth, const u64 *__restrict__ rowStart, u32 rowShift, u64 *__restrict__ goodRow);
 static int bitsForC(u64 maxValue) { int b = 1; while (b < 64 && (maxValue >> b)) ++b; return b; }
 
 int stageC_depthRange(Ctx *c, int lo, int hi) {
@@ -154,11 +165,14 @@ int stageC_depthRange(Ctx *c, int lo, int hi) {
     c->haveRange = true; c->rangeMin = lo; c->rangeMax = hi;
     if (hi > 0 && (u32)hi > c->rangeHiMax) c->rangeHiMax = (u32)hi;
   }
+  // sharded: the barcode lists of the in-range hashes come from their owners first (they depend on the ranges alone), so that
+  // the good lists below can point into them
+  if (c->sharded) { c->tstop(T_GOOD); H10X_TRY(shard_exchangeRows(c)); c->tstart(T_GOOD); }
   // goodHashesBuild (hash10x.c:738-766)
   DevBuf<u64> key, keyS; DevBuf<u32> key32, keyS32, off32, segEnd, wdepth, red;
   H10X_HIP(c, off32.alloc((size_t)nBlocks + 1));
   H10X_HIP(c, segEnd.alloc(nBlocks)); H10X_HIP(c, wdepth.alloc(U1)); H10X_HIP(c, red.alloc(2));
-  H10X_HIP(c, c->nGood.alloc(nBlocks)); H10X_HIP(c, c->goodPos.alloc(H)); H10X_HIP(c, c->goodEntries.alloc(nBlocks));
+  H10X_HIP(c, c->nGood.alloc(nBlocks)); H10X_HIP(c, c->goodPos.alloc(H)); H10X_HIP(c, c->goodEntries.alloc(nBlocks)); H10X_HIP(c, c->goodRow.alloc(H));
   // no in-range depth exceeds this, known without a round trip: the data set's barcode count (Ctx::depthBound) or the ranges' limit
   const u32 goodDepthBound = hmin<u32>(c->depthBound, c->rangeHiMax ? c->rangeHiMax - 1 : 0);
   const bool narrow = goodDepthBound <= 65535u;
@@ -173,8 +187,8 @@ int stageC_depthRange(Ctx *c, int lo, int hi) {
     const int side = c->maxBlockHashes > BLOCK_SORT_CAP1 ? 2 : (c->maxBlockHashes > BLOCK_SORT_CAP0 ? 1 : 0);
     if (side) H10X_TRY(c->forkStreams(side));
 #define H10X_GOOD_LAUNCH(T, I, STREAM)                                                                                              \
-    { if (wdepth8.p) good_block_kernel<T, I, u8><<<grid, T, 0, STREAM>>>(c->clusHash.p, c->blockOff.p, c->blocks.p, nBlocks, wdepth8.p, sortBits, c->goodPos.p, c->nGood.p, c->goodEntries.p); \
-      else good_block_kernel<T, I, u32><<<grid, T, 0, STREAM>>>(c->clusHash.p, c->blockOff.p, c->blocks.p, nBlocks, wdepth.p, sortBits, c->goodPos.p, c->nGood.p, c->goodEntries.p); }
+    { if (wdepth8.p) good_block_kernel<T, I, u8><<<grid, T, 0, STREAM>>>(c->clusHash.p, c->blockOff.p, c->blocks.p, nBlocks, wdepth8.p, sortBits, c->goodPos.p, c->nGood.p, c->goodEntries.p, c->rowStart.p, (u32)c->rowShift, c->goodRow.p); \
+      else good_block_kernel<T, I, u32><<<grid, T, 0, STREAM>>>(c->clusHash.p, c->blockOff.p, c->blocks.p, nBlocks, wdepth.p, sortBits, c->goodPos.p, c->nGood.p, c->goodEntries.p, c->rowStart.p, (u32)c->rowShift, c->goodRow.p); }
     H10X_GOOD_LAUNCH(256, 12, st)
     if (side >= 1) H10X_GOOD_LAUNCH(512, 12, c->aux[0])
     if (side >= 2) H10X_GOOD_LAUNCH(1024, 8, c->aux[1])
@@ -207,10 +221,12 @@ int stageC_depthRange(Ctx *c, int lo, int hi) {
       good_pos_kernel<u64><<<(unsigned)hmin<u64>(divUp(H, 256), 65535u * 2), 256, 0, st>>>(keyS.p, H, c->goodPos.p);
     }
   }
+  // list descriptors per good hash, in rank order: written by good_block_kernel; the device-wide sort path adds them here
+  if (!byBlocks && nBlocks) good_rows_kernel<<<hmin<u32>(nBlocks, 65535u * 4), 256, 0, st>>>(c->clusHash.p, c->blockOff.p, c->nGood.p, c->goodPos.p, nBlocks, c->hashDepth.p, c->rowStart.p,
+                                                                                           (u32)c->rowShift, c->goodRow.p);
   H10X_HIP(c, hipGetLastError());                            // (no round trip here: --cluster, the next command, starts with one)
   c->haveGood = true;
   c->tstop(T_GOOD);
-  if (c->sharded) H10X_TRY(shard_exchangeRows(c));           // barcode lists of the in-range hashes, from their owners
   return 0;
 }
 
@@ -218,7 +234,8 @@ int stageC_depthRange(Ctx *c, int lo, int hi) {
 struct ClusterArgs {
   h10x_block *blocks; const u64 *blockOff; h10x_clushash *clusHash;
   const u16 *goodPos; const u32 *nGood;
-  const u32 *hashDepth; const u64 *rowStart; const u32 *rows;
+  const u64 *goodRow;                                       // per rank (slice of block c at blockOff[c]): low word = list offset in rows[] (>> rowShift), high word = list length = hashDepth
+  const u32 *rows;
   const u32 *list; u32 nList; u32 *workCounter;
   u32 *started;                 // host-visible word per workgroup, set when the workgroup starts (whole-CU class only)
   const u32 *front; u32 nFront;                             // handed out before list[]: the largest barcodes of the launch
@@ -233,39 +250,40 @@ struct ClusterArgs {
   unsigned char *scratch; size_t scratchStride;             // global-mode working set per workgroup
   u32 maxGood;
   u32 ldsBudget;                                            // LDS bytes of the launch class (list loop: as many waves as have room for a histogram)
-  double *term;                                             // per rank (slice of block c at blockOff[c]): its pointToMin term, 0.0 if none
+  u64 *res;                                                 // out, per rank (slice of block c at blockOff[c]): RES_PACK(msBest or NONE16 if msMax < threshold,
+                                                            // minShareCount[clusterMin], msTot) — replay_kernel turns it into the rank's pointToMin term in place
   u64 *stats;                                               // [0] sum good, [1] sum good depth, [2] sum nHash, [3] codes
   u64 *phase;                                               // diagnostic per-phase ticks (null = off)
   u32 narrowFirst;                                          // test / A-B knob: keep first[] at 2 bytes per entry in every block
-  u32 dbgSkip;                                              // diagnostic what-if timing (results are WRONG): 1 no first[] update, 2 no mode, 4 no phase (d), 8 no barrier
+  u32 dbgSkip;                                              // diagnostic what-if timing (results are WRONG): 1 no first[] update, 2 no mode, 4 no pending pass, 8 no barrier
 };
 
-// working set layout inside a region (LDS or HBM scratch). CT = type of the per-rank counts and list lengths:
-// u16 in the LDS instantiations (the driver sends every barcode to the HBM-scratch class when a list of the
-// depth range is longer than 65535), u32 on the HBM scratch.
-template <typename CT> struct Work {
+// Working set of the list loop inside a region (LDS or HBM scratch). Since round 3 the per-rank arrays of the reference's
+// bookkeeping (list offset and length, msMax, msTot, msBest, label: 15 bytes per rank) are gone from it: the list
+// descriptors are read from goodRow[] (built once per --hashDepthRange), what a rank contributes to pointToMin is read off
+// the list's histogram in the list loop itself and written to HBM in one word per rank, and the order-dependent labelling
+// runs in a kernel of its own (replay_kernel) from those words. What a block keeps on chip is first[], 2 bytes per rank
+// and one byte-histogram per wave.
+// one word per rank: bits 0-15 msBest of an active rank (NONE16: inactive), 16-39 minShareCount[clusterMin[label]], 40-63 msTot (hash10x.c:803-821)
+#define RES_PACK(best, q, tot) ((u64)(best) | ((u64)(q) << 16) | ((u64)(tot) << 40))
+constexpr u32 RES_COUNT_MAX = (1u << 24) - 1;               // list lengths beyond this do not fit the word: refused by stageC_cluster
+struct Work {
   u16 *first;        // NONE16 = unseen; indexed by barcode (dense) or by the barcode's rank among those present (ranked)
   u32 *bm; u16 *pre; // ranked placement: presence bitmap over all barcodes and its exclusive popcount prefix per word (< 65536 present)
-  u32 *rs;           // offset of the rank's barcode list in rows[] (prefetched once)
-  CT  *dd;           // its length (hashDepth)
-  CT  *cnt, *tot;    // msMax / msTot per rank; cnt later holds minShareCount[clusterMin] (phase d)
-  u16 *best;         // msBest per rank
-  u16 *qj;           // founding rank of the cluster the rank joins (NONE16 = no term)
-  u8  *lab;          // label per rank
+  u16 *root;         // founding rank of the cluster the rank joins (clusterMin[label], hash10x.c:819-821): the rank itself while it is
+                     // inactive; NONE16 = active but not known yet (its msBest belongs to the same round: settled after the loop)
   u32 *hist;         // CL_WAVES private byte-histograms over ranks (4 counters per word), all zero between lists
   u32 histWords;     // words per wave
 };
-__host__ __device__ inline size_t workBytes(u32 nFirst, u32 n, u32 nWaves, u32 bmWords, u32 ctBytes) {
-  size_t b = (((size_t)nFirst * 2 + 15) & ~(size_t)15) + (((size_t)bmWords * 4 + 15) & ~(size_t)15) + (((size_t)bmWords * 2 + 15) & ~(size_t)15);
-  b += ((size_t)n * 4 + 15) & ~(size_t)15;                  // rs (padded: rs and dd are read RIF ranks at a time)
-  b += (((size_t)n * ctBytes + 3) & ~(size_t)3) * 3;        // dd, cnt, tot
-  b += (((size_t)n * 2 + 3) & ~(size_t)3) * 2;              // best, qj
-  b += ((size_t)n + 15) & ~(size_t)15;                      // lab
-  b += (size_t)nWaves * (((size_t)n + 3) / 4) * 4;          // hist (the replay's temporaries, 4 n + 8 bytes, overlay it: nWaves >= 8)
+__host__ __device__ inline size_t pad16(size_t b) { return (b + 15) & ~(size_t)15; }
+__host__ __device__ inline size_t workBytes(u32 nFirst, u32 n, u32 nWaves, u32 bmWords) {
+  size_t b = pad16((size_t)nFirst * 2) + pad16((size_t)bmWords * 4) + pad16((size_t)bmWords * 2);
+  b += pad16((size_t)n * 2);                                // root
+  b += (size_t)nWaves * (((size_t)n + 3) / 4) * 4;          // hist (the list of unsettled ranks, 2 n bytes at most, overlays it after the loop: nWaves >= 5)
   return b + 16;
 }
 // waves of the workgroup that take part in the list loop of a barcode with n ranks: as many as have room for a private
-// histogram in what the fixed part leaves of `budget` (0 = does not fit; the replay's temporaries need >= MIN_HIST_WAVES)
+// histogram in what the fixed part leaves of `budget` (0 = does not fit)
 constexpr u32 MIN_HIST_WAVES = 5;
 constexpr u32 RANKED_FIRST_PER_RANK = 6;                    // ranked placement: first[] entries budgeted per rank when a block is classified
                                                            // (3-7 barcodes present per rank on the synthetic sets); the kernel then takes
@@ -276,8 +294,8 @@ __host__ __device__ inline u32 rankedFirstEstimate(u32 nBarcodes, u32 n) { const
 // sets, more on deeper ones), whichever is larger. Erring low is cheap: the ranked kernel knows the true number right
 // after its bitmap pass and hands the block on before the list loop.
 __host__ __device__ inline u32 rankedFirstEstimateE(u32 nBarcodes, u32 n, u32 entries) { const u32 a = rankedFirstEstimate(nBarcodes, n), b = entries / 7; const u32 m = a > b ? a : b; return m < nBarcodes ? m : nBarcodes; }
-__host__ __device__ inline u32 histWaves(u32 nFirst, u32 n, u32 maxWaves, u32 bmWords, u32 ctBytes, size_t budget) {
-  const size_t fixed = workBytes(nFirst, n, 0, bmWords, ctBytes), per = (((size_t)n + 3) / 4) * 4;
+__host__ __device__ inline u32 histWaves(u32 nFirst, u32 n, u32 maxWaves, u32 bmWords, size_t budget) {
+  const size_t fixed = workBytes(nFirst, n, 0, bmWords), per = (((size_t)n + 3) / 4) * 4;
   if (fixed + MIN_HIST_WAVES * per > budget) return 0;
   const size_t wv = (budget - fixed) / (per ? per : 1);
   return wv < maxWaves ? (u32)wv : maxWaves;
@@ -292,12 +310,12 @@ constexpr u32 HASHED_MIN_SLOTS = 1024, HASHED_MAX_SLOTS = 1u << 16;
 #define H10X_HASHED_WANT_PCT 150
 #endif
 __host__ __device__ inline u32 hashedWant(u32 est) { return (u32)(((u64)est * H10X_HASHED_WANT_PCT) / 100); }   // slots asked for per barcode expected in the table
-__host__ __device__ inline void hashedShape(u32 n, u32 maxWaves, u32 ctBytes, size_t budget, u32 minSlots, u32 want, u32 &nW, u32 &slots) {
+__host__ __device__ inline void hashedShape(u32 n, u32 maxWaves, size_t budget, u32 minSlots, u32 want, u32 &nW, u32 &slots) {
   const u32 tryW[3] = {maxWaves, maxWaves < 8 ? maxWaves : 8, MIN_HIST_WAVES};
   const size_t need = minSlots > HASHED_MIN_SLOTS ? minSlots : HASHED_MIN_SLOTS;
   nW = 0; slots = 0;
   for (int t = 0; t < 3; ++t) {
-    const size_t used = workBytes(0, n, tryW[t], 0, ctBytes) + 32;
+    const size_t used = workBytes(0, n, tryW[t], 0) + 32;
     if (used >= budget) continue;
     size_t sl = (budget - used) / 4; if (sl > HASHED_MAX_SLOTS) sl = HASHED_MAX_SLOTS;
     if (sl < need) continue;
@@ -305,20 +323,12 @@ __host__ __device__ inline void hashedShape(u32 n, u32 maxWaves, u32 ctBytes, si
     if (sl >= want) return;
   }
 }
-template <typename CT>
-__device__ inline Work<CT> carve(unsigned char *base, u32 nFirst, u32 n, u32 bmWords = 0) {
-  Work<CT> w; size_t o = 0;
-  const size_t ctb = ((size_t)n * sizeof(CT) + 3) & ~(size_t)3, b2 = ((size_t)n * 2 + 3) & ~(size_t)3;
-  w.first = (u16 *)(base + o); o += (((size_t)nFirst * 2 + 15) & ~(size_t)15);
-  w.bm = (u32 *)(base + o); o += ((size_t)bmWords * 4 + 15) & ~(size_t)15;
-  w.pre = (u16 *)(base + o); o += ((size_t)bmWords * 2 + 15) & ~(size_t)15;
-  w.rs = (u32 *)(base + o); o += ((size_t)n * 4 + 15) & ~(size_t)15;
-  w.dd = (CT *)(base + o); o += ctb;
-  w.cnt = (CT *)(base + o); o += ctb;
-  w.tot = (CT *)(base + o); o += ctb;
-  w.best = (u16 *)(base + o); o += b2;
-  w.qj = (u16 *)(base + o); o += b2;
-  w.lab = (u8 *)(base + o); o += ((size_t)n + 15) & ~(size_t)15;
+__device__ inline Work carve(unsigned char *base, u32 nFirst, u32 n, u32 bmWords = 0) {
+  Work w; size_t o = 0;
+  w.first = (u16 *)(base + o); o += pad16((size_t)nFirst * 2);
+  w.bm = (u32 *)(base + o); o += pad16((size_t)bmWords * 4);
+  w.pre = (u16 *)(base + o); o += pad16((size_t)bmWords * 2);
+  w.root = (u16 *)(base + o); o += pad16((size_t)n * 2);
   w.hist = (u32 *)(base + o); w.histWords = (n + 3) / 4;
   return w;
 }
@@ -460,9 +470,14 @@ __device__ __forceinline__ u32 wave_max_u32(u32 v) {
 // last at a value sees its full count, so a DPP wave max over (arrival count, lowest rank) is the mode —
 // one LDS round trip for the gather, one for the atomics. Lists with fewer usable entries than the
 // threshold are skipped (only "msMax < threshold" matters to the caller then).
+// Round 3: while the histogram of the list still stands, an active rank (msMax >= threshold) also reads from it what the
+// reference adds to pointToMin for it (hash10x.c:821): minShareCount[clusterMin[label]] = the count of the founding rank of
+// the cluster it joins, rb = root[msBest] — known as soon as msBest's own round is over, i.e. for all but the few ranks
+// whose msBest lies in the round being processed (rb = NONE16: settled after the loop). The second gather of round 2's
+// phase (d) is gone for the rest, and with it the need to keep msMax / msTot per rank on chip.
 template <bool IN_LDS, int RCHUNK, typename FT>
 __device__ __forceinline__ void row_mode_hist(const u32 *__restrict__ row, u32 h0, u32 h1 /* handles of entries lane, 64 + lane; NOHANDLE = none */, u32 d, u32 code, u32 i, const FT &ft, u32 *hist,
-                                              u32 thr, u32 &best, u32 &bcnt, u32 &tot) {
+                                              const u16 *root, u32 thr, u32 &best, u32 &bcnt, u32 &tot, u32 &rb, u32 &q) {
   const int lane = threadIdx.x & (WAVE - 1);
   u32 f[RCHUNK]; bool ok[RCHUNK];
   tot = 0;
@@ -476,7 +491,7 @@ __device__ __forceinline__ void row_mode_hist(const u32 *__restrict__ row, u32 h
       tot += (u32)__popcll(__ballot(ok[r]));
     }
   }
-  best = NONE16; bcnt = 0;
+  best = NONE16; bcnt = 0; rb = NONE16; q = 0;
   // lists of up to two chunks (nearly all) run straight through: a list with fewer usable entries than the threshold then
   // counts and clears its few values for nothing, which is cheaper than two branches per list (2.41 -> 2.36 ms)
   if (RCHUNK > 2 && tot < thr) return;
@@ -489,18 +504,35 @@ __device__ __forceinline__ void row_mode_hist(const u32 *__restrict__ row, u32 h
       const u32 k = (c << 16) | (0xFFFFu - f[r]);
       key = k > key ? k : key;
     }
+  // no value reached the threshold (most long lists): the caller only tests msMax >= threshold (hash10x.c:807), so the
+  // wave reduction is skipped and the rank is reported inactive
+  if (!(RCHUNK > 2) || __builtin_amdgcn_ballot_w64((key >> 16) >= thr)) {
+    key = wave_max_u32(key);
+    bcnt = key >> 16;
+    best = key ? 0xFFFFu - (key & 0xFFFFu) : NONE16;
+    if (bcnt >= thr) {                                       // wave-uniform (readlane result)
+      rb = ld_shared<IN_LDS>(&root[best]);
+      if (rb != NONE16) q = (ld_shared<IN_LDS>(&hist[rb >> 2]) >> ((rb & 3) * 8)) & 0xFFu;
+    }
+  }
 #pragma unroll
   for (int r = 0; r < RCHUNK; ++r)
     if ((u32)(r * WAVE) < d && ok[r]) {
       if (IN_LDS) hist[f[r] >> 2] = 0;                       // ds ops of a wave stay in order
       else atomicAnd(&hist[f[r] >> 2], 0u);                  // HBM scratch: a plain store could be overtaken by the next list's atomics
     }
-  // no value reached the threshold (most lists): the caller only tests msMax >= threshold (hash10x.c:807), so the
-  // wave reduction is skipped and the rank is reported inactive
-  if (RCHUNK > 2 && !__builtin_amdgcn_ballot_w64((key >> 16) >= thr)) return;
-  key = wave_max_u32(key);
-  bcnt = key >> 16;
-  best = key ? 0xFFFFu - (key & 0xFFFFu) : NONE16;
+}
+// entries of a list whose first[] value equals v (and, in tot, those below i): one wavefront, any length
+template <typename FT>
+__device__ __forceinline__ u32 row_count_value(const u32 *__restrict__ row, u32 d, u32 code, u32 i, const FT &ft, u32 v, u32 &tot) {
+  const int lane = threadIdx.x & (WAVE - 1);
+  u32 q = 0; tot = 0;
+  for (u32 b0 = 0; b0 < d; b0 += WAVE) {
+    u32 f = NONE16;
+    if (b0 + lane < d) { const u32 cj = row[b0 + lane]; if (cj != code) f = ft.lookup(cj); }
+    q += (u32)__popcll(__ballot(f == v && v != NONE16)); tot += (u32)__popcll(__ballot(f < i));
+  }
+  return q;
 }
 // lists of 256 entries and more (exotic depth ranges): re-gather per candidate
 template <typename FT>
@@ -544,6 +576,19 @@ __device__ void row_mode_long(const u32 *__restrict__ row, u32 d, u32 code, u32 
 // flight (a full __syncthreads() drains vmcnt too). The HBM-scratch instantiation keeps the full barrier + L1 drop.
 #define SYNC_LDS() do { if (IN_LDS) { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); } else SYNC(); } while (0)
 
+// The list descriptors of a block (goodRow[]) travel in ONE vector register per round, one list per LANE: lane t of a wave
+// loads the offset and lane 32 + t the length of the wave's t-th list of a round (one load instruction for all of them,
+// three rounds ahead), and the scalars a list's loads and loops need are taken from those lanes with v_readlane when they
+// are needed — no LDS array and no init pass, and no scalar register holds a descriptor across rounds (scalar registers
+// are what this kernel spills).
+struct Desc { u32 x /* list offset in rows[] >> rowShift */, y /* list length */; };
+__device__ __forceinline__ Desc descLane(u32 v, int t) { Desc d; d.x = (u32)__builtin_amdgcn_readlane((int)v, t); d.y = (u32)__builtin_amdgcn_readlane((int)v, 32 + t); return d; }
+// lane t < nLists: low word of the descriptor of rank i0 + t, lane 32 + t: its high word; 0 for rank 0 and past the last rank
+__device__ __forceinline__ u32 descLoad(const u64 *gr, u32 i0, u32 nLists, u32 n) {
+  const u32 lane = threadIdx.x & (WAVE - 1), t = lane & 31, i = i0 + t;
+  return (t < nLists && i >= 1 && i < n) ? ((const u32 *)gr)[2 * (size_t)i + (lane >> 5)] : 0u;
+}
+
 template <bool IN_LDS, int FIRST_MODE /* 0 dense in LDS, 1 ranked in LDS, 2 dense on an HBM slot, 3 hashed in LDS */, int CL_THREADS, int KLASS>
 __device__ void cluster_one_block(const ClusterArgs &a, u32 code, unsigned char *region, u16 *firstGlobal, u32 *sh /* small shared ints */, u64 (&acc)[4]) {   // code: local block number
   constexpr int CL_WAVES = CL_THREADS / WAVE;
@@ -552,9 +597,9 @@ __device__ void cluster_one_block(const ClusterArgs &a, u32 code, unsigned char 
   // and 2 for the hashed placement in every class: with 4 its list loop unrolls to 61 KB of code (the compiler then keeps
   // the block function out of line) against 42 KB — 300 k-barcode set: 0.533 -> 0.507 s
   constexpr int RIF = ((KLASS == 0 && CL_THREADS == 1024 && FIRST_MODE == 1) || (FIRST_MODE == 3 && KLASS == 0)) ? 2 : ROWS_IN_FLIGHT;
-  typedef typename std::conditional<IN_LDS, u16, u32>::type CT;
   const int tid = threadIdx.x, lane = tid & (WAVE - 1), wave = tid / WAVE;
-  const u32 n = a.nGood[code];
+  code = (u32)__builtin_amdgcn_readfirstlane((int)code);     // (the block number reaches every lane through LDS: say that it is uniform)
+  const u32 n = (u32)__builtin_amdgcn_readfirstlane((int)a.nGood[code]);
   if (n == 0) return;                                        // hash10x.c:780: block left untouched
   const u64 o = a.blockOff[code];
   constexpr bool FIRST_LDS = IN_LDS && FIRST_MODE != 2;
@@ -562,29 +607,29 @@ __device__ void cluster_one_block(const ClusterArgs &a, u32 code, unsigned char 
   constexpr bool HASHED = IN_LDS && FIRST_MODE == 3;
   const u32 bmWords = RANKED ? (a.nBlocksFirst + 31) / 32 : 0;
   // list-loop waves: all of them where the histograms fit, fewer for a barcode with many ranks (one kernel and one
-  // work queue then serve nearly every barcode; the rest of the phases always use the whole workgroup)
+  // work queue then serve nearly every barcode; the phases behind the loop always use the whole workgroup)
   u32 nW, slots = 0;
   if constexpr (HASHED) {
     const u32 want = hashedWant(rankedFirstEstimateE(a.nBlocksFirst, n, a.entries[code]));
-    hashedShape(n, CL_WAVES, sizeof(CT), a.ldsBudget, a.hashMinSlots, want, nW, slots);
+    hashedShape(n, CL_WAVES, a.ldsBudget, a.hashMinSlots, want, nW, slots);
     if (a.firstCap && slots > a.firstCap) slots = a.firstCap;                  // test knob: small tables, to exercise the overflow chain
     if (!nW || !slots) {                                     // cannot hold this barcode at all: hand it on
       if (tid == 0) a.overflow[atomicAdd(a.overflowCount, 1u)] = code;
       return;
     }
   } else if constexpr (RANKED) nW = 0;                       // ranked placement: decided once the bitmap pass has counted the barcodes present
-  else nW = IN_LDS ? histWaves(FIRST_LDS ? a.nBlocksFirst : 0, n, CL_WAVES, bmWords, sizeof(CT), a.ldsBudget) : (u32)CL_WAVES;
+  else nW = IN_LDS ? histWaves(FIRST_LDS ? a.nBlocksFirst : 0, n, CL_WAVES, bmWords, a.ldsBudget) : (u32)CL_WAVES;
   if (!RANKED && !nW) return;                                // cannot happen: the classification sends such a barcode to the HBM-scratch class
   // dense placement in LDS: 4-byte entries where that costs the list loop no wave (see FirstDense)
   bool wideFirst = false;
   if (FIRST_LDS && !RANKED && !HASHED && a.narrowFirst != 1) {
-    const u32 nW4 = histWaves(2 * a.nBlocksFirst, n, CL_WAVES, bmWords, sizeof(CT), a.ldsBudget);
+    const u32 nW4 = histWaves(2 * a.nBlocksFirst, n, CL_WAVES, bmWords, a.ldsBudget);
     wideFirst = nW4 >= nW || (a.narrowFirst >= 2 && nW4 >= a.narrowFirst);   // (A/B: accept down to narrowFirst waves)
     if (wideFirst) nW = nW4;
   }
   // ranked placement: first[] lies BEHIND the histograms and both are laid out after the bitmap pass, when the number of
   // barcodes present is known: the list loop then runs on as many waves as what is left of the budget has room for
-  Work<CT> w = carve<CT>(region, HASHED ? 2 * slots : (RANKED ? 0 : (FIRST_LDS || !IN_LDS ? (wideFirst ? 2 * a.nBlocksFirst : a.nBlocksFirst) : 0)), n, bmWords);
+  Work w = carve(region, HASHED ? 2 * slots : (RANKED ? 0 : (FIRST_LDS || !IN_LDS ? (wideFirst ? 2 * a.nBlocksFirst : a.nBlocksFirst) : 0)), n, bmWords);
   if (IN_LDS && FIRST_MODE == 2) w.first = firstGlobal;      // hybrid: first[] on this workgroup's HBM slot, the rest in LDS
   typename std::conditional<HASHED, FirstHashed, typename std::conditional<RANKED, FirstRanked, FirstDense<FIRST_LDS>>::type>::type ft{};
   if constexpr (HASHED) { slots &= ~3u; ft.tab = (u32 *)w.first; ft.NB = slots / 4; ft.recip = (u32)((0x100000000ULL + ft.NB - 1) / ft.NB); ft.bmask = a.hashMask; ft.ovf = &sh[2]; }
@@ -593,10 +638,12 @@ __device__ void cluster_one_block(const ClusterArgs &a, u32 code, unsigned char 
   const u32 lcode = code; code = a.segs.globalOf(lcode);     // from here on `code` is the global barcode number (what the lists hold)
   const u32 rsh = a.rowShift;
 #define ROWP(rs) (a.rows + ((size_t)(rs) << rsh))
-  h10x_clushash *ch = a.clusHash + o; const u16 *g = a.goodPos + o;
+  const u64 *const gr = a.goodRow + o;
+  u64 *const res = a.res + o;
+  const u32 thr = (u32)a.threshold;
 
   u64 tPrev = a.phase ? wall_clock64() : 0;
-  // ---- init: prefetch every rank's list offset/length once
+  // ---- init: clear the tables; nothing is fetched per rank any more
   if (FIRST_LDS && !RANKED) {
     if (wideFirst) for (u32 i = tid; i < a.nBlocksFirst; i += CL_THREADS) ((u32 *)w.first)[i] = NONE16;
     else for (u32 i = tid; i < (HASHED ? slots : (a.nBlocksFirst + 1) / 2); i += CL_THREADS) ((u32 *)w.first)[i] = 0xFFFFFFFFu;
@@ -604,28 +651,33 @@ __device__ void cluster_one_block(const ClusterArgs &a, u32 code, unsigned char 
   if (HASHED && tid == 0) sh[2] = 0;
   if (RANKED) for (u32 i = tid; i < bmWords; i += CL_THREADS) w.bm[i] = 0;
   if (!RANKED) for (u32 i = tid; i < nW * w.histWords; i += CL_THREADS) w.hist[i] = 0;
-  u64 myDepth = 0;
-  for (u32 i = tid; i < n; i += CL_THREADS) {
-    const u32 x = ch[g[i]].hash; const u32 d = a.hashDepth[x];
-    w.rs[i] = (u32)(a.rowStart[x] >> rsh); w.dd[i] = (CT)d; w.lab[i] = 0; w.qj[i] = NONE16; w.best[i] = NONE16;
-    w.cnt[i] = 0; w.tot[i] = 0; myDepth += d;
-  }
+  for (u32 i = tid; i < n; i += CL_THREADS) w.root[i] = i ? NONE16 : (u16)0;   // rank 0 is never processed (hash10x.c:789): inactive, its own root
+  if (tid == 0) res[0] = RES_PACK(NONE16, 0, 0);
   SYNC();
   if constexpr (RANKED) {
     // ---- (0) which barcodes occur in this block's lists: presence bitmap, per-word popcount prefix, and a first[] sized by
     // the number present. More present than the table holds => the block is handed to the HBM-slot variant.
     // eight lists per wave in flight (their chunks are requested together); most entries meet a bit that is already
     // set: look before the atomic (LDS atomics cost per active lane)
-    auto mark = [&](u32 cj) { if (cj != code) { const u32 bit = 1u << (cj & 31); if (!(*(volatile u32 *)&w.bm[cj >> 5] & bit)) atomicOr(&w.bm[cj >> 5], bit); } };
-    // (both chunks of the four lists are requested together: met one list at a time, the second chunk — most lists have one where the
+    // (the bitmap is addressed as LDS explicitly: through the generic pointer this build of the compiler emits an invalid compare
+    // against the shared aperture base for the volatile look — "Illegal instruction detected" — in the RIF = 2 instantiation)
+    typedef __attribute__((address_space(3))) u32 lds_u32;
+    lds_u32 *const bm3 = (lds_u32 *)w.bm;
+    auto mark = [&](u32 cj) { if (cj != code) { const u32 bit = 1u << (cj & 31); if (!(*(volatile lds_u32 *)&bm3[cj >> 5] & bit)) __hip_atomic_fetch_or(&bm3[cj >> 5], bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); } };
+    // (both chunks of the eight lists are requested together: met one list at a time, the second chunk — most lists have one where the
     // depth range reaches 100 and the lists are long — was a load waited for per list: a third of the launch on the 1/10 config-3 set)
     constexpr int BIF = 8;                                   // lists in flight per wave in this pass (few live registers here)
-    for (u32 i0 = 1 + wave * BIF; i0 < n; i0 += CL_WAVES * BIF) {
-      u32 c0[BIF], c1[BIF], d4[BIF];
+    const u32 uw = (u32)__builtin_amdgcn_readfirstlane(wave);
+    u32 dvN = descLoad(gr, 1 + uw * BIF, BIF, n);
+    for (u32 i0 = 1 + uw * BIF; i0 < n; i0 += CL_WAVES * BIF) {
+      u32 c0[BIF], c1[BIF], d4[BIF], r4[BIF];
+      const u32 dv = dvN;
+      dvN = descLoad(gr, i0 + CL_WAVES * BIF, BIF, n);
 #pragma unroll
       for (int t = 0; t < BIF; ++t) {
-        const u32 i = i0 + t; d4[t] = i < n ? (u32)w.dd[i] : 0;
-        const u32 *row = ROWP(w.rs[i < n ? i : n - 1]);
+        const Desc g2 = descLane(dv, t);
+        d4[t] = g2.y; r4[t] = g2.x;
+        const u32 *row = ROWP(r4[t]);
         c0[t] = (u32)lane < d4[t] ? row[lane] : code; c1[t] = (u32)(WAVE + lane) < d4[t] ? row[WAVE + lane] : code;
       }
 #pragma unroll
@@ -633,7 +685,7 @@ __device__ void cluster_one_block(const ClusterArgs &a, u32 code, unsigned char 
         mark(c0[t]);
         if (d4[t] > WAVE) {
           mark(c1[t]);
-          if (d4[t] > 2 * WAVE) { const u32 *row = ROWP(w.rs[i0 + t]); for (u32 j = 2 * WAVE + lane; j < d4[t]; j += WAVE) mark(row[j]); }
+          if (d4[t] > 2 * WAVE) { const u32 *row = ROWP(r4[t]); for (u32 j = 2 * WAVE + lane; j < d4[t]; j += WAVE) mark(row[j]); }
         }
       }
     }
@@ -650,7 +702,7 @@ __device__ void cluster_one_block(const ClusterArgs &a, u32 code, unsigned char 
     for (int q = 0; q < CL_WAVES; ++q) { if (q < wave) run += sh[4 + q]; total += sh[4 + q]; }
     for (u32 q = s0; q < s1; ++q) { w.pre[q] = (u16)run; run += (u32)__popc(w.bm[q]); }
     {                                                         // uniform: every thread sees the same total
-      const size_t fixed = workBytes(0, n, 0, bmWords, sizeof(CT)), per = (size_t)w.histWords * 4, need = (((size_t)total * 2 + 15) & ~(size_t)15) + 32;
+      const size_t fixed = workBytes(0, n, 0, bmWords), per = (size_t)w.histWords * 4, need = pad16((size_t)total * 2) + 32;
       const bool fits = total <= 65535u && fixed + need + MIN_HIST_WAVES * per <= a.ldsBudget && !(a.firstCap && total > a.firstCap);   // (firstCap: test knob)
       if (!fits) {                                             // more barcodes present than this class has room for: the next larger class takes the block
         if (tid == 0) a.overflow[atomicAdd(a.overflowCount, 1u)] = lcode;
@@ -659,9 +711,9 @@ __device__ void cluster_one_block(const ClusterArgs &a, u32 code, unsigned char 
       }
       const size_t wv = (a.ldsBudget - fixed - need) / (per ? per : 1);
       nW = wv < (size_t)CL_WAVES ? (u32)wv : (u32)CL_WAVES;
-      const size_t need4 = (((size_t)total * 4 + 15) & ~(size_t)15) + 32;      // 4-byte entries where that costs the list loop no wave
+      const size_t need4 = pad16((size_t)total * 4) + 32;      // 4-byte entries where that costs the list loop no wave
       ft.wide = (a.narrowFirst != 1 && fixed + need4 + (size_t)nW * per <= a.ldsBudget) ? 1u : 0u;
-      w.first = (u16 *)((unsigned char *)w.hist + (((size_t)nW * per + 15) & ~(size_t)15));
+      w.first = (u16 *)((unsigned char *)w.hist + pad16((size_t)nW * per));
       ft.first = w.first;
     }
     for (u32 i = tid; i < nW * w.histWords; i += CL_THREADS) w.hist[i] = 0;
@@ -673,46 +725,43 @@ __device__ void cluster_one_block(const ClusterArgs &a, u32 code, unsigned char 
 
   // ---- (a)+(b) in one pass over the lists, in rank order, CL_WAVES * RIF ranks per round:
   //   (a) first[cj] = lowest rank >= 1 sharing barcode cj (hash10x.c:794-799, minShare) by CAS-min,
-  //   (b) msBest / msMax / msTot of the same ranks (hash10x.c:801-806) from the list entries still in registers.
+  //   (b) msBest / msMax / msTot of the same ranks (hash10x.c:801-806) from the list entries still in registers, and from
+  //       them, while the list's histogram stands, the rank's pointToMin term (hash10x.c:819-821).
   // first[cj] for a barcode of list i is final once every list <= i has been merged (later lists can only
   // offer larger ranks), so one barrier per round is enough.
-  // The lists of round r+1 are requested before round r is processed, so their HBM latency hides behind the
-  // CAS-min / barrier / mode work of round r.
   // A wave keeps the first two chunks (128 entries) of each of its lists in registers; longer lists re-read the rest.
-  u32 cjN[RIF], cj2N[RIF], dlN[RIF];
-  // The rounds start at rank 0 (never processed, hash10x.c:789: its slot gets length 0), so a wave's RIF ranks start at a
-  // multiple of RIF: their lengths and offsets come in ONE wide LDS read each (wave-uniform), are made scalar, and the
-  // list loads use a scalar base + lane offset.
-#define H10X_LOAD_AB(I0, CJ, DL, RS)                                                                          \
-  { const u32 ib = (I0); u32 dv[RIF], rv[RIF];                                                                \
-    if constexpr (IN_LDS && RIF == 4) { const uint2 d2 = *(const uint2 *)&w.dd[ib < n ? ib : 0]; const uint4 r4 = *(const uint4 *)&w.rs[ib < n ? ib : 0]; \
-      dv[0] = d2.x & 0xFFFFu; dv[1] = d2.x >> 16; dv[2] = d2.y & 0xFFFFu; dv[3] = d2.y >> 16; rv[0] = r4.x; rv[1] = r4.y; rv[2] = r4.z; rv[3] = r4.w; } \
-    else if constexpr (IN_LDS && RIF == 2) { const u32 d1 = *(const u32 *)&w.dd[ib < n ? ib : 0]; const uint2 r2 = *(const uint2 *)&w.rs[ib < n ? ib : 0]; \
-      dv[0] = d1 & 0xFFFFu; dv[1] = d1 >> 16; rv[0] = r2.x; rv[1] = r2.y; }                                   \
-    else { _Pragma("unroll") for (int t = 0; t < RIF; ++t) { const u32 i = ib + t; dv[t] = i < n ? (u32)w.dd[i] : 0; rv[t] = w.rs[i < n ? i : 0]; } } \
-    _Pragma("unroll") for (int t = 0; t < RIF; ++t) {                                                         \
-      const u32 i = ib + t;                                                                                   \
-      DL[t] = (u32)__builtin_amdgcn_readfirstlane((int)((i >= 1 && i < n) ? dv[t] : 0u));                     \
-      RS[t] = (u32)__builtin_amdgcn_readfirstlane((int)rv[t]);                                                \
-      CJ[t] = (u32)lane < DL[t] ? ROWP(RS[t])[lane] : code;                                                   \
-    } }
-  // the first chunk of a list is requested TWO rounds before its turn (the loop is bound by the latency of these short
-  // random reads), the second chunk — one list in seven has one — a round before
-  const bool listWave = (u32)wave < nW;                      // the other waves only keep the barriers company
+  // Pipeline per wave, in rounds: descriptors (scalar loads) three rounds ahead, the first chunk of a list two rounds ahead
+  // (the loop is bound by the latency of these short random reads), the second chunk — one list in seven has one at
+  // yeast scale, most at config-3 scale — one round ahead.
+  // The rounds start at rank 0 (never processed, hash10x.c:789: its slot gets length 0).
+#define H10X_LOAD_D(I0, DV) { DV = descLoad(gr, (I0), RIF, n); }
+#define H10X_LOAD_A(CJ, DV)                                                                                   \
+  { _Pragma("unroll") for (int t = 0; t < RIF; ++t) { const Desc g2 = descLane(DV, t); CJ[t] = (u32)lane < g2.y ? ROWP(g2.x)[lane] : code; } }
+#define H10X_LOAD_B(CJ2, DV)                                                                                  \
+  { _Pragma("unroll") for (int t = 0; t < RIF; ++t) { const Desc g2 = descLane(DV, t); CJ2[t] = (u32)(WAVE + lane) < g2.y ? ROWP(g2.x)[WAVE + lane] : code; } }
+  nW = (u32)__builtin_amdgcn_readfirstlane((int)nW);
   const u32 uwave = (u32)__builtin_amdgcn_readfirstlane(wave);
-  u32 cjNN[RIF], dlNN[RIF], rsN[RIF], rsNN[RIF];
-  H10X_LOAD_AB(listWave ? uwave * RIF : n, cjN, dlN, rsN)
-#pragma unroll
-  for (int t = 0; t < RIF; ++t) cj2N[t] = (u32)(WAVE + lane) < dlN[t] ? ROWP(rsN[t])[WAVE + lane] : code;
-  H10X_LOAD_AB(listWave ? (uwave + nW) * RIF : n, cjNN, dlNN, rsNN)
-  for (u32 r0 = 0; r0 < n; r0 += nW * RIF) {
+  const bool listWave = uwave < nW;                          // the other waves only keep the barriers company
+  const u32 stepR = nW * RIF;
+  u32 cjN[RIF], cj2N[RIF], cjNN[RIF];
+  u32 dvCur, dvN, dvNN, dvD;                                 // descriptors of this round's lists and of the next three rounds' (see descLoad)
+  u32 sDepth = 0;                                            // entries of the lists this wave has worked through (work counter)
+  H10X_LOAD_D(listWave ? uwave * RIF : n, dvN)
+  H10X_LOAD_D(listWave ? uwave * RIF + stepR : n, dvNN)
+  H10X_LOAD_D(listWave ? uwave * RIF + 2 * stepR : n, dvD)
+  H10X_LOAD_A(cjN, dvN)
+  H10X_LOAD_B(cj2N, dvN)
+  H10X_LOAD_A(cjNN, dvNN)
+  for (u32 r0 = 0; r0 < n; r0 += stepR) {
     const u32 i0 = listWave ? r0 + uwave * RIF : n;
     u32 cj[RIF], cj2[RIF], dl[RIF];
+    dvCur = dvN; dvN = dvNN; dvNN = dvD;
 #pragma unroll
-    for (int t = 0; t < RIF; ++t) { cj[t] = cjN[t]; cj2[t] = cj2N[t]; dl[t] = dlN[t]; cjN[t] = cjNN[t]; dlN[t] = dlNN[t]; rsN[t] = rsNN[t]; }
-#pragma unroll
-    for (int t = 0; t < RIF; ++t) cj2N[t] = (u32)(WAVE + lane) < dlN[t] ? ROWP(rsN[t])[WAVE + lane] : code;
-    H10X_LOAD_AB(listWave ? i0 + 2 * nW * RIF : n, cjNN, dlNN, rsNN)
+    for (int t = 0; t < RIF; ++t) { cj[t] = cjN[t]; cj2[t] = cj2N[t]; cjN[t] = cjNN[t]; dl[t] = (u32)__builtin_amdgcn_readlane((int)dvCur, 32 + t); }
+    H10X_LOAD_B(cj2N, dvN)
+    H10X_LOAD_A(cjNN, dvNN)
+    H10X_LOAD_D(listWave ? i0 + 3 * stepR : n, dvD)
+#define RS_OF(t) ((u32)__builtin_amdgcn_readlane((int)dvCur, t))   /* list offset of this round's list t: only lists of more than two chunks ask */
 #pragma unroll
     for (int t = 0; t < RIF; ++t) {
       const u32 i = i0 + t;
@@ -720,7 +769,7 @@ __device__ void cluster_one_block(const ClusterArgs &a, u32 code, unsigned char 
       cj[t] = cj[t] != code ? ft.update(cj[t], i) : NOHANDLE;          // from here on cj / cj2 hold handles
       if (dl[t] > WAVE) {
         cj2[t] = cj2[t] != code ? ft.update(cj2[t], i) : NOHANDLE;
-        if (dl[t] > 2 * WAVE) { const u32 *row = ROWP(w.rs[i]); for (u32 j = 2 * WAVE + lane; j < dl[t]; j += WAVE) { const u32 c2 = row[j]; if (c2 != code) ft.update(c2, i); } }
+        if (dl[t] > 2 * WAVE) { const u32 *row = ROWP(RS_OF(t)); for (u32 j = 2 * WAVE + lane; j < dl[t]; j += WAVE) { const u32 c2 = row[j]; if (c2 != code) ft.update(c2, i); } }
       }
     }
     if (!H10X_DBGSKIP(8)) SYNC_LDS();
@@ -731,102 +780,50 @@ __device__ void cluster_one_block(const ClusterArgs &a, u32 code, unsigned char 
       const u32 i = i0 + t;
       if (dl[t]) {                                           // 0 for rank 0 and past the last rank; a list of the depth range holds at least one barcode
         const u32 d = dl[t];
-        u32 best, bcnt, tot;
+        u32 best, bcnt, tot, rb, q;
         // (the list's address is only formed where entries beyond the two chunks held in registers are read)
-        if (d <= WAVE) row_mode_hist<IN_LDS, 1>(nullptr, cj[t], NOHANDLE, d, code, i, ft, w.hist + wave * w.histWords, (u32)a.threshold, best, bcnt, tot);
-        else if (d <= 2 * WAVE) row_mode_hist<IN_LDS, 2>(nullptr, cj[t], cj2[t], d, code, i, ft, w.hist + wave * w.histWords, (u32)a.threshold, best, bcnt, tot);
-        else if (d < RCHUNK * WAVE) row_mode_hist<IN_LDS, RCHUNK>(ROWP(w.rs[i]), cj[t], cj2[t], d, code, i, ft, w.hist + wave * w.histWords, (u32)a.threshold, best, bcnt, tot);
-        else row_mode_long(ROWP(w.rs[i]), d, code, i, ft, best, bcnt, tot);
-        if (lane == 0) { w.best[i] = (u16)best; w.cnt[i] = (CT)bcnt; w.tot[i] = (CT)tot; }
+        if (d <= WAVE) row_mode_hist<IN_LDS, 1>(nullptr, cj[t], NOHANDLE, d, code, i, ft, w.hist + wave * w.histWords, w.root, thr, best, bcnt, tot, rb, q);
+        else if (d <= 2 * WAVE) row_mode_hist<IN_LDS, 2>(nullptr, cj[t], cj2[t], d, code, i, ft, w.hist + wave * w.histWords, w.root, thr, best, bcnt, tot, rb, q);
+        else if (d < RCHUNK * WAVE) row_mode_hist<IN_LDS, RCHUNK>(ROWP(RS_OF(t)), cj[t], cj2[t], d, code, i, ft, w.hist + wave * w.histWords, w.root, thr, best, bcnt, tot, rb, q);
+        else {
+          row_mode_long(ROWP(RS_OF(t)), d, code, i, ft, best, bcnt, tot); rb = NONE16; q = 0;
+          if (bcnt >= thr) { rb = ld_shared<IN_LDS>(&w.root[best]); if (rb != NONE16) { u32 t2; q = row_count_value(ROWP(RS_OF(t)), d, code, i, ft, rb, t2); } }
+        }
+        const bool act = bcnt >= thr;                        // hash10x.c:807
+        if (lane == 0) {
+          w.root[i] = act ? (u16)rb : (u16)i;               // rb = NONE16: msBest belongs to this round, settled behind the loop
+          res[i] = RES_PACK(act ? best : NONE16, q, tot);     // (the quotient is formed by replay_kernel: an fp64 divide per list is 40 instructions in this loop)
+        }
+        sDepth += d;
       }
     }
   }
-#undef H10X_LOAD_AB
+#undef RS_OF
+#undef H10X_LOAD_D
+#undef H10X_LOAD_A
+#undef H10X_LOAD_B
   STAMP(1);
   SYNC();
-  if (HASHED && sh[2]) {                                     // hand the block to the next larger placement; nothing has been written yet
+  if (HASHED && sh[2]) {                                     // hand the block to the next larger placement; what has been written is written again there
     if (tid == 0) a.overflow[atomicAdd(a.overflowCount, 1u)] = lcode;
     SYNC();
     return;
   }
   STAMP(2);
 
-  // ---- (c) the order-dependent part of hash10x.c:807-822, restated without a serial walk.
-  // Call rank i "active" if msMax >= threshold. An active rank always ends up labelled at its own turn, and
-  // msBest < i, so: the cluster of an active rank is the one of the first INACTIVE rank on its msBest chain
-  // (its root = clusterMin of that cluster); an inactive rank founds a cluster at the first turn i' of an
-  // active rank pointing at it directly; clusters are numbered in founding order; the 256th founding turn is
-  // where the reference gives up. => roots by pointer jumping, founding turns by CAS-min, numbers by a scan.
-  {
-    u16 *ptr = w.qj;                                         // becomes root(i) = clusterMin[label(i)] for active ranks
-    u16 *ft = (u16 *)w.hist;                                 // founding turn of each inactive rank (NONE16 = never)
-    u16 *fl = ft + ((n + 2) & ~1u);                          // 1 at founding turns -> inclusive scan = cluster number
-    for (u32 i = tid; i < n; i += CL_THREADS) {
-      const bool act = i >= 1 && (int)w.cnt[i] >= a.threshold;
-      ptr[i] = act ? w.best[i] : (u16)i; ft[i] = NONE16; fl[i] = 0;
-    }
-    SYNC();
-    for (u32 i = tid; i < n; i += CL_THREADS)
-      if (i >= 1 && (int)w.cnt[i] >= a.threshold) {
-        const u32 b = w.best[i];
-        if (!(b >= 1 && (int)w.cnt[b] >= a.threshold)) min_u16<IN_LDS>(ft, b, i);
-      }
-    u32 rounds = 1; while ((1u << rounds) < n) ++rounds;
-    for (u32 r = 0; r <= rounds; ++r) {                      // chains only run downwards: in-place jumping converges
-      SYNC();
-      for (u32 i = tid; i < n; i += CL_THREADS) { const u32 p = ptr[i]; const u32 pp = *(volatile u16 *)&ptr[p]; if (pp != p) ptr[i] = (u16)pp; }
-    }
-    SYNC();
-    for (u32 i = tid; i < n; i += CL_THREADS) { const u32 t = ld_shared<IN_LDS>(&ft[i]); if (t != NONE16) fl[t] = 1; }   // founding turns are distinct
-    SYNC();
-    // block-wide inclusive scan of fl[0..n)
-    const u32 ipt = (n + CL_THREADS - 1) / CL_THREADS, s0 = tid * ipt, s1 = s0 + ipt < n ? s0 + ipt : n;
-    u32 mine = 0;
-    for (u32 i = s0; i < s1; ++i) mine += fl[i];
-    u32 inc = mine;
-#pragma unroll
-    for (int d = 1; d < WAVE; d <<= 1) { const u32 o = (u32)__shfl_up((int)inc, d); if (lane >= d) inc += o; }
-    if (lane == WAVE - 1) sh[4 + wave] = inc;
-    SYNC();
-    u32 run = inc - mine;
-    for (int q = 0; q < wave; ++q) run += sh[4 + q];
-    for (u32 i = s0; i < s1; ++i) { run += fl[i]; fl[i] = (u16)run; }
-    SYNC();
-    const u32 nRoots = fl[n - 1];
-    if (nRoots > 255) {                                      // hash10x.c:810-816: abandon at the 256th founding turn
-      for (u32 i = tid; i < n; i += CL_THREADS) {
-        if (fl[i] == 256 && (i == 0 || fl[i - 1] == 255)) { sh[0] = 0; sh[1] = i; }
-        w.lab[i] = 0;
-        if (!(i >= 1 && (int)w.cnt[i] >= a.threshold)) ptr[i] = NONE16;
-      }
-    } else {
-      if (tid == 0) { sh[0] = nRoots; sh[1] = n; }
-      for (u32 i = tid; i < n; i += CL_THREADS) {
-        const bool act = i >= 1 && (int)w.cnt[i] >= a.threshold;
-        u32 L = 0;
-        if (act) L = fl[ld_shared<IN_LDS>(&ft[ptr[i]])];
-        else { const u32 t = ld_shared<IN_LDS>(&ft[i]); if (t != NONE16) L = fl[t]; ptr[i] = NONE16; }
-        w.lab[i] = (u8)L;
-      }
-    }
-  }
-  SYNC();
-  const u32 nSub = sh[0], stop = sh[1];
-  STAMP(3);
-
-  // ---- (d) minShareCount[clusterMin[label]] per rank (hash10x.c:821) into cnt[]. The barcode list is read again only for
-  // the ranks whose cluster founder is not msBest — one rank in sixteen — so those ranks are first collected (what a wave
-  // would otherwise meet is a handful of 2 us loads scattered over twenty near-empty iterations, each waited for in
-  // turn), then worked off RIF lists per wave at a time with their loads issued together.
+  // ---- the ranks left open by the loop: active ranks whose msBest was processed in the same round (its root was not on
+  // record yet). Collected, their roots settled by walking down the msBest chain to the first rank with a root on record
+  // (an inactive rank is its own root; chains only run downwards), then their lists are gathered once more — RIF lists per
+  // wave with the loads in flight together — for minShareCount[root] and msTot. A few per cent of the ranks.
   {
     u16 *todo = (u16 *)w.hist;                               // the histograms are idle from here on
     if (tid == 0) sh[2] = 0;
     SYNC();
     if (!H10X_DBGSKIP(4))
-      for (u32 i0 = 0; i0 < stop; i0 += CL_THREADS) {
+      for (u32 i0 = 0; i0 < n; i0 += CL_THREADS) {
         const u32 i = i0 + tid;
         bool need = false;
-        if (i >= 1 && i < stop) { const u32 q = w.qj[i]; need = q != NONE16 && q != w.best[i]; }
+        if (i >= 1 && i < n) need = ld_shared<IN_LDS>(&w.root[i]) == NONE16;
         const u64 bal = __ballot(need);
         if (bal) {
           u32 base = 0;
@@ -837,49 +834,57 @@ __device__ void cluster_one_block(const ClusterArgs &a, u32 code, unsigned char 
       }
     SYNC();
     const u32 nTodo = sh[2];
-    for (u32 k0 = wave * RIF; k0 < nTodo; k0 += CL_WAVES * RIF) {
-      u32 ii[RIF], cj[RIF], cjB[RIF], dl[RIF], qv[RIF];
+    for (u32 k = tid; k < nTodo; k += CL_THREADS) {
+      const u32 i = ld_shared<IN_LDS>(&todo[k]);
+      // msBest of an unsettled rank comes from its result word in HBM (written before the barriers above; read past this CU's L1)
+      u32 r = (u32)(__hip_atomic_load(&res[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 0xFFFFu);
+      for (u32 hop = 0; hop < n && r < n; ++hop) {           // (r < n always on consistent data)
+        const u32 rr = ld_shared<IN_LDS>(&w.root[r]);
+        if (rr != NONE16) { r = rr; break; }
+        r = (u32)(__hip_atomic_load(&res[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 0xFFFFu);
+      }
+      w.root[i] = (u16)r;                                    // (a walker passing through i meanwhile reads NONE16 or r: the same answer either way)
+    }
+    SYNC();
+    STAMP(3);
+    const u32 uw = (u32)__builtin_amdgcn_readfirstlane(wave);
+    for (u32 k0 = uw * RIF; k0 < nTodo; k0 += CL_WAVES * RIF) {
+      u32 ii[RIF], cj[RIF], cjB[RIF], dl[RIF], rsv[RIF], qv[RIF];
 #pragma unroll
       for (int t = 0; t < RIF; ++t) {
         const bool on = k0 + t < nTodo;
-        ii[t] = on ? (u32)ld_shared<IN_LDS>(&todo[k0 + t]) : 0u;
-        qv[t] = on ? (u32)w.qj[ii[t]] : NONE16; dl[t] = on ? (u32)w.dd[ii[t]] : 0u;
-        const u32 *row = ROWP(w.rs[ii[t]]);
+        ii[t] = (u32)__builtin_amdgcn_readfirstlane((int)(on ? (u32)ld_shared<IN_LDS>(&todo[k0 + t]) : 0u));
+        qv[t] = on ? (u32)ld_shared<IN_LDS>(&w.root[ii[t]]) : NONE16;
+        const u64 g2 = gr[ii[t]];
+        dl[t] = on ? (u32)__builtin_amdgcn_readfirstlane((int)(u32)(g2 >> 32)) : 0u; rsv[t] = (u32)__builtin_amdgcn_readfirstlane((int)(u32)g2);
+        const u32 *row = ROWP(rsv[t]);
         cj[t] = (u32)lane < dl[t] ? row[lane] : code; cjB[t] = (u32)(WAVE + lane) < dl[t] ? row[WAVE + lane] : code;   // both chunks up front
       }
 #pragma unroll
       for (int t = 0; t < RIF; ++t) {
         if (dl[t] == 0) continue;
         const u32 i = ii[t];
-        u32 q = (u32)__popcll(__ballot(cj[t] != code && ft.lookup(cj[t]) == qv[t]));
-        if (dl[t] > WAVE) q += (u32)__popcll(__ballot(cjB[t] != code && ft.lookup(cjB[t]) == qv[t]));
-        if (dl[t] > 2 * WAVE) { const u32 *row = ROWP(w.rs[i]); for (u32 b0 = 2 * WAVE; b0 < dl[t]; b0 += WAVE) { bool m = false; if (b0 + lane < dl[t]) { const u32 c2 = row[b0 + lane]; m = c2 != code && ft.lookup(c2) == qv[t]; } q += (u32)__popcll(__ballot(m)); } }
-        if (lane == 0) w.cnt[i] = (CT)q;
+        u32 f = cj[t] != code ? ft.lookup(cj[t]) : NONE16;
+        u32 q = (u32)__popcll(__ballot(f == qv[t])), tt = (u32)__popcll(__ballot(f < i));
+        if (dl[t] > WAVE) { f = cjB[t] != code ? ft.lookup(cjB[t]) : NONE16; q += (u32)__popcll(__ballot(f == qv[t])); tt += (u32)__popcll(__ballot(f < i)); }
+        if (dl[t] > 2 * WAVE) { const u32 *row = ROWP(rsv[t]); for (u32 b0 = 2 * WAVE; b0 < dl[t]; b0 += WAVE) { f = NONE16; if (b0 + lane < dl[t]) { const u32 c2 = row[b0 + lane]; if (c2 != code) f = ft.lookup(c2); } q += (u32)__popcll(__ballot(f == qv[t])); tt += (u32)__popcll(__ballot(f < i)); } }
+        if (lane == 0) res[i] = RES_PACK(__hip_atomic_load(&res[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 0xFFFFu, q, tt);
       }
     }
   }
-  SYNC();
   STAMP(4);
 
-  // ---- out: the pointToMin term of every rank (IEEE double quotient; 0.0 where the reference adds nothing — adding
-  // +0.0 is exact), labels (includes the wipe of hash10x.c:783), the raw cluster count. point_sum_kernel and
-  // read_merge_kernel finish the block.
-  double *term = a.term + o;
-  for (u32 i = tid; i < n; i += CL_THREADS) {
-    const bool has = i >= 1 && i < stop && w.qj[i] != NONE16;
-    term[i] = has ? (double)(int)w.cnt[i] / (double)(int)w.tot[i] : 0.0;
-    ch[g[i]].subCluster = w.lab[i];
-  }
-  if (tid == 0) a.blocks[lcode].nSubCluster = nSub;
-  // wave-reduce the per-thread depth sums for the work counters
+  // ---- out: nothing is left to write — every rank's result word is in place; replay_kernel (labels, cluster count, the > 255
+  // clusters cut, the quotients), point_sum_kernel and read_merge_kernel finish the block.
   // work counters: kept per lane over the barcodes of the workgroup, posted once when the kernel ends (19 atomics per
   // barcode on four shared words would queue up in L2 behind those of every other workgroup)
-  acc[1] += myDepth;
-  if (tid == 0) { acc[0] += n; acc[2] += a.blocks[lcode].nHash; acc[3] += 1; }
+  if (lane == 0) acc[1] += sDepth;
+  if (tid == 0) { acc[1] += (u32)(gr[0] >> 32); acc[0] += n; acc[2] += a.blocks[lcode].nHash; acc[3] += 1; }
   if (!FIRST_LDS) {                                          // leave first[] clean for the next barcode of this workgroup
     SYNC();
-    for (u32 i = 1 + wave; i < n; i += CL_WAVES) {
-      const u32 d = w.dd[i]; const u32 *row = ROWP(w.rs[i]);
+    const u32 uw = (u32)__builtin_amdgcn_readfirstlane(wave);
+    for (u32 i = 1 + uw; i < n; i += CL_WAVES) {
+      const u64 g2 = gr[i]; const u32 d = (u32)__builtin_amdgcn_readfirstlane((int)(u32)(g2 >> 32)); const u32 *row = ROWP((u32)__builtin_amdgcn_readfirstlane((int)(u32)g2));
       for (u32 j = lane; j < d; j += WAVE) w.first[row[j]] = NONE16;
     }
   }
@@ -918,6 +923,122 @@ void cluster_kernel(ClusterArgs a) {
   if ((threadIdx.x & (WAVE - 1)) == 0 && depth) atomicAdd((u64 *)&a.stats[1], depth);
   if (threadIdx.x == 0 && acc[3]) { atomicAdd((u64 *)&a.stats[0], acc[0]); atomicAdd((u64 *)&a.stats[2], acc[2]); atomicAdd((u64 *)&a.stats[3], acc[3]); }
 }
+
+// ---- list descriptors: per good hash of a block, in rank order, where its barcode list starts in rows[] and how long it is.
+// Built once per --hashDepthRange (after the list exchange of a sharded run), read by every --cluster that follows: the
+// cluster kernel used to fetch them per barcode through three dependent gathers (position -> hash index -> offset, depth)
+// into LDS arrays of 6 bytes per rank.
+__global__ __launch_bounds__(256)
+void good_rows_kernel(const h10x_clushash *__restrict__ ch, const u64 *__restrict__ blockOff, const u32 *__restrict__ nGood, const u16 *__restrict__ goodPos, u32 nBlocks,
+                      const u32 *__restrict__ hashDepth, const u64 *__restrict__ rowStart, u32 rowShift, u64 *__restrict__ goodRow) {
+  for (u32 c = blockIdx.x; c < nBlocks; c += gridDim.x) {
+    const u32 n = nGood[c]; const u64 o = blockOff[c];
+    for (u32 i = threadIdx.x; i < n; i += blockDim.x) {
+      const u32 x = ch[o + goodPos[o + i]].hash;
+      goodRow[o + i] = (u64)(u32)(rowStart[x] >> rowShift) | ((u64)hashDepth[x] << 32);
+    }
+  }
+}
+
+// ---- (c) the order-dependent part of hash10x.c:807-822, restated without a serial walk, from the msBest column the list
+// loop left behind (res[], RES_PACK: msBest of an active rank — msMax >= threshold — NONE16 otherwise, and the two counts
+// of its pointToMin term, which this kernel divides and leaves in the same 8 bytes as a double: 0.0 for an inactive rank
+// and for every rank from the abandoning turn on, so that point_sum_kernel simply adds the column in order).
+// An active rank always ends up labelled at its own turn, and msBest < i, so: the cluster of an active rank is the one of
+// the first INACTIVE rank on its msBest chain (its root = clusterMin of that cluster); an inactive rank founds a cluster at
+// the first turn i' of an active rank pointing at it directly; clusters are numbered in founding order; the 256th founding
+// turn is where the reference gives up (hash10x.c:810-816: labels wiped, pointToMin keeps the terms added so far).
+// => roots by pointer jumping, founding turns by CAS-min, numbers by a scan. One workgroup per barcode, 8 bytes of LDS per
+// rank; launched in classes by rank count (each launch skips the blocks of the others), the largest on HBM scratch.
+struct ReplayArgs {
+  h10x_block *blocks; const u64 *blockOff; h10x_clushash *clusHash; const u16 *goodPos; const u32 *nGood;
+  u64 *res;                                                 // in: result words of the list loop; out: the ranks' pointToMin terms (double)
+  u32 codeMin, span, nLo, nHi;                               // blocks [codeMin, codeMin + span) with nLo < nGood <= nHi
+  unsigned char *scratch; size_t scratchStride;              // IN_LDS = false: working set per workgroup
+};
+#define SYNC() do { __syncthreads(); if (!IN_LDS) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); } while (0)
+template <bool IN_LDS, int THREADS>
+__global__ __launch_bounds__(THREADS)
+void replay_kernel(ReplayArgs a) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  __shared__ u32 sh[4 + THREADS / WAVE];
+  const int tid = threadIdx.x, lane = tid & (WAVE - 1), wave = tid / WAVE;
+  unsigned char *region = IN_LDS ? smem : a.scratch + (size_t)blockIdx.x * a.scratchStride;
+  for (u32 wi = blockIdx.x; wi < a.span; wi += gridDim.x) {
+    const u32 c = a.codeMin + wi;
+    const u32 n = a.nGood[c];
+    if (n == 0 || n <= a.nLo || n > a.nHi) continue;         // uniform; n == 0: block left untouched (hash10x.c:780)
+    const u64 o = a.blockOff[c];
+    const size_t col = ((size_t)n * 2 + 15) & ~(size_t)15;
+    u16 *bst = (u16 *)region, *ptr = (u16 *)(region + col), *ft = (u16 *)(region + 2 * col), *fl = (u16 *)(region + 3 * col);
+    SYNC();                                                  // the previous block of this workgroup is done with the region
+    for (u32 i = tid; i < n; i += THREADS) {
+      const u16 m = (u16)(a.res[o + i] & 0xFFFFu);
+      bst[i] = m; ptr[i] = m != NONE16 ? m : (u16)i; ft[i] = NONE16; fl[i] = 0;
+    }
+    SYNC();
+    for (u32 i = tid; i < n; i += THREADS) {
+      const u32 b = ld_shared<IN_LDS>(&bst[i]);
+      if (b != NONE16 && b < n && ld_shared<IN_LDS>(&bst[b]) == NONE16) min_u16<IN_LDS>(ft, b, i);   // b inactive: i's turn may be its founding turn
+    }
+    u32 rounds = 1; while ((1u << rounds) < n) ++rounds;
+    SYNC();
+    for (u32 r = 0; r <= rounds; ++r) {                      // chains only run downwards: in-place jumping converges; they are short, so
+      int moved = 0;                                         // the rounds end with the first one in which no pointer moved
+      for (u32 i = tid; i < n; i += THREADS) {
+        const u32 p = ld_shared<IN_LDS>(&ptr[i]);
+        if (p < n) { const u32 pp = IN_LDS ? (u32)*(volatile u16 *)&ptr[p] : (u32)ld_shared<false>(&ptr[p]); if (pp != p) { ptr[i] = (u16)pp; moved = 1; } }
+      }
+      const int any = __syncthreads_or(moved);
+      if (!IN_LDS) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      if (!any) break;
+    }
+    for (u32 i = tid; i < n; i += THREADS) { const u32 t = ld_shared<IN_LDS>(&ft[i]); if (t != NONE16) fl[t] = 1; }   // founding turns are distinct
+    SYNC();
+    // block-wide inclusive scan of fl[0..n)
+    const u32 ipt = (n + THREADS - 1) / THREADS, s0 = tid * ipt < n ? tid * ipt : n, s1 = s0 + ipt < n ? s0 + ipt : n;
+    u32 mine = 0;
+    for (u32 i = s0; i < s1; ++i) mine += ld_shared<IN_LDS>(&fl[i]);
+    u32 inc = mine;
+#pragma unroll
+    for (int d = 1; d < WAVE; d <<= 1) { const u32 o2 = (u32)__shfl_up((int)inc, d); if (lane >= d) inc += o2; }
+    if (lane == WAVE - 1) sh[4 + wave] = inc;
+    __syncthreads();
+    u32 run = inc - mine;
+    for (int q = 0; q < wave; ++q) run += sh[4 + q];
+    for (u32 i = s0; i < s1; ++i) { run += ld_shared<IN_LDS>(&fl[i]); fl[i] = (u16)run; }
+    SYNC();
+    const u32 nRoots = ld_shared<IN_LDS>(&fl[n - 1]);
+    u32 stop = n;
+    h10x_clushash *ch = a.clusHash + o; const u16 *g = a.goodPos + o;
+    if (nRoots > 255) {                                      // hash10x.c:810-816: abandon at the 256th founding turn
+      for (u32 i = tid; i < n; i += THREADS)
+        if (ld_shared<IN_LDS>(&fl[i]) == 256 && (i == 0 || ld_shared<IN_LDS>(&fl[i - 1]) == 255)) sh[1] = i;
+      __syncthreads();
+      stop = sh[1];                                            // the terms of the turns before it stay in pointToMin
+      for (u32 i = tid; i < n; i += THREADS) ch[g[i]].subCluster = 0;
+      if (tid == 0) a.blocks[c].nSubCluster = 0;
+    } else {
+      for (u32 i = tid; i < n; i += THREADS) {
+        u32 L = 0;
+        if (ld_shared<IN_LDS>(&bst[i]) != NONE16) { const u32 rt = ld_shared<IN_LDS>(&ptr[i]); const u32 t = rt < n ? (u32)ld_shared<IN_LDS>(&ft[rt]) : NONE16; L = t != NONE16 ? (u32)ld_shared<IN_LDS>(&fl[t]) : 0u; }
+        else { const u32 t = ld_shared<IN_LDS>(&ft[i]); if (t != NONE16) L = ld_shared<IN_LDS>(&fl[t]); }
+        ch[g[i]].subCluster = (u8)L;                         // includes the wipe of hash10x.c:783
+      }
+      if (tid == 0) a.blocks[c].nSubCluster = nRoots;
+    }
+    // the ranks' pointToMin terms (hash10x.c:821): one IEEE double divide per active rank, written over its result word
+    double *term = (double *)(a.res + o);
+    for (u32 i = tid; i < n; i += THREADS) {
+      const u64 r = a.res[o + i];
+      const bool has = i >= 1 && i < stop && (u32)(r & 0xFFFFu) != NONE16;
+      term[i] = has ? (double)(int)(u32)((r >> 16) & 0xFFFFFFu) / (double)(int)(u32)(r >> 40) : 0.0;
+    }
+  }
+}
+#undef SYNC
+__host__ __device__ inline size_t replayBytes(u32 n) { return 4 * (((size_t)n * 2 + 15) & ~(size_t)15) + 16; }
+constexpr u32 REPLAY_SMALL = 2040, REPLAY_MID = 16376;       // rank counts up to which a block's replay runs in 16 KB / 128 KB of LDS
 
 // ---- (e) pointToMin = the terms added in rank order (hash10x.c:821): a serial fp64 chain per barcode. One WAVE per
 // barcode: 64 terms per coalesced load, added in order through readlane (the chain costs one v_add_f64 latency per
@@ -1033,7 +1154,7 @@ void read_merge_kernel(h10x_block *__restrict__ blocks, const u64 *__restrict__ 
 // launch classes by working-set size: 0 = half a CU's LDS (barcodes with many ranks run their list loop on fewer waves:
 // histWaves), 2 = the whole LDS of a CU, 3 = HBM scratch (class 1 is no longer used)
 __global__ void cluster_classify_kernel(const h10x_block *__restrict__ blocks, const u32 *__restrict__ nGood, const u32 *__restrict__ entries, u32 codeMin, u32 codeMax,
-                                        u32 nBlocks /* LDS entries of first[] (ranked, hashed: barcodes of the data set) */, int ranked /* 1 ranked, 2 hashed */, u32 hashMinSlots, u32 bmWords, u32 waves0, size_t budget0, size_t budgetSmall, size_t budgetBig, int wide, u32 bigRanks,
+                                        u32 nBlocks /* LDS entries of first[] (ranked, hashed: barcodes of the data set) */, int ranked /* 1 ranked, 2 hashed */, u32 hashMinSlots, u32 bmWords, u32 waves0, size_t budget0, size_t budgetSmall, size_t budgetBig, u32 bigRanks,
                                         u32 *__restrict__ list0, u32 *__restrict__ list1, u32 *__restrict__ list2, u32 *__restrict__ list3,
                                         u32 *__restrict__ counts) {
   const u32 c = codeMin + blockIdx.x * blockDim.x + threadIdx.x;
@@ -1042,16 +1163,15 @@ __global__ void cluster_classify_kernel(const h10x_block *__restrict__ blocks, c
   int cls = -1; u32 nRead = 0;
   if (n) {
     nRead = blocks[c].nRead;
-    if (wide) cls = 3;                                       // counts do not fit the u16 arrays of the LDS instantiations
-    else if (ranked == 2) {                                  // hashed placement
+    if (ranked == 2) {                                  // hashed placement
       const u32 want = hashedWant(rankedFirstEstimateE(nBlocks, n, entries[c]));
       u32 nW, slots;
-      hashedShape(n, waves0, 2, budget0, hashMinSlots, want, nW, slots);
+      hashedShape(n, waves0, budget0, hashMinSlots, want, nW, slots);
       if (slots >= want) cls = 0;
-      else { hashedShape(n, CL_THREADS_HUGE / WAVE, 2, budgetBig, hashMinSlots, want, nW, slots); cls = slots ? 2 : 3; }
+      else { hashedShape(n, CL_THREADS_HUGE / WAVE, budgetBig, hashMinSlots, want, nW, slots); cls = slots ? 2 : 3; }
     }
-    else if (histWaves(ranked ? rankedFirstEstimateE(nBlocks, n, entries[c]) : nBlocks, n, waves0, bmWords, 2, budget0)) cls = 0;
-    else if (histWaves(ranked ? rankedFirstEstimate(nBlocks, n) : nBlocks, n, CL_THREADS_HUGE / WAVE, bmWords, 2, budgetBig)) cls = 2;
+    else if (histWaves(ranked ? rankedFirstEstimateE(nBlocks, n, entries[c]) : nBlocks, n, waves0, bmWords, budget0)) cls = 0;
+    else if (histWaves(ranked ? rankedFirstEstimate(nBlocks, n) : nBlocks, n, CL_THREADS_HUGE / WAVE, bmWords, budgetBig)) cls = 2;
     else cls = 3;
   }
   // the largest barcodes of the main class go to the front of its work queue (list1, handed out before list0): the launch
@@ -1078,7 +1198,7 @@ static int cluster_local_range(Ctx *c, int codeMin, int codeMax, int threshold, 
   const u32 nGlobal = c->sharded ? c->nBlocksGlobal : c->nBlocks;
   c->tstart(T_CLUSTER);
   const u32 span = (u32)(codeMax - codeMin);
-  DevBuf<u32> list0, list1, list2, list3; DevBuf<u64> zeroed; DevBuf<double> term;
+  DevBuf<u32> list0, list1, list2, list3; DevBuf<u64> zeroed; DevBuf<u64> term;
   H10X_HIP(c, list0.alloc(span)); H10X_HIP(c, list1.alloc(span)); H10X_HIP(c, list2.alloc(span)); H10X_HIP(c, list3.alloc(span));
   // every small counter of the command in one buffer, cleared by one memset: counts[0..3] class sizes, [4] [6] [7] work
   // queue positions, [8] largest nRead, [10] [11] overflowed blocks (lists A, B); stats[0..7] the work counters
@@ -1103,14 +1223,13 @@ static int cluster_local_range(Ctx *c, int codeMin, int codeMax, int threshold, 
   int firstMode = (size_t)nGlobal * 2 <= 48 * 1024 ? 0 : (rankedSure || rankedTry ? 1 : (hashBits <= 22 ? 3 : 2));
   if (c->optFirstGlobal == 1) firstMode = 2; else if (c->optFirstGlobal == 2) firstMode = 1; else if (c->optFirstGlobal == 3) firstMode = 3;   // test knobs
   const u32 firstCap = c->optFirstCap > 0 ? (u32)c->optFirstCap : 0u;      // test knob only
-  const int wide = c->maxGoodDepth > 65535u ? 1 : 0;         // list lengths / counts beyond the u16 arrays of the LDS instantiations
   u32 hc[12]; u32 nFirstLds = 0, bmWords = 0;
   for (int attempt = 0; attempt < 2; ++attempt) {
     nFirstLds = firstMode == 0 ? nGlobal : 0;
     bmWords = firstMode == 1 ? bmWordsAll : 0;
     cluster_classify_kernel<<<divUp(span, 256), 256, 0, st>>>(c->blocks.p, c->nGood.p, c->goodEntries.p, (u32)codeMin, (u32)codeMax,
                                                             firstMode == 1 || firstMode == 3 ? nGlobal : nFirstLds, firstMode == 1 ? 1 : (firstMode == 3 ? 2 : 0), hashMinSlots,
-                                                            bmWords, (u32)threads0 / WAVE, budget0, budgetSmall, budgetBig, wide, c->optBigRanks > 0 ? (u32)c->optBigRanks : c->meanGood + c->meanGood / 2,
+                                                            bmWords, (u32)threads0 / WAVE, budget0, budgetSmall, budgetBig, c->optBigRanks > 0 ? (u32)c->optBigRanks : c->meanGood + c->meanGood / 2,
                                                             list0.p, list1.p, list2.p, list3.p, counts.p);
     H10X_TRY(c->readback(hc, counts.p, 48));
     H10X_TRY(c->syncReadbacks());
@@ -1124,11 +1243,11 @@ static int cluster_local_range(Ctx *c, int codeMin, int codeMax, int threshold, 
   // contend for the same unit at the same time)
   ClusterArgs a{};
   a.blocks = c->blocks.p; a.blockOff = c->blockOff.p; a.clusHash = c->clusHash.p; a.goodPos = c->goodPos.p; a.nGood = c->nGood.p;
-  a.hashDepth = c->hashDepth.p; a.rowStart = c->rowStart.p; a.rows = c->rows.p; a.nBlocks = c->nBlocks; a.threshold = threshold;
+  a.goodRow = c->goodRow.p; a.rows = c->rows.p; a.nBlocks = c->nBlocks; a.threshold = threshold;
   a.segs = c->segs; a.nBlocksFirst = nGlobal; a.rowShift = (u32)c->rowShift;
   if (c->sharded && c->optRowsFakeBase) a.rows = c->rows.p - (size_t)c->optRowsFakeBase;   // test knob: rowStart[] carries the same offset (shard_exchangeRows)
   a.dbgSkip = (u32)c->optDbgSkip; a.narrowFirst = (u32)c->optNarrowFirst;
-  a.maxGood = c->maxGood; a.stats = stats.p; a.term = term.p; a.entries = c->goodEntries.p;
+  a.maxGood = c->maxGood; a.stats = stats.p; a.res = term.p; a.entries = c->goodEntries.p;
   a.firstCap = firstCap; a.hashMask = hashBits >= 32 ? 0xFFFFFFFFu : (1u << hashBits) - 1u; a.hashMinSlots = hashMinSlots;
   // ranked / hashed placement: blocks whose table was too small are re-run — those of the half-CU class (list A) with the
   // whole LDS of a CU, those that fail there as well (list B) with first[] dense on an HBM slot
@@ -1140,7 +1259,7 @@ static int cluster_local_range(Ctx *c, int codeMin, int codeMax, int threshold, 
   DevBuf<unsigned char> scratch;
   size_t stride = 0; u32 grid3 = 0;
   if (hc[3]) {
-    stride = (workBytes(nGlobal, c->maxGood, CL_THREADS_SMALL / WAVE, 0, 4) + 255) & ~(size_t)255;
+    stride = (workBytes(nGlobal, c->maxGood, CL_THREADS_SMALL / WAVE, 0) + 255) & ~(size_t)255;
     grid3 = hmin<u32>(hc[3], (u32)c->numCU);
     H10X_HIP(c, scratch.alloc(stride * grid3));
     H10X_HIP(c, hipMemsetAsync(scratch.p, 0xFF, stride * grid3, st));    // first[] = unseen everywhere
@@ -1240,9 +1359,30 @@ static int cluster_local_range(Ctx *c, int codeMin, int codeMax, int threshold, 
   }
 #undef H10X_LAUNCH_LDS
 #undef H10X_LAUNCH_ONE
+  // (c) labels, cluster counts and the > 255 clusters cut from the msBest column: one workgroup per barcode, classes by rank count
+  DevBuf<unsigned char> replayScratch;
+  {
+    ReplayArgs ra{}; ra.blocks = c->blocks.p; ra.blockOff = c->blockOff.p; ra.clusHash = c->clusHash.p; ra.goodPos = c->goodPos.p; ra.nGood = c->nGood.p;
+    ra.res = term.p; ra.codeMin = (u32)codeMin; ra.span = span;
+    ra.nLo = 0; ra.nHi = REPLAY_SMALL;
+    replay_kernel<true, 256><<<span, 256, replayBytes(REPLAY_SMALL), st>>>(ra);
+    if (c->maxGood > REPLAY_SMALL) {
+      H10X_HIP(c, hipFuncSetAttribute((const void *)replay_kernel<true, 1024>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)replayBytes(REPLAY_MID)));
+      ra.nLo = REPLAY_SMALL; ra.nHi = REPLAY_MID;
+      replay_kernel<true, 1024><<<span, 1024, replayBytes(REPLAY_MID), st>>>(ra);
+    }
+    if (c->maxGood > REPLAY_MID) {
+      const u32 grid = hmin<u32>(span, (u32)c->numCU);
+      ra.scratchStride = (replayBytes(c->maxGood) + 255) & ~(size_t)255;
+      H10X_HIP(c, replayScratch.alloc(ra.scratchStride * grid));
+      ra.scratch = replayScratch.p; ra.nLo = REPLAY_MID; ra.nHi = 0xFFFFFFFFu;
+      replay_kernel<false, 1024><<<grid, 1024, 0, st>>>(ra);
+    }
+    H10X_HIP(c, hipGetLastError());
+  }
   // (e) the ordered sums on a side stream beside (f) the read merges: they touch disjoint fields
   H10X_TRY(c->forkStreams(1));
-  point_sum_kernel<<<divUp(span, SUM_THREADS / WAVE), SUM_THREADS, 0, c->aux[0]>>>(c->blocks.p, c->blockOff.p, c->nGood.p, term.p, (u32)codeMin, (u32)codeMax);
+  point_sum_kernel<<<divUp(span, SUM_THREADS / WAVE), SUM_THREADS, 0, c->aux[0]>>>(c->blocks.p, c->blockOff.p, c->nGood.p, (const double *)term.p, (u32)codeMin, (u32)codeMax);
   {
     const size_t ldsSmall = mergeBytes(MERGE_SMALL_READS), ldsBig = mergeBytes(65536);
     read_merge_kernel<false><<<span, MERGE_THREADS, ldsSmall, st>>>(c->blocks.p, c->blockOff.p, c->nGood.p, c->clusHash.p, (u32)codeMin);
@@ -1273,6 +1413,7 @@ static int cluster_local_range(Ctx *c, int codeMin, int codeMax, int threshold, 
 int stageC_cluster(Ctx *c, int codeMin, int codeMax, int threshold) {
   if (!c->haveGood) return c->fail("!! you must set hashDepthRange before cluster");          // hash10x.c:1258
   if (threshold < 1) return c->fail("clusterThreshold %d must be >= 1 (the reference reads an uninitialised msBest otherwise)", threshold);
+  if (c->maxGoodDepth > RES_COUNT_MAX) return c->fail("a hash of the depth range lies in %u barcodes: beyond %u, the limit of this build", c->maxGoodDepth, RES_COUNT_MAX);
   const u32 nGlobal = c->sharded ? c->nBlocksGlobal : c->nBlocks;
   if (!codeMin) codeMin = 1;                                                                    // hash10x.c:1243-1244
   if (!codeMax) codeMax = (int)nGlobal;
@@ -1385,7 +1526,7 @@ int stageC_split(Ctx *c) {
   H10X_HIP(c, hipStreamSynchronize(st));
   c->blocks.swap(newB); c->blockOff.swap(newOff); c->clusHash.swap(out);
   c->nBlocks = nNew;
-  c->haveGood = false; c->goodPos.release(); c->nGood.release(); c->goodEntries.release();      // lists refer to the old blocks: a new --hashDepthRange is required
+  c->haveGood = false; c->goodPos.release(); c->nGood.release(); c->goodEntries.release(); c->goodRow.release();      // lists refer to the old blocks: a new --hashDepthRange is required
   if (c->sharded) H10X_TRY(shard_split(c, subBefore.p, totalSub));   // new blocks get their global numbers; the hash owners rebuild their lists
   else { c->segs.n = 1; c->segs.s[0] = BlockSeg{0, nNew, 0}; H10X_TRY(stageB_buildCSR(c)); }   // hash10x.c:1008-1012: hashCodes rebuilt, hashDepth unchanged
   c->tstop(T_SPLIT);
