@@ -223,8 +223,8 @@ def main():
     # ---------------- digest-only cases: inputs regenerated by gen_fqb (seeded), outputs pinned by sha256
     def digest_case(name, gen, B, extra):
         p = os.path.join(tmp, name + ".fqb")
-        recs = orc.gen_fqb(p, **gen)
-        pre = [a for a in extra[:2]] if extra and extra[0] == "-ct" else []
+        recs = orc.digest_input(p, gen)
+        pre = orc.leading_options(extra)
         args = ["-B", B] + pre + ["--readFQB", name + ".fqb"] + extra[len(pre):] + ["--writeHash", name + ".hash"]
         ref(args, tmp)
         data = orc.canonical_hash_bytes(open(os.path.join(tmp, name + ".hash"), "rb").read())
@@ -244,6 +244,11 @@ def main():
     # a barcode with > 65535 unique hashes is ignored by clustering (hash10x.c:748-753)
     digest_case("big65k.c", dict(pairs=36000, barcodes=3, genome=3000000, err=0.01, seed=3, mol=12.0), 20,
                 ["--hashDepthRange", 1, 3, "--cluster", 1, 0])
+
+    # a barcode with > 65535 read pairs (ClusterHash.read is U16: hash10x.c:37,180): BIG also has > 65535 hashes, BIG2 has few
+    # hashes and is clustered with its late reads stored modulo 2^16; -c must exceed the longest run (hash10x.c:206)
+    digest_case("pairs65k.c", {"builder": "pairs65k"}, 22, ["-c", 200000, "-ct", 2, "--hashDepthRange", 4, 30, "--cluster", 1, 0])
+    digest_case("pairs65k.split", {"builder": "pairs65k"}, 22, ["-c", 200000, "-ct", 2, "--hashDepthRange", 4, 30, "--cluster", 1, 0, "--clusterSplit"])
 
     # BASELINE configs[2] proportions (500 Mb x 2, 200 M pairs, 1 M barcodes, e = 0.1 %) at 1/10 and 1/4 scale: the ranked and the
     # hashed placement of first[] at their natural sizes. The reference needs 4.5 and 12.5 minutes for them, so they are only

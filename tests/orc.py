@@ -342,3 +342,45 @@ def make_record(barcode_word, read1_tail_codes, read2_codes):
     rec[29] = 0x007FFFFF
     assert rec[0] == barcode_word
     return rec
+
+
+def build_pairs65k(path):
+    """Input of the > 65535-read-pairs edge (ClusterHash.read is U16: hash10x.c:37,180): seeded records of gen_fqb
+    regrouped so that the file holds, between ordinary barcodes, BIG = ~84 k distinct pairs under one barcode (more than 65535
+    pairs AND more than 65535 unique hashes: ignored by clustering, hash10x.c:748-753) and BIG2 = 66 000 records repeating 400
+    pairs followed by ~5 k new pairs (more than 65535 pairs but few hashes: clustered, its late reads stored modulo 2^16 and so
+    sharing read numbers with early ones). Needs -c 200000; the last barcode is the file's unhashed trailing block."""
+    base = gen_fqb(str(path) + ".base", pairs=330000, barcodes=60, genome=400000, err=0.004, seed=23, mol=6.0, mol_len=20000)
+    os.remove(str(path) + ".base")
+    w0 = base[:, 0]
+    starts = np.flatnonzero(np.r_[True, w0[1:] != w0[:-1]]).tolist() + [len(w0)]
+    run = lambda r, n=None: base[starts[r]: (starts[r + 1] if n is None else min(starts[r] + n, starts[r + 1]))]
+    parts = [run(r, 1500) for r in range(0, 3)]
+    big = np.concatenate([run(r) for r in range(30, 44)]).copy(); big[:, 0] = 0x0BADC0DE
+    big[:, 1:] = big[:, 1:]                                   # (bases 16.. of read 1 keep their own barcode's tail: never hashed before base 23)
+    parts.append(big)
+    parts += [run(r, 1500) for r in range(3, 14)]
+    rep = run(45, 400)
+    big2 = np.concatenate([np.tile(rep, (165, 1)), run(46), run(47)]).copy(); big2[:, 0] = 0x5EED5EED
+    parts.append(big2)
+    parts += [run(r, 1500) for r in range(14, 30)]
+    parts.append(run(58, 300))                                # trailing block: never hashed (SURVEY F5)
+    out = np.concatenate(parts).astype(np.uint32)
+    assert len(big) > 70000 and len(big2) > 66000 + 4000
+    out.tofile(str(path))
+    return out
+
+
+def digest_input(path, gen):
+    """records of a digest case of tests/golden/manifest.json: seeded gen_fqb parameters, or {"builder": name} for a hand-arranged set"""
+    if "builder" in gen:
+        return globals()["build_" + gen["builder"]](path)
+    return gen_fqb(path, **gen)
+
+
+def leading_options(extra):
+    """the option pairs (-ct n, -c n) at the head of a digest case's argument list: they go in front of --readFQB"""
+    n = 0
+    while n + 1 < len(extra) and str(extra[n]) in ("-ct", "-c"):
+        n += 2
+    return list(extra[:n])

@@ -49,10 +49,10 @@ def test_hip_matches_reference_golden(case, workdir):
 
 @pytest.mark.parametrize("case", MAN["digest_cases"], ids=[c["name"] for c in MAN["digest_cases"]])
 def test_hip_matches_reference_digests(case, workdir):
-    recs = orc.gen_fqb(workdir.file(case["name"] + ".fqb"), **case["gen"])
+    recs = orc.digest_input(workdir.file(case["name"] + ".fqb"), case["gen"])
     assert orc.sha256(recs.tobytes()) == case["input_sha256"]
     extra = list(case["args"])
-    pre = extra[:2] if extra and extra[0] == "-ct" else []
+    pre = orc.leading_options(extra)
     args = ["-B", case["B"]] + pre + ["--readFQB", case["name"] + ".fqb"] + extra[len(pre):] + ["--writeHash", "out.hash"]
     run_commands(_factory(), args, workdir.path)
     got = open(workdir.file("out.hash"), "rb").read()
@@ -531,6 +531,46 @@ def test_cli_crib_reports_match_reference(workdir):
             assert a == b, "--gpus %d, line %d differs:\n  hip: %s\n  ref: %s" % (gpus, i, a, b)
         assert len(got) == len(exp) and len(got) > 400
         assert any("OTHER" in ln for ln in got) and any(" mul," in ln for ln in got)
+        got_hash = open(workdir.file("hip%d.hash" % gpus), "rb").read()
+        assert got_hash == exp_hash, "--gpus %d: %s" % (gpus, orc.describe_diff(got_hash, exp_hash))
+
+
+@pytest.mark.skipif(not orc.have_ref(), reason="oracle/_ref not present")
+def test_cli_barcode_with_more_than_65535_pairs(workdir):
+    """ClusterHash.read is a U16 (hash10x.c:37,180), so a barcode with more than 65535 read pairs has its late
+    reads stored modulo 2^16 — stage A sends such a block to the global-memory mosh path, the read merge and the reports size
+    their per-read tables by nRead. Input (orc.build_pairs65k): BIG = 74 k pairs and > 65535 hashes (ignored by clustering,
+    hash10x.c:748-753), BIG2 = 75 k pairs of which the first 66 000 repeat 400 pairs (clustered; its late reads share numbers
+    with early ones), ordinary barcodes around them. The README's recipe behind it (range, cluster, report, split, cluster
+    again): .hash bytes and every report line of bin/hash10x-amd equal the reference binary's, on one GPU and on 3 shards.
+    (The same set is pinned by two reference digests in manifest.json: test_hip_matches_reference_digests[pairs65k.*].)"""
+    import subprocess
+    orc.build_pairs65k(workdir.file("x.fqb"))
+    args = ["-B", "22", "-c", "200000", "-ct", "2", "--readFQB", "x.fqb", "--hashDepthRange", "4", "30", "--cluster", "1", "0", "--clusterReport", "0", "0",
+            "--codeStats", "--clusterSplit", "--hashDepthRange", "4", "30", "--cluster", "1", "0", "--clusterReport", "0", "0", "--codeStats", "--writeHash", "ref.hash"]
+    r = orc.run_ref(args, workdir.path)
+    assert r.returncode == 0, r.stderr.decode()
+
+    def report(txt):
+        keep = ("  CLUSTER_SUMMARY", "    CODE_CLUSTER", "  MIN_POINT_DENSITY", "CODE_SIZE_", "CODE_CLUSTER_")
+        return [ln for ln in txt.decode().splitlines() if ln.startswith(keep)]
+    exp = report(r.stdout)
+    exp_hash = orc.canonical_hash_bytes(open(workdir.file("ref.hash"), "rb").read())
+    hf = orc.HashFile(exp_hash)
+    assert len(exp) > 100 and int(hf.blocks["nRead"].max()) > 65535
+    # with a chunk size below the longest run the reference dies on this file, and so must we (hash10x.c:206)
+    rbad = orc.run_ref(["-B", "22", "-c", "70000", "--readFQB", "x.fqb"], workdir.path)
+    assert rbad.returncode != 0 and b"FATAL ERROR: chunkSize too small" in rbad.stderr
+    bad = subprocess.run([os.path.join(orc.REPO, "bin", "hash10x-amd"), "-B", "22", "-c", "70000", "--readFQB", "x.fqb"], cwd=workdir.path, stderr=subprocess.PIPE, stdout=subprocess.PIPE)
+    assert bad.returncode == 255 and b"FATAL ERROR: chunkSize too small" in bad.stderr
+    for gpus in (1, 3):
+        g = subprocess.run([os.path.join(orc.REPO, "bin", "hash10x-amd")] + (["--gpus", str(gpus)] if gpus > 1 else []) +
+                           [a if a != "ref.hash" else "hip%d.hash" % gpus for a in args], cwd=workdir.path, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+        assert g.returncode == 0, g.stderr.decode()
+        got = report(g.stdout)
+        for i, (x, y) in enumerate(zip(got, exp)):
+            assert x == y, "--gpus %d, line %d differs:\n  hip: %s\n  ref: %s" % (gpus, i, x, y)
+        assert len(got) == len(exp)
         got_hash = open(workdir.file("hip%d.hash" % gpus), "rb").read()
         assert got_hash == exp_hash, "--gpus %d: %s" % (gpus, orc.describe_diff(got_hash, exp_hash))
 

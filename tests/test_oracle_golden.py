@@ -56,10 +56,10 @@ def test_oracle_matches_reference_golden(case, workdir):
 
 @pytest.mark.parametrize("case", MAN["digest_cases"], ids=[c["name"] for c in MAN["digest_cases"]])
 def test_oracle_matches_reference_digests(case, workdir):
-    recs = orc.gen_fqb(workdir.file(case["name"] + ".fqb"), **case["gen"])
+    recs = orc.digest_input(workdir.file(case["name"] + ".fqb"), case["gen"])
     assert orc.sha256(recs.tobytes()) == case["input_sha256"], "gen_fqb is not reproducing the seeded input"
     extra = list(case["args"])
-    pre = extra[:2] if extra and extra[0] == "-ct" else []
+    pre = orc.leading_options(extra)
     args = ["-B", case["B"]] + pre + ["--readFQB", case["name"] + ".fqb"] + extra[len(pre):] + ["--writeHash", "out.hash"]
     run_commands(lambda k, w, r, B: orc.Oracle(k, w, r, B), args, workdir.path)
     got = open(workdir.file("out.hash"), "rb").read()
