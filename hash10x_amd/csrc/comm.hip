@@ -124,7 +124,11 @@ struct SockComm : Comm {
       pollfd pf[2]; int k = 0, io = -1, ii = -1;
       if (nOut) { pf[k] = pollfd{fdOut, POLLOUT, 0}; io = k++; }
       if (nIn) { pf[k] = pollfd{fdIn, POLLIN, 0}; ii = k++; }
-      if (poll(pf, (nfds_t)k, 60000) <= 0) return -1;
+      // ranks that share a GPU serialise their kernels: a peer may be minutes behind at config-3 scale; signals interrupt poll
+      static const int timeoutMs = [] { const char *e = getenv("H10X_SOCK_TIMEOUT_MS"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 1800000; }();
+      const int pr = poll(pf, (nfds_t)k, timeoutMs);
+      if (pr < 0) { if (errno == EINTR) continue; return -1; }
+      if (pr == 0) { errno = ETIMEDOUT; return -1; }
       if (io >= 0 && (pf[io].revents & (POLLOUT | POLLERR | POLLHUP))) { const ssize_t w = send(fdOut, out, nOut > (1u << 20) ? (1u << 20) : nOut, MSG_DONTWAIT | MSG_NOSIGNAL); if (w < 0 && errno != EAGAIN && errno != EWOULDBLOCK) return -1; if (w > 0) { out += w; nOut -= (size_t)w; } }
       if (ii >= 0 && (pf[ii].revents & (POLLIN | POLLERR | POLLHUP))) { const ssize_t r = recv(fdIn, in, nIn, MSG_DONTWAIT); if (r == 0 || (r < 0 && errno != EAGAIN && errno != EWOULDBLOCK)) return -1; if (r > 0) { in += r; nIn -= (size_t)r; } }
     }
@@ -193,13 +197,14 @@ int h10x_comm_create_rccl(h10x_comm **out, int rank, int nranks, const void *id1
 int h10x_comm_create_socket(h10x_comm **out, int rank, int nranks, const char *addr, int basePort, char *err, int errlen) {
   *out = nullptr;
   auto bad = [&](const char *what) { if (err) snprintf(err, (size_t)errlen, "socket communicator, rank %d: %s: %s", rank, what, strerror(errno)); return -1; };
+  if (nranks < 1 || rank < 0 || rank >= nranks || basePort < 1 || basePort + nranks - 1 > 65535) { errno = EINVAL; return bad("rank / port range (basePort + nranks - 1 must be <= 65535)"); }
   SockComm *sc = new SockComm(); sc->rank = rank; sc->n = nranks; sc->fd.assign((size_t)nranks, -1);
   sockaddr_in a; memset(&a, 0, sizeof a); a.sin_family = AF_INET;
   if (inet_pton(AF_INET, addr && *addr ? addr : "127.0.0.1", &a.sin_addr) != 1) { delete sc; errno = EINVAL; return bad("address"); }
   int srv = -1; const int one = 1;
   if (rank < nranks - 1) {                                   // the higher ranks connect to me
     srv = socket(AF_INET, SOCK_STREAM, 0);
-    setsockopt(srv, SOL_SOCKET, SO_REUSEADDR, &one, sizeof one);
+    if (srv < 0 || setsockopt(srv, SOL_SOCKET, SO_REUSEADDR, &one, sizeof one)) { if (srv >= 0) close(srv); delete sc; return bad("socket"); }
     a.sin_port = htons((uint16_t)(basePort + rank));
     if (srv < 0 || bind(srv, (sockaddr *)&a, sizeof a) || listen(srv, nranks)) { if (srv >= 0) close(srv); delete sc; return bad("listen"); }
   }
@@ -226,6 +231,32 @@ int h10x_comm_create_socket(h10x_comm **out, int rank, int nranks, const char *a
   }
   if (srv >= 0) close(srv);
   *out = new h10x_comm{sc};
+  return 0;
+}
+
+int h10x_comm_create_rccl_all(h10x_comm **outs, int nranks, const int *devices, char *err, int errlen) {
+  for (int i = 0; i < nranks; ++i) outs[i] = nullptr;
+  for (int i = 0; i < nranks; ++i) for (int j = 0; j < i; ++j)
+    if (devices[i] == devices[j]) { if (err) snprintf(err, (size_t)errlen, "RCCL needs one device per rank: ranks %d and %d share device %d", j, i, devices[i]); return -1; }
+  std::vector<ncclComm_t> nc((size_t)nranks, nullptr);
+  const ncclResult_t rc = ncclCommInitAll(nc.data(), nranks, devices);
+  if (rc != ncclSuccess) { if (err) snprintf(err, (size_t)errlen, "ncclCommInitAll failed: %s", ncclGetErrorString(rc)); return -1; }
+  for (int i = 0; i < nranks; ++i) { RcclComm *r = new RcclComm(); r->rank = i; r->n = nranks; r->nc = nc[(size_t)i]; outs[i] = new h10x_comm{r}; }
+  return 0;
+}
+
+int h10x_device_enable_peers(const int *devices, int n) {
+  int prev = 0; (void)hipGetDevice(&prev);
+  for (int i = 0; i < n; ++i) for (int j = 0; j < n; ++j) {
+    if (i == j || devices[i] == devices[j]) continue;
+    int can = 0;
+    if (hipDeviceCanAccessPeer(&can, devices[i], devices[j]) != hipSuccess || !can) continue;
+    if (hipSetDevice(devices[i]) != hipSuccess) continue;
+    const hipError_t e = hipDeviceEnablePeerAccess(devices[j], 0);
+    if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) (void)hipGetLastError();
+  }
+  (void)hipGetLastError();
+  (void)hipSetDevice(prev);
   return 0;
 }
 

@@ -206,6 +206,8 @@ struct Ctx {
   int64_t optStamps = 0;      // diagnostic: per-phase wall-clock stamps in cluster_kernel
   int64_t optChunk = 0;       // -c <chunkSize> of the reference's readFQB loop (hash10x.c:202-223): 0 = no chunk semantics (no "chunkSize too small", no
                               // all-A-barcode quirk); set by the session layer for --readFQB
+  int64_t optChunkEof = 1;    // the records given end the file (no -N cut): the reference's loop then makes one more pass, which dies if the last
+                              // block holds chunkSize records (hash10x.c:205-208); 0 = -N ended the loop
   std::vector<u64> mergePoints; bool replayDone = false;     // records whose barcode change does NOT start a block (chunk replay; consumed by stageA_run)
   int64_t optRowShift = -1;   // testing knob: force the list alignment of the sharded rows[] (-1 = as small as the offsets allow)
   int64_t optDeltaLists = -1; // in-range barcode lists travel delta-coded between ranks: -1 = when there is more than one rank, 0 never, 1 always (tests)
@@ -304,7 +306,7 @@ int stageA_sortRecords(Ctx *c, const u32 *dIn, u64 nRecords, u32 *dOut);
 int stageA_runStarts(Ctx *c, const u32 *dRec, u64 nRec, std::vector<u64> &starts, std::vector<u32> &zeroRuns);
 // the reference's chunk loop replayed over the runs of the whole file: 1 = "chunkSize too small"; merges = records (file positions) that
 // start a run but not a block (an all-A barcode's run ended exactly at a chunk boundary: hash10x.c:212)
-int replayChunks(const std::vector<u64> &starts, const std::vector<u32> &zeroRuns, u64 chunk, std::vector<u64> &merges);   // stable sort of .fqb records by their first 4 bytes
+int replayChunks(const std::vector<u64> &starts, const std::vector<u32> &zeroRuns, u64 chunk, std::vector<u64> &merges, bool eofPass);   // stable sort of .fqb records by their first 4 bytes
 int stageB_run(Ctx *c, DevBuf<u64> &entHash, DevBuf<u32> &entCode, DevBuf<u32> &entRead);
 int stageB_buildCSR(Ctx *c);                   // rows/rowStart from clusHash + hashDepth (fillHashTable)
 int stageB_finishClusHash(Ctx *c, DevBuf<u64> &key);   // key[e] = index << 32 | read16 in block order -> clusHash sorted per block

@@ -1,5 +1,6 @@
 // h10x_api.hip — the C ABI of include/h10x.h over the stage drivers. No torch, no CPU fallback.
 #include "common.hpp"
+#include "comm.hpp"
 #include <cstdlib>
 #include <ctime>
 #include <new>
@@ -117,8 +118,7 @@ int h10x_read_fqb_device(h10x_ctx *h, const uint32_t *dRec, uint64_t n) {
   timespec t0, t1, t2; clock_gettime(CLOCK_MONOTONIC, &t0);
   DevBuf<u64> entHash; DevBuf<u32> entCode, entRead;
   c.wantPacked = !c.optNoPack;
-  H10X_TRY(stageA_run(&c, dRec, n, entHash, entCode, entRead));
-  c.wantPacked = false;
+  { const int rcA = stageA_run(&c, dRec, n, entHash, entCode, entRead); c.wantPacked = false; if (rcA) return rcA; }   // (the flag must not outlive a failed run)
   c.segs.n = 1; c.segs.s[0] = BlockSeg{0, c.nBlocks, 0};
   clock_gettime(CLOCK_MONOTONIC, &t1);
   H10X_TRY(stageB_run(&c, entHash, entCode, entRead));
@@ -232,9 +232,31 @@ int h10x_shard_load_state(h10x_ctx *h, const uint32_t *hashIndex, uint32_t hashN
   H10X_TRY(enter(c));
   if (!c.comm) return c.fail("h10x_shard_load_state: no communicator attached");
   Comm *cm = c.comm;
-  H10X_TRY(upload_state(c, hashIndex, hashNumber, hashValue, hashDepth, localBlocks, nLocalBlocks, localClusHash));
+  // upload_state validates THIS rank's cut of the file only: every rank learns the verdict of all before the first
+  // collective of the adoption, or a rank that fails alone would leave the others waiting for it for ever
+  const int rcUp = upload_state(c, hashIndex, hashNumber, hashValue, hashDepth, localBlocks, nLocalBlocks, localClusHash);
   c.comm = cm;
+  u64 bad = rcUp ? 1 : 0; std::vector<u64> all((size_t)cm->n);
+  const std::string mine = c.err;
+  if (cm->allgatherHost(&c, &bad, all.data(), 8)) return -1;
+  if (rcUp) { c.err = mine; return rcUp; }
+  for (int r = 0; r < cm->n; ++r) if (all[(size_t)r]) return c.fail("rank %d failed to load its part of the hash file", r);
   return shard_adoptLoadedState(&c, cm, codeBase, nBlocksGlobal);
+}
+/* collective over the attached communicator, with or without a loaded state: do all ranks say ok? (a rank that failed on its own
+   — a short read, no memory — says so here instead of leaving the others in the next collective) */
+int h10x_shard_agree(h10x_ctx *h, int ok, int *allOk) {
+  if (!h || !allOk) return -1;
+  Ctx &c = h->c;
+  H10X_TRY(enter(c));
+  if (!c.comm) { *allOk = ok ? 1 : 0; return 0; }
+  u64 bad = ok ? 0 : 1; std::vector<u64> all((size_t)c.comm->n);
+  const std::string mine = c.err;
+  if (c.comm->allgatherHost(&c, &bad, all.data(), 8)) return -1;
+  c.err = mine;
+  *allOk = 1;
+  for (int r = 0; r < c.comm->n; ++r) if (all[(size_t)r]) *allOk = 0;
+  return 0;
 }
 
 int h10x_depth_range(h10x_ctx *h, int32_t lo, int32_t hi) {
@@ -312,6 +334,7 @@ int h10x_shard_read_fqb_device(h10x_ctx *h, const uint32_t *dRec, uint64_t n) {
   if (!c.comm) return c.fail("h10x_shard_read_fqb: no communicator attached");
   if (n && !dRec) return c.fail("h10x_shard_read_fqb_device: null records");
   Comm *cm = c.comm;
+  c.wantPacked = false;                                      // (the sharded path sends unpacked entries: shard.hip)
   reset_state(c);
   c.comm = cm;
   return shard_readFqb(&c, cm, dRec, n);
@@ -500,6 +523,7 @@ int h10x_set_option(h10x_ctx *h, const char *name, int64_t value) {
   if (!strcmp(name, "index_no_pack")) { h->c.optNoPack = value; return 0; }
   if (!strcmp(name, "cluster_stamps")) { h->c.optStamps = value; return 0; }
   if (!strcmp(name, "chunk_size")) { if (value < 0) return h->c.fail("chunk_size must be >= 0"); h->c.optChunk = value; return 0; }
+  if (!strcmp(name, "chunk_eof_pass")) { h->c.optChunkEof = value ? 1 : 0; return 0; }
   if (!strcmp(name, "shard_row_shift")) { if (value < -1 || value > 8) return h->c.fail("shard_row_shift must be -1..8"); h->c.optRowShift = value; return 0; }
   if (!strcmp(name, "shard_delta_lists")) { if (value < -1 || value > 1) return h->c.fail("shard_delta_lists must be -1, 0 or 1"); h->c.optDeltaLists = value; return 0; }
   if (!strcmp(name, "shard_rows_fake_base")) { if (value < 0) return h->c.fail("shard_rows_fake_base must be >= 0"); h->c.optRowsFakeBase = value; return 0; }

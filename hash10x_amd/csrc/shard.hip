@@ -198,7 +198,7 @@ int shard_readFqb(Ctx *c, Comm *cm, const u32 *dRec, u64 nRec) {
     }
     starts.push_back(recBase[N]);
     std::vector<u64> merges;
-    if (replayChunks(starts, zeroRuns, (u64)c->optChunk, merges)) return c->fail("chunkSize too small");       // hash10x.c:206
+    if (replayChunks(starts, zeroRuns, (u64)c->optChunk, merges, c->optChunkEof != 0)) return c->fail("chunkSize too small");       // hash10x.c:206
     c->mergePoints.clear();
     for (u64 m : merges) {
       for (int r = 1; r < N; ++r) if (m == recBase[r] && recsOf[r])

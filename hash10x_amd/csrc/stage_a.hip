@@ -429,7 +429,7 @@ int stageA_sortRecords(Ctx *c, const u32 *dIn, u64 n, u32 *dOut) {
 // boundaries and nothing else: a block with chunkSize or more records dies ("chunkSize too small"), and — `if (!barcode)
 // barcode = u[0]` at every chunk start (hash10x.c:212) — a run of the all-A barcode (word 0) that ends exactly at a chunk
 // boundary swallows the run behind it. Both are replayed here from the run starts alone.
-int replayChunks(const std::vector<u64> &starts, const std::vector<u32> &zeroRuns, u64 chunk, std::vector<u64> &merges) {
+int replayChunks(const std::vector<u64> &starts, const std::vector<u32> &zeroRuns, u64 chunk, std::vector<u64> &merges, bool eofPass) {
   merges.clear();
   const size_t R = starts.size() - 1; const u64 total = starts[R];
   if (!R || !total) return 0;
@@ -453,6 +453,10 @@ int replayChunks(const std::vector<u64> &starts, const std::vector<u32> &zeroRun
     head = starts[q];
     pos = end;
   }
+  // Unless -N ended the loop (hash10x.c:202: `while (!N || nReads < N)`), the reference comes round once more at end of file and
+  // tests `chunkSize - b->nRead <= 0` BEFORE the fread that finds the end (hash10x.c:205-208): a file whose last block holds
+  // exactly chunkSize records dies there
+  if (eofPass && open && total - head >= chunk) return 1;
   return 0;
 }
 
@@ -507,7 +511,7 @@ int stageA_run(Ctx *c, const u32 *dRec, u64 nRec, DevBuf<u64> &entHash, DevBuf<u
     if (c->optChunk > 0 && !c->replayDone) {                 // the reference's chunk loop over this (whole) file
       std::vector<u64> starts; std::vector<u32> zeroRuns;
       H10X_TRY(stageA_runStarts(c, dRec, nRec, starts, zeroRuns));
-      if (replayChunks(starts, zeroRuns, (u64)c->optChunk, c->mergePoints)) return c->fail("chunkSize too small");   // hash10x.c:206
+      if (replayChunks(starts, zeroRuns, (u64)c->optChunk, c->mergePoints, c->optChunkEof != 0)) return c->fail("chunkSize too small");   // hash10x.c:206
     }
     c->replayDone = false;
     head_flags_kernel<<<g, 256, 0, st>>>(dRec, nRec, flags.p);

@@ -90,6 +90,9 @@ int64_t h10x_host_check_chunks(const uint32_t *rec, uint64_t total, int N, int c
     if (!cur) cur = rec[30 * pos];                                                      /* hash10x.c:212 */
     for (; pos < end; ++pos) { const uint32_t b = rec[30 * pos]; if (b == cur) ++runLen; else { cur = b; runLen = 1; } }
   }
+  /* unless -N ended the loop (`while (!N || nReads < N)`), the reference comes round once more and tests the chunk size before
+     the fread that finds the end of the file (hash10x.c:205-208) */
+  if (!(N > 0 && (uint64_t)N <= total) && runLen >= (uint64_t)chunk) { if (err) snprintf(err, (size_t)errlen, "chunkSize too small"); return -1; }
   return (int64_t)limit;
 }
 
@@ -176,8 +179,9 @@ static int after_readFQB(h10x_session *s) {
    "chunkSize too small" death and the all-A-barcode quirk) are replayed inside the library from the run starts */
 int h10x_session_readFQB_mem(h10x_session *s, const uint32_t *rec, uint64_t n) {
   if (session_init(s)) return -1;
+  const int cutByN = s->N > 0 && (uint64_t)s->N <= n;                                 /* -N ends the reference's loop before its pass at end of file */
   if (s->N > 0 && (uint64_t)s->N < n) n = (uint64_t)s->N;
-  if (h10x_set_option(s->ctx, "chunk_size", s->chunk)) return fail_ctx(s);
+  if (h10x_set_option(s->ctx, "chunk_size", s->chunk) || h10x_set_option(s->ctx, "chunk_eof_pass", !cutByN)) return fail_ctx(s);
   if (h10x_read_fqb(s->ctx, rec, n)) return fail_ctx(s);
   return after_readFQB(s);
 }
@@ -213,21 +217,22 @@ static int stream_records(h10x_session *s, const char *path, uint64_t first, uin
   *devOut = dev;
   return 0;
 }
-static int file_records(h10x_session *s, const char *path, uint64_t *n) {
+static int file_records(h10x_session *s, const char *path, uint64_t *n, int *cutByN) {
   struct stat sb;
   if (stat(path, &sb)) return fail(s, "failed to open fqb file %s", path);
   *n = (uint64_t)sb.st_size / 120;                                                   /* fread(u,120,…) ignores a partial tail */
+  if (cutByN) *cutByN = s->N > 0 && (uint64_t)s->N <= *n;                            /* -N ends the reference's loop before its pass at end of file */
   if (s->N > 0 && (uint64_t)s->N < *n) *n = (uint64_t)s->N;
   return 0;
 }
 
 int h10x_session_readFQB(h10x_session *s, const char *path) {
-  uint64_t n = 0; void *dev;
-  if (file_records(s, path, &n)) return -1;
+  uint64_t n = 0; void *dev; int cutByN = 0;
+  if (file_records(s, path, &n, &cutByN)) return -1;
   if (session_init(s)) return -1;
   if (stream_records(s, path, 0, n, &dev)) return -1;
   int rc = 0;
-  if (h10x_set_option(s->ctx, "chunk_size", s->chunk) || h10x_read_fqb_device(s->ctx, (const uint32_t *)dev, n)) rc = fail_ctx(s);
+  if (h10x_set_option(s->ctx, "chunk_size", s->chunk) || h10x_set_option(s->ctx, "chunk_eof_pass", !cutByN) || h10x_read_fqb_device(s->ctx, (const uint32_t *)dev, n)) rc = fail_ctx(s);
   h10x_device_free(s->device, dev);
   return rc ? rc : after_readFQB(s);
 }
@@ -249,10 +254,11 @@ int h10x_session_shardReadFQB_dev(h10x_session *s, h10x_comm *comm, const uint32
 int h10x_session_shardReadFQB_file(h10x_session *s, h10x_comm *comm, const char *path, uint64_t first, uint64_t n) {
   if (session_init(s)) return -1;
   if (h10x_shard_attach(s->ctx, comm)) return fail(s, "h10x_shard_attach failed");
-  void *dev;
+  void *dev; uint64_t nFile = 0; int cutByN = 0;
+  if (file_records(s, path, &nFile, &cutByN)) return -1;
   if (stream_records(s, path, first, n, &dev)) return -1;
   int rc = 0;
-  if (h10x_set_option(s->ctx, "chunk_size", s->chunk) || h10x_shard_read_fqb_device(s->ctx, (const uint32_t *)dev, n)) rc = fail_ctx(s);
+  if (h10x_set_option(s->ctx, "chunk_size", s->chunk) || h10x_set_option(s->ctx, "chunk_eof_pass", !cutByN) || h10x_shard_read_fqb_device(s->ctx, (const uint32_t *)dev, n)) rc = fail_ctx(s);
   h10x_device_free(s->device, dev);
   return rc ? rc : after_readFQB(s);
 }
@@ -311,9 +317,10 @@ int h10x_session_writeHash(h10x_session *s, const char *path) {
                  oBlocksHdr = oDepth + 4 * depthDim, oBlocks = oBlocksHdr + 32, oClus = oBlocks + 32 * blocksDim, total = oClus + 8 * z.nEntriesGlobal;
   int fd = -1, rc = 0; enum { BUF = 32 << 20 }; void *buf = malloc(BUF);
   h10x_shard_seg *segs = (h10x_shard_seg *)calloc((size_t)z.nSegs + 1, sizeof *segs);
-  if (!buf || !segs) { rc = fail(s, "out of host memory for .hash export"); goto done; }
-  if (h10x_shard_segments(s->ctx, segs, z.nSegs + 1)) { rc = fail_ctx(s); goto done; }
-  if (z.rank == 0) {
+  /* (a failure of one rank up to here is carried into the agreement below: nobody skips a collective) */
+  if (!buf || !segs) rc = fail(s, "out of host memory for .hash export");
+  else if (h10x_shard_segments(s->ctx, segs, z.nSegs + 1)) rc = fail_ctx(s);
+  if (!rc && z.rank == 0) {
     fd = open(path, O_WRONLY | O_CREAT | O_TRUNC, 0666);
     if (fd < 0) rc = fail(s, "failed to open hash file %s", path);
     else if (ftruncate(fd, (off_t)total)) rc = fail(s, "write fail 1");              /* unwritten parts read as zeros: Array tails beyond max */
@@ -331,7 +338,7 @@ int h10x_session_writeHash(h10x_session *s, const char *path) {
   {                                                                                  /* the file exists (or rank 0 failed) before anybody else opens it */
     uint64_t bad = rc ? 1 : 0;
     if (h10x_shard_allreduce_max_u64(s->ctx, &bad, 1)) { rc = fail_ctx(s); goto done; }
-    if (bad) { if (!rc) rc = fail(s, "rank 0 could not create %s", path); goto done; }
+    if (bad) { if (!rc) rc = fail(s, "another rank could not prepare the export of %s", path); goto done; }
   }
   if (z.rank != 0 && (fd = open(path, O_WRONLY)) < 0) rc = fail(s, "failed to open hash file %s", path);
   if (!rc) {                                                                         /* replicated tables: rank r writes the r-th part of each */
@@ -426,7 +433,7 @@ int h10x_session_shardReadHash(h10x_session *s, h10x_comm *comm, const char *pat
   if (!f) return fail(s, "failed to open hash file %s", path);
   if (session_init(s)) { fclose(f); return -1; }
   if (h10x_shard_attach(s->ctx, comm)) { fclose(f); return fail(s, "h10x_shard_attach failed"); }
-  int rc = 0;
+  int rc = 0, agreed = 0;
   struct { char magic[4]; uint32_t version; uint16_t chs, cbs; int32_t B; } head;
   uint32_t *hashIndex = 0, *depth = 0; uint64_t *hashValue = 0; h10x_block *blocks = 0; h10x_clushash *ch = 0;
   uint32_t hashNumber = 0; array_hdr h, hb;
@@ -470,6 +477,11 @@ int h10x_session_shardReadHash(h10x_session *s, h10x_comm *comm, const char *pat
     memcpy(mine + 1, blocks + b0, (size_t)(b1 - b0) * 32);
     if (e1 > e0 && (fseeko(f, chBase + (off_t)(e0 * 8), SEEK_SET) || fread(ch, 8, e1 - e0, f) != e1 - e0)) { free(mine); rc = fail(s, "read fail 3"); goto done; }
     if (hashNumber < 1) hashNumber = 1;
+    /* every rank has read its own part by now: one that failed alone (a file cut short inside its records) must not leave
+       the others waiting in the collective load */
+    { int allOk = 0; if (h10x_shard_agree(s->ctx, 1, &allOk)) { free(mine); rc = fail_ctx(s); goto out; }
+      if (!allOk) { free(mine); rc = fail(s, "another rank failed to read its part of %s", path); goto out; } }
+    agreed = 1;
     if (h10x_shard_load_state(s->ctx, hashIndex, hashNumber, hashValue, depth, mine, nLocal, ch, b0 - 1, (uint32_t)hb.max)) rc = fail_ctx(s);
     free(mine);
     if (rc) goto done;
@@ -482,6 +494,8 @@ int h10x_session_shardReadHash(h10x_session *s, h10x_comm *comm, const char *pat
     memcpy(s->depthTail, depth + hashNumber, (size_t)(h.dim - (int)hashNumber) * 4);
   }
 done:
+  if (rc && !agreed) { int allOk = 0; (void)h10x_shard_agree(s->ctx, 0, &allOk); }    /* my failure, told to the ranks that wait for the verdict */
+out:
   fclose(f);
   free(hashIndex); free(hashValue); free(depth); free(blocks); free(ch);
   return rc;

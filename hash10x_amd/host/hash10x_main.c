@@ -67,21 +67,48 @@ static int on_all_ranks(rank_fn fn, void *arg) {
 static void die_of(int bad) { die("%s", h10x_session_error(team.s[bad - 1])); }
 static void set_all(const char *name, int v) { for (int r = 0; r < team.n; ++r) h10x_session_set(team.s[r], name, v); }
 
+/* The ranks' communicators. With a GPU per rank the exchange is RCCL over xGMI (north_star: "host code stays in C ... RCCL all-to-all
+   over xGMI"): ncclCommInitAll gives this one process a communicator per device, each driven by its rank's thread. With fewer devices
+   than ranks (a 1-GPU test box) RCCL cannot run — it refuses two ranks on a device — and the ranks use the in-process communicator
+   (device-to-device copies behind a thread barrier). H10X_COMM=local forces the latter, H10X_COMM=rccl insists on the former. */
+static const char *teamBackend = "none";
 static void set_gpus(int n) {
   if (n < 1 || n > MAX_RANKS) die("--gpus %d: must be 1..%d", n, MAX_RANKS);
   if (n == team.n) return;
   int nDev = h10x_device_count(); if (nDev < 1) nDev = 1;
-  const char *copy[] = {"k", "w", "r", "B", "N", "c", "ct", 0};
+  const char *copy[] = {"k", "w", "r", "B", "N", "c", "ct", "timing", 0};
   const int dev0 = h10x_session_get(team.s[0], "device");
+  /* a state loaded under the old team goes with it: its context is bound to that team's communicator and shard layout (the next
+     command after --gpus is a --readFQB / --readHash anyway: the parameters are latched until then, like -k -w -r -B) */
+  { h10x_session *fresh = h10x_session_new(); if (!fresh) die("out of memory");
+    for (int i = 0; copy[i]; ++i) h10x_session_set(fresh, copy[i], h10x_session_get(team.s[0], copy[i]));
+    h10x_session_set(fresh, "device", dev0);
+    h10x_session_free(team.s[0]); team.s[0] = fresh; }
   for (int r = 1; r < team.n; ++r) { h10x_session_free(team.s[r]); team.s[r] = 0; }
   for (int r = 0; r < team.n; ++r) if (team.comm[r]) { h10x_comm_destroy(team.comm[r]); team.comm[r] = 0; }
+  int devs[MAX_RANKS]; devs[0] = dev0;
   for (int r = 1; r < n; ++r) {
     if (!(team.s[r] = h10x_session_new())) die("out of memory");
     for (int i = 0; copy[i]; ++i) h10x_session_set(team.s[r], copy[i], h10x_session_get(team.s[0], copy[i]));
-    h10x_session_set(team.s[r], "device", (dev0 + r) % nDev);                          /* more ranks than devices: they share (tests on a 1-GPU box) */
+    devs[r] = (dev0 + r) % nDev;
+    h10x_session_set(team.s[r], "device", devs[r]);                                    /* more ranks than devices: they share (tests on a 1-GPU box) */
   }
-  team.n = n;
-  if (n > 1 && h10x_comm_create_local(team.comm, n)) die("h10x_comm_create_local failed");
+  team.n = n; teamBackend = "none";
+  if (n > 1) {
+    const char *want = getenv("H10X_COMM");
+    const int canRccl = n <= nDev, wantRccl = want ? !strcmp(want, "rccl") : canRccl;
+    if (want && strcmp(want, "rccl") && strcmp(want, "local")) die("H10X_COMM=%s: must be rccl or local", want);
+    if (wantRccl) {
+      char err[256] = "";
+      if (!canRccl) die("H10X_COMM=rccl: %d ranks need %d devices, %d visible (RCCL refuses two ranks on one device)", n, n, nDev);
+      if (h10x_comm_create_rccl_all(team.comm, n, devs, err, (int)sizeof err)) die("%s", err);
+      teamBackend = "rccl";
+    } else {
+      h10x_device_enable_peers(devs, n);
+      if (h10x_comm_create_local(team.comm, n)) die("h10x_comm_create_local failed");
+      teamBackend = "local";
+    }
+  }
 }
 
 /* ---- commands ---- */
@@ -206,7 +233,7 @@ static void cmd_threads(char **a) { (void)a; fprintf(stderr, "  can't set thread
 static void cmd_tables(char **a) { (void)a; printTables = !printTables; }                 /* hash10x.c:1198 */
 static void cmd_nothing(char **a) { (void)a; }
 static void cmd_help(char **a) { (void)a; usage(); }
-static void cmd_gpus(char **a) { set_gpus(atoi(a[0])); }
+static void cmd_gpus(char **a) { set_gpus(atoi(a[0])); fprintf(outFile, "  %d rank(s), communicator: %s\n", team.n, team.n > 1 ? teamBackend : "none (one GPU)"); }
 static void cmd_device(char **a) {
   int nDev = h10x_device_count(); if (nDev < 1) nDev = 1;
   for (int r = 0; r < team.n; ++r) h10x_session_set(team.s[r], "device", (atoi(a[0]) + r) % nDev);

@@ -149,6 +149,12 @@ typedef struct h10x_comm h10x_comm;
 int  h10x_comm_unique_id(void *id128);
 int  h10x_comm_create_rccl(h10x_comm **comm, int rank, int nranks, const void *id128, int device, char *err, int errlen);
 int  h10x_comm_create_local(h10x_comm **comms /* nranks outputs */, int nranks);
+/* RCCL communicators for N ranks of ONE process (ncclCommInitAll), rank r on devices[r]: what a single-process host — the C program's
+   --gpus N — uses when the box has a GPU per rank; each communicator is then driven by its rank's thread. Distinct devices required. */
+int  h10x_comm_create_rccl_all(h10x_comm **comms /* nranks outputs */, int nranks, const int *devices, char *err, int errlen);
+/* peer access between every pair of the listed devices (best effort; ranks of an in-process communicator that sit on different
+   devices then copy device to device directly instead of through the host) */
+int  h10x_device_enable_peers(const int *devices, int n);
 /* one process per rank like RCCL, but host-staged over TCP (rank r listens on basePort + r at addr): for exercising the
    multi-process launch path where RCCL cannot run — several ranks sharing one GPU on a test box. Not a production path. */
 int  h10x_comm_create_socket(h10x_comm **comm, int rank, int nranks, const char *addr, int basePort, char *err, int errlen);
@@ -206,6 +212,10 @@ int  h10x_export_slice(h10x_ctx *ctx, int table, uint64_t first, uint64_t count,
    arrays (in place), and a gather of byte strings to rank 0 (recv = the strings in rank order, counts[r] = bytes of
    rank r; recv / cap are read on rank 0 only). On an unsharded context these are the identity. */
 int  h10x_shard_barrier(h10x_ctx *ctx);
+/* do all ranks of the attached communicator say ok? Works before a state is loaded (h10x_shard_allreduce_* are the identity then):
+   a launcher whose rank failed on its own — a short read of its part of a file, no memory — reports it here, so that every rank
+   leaves with the same verdict instead of waiting in the next collective. Without a communicator *allOk = ok. */
+int  h10x_shard_agree(h10x_ctx *ctx, int ok, int *allOk);
 int  h10x_shard_allreduce_max(h10x_ctx *ctx, double *value);
 int  h10x_shard_allreduce_sum_u64(h10x_ctx *ctx, uint64_t *values, uint32_t n);
 int  h10x_shard_allreduce_max_u64(h10x_ctx *ctx, uint64_t *values, uint32_t n);

@@ -747,6 +747,121 @@ def test_all_A_barcode_run_ending_at_a_chunk_boundary(workdir):
         h = hash10x_amd.Hash10x(B=20); h.read_fqb(recs.reshape(-1), 0, 100)
 
 
+def test_last_block_of_exactly_chunk_size_records(workdir):
+    """unless -N ends it, the reference's read loop comes round once more at end of file and tests
+    `chunkSize - b->nRead <= 0` before the fread that finds the end (hash10x.c:202-208): a file whose LAST block holds exactly
+    chunkSize records dies with "chunkSize too small" although no block exceeds the chunk. -N equal to the record count ends
+    the loop first (no death); -N beyond it does not. Oracle, reference binary and the HIP path (memory image, file, CLI, 2 shards)."""
+    import subprocess
+    import hash10x_amd
+    src = orc.gen_fqb(workdir.file("x.fqb"), 3000, 12, 40000, 0.003, 5, 3.0, 150, 3000)
+    starts = [0] + [i for i in range(1, src.shape[0]) if src[i, 0] != src[i - 1, 0]] + [src.shape[0]]
+    parts = [src[starts[r]: starts[r] + 20] for r in range(4)] + [src[starts[4]: starts[4] + 30]]
+    recs = np.concatenate(parts).astype(np.uint32); n = recs.shape[0]             # blocks of 20, 20, 20, 20 and a last one of 30 records
+    recs.tofile(workdir.file("q.fqb"))
+    exe = os.path.join(orc.REPO, "bin", "hash10x-amd")
+    for N, c, dies in ((0, 30, True), (0, 31, False), (n, 30, False), (n + 5, 30, True), (n - 1, 30, False)):
+        o = orc.Oracle(B=20)
+        if dies:
+            with pytest.raises(orc.OracleError, match="chunkSize too small"):
+                o.read_fqb(recs.reshape(-1), N, c)
+        else:
+            o.read_fqb(recs.reshape(-1), N, c); o.write_hash(workdir.file("orc.hash"))
+        for how in ("mem", "file"):
+            h = hash10x_amd.Hash10x(B=20)
+            read = (lambda: h.read_fqb(recs.reshape(-1), N, c)) if how == "mem" else (lambda: h.read_fqb_file(workdir.file("q.fqb"), N, c))
+            if dies:
+                with pytest.raises(hash10x_amd.Hash10xError, match="chunkSize too small"):
+                    read()
+            else:
+                read(); h.write_hash(workdir.file("hip.hash"))
+                assert open(workdir.file("hip.hash"), "rb").read() == open(workdir.file("orc.hash"), "rb").read(), (N, c, how)
+            h.close()
+        args = ["-B", "20", "-c", str(c)] + (["-N", str(N)] if N else []) + ["--readFQB", "q.fqb", "--writeHash", "cli.hash"]
+        for gpus in (1, 2):
+            g = subprocess.run([exe] + (["--gpus", str(gpus)] if gpus > 1 else []) + args, cwd=workdir.path, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=120)
+            if dies:
+                assert g.returncode == 255 and b"FATAL ERROR: chunkSize too small" in g.stderr, (N, c, gpus, g.stderr.decode()[-300:])
+            else:
+                assert g.returncode == 0, g.stderr.decode()
+                assert open(workdir.file("cli.hash"), "rb").read() == open(workdir.file("orc.hash"), "rb").read(), (N, c, gpus)
+        if orc.have_ref():
+            r = orc.run_ref(["-B", 20, "-c", c] + (["-N", N] if N else []) + ["--readFQB", "q.fqb", "--writeHash", "ref.hash"], workdir.path)
+            assert (r.returncode != 0 and b"chunkSize too small" in r.stderr) if dies else r.returncode == 0, (N, c, r.stderr.decode()[-300:])
+            if not dies:
+                assert orc.canonical_hash_bytes(open(workdir.file("ref.hash"), "rb").read()) == open(workdir.file("orc.hash"), "rb").read()
+
+
+@pytest.mark.parametrize("gpus", [2, 3])
+def test_sharded_read_hash_of_a_truncated_file_fails_on_every_rank(workdir, gpus):
+    """every rank of a sharded --readHash preads its own ClusterHash records, so a file cut short inside the LAST
+    rank's records fails on that rank alone ("read fail 3") — the others must hear of it before they enter the collective load
+    instead of waiting for ever. Likewise a bad hash index inside one rank's cut ("corrupt hash file" from that rank's validation)."""
+    import subprocess
+    exe = os.path.join(orc.REPO, "bin", "hash10x-amd")
+    data = orc.read_maybe_gz(os.path.join(orc.GOLDEN, "small.c_3_14_2.hash.gz"))
+    hf = orc.HashFile(data)
+    open(workdir.file("short.hash"), "wb").write(data[:-4000])                  # ends inside the last rank's records
+    bad = bytearray(data); bad[-8:-4] = (hf.hash_number + 5).to_bytes(4, "little")  # last ClusterHash.hash: the last rank's cut only
+    open(workdir.file("bad.hash"), "wb").write(bad)
+    for name, msg in (("short.hash", b"read fail 3"), ("bad.hash", b"corrupt hash file")):
+        g = subprocess.run([exe, "--gpus", str(gpus), "-B", "20", "--readHash", name, "--hashDepthRange", "3", "14", "--cluster", "1", "0"], cwd=workdir.path,
+                           stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=120)
+        assert g.returncode == 255 and b"FATAL ERROR" in g.stderr, g.stderr.decode()[-500:]
+        assert msg in g.stderr or b"another rank failed" in g.stderr or b"failed to load its part" in g.stderr, g.stderr.decode()[-500:]
+
+
+def test_cli_gpus_changed_between_commands(workdir):
+    """--gpus after a state was loaded drops that state with its team (its context is bound to the old communicator):
+    the commands that follow a new --readFQB give the golden bytes; a command that needs a state right after the change is told so."""
+    import subprocess
+    workdir.need("small.fqb.gz")
+    exe = os.path.join(orc.REPO, "bin", "hash10x-amd")
+    exp = orc.read_maybe_gz(os.path.join(orc.GOLDEN, "small.e2e.hash.gz"))
+    tail = ["--readFQB", "small.fqb", "--hashDepthRange", "3", "14", "--cluster", "1", "0", "--writeHash"]
+    g = subprocess.run([exe, "-B", "20", "-ct", "2", "--gpus", "3", "--readFQB", "small.fqb", "--gpus", "1"] + tail + ["a.hash", "--gpus", "2"] + tail + ["b.hash"],
+                       cwd=workdir.path, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    assert g.returncode == 0, g.stderr.decode()
+    assert open(workdir.file("a.hash"), "rb").read() == exp and open(workdir.file("b.hash"), "rb").read() == exp
+    g = subprocess.run([exe, "-B", "20", "--gpus", "2", "--readFQB", "small.fqb", "--gpus", "1", "--hashDepthRange", "3", "14", "--writeHash", "c.hash"],
+                       cwd=workdir.path, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    assert g.returncode == 255 and b"no hash state loaded" in g.stderr, g.stderr.decode()[-500:]
+
+
+def _device_count():
+    import hash10x_amd
+    return hash10x_amd.device_count()
+
+
+@pytest.mark.skipif("_device_count() < 2", reason="RCCL needs one GPU per rank: this box has fewer than 2")
+def test_rccl_two_gpus_cli_and_two_processes(workdir):
+    """RCCL with more than one rank (needs a box with two GPUs; skipped on the 1-GPU test boxes): (1) the C program's --gpus 2 builds its
+    team with ncclCommInitAll and must give the golden bytes; (2) two PROCESSES, one GPU each, rendezvous by ncclUniqueId over a file
+    (tests/shard_worker.py --comm rccl) through --clusterSplit and the slice-wise --writeHash, equal to the oracle."""
+    import subprocess, sys
+    workdir.need("small.fqb.gz")
+    exe = os.path.join(orc.REPO, "bin", "hash10x-amd")
+    exp = orc.read_maybe_gz(os.path.join(orc.GOLDEN, "small.e2e.hash.gz"))
+    env = dict(os.environ, H10X_COMM="rccl")
+    g = subprocess.run([exe, "-B", "20", "-ct", "2", "--gpus", "2", "--readFQB", "small.fqb", "--hashDepthRange", "3", "14", "--cluster", "1", "0", "--writeHash", "r.hash"],
+                       cwd=workdir.path, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600, env=env)
+    assert g.returncode == 0, g.stderr.decode()[-1500:]
+    assert b"communicator: rccl" in g.stdout
+    assert open(workdir.file("r.hash"), "rb").read() == exp
+    recs = orc.gen_fqb(workdir.file("x.fqb"), 40000, 180, 300000, 0.003, 61, 4.0, 150, 6000)
+    o = orc.Oracle(B=20)
+    o.read_fqb(recs); o.depth_range(4, 30); o.cluster(1, 0, 3); o.cluster_split(); o.depth_range(4, 30); o.cluster(1, 0, 3)
+    o.write_hash(workdir.file("orc.hash"))
+    worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), "shard_worker.py")
+    ps = [subprocess.Popen([sys.executable, worker, str(r), "2", "rccl:" + workdir.file("uid.bin"), workdir.file("x.fqb"), "20", "4", "30", "3", workdir.file("p.hash")],
+                           stdout=subprocess.PIPE, stderr=subprocess.PIPE) for r in range(2)]
+    outs = [p.communicate(timeout=600) for p in ps]
+    for p, (so, se) in zip(ps, outs):
+        assert p.returncode == 0, se.decode()[-1500:]
+    got, want = open(workdir.file("p.hash"), "rb").read(), open(workdir.file("orc.hash"), "rb").read()
+    assert got == want, orc.describe_diff(got, want)
+
+
 def test_corrupt_hash_file_is_refused(workdir):
     """--readHash checks what it later uses as an index: a hash index beyond hashNumber in clusHash or in
     hashIndex[] gives an error message, not a device fault."""
