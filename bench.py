@@ -71,6 +71,109 @@ def generate(wl, seed):
     return out
 
 
+def _gen_lib():
+    so = os.path.join(REPO, "build", "libgen_fqb.so")
+    if not os.path.exists(so):
+        import __graft_entry__
+        __graft_entry__.build()
+    g = ctypes.CDLL(so)
+    g.h10x_gen2_plan_new.restype = ctypes.c_void_p
+    g.h10x_gen2_plan_new.argtypes = [ctypes.POINTER(GenParams)]
+    g.h10x_gen2_offsets.restype = ctypes.POINTER(ctypes.c_uint64)
+    g.h10x_gen2_offsets.argtypes = [ctypes.c_void_p]
+    g.h10x_gen2_cut.restype = ctypes.c_uint32
+    g.h10x_gen2_cut.argtypes = [ctypes.c_void_p, ctypes.c_uint64]
+    g.h10x_gen2_fill.restype = ctypes.c_uint64
+    g.h10x_gen2_fill.argtypes = [ctypes.c_void_p, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_void_p]
+    g.h10x_gen2_free.argtypes = [ctypes.c_void_p]
+    return g
+
+
+def generate_v2(wl, seed, part=0, parts=1):
+    """Generator v2 (gen_fqb.c: counter-based streams, OpenMP): the records of part `part` of `parts` of the data set — the barcodes
+    whose records start in [P part / parts, P (part + 1) / parts) — WITHOUT generating the rest: a rank of a sharded run builds only
+    its own shard. Returns (records, first record of the part in the whole set, pairs of the whole set)."""
+    g = _gen_lib()
+    p = GenParams(wl["pairs"], wl["barcodes"], wl["genome"], wl["err"], seed, wl["mol"], wl["snp"], wl["mol_len"])
+    plan = g.h10x_gen2_plan_new(ctypes.byref(p))
+    if not plan:
+        raise MemoryError("gen_fqb v2: plan")
+    try:
+        P, C = wl["pairs"], wl["barcodes"]
+        b0 = g.h10x_gen2_cut(plan, P * part // parts) if part else 0
+        b1 = g.h10x_gen2_cut(plan, P * (part + 1) // parts) if part + 1 < parts else C
+        off = g.h10x_gen2_offsets(plan)
+        first, n = int(off[b0]), int(off[b1]) - int(off[b0])
+        out = np.empty(max(n, 1) * 30, dtype=np.uint32)
+        got = g.h10x_gen2_fill(plan, b0, b1, out.ctypes.data)
+        assert got == n
+        return out[: n * 30], first, P
+    finally:
+        g.h10x_gen2_free(plan)
+
+
+# ---- a checksum of a clustered state that ranks can add up: every 8-byte word of the ClusterBlock array (heap-pointer word zeroed) and of
+# the ClusterHash records, in the FILE's numbering, goes through a 64-bit mixer together with its position, and the results are summed
+# mod 2^64 under two different salts. A rank sums over its own segments; the sum over ranks is what the same function gives for the
+# reference binary's .hash (tests/golden/make_golden.py --scale commits those under "bench_scale_digests").
+_SALTS = (0x243F6A8885A308D3, 0x13198A2E03707344)
+
+
+def _mix64(x):
+    x = (x ^ (x >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+    x = (x ^ (x >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+    return x ^ (x >> np.uint64(31))
+
+
+def checksum_words(words, first_index, domain):
+    """[sum over i of mix(words[i] ^ mix(first_index + i + salt + domain))] for the two salts, mod 2^64"""
+    w = np.ascontiguousarray(words, dtype=np.uint64)
+    out = []
+    with np.errstate(over="ignore"):
+        for salt in _SALTS:
+            tot = np.uint64(0)
+            for a in range(0, w.size, 1 << 24):
+                part = w[a: a + (1 << 24)]
+                idx = np.arange(part.size, dtype=np.uint64) + np.uint64((first_index + a + salt + domain * 0x9E3779B97F4A7C15) & 0xFFFFFFFFFFFFFFFF)
+                tot = tot + np.sum(_mix64(part ^ _mix64(idx)), dtype=np.uint64)
+            out.append(int(tot))
+    return out
+
+
+def checksum_state(block_bytes, first_block, clushash_bytes, first_entry):
+    b = np.frombuffer(bytes(block_bytes), dtype=np.uint64).copy() if not isinstance(block_bytes, np.ndarray) else block_bytes.view(np.uint64).copy()
+    b[2::4] = 0                                             # ClusterBlock.clusHash: a heap pointer in the reference's file
+    c = np.frombuffer(bytes(clushash_bytes), dtype=np.uint64) if not isinstance(clushash_bytes, np.ndarray) else clushash_bytes.view(np.uint64)
+    x, y = checksum_words(b, 4 * first_block, 1), checksum_words(c, first_entry, 2)
+    return [(x[0] + y[0]) & 0xFFFFFFFFFFFFFFFF, (x[1] + y[1]) & 0xFFFFFFFFFFFFFFFF]
+
+
+def sharded_state_checksum(h, rank):
+    """this rank's share of checksum_state over the whole data set, summed over the ranks (collective)"""
+    mine = [0, 0]
+    for sg in h.shard_segments():
+        if sg["rank"] != rank:
+            continue
+        ls, cnt, gb = sg["localStart"], sg["count"], sg["globalBase"]
+        if gb == 0:                                          # slot 0 of the block array is nobody's block (hash10x.c:200): left out on both sides
+            ls, cnt, gb = ls + 1, cnt - 1, 1
+        blocks = h.export_slice(3, ls, cnt) if cnt > 0 else np.zeros(0, dtype=np.uint8)
+        for a in range(0, max(sg["entries"], 1), 1 << 25):   # ClusterHash records 256 MB at a time
+            n = min(1 << 25, sg["entries"] - a)
+            ch = h.export_slice(4, sg["localEntryStart"] + a, n) if n > 0 else np.zeros(0, dtype=np.uint8)
+            part = checksum_state(blocks if a == 0 else np.zeros(0, dtype=np.uint8), gb, ch, sg["globalEntryStart"] + a)
+            mine = [(mine[0] + part[0]) & 0xFFFFFFFFFFFFFFFF, (mine[1] + part[1]) & 0xFFFFFFFFFFFFFFFF]
+    return h.shard_allreduce_sum_u64(mine)
+
+
+def scaled_workload(wl, world):
+    """weak scaling: `world` times the yeast-scale set (pairs, barcodes, genome; table bits grow with log2)"""
+    w = dict(wl)
+    w["pairs"] *= world; w["barcodes"] *= world; w["genome"] *= world
+    w["B"] += (world - 1).bit_length()
+    return w
+
+
 def rendezvous_unique_id(rank, world, hash10x_amd):
     """RCCL bootstrap without torch in the process (torch ships its own HIP/RCCL runtimes; a second runtime next to
     libh10x_hip's cost ~3 ms per step at N = 1): rank 0 draws the ncclUniqueId and serves "H10X" + its 128 bytes on
@@ -128,6 +231,21 @@ def rendezvous_unique_id(rank, world, hash10x_amd):
                 return buf[4:]
         time.sleep(0.2)
     raise RuntimeError("rendezvous: rank 0 did not answer on %s:%r" % (addr, ports))
+
+
+# K1's ceiling is the integer multiplier, not HBM: hashFunc (seqhash.c:58-59) is a 64 x 64 -> low 64 multiply = 1 v_mad_u64_u32 + 2 v_mul_lo_u32
+# per k-mer and strand. scratch/valu_rate64.hip measured their issue cost on this chip at 4.9 and 4.2 SIMD cycles per wave instruction
+# (plain 32-bit ops: 2), so a multiply-ONLY kernel on 1024 SIMDs at 2.4 GHz would do 64 lanes x 1024 x 2.4e9 / (4.9 + 2 x 4.2) per second.
+INT_PEAK_U64_MUL_PER_S = 64 * 1024 * 2.4e9 / (4.9 + 2 * 4.2)
+
+
+def mosh_int_ops(kmers, ms_per_step):
+    if not ms_per_step:
+        return {"u64_multiplies_per_s": None, "kmers_per_step": kmers}
+    rate = 2.0 * kmers / (ms_per_step * 1e-3)
+    return {"u64_multiplies_per_s": rate, "kmers_per_step": kmers, "int_peak_u64_multiplies_per_s": INT_PEAK_U64_MUL_PER_S, "frac_of_int_peak": rate / INT_PEAK_U64_MUL_PER_S,
+            "int_peak_derivation": "64 lanes x 1024 SIMDs x 2.4 GHz / (4.9 + 2 x 4.2) SIMD cycles per u64 multiply (v_mad_u64_u32 + 2 v_mul_lo_u32, rates measured by scratch/valu_rate64.hip); "
+                                   "the multiplies are 13 of the ~250 SIMD cycles a wave spends per 64 k-mer slots (DESIGN 3, K1), so the kernel as a whole cannot reach it"}
 
 
 def cpu_model():
@@ -198,6 +316,33 @@ def cpu_baseline(wl, recs, workdir, gpu_hash_path):
                              "(of which ~%.2fs are --readHash / fillHashTable / goodHashes / --writeHash, serial)" % (cores, o_read, o_clu, other),
                    "read_pairs_per_s_hashed": pairs / o_read, "second_process_seconds": o_clu,
                    "cluster_seconds_estimate": max(o_clu - other, 1e-9), "parity_with_1_thread": "identical" if omp_canon == ref_canon else "DIFFERENT"}
+        # end to end as a user runs it: the C program (bin/hash10x-amd), file in, file out, one process — next to the reference's two
+        e2e = None
+        exe = os.path.join(REPO, "bin", "hash10x-amd")
+        if os.path.exists(exe):
+            cmd = [exe, "-B", str(wl["B"]), "-ct", str(wl["ct"]), "--readFQB", "bench.fqb", "--hashDepthRange", str(wl["lo"]), str(wl["hi"]), "--cluster", "1", "0", "--writeHash", "cli.hash"]
+            best = None
+            for _ in range(2):                               # the second run has the file in the page cache, like the reference's runs above
+                t0 = time.perf_counter()
+                g = subprocess.run(cmd, cwd=workdir, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+                dt = time.perf_counter() - t0
+                if g.returncode != 0:
+                    raise RuntimeError("hash10x-amd failed: " + g.stderr.decode()[-300:])
+                best = dt if best is None or dt < best else best
+            walls = {}
+            cmdname = None
+            for line in g.stdout.decode().splitlines():     # the program's own per-command wall seconds (its resource lines)
+                if line.startswith("COMMAND "):
+                    cmdname = line.split()[1]
+                elif line.startswith("user") and cmdname and "wall" in line:
+                    walls[cmdname] = walls.get(cmdname, 0.0) + float(line.split()[-1])
+            cli_same = open(os.path.join(workdir, "cli.hash"), "rb").read() == gpu_canon
+            os.remove(os.path.join(workdir, "cli.hash"))
+            e2e = {"command": "hash10x-amd -B %d --readFQB bench.fqb --hashDepthRange %d %d --cluster 1 0 --writeHash cli.hash" % (wl["B"], wl["lo"], wl["hi"]),
+                   "wall_seconds": best, "read_pairs_per_s": pairs / best, "includes": "process start, HIP context, file read (page cache) + H2D in 64 MB slabs, all kernels, D2H + file write of the .hash",
+                   "per_command_wall_seconds": walls, "reference_two_processes_wall_seconds": w_read + w_clu, "speedup_vs_reference_1thread": (w_read + w_clu) / best,
+                   "reference_omp_wall_seconds": (o_read + o_clu) if omp else None, "hash_identical_to_library_path": cli_same}
+        one["end_to_end"] = e2e
         return one, omp, parity
     o = orc.Oracle(B=wl["B"])
     t0 = time.perf_counter(); o.read_fqb(recs); t1 = time.perf_counter()
@@ -229,7 +374,7 @@ def secondary_block(hash10x_amd, local_rank):
     del recs
     h = hash10x_amd.Hash10x(B=wl["B"], device=local_rank)
     h.enable_timing(True)
-    steps, wall, tm = 2, [], {}
+    steps, wall, tm = 5, [], {}
     for it in range(steps + 1):                             # one warm-up
         hash10x_amd.synchronize(local_rank)
         t = time.perf_counter()
@@ -244,7 +389,7 @@ def secondary_block(hash10x_amd, local_rank):
     alg = 4.0 * c["cluster_main"][1] + 14.0 * c["cluster_main"][0] + 16.0 * c["cluster_main"][2]
     clu_all_ms = tm["cluster_kernel"][0] / steps
     alg_all = 4.0 * c["sum_good_depth"] + 14.0 * c["sum_good"] + 16.0 * c["sum_hash_clustered"]
-    c3_traffic = c3_src = None                              # rocprofv3 --pmc passes of this workload, committed under profiles/
+    c3_traffic = c3_src = c3_head = c3_build = None          # rocprofv3 --pmc passes of this workload, committed under profiles/
     try:
         import glob
         cands = sorted(glob.glob(os.path.join(REPO, "profiles", "*config3*_pmc_traffic.json")))
@@ -252,7 +397,7 @@ def secondary_block(hash10x_amd, local_rank):
             pm = json.load(open(cands[-1]))
             tb = sum(sum(x["bytes_per_step"] for x in v.values()) for k, v in pm["kernels"].items() if pm.get("dominant", "cluster_kernel") in k)
             if tb:
-                c3_traffic, c3_src = tb, os.path.basename(cands[-1])
+                c3_traffic, c3_src, c3_head, c3_build = tb, os.path.basename(cands[-1]), pm.get("head"), pm.get("build_id")
     except Exception:
         pass
     out = {"workload": "config3-tenth-20M (BASELINE configs[2] proportions at 1/10: 20 M pairs, 100 k barcodes, 50 Mb x 2, e = 0.1 %, -B 26)",
@@ -265,7 +410,8 @@ def secondary_block(hash10x_amd, local_rank):
                         "frac": alg / (main_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if main_ms else None, "algorithmic_bytes_per_launch": alg, "avg_launch_ms": main_ms,
                         "barcodes_in_launch": c["cluster_main"][3],
                         "all_cluster_launches": {"GB/s": alg_all / (clu_all_ms * 1e-3) / 1e9 if clu_all_ms else None, "ms_per_step": clu_all_ms, "algorithmic_bytes": alg_all}},
-           "generate_seconds": gen_s, "traffic": c3_traffic, "traffic_source": c3_src,
+           "generate_seconds": gen_s, "traffic": c3_traffic, "traffic_source": c3_src, "traffic_head": c3_head, "traffic_build_id": c3_build,
+           "traffic_stale": (c3_build != hash10x_amd.build_id()) if c3_traffic is not None else None,
            "parity": "tests/test_gpu_parity.py::test_config3_proportions_match_reference_digests pins this exact set (sha256 of the reference binary's .hash)"}
     h.close(); d.free()
     return out
@@ -306,10 +452,7 @@ def main():
     if world > 1 or args.sharded:
         # weak scaling: N times the yeast-scale set (N x pairs, barcodes and genome; table bits grow with log2 N),
         # barcodes sharded over the ranks, hash index exchanged by RCCL all-to-all (csrc/shard.hip)
-        wl["pairs"] *= world
-        wl["barcodes"] *= world
-        wl["genome"] *= world
-        wl["B"] += (world - 1).bit_length()
+        wl = scaled_workload(wl, world)
         ndev = hash10x_amd.device_count()
         backend = args.comm if args.comm != "auto" else ("socket" if world > max(ndev, 1) else "rccl")
         if backend == "socket":
@@ -318,11 +461,15 @@ def main():
                                            int(os.environ.get("MASTER_PORT", "29500")) + 61)
         else:
             comm = hash10x_amd.Comm.rccl(rank, world, rendezvous_unique_id(rank, world, hash10x_amd), local_rank)
-    recs = generate(wl, seed=1)                              # every rank builds the same seeded set and keeps its shard
-    total_pairs = recs.size // 30
-    if comm is not None:
-        cut = hash10x_amd.partition(recs, world)
-        recs = recs[30 * cut[rank]: 30 * cut[rank + 1]].copy()
+    t_gen = time.perf_counter()
+    if comm is None:
+        recs = generate(wl, seed=1)                          # N = 1: the v1 set (the one the committed digests and profiles are of)
+        total_pairs = recs.size // 30
+    else:
+        # N > 1: every rank generates ONLY its shard (generator v2: counter-based streams, OpenMP) — barcodes whose records start in
+        # [P r / N, P (r + 1) / N)
+        recs, first_record, total_pairs = generate_v2(wl, 1, rank, world)
+    gen_s = time.perf_counter() - t_gen
     pairs = recs.size // 30
     d_recs = hash10x_amd.DeviceRecords(recs, device=local_rank)   # resident in HBM before the timed region
     hash10x_amd.synchronize(local_rank)
@@ -407,7 +554,7 @@ def main():
 
     # HBM traffic of the dominant kernel: PMC counters cannot be read from inside this process; the figure is the
     # one measured by the committed rocprofv3 --pmc passes (profiles/*_pmc_traffic.json), per step, raw counters
-    traffic = traffic_src = None
+    traffic = traffic_src = traffic_head = traffic_build = None
     try:
         import glob
         cands = sorted(f for f in glob.glob(os.path.join(REPO, "profiles", "*_pmc_traffic.json")) if "config3" not in os.path.basename(f))
@@ -416,6 +563,7 @@ def main():
             tb = sum(sum(c["bytes_per_step"] for c in v.values()) for k, v in pm["kernels"].items() if (pm.get("dominant") or dom.split("_")[0]) in k)
             if tb:
                 traffic, traffic_src = tb, os.path.basename(cands[-1])
+                traffic_head, traffic_build = pm.get("head"), pm.get("build_id")
     except Exception:
         traffic = None
 
@@ -435,6 +583,10 @@ def main():
         "entries_H": H, "distinct_U": U, "hashNumber": sizes["hashNumber"], "fallback_blocks": ctr["fallback_blocks"],
         "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+                     # the counters are collected by rocprofv3 --pmc passes of their own (they cannot be read in this process): the figure is of
+                     # the build recorded beside it, and stale when that is not the library running now
+                     "traffic_head": traffic_head, "traffic_build_id": traffic_build,
+                     "traffic_stale": (traffic_build != hash10x_amd.build_id()) if traffic is not None else None,
                      "algorithmic_bytes_per_launch": alg[dom], "avg_launch_ms": dom_ms, "barcodes_in_launch": ctr["cluster_main"][3] if dom == "cluster_main" else None,
                      "other_kernels": {k: {"GB/s": alg[k] / (per[k][2] * 1e-3) / 1e9, "frac": alg[k] / (per[k][2] * 1e-3) / 1e9 / HBM_PEAK_GBS, "ms_per_step": per[k][2],
                                            "algorithmic_bytes": alg[k]} for k in alg if k in per and per[k][2] > 0},
@@ -442,15 +594,35 @@ def main():
                                      "ms_per_step": index_ms, "algorithmic_bytes": index_alg, "timers": "sort_by_hash + index_rank + probe_table + clushash_build"},
                      # K1 is bounded by integer ALU, not HBM: 2 x 64-bit multiplies per k-mer (seqhash.c:58-59), 237 k-mers per pair at k = 21;
                      # SQ_INSTS_VALU per launch is in profiles/*_pmc_sq.json (collected by rocprofv3 in passes of their own)
-                     "mosh_extract_int_ops": {"u64_multiplies_per_s": 2.0 * ctr["kmers"] / (per["mosh_extract"][2] * 1e-3) if per.get("mosh_extract", (0, 0, 0))[2] else None,
-                                              "kmers_per_step": ctr["kmers"]}},
+                     "mosh_extract_int_ops": mosh_int_ops(ctr["kmers"], per.get("mosh_extract", (0, 0, 0))[2])},
     }
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    out["generate_seconds"] = round(gen_s, 2)
+    out["build_id"] = hash10x_amd.build_id()
+    if world > 1 or args.sharded:
+        # correctness gate of a sharded run: a checksum of every rank's blocks and ClusterHash records in file numbering,
+        # summed over the ranks, against the one of the REFERENCE binary's .hash of this data set (tests/golden/manifest.json,
+        # "bench_scale_digests", made in the build container by make_golden.py --scale)
+        try:
+            cs = sharded_state_checksum(h, rank)
+            ctr_entries_global = h.shard_info()["nEntriesGlobal"]
+            man = json.load(open(os.path.join(REPO, "tests", "golden", "manifest.json")))
+            exp = man.get("bench_scale_digests", {}).get(str(world))
+            out["state_checksum"] = ["0x%016x" % v for v in cs]
+            if exp is None:
+                out["parity_vs_reference_digest"] = "no reference digest committed for x%d" % world
+            else:
+                same = [int(v, 16) for v in exp["checksum"]] == cs and exp["hash_number"] == sizes["hashNumber"] and exp["sum_nHash"] == ctr_entries_global
+                out["parity_vs_reference_digest"] = "identical" if same else "DIFFERENT (reference %s, H %d, hashNumber %d)" % (exp["checksum"], exp["sum_nHash"], exp["hash_number"])
+        except Exception as e:
+            out["parity_vs_reference_digest"] = "check failed: " + str(e)[:200]
+    if rank == 0 and world == 1 and not args.sharded and not args.no_cpu_baseline:
         with tempfile.TemporaryDirectory() as d:
             gp = os.path.join(d, "gpu.hash")
             h.write_hash(gp)
             try:
                 cb, omp, parity = cpu_baseline(wl, recs, d, gp)
+                if cb.get("end_to_end"):
+                    out["end_to_end"] = cb.pop("end_to_end")
                 out["cpu_baseline"] = cb
                 if omp:
                     out["cpu_baseline_omp"] = omp

@@ -103,6 +103,8 @@ def load_native():
     hip.h10x_comm_destroy.argtypes = [vp]
     hip.h10x_shard_barrier.argtypes = [vp]
     hip.h10x_shard_allreduce_max.argtypes = [vp, ctypes.POINTER(ctypes.c_double)]
+    hip.h10x_shard_allreduce_sum_u64.argtypes = [vp, vp, ctypes.c_uint32]
+    hip.h10x_build_id.restype = cs
     hip.h10x_device_malloc.restype = vp
     hip.h10x_device_malloc.argtypes = [ci, cu64]
     hip.h10x_device_free.argtypes = [ci, vp]
@@ -130,6 +132,11 @@ def load_native():
 
 def device_count():
     return load_native()[0].h10x_device_count()
+
+
+def build_id():
+    """what libh10x_hip.so was built from: "<git describe or 'nogit'> src:<sha256 of its sources, 16 hex>" (embedded at build time)"""
+    return load_native()[0].h10x_build_id().decode()
 
 
 class DeviceRecords:
@@ -309,6 +316,19 @@ class Hash10x:
         v = ctypes.c_double(value)
         self._chk_ctx(self._hip.h10x_shard_allreduce_max(self._ctx(), ctypes.byref(v)))
         return v.value
+
+    def shard_allreduce_sum_u64(self, values):
+        """sums (mod 2^64) over the ranks of a small list of integers; the identity on an unsharded context"""
+        v = np.array([int(x) & 0xFFFFFFFFFFFFFFFF for x in values], dtype=np.uint64)
+        self._chk_ctx(self._hip.h10x_shard_allreduce_sum_u64(self._ctx(), v.ctypes.data, len(v)))
+        return [int(x) for x in v]
+
+    def export_slice(self, table, first, count):
+        """elements [first, first + count) of one table of THIS rank (h10x_export_slice; works on shards): 3 = blocks (32 B), 4 = ClusterHash (8 B)"""
+        width = {0: 4, 1: 8, 2: 4, 3: 32, 4: 8, 5: 4}[table]
+        out = np.zeros(max(int(count), 1) * width, dtype=np.uint8)
+        self._chk_ctx(self._hip.h10x_export_slice(self._ctx(), table, int(first), int(count), out.ctypes.data))
+        return out[: int(count) * width]
 
     def shard_info(self):
         z = _ShardInfo()

@@ -1,6 +1,7 @@
 // h10x_api.hip — the C ABI of include/h10x.h over the stage drivers. No torch, no CPU fallback.
 #include "common.hpp"
 #include "comm.hpp"
+#include "build_id.h"
 #include <cstdlib>
 #include <ctime>
 #include <new>
@@ -21,6 +22,7 @@ struct h10x_ctx { Ctx c; };
 extern "C" {
 
 int h10x_abi_version(void) { return H10X_ABI_VERSION; }
+const char *h10x_build_id(void) { return H10X_BUILD_ID; }
 
 int h10x_device_count(void) {
   int n = 0;

@@ -65,6 +65,9 @@ typedef struct {
 uint64_t h10x_factor1_from_seed(int32_t seed);
 
 int  h10x_abi_version(void);
+/* "src:<first 16 hex digits of the sha256 over the .hip and .hpp files of csrc (sorted by name) and this header>": what this library
+   was built from (measurements record it; tests compare it with the sources of the tree they run in) */
+const char *h10x_build_id(void);
 /* number of HIP devices visible (0 if none / no driver); never initialises a context */
 int  h10x_device_count(void);
 

@@ -280,6 +280,34 @@ def main():
         except OSError:
             man["big_digest_cases"] = []
             man["die_cases"] = []
+    # reference digests of the weak-scaling workloads of bench.py --gpus N (N x the yeast-scale set, generator v2): the composable
+    # checksum of bench.checksum_state over the reference binary's blocks + ClusterHash records (`make_golden.py --scale`)
+    if "--scale" in sys.argv:
+        sys.path.insert(0, orc.REPO)
+        import bench
+        man["bench_scale_digests"] = {}
+        for n in (2, 4, 8):
+            wl = bench.scaled_workload(bench.WORKLOADS["yeast-like-2.5M"], n)
+            recs, _first, _total = bench.generate_v2(wl, 1)
+            recs.tofile(os.path.join(tmp, "scale.fqb"))
+            binary = "hash10x_omp" if os.path.exists(os.path.join(orc.REF_DIR, "hash10x_omp")) else "hash10x"
+            r = orc.run_ref((["-t", os.cpu_count()] if binary == "hash10x_omp" else []) + ["-B", wl["B"], "-ct", wl["ct"], "--readFQB", "scale.fqb", "--hashDepthRange", wl["lo"], wl["hi"],
+                             "--cluster", 1, 0, "--writeHash", "scale.hash"], tmp, binary=binary, timeout=7200)
+            assert r.returncode == 0, r.stderr.decode()
+            hf = orc.HashFile(open(os.path.join(tmp, "scale.hash"), "rb").read())
+            blocks = np.frombuffer(hf.blocks[1: hf.blocks_max].tobytes(), dtype=np.uint8)      # slot 0 is nobody's block
+            ch = np.frombuffer(hf.clushash.tobytes(), dtype=np.uint8)
+            cs = bench.checksum_state(blocks, 1, ch, 0)
+            man["bench_scale_digests"][str(n)] = {"workload": "yeast-like-2.5M x%d (gen_fqb v2, seed 1)" % n, "B": wl["B"], "input_sha256": orc.sha256(recs.tobytes()),
+                                                  "checksum": ["0x%016x" % v for v in cs], "hash_number": hf.hash_number, "blocks_max": hf.blocks_max,
+                                                  "sum_nHash": int(hf.blocks["nHash"].sum()), "sum_nSubCluster": int(hf.blocks["nSubCluster"].sum()), "reference_binary": binary}
+            os.remove(os.path.join(tmp, "scale.hash")); os.remove(os.path.join(tmp, "scale.fqb"))
+    else:
+        try:
+            with open(os.path.join(HERE, "manifest.json")) as f:
+                man["bench_scale_digests"] = json.load(f).get("bench_scale_digests", {})
+        except OSError:
+            man["bench_scale_digests"] = {}
     man["big_note"] = ("big_digest_cases: BASELINE configs[2] proportions at 1/10 and 1/4 scale, generated by `make_golden.py --big` from "
                        "oracle/_ref (4.5 and 12.5 minutes of the reference); only the GPU tests run them")
     with open(os.path.join(HERE, "manifest.json"), "w") as f:

@@ -299,7 +299,7 @@ def build_gen():
     src = os.path.join(REPO, "hash10x_amd", "tools", "gen_fqb.c")
     if not os.path.exists(out) or os.path.getmtime(out) < os.path.getmtime(src):
         os.makedirs(os.path.dirname(out), exist_ok=True)
-        subprocess.run(["gcc", "-O2", "-ffp-contract=off", "-o", out, src, "-lm"], check=True)
+        subprocess.run(["gcc", "-O2", "-ffp-contract=off", "-fopenmp", "-o", out, src, "-lm"], check=True)
     return out
 
 

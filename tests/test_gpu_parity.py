@@ -35,6 +35,14 @@ def test_native_library_is_the_path():
     assert hip.h10x_abi_version() == 1
     assert hash10x_amd.device_count() >= 1
     assert hip.h10x_factor1_from_seed(17) == 0x49308BB9003CB3AD
+    # the library that is mapped was built from the sources of this tree (the .so files are git-ignored and ship prebuilt)
+    import glob, hashlib
+    csrc = os.path.join(orc.REPO, "hash10x_amd", "csrc")
+    names = sorted(os.path.basename(f) for f in glob.glob(os.path.join(csrc, "*.hip")) + glob.glob(os.path.join(csrc, "*.hpp")))
+    sha = hashlib.sha256()
+    for f in [os.path.join(csrc, n) for n in names] + [os.path.join(orc.REPO, "include", "h10x.h")]:
+        sha.update(open(f, "rb").read())
+    assert hash10x_amd.build_id() == "src:" + sha.hexdigest()[:16], "libh10x_hip.so is stale: rebuild with make -C hash10x_amd/csrc"
 
 
 @pytest.mark.parametrize("case", MAN["cases"], ids=[c["name"] for c in MAN["cases"]])
@@ -860,6 +868,27 @@ def test_rccl_two_gpus_cli_and_two_processes(workdir):
         assert p.returncode == 0, se.decode()[-1500:]
     got, want = open(workdir.file("p.hash"), "rb").read(), open(workdir.file("orc.hash"), "rb").read()
     assert got == want, orc.describe_diff(got, want)
+
+
+def test_bench_with_two_ranks_carries_a_parity_gate(workdir):
+    """a correctness gate for every timed run — also with more than one rank. bench.py --gpus 2 as its launcher starts it
+    (one process per rank, RANK / WORLD_SIZE / MASTER_* in the environment; socket backend: both ranks share this box's GPU), every rank
+    generating only its own shard (gen_fqb v2): the line must say that the summed checksum of all ranks' blocks + ClusterHash records equals
+    the one of the REFERENCE binary's .hash of that data set (manifest.json "bench_scale_digests", made by make_golden.py --scale)."""
+    import subprocess, sys
+    port = 32000 + os.getpid() % 2000
+    ps = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        ps.append(subprocess.Popen([sys.executable, os.path.join(orc.REPO, "bench.py"), "--gpus", "2", "--comm", "socket", "--steps", "1", "--warmup", "0"],
+                                   stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env, cwd=workdir.path))
+    outs = [p.communicate(timeout=600) for p in ps]
+    for p, (so, se) in zip(ps, outs):
+        assert p.returncode == 0, se.decode()[-1500:]
+    line = json.loads(outs[0][0].decode().strip().splitlines()[-1])
+    assert line["n_gpus"] == 2 and line["config"]["read_pairs"] == 5000000
+    assert line["parity_vs_reference_digest"] == "identical", line
+    assert outs[1][0].decode().strip() == ""                # one JSON line, on rank 0
 
 
 def test_corrupt_hash_file_is_refused(workdir):
