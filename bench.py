@@ -334,7 +334,7 @@ def cpu_baseline(wl, recs, workdir, gpu_hash_path):
             for line in g.stdout.decode().splitlines():     # the program's own per-command wall seconds (its resource lines)
                 if line.startswith("COMMAND "):
                     cmdname = line.split()[1]
-                elif line.startswith("user") and cmdname and "wall" in line:
+                elif line.strip().startswith("user") and cmdname and "wall" in line:
                     walls[cmdname] = walls.get(cmdname, 0.0) + float(line.split()[-1])
             cli_same = open(os.path.join(workdir, "cli.hash"), "rb").read() == gpu_canon
             os.remove(os.path.join(workdir, "cli.hash"))
@@ -496,7 +496,7 @@ def main():
 
     def barrier():
         hash10x_amd.synchronize(local_rank)      # hipDeviceSynchronize (every command also syncs before returning)
-        if comm is not None:
+        if comm is not None and h._ctx():        # (no context before the first step: --warmup 0)
             h.shard_barrier()                    # RCCL allreduce
         hash10x_amd.synchronize(local_rank)
 

@@ -70,6 +70,8 @@ def load_native():
     host.h10x_session_ctx.restype = vp
     host.h10x_session_ctx.argtypes = [vp]
     host.h10x_session_readFQB.argtypes = [vp, cs]
+    host.h10x_session_begin.argtypes = [vp]
+    host.h10x_session_after_read.argtypes = [vp]
     host.h10x_session_readFQB_mem.argtypes = [vp, vp, cu64]
     host.h10x_session_readFQB_dev.argtypes = [vp, vp, cu64]
     host.h10x_session_readHash.argtypes = [vp, cs]
@@ -104,6 +106,8 @@ def load_native():
     hip.h10x_shard_barrier.argtypes = [vp]
     hip.h10x_shard_allreduce_max.argtypes = [vp, ctypes.POINTER(ctypes.c_double)]
     hip.h10x_shard_allreduce_sum_u64.argtypes = [vp, vp, ctypes.c_uint32]
+    hip.h10x_ingest_fqb.argtypes = [vp, vp, cu64, ci]
+    hip.h10x_ingest_reserve.argtypes = [vp, cu64]
     hip.h10x_build_id.restype = cs
     hip.h10x_device_malloc.restype = vp
     hip.h10x_device_malloc.argtypes = [ci, cu64]
@@ -266,6 +270,22 @@ class Hash10x:
             r = r[: r.size - r.size % 30]
         self._pre(N, chunk)
         self._chk(self._host.h10x_session_readFQB_mem(self._s, r.ctypes.data, r.size // 30))
+        self._after_init()
+
+    def ingest_fqb(self, chunks, N=0, chunk=100000, reserve=0):
+        """--readFQB through the streaming C ABI (h10x_ingest_fqb): `chunks` = an iterable of record arrays (any sizes), appended on the
+        device one by one; the last call closes the ingest. The session's parameters are latched as for read_fqb."""
+        self._pre(N, chunk)
+        self._chk(self._host.h10x_session_begin(self._s))
+        if self._hip.h10x_set_option(self._ctx(), b"chunk_size", int(chunk)):
+            raise Hash10xError(self._hip.h10x_last_error(self._ctx()).decode())
+        if reserve:
+            self._chk_ctx(self._hip.h10x_ingest_reserve(self._ctx(), int(reserve)))
+        for part in chunks:
+            r = np.ascontiguousarray(part, dtype=np.uint32).reshape(-1)
+            self._chk_ctx(self._hip.h10x_ingest_fqb(self._ctx(), r.ctypes.data, r.size // 30, 0))
+        self._chk_ctx(self._hip.h10x_ingest_fqb(self._ctx(), None, 0, 1))
+        self._chk(self._host.h10x_session_after_read(self._s))
         self._after_init()
 
     def read_fqb_file(self, path, N=0, chunk=100000):

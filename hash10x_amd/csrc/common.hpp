@@ -212,6 +212,11 @@ struct Ctx {
   int64_t optRowShift = -1;   // testing knob: force the list alignment of the sharded rows[] (-1 = as small as the offsets allow)
   int64_t optDeltaLists = -1; // in-range barcode lists travel delta-coded between ranks: -1 = when there is more than one rank, 0 never, 1 always (tests)
   int64_t optRowsFakeBase = 0; // testing knob: list offsets start at this many entries (multiple of 2^rowShift) in front of the real array: 64-bit offsets on small inputs
+  // streaming ingest (h10x_ingest_fqb): the record image grows on the device as the chunks arrive
+  DevBuf<u32> ingestBuf; u64 ingestRecords = 0, ingestCap = 0;
+  int64_t optFaultInject = 0; // test knob: the fork/join region with this number (1 mosh classes, 2 clusHash classes, 3 good-list classes, 4 cluster
+                              // classes, 5 sums beside merges) fails once between its fork and its join, then the knob clears itself
+  int faultAt(int region) { if (optFaultInject != region) return 0; optFaultInject = 0; return fail("injected fault in fork/join region %d", region); }
   bool timing = false;
   u32 *startFlags = nullptr;   // pinned host words a side-stream kernel's workgroups set when they start (stageC_cluster)
   Timer timers[T_COUNT];
@@ -277,6 +282,17 @@ struct Ctx {
     Timer &x = timers[t];
     if (x.pending) { float ms = 0; (void)hipEventSynchronize(x.b); (void)hipEventElapsedTime(&ms, x.a, x.b); x.ms += ms; x.pending = false; }
   }
+};
+
+// A fork/join region: side streams run kernels on buffers that go back to the per-stream block cache when the function returns (the
+// cache orders reuse within ONE stream only). If the function leaves early — an error between fork and join — the guard waits for every
+// stream before those destructors run; after a successful join the main stream is ordered behind the side streams and done() disarms it.
+struct ForkGuard {
+  Ctx *c; bool armed = true;
+  explicit ForkGuard(Ctx *c_) : c(c_) {}
+  ForkGuard(const ForkGuard &) = delete; ForkGuard &operator=(const ForkGuard &) = delete;
+  ~ForkGuard() { if (!armed) return; for (int i = 0; i < 3; ++i) if (c->aux[i]) (void)hipStreamSynchronize(c->aux[i]); (void)hipStreamSynchronize(c->stream); }
+  void done() { armed = false; }
 };
 
 #define H10X_HIP(ctx, call)                                                                      \

@@ -341,6 +341,61 @@ int h10x_shard_read_fqb_device(h10x_ctx *h, const uint32_t *dRec, uint64_t n) {
   c.comm = cm;
   return shard_readFqb(&c, cm, dRec, n);
 }
+/* ---- streaming ingest: the reference reads the file in chunks of chunkSize records (hash10x.c:202-223) and so can a caller of this
+   library — a chunk is copied to the device and appended to the context's record image, which grows geometrically (or to the size
+   announced by h10x_ingest_reserve); the closing call hashes the image exactly as h10x_read_fqb_device does and gives the memory back.
+   The host never holds more than one chunk. */
+static int ingest_append(Ctx &c, const uint32_t *hostRec, uint64_t n) {
+  if (n && !hostRec) return c.fail("h10x_ingest_fqb: null records");
+  const u64 need = c.ingestRecords + n;
+  if (need > c.ingestCap) {
+    u64 cap = c.ingestCap ? c.ingestCap * 2 : (u64)1 << 16;
+    if (cap < need) cap = need;
+    DevBuf<u32> bigger;
+    H10X_HIP(&c, bigger.alloc(cap * 30));
+    if (c.ingestRecords) H10X_HIP(&c, hipMemcpyAsync(bigger.p, c.ingestBuf.p, c.ingestRecords * 120, hipMemcpyDeviceToDevice, c.stream));
+    H10X_HIP(&c, hipStreamSynchronize(c.stream));            // (the old block goes back to the cache only after the copy)
+    c.ingestBuf.swap(bigger); c.ingestCap = cap;
+  }
+  if (n) {
+    H10X_HIP(&c, hipMemcpyAsync(c.ingestBuf.p + c.ingestRecords * 30, hostRec, n * 120, hipMemcpyHostToDevice, c.stream));
+    H10X_HIP(&c, hipStreamSynchronize(c.stream));            // the caller may reuse its chunk buffer when this returns
+    c.ingestRecords += n;
+  }
+  return 0;
+}
+static void ingest_drop(Ctx &c) { c.ingestBuf.release(); c.ingestRecords = 0; c.ingestCap = 0; }
+int h10x_ingest_reserve(h10x_ctx *h, uint64_t n_records) {
+  if (!h) return -1;
+  Ctx &c = h->c;
+  H10X_TRY(enter(c));
+  if (!n_records) { ingest_drop(c); return 0; }              // 0 = give up the image of an ingest that will not be closed
+  if (c.ingestRecords) return c.fail("h10x_ingest_reserve: an ingest is under way");
+  ingest_drop(c);
+  H10X_HIP(&c, c.ingestBuf.alloc(n_records * 30));
+  c.ingestCap = n_records;
+  return 0;
+}
+int h10x_ingest_fqb(h10x_ctx *h, const uint32_t *hostRec, uint64_t n, int final_chunk) {
+  if (!h) return -1;
+  Ctx &c = h->c;
+  H10X_TRY(enter(c));
+  if (const int rc = ingest_append(c, hostRec, n)) { ingest_drop(c); return rc; }
+  if (!final_chunk) return 0;
+  DevBuf<u32> image; image.swap(c.ingestBuf);                // released when this returns, whatever happens
+  const u64 total = c.ingestRecords; c.ingestRecords = 0; c.ingestCap = 0;
+  return h10x_read_fqb_device(h, image.p, total);
+}
+int h10x_shard_ingest_fqb(h10x_ctx *h, const uint32_t *hostRec, uint64_t n, int final_chunk) {
+  if (!h) return -1;
+  Ctx &c = h->c;
+  H10X_TRY(enter(c));
+  if (const int rc = ingest_append(c, hostRec, n)) { ingest_drop(c); return rc; }
+  if (!final_chunk) return 0;
+  DevBuf<u32> image; image.swap(c.ingestBuf);
+  const u64 total = c.ingestRecords; c.ingestRecords = 0; c.ingestCap = 0;
+  return h10x_shard_read_fqb_device(h, image.p, total);
+}
 int h10x_shard_read_fqb(h10x_ctx *h, const uint32_t *hostRec, uint64_t n) {
   if (!h) return -1;
   Ctx &c = h->c;
@@ -526,6 +581,7 @@ int h10x_set_option(h10x_ctx *h, const char *name, int64_t value) {
   if (!strcmp(name, "cluster_stamps")) { h->c.optStamps = value; return 0; }
   if (!strcmp(name, "chunk_size")) { if (value < 0) return h->c.fail("chunk_size must be >= 0"); h->c.optChunk = value; return 0; }
   if (!strcmp(name, "chunk_eof_pass")) { h->c.optChunkEof = value ? 1 : 0; return 0; }
+  if (!strcmp(name, "fault_inject")) { h->c.optFaultInject = value; return 0; }
   if (!strcmp(name, "shard_row_shift")) { if (value < -1 || value > 8) return h->c.fail("shard_row_shift must be -1..8"); h->c.optRowShift = value; return 0; }
   if (!strcmp(name, "shard_delta_lists")) { if (value < -1 || value > 1) return h->c.fail("shard_delta_lists must be -1, 0 or 1"); h->c.optDeltaLists = value; return 0; }
   if (!strcmp(name, "shard_rows_fake_base")) { if (value < 0) return h->c.fail("shard_rows_fake_base must be >= 0"); h->c.optRowsFakeBase = value; return 0; }

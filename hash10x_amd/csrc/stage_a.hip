@@ -564,6 +564,7 @@ int stageA_run(Ctx *c, const u32 *dRec, u64 nRec, DevBuf<u64> &entHash, DevBuf<u
   c->tstart(T_MOSH);
   // the three table classes are independent: side by side on forked streams, the few blocks with many read pairs
   // (largest tables, most lanes per workgroup) first
+  ForkGuard forkGuard(c);                                    // (declared behind every buffer the side streams touch)
   H10X_TRY(c->forkStreams(2));
 #define H10X_MOSH_LAUNCH(W, LL, FK, TH, STREAM)                                                                                    \
     { if (lds > 48 * 1024) H10X_HIP(c, hipFuncSetAttribute((const void *)mosh_lds_kernel<W, LL, FK>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
@@ -585,7 +586,9 @@ int stageA_run(Ctx *c, const u32 *dRec, u64 nRec, DevBuf<u64> &entHash, DevBuf<u
   }
 #undef H10X_MOSH_CLASS
 #undef H10X_MOSH_LAUNCH
+  H10X_TRY(c->faultAt(1));
   H10X_TRY(c->joinStreams(2));
+  forkGuard.done();
   c->tstop(T_MOSH);
 
   // ---- global path: class F plus any block whose LDS set overflowed. The usual case — no such block — is recognised

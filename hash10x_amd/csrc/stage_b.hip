@@ -214,11 +214,14 @@ static int clusHashByBlocks(Ctx *c, const u64 *entHash, const u32 *entRead, cons
   const int B = c->prm.B; const u64 w = (u64)c->prm.w; const int qBits = c->keyBits;
 #define H10X_CH_LAUNCH(T, I, LOOK, STREAM) clushash_block_kernel<T, I, LOOK><<<grid, T, 0, STREAM>>>(entHash, entRead, key, c->blockOff.p, nBlocks, table64, B, w, qBits, key ? 0 : c->entCodeBits, sortBits, c->clusHash.p)
   const int side = c->maxBlockHashes > BLOCK_SORT_CAP1 ? 2 : (c->maxBlockHashes > BLOCK_SORT_CAP0 ? 1 : 0);
+  ForkGuard forkGuard(c);
   if (side) H10X_TRY(c->forkStreams(side));                  // the few large blocks beside the many small ones
   if (key) { H10X_CH_LAUNCH(256, 12, false, st); if (side >= 1) H10X_CH_LAUNCH(512, 12, false, c->aux[0]); if (side >= 2) H10X_CH_LAUNCH(1024, 8, false, c->aux[1]); }
   else { H10X_CH_LAUNCH(256, 12, true, st); if (side >= 1) H10X_CH_LAUNCH(512, 12, true, c->aux[0]); if (side >= 2) H10X_CH_LAUNCH(1024, 8, true, c->aux[1]); }
 #undef H10X_CH_LAUNCH
+  H10X_TRY(c->faultAt(2));
   if (side) H10X_TRY(c->joinStreams(side));
+  forkGuard.done();
   H10X_HIP(c, hipGetLastError());
   return 0;                                                  // no round trip: the buffers go back to the stream-ordered block cache, the next command queues behind
 }

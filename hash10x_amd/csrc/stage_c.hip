@@ -185,6 +185,7 @@ int stageC_depthRange(Ctx *c, int lo, int hi) {
     const int sortBits = db + 1;                                              // one bit more than the largest depth: padding keys sort last
     const unsigned grid = hmin<u32>(nBlocks, 65535u * 4);
     const int side = c->maxBlockHashes > BLOCK_SORT_CAP1 ? 2 : (c->maxBlockHashes > BLOCK_SORT_CAP0 ? 1 : 0);
+    ForkGuard forkGuard(c);
     if (side) H10X_TRY(c->forkStreams(side));
 #define H10X_GOOD_LAUNCH(T, I, STREAM)                                                                                              \
     { if (wdepth8.p) good_block_kernel<T, I, u8><<<grid, T, 0, STREAM>>>(c->clusHash.p, c->blockOff.p, c->blocks.p, nBlocks, wdepth8.p, sortBits, c->goodPos.p, c->nGood.p, c->goodEntries.p, c->rowStart.p, (u32)c->rowShift, c->goodRow.p); \
@@ -193,7 +194,9 @@ int stageC_depthRange(Ctx *c, int lo, int hi) {
     if (side >= 1) H10X_GOOD_LAUNCH(512, 12, c->aux[0])
     if (side >= 2) H10X_GOOD_LAUNCH(1024, 8, c->aux[1])
 #undef H10X_GOOD_LAUNCH
+    H10X_TRY(c->faultAt(3));
     if (side) H10X_TRY(c->joinStreams(side));
+    forkGuard.done();
   }
   else if (narrow) { H10X_HIP(c, key32.alloc(H)); H10X_HIP(c, keyS32.alloc(H)); } else { H10X_HIP(c, key.alloc(H)); H10X_HIP(c, keyS.alloc(H)); }
   if (byBlocks) {}
@@ -1277,7 +1280,7 @@ static int cluster_local_range(Ctx *c, int codeMin, int codeMax, int threshold, 
   // allocated before the fork and is released after the join, which is what the block cache requires.
   // a failure between here and the join must not let the buffers above go back to the block cache while a side stream
   // still runs a kernel on them (the cache orders reuse within ONE stream only)
-  struct ForkGuard { Ctx *c; bool armed; ~ForkGuard() { if (!armed) return; for (int i = 0; i < 3; ++i) if (c->aux[i]) (void)hipStreamSynchronize(c->aux[i]); (void)hipStreamSynchronize(c->stream); } } forkGuard{c, true};
+  ForkGuard forkGuard(c);
   c->tstart(T_CLUSTER_K);
   H10X_TRY(c->forkStreams(3));
   if (hc[3]) {
@@ -1328,6 +1331,7 @@ static int cluster_local_range(Ctx *c, int codeMin, int codeMax, int threshold, 
     a.stats = stats.p; a.front = nullptr; a.nFront = 0;
   }
   H10X_HIP(c, hipGetLastError());
+  H10X_TRY(c->faultAt(4));
   H10X_TRY(c->joinStreams(3));
   u32 nOverflow = 0;
   DevBuf<unsigned char> scratch2;
@@ -1392,6 +1396,7 @@ static int cluster_local_range(Ctx *c, int codeMin, int codeMax, int threshold, 
     }
   }
   H10X_HIP(c, hipGetLastError());
+  H10X_TRY(c->faultAt(5));
   H10X_TRY(c->joinStreams(1));
   c->tstop(T_CLUSTER_K);
   u64 hs[8];
@@ -1399,7 +1404,7 @@ static int cluster_local_range(Ctx *c, int codeMin, int codeMax, int threshold, 
   H10X_TRY(c->syncReadbacks());
   c->tstop(T_CLUSTER);
   if (c->optStamps) { H10X_HIP(c, hipMemcpy(c->ctr.cluster_phase_ticks, phase.p, 64, hipMemcpyDeviceToHost)); }
-  forkGuard.armed = false;                                   // everything has been waited for
+  forkGuard.done();                                          // everything has been waited for
   if (!more) { memset(c->ctr.cluster_main, 0, sizeof c->ctr.cluster_main); memset(c->ctr.cluster_class_counts, 0, sizeof c->ctr.cluster_class_counts);
                c->ctr.sum_good = c->ctr.sum_good_depth = c->ctr.sum_hash_clustered = c->ctr.clustered_codes = c->ctr.cluster_overflow_blocks = 0; }
   for (int k = 0; k < 4; ++k) { c->ctr.cluster_main[k] += hs[4 + k]; hs[k] += hs[4 + k]; }   // re-runs of overflowed blocks count again (they did the work twice)

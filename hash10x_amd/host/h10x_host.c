@@ -175,6 +175,11 @@ static int after_readFQB(h10x_session *s) {
   return 0;
 }
 
+/* for callers that drive the library's C ABI themselves between the two (streaming ingest): initialise() with the latched parameters,
+   and the Array dims a finished --readFQB leaves */
+int h10x_session_begin(h10x_session *s) { return session_init(s) ? -1 : 0; }
+int h10x_session_after_read(h10x_session *s) { return after_readFQB(s); }
+
 /* --readFQB on an image in host memory: -N truncates (hash10x.c:202,207); the chunk loop's two side effects (the
    "chunkSize too small" death and the all-A-barcode quirk) are replayed inside the library from the run starts */
 int h10x_session_readFQB_mem(h10x_session *s, const uint32_t *rec, uint64_t n) {
@@ -194,27 +199,31 @@ int h10x_session_readFQB_dev(h10x_session *s, const uint32_t *devRec, uint64_t n
   return after_readFQB(s);
 }
 
-/* records [first, first + n) of a file into a device buffer, 64 MiB at a time: the file never sits in host memory */
-static int stream_records(h10x_session *s, const char *path, uint64_t first, uint64_t n, void **devOut) {
+/* records [first, first + n) of a file through the library's streaming ingest (h10x_ingest_fqb / h10x_shard_ingest_fqb), 64 MiB at a
+   time: the file never sits in host memory, and the closing call is the --readFQB itself (collective when sharded). A rank that fails
+   here while sharded still makes the closing call's counterpart impossible for the others, so the verdict is agreed on first. */
+static int stream_records(h10x_session *s, const char *path, uint64_t first, uint64_t n, int sharded) {
   enum { SLAB = 64 << 20 };
-  *devOut = 0;
+  int rc = 0;
   const int fd = open(path, O_RDONLY);
-  if (fd < 0) return fail(s, "failed to open fqb file %s", path);                    /* hash10x.c:1201 */
-  void *dev = h10x_device_malloc(s->device, n ? n * 120 : 120);
   char *slab = (char *)malloc(SLAB);
-  if (!dev || !slab) { close(fd); free(slab); if (dev) h10x_device_free(s->device, dev); return fail(s, "out of memory for %llu records", (unsigned long long)n); }
-  const uint64_t bytes = n * 120; uint64_t done = 0; int rc = 0;
-  while (done < bytes) {
+  if (fd < 0) rc = fail(s, "failed to open fqb file %s", path);                       /* hash10x.c:1201 */
+  else if (!slab) rc = fail(s, "out of memory for a %d MiB read buffer", SLAB >> 20);
+  else if (h10x_ingest_reserve(s->ctx, n)) rc = fail_ctx(s);
+  const uint64_t bytes = n * 120; uint64_t done = 0;
+  while (!rc && done < bytes) {
     const uint64_t want = bytes - done < SLAB ? bytes - done : SLAB;
     uint64_t got = 0;
     while (got < want) { const ssize_t r = pread(fd, slab + got, want - got, (off_t)(first * 120 + done + got)); if (r <= 0) break; got += (uint64_t)r; }
     if (got != want) { rc = fail(s, "file read problem"); break; }                   /* hash10x.c:209 */
-    if (h10x_device_upload(s->device, (char *)dev + done, slab, want)) { rc = fail(s, "upload of %llu bytes to device %d failed", (unsigned long long)want, s->device); break; }
+    if (sharded ? h10x_shard_ingest_fqb(s->ctx, (const uint32_t *)slab, want / 120, 0) : h10x_ingest_fqb(s->ctx, (const uint32_t *)slab, want / 120, 0)) { rc = fail_ctx(s); break; }
     done += want;
   }
-  close(fd); free(slab);
-  if (rc) { h10x_device_free(s->device, dev); return rc; }
-  *devOut = dev;
+  if (fd >= 0) close(fd);
+  free(slab);
+  if (sharded) { int allOk = 0; if (h10x_shard_agree(s->ctx, !rc, &allOk)) return fail_ctx(s); if (!allOk && !rc) rc = fail(s, "another rank failed to read its part of %s", path); }
+  if (rc) { h10x_ingest_reserve(s->ctx, 0); return rc; }
+  if (sharded ? h10x_shard_ingest_fqb(s->ctx, 0, 0, 1) : h10x_ingest_fqb(s->ctx, 0, 0, 1)) return fail_ctx(s);
   return 0;
 }
 static int file_records(h10x_session *s, const char *path, uint64_t *n, int *cutByN) {
@@ -227,14 +236,12 @@ static int file_records(h10x_session *s, const char *path, uint64_t *n, int *cut
 }
 
 int h10x_session_readFQB(h10x_session *s, const char *path) {
-  uint64_t n = 0; void *dev; int cutByN = 0;
+  uint64_t n = 0; int cutByN = 0;
   if (file_records(s, path, &n, &cutByN)) return -1;
   if (session_init(s)) return -1;
-  if (stream_records(s, path, 0, n, &dev)) return -1;
-  int rc = 0;
-  if (h10x_set_option(s->ctx, "chunk_size", s->chunk) || h10x_set_option(s->ctx, "chunk_eof_pass", !cutByN) || h10x_read_fqb_device(s->ctx, (const uint32_t *)dev, n)) rc = fail_ctx(s);
-  h10x_device_free(s->device, dev);
-  return rc ? rc : after_readFQB(s);
+  if (h10x_set_option(s->ctx, "chunk_size", s->chunk) || h10x_set_option(s->ctx, "chunk_eof_pass", !cutByN)) return fail_ctx(s);
+  if (stream_records(s, path, 0, n, 0)) return -1;
+  return after_readFQB(s);
 }
 
 /* ---- sharded sessions: one per rank; every call below is collective ---- */
@@ -254,13 +261,11 @@ int h10x_session_shardReadFQB_dev(h10x_session *s, h10x_comm *comm, const uint32
 int h10x_session_shardReadFQB_file(h10x_session *s, h10x_comm *comm, const char *path, uint64_t first, uint64_t n) {
   if (session_init(s)) return -1;
   if (h10x_shard_attach(s->ctx, comm)) return fail(s, "h10x_shard_attach failed");
-  void *dev; uint64_t nFile = 0; int cutByN = 0;
+  uint64_t nFile = 0; int cutByN = 0;
   if (file_records(s, path, &nFile, &cutByN)) return -1;
-  if (stream_records(s, path, first, n, &dev)) return -1;
-  int rc = 0;
-  if (h10x_set_option(s->ctx, "chunk_size", s->chunk) || h10x_set_option(s->ctx, "chunk_eof_pass", !cutByN) || h10x_shard_read_fqb_device(s->ctx, (const uint32_t *)dev, n)) rc = fail_ctx(s);
-  h10x_device_free(s->device, dev);
-  return rc ? rc : after_readFQB(s);
+  if (h10x_set_option(s->ctx, "chunk_size", s->chunk) || h10x_set_option(s->ctx, "chunk_eof_pass", !cutByN)) return fail_ctx(s);
+  if (stream_records(s, path, first, n, 1)) return -1;
+  return after_readFQB(s);
 }
 int h10x_session_shardGather(h10x_session *s) {
   if (!s->ctx) return fail(s, "no hash state loaded: use readFQB or readHash first");

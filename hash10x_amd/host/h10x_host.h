@@ -28,6 +28,8 @@ const char *h10x_session_error(const h10x_session *s);
 h10x_ctx *h10x_session_ctx(h10x_session *s);
 
 int  h10x_session_readFQB(h10x_session *s, const char *path);                         /* hash10x.c:1200-1205 */
+int  h10x_session_begin(h10x_session *s);                 /* initialise() with the latched parameters (callers that use the C ABI directly) */
+int  h10x_session_after_read(h10x_session *s);            /* Array dims as a finished --readFQB leaves them */
 int  h10x_session_readFQB_mem(h10x_session *s, const uint32_t *records, uint64_t nRecords);
 int  h10x_session_readFQB_dev(h10x_session *s, const uint32_t *devRecords, uint64_t nRecords);  /* records already in HBM */
 int  h10x_session_readHash(h10x_session *s, const char *path);                        /* hash10x.c:1206-1211 */

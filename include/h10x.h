@@ -89,6 +89,15 @@ const char *h10x_last_error(const h10x_ctx *ctx);
 /* Both return once the last launches are queued (every size the host needs has been read back by then): the next call on the
    context waits for them, and a device fault in them is reported there. */
 int  h10x_read_fqb(h10x_ctx *ctx, const uint32_t *host_records, uint64_t n_records);
+/* The same in chunks, as the reference's loop reads the file (hash10x.c:202-223: fread of chunkSize records at a time): every call
+   appends n_records records to the context's record image ON THE DEVICE (the chunk buffer is the caller's again when the call returns;
+   barcode runs may straddle chunks in any way, the runs are found over the whole image); the call with final_chunk != 0 (n_records may
+   be 0) hashes the image exactly as h10x_read_fqb_device and releases it. The host never holds more than one chunk. h10x_ingest_reserve
+   (optional, before the first chunk) announces the total so that the image is allocated once instead of growing geometrically.
+   The chunk semantics of "chunk_size" apply to the whole image as above. A failed call drops the image; h10x_ingest_reserve(ctx, 0)
+   gives up an ingest that will not be closed. */
+int  h10x_ingest_reserve(h10x_ctx *ctx, uint64_t n_records_total);
+int  h10x_ingest_fqb(h10x_ctx *ctx, const uint32_t *host_records, uint64_t n_records, int final_chunk);
 int  h10x_read_fqb_device(h10x_ctx *ctx, const uint32_t *dev_records, uint64_t n_records);
 
 /* replaces the external record sort between fq2b and hash10x (README.md:26 `bsort -k 4 -r 120 x.fqb`): orders the
@@ -175,6 +184,8 @@ int  h10x_shard_attach(h10x_ctx *ctx, h10x_comm *comm);
    set (only --writeHash and the crib read them) are built by h10x_shard_gather, not here. */
 int  h10x_shard_read_fqb(h10x_ctx *ctx, const uint32_t *host_records, uint64_t n_records);
 int  h10x_shard_read_fqb_device(h10x_ctx *ctx, const uint32_t *dev_records, uint64_t n_records);
+/* h10x_ingest_fqb for this rank's record range of the file: chunks append, the closing call runs the sharded --readFQB (collective) */
+int  h10x_shard_ingest_fqb(h10x_ctx *ctx, const uint32_t *host_records, uint64_t n_records, int final_chunk);
 /* --readHash onto shards (collective): the replicated tables of the file (hashIndex, hashValue, hashDepth: whole data set) plus THIS
    rank's contiguous cut of the file's blocks — localBlocks[0] unused, localBlocks[1 ..] = blocks codeBase + 1 .. of the file, with
    their ClusterHash records concatenated. The hash owners' barcode lists are rebuilt by an exchange (ownership by index range);

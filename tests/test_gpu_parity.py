@@ -880,7 +880,7 @@ def test_bench_with_two_ranks_carries_a_parity_gate(workdir):
     ps = []
     for r in range(2):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-        ps.append(subprocess.Popen([sys.executable, os.path.join(orc.REPO, "bench.py"), "--gpus", "2", "--comm", "socket", "--steps", "1", "--warmup", "0"],
+        ps.append(subprocess.Popen([sys.executable, os.path.join(orc.REPO, "bench.py"), "--gpus", "2", "--comm", "socket", "--steps", "1", "--warmup", "1"],
                                    stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env, cwd=workdir.path))
     outs = [p.communicate(timeout=600) for p in ps]
     for p, (so, se) in zip(ps, outs):
@@ -889,6 +889,54 @@ def test_bench_with_two_ranks_carries_a_parity_gate(workdir):
     assert line["n_gpus"] == 2 and line["config"]["read_pairs"] == 5000000
     assert line["parity_vs_reference_digest"] == "identical", line
     assert outs[1][0].decode().strip() == ""                # one JSON line, on rank 0
+
+
+def test_streaming_ingest_at_the_c_abi(workdir):
+    """h10x_ingest_fqb: the reference reads the file chunk by chunk (hash10x.c:202-223) and so can a caller of the C ABI — chunks of 7
+    records (barcode runs straddle them at random), of one record, and one chunk for everything, with and without h10x_ingest_reserve,
+    all give the golden bytes of `--readFQB small.fqb --hashDepthRange 3 14 --cluster 1 0`; -N is the caller's (fewer records fed); an
+    ingest given up half way leaves the context usable."""
+    import hash10x_amd
+    recs = np.frombuffer(orc.read_maybe_gz(os.path.join(orc.GOLDEN, "small.fqb.gz")), dtype=np.uint32).reshape(-1, 30)
+    gold = orc.read_maybe_gz(os.path.join(orc.GOLDEN, "small.e2e.hash.gz"))
+    h = hash10x_amd.Hash10x(B=20)
+    for step, reserve in ((7, 0), (1, 0), (recs.shape[0], 0), (333, recs.shape[0]), (7, recs.shape[0])):
+        h.ingest_fqb((recs[a: a + step] for a in range(0, recs.shape[0], step)), reserve=reserve)
+        h.depth_range(3, 14); h.cluster(1, 0, 2); h.write_hash(workdir.file("ing.hash"))
+        got = open(workdir.file("ing.hash"), "rb").read()
+        assert got == gold, (step, reserve, orc.describe_diff(got, gold))
+    # a barcode of chunkSize pairs dies as from a file (the chunk semantics are those of the whole image)
+    with pytest.raises(hash10x_amd.Hash10xError, match="chunkSize too small"):
+        h.ingest_fqb((recs[a: a + 50] for a in range(0, recs.shape[0], 50)), chunk=20)
+    # an ingest that is never closed: dropped by reserve(0); the context reads a file afterwards as if nothing had happened
+    hip = hash10x_amd.load_native()[0]
+    assert hip.h10x_ingest_fqb(h._ctx(), recs[:100].ctypes.data, 100, 0) == 0
+    assert hip.h10x_ingest_reserve(h._ctx(), 5) != 0 and hip.h10x_ingest_reserve(h._ctx(), 0) == 0
+    h.read_fqb(recs.reshape(-1)); h.depth_range(3, 14); h.cluster(1, 0, 2); h.write_hash(workdir.file("ing.hash"))
+    assert open(workdir.file("ing.hash"), "rb").read() == gold
+    h.close()
+
+
+def test_fault_between_fork_and_join_leaves_the_context_usable(workdir):
+    """Five places fork independent launch classes onto side streams (mosh table classes, clusHash classes, good-list classes, cluster
+    classes, the ordered sums beside the read merges). An error between fork and join must not hand the buffers of still running kernels
+    back to the block cache: every region is made to fail once ("fault_inject"), the call reports it, and the
+    SAME context then gives the oracle's bytes. The set has blocks of more than 3072 entries, so the block-sorting classes really fork."""
+    import hash10x_amd
+    recs = orc.gen_fqb(workdir.file("x.fqb"), 60000, 40, 600000, 0.003, 9, 6.0, 150, 20000).reshape(-1)
+    o = orc.Oracle(B=20); o.read_fqb(recs); o.depth_range(3, 30); o.cluster(1, 0, 2); o.write_hash(workdir.file("orc.hash"))
+    exp = open(workdir.file("orc.hash"), "rb").read()
+    assert int(orc.HashFile(exp).blocks["nHash"].max()) > 3072
+    h = hash10x_amd.Hash10x(B=20)
+    h.read_fqb(recs)                                          # a context (and its side streams) to inject into
+    for region in (1, 2, 3, 4, 5):
+        assert hash10x_amd.load_native()[0].h10x_set_option(h._ctx(), b"fault_inject", region) == 0     # (on the live context: the knob clears itself when it fires)
+        with pytest.raises(hash10x_amd.Hash10xError, match="injected fault in fork/join region %d" % region):
+            h.read_fqb(recs); h.depth_range(3, 30); h.cluster(1, 0, 2)
+        h.read_fqb(recs); h.depth_range(3, 30); h.cluster(1, 0, 2); h.write_hash(workdir.file("hip.hash"))
+        got = open(workdir.file("hip.hash"), "rb").read()
+        assert got == exp, "after a fault in region %d: %s" % (region, orc.describe_diff(got, exp))
+    h.close()
 
 
 def test_corrupt_hash_file_is_refused(workdir):
