@@ -479,7 +479,7 @@ __device__ __forceinline__ u32 wave_max_u32(u32 v) {
 // whose msBest lies in the round being processed (rb = NONE16: settled after the loop). The second gather of round 2's
 // phase (d) is gone for the rest, and with it the need to keep msMax / msTot per rank on chip.
 template <bool IN_LDS, int RCHUNK, typename FT>
-__device__ __forceinline__ void row_mode_hist(const u32 *__restrict__ row, u32 h0, u32 h1 /* handles of entries lane, 64 + lane; NOHANDLE = none */, u32 d, u32 code, u32 i, const FT &ft, u32 *hist,
+__device__ __forceinline__ void row_mode_hist(const u32 *__restrict__ row, u32 f0, u32 f1 /* first[] of entries lane, 64 + lane, read for all lists of the round together; NONE16 = no entry */, u32 d, u32 code, u32 i, const FT &ft, u32 *hist,
                                               const u16 *root, u32 thr, u32 &best, u32 &bcnt, u32 &tot, u32 &rb, u32 &q) {
   const int lane = threadIdx.x & (WAVE - 1);
   u32 f[RCHUNK]; bool ok[RCHUNK];
@@ -489,7 +489,7 @@ __device__ __forceinline__ void row_mode_hist(const u32 *__restrict__ row, u32 h
     f[r] = NONE16; ok[r] = false;
     if ((u32)(r * WAVE) < d) {
       const u32 j = r * WAVE + lane;
-      if (r < 2) { const u32 h = r == 0 ? h0 : h1; if (h != NOHANDLE) { f[r] = ft.peek(h); ok[r] = f[r] < i; } }
+      if (r < 2) { f[r] = r == 0 ? f0 : f1; ok[r] = f[r] < i; }
       else if (j < d) { const u32 cj = row[j]; if (cj != code) { f[r] = ft.lookup(cj); ok[r] = f[r] < i; } }
       tot += (u32)__popcll(__ballot(ok[r]));
     }
@@ -778,6 +778,14 @@ __device__ void cluster_one_block(const ClusterArgs &a, u32 code, unsigned char 
     if (!H10X_DBGSKIP(8)) SYNC_LDS();
     if (HASHED && sh[2]) break;                              // the table filled up (uniform: read after the barrier)
     if (H10X_DBGSKIP(2)) continue;
+    // the first[] values of all the round's lists are read back in one go (one wait for up to 2 RIF LDS reads instead of one per list):
+    // from here on cj / cj2 hold first[] values, NONE16 where a lane has no entry
+#pragma unroll
+    for (int t = 0; t < RIF; ++t) {
+      cj[t] = (dl[t] && cj[t] != NOHANDLE) ? ft.peek(cj[t]) : (u32)NONE16;
+      cj2[t] = (dl[t] > WAVE && cj2[t] != NOHANDLE) ? ft.peek(cj2[t]) : (u32)NONE16;
+    }
+    u32 rootV = 0; u64 resV = 0; bool mine = false;          // results of the round's lists, list t in lane t: one LDS and one HBM store per round
 #pragma unroll
     for (int t = 0; t < RIF; ++t) {
       const u32 i = i0 + t;
@@ -785,7 +793,7 @@ __device__ void cluster_one_block(const ClusterArgs &a, u32 code, unsigned char 
         const u32 d = dl[t];
         u32 best, bcnt, tot, rb, q;
         // (the list's address is only formed where entries beyond the two chunks held in registers are read)
-        if (d <= WAVE) row_mode_hist<IN_LDS, 1>(nullptr, cj[t], NOHANDLE, d, code, i, ft, w.hist + wave * w.histWords, w.root, thr, best, bcnt, tot, rb, q);
+        if (d <= WAVE) row_mode_hist<IN_LDS, 1>(nullptr, cj[t], NONE16, d, code, i, ft, w.hist + wave * w.histWords, w.root, thr, best, bcnt, tot, rb, q);
         else if (d <= 2 * WAVE) row_mode_hist<IN_LDS, 2>(nullptr, cj[t], cj2[t], d, code, i, ft, w.hist + wave * w.histWords, w.root, thr, best, bcnt, tot, rb, q);
         else if (d < RCHUNK * WAVE) row_mode_hist<IN_LDS, RCHUNK>(ROWP(RS_OF(t)), cj[t], cj2[t], d, code, i, ft, w.hist + wave * w.histWords, w.root, thr, best, bcnt, tot, rb, q);
         else {
@@ -793,13 +801,13 @@ __device__ void cluster_one_block(const ClusterArgs &a, u32 code, unsigned char 
           if (bcnt >= thr) { rb = ld_shared<IN_LDS>(&w.root[best]); if (rb != NONE16) { u32 t2; q = row_count_value(ROWP(RS_OF(t)), d, code, i, ft, rb, t2); } }
         }
         const bool act = bcnt >= thr;                        // hash10x.c:807
-        if (lane == 0) {
-          w.root[i] = act ? (u16)rb : (u16)i;               // rb = NONE16: msBest belongs to this round, settled behind the loop
-          res[i] = RES_PACK(act ? best : NONE16, q, tot);     // (the quotient is formed by replay_kernel: an fp64 divide per list is 40 instructions in this loop)
-        }
+        // rb = NONE16: msBest belongs to this round (or to an earlier list of this wave's round: its root is stored with the round's),
+        // settled behind the loop. The quotient is formed by replay_kernel: an fp64 divide per list is 40 instructions in this loop.
+        if (lane == t) { rootV = act ? rb : i; resV = RES_PACK(act ? best : NONE16, q, tot); mine = true; }
         sDepth += d;
       }
     }
+    if (mine) { w.root[i0 + lane] = (u16)rootV; res[i0 + lane] = resV; }
   }
 #undef RS_OF
 #undef H10X_LOAD_D
@@ -1040,6 +1048,83 @@ void replay_kernel(ReplayArgs a) {
   }
 }
 #undef SYNC
+// The same for the common sizes with one WAVE per barcode: the passes above are a dozen short steps with a barrier between them, which
+// a 256-lane workgroup per barcode spends almost entirely waiting (0.25 ms for the 10 000 barcodes of the yeast-scale set); a wave runs
+// them back to back — LDS operations of a wave complete in order, so no barrier is needed at all — and 8192 waves work side by side.
+constexpr int REPLAY_WAVES = 4;                              // barcodes per workgroup
+__global__ __launch_bounds__(REPLAY_WAVES * WAVE)
+void replay_wave_kernel(ReplayArgs a, u32 sliceBytes) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  const int lane = threadIdx.x & (WAVE - 1), wave = threadIdx.x / WAVE;
+  const u32 wi = blockIdx.x * REPLAY_WAVES + wave;
+  if (wi >= a.span) return;
+  const u32 c = a.codeMin + wi;
+  const u32 n = a.nGood[c];
+  if (n == 0 || n <= a.nLo || n > a.nHi) return;             // wave-uniform
+  const u64 o = a.blockOff[c];
+  unsigned char *region = smem + (size_t)wave * sliceBytes;
+  const size_t col = ((size_t)n * 2 + 15) & ~(size_t)15;
+  u16 *bst = (u16 *)region, *ptr = (u16 *)(region + col), *ft = (u16 *)(region + 2 * col), *fl = (u16 *)(region + 3 * col);
+#define WSYNC() __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront")
+  for (u32 i = lane; i < n; i += WAVE) {
+    const u16 m = (u16)(a.res[o + i] & 0xFFFFu);
+    bst[i] = m; ptr[i] = m != NONE16 ? m : (u16)i; ft[i] = NONE16; fl[i] = 0;
+  }
+  WSYNC();
+  for (u32 i = lane; i < n; i += WAVE) {
+    const u32 b = bst[i];
+    if (b != NONE16 && b < n && bst[b] == NONE16) min_u16<true>(ft, b, i);   // b inactive: i's turn may be its founding turn
+  }
+  WSYNC();
+  for (u32 r = 0; r < 20; ++r) {                             // chains only run downwards and are short: until no pointer moves
+    bool moved = false;
+    for (u32 i = lane; i < n; i += WAVE) {
+      const u32 p = ptr[i];
+      if (p < n) { const u32 pp = *(volatile u16 *)&ptr[p]; if (pp != p) { ptr[i] = (u16)pp; moved = true; } }
+    }
+    WSYNC();
+    if (!__ballot(moved)) break;
+  }
+  for (u32 i = lane; i < n; i += WAVE) { const u32 t = ft[i]; if (t != NONE16) fl[t] = 1; }   // founding turns are distinct
+  WSYNC();
+  // inclusive scan of fl[0..n): a lane takes a contiguous piece, the pieces' totals are scanned across the wave
+  const u32 ipt = (n + WAVE - 1) / WAVE, s0 = (u32)lane * ipt < n ? (u32)lane * ipt : n, s1 = s0 + ipt < n ? s0 + ipt : n;
+  u32 mine = 0;
+  for (u32 i = s0; i < s1; ++i) mine += fl[i];
+  u32 inc = mine;
+#pragma unroll
+  for (int d = 1; d < WAVE; d <<= 1) { const u32 o2 = (u32)__shfl_up((int)inc, d); if (lane >= d) inc += o2; }
+  u32 run = inc - mine;
+  for (u32 i = s0; i < s1; ++i) { run += fl[i]; fl[i] = (u16)run; }
+  WSYNC();
+  const u32 nRoots = fl[n - 1];
+  u32 stop = n;
+  h10x_clushash *ch = a.clusHash + o; const u16 *g = a.goodPos + o;
+  if (nRoots > 255) {                                        // hash10x.c:810-816: abandon at the 256th founding turn
+    u32 st = 0xFFFFFFFFu;
+    for (u32 i = lane; i < n; i += WAVE) if (fl[i] == 256 && (i == 0 || fl[i - 1] == 255)) st = i;
+#pragma unroll
+    for (int sft = 32; sft; sft >>= 1) { const u32 o2 = (u32)__shfl_xor((int)st, sft); st = o2 < st ? o2 : st; }
+    stop = st;                                               // the terms of the turns before it stay in pointToMin
+    for (u32 i = lane; i < n; i += WAVE) ch[g[i]].subCluster = 0;
+    if (lane == 0) a.blocks[c].nSubCluster = 0;
+  } else {
+    for (u32 i = lane; i < n; i += WAVE) {
+      u32 L = 0;
+      if (bst[i] != NONE16) { const u32 rt = ptr[i]; const u32 t = rt < n ? (u32)ft[rt] : NONE16; L = t != NONE16 ? (u32)fl[t] : 0u; }
+      else { const u32 t = ft[i]; if (t != NONE16) L = fl[t]; }
+      ch[g[i]].subCluster = (u8)L;                           // includes the wipe of hash10x.c:783
+    }
+    if (lane == 0) a.blocks[c].nSubCluster = nRoots;
+  }
+  double *term = (double *)(a.res + o);                      // hash10x.c:821: one IEEE double divide per active rank, over its result word
+  for (u32 i = lane; i < n; i += WAVE) {
+    const u64 r = a.res[o + i];
+    const bool has = i >= 1 && i < stop && (u32)(r & 0xFFFFu) != NONE16;
+    term[i] = has ? (double)(int)(u32)((r >> 16) & 0xFFFFFFu) / (double)(int)(u32)(r >> 40) : 0.0;
+  }
+#undef WSYNC
+}
 __host__ __device__ inline size_t replayBytes(u32 n) { return 4 * (((size_t)n * 2 + 15) & ~(size_t)15) + 16; }
 constexpr u32 REPLAY_SMALL = 2040, REPLAY_MID = 16376;       // rank counts up to which a block's replay runs in 16 KB / 128 KB of LDS
 
@@ -1368,8 +1453,12 @@ static int cluster_local_range(Ctx *c, int codeMin, int codeMax, int threshold, 
   {
     ReplayArgs ra{}; ra.blocks = c->blocks.p; ra.blockOff = c->blockOff.p; ra.clusHash = c->clusHash.p; ra.goodPos = c->goodPos.p; ra.nGood = c->nGood.p;
     ra.res = term.p; ra.codeMin = (u32)codeMin; ra.span = span;
-    ra.nLo = 0; ra.nHi = REPLAY_SMALL;
-    replay_kernel<true, 256><<<span, 256, replayBytes(REPLAY_SMALL), st>>>(ra);
+    ra.nLo = 0; ra.nHi = hmin<u32>(REPLAY_SMALL, hmax<u32>(c->maxGood, 1));   // (the slice is sized by the launch's largest barcode: more waves per CU on small sets)
+    {
+      const u32 slice = (u32)replayBytes(ra.nHi);
+      H10X_HIP(c, hipFuncSetAttribute((const void *)replay_wave_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(REPLAY_WAVES * slice)));
+      replay_wave_kernel<<<divUp(span, REPLAY_WAVES), REPLAY_WAVES * WAVE, (size_t)REPLAY_WAVES * slice, st>>>(ra, slice);
+    }
     if (c->maxGood > REPLAY_SMALL) {
       H10X_HIP(c, hipFuncSetAttribute((const void *)replay_kernel<true, 1024>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)replayBytes(REPLAY_MID)));
       ra.nLo = REPLAY_SMALL; ra.nHi = REPLAY_MID;
