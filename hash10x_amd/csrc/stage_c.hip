@@ -36,6 +36,16 @@ constexpr u32 NOHANDLE = 0xFFFFFFFFu;                        // FirstDense/Ranke
 #ifndef H10X_RIF
 #define H10X_RIF 4
 #endif
+// A/B switches of the list loop (scratch/r3_variants.sh builds and times them; the defaults are what measured fastest):
+#ifndef H10X_PREPEEK
+#define H10X_PREPEEK 0        // 1: the first[] values of all lists of a round are read back together, in front of the per-list work
+#endif
+#ifndef H10X_BATCH
+#define H10X_BATCH 0          // 1: the results of a round's lists are parked in lanes and stored once per round
+#endif
+#ifndef H10X_REPLAY_WAVE
+#define H10X_REPLAY_WAVE 0    // 1: replay with one wave per barcode (no workgroup barriers) for the common sizes
+#endif
 constexpr int ROWS_IN_FLIGHT = H10X_RIF;                          // barcode lists a wavefront keeps in flight
 constexpr int RCHUNK = 4;                                   // register chunks: lists up to 256 entries
 
@@ -489,7 +499,13 @@ __device__ __forceinline__ void row_mode_hist(const u32 *__restrict__ row, u32 f
     f[r] = NONE16; ok[r] = false;
     if ((u32)(r * WAVE) < d) {
       const u32 j = r * WAVE + lane;
-      if (r < 2) { f[r] = r == 0 ? f0 : f1; ok[r] = f[r] < i; }
+      if (r < 2) {
+#if H10X_PREPEEK
+        f[r] = r == 0 ? f0 : f1; ok[r] = f[r] < i;
+#else
+        const u32 h = r == 0 ? f0 : f1; if (h != NOHANDLE) { f[r] = ft.peek(h); ok[r] = f[r] < i; }   // (f0 / f1 are handles in this build)
+#endif
+      }
       else if (j < d) { const u32 cj = row[j]; if (cj != code) { f[r] = ft.lookup(cj); ok[r] = f[r] < i; } }
       tot += (u32)__popcll(__ballot(ok[r]));
     }
@@ -599,7 +615,10 @@ __device__ void cluster_one_block(const ClusterArgs &a, u32 code, unsigned char 
   // the ranked / hashed lookup: fewer registers spilled is worth more there than the deeper prefetch (8x set: 52.8 -> 41.4 ms);
   // and 2 for the hashed placement in every class: with 4 its list loop unrolls to 61 KB of code (the compiler then keeps
   // the block function out of line) against 42 KB — 300 k-barcode set: 0.533 -> 0.507 s
-  constexpr int RIF = ((KLASS == 0 && CL_THREADS == 1024 && FIRST_MODE == 1) || (FIRST_MODE == 3 && KLASS == 0)) ? 2 : ROWS_IN_FLIGHT;
+#ifndef H10X_RIF_SMALL
+#define H10X_RIF_SMALL 2
+#endif
+  constexpr int RIF = ((KLASS == 0 && CL_THREADS == 1024 && FIRST_MODE == 1) || (FIRST_MODE == 3 && KLASS == 0)) ? H10X_RIF_SMALL : ROWS_IN_FLIGHT;
   const int tid = threadIdx.x, lane = tid & (WAVE - 1), wave = tid / WAVE;
   code = (u32)__builtin_amdgcn_readfirstlane((int)code);     // (the block number reaches every lane through LDS: say that it is uniform)
   const u32 n = (u32)__builtin_amdgcn_readfirstlane((int)a.nGood[code]);
@@ -780,12 +799,17 @@ __device__ void cluster_one_block(const ClusterArgs &a, u32 code, unsigned char 
     if (H10X_DBGSKIP(2)) continue;
     // the first[] values of all the round's lists are read back in one go (one wait for up to 2 RIF LDS reads instead of one per list):
     // from here on cj / cj2 hold first[] values, NONE16 where a lane has no entry
+#if H10X_PREPEEK
 #pragma unroll
     for (int t = 0; t < RIF; ++t) {
       cj[t] = (dl[t] && cj[t] != NOHANDLE) ? ft.peek(cj[t]) : (u32)NONE16;
       cj2[t] = (dl[t] > WAVE && cj2[t] != NOHANDLE) ? ft.peek(cj2[t]) : (u32)NONE16;
     }
-    u32 rootV = 0; u64 resV = 0; bool mine = false;          // results of the round's lists, list t in lane t: one LDS and one HBM store per round
+    constexpr u32 NOENTRY = NONE16;
+#else
+    constexpr u32 NOENTRY = NOHANDLE;
+#endif
+    u32 rootV = 0; u64 resV = 0; bool mine = false;          // results of the round's lists, list t in lane t: one LDS and one HBM store per round (H10X_BATCH)
 #pragma unroll
     for (int t = 0; t < RIF; ++t) {
       const u32 i = i0 + t;
@@ -793,7 +817,7 @@ __device__ void cluster_one_block(const ClusterArgs &a, u32 code, unsigned char 
         const u32 d = dl[t];
         u32 best, bcnt, tot, rb, q;
         // (the list's address is only formed where entries beyond the two chunks held in registers are read)
-        if (d <= WAVE) row_mode_hist<IN_LDS, 1>(nullptr, cj[t], NONE16, d, code, i, ft, w.hist + wave * w.histWords, w.root, thr, best, bcnt, tot, rb, q);
+        if (d <= WAVE) row_mode_hist<IN_LDS, 1>(nullptr, cj[t], NOENTRY, d, code, i, ft, w.hist + wave * w.histWords, w.root, thr, best, bcnt, tot, rb, q);
         else if (d <= 2 * WAVE) row_mode_hist<IN_LDS, 2>(nullptr, cj[t], cj2[t], d, code, i, ft, w.hist + wave * w.histWords, w.root, thr, best, bcnt, tot, rb, q);
         else if (d < RCHUNK * WAVE) row_mode_hist<IN_LDS, RCHUNK>(ROWP(RS_OF(t)), cj[t], cj2[t], d, code, i, ft, w.hist + wave * w.histWords, w.root, thr, best, bcnt, tot, rb, q);
         else {
@@ -803,11 +827,19 @@ __device__ void cluster_one_block(const ClusterArgs &a, u32 code, unsigned char 
         const bool act = bcnt >= thr;                        // hash10x.c:807
         // rb = NONE16: msBest belongs to this round (or to an earlier list of this wave's round: its root is stored with the round's),
         // settled behind the loop. The quotient is formed by replay_kernel: an fp64 divide per list is 40 instructions in this loop.
+#if H10X_BATCH
         if (lane == t) { rootV = act ? rb : i; resV = RES_PACK(act ? best : NONE16, q, tot); mine = true; }
+#else
+        if (lane == 0) { w.root[i] = act ? (u16)rb : (u16)i; res[i] = RES_PACK(act ? best : NONE16, q, tot); }
+#endif
         sDepth += d;
       }
     }
+#if H10X_BATCH
     if (mine) { w.root[i0 + lane] = (u16)rootV; res[i0 + lane] = resV; }
+#else
+    (void)rootV; (void)resV; (void)mine;
+#endif
   }
 #undef RS_OF
 #undef H10X_LOAD_D
@@ -1453,12 +1485,17 @@ static int cluster_local_range(Ctx *c, int codeMin, int codeMax, int threshold, 
   {
     ReplayArgs ra{}; ra.blocks = c->blocks.p; ra.blockOff = c->blockOff.p; ra.clusHash = c->clusHash.p; ra.goodPos = c->goodPos.p; ra.nGood = c->nGood.p;
     ra.res = term.p; ra.codeMin = (u32)codeMin; ra.span = span;
+#if H10X_REPLAY_WAVE
     ra.nLo = 0; ra.nHi = hmin<u32>(REPLAY_SMALL, hmax<u32>(c->maxGood, 1));   // (the slice is sized by the launch's largest barcode: more waves per CU on small sets)
     {
       const u32 slice = (u32)replayBytes(ra.nHi);
       H10X_HIP(c, hipFuncSetAttribute((const void *)replay_wave_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(REPLAY_WAVES * slice)));
       replay_wave_kernel<<<divUp(span, REPLAY_WAVES), REPLAY_WAVES * WAVE, (size_t)REPLAY_WAVES * slice, st>>>(ra, slice);
     }
+#else
+    ra.nLo = 0; ra.nHi = REPLAY_SMALL;
+    replay_kernel<true, 256><<<span, 256, replayBytes(hmin<u32>(REPLAY_SMALL, hmax<u32>(c->maxGood, 1))), st>>>(ra);
+#endif
     if (c->maxGood > REPLAY_SMALL) {
       H10X_HIP(c, hipFuncSetAttribute((const void *)replay_kernel<true, 1024>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)replayBytes(REPLAY_MID)));
       ra.nLo = REPLAY_SMALL; ra.nHi = REPLAY_MID;

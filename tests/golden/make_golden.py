@@ -308,6 +308,27 @@ def main():
                 man["bench_scale_digests"] = json.load(f).get("bench_scale_digests", {})
         except OSError:
             man["bench_scale_digests"] = {}
+    # BASELINE configs[2] at its own size (200 M pairs, 1 M barcodes, -B 29): `make_golden.py --full <dir>` takes the reference's .hash of
+    # the gen_fqb v2 set from <dir> (c3.fqb + c3.ref.hash, made there by build/gen_fqb -v 2 ... and oracle/_ref/hash10x_omp: 24 + 15 GB, half an hour)
+    if "--full" in sys.argv:
+        import hashlib
+        d = sys.argv[sys.argv.index("--full") + 1]
+        gen2 = dict(pairs=200000000, barcodes=1000000, genome=500000000, err=0.001, seed=2, mol=10.0, snp=150, mol_len=50000.0)
+        fq = np.memmap(os.path.join(d, "c3.fqb"), dtype=np.uint32, mode="r")
+        assert fq.size == 30 * gen2["pairs"]
+        digest, info = orc.canonical_file_digest(os.path.join(d, "c3.ref.hash"))
+        man["full_digest_cases"] = [{"name": "c3_200m.c", "gen2": gen2, "B": 29, "args": ["--hashDepthRange", "30", "100", "--cluster", "1", "0"],
+                                     "input": {"head_sha256": hashlib.sha256(fq[: 30 << 20].tobytes()).hexdigest(), "tail_sha256": hashlib.sha256(fq[-(30 << 20):].tobytes()).hexdigest()},
+                                     "sha256": digest, "size": info["size"], "hash_number": info["hash_number"], "blocks_max": info["blocks_max"],
+                                     "sum_nHash": info["sum_nHash"], "sum_nSubCluster": info["sum_nSubCluster"],
+                                     "reference": "oracle/_ref/hash10x_omp -t 8 -B 29 --readFQB c3.fqb --hashDepthRange 30 100 --cluster 1 0 --writeHash c3.ref.hash "
+                                                  "(MALLOC_PERTURB_=255, tcache off); gen: build/gen_fqb -v 2 -P 200000000 -C 1000000 -G 500000000 -e 0.001 -s 2"}]
+    else:
+        try:
+            with open(os.path.join(HERE, "manifest.json")) as f:
+                man["full_digest_cases"] = json.load(f).get("full_digest_cases", [])
+        except OSError:
+            man["full_digest_cases"] = []
     man["big_note"] = ("big_digest_cases: BASELINE configs[2] proportions at 1/10 and 1/4 scale, generated by `make_golden.py --big` from "
                        "oracle/_ref (4.5 and 12.5 minutes of the reference); only the GPU tests run them")
     with open(os.path.join(HERE, "manifest.json"), "w") as f:

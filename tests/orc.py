@@ -384,3 +384,46 @@ def leading_options(extra):
     while n + 1 < len(extra) and str(extra[n]) in ("-ct", "-c"):
         n += 2
     return list(extra[:n])
+
+
+def canonical_file_digest(path, chunk=1 << 26):
+    """sha256 of the CANONICAL form of a .hash file (heap-pointer fields zeroed) without holding it in memory — files of
+    10+ GB (full-size BASELINE configs[2]). Also returns the sizes read on the way: (hexdigest, {hash_number, blocks_max, blocks_dim, sum_nHash,
+    sum_nSubCluster, size})."""
+    sha = hashlib.sha256()
+    info = {}
+    with open(path, "rb") as f:
+        head = f.read(16); sha.update(head)
+        assert head[:4] == b"10XH" and int.from_bytes(head[4:8], "little") == 2
+        B = int.from_bytes(head[12:16], "little")
+        left = 4 << B
+        while left:                                          # hashIndex
+            b = f.read(min(chunk, left)); sha.update(b); left -= len(b)
+        b = f.read(4); sha.update(b); hash_number = int.from_bytes(b, "little")
+        left = 8 * hash_number
+        while left:                                          # hashValue
+            b = f.read(min(chunk, left)); sha.update(b); left -= len(b)
+        hdr = bytearray(f.read(32)); hdr[8:16] = bytes(8); sha.update(hdr)      # ArrayStruct of hashDepth: base pointer zeroed
+        dim = int.from_bytes(hdr[16:20], "little")
+        left = 4 * dim
+        while left:
+            b = f.read(min(chunk, left)); sha.update(b); left -= len(b)
+        hdr = bytearray(f.read(32)); hdr[8:16] = bytes(8); sha.update(hdr)      # ArrayStruct of clusterBlocks
+        bdim, bmax = int.from_bytes(hdr[16:20], "little"), int.from_bytes(hdr[24:28], "little")
+        sum_hash = sum_sub = 0
+        done = 0
+        while done < bdim:                                   # ClusterBlock[dim]: clusHash pointer zeroed
+            nb = min(chunk // 32, bdim - done)
+            blk = np.frombuffer(bytearray(f.read(32 * nb)), dtype=BLOCK).copy()
+            blk["ptr"] = 0
+            lo, hi = max(1 - done, 0), max(min(bmax - done, nb), 0)
+            if hi > lo:
+                sum_hash += int(blk["nHash"][lo:hi].sum(dtype=np.uint64)); sum_sub += int(blk["nSubCluster"][lo:hi].sum(dtype=np.uint64))
+            sha.update(blk.tobytes()); done += nb
+        while True:                                          # ClusterHash records
+            b = f.read(chunk)
+            if not b:
+                break
+            sha.update(b)
+        info = {"B": B, "hash_number": hash_number, "blocks_max": bmax, "blocks_dim": bdim, "sum_nHash": sum_hash, "sum_nSubCluster": sum_sub, "size": f.tell()}
+    return sha.hexdigest(), info

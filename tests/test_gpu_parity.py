@@ -5,6 +5,7 @@ Bar: bit-exact canonical .hash (integer/byte work; the one floating-point field,
 ordered IEEE double sum and is compared bit-for-bit too)."""
 import json
 import os
+import sys
 
 import numpy as np
 import pytest
@@ -698,6 +699,45 @@ def test_config3_proportions_match_reference_digests(case, tmp_path_factory, wor
             sha.update(blk)
     os.remove(workdir.file("big.hash"))
     assert sha.hexdigest() == case["sha256"]
+
+
+@pytest.mark.parametrize("case", MAN.get("full_digest_cases", []), ids=[c["name"] for c in MAN.get("full_digest_cases", [])])
+def test_config3_full_size_matches_reference_digest(case, tmp_path_factory):
+    """BASELINE configs[2] AT ITS OWN SIZE: 200 M read pairs, 1 M barcodes, 500 Mb x 2 haplotypes, e = 0.1 %, --hashDepthRange 30 100
+    --cluster 1 0, with the table size the reference accepts for it (-B 29; -B 28 dies, see the next test). The whole canonical .hash
+    (15 GB) must have the sha256 of the REFERENCE binary's (oracle/_ref/hash10x_omp, 8 threads, in the build container: make_golden.py
+    --full; 16 min of --readFQB and 14 of --cluster there). This is the regime the placement logic changes in: a million barcodes, hashed
+    first[] tables, tens of thousands of blocks on the > 255 clusters path. The input is generated here by gen_fqb v2 (OpenMP, seeded)."""
+    import hashlib
+    import hash10x_amd
+    sys.path.insert(0, orc.REPO)
+    import bench
+    g = case["gen2"]
+    wl = dict(pairs=g["pairs"], barcodes=g["barcodes"], genome=g["genome"], err=g["err"], mol=g["mol"], snp=g["snp"], mol_len=g["mol_len"])
+    recs, _first, total = bench.generate_v2(wl, g["seed"])
+    assert total == g["pairs"] and recs.size == 30 * g["pairs"]
+    for key, sl in (("head_sha256", recs[: 30 << 20]), ("tail_sha256", recs[-(30 << 20):])):          # 1 M records of each end (the whole image is 24 GB)
+        assert hashlib.sha256(sl.tobytes()).hexdigest() == case["input"][key], "gen_fqb v2 is not reproducing the seeded input (%s)" % key
+    d = hash10x_amd.DeviceRecords(recs)
+    del recs
+    h = hash10x_amd.Hash10x(B=case["B"])
+    h.read_fqb_device(d.ptr, d.n_records)
+    d.free()
+    a = case["args"]
+    h.depth_range(int(a[1]), int(a[2]))
+    h.cluster(int(a[4]), int(a[5]), 5)
+    z = h.sizes()
+    assert z["hashNumber"] == case["hash_number"] and z["nBlocks"] == case["blocks_max"] and z["nClusHash"] == case["sum_nHash"]
+    out = str(tmp_path_factory.mktemp("full") / "full.hash")
+    try:
+        h.write_hash(out)
+        h.close()
+        digest, info = orc.canonical_file_digest(out)
+    finally:
+        if os.path.exists(out):
+            os.remove(out)
+    assert info["sum_nSubCluster"] == case["sum_nSubCluster"] and info["size"] == case["size"]
+    assert digest == case["sha256"]
 
 
 def test_config3_dies_at_the_table_size_of_BASELINE(tmp_path_factory):
