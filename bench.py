@@ -362,6 +362,54 @@ def cpu_baseline(wl, recs, workdir, gpu_hash_path):
     return one, omp, parity
 
 
+def full_config3_block(hash10x_amd, local_rank, steps=3):
+    """BASELINE configs[2] AT ITS OWN SIZE on this GPU: 200 M read pairs, 1 M barcodes, 500 Mb x 2, e = 0.1 %, -B 29 (the table size the reference
+    accepts for it), --hashDepthRange 30 100 --cluster 1 0 — the set whose whole .hash is pinned by the reference binary's sha256 in the GPU tests
+    (test_config3_full_size_matches_reference_digest). Generated here by gen_fqb v2 (OpenMP); 24 GB of records resident in HBM."""
+    man = json.load(open(os.path.join(REPO, "tests", "golden", "manifest.json"))).get("full_digest_cases", [])
+    if not man:
+        return {"skipped": "no full_digest_cases in tests/golden/manifest.json"}
+    case = man[0]; g = case["gen2"]
+    wl = dict(pairs=g["pairs"], barcodes=g["barcodes"], genome=g["genome"], err=g["err"], mol=g["mol"], snp=g["snp"], mol_len=g["mol_len"])
+    t0 = time.perf_counter()
+    recs, _first, _total = generate_v2(wl, g["seed"])
+    gen_s = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    d = hash10x_amd.DeviceRecords(recs, device=local_rank)
+    up_s = time.perf_counter() - t0
+    pairs = recs.size // 30
+    del recs
+    h = hash10x_amd.Hash10x(B=case["B"], device=local_rank)
+    h.enable_timing(True)
+    wall, tm = [], {}
+    for it in range(steps + 1):                             # one warm-up
+        hash10x_amd.synchronize(local_rank)
+        t = time.perf_counter()
+        h.read_fqb_device(d.ptr, pairs); h.depth_range(30, 100); h.cluster(1, 0, 5)
+        hash10x_amd.synchronize(local_rank)
+        if it:
+            wall.append(time.perf_counter() - t)
+            for k, (ms, n) in h.timings().items():
+                a = tm.setdefault(k, [0.0, 0]); a[0] += ms; a[1] += n
+    c = h.counters(); z = h.sizes()
+    clu_ms = tm["cluster_kernel"][0] / steps
+    alg = 4.0 * c["sum_good_depth"] + 14.0 * c["sum_good"] + 16.0 * c["sum_hash_clustered"]
+    out = {"workload": "config3-full-200M (BASELINE configs[2] at its own size: 200 M pairs, 1 M barcodes, 500 Mb x 2, e = 0.1 %, -B 29; gen_fqb v2 seed %d)" % g["seed"],
+           "ms_per_step": 1e3 * sum(wall) / len(wall), "read_pairs_per_s": pairs * len(wall) / sum(wall), "steps": steps,
+           "device_ms_per_step": {k: round(v[0] / steps, 2) for k, v in tm.items() if v[0] > 0},
+           "entries_H": c["entries"], "distinct_U": c["distinct"], "hashNumber": z["hashNumber"],
+           "sizes_match_reference": z["hashNumber"] == case["hash_number"] and z["nBlocks"] == case["blocks_max"] and z["nClusHash"] == case["sum_nHash"],
+           "first_placement": {0: "dense", 1: "ranked", 2: "hbm-slot", 3: "hashed"}.get(c["cluster_first_mode"]),
+           "cluster_class_counts": c["cluster_class_counts"], "cluster_overflow_blocks": c["cluster_overflow_blocks"],
+           "roofline": {"bound": "hbm", "kernel": "all cluster launches", "achieved": alg / (clu_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": alg / (clu_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes": alg, "ms_per_step": clu_ms},
+           "barcodes_per_s_clustered": wl["barcodes"] / (tm["cluster"][0] / steps * 1e-3),
+           "generate_seconds": round(gen_s, 1), "upload_seconds": round(up_s, 2), "host_threads": os.cpu_count(),
+           "parity": "tests/test_gpu_parity.py::test_config3_full_size_matches_reference_digest: the whole 15 GB .hash of this set has the reference binary's sha256"}
+    h.close(); d.free()
+    return out
+
+
 def secondary_block(hash10x_amd, local_rank):
     """The 1/10-scale BASELINE configs[2] set in the same process (single GPU): ms per step and the roofline of the main
     cluster launch in the ranked placement — the regime real data sets are in, next to the yeast-scale headline."""
@@ -424,7 +472,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="yeast-like-2.5M", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-secondary", action="store_true", help="skip the config-3-scale block (20 M pairs: ~40 s of generation + 3 passes)")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the config-3-scale blocks (1/10 scale: ~15 s of generation + 6 passes; full size: 24 GB, needs >= 32 host threads)")
     ap.add_argument("--comm", default="auto", choices=["auto", "rccl", "socket"], help="multi-process backend: RCCL over xGMI (one GPU per rank), or the "
                     "host-staged socket backend where ranks share a GPU (test boxes); auto = socket when there are fewer devices than ranks")
     ap.add_argument("--sharded", action="store_true", help="use the multi-GPU code path (RCCL communicator, shard exchange) even with one rank")
@@ -640,6 +688,10 @@ def main():
             out["secondary"] = secondary_block(hash10x_amd, local_rank)
         except Exception as e:                           # never lose the headline over the side block
             out["secondary"] = {"error": str(e)[:300]}
+        try:                                                 # BASELINE configs[2] at its own size where the host can generate it in seconds
+            out["full_config3"] = full_config3_block(hash10x_amd, local_rank) if (os.cpu_count() or 1) >= 32 else {"skipped": "fewer than 32 host threads: generating 200 M pairs would take minutes"}
+        except Exception as e:
+            out["full_config3"] = {"error": str(e)[:300]}
     if rank == 0:
         os.write(json_fd, (json.dumps(out) + "\n").encode())
     if comm is not None:

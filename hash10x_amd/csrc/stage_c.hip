@@ -306,21 +306,27 @@ __host__ __device__ inline u32 rankedFirstEstimate(u32 nBarcodes, u32 n) { const
 // … and, where the entries of the block's lists are known (classification): a seventh of them (6-8 % on the yeast-like
 // sets, more on deeper ones), whichever is larger. Erring low is cheap: the ranked kernel knows the true number right
 // after its bitmap pass and hands the block on before the list loop.
-__host__ __device__ inline u32 rankedFirstEstimateE(u32 nBarcodes, u32 n, u32 entries) { const u32 a = rankedFirstEstimate(nBarcodes, n), b = entries / 7; const u32 m = a > b ? a : b; return m < nBarcodes ? m : nBarcodes; }
+#ifndef H10X_EST_DIV
+#define H10X_EST_DIV 7
+#endif
+__host__ __device__ inline u32 rankedFirstEstimateE(u32 nBarcodes, u32 n, u32 entries) { const u32 a = rankedFirstEstimate(nBarcodes, n), b = entries / H10X_EST_DIV; const u32 m = a > b ? a : b; return m < nBarcodes ? m : nBarcodes; }
 __host__ __device__ inline u32 histWaves(u32 nFirst, u32 n, u32 maxWaves, u32 bmWords, size_t budget) {
   const size_t fixed = workBytes(nFirst, n, 0, bmWords), per = (((size_t)n + 3) / 4) * 4;
   if (fixed + MIN_HIST_WAVES * per > budget) return 0;
   const size_t wv = (budget - fixed) / (per ? per : 1);
   return wv < maxWaves ? (u32)wv : maxWaves;
 }
-// Hashed placement (FirstHashed): slots wanted for a block = 1.5 x the barcodes expected in its lists (see
-// rankedFirstEstimateE), so that the table stays under ~2/3 full. The kernel gives the table every byte the budget
-// leaves; a block whose table still fills up is re-run in the next larger placement.
+// Hashed placement (FirstHashed): slots wanted for a block = 1.25 x the barcodes expected in its lists (see
+// rankedFirstEstimateE: a seventh of the lists' entries; measured on the 1/10 config-3 set: 12 % on average, 15 % at the 90th
+// percentile, 19 % at most), so that the table stays under ~80 % full. The kernel gives the table every byte the budget
+// leaves; a block whose table still fills up is re-run in the next larger placement (0.2 % of the blocks at 1 M barcodes).
+// Round 3, full-size config 3 (scratch/r3_variants.sh): 1.5 x -> 1155 ms, 1.25 x -> 1094 ms (546 k instead of 407 k blocks in the
+// half-CU class), a ninth of the entries at 1.25 x -> 1296 ms (98 k blocks overflow and run twice).
 constexpr u32 HASHED_MIN_SLOTS = 1024, HASHED_MAX_SLOTS = 1u << 16;
 // list-loop waves and table slots of a block in the hashed placement: all waves if the table then still has `want`
 // slots, else 8, else the minimum (fewer waves => more slots); slots = 0 if nothing fits
 #ifndef H10X_HASHED_WANT_PCT
-#define H10X_HASHED_WANT_PCT 150
+#define H10X_HASHED_WANT_PCT 125
 #endif
 __host__ __device__ inline u32 hashedWant(u32 est) { return (u32)(((u64)est * H10X_HASHED_WANT_PCT) / 100); }   // slots asked for per barcode expected in the table
 __host__ __device__ inline void hashedShape(u32 n, u32 maxWaves, size_t budget, u32 minSlots, u32 want, u32 &nW, u32 &slots) {

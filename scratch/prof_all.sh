@@ -8,7 +8,8 @@ TAG=$1; SCRIPT=${2:-scratch/one_step.py}
 export TMPDIR=/tmp
 O=gpurun_out
 mkdir -p $O
-if [ -z "$SKIP_BENCH" ]; then
+if [ -n "$ONLY_SQ" ]; then :                      # counters only (no bench, no kernel trace): quick look at one script
+elif [ -z "$SKIP_BENCH" ]; then
   python3 bench.py --steps 10 --warmup 2 > $O/${TAG}_bench.json 2> $O/${TAG}_bench.err
   echo "bench done"
   rocprofv3 --kernel-trace --stats --output-format csv -d $O/${TAG}_stats -o runc -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-secondary > $O/${TAG}_bench_under_rocprof.json 2> $O/${TAG}_rocprof.err
@@ -17,8 +18,10 @@ else                                            # another workload than the benc
 fi
 echo "kernel trace done"
 pass() { rocprofv3 --pmc $2 --output-format csv -d $O/${TAG}_$1 -o runc -- python3 $SCRIPT > $O/${TAG}_$1.log 2>&1; echo "pass $1 done"; }
+if [ -z "$ONLY_SQ" ]; then
 pass fetch "FETCH_SIZE"
 pass write "WRITE_SIZE"
+fi
 pass sqA "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR GRBM_GUI_ACTIVE"
 pass sqB "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_VMEM SQ_WAIT_INST_LDS"
 pass sqC "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_FLAT SQ_INSTS_FLAT_FLATSEG SQ_INSTS_BRANCH SQ_INSTS_SMEM SQ_LDS_ATOMIC_RETURN SQ_THREAD_CYCLES_VALU"

@@ -19,7 +19,8 @@ else
   for name in "$@"; do
     cp scratch/bin/var_$name/libh10x_hip.so hash10x_amd/libh10x_hip.so
     echo "=== variant $name"
-    timeout -k 10 300 python scratch/r3_time.py $what 2>&1 | grep -v "^  mode"
+    if [ "$what" = full ]; then timeout -k 10 300 python scratch/r3_full.py 2 2>&1 | grep -E "^pass 1|cluster_kernel" | tail -2
+    else timeout -k 10 300 python scratch/r3_time.py $what 2>&1 | grep -v "^  mode"; fi
   done
   cp /tmp/libh10x_hip.orig.so hash10x_amd/libh10x_hip.so
 fi
