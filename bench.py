@@ -394,7 +394,7 @@ def full_config3_block(hash10x_amd, local_rank, steps=3):
     c = h.counters(); z = h.sizes()
     clu_ms = tm["cluster_kernel"][0] / steps
     alg = 4.0 * c["sum_good_depth"] + 14.0 * c["sum_good"] + 16.0 * c["sum_hash_clustered"]
-    out = {"workload": "config3-full-200M (BASELINE configs[2] at its own size: 200 M pairs, 1 M barcodes, 500 Mb x 2, e = 0.1 %, -B 29; gen_fqb v2 seed %d)" % g["seed"],
+    out = {"workload": "config3-full-200M (BASELINE configs[2] at its own size: 200 M pairs, 1 M barcodes, 500 Mb x 2, e = 0.1 %%, -B 29; gen_fqb v2 seed %d)" % g["seed"],
            "ms_per_step": 1e3 * sum(wall) / len(wall), "read_pairs_per_s": pairs * len(wall) / sum(wall), "steps": steps,
            "device_ms_per_step": {k: round(v[0] / steps, 2) for k, v in tm.items() if v[0] > 0},
            "entries_H": c["entries"], "distinct_U": c["distinct"], "hashNumber": z["hashNumber"],

@@ -203,7 +203,7 @@ int h10x_session_readFQB_dev(h10x_session *s, const uint32_t *devRec, uint64_t n
    time: the file never sits in host memory, and the closing call is the --readFQB itself (collective when sharded). A rank that fails
    here while sharded still makes the closing call's counterpart impossible for the others, so the verdict is agreed on first. */
 static int stream_records(h10x_session *s, const char *path, uint64_t first, uint64_t n, int sharded) {
-  enum { SLAB = 64 << 20 };
+  enum { SLAB = ((64 << 20) / 120) * 120 };                                          /* whole records per read */
   int rc = 0;
   const int fd = open(path, O_RDONLY);
   char *slab = (char *)malloc(SLAB);

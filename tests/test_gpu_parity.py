@@ -931,6 +931,25 @@ def test_bench_with_two_ranks_carries_a_parity_gate(workdir):
     assert outs[1][0].decode().strip() == ""                # one JSON line, on rank 0
 
 
+def test_cli_streams_files_larger_than_one_slab(workdir):
+    """bin/hash10x-amd reads the .fqb in 64 MiB slabs through h10x_ingest_fqb: a file of more than one slab (72 MB; the slab is a whole
+    number of 120-byte records, which a round-3 build got wrong — bench.py's end-to-end check caught it) gives the bytes of the library
+    path on the same records, on one GPU and on 2 shards (every shard's range larger or smaller than a slab)."""
+    import subprocess
+    import hash10x_amd
+    recs = orc.gen_fqb(workdir.file("x.fqb"), 600000, 2400, 3000000, 0.003, 77, 8.0, 150, 30000)
+    assert recs.nbytes > (64 << 20)
+    h = hash10x_amd.Hash10x(B=22); h.read_fqb(recs.reshape(-1)); h.depth_range(10, 60); h.cluster(1, 0, 4); h.write_hash(workdir.file("lib.hash")); h.close()
+    exp = open(workdir.file("lib.hash"), "rb").read()
+    exe = os.path.join(orc.REPO, "bin", "hash10x-amd")
+    for gpus in (1, 2):
+        g = subprocess.run([exe] + (["--gpus", str(gpus)] if gpus > 1 else []) + ["-B", "22", "-ct", "4", "--readFQB", "x.fqb", "--hashDepthRange", "10", "60", "--cluster", "1", "0",
+                           "--writeHash", "cli.hash"], cwd=workdir.path, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+        assert g.returncode == 0, g.stderr.decode()
+        got = open(workdir.file("cli.hash"), "rb").read()
+        assert got == exp, "--gpus %d: %s" % (gpus, orc.describe_diff(got, exp))
+
+
 def test_streaming_ingest_at_the_c_abi(workdir):
     """h10x_ingest_fqb: the reference reads the file chunk by chunk (hash10x.c:202-223) and so can a caller of the C ABI — chunks of 7
     records (barcode runs straddle them at random), of one record, and one chunk for everything, with and without h10x_ingest_reserve,
