@@ -330,6 +330,10 @@ int stageB_finishClusHash(Ctx *c, DevBuf<u64> &key);   // key[e] = index << 32 |
 // forked streams — 256 lanes x 12 items (blocks up to 3072 entries: 98 % of them at 250 read pairs per barcode), 512 x 12, 1024 x 8
 constexpr u32 BLOCK_SORT_CAP0 = 3072, BLOCK_SORT_CAP1 = 6144, BLOCK_SORT_MAX = 8192;
 int stageB_buildProbeTable(Ctx *c);            // hashIndex[] from hashValue[1..hashNumber)
+// the blocks of the three workgroup-local-sort classes as lists: lists[k * nBlocks ..] holds counts[k] block numbers (entries up to CAP0 — incl. the
+// empty blocks and slot 0 —, up to CAP1, up to BLOCK_SORT_MAX); larger blocks are in none. A class's kernel then starts workgroups for ITS blocks
+// only: launched over all blocks, the two large classes spent as long dispatching workgroups that had nothing to do as the small class spent working.
+int stageB_blockClassLists(Ctx *c, DevBuf<u32> &lists, DevBuf<u32> &counts);
 int stageC_depthRange(Ctx *c, int min, int max);
 int stageC_cluster(Ctx *c, int codeMin, int codeMax, int threshold);
 int stageC_split(Ctx *c);

@@ -156,17 +156,41 @@ __global__ void write_clushash_kernel(const u64 *__restrict__ key, u64 n, h10x_c
 // per pass) and write the ClusterHash records — one kernel and one pass over the entries instead of look-up kernel, key
 // array, device-wide segmented sort and record kernel. Three launch classes by block size (2048 / 4096 / 8192 entries);
 // a data set with a larger block takes the device-wide path for everything.
+__global__ void block_class_kernel(const u64 *__restrict__ blockOff, u32 nBlocks, u32 *__restrict__ lists, u32 *__restrict__ counts) {
+  const u32 c = blockIdx.x * blockDim.x + threadIdx.x;
+  const int lane = threadIdx.x & (WAVE - 1);
+  int cls = -1;
+  if (c < nBlocks) { const u64 n = blockOff[c + 1] - blockOff[c]; cls = n <= BLOCK_SORT_CAP0 ? 0 : (n <= BLOCK_SORT_CAP1 ? 1 : (n <= BLOCK_SORT_MAX ? 2 : -1)); }
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {                              // one atomic per wave and class
+    const u64 bal = __ballot(cls == k);
+    if (!bal) continue;
+    u32 base = 0;
+    if (lane == 0) base = atomicAdd(&counts[k], (u32)__popcll(bal));
+    base = (u32)__shfl((int)base, 0);
+    if (cls == k) lists[(size_t)k * nBlocks + base + (u32)__popcll(bal & ((1ULL << lane) - 1))] = c;
+  }
+}
+int stageB_blockClassLists(Ctx *c, DevBuf<u32> &lists, DevBuf<u32> &counts) {
+  H10X_HIP(c, lists.alloc((size_t)3 * c->nBlocks)); H10X_HIP(c, counts.alloc(4));
+  H10X_HIP(c, hipMemsetAsync(counts.p, 0, 16, c->stream));
+  if (c->nBlocks) block_class_kernel<<<divUp(c->nBlocks, 256), 256, 0, c->stream>>>(c->blockOff.p, c->nBlocks, lists.p, counts.p);
+  return 0;
+}
+
 template <int THREADS, int IPT, bool LOOKUP>
 __global__ __launch_bounds__(THREADS)
 void clushash_block_kernel(const u64 *__restrict__ entHash /* hash / w */, const u32 *__restrict__ entRead, const u64 *__restrict__ key /* !LOOKUP: index << 32 | read */,
-                           const u64 *__restrict__ blockOff, u32 nBlocks, const u64 *__restrict__ table64, int B, u64 w, int qBits, int cb /* packed entries */, int sortBits,
+                           const u64 *__restrict__ blockOff, const u32 *__restrict__ list, const u32 *__restrict__ count /* this class's blocks */,
+                           const u64 *__restrict__ table64, int B, u64 w, int qBits, int cb /* packed entries */, int sortBits,
                            h10x_clushash *__restrict__ out) {
   using Sort = rocprim::block_radix_sort<u32, THREADS, IPT, u32>;
   __shared__ typename Sort::storage_type storage;
-  constexpr u32 CAP = THREADS * IPT, LOWER = CAP == BLOCK_SORT_CAP0 ? 0 : (CAP == BLOCK_SORT_CAP1 ? BLOCK_SORT_CAP0 : BLOCK_SORT_CAP1);
-  for (u32 c = blockIdx.x + 1; c < nBlocks; c += gridDim.x) {
+  const u32 nList = *count;
+  for (u32 wi = blockIdx.x; wi < nList; wi += gridDim.x) {
+    const u32 c = list[wi];
     const u64 o = blockOff[c]; const u64 n64 = blockOff[c + 1] - o;
-    if (n64 > CAP || n64 <= LOWER) continue;                 // another class's block (uniform)
+    if (n64 == 0) continue;                                  // (slot 0 and empty blocks are on the small class's list)
     const u32 n = (u32)n64;
     u32 k[IPT], v[IPT];
     const u64 mask = ((u64)1 << B) - 1, qmask = qBits >= 64 ? ~0ULL : ((u64)1 << qBits) - 1;
@@ -210,9 +234,13 @@ static int clusHashByBlocks(Ctx *c, const u64 *entHash, const u32 *entRead, cons
 #ifdef H10X_DBG_SKIP
   sortBits |= (int)(c->optDbgSkip & (1024 | 2048)) >> 4;     // what-if timing (results wrong): 1024 no look-up, 2048 no sort
 #endif
-  const unsigned grid = hmin<u32>(nBlocks - 1, 65535u * 4);
   const int B = c->prm.B; const u64 w = (u64)c->prm.w; const int qBits = c->keyBits;
-#define H10X_CH_LAUNCH(T, I, LOOK, STREAM) clushash_block_kernel<T, I, LOOK><<<grid, T, 0, STREAM>>>(entHash, entRead, key, c->blockOff.p, nBlocks, table64, B, w, qBits, key ? 0 : c->entCodeBits, sortBits, c->clusHash.p)
+  DevBuf<u32> lists, counts;
+  H10X_TRY(stageB_blockClassLists(c, lists, counts));
+  // workgroups per launch: the class's blocks are pulled from its list (count on the device: no round trip); enough workgroups to fill the chip
+  const unsigned gridBig = hmin<u32>(nBlocks, (u32)c->numCU * 8), gridSmall = hmin<u32>(nBlocks, 65535u * 4);
+#define H10X_CH_LAUNCH(T, I, LOOK, STREAM) clushash_block_kernel<T, I, LOOK><<<(T == 256 ? gridSmall : gridBig), T, 0, STREAM>>>(entHash, entRead, key, c->blockOff.p, \
+    lists.p + (size_t)(T == 256 ? 0 : (T == 512 ? 1 : 2)) * nBlocks, counts.p + (T == 256 ? 0 : (T == 512 ? 1 : 2)), table64, B, w, qBits, key ? 0 : c->entCodeBits, sortBits, c->clusHash.p)
   const int side = c->maxBlockHashes > BLOCK_SORT_CAP1 ? 2 : (c->maxBlockHashes > BLOCK_SORT_CAP0 ? 1 : 0);
   ForkGuard forkGuard(c);
   if (side) H10X_TRY(c->forkStreams(side));                  // the few large blocks beside the many small ones

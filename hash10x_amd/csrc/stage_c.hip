@@ -116,17 +116,18 @@ __global__ void offsets32c_kernel(const u64 *__restrict__ off, u32 n, u32 *__res
 // 30 MB at yeast scale, against 4 MB of L2 per XCD)
 template <int THREADS, int IPT, typename WT>
 __global__ __launch_bounds__(THREADS)
-void good_block_kernel(const h10x_clushash *__restrict__ ch, const u64 *__restrict__ blockOff, const h10x_block *__restrict__ blocks, u32 nBlocks,
+void good_block_kernel(const h10x_clushash *__restrict__ ch, const u64 *__restrict__ blockOff, const h10x_block *__restrict__ blocks,
+                       const u32 *__restrict__ list, const u32 *__restrict__ count /* this class's blocks: stageB_blockClassLists */,
                        const WT *__restrict__ wdepth /* 0 = not in range, else depth + 1 */, int sortBits,
                        u16 *__restrict__ goodPos, u32 *__restrict__ nGood, u32 *__restrict__ entries /* sum of depths, saturating */,
                        const u64 *__restrict__ rowStart, u32 rowShift, u64 *__restrict__ goodRow /* list descriptor per rank: see good_rows_kernel */) {
   using Sort = rocprim::block_radix_sort<u32, THREADS, IPT, u32>;
   __shared__ typename Sort::storage_type storage;
   __shared__ u32 sCount; __shared__ unsigned long long sDepth;
-  constexpr u32 CAP = THREADS * IPT, LOWER = CAP == BLOCK_SORT_CAP0 ? 0 : (CAP == BLOCK_SORT_CAP1 ? BLOCK_SORT_CAP0 : BLOCK_SORT_CAP1);
-  for (u32 c = blockIdx.x; c < nBlocks; c += gridDim.x) {
-    const u32 nHash = blocks[c].nHash;
-    if (nHash > CAP || (nHash <= LOWER && LOWER)) continue;  // another class's block (uniform); the smallest class also takes the empty blocks
+  const u32 nList = *count;
+  for (u32 wi = blockIdx.x; wi < nList; wi += gridDim.x) {
+    const u32 c = list[wi];
+    const u32 nHash = blocks[c].nHash;                       // (the smallest class also takes the empty blocks: their counts are written too)
     const u64 o = blockOff[c];
     __syncthreads();
     if (threadIdx.x == 0) { sCount = 0; sDepth = 0; }
@@ -193,13 +194,16 @@ int stageC_depthRange(Ctx *c, int lo, int hi) {
   if (byBlocks) {
     int db = 1; while (db < 16 && (goodDepthBound >> db)) ++db;
     const int sortBits = db + 1;                                              // one bit more than the largest depth: padding keys sort last
-    const unsigned grid = hmin<u32>(nBlocks, 65535u * 4);
+    DevBuf<u32> lists, counts;
+    H10X_TRY(stageB_blockClassLists(c, lists, counts));
+    const unsigned gridBig = hmin<u32>(nBlocks, (u32)c->numCU * 8), gridSmall = hmin<u32>(nBlocks, 65535u * 4);
     const int side = c->maxBlockHashes > BLOCK_SORT_CAP1 ? 2 : (c->maxBlockHashes > BLOCK_SORT_CAP0 ? 1 : 0);
     ForkGuard forkGuard(c);
     if (side) H10X_TRY(c->forkStreams(side));
 #define H10X_GOOD_LAUNCH(T, I, STREAM)                                                                                              \
-    { if (wdepth8.p) good_block_kernel<T, I, u8><<<grid, T, 0, STREAM>>>(c->clusHash.p, c->blockOff.p, c->blocks.p, nBlocks, wdepth8.p, sortBits, c->goodPos.p, c->nGood.p, c->goodEntries.p, c->rowStart.p, (u32)c->rowShift, c->goodRow.p); \
-      else good_block_kernel<T, I, u32><<<grid, T, 0, STREAM>>>(c->clusHash.p, c->blockOff.p, c->blocks.p, nBlocks, wdepth.p, sortBits, c->goodPos.p, c->nGood.p, c->goodEntries.p, c->rowStart.p, (u32)c->rowShift, c->goodRow.p); }
+    { const u32 *const L = lists.p + (size_t)(T == 256 ? 0 : (T == 512 ? 1 : 2)) * nBlocks, *const N = counts.p + (T == 256 ? 0 : (T == 512 ? 1 : 2)); const unsigned grid = T == 256 ? gridSmall : gridBig; \
+      if (wdepth8.p) good_block_kernel<T, I, u8><<<grid, T, 0, STREAM>>>(c->clusHash.p, c->blockOff.p, c->blocks.p, L, N, wdepth8.p, sortBits, c->goodPos.p, c->nGood.p, c->goodEntries.p, c->rowStart.p, (u32)c->rowShift, c->goodRow.p); \
+      else good_block_kernel<T, I, u32><<<grid, T, 0, STREAM>>>(c->clusHash.p, c->blockOff.p, c->blocks.p, L, N, wdepth.p, sortBits, c->goodPos.p, c->nGood.p, c->goodEntries.p, c->rowStart.p, (u32)c->rowShift, c->goodRow.p); }
     H10X_GOOD_LAUNCH(256, 12, st)
     if (side >= 1) H10X_GOOD_LAUNCH(512, 12, c->aux[0])
     if (side >= 2) H10X_GOOD_LAUNCH(1024, 8, c->aux[1])
@@ -1002,7 +1006,8 @@ void good_rows_kernel(const h10x_clushash *__restrict__ ch, const u64 *__restric
 struct ReplayArgs {
   h10x_block *blocks; const u64 *blockOff; h10x_clushash *clusHash; const u16 *goodPos; const u32 *nGood;
   u64 *res;                                                 // in: result words of the list loop; out: the ranks' pointToMin terms (double)
-  u32 codeMin, span, nLo, nHi;                               // blocks [codeMin, codeMin + span) with nLo < nGood <= nHi
+  u32 codeMin, span, nLo, nHi;                               // blocks [codeMin, codeMin + span) with nLo < nGood <= nHi ...
+  const u32 *list;                                           // ... or, if not null, the `span` blocks of this list (the few large ones: no workgroup per barcode of the range)
   unsigned char *scratch; size_t scratchStride;              // IN_LDS = false: working set per workgroup
 };
 #define SYNC() do { __syncthreads(); if (!IN_LDS) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); } while (0)
@@ -1014,7 +1019,7 @@ void replay_kernel(ReplayArgs a) {
   const int tid = threadIdx.x, lane = tid & (WAVE - 1), wave = tid / WAVE;
   unsigned char *region = IN_LDS ? smem : a.scratch + (size_t)blockIdx.x * a.scratchStride;
   for (u32 wi = blockIdx.x; wi < a.span; wi += gridDim.x) {
-    const u32 c = a.codeMin + wi;
+    const u32 c = a.list ? a.list[wi] : a.codeMin + wi;
     const u32 n = a.nGood[c];
     if (n == 0 || n <= a.nLo || n > a.nHi) continue;         // uniform; n == 0: block left untouched (hash10x.c:780)
     const u64 o = a.blockOff[c];
@@ -1282,7 +1287,7 @@ void read_merge_kernel(h10x_block *__restrict__ blocks, const u64 *__restrict__ 
 __global__ void cluster_classify_kernel(const h10x_block *__restrict__ blocks, const u32 *__restrict__ nGood, const u32 *__restrict__ entries, u32 codeMin, u32 codeMax,
                                         u32 nBlocks /* LDS entries of first[] (ranked, hashed: barcodes of the data set) */, int ranked /* 1 ranked, 2 hashed */, u32 hashMinSlots, u32 bmWords, u32 waves0, size_t budget0, size_t budgetSmall, size_t budgetBig, u32 bigRanks,
                                         u32 *__restrict__ list0, u32 *__restrict__ list1, u32 *__restrict__ list2, u32 *__restrict__ list3,
-                                        u32 *__restrict__ counts) {
+                                        u32 *__restrict__ listBig /* blocks with more ranks than the small replay class holds: counts[9] */, u32 *__restrict__ counts) {
   const u32 c = codeMin + blockIdx.x * blockDim.x + threadIdx.x;
   const int lane = threadIdx.x & (WAVE - 1);
   const u32 n = c < codeMax ? nGood[c] : 0;
@@ -1306,6 +1311,15 @@ __global__ void cluster_classify_kernel(const h10x_block *__restrict__ blocks, c
   if (cls == 0 && n > bigRanks) cls = 1;
   for (int s = 32; s; s >>= 1) nRead = max(nRead, (u32)__shfl_xor((int)nRead, s));
   if (lane == 0 && nRead) atomicMax(&counts[8], nRead);
+  {
+    const u64 bal = __ballot(n > REPLAY_SMALL);
+    if (bal) {
+      u32 base = 0;
+      if (lane == 0) base = atomicAdd(&counts[9], (u32)__popcll(bal));
+      base = (u32)__shfl((int)base, 0);
+      if (n > REPLAY_SMALL) listBig[base + (u32)__popcll(bal & ((1ULL << lane) - 1))] = c;
+    }
+  }
   u32 *const lists[4] = {list0, list1, list2, list3};
 #pragma unroll
   for (int k = 0; k < 4; ++k) {                              // one atomic per wave and class
@@ -1324,8 +1338,8 @@ static int cluster_local_range(Ctx *c, int codeMin, int codeMax, int threshold, 
   const u32 nGlobal = c->sharded ? c->nBlocksGlobal : c->nBlocks;
   c->tstart(T_CLUSTER);
   const u32 span = (u32)(codeMax - codeMin);
-  DevBuf<u32> list0, list1, list2, list3; DevBuf<u64> zeroed; DevBuf<u64> term;
-  H10X_HIP(c, list0.alloc(span)); H10X_HIP(c, list1.alloc(span)); H10X_HIP(c, list2.alloc(span)); H10X_HIP(c, list3.alloc(span));
+  DevBuf<u32> list0, list1, list2, list3, listBig; DevBuf<u64> zeroed; DevBuf<u64> term;
+  H10X_HIP(c, list0.alloc(span)); H10X_HIP(c, list1.alloc(span)); H10X_HIP(c, list2.alloc(span)); H10X_HIP(c, list3.alloc(span)); H10X_HIP(c, listBig.alloc(span));
   // every small counter of the command in one buffer, cleared by one memset: counts[0..3] class sizes, [4] [6] [7] work
   // queue positions, [8] largest nRead, [10] [11] overflowed blocks (lists A, B); stats[0..7] the work counters
   H10X_HIP(c, zeroed.alloc(6 + 8)); H10X_HIP(c, term.alloc(c->nEntries));
@@ -1356,13 +1370,14 @@ static int cluster_local_range(Ctx *c, int codeMin, int codeMax, int threshold, 
     cluster_classify_kernel<<<divUp(span, 256), 256, 0, st>>>(c->blocks.p, c->nGood.p, c->goodEntries.p, (u32)codeMin, (u32)codeMax,
                                                             firstMode == 1 || firstMode == 3 ? nGlobal : nFirstLds, firstMode == 1 ? 1 : (firstMode == 3 ? 2 : 0), hashMinSlots,
                                                             bmWords, (u32)threads0 / WAVE, budget0, budgetSmall, budgetBig, c->optBigRanks > 0 ? (u32)c->optBigRanks : c->meanGood + c->meanGood / 2,
-                                                            list0.p, list1.p, list2.p, list3.p, counts.p);
+                                                            list0.p, list1.p, list2.p, list3.p, listBig.p, counts.p);
     H10X_TRY(c->readback(hc, counts.p, 48));
     H10X_TRY(c->syncReadbacks());
     const u32 classified = hc[0] + hc[1] + hc[2] + hc[3];
     if (attempt || !rankedTry || c->optFirstGlobal || firstMode != 1 || hc[3] <= 16 + classified / 200) break;
     firstMode = 3;                                           // too many blocks without room beside the bitmap: the hashed table after all
     H10X_HIP(c, hipMemsetAsync(counts.p, 0, 16, st));        // the four class sizes
+    H10X_HIP(c, hipMemsetAsync(counts.p + 9, 0, 4, st));
   }
   // (the work queue hands barcodes out in the order the classification appended them, i.e. mixed sizes: sorting the
   // queue by descending rank count was measured 17 % SLOWER — workgroups of like size run their phases in step and
@@ -1502,13 +1517,16 @@ static int cluster_local_range(Ctx *c, int codeMin, int codeMax, int threshold, 
     ra.nLo = 0; ra.nHi = REPLAY_SMALL;
     replay_kernel<true, 256><<<span, 256, replayBytes(hmin<u32>(REPLAY_SMALL, hmax<u32>(c->maxGood, 1))), st>>>(ra);
 #endif
-    if (c->maxGood > REPLAY_SMALL) {
-      H10X_HIP(c, hipFuncSetAttribute((const void *)replay_kernel<true, 1024>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)replayBytes(REPLAY_MID)));
+    // the barcodes with more ranks than that (hc[9] of them, listed by the classification): workgroups for those only
+    ra.list = listBig.p; ra.span = hc[9];
+    if (hc[9]) {
+      const size_t lds = replayBytes(hmin<u32>(REPLAY_MID, c->maxGood));
+      H10X_HIP(c, hipFuncSetAttribute((const void *)replay_kernel<true, 1024>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
       ra.nLo = REPLAY_SMALL; ra.nHi = REPLAY_MID;
-      replay_kernel<true, 1024><<<span, 1024, replayBytes(REPLAY_MID), st>>>(ra);
+      replay_kernel<true, 1024><<<hc[9], 1024, lds, st>>>(ra);
     }
-    if (c->maxGood > REPLAY_MID) {
-      const u32 grid = hmin<u32>(span, (u32)c->numCU);
+    if (hc[9] && c->maxGood > REPLAY_MID) {
+      const u32 grid = hmin<u32>(hc[9], (u32)c->numCU);
       ra.scratchStride = (replayBytes(c->maxGood) + 255) & ~(size_t)255;
       H10X_HIP(c, replayScratch.alloc(ra.scratchStride * grid));
       ra.scratch = replayScratch.p; ra.nLo = REPLAY_MID; ra.nHi = 0xFFFFFFFFu;

@@ -49,11 +49,17 @@ for f in glob.glob(os.path.join(G, tag + "_stats", "**", "*kernel_stats.csv"), r
     if not suffix:
         shutil.copy(f, os.path.join(P, tag + "_kernel_stats.csv"))
 
+# what was measured: the commit the tree was at when it was sent to the GPU box, and the library's embedded source hash (h10x_build_id):
+# bench.py copies them into the line and flags the traffic figure as stale when the running library is another build
+meta_path = os.path.join(G, tag + "_meta.json")
+META = json.load(open(meta_path)) if os.path.exists(meta_path) else {}
+
 interesting = ("h10x::", "radix_sort", "segmented", "onesweep")
 traffic = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, no trace flags) -- python3 <script>; dispatches of the last step",
            "unit": "bytes (counter value x 1024)",
            "note": "raw counters; MI355X_MICROARCH.md: on gfx950 FETCH_SIZE reads 1/2 of wide (16 B/lane) coalesced reads; 4-8 B/lane gathers are uncalibrated",
-           "dominant": "cluster_kernel<true, 1, 1024, 0>" if "config3" in tag else "cluster_kernel<true, 0, 1024, 0>", "kernels": {}}
+           "dominant": os.environ.get("H10X_DOMINANT") or ("cluster_kernel<true, 1, 1024, 0>" if "config3" in tag else "cluster_kernel<true, 0, 1024, 0>"),
+           "head": META.get("head"), "build_id": META.get("build_id"), "script": META.get("script"), "kernels": {}}
 for counter, sub in (("FETCH_SIZE", "fetch"), ("WRITE_SIZE", "write")):
     per, _ = load(os.path.join(G, "%s_%s" % (tag, sub)))
     for k, cs in per.items():
@@ -66,7 +72,7 @@ if traffic["kernels"]:
 
 sq = {"source": "rocprofv3 --pmc <8 SQ counters per pass> (passes sqA..sqD, tcc of scratch/prof_all.sh; no trace flags); sums over the dispatches of the last step",
       "units": "SQ_*_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* are quad-cycles summed over waves (MI355X_MICROARCH.md); SQ_BUSY_CYCLES per SE; GRBM_GUI_ACTIVE summed over XCDs",
-      "kernels": {}}
+      "head": META.get("head"), "build_id": META.get("build_id"), "script": META.get("script"), "kernels": {}}
 for sub in ("sqA", "sqB", "sqC", "sqD", "tcc"):
     per, meta = load(os.path.join(G, "%s_%s" % (tag, sub)))
     for k, cs in per.items():

@@ -8,6 +8,7 @@ TAG=$1; SCRIPT=${2:-scratch/one_step.py}
 export TMPDIR=/tmp
 O=gpurun_out
 mkdir -p $O
+python3 -c "import json, os, sys; sys.path.insert(0, '.'); import hash10x_amd; json.dump({'head': os.environ.get('H10X_HEAD'), 'build_id': hash10x_amd.build_id(), 'script': '$SCRIPT'}, open('$O/${TAG}_meta.json', 'w'))"
 if [ -n "$ONLY_SQ" ]; then :                      # counters only (no bench, no kernel trace): quick look at one script
 elif [ -z "$SKIP_BENCH" ]; then
   python3 bench.py --steps 10 --warmup 2 > $O/${TAG}_bench.json 2> $O/${TAG}_bench.err
