@@ -535,7 +535,10 @@ __device__ __forceinline__ void row_mode_hist(const u32 *__restrict__ row, u32 f
     }
   // no value reached the threshold (most long lists): the caller only tests msMax >= threshold (hash10x.c:807), so the
   // wave reduction is skipped and the rank is reported inactive
-  if (!(RCHUNK > 2) || __builtin_amdgcn_ballot_w64((key >> 16) >= thr)) {
+#ifndef H10X_SKIP_DPP
+#define H10X_SKIP_DPP 0       // 1: also the short lists test "some count reaches the threshold" before the wave reduction
+#endif
+  if ((!(RCHUNK > 2) && !H10X_SKIP_DPP) || __builtin_amdgcn_ballot_w64(key >= (thr << 16))) {
     key = wave_max_u32(key);
     bcnt = key >> 16;
     best = key ? 0xFFFFu - (key & 0xFFFFu) : NONE16;

@@ -722,12 +722,18 @@ def test_config3_full_size_matches_reference_digest(case, tmp_path_factory):
     del recs
     h = hash10x_amd.Hash10x(B=case["B"])
     h.read_fqb_device(d.ptr, d.n_records)
-    d.free()
     a = case["args"]
     h.depth_range(int(a[1]), int(a[2]))
     h.cluster(int(a[4]), int(a[5]), 5)
     z = h.sizes()
     assert z["hashNumber"] == case["hash_number"] and z["nBlocks"] == case["blocks_max"] and z["nClusHash"] == case["sum_nHash"]
+    # BASELINE names -B 28 for this set: 101.9 M distinct hashes against the cap of 2^26 - 2 = 67.1 M — the reference dies there
+    # (manifest.json "die_cases": c3_200m.B28, 11 minutes into --readFQB), and so must we, with its message
+    h28 = hash10x_amd.Hash10x(B=28)
+    with pytest.raises(hash10x_amd.Hash10xError, match="hashTableSize is too small"):
+        h28.read_fqb_device(d.ptr, d.n_records)
+    h28.close()
+    d.free()
     out = str(tmp_path_factory.mktemp("full") / "full.hash")
     try:
         h.write_hash(out)
