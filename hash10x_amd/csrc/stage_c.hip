@@ -400,7 +400,11 @@ __device__ __forceinline__ void min_u16(u16 *arr, u32 idx, u32 val) {
 // Dense and ranked placements in LDS come in two widths, chosen per block: a u32 per entry where the block's working set
 // leaves the room (minimum = one fire-and-forget ds_min_u32, no loop), the u16 of the CAS-min otherwise. The list loop is
 // bound by scalar and branch instructions (0.8 per CU cycle), and the CAS loop is mostly those.
+#ifndef H10X_SELF_HANDLE
+#define H10X_SELF_HANDLE 1    // dense placement: a lane without an entry (and the barcode's own number) keeps the barcode's own slot as its handle — first[] of
+#endif                        // the barcode itself is never written and reads "unseen", so the read-back needs no test and no exec mask
 template <bool FIRST_LDS> struct FirstDense {
+  static constexpr bool SELF = H10X_SELF_HANDLE != 0;
   u16 *first; u32 wide;                                      // wide: 1 = 4-byte entries (their low half, at the same address, is the value), else 0
   __device__ __forceinline__ u32 update(u32 cj, u32 i) const {
     if (FIRST_LDS && wide) atomicMin(&((u32 *)first)[cj], i); else min_u16<FIRST_LDS>(first, cj, i);
@@ -413,6 +417,7 @@ template <bool FIRST_LDS> struct FirstDense {
   __device__ __forceinline__ u32 lookup(u32 cj) const { return peek(cj); }
 };
 struct FirstRanked {
+  static constexpr bool SELF = false;
   u16 *first; const u32 *bm; const u16 *pre; u32 wide;
   __device__ __forceinline__ u32 at(u32 cj) const { const u32 w = cj >> 5; return pre[w] + (u32)__popc(bm[w] & ((1u << (cj & 31)) - 1u)); }
   __device__ __forceinline__ u32 update(u32 cj, u32 i) const { const u32 h = at(cj); if (wide) atomicMin(&((u32 *)first)[h], i); else min_u16<true>(first, h, i); return h; }
@@ -420,6 +425,7 @@ struct FirstRanked {
   __device__ __forceinline__ u32 lookup(u32 cj) const { return peek(at(cj)); }
 };
 struct FirstHashed {
+  static constexpr bool SELF = false;
   // Buckets of 4 entries (one ds_read_b128 shows a whole bucket: at 2/3 load nearly every search ends in its home bucket).
   // Entry = rank << 16 | bucket displacement << 10 | tag, (home bucket, tag) = (q mod NB, q div NB); 0xFFFFFFFF = empty.
   u32 *tab; u32 NB /* buckets */, recip /* ceil(2^32 / NB) */, bmask; u32 *ovf;
@@ -498,6 +504,9 @@ __device__ __forceinline__ u32 wave_max_u32(u32 v) {
 // the cluster it joins, rb = root[msBest] — known as soon as msBest's own round is over, i.e. for all but the few ranks
 // whose msBest lies in the round being processed (rb = NONE16: settled after the loop). The second gather of round 2's
 // phase (d) is gone for the rest, and with it the need to keep msMax / msTot per rank on chip.
+#ifndef H10X_Q_BALLOT
+#define H10X_Q_BALLOT 1       // the count of the root's value is taken from the registers (one compare + ballot per chunk) instead of from the histogram,
+#endif                        // which can then be cleared in the same exec region as its atomics
 template <bool IN_LDS, int RCHUNK, typename FT>
 __device__ __forceinline__ void row_mode_hist(const u32 *__restrict__ row, u32 f0, u32 f1 /* first[] of entries lane, 64 + lane, read for all lists of the round together; NONE16 = no entry */, u32 d, u32 code, u32 i, const FT &ft, u32 *hist,
                                               const u16 *root, u32 thr, u32 &best, u32 &bcnt, u32 &tot, u32 &rb, u32 &q) {
@@ -513,7 +522,7 @@ __device__ __forceinline__ void row_mode_hist(const u32 *__restrict__ row, u32 f
 #if H10X_PREPEEK
         f[r] = r == 0 ? f0 : f1; ok[r] = f[r] < i;
 #else
-        const u32 h = r == 0 ? f0 : f1; if (h != NOHANDLE) { f[r] = ft.peek(h); ok[r] = f[r] < i; }   // (f0 / f1 are handles in this build)
+        const u32 h = r == 0 ? f0 : f1; if (FT::SELF || h != NOHANDLE) { f[r] = ft.peek(h); ok[r] = f[r] < i; }   // (f0 / f1 are handles in this build)
 #endif
       }
       else if (j < d) { const u32 cj = row[j]; if (cj != code) { f[r] = ft.lookup(cj); ok[r] = f[r] < i; } }
@@ -532,7 +541,23 @@ __device__ __forceinline__ void row_mode_hist(const u32 *__restrict__ row, u32 f
       const u32 c = ((atomicAdd(&hist[f[r] >> 2], 1u << sh8) >> sh8) & 0xFFu) + 1;
       const u32 k = (c << 16) | (0xFFFFu - f[r]);
       key = k > key ? k : key;
+#if H10X_Q_BALLOT
+      if (RCHUNK == 1) {                                     // a one-chunk list is cleared in the exec region of its atomics (ds ops of a wave stay in order)
+        if (IN_LDS) hist[f[r] >> 2] = 0;
+        else atomicAnd(&hist[f[r] >> 2], 0u);                // HBM scratch: a plain store could be overtaken by the next list's atomics
+      }
+#endif
     }
+#if H10X_Q_BALLOT
+  if (RCHUNK > 1) {                                          // longer lists: once every chunk has been counted (a value's entries may lie in several chunks)
+#pragma unroll
+    for (int r = 0; r < RCHUNK; ++r)
+      if ((u32)(r * WAVE) < d && ok[r]) {
+        if (IN_LDS) hist[f[r] >> 2] = 0;
+        else atomicAnd(&hist[f[r] >> 2], 0u);
+      }
+  }
+#endif
   // no value reached the threshold (most long lists): the caller only tests msMax >= threshold (hash10x.c:807), so the
   // wave reduction is skipped and the rank is reported inactive
 #ifndef H10X_SKIP_DPP
@@ -544,15 +569,24 @@ __device__ __forceinline__ void row_mode_hist(const u32 *__restrict__ row, u32 f
     best = key ? 0xFFFFu - (key & 0xFFFFu) : NONE16;
     if (bcnt >= thr) {                                       // wave-uniform (readlane result)
       rb = ld_shared<IN_LDS>(&root[best]);
+#if H10X_Q_BALLOT
+      if (rb != NONE16) {
+#pragma unroll
+        for (int r = 0; r < RCHUNK; ++r) if ((u32)(r * WAVE) < d) q += (u32)__popcll(__ballot(ok[r] && f[r] == rb));
+      }
+#else
       if (rb != NONE16) q = (ld_shared<IN_LDS>(&hist[rb >> 2]) >> ((rb & 3) * 8)) & 0xFFu;
+#endif
     }
   }
+#if !H10X_Q_BALLOT
 #pragma unroll
   for (int r = 0; r < RCHUNK; ++r)
     if ((u32)(r * WAVE) < d && ok[r]) {
       if (IN_LDS) hist[f[r] >> 2] = 0;                       // ds ops of a wave stay in order
       else atomicAnd(&hist[f[r] >> 2], 0u);                  // HBM scratch: a plain store could be overtaken by the next list's atomics
     }
+#endif
 }
 // entries of a list whose first[] value equals v (and, in tot, those below i): one wavefront, any length
 template <typename FT>
@@ -793,17 +827,31 @@ __device__ void cluster_one_block(const ClusterArgs &a, u32 code, unsigned char 
     dvCur = dvN; dvN = dvNN; dvNN = dvD;
 #pragma unroll
     for (int t = 0; t < RIF; ++t) { cj[t] = cjN[t]; cj2[t] = cj2N[t]; cjN[t] = cjNN[t]; dl[t] = (u32)__builtin_amdgcn_readlane((int)dvCur, 32 + t); }
+#ifndef H10X_SKIP_B
+#define H10X_SKIP_B 1         // 1: the second chunks of a round's lists are only asked for when one of the lists has one
+#endif
+#if H10X_SKIP_B
+    if constexpr (FIRST_MODE != 0) H10X_LOAD_B(cj2N, dvN) else
+    // (dense placement = small data sets, where most lists fit one chunk; lanes 32 .. 32 + RIF - 1 of the descriptor register hold the lengths: one compare and a ballot say whether any list of the next round is longer than
+    // a chunk — at yeast scale one list in seven is, so more than half of the rounds skip the RIF address set-ups; the registers then keep stale values that
+    // nobody reads: every use of a second chunk is behind `length > 64`)
+    if (__builtin_amdgcn_ballot_w64(lane >= 32 && dvN > (u32)WAVE)) H10X_LOAD_B(cj2N, dvN)
+#else
     H10X_LOAD_B(cj2N, dvN)
+#endif
     H10X_LOAD_A(cjNN, dvNN)
     H10X_LOAD_D(listWave ? i0 + 3 * stepR : n, dvD)
 #define RS_OF(t) ((u32)__builtin_amdgcn_readlane((int)dvCur, t))   /* list offset of this round's list t: only lists of more than two chunks ask */
 #pragma unroll
     for (int t = 0; t < RIF; ++t) {
       const u32 i = i0 + t;
-      if (H10X_DBGSKIP(1)) { cj[t] = cj[t] != code ? cj[t] : NOHANDLE; continue; }
-      cj[t] = cj[t] != code ? ft.update(cj[t], i) : NOHANDLE;          // from here on cj / cj2 hold handles
+      using FTT = decltype(ft);
+      if (H10X_DBGSKIP(1)) { if (!FTT::SELF) cj[t] = cj[t] != code ? cj[t] : NOHANDLE; continue; }
+      if constexpr (FTT::SELF) { if (cj[t] != code) ft.update(cj[t], i); }          // dense: the barcode number IS the handle (the barcode's own: reads "unseen")
+      else cj[t] = cj[t] != code ? ft.update(cj[t], i) : NOHANDLE;    // from here on cj / cj2 hold handles
       if (dl[t] > WAVE) {
-        cj2[t] = cj2[t] != code ? ft.update(cj2[t], i) : NOHANDLE;
+        if constexpr (FTT::SELF) { if (cj2[t] != code) ft.update(cj2[t], i); }
+        else cj2[t] = cj2[t] != code ? ft.update(cj2[t], i) : NOHANDLE;
         if (dl[t] > 2 * WAVE) { const u32 *row = ROWP(RS_OF(t)); for (u32 j = 2 * WAVE + lane; j < dl[t]; j += WAVE) { const u32 c2 = row[j]; if (c2 != code) ft.update(c2, i); } }
       }
     }
@@ -843,7 +891,19 @@ __device__ void cluster_one_block(const ClusterArgs &a, u32 code, unsigned char 
 #if H10X_BATCH
         if (lane == t) { rootV = act ? rb : i; resV = RES_PACK(act ? best : NONE16, q, tot); mine = true; }
 #else
+#ifndef H10X_SCALAR_PACK
+#define H10X_SCALAR_PACK 0    // 1: the result word is put together on the scalar unit (every input is wave-uniform)
+#endif
+#if H10X_SCALAR_PACK
+        {
+          const u32 sBest = (u32)__builtin_amdgcn_readfirstlane((int)(act ? best : (u32)NONE16)), sQ = (u32)__builtin_amdgcn_readfirstlane((int)q), sTot = (u32)__builtin_amdgcn_readfirstlane((int)tot);
+          const u32 sRoot = (u32)__builtin_amdgcn_readfirstlane((int)(act ? rb : i));
+          const u64 word = RES_PACK(sBest, sQ, sTot);
+          if (lane == 0) { w.root[i] = (u16)sRoot; res[i] = word; }
+        }
+#else
         if (lane == 0) { w.root[i] = act ? (u16)rb : (u16)i; res[i] = RES_PACK(act ? best : NONE16, q, tot); }
+#endif
 #endif
         sDepth += d;
       }

@@ -268,7 +268,12 @@ def main():
         r = orc.run_ref(["-B", B - 1, "--readFQB", "die.fqb"], tmp, timeout=3600)
         os.remove(os.path.join(tmp, "die.fqb"))
         assert r.returncode != 0 and b"hashTableSize is too small" in r.stderr, r.stderr
-        man["die_cases"] = [{"name": "c3_20m.B%d" % (B - 1), "gen": gen, "B": B - 1, "message": "hashTableSize is too small",
+        try:
+            with open(os.path.join(HERE, "manifest.json")) as f:
+                other_dies = [d for d in json.load(f).get("die_cases", []) if d["name"] != "c3_20m.B%d" % (B - 1)]      # (c3_200m.B28: recorded by hand from a 9-minute run, see its note)
+        except OSError:
+            other_dies = []
+        man["die_cases"] = other_dies + [{"name": "c3_20m.B%d" % (B - 1), "gen": gen, "B": B - 1, "message": "hashTableSize is too small",
                              "note": "reference binary: FATAL ERROR: hashTableSize is too small (the -B %d run of the same set counts %d hashes)"
                                      % (B, man["big_digest_cases"][0]["hash_number"])}]
     else:
