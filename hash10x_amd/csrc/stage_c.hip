@@ -405,6 +405,7 @@ __device__ __forceinline__ void min_u16(u16 *arr, u32 idx, u32 val) {
 #endif                        // the barcode itself is never written and reads "unseen", so the read-back needs no test and no exec mask
 template <bool FIRST_LDS> struct FirstDense {
   static constexpr bool SELF = H10X_SELF_HANDLE != 0;
+  u32 none;                                                  // (the barcode's own number: set per barcode)
   u16 *first; u32 wide;                                      // wide: 1 = 4-byte entries (their low half, at the same address, is the value), else 0
   __device__ __forceinline__ u32 update(u32 cj, u32 i) const {
     if (FIRST_LDS && wide) atomicMin(&((u32 *)first)[cj], i); else min_u16<FIRST_LDS>(first, cj, i);
@@ -419,6 +420,7 @@ template <bool FIRST_LDS> struct FirstDense {
 struct FirstRanked {
   static constexpr bool SELF = false;
   u16 *first; const u32 *bm; const u16 *pre; u32 wide;
+  u32 none;                                                  // handle of a lane without an entry: one slot behind the last barcode present, always unseen
   __device__ __forceinline__ u32 at(u32 cj) const { const u32 w = cj >> 5; return pre[w] + (u32)__popc(bm[w] & ((1u << (cj & 31)) - 1u)); }
   __device__ __forceinline__ u32 update(u32 cj, u32 i) const { const u32 h = at(cj); if (wide) atomicMin(&((u32 *)first)[h], i); else min_u16<true>(first, h, i); return h; }
   __device__ __forceinline__ u32 peek(u32 h) const { return *(const u16 *)((const unsigned char *)first + ((size_t)h << (1 + wide))); }
@@ -426,6 +428,7 @@ struct FirstRanked {
 };
 struct FirstHashed {
   static constexpr bool SELF = false;
+  u32 none;                                                  // handle of a lane without an entry: one word behind the table, always empty (reads as unseen)
   // Buckets of 4 entries (one ds_read_b128 shows a whole bucket: at 2/3 load nearly every search ends in its home bucket).
   // Entry = rank << 16 | bucket displacement << 10 | tag, (home bucket, tag) = (q mod NB, q div NB); 0xFFFFFFFF = empty.
   u32 *tab; u32 NB /* buckets */, recip /* ceil(2^32 / NB) */, bmask; u32 *ovf;
@@ -522,7 +525,7 @@ __device__ __forceinline__ void row_mode_hist(const u32 *__restrict__ row, u32 f
 #if H10X_PREPEEK
         f[r] = r == 0 ? f0 : f1; ok[r] = f[r] < i;
 #else
-        const u32 h = r == 0 ? f0 : f1; if (FT::SELF || h != NOHANDLE) { f[r] = ft.peek(h); ok[r] = f[r] < i; }   // (f0 / f1 are handles in this build)
+        const u32 h = r == 0 ? f0 : f1; if (H10X_SELF_HANDLE || h != NOHANDLE) { f[r] = ft.peek(h); ok[r] = f[r] < i; }   // (f0 / f1 are handles in this build)
 #endif
       }
       else if (j < d) { const u32 cj = row[j]; if (cj != code) { f[r] = ft.lookup(cj); ok[r] = f[r] < i; } }
@@ -698,13 +701,14 @@ __device__ void cluster_one_block(const ClusterArgs &a, u32 code, unsigned char 
   }
   // ranked placement: first[] lies BEHIND the histograms and both are laid out after the bitmap pass, when the number of
   // barcodes present is known: the list loop then runs on as many waves as what is left of the budget has room for
-  Work w = carve(region, HASHED ? 2 * slots : (RANKED ? 0 : (FIRST_LDS || !IN_LDS ? (wideFirst ? 2 * a.nBlocksFirst : a.nBlocksFirst) : 0)), n, bmWords);
+  Work w = carve(region, HASHED ? 2 * slots + 8 : (RANKED ? 0 : (FIRST_LDS || !IN_LDS ? (wideFirst ? 2 * a.nBlocksFirst : a.nBlocksFirst) : 0)), n, bmWords);
   if (IN_LDS && FIRST_MODE == 2) w.first = firstGlobal;      // hybrid: first[] on this workgroup's HBM slot, the rest in LDS
   typename std::conditional<HASHED, FirstHashed, typename std::conditional<RANKED, FirstRanked, FirstDense<FIRST_LDS>>::type>::type ft{};
-  if constexpr (HASHED) { slots &= ~3u; ft.tab = (u32 *)w.first; ft.NB = slots / 4; ft.recip = (u32)((0x100000000ULL + ft.NB - 1) / ft.NB); ft.bmask = a.hashMask; ft.ovf = &sh[2]; }
+  if constexpr (HASHED) { slots &= ~3u; ft.none = slots; ft.tab = (u32 *)w.first; ft.NB = slots / 4; ft.recip = (u32)((0x100000000ULL + ft.NB - 1) / ft.NB); ft.bmask = a.hashMask; ft.ovf = &sh[2]; }
   else if constexpr (RANKED) { ft.first = w.first; ft.bm = w.bm; ft.pre = w.pre; ft.wide = 0; }
   else { ft.first = w.first; ft.wide = wideFirst ? 1u : 0u; }
-  const u32 lcode = code; code = a.segs.globalOf(lcode);     // from here on `code` is the global barcode number (what the lists hold)
+  const u32 lcode = code; code = a.segs.globalOf(lcode);
+  if constexpr (!HASHED && !RANKED) ft.none = code;     // from here on `code` is the global barcode number (what the lists hold)
   const u32 rsh = a.rowShift;
 #define ROWP(rs) (a.rows + ((size_t)(rs) << rsh))
   const u64 *const gr = a.goodRow + o;
@@ -715,7 +719,7 @@ __device__ void cluster_one_block(const ClusterArgs &a, u32 code, unsigned char 
   // ---- init: clear the tables; nothing is fetched per rank any more
   if (FIRST_LDS && !RANKED) {
     if (wideFirst) for (u32 i = tid; i < a.nBlocksFirst; i += CL_THREADS) ((u32 *)w.first)[i] = NONE16;
-    else for (u32 i = tid; i < (HASHED ? slots : (a.nBlocksFirst + 1) / 2); i += CL_THREADS) ((u32 *)w.first)[i] = 0xFFFFFFFFu;
+    else for (u32 i = tid; i < (HASHED ? slots + 1 : (a.nBlocksFirst + 1) / 2); i += CL_THREADS) ((u32 *)w.first)[i] = 0xFFFFFFFFu;   // (hashed: + the word of handle `none`)
   }
   if (HASHED && tid == 0) sh[2] = 0;
   if (RANKED) for (u32 i = tid; i < bmWords; i += CL_THREADS) w.bm[i] = 0;
@@ -726,13 +730,21 @@ __device__ void cluster_one_block(const ClusterArgs &a, u32 code, unsigned char 
   if constexpr (RANKED) {
     // ---- (0) which barcodes occur in this block's lists: presence bitmap, per-word popcount prefix, and a first[] sized by
     // the number present. More present than the table holds => the block is handed to the HBM-slot variant.
-    // eight lists per wave in flight (their chunks are requested together); most entries meet a bit that is already
-    // set: look before the atomic (LDS atomics cost per active lane)
+    // eight lists per wave in flight (their chunks are requested together). Round 2 looked at the word before the atomic (most entries
+    // meet a bit that is already set, and LDS atomics cost per active lane); since the kernel is bound by its vector instructions
+    // and not by LDS time, the unconditional OR is the cheaper one (1/10 config-3 set: cluster 40.9 -> 40.0 ms)
     // (the bitmap is addressed as LDS explicitly: through the generic pointer this build of the compiler emits an invalid compare
     // against the shared aperture base for the volatile look — "Illegal instruction detected" — in the RIF = 2 instantiation)
     typedef __attribute__((address_space(3))) u32 lds_u32;
     lds_u32 *const bm3 = (lds_u32 *)w.bm;
+#ifndef H10X_MARK_DIRECT
+#define H10X_MARK_DIRECT 1    // 1: the bitmap pass ORs every entry's bit in without looking first
+#endif
+#if H10X_MARK_DIRECT
+    auto mark = [&](u32 cj) { if (cj != code) __hip_atomic_fetch_or(&bm3[cj >> 5], 1u << (cj & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); };
+#else
     auto mark = [&](u32 cj) { if (cj != code) { const u32 bit = 1u << (cj & 31); if (!(*(volatile lds_u32 *)&bm3[cj >> 5] & bit)) __hip_atomic_fetch_or(&bm3[cj >> 5], bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); } };
+#endif
     // (both chunks of the eight lists are requested together: met one list at a time, the second chunk — most lists have one where the
     // depth range reaches 100 and the lists are long — was a load waited for per list: a third of the launch on the 1/10 config-3 set)
     constexpr int BIF = 8;                                   // lists in flight per wave in this pass (few live registers here)
@@ -786,8 +798,9 @@ __device__ void cluster_one_block(const ClusterArgs &a, u32 code, unsigned char 
       ft.first = w.first;
     }
     for (u32 i = tid; i < nW * w.histWords; i += CL_THREADS) w.hist[i] = 0;
-    if (ft.wide) for (u32 q = tid; q < total; q += CL_THREADS) ((u32 *)w.first)[q] = NONE16;
-    else for (u32 q = tid; q < (total + 1) / 2; q += CL_THREADS) ((u32 *)w.first)[q] = 0xFFFFFFFFu;
+    ft.none = total;                                          // (the 32 spare bytes of `need` hold this slot)
+    if (ft.wide) for (u32 q = tid; q <= total; q += CL_THREADS) ((u32 *)w.first)[q] = NONE16;
+    else for (u32 q = tid; q < (total + 2) / 2; q += CL_THREADS) ((u32 *)w.first)[q] = 0xFFFFFFFFu;
     SYNC();
   }
   STAMP(0);
@@ -846,12 +859,12 @@ __device__ void cluster_one_block(const ClusterArgs &a, u32 code, unsigned char 
     for (int t = 0; t < RIF; ++t) {
       const u32 i = i0 + t;
       using FTT = decltype(ft);
-      if (H10X_DBGSKIP(1)) { if (!FTT::SELF) cj[t] = cj[t] != code ? cj[t] : NOHANDLE; continue; }
+      if (H10X_DBGSKIP(1)) { if (!FTT::SELF) cj[t] = cj[t] != code ? cj[t] : (H10X_SELF_HANDLE ? ft.none : NOHANDLE); continue; }
       if constexpr (FTT::SELF) { if (cj[t] != code) ft.update(cj[t], i); }          // dense: the barcode number IS the handle (the barcode's own: reads "unseen")
-      else cj[t] = cj[t] != code ? ft.update(cj[t], i) : NOHANDLE;    // from here on cj / cj2 hold handles
+      else cj[t] = cj[t] != code ? ft.update(cj[t], i) : (H10X_SELF_HANDLE ? ft.none : NOHANDLE);    // from here on cj / cj2 hold handles
       if (dl[t] > WAVE) {
         if constexpr (FTT::SELF) { if (cj2[t] != code) ft.update(cj2[t], i); }
-        else cj2[t] = cj2[t] != code ? ft.update(cj2[t], i) : NOHANDLE;
+        else cj2[t] = cj2[t] != code ? ft.update(cj2[t], i) : (H10X_SELF_HANDLE ? ft.none : NOHANDLE);
         if (dl[t] > 2 * WAVE) { const u32 *row = ROWP(RS_OF(t)); for (u32 j = 2 * WAVE + lane; j < dl[t]; j += WAVE) { const u32 c2 = row[j]; if (c2 != code) ft.update(c2, i); } }
       }
     }
