@@ -51,6 +51,11 @@ int prim_sort_pairs_u32_u32(Ctx *c, PrimTemp &t, const u32 *kin, u32 *kout, cons
   PRIM_TWO_PHASE(c, t, rocprim::radix_sort_pairs(tmp, bytes, kin, kout, vin, vout, n, (unsigned)b0, (unsigned)b1, c->stream));
   return 0;
 }
+int prim_sort_pairs_u32_v16(Ctx *c, PrimTemp &t, const u32 *kin, u32 *kout, const Val16 *vin, Val16 *vout, size_t n, int b0, int b1) {
+  if (!n) return 0;
+  PRIM_TWO_PHASE(c, t, rocprim::radix_sort_pairs(tmp, bytes, kin, kout, vin, vout, n, (unsigned)b0, (unsigned)b1, c->stream));
+  return 0;
+}
 int prim_sort_keys_u64(Ctx *c, PrimTemp &t, const u64 *kin, u64 *kout, size_t n, int b0, int b1) {
   if (!n) return 0;
   PRIM_TWO_PHASE(c, t, rocprim::radix_sort_keys(tmp, bytes, kin, kout, n, (unsigned)b0, (unsigned)(b1 > 64 ? 64 : b1), c->stream));

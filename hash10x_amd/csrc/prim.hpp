@@ -16,6 +16,8 @@ int prim_inclusive_scan_u32(Ctx *c, PrimTemp &t, const u32 *in, u32 *out, size_t
 int prim_sort_pairs_u64_u32(Ctx *c, PrimTemp &t, const u64 *kin, u64 *kout, const u32 *vin, u32 *vout, size_t n, int beginBit, int endBit);
 int prim_sort_pairs_u32_u32(Ctx *c, PrimTemp &t, const u32 *kin, u32 *kout, const u32 *vin, u32 *vout, size_t n, int beginBit, int endBit);
 int prim_sort_keys_u64(Ctx *c, PrimTemp &t, const u64 *kin, u64 *kout, size_t n, int beginBit, int endBit);
+struct Val16 { u64 a; u32 b, c; };                          // a 16-byte payload that rides through a sort (stage_b.hip: a distinct hash with its list's start and end)
+int prim_sort_pairs_u32_v16(Ctx *c, PrimTemp &t, const u32 *kin, u32 *kout, const Val16 *vin, Val16 *vout, size_t n, int beginBit, int endBit);
 // per-segment sort of 64-bit keys (segments = [begin[i], end[i]) ), keys must be distinct per segment
 int prim_seg_sort_keys_u64(Ctx *c, PrimTemp &t, const u64 *kin, u64 *kout, u32 n, u32 nSeg, const u32 *begin, const u32 *end, int beginBit, int endBit);
 int prim_seg_sort_keys_u32(Ctx *c, PrimTemp &t, const u32 *kin, u32 *kout, u32 n, u32 nSeg, const u32 *begin, const u32 *end, int beginBit, int endBit);

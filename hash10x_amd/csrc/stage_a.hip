@@ -176,11 +176,13 @@ __device__ __forceinline__ bool probe_done(u64 *table, u32 slot, u64 cur, u32 pL
 // one write per slot — and empties it 64 at a time with every lane probing for one entry.
 constexpr u32 MOSH_QCAP = 96, MOSH_QKEEP = MOSH_QCAP - WAVE;      // entries per wave; at most QKEEP may stay behind before a slot's push of up to 64
 typedef __attribute__((address_space(3))) volatile u64 lds_queue_t;   // typed as LDS: a volatile generic pointer compiles to flat accesses, each waited for
-__device__ __forceinline__ void queue_push(lds_queue_t *q, u32 &qn /* wave-uniform */, bool ok, u32 hLo, u32 hHi, u32 read) {
+// (a queue entry is the hash with the read above it — hash | read << 48, 2k <= 48 — and becomes the set's hash << 16 | read on the way out:
+// the push runs for nine slots in ten with two or three lanes, the drain with all 64)
+__device__ __forceinline__ void queue_push(lds_queue_t *q, u32 &qn /* wave-uniform */, bool ok, u32 hLo, u32 hHi, u32 read16 /* read << 16 */) {
   const u64 bal = __builtin_amdgcn_ballot_w64(ok);
   if (!bal) return;
   const u32 pre = __builtin_amdgcn_mbcnt_hi((u32)(bal >> 32), __builtin_amdgcn_mbcnt_lo((u32)bal, 0u));
-  if (ok) q[qn + pre] = mk64(__builtin_amdgcn_alignbit(hHi, hLo, 16), (hLo << 16) | read);
+  if (ok) q[qn + pre] = mk64(hHi | read16, hLo);
   qn += (u32)__popcll(bal);
 }
 // takes up to 64 entries off the top of the queue; false = the table is full
@@ -188,10 +190,12 @@ __device__ __forceinline__ bool queue_drain(u64 *table, u32 mask, lds_queue_t *q
   const u32 n = qn < (u32)WAVE ? qn : (u32)WAVE;
   qn -= n;
   bool go = (u32)lane < n;
-  u64 packed = EMPTY64;
-  if (go) packed = q[qn + lane];
-  const u32 pLo = lo32(packed), pHi = hi32(packed);
-  u32 slot = set_slot_of(__builtin_amdgcn_alignbit(pHi, pLo, 16), pHi >> 16, mask);
+  u64 raw = 0;
+  if (go) raw = q[qn + lane];
+  const u32 hLo = lo32(raw), hHi = hi32(raw) & 0xFFFFu;
+  const u32 pLo = (hLo << 16) | (hi32(raw) >> 16), pHi = __builtin_amdgcn_alignbit(hHi, hLo, 16);
+  const u64 packed = mk64(pHi, pLo);
+  u32 slot = set_slot_of(hLo, hHi, mask);
   for (u32 probes = 0; __builtin_amdgcn_ballot_w64(go); ++probes) {
     if (probes > mask) return false;
     if (go) {
@@ -208,15 +212,40 @@ __device__ __forceinline__ void mul64_lo(u32 xLo, u32 xHi, u32 fLo, u32 fHi, u32
   pLo = lo32(p); pHi = hi32(p) + xLo * fHi + xHi * fLo;
 }
 
+// min of two 64-bit words held as halves: the borrow of a 32-bit subtract chain picks (a 64-bit compare costs four times a 32-bit operation)
+__device__ __forceinline__ void min64_halves(u32 aLo, u32 aHi, u32 bLo, u32 bHi, u32 &mLo, u32 &mHi) {
+  asm("v_sub_co_u32 %0, vcc, %2, %4\n\tv_subb_co_u32 %0, vcc, %3, %5, vcc\n\tv_cndmask_b32 %0, %4, %2, vcc\n\tv_cndmask_b32 %1, %5, %3, vcc"
+      : "=&v"(mLo), "=&v"(mHi) : "v"(aLo), "v"(aHi), "v"(bLo), "v"(bHi) : "vcc");
+}
+// 4 p + t in one instruction (the compiler reaches v_lshl_add_u64 only with a shift of 0 here)
+__device__ __forceinline__ u64 roll_product(u64 p, u64 t) {
+  u64 r;
+  asm("v_lshl_add_u64 %0, %1, 2, %2" : "=v"(r) : "v"(p), "v"(t));
+  return r;
+}
+// reverse complement of the 2k-bit word (hi, lo), 32 < 2k < 64, on halves: reverse the bits of the complement, put the bit pairs back in order, shift down
+__device__ __forceinline__ void revcomp_halves(u32 lo, u32 hi, int down /* 64 - 2k, 1..31 */, u32 &rLo, u32 &rHi) {
+  u32 a = __builtin_bitreverse32(~lo), b = __builtin_bitreverse32(~hi);   // the reversed word is (a, b): a its high half
+  a = ((a >> 1) & 0x55555555u) | ((a << 1) & 0xAAAAAAAAu);
+  b = ((b >> 1) & 0x55555555u) | ((b << 1) & 0xAAAAAAAAu);
+  rLo = __builtin_amdgcn_alignbit(a, b, (u32)down); rHi = a >> down;
+}
+
 // One workgroup per barcode block, no staging tile and no barrier in the main loop: 32 lanes share a read pair, each
 // lane owns a run of L (8 or 9) consecutive k-mer slots of one read. It fetches the 4 packed dwords that cover its run
 // straight from HBM (the next pair's are requested before the current pair is hashed) and ROLLS the forward word (2 bits in
 // per step) and the reverse-complement word (seqhash.c:75: shift right, complement of the new base in at the top) instead
 // of re-extracting a window per slot; what is left per slot is the two 64-bit multiplies of hashFunc, the min and the
 // divisibility test. Survivors (1 in w) are parked, two per lane, and inserted into the LDS hash set once per pair.
-// FAST (17 <= k <= 30, the usual range): everything on 32-bit halves — the two words roll by funnel shifts, the bases still
-// to come sit in one dword (2 L <= 32 bits) whose fields are picked with constant offsets, min(hf, hr) is taken before the
-// one shift both share; the general form keeps 64-bit arithmetic.
+// FAST (17 <= k <= 30, the usual range): everything on 32-bit halves, and the PRODUCTS roll, not the words. With F = factor1 and b(i) base i
+// of the run, the forward word obeys f(j+1) = 4 f(j) + b(j+k) - b(j) 2^2k, so f(j+1) F = 4 f(j) F + [b(j+k) F - b(j) (F << 2k)] (mod 2^64);
+// the reverse-complement word (seqhash.c:75) obeys the mirror image walking BACKWARDS, rc(j) = 4 rc(j+1) + (3 - b(j)) - (3 - b(j+k)) 2^2k.
+// Both bracketed terms depend on the same two bases: one 16-entry table in LDS, indexed by b(j) << 2 | b(j+k), holds them side by
+// side. A lane multiplies twice per read pair (first forward word, last reverse word), walks the reverse products back into registers,
+// then walks forward: per slot two shift-and-adds, the min (taken before the one shift both products share), the divisibility test.
+// The quarter-rate multiplies of hashFunc (seqhash.c:58-59) — six per slot before — are gone from the loop; results are the same
+// products mod 2^64. Every lane owns a FULL run of L slots (the last lane of a read starts early and re-hashes a few slots of its
+// neighbour: the set drops the duplicates), so the loop has no per-slot mask. The general form keeps 64-bit arithmetic.
 template <bool W31, int L /* slots per lane: mc.run */, bool FAST>
 __global__ __launch_bounds__(1024)
 void mosh_lds_kernel(const u32 *__restrict__ rec, const u32 *__restrict__ list, u32 nList,
@@ -228,27 +257,36 @@ void mosh_lds_kernel(const u32 *__restrict__ rec, const u32 *__restrict__ list, 
   const u32 code = list[blockIdx.x];
   const u32 S = slots[code], mask = S - 1;
   u64 *table = (u64 *)smem;
-  lds_queue_t *queue = (lds_queue_t *)(smem + tableBytes) + (threadIdx.x / WAVE) * MOSH_QCAP;
+  lds_queue_t *queue = (lds_queue_t *)(smem + tableBytes) + (u32)__builtin_amdgcn_readfirstlane((int)(threadIdx.x / WAVE)) * MOSH_QCAP;   // (a scalar: the push adds its lane offset in one instruction)
   u32 qn = 0;
   __shared__ u32 sOverflow, sCount;
+  __shared__ u64 sRoll[32];                                  // FAST: [2 t] forward, [2 t + 1] reverse roll term of t = leaving base << 2 | entering base
   const u64 rec0 = startRec[code];
   const u32 nRead = (u32)(startRec[code + 1] - rec0);
 
   for (u32 i = threadIdx.x; i < S; i += blockDim.x) table[i] = EMPTY64;
   if (threadIdx.x == 0) { sOverflow = 0; sCount = 0; }
+  if (FAST && threadIdx.x < 16) {
+    const u64 a = threadIdx.x >> 2, b = threadIdx.x & 3, top = mc.factor1 << (2 * mc.k);   // (2k < 64 here)
+    sRoll[2 * threadIdx.x] = b * mc.factor1 - a * top;
+    sRoll[2 * threadIdx.x + 1] = (3 - a) * mc.factor1 - (3 - b) * top;
+  }
   __syncthreads();
 
   // this lane's run of slots
   const int lane = threadIdx.x & (WAVE - 1), sub = lane & 31, wv = threadIdx.x / WAVE;
   const int lanes1 = (mc.n1 + L - 1) / L, lanes2 = (mc.n2 + L - 1) / L;                 // lanes1 + lanes2 <= 32 (stageA_run picks L)
   int cnt = 0, pos0 = 0, wordBase = 0;
-  if (sub < lanes1) { const int t0 = sub * L; cnt = min(L, mc.n1 - t0); pos0 = 23 + t0; }                                  // hash10x.c:162  &s1[23], 127 bases
-  else if (sub < lanes1 + lanes2) { const int t0 = (sub - lanes1) * L; cnt = min(L, mc.n2 - t0); pos0 = t0; wordBase = 15; }   // hash10x.c:163  s2, 150 bases
-  const int wi = wordBase + (pos0 >> 4), sh = (pos0 & 15) * 2;
+  if (sub < lanes1) { int t0 = sub * L; if (FAST) t0 = min(t0, mc.n1 - L); cnt = min(L, mc.n1 - t0); pos0 = 23 + t0; }   // hash10x.c:162  &s1[23], 127 bases
+  else if (sub < lanes1 + lanes2) { int t0 = (sub - lanes1) * L; if (FAST) t0 = min(t0, mc.n2 - L); cnt = min(L, mc.n2 - t0); pos0 = t0; wordBase = 15; }   // hash10x.c:163  s2, 150 bases
+  const int sh = (pos0 & 15) * 2;
+  // FAST aligns the run with 32-bit funnel shifts by 32 - sh; a run that starts on a dword edge fetches from one dword earlier, the
+  // shift by 32 - 32 then hands back the second word of each pair — no special case (the dword before a read is inside the record)
+  const int wi = wordBase + (pos0 >> 4) - (FAST && sh == 0 ? 1 : 0);
+  const u32 unal = (u32)(32 - sh) & 31u;
   const int k2 = 2 * mc.k, down = 64 - k2;
   const u32 pairsPerRound = (blockDim.x / WAVE) * 2;
   const u32 fLo = lo32(mc.factor1), fHi = hi32(mc.factor1);
-  const u32 maskHi = 0xFFFFFFFFu >> (down & 31);            // FAST: the 2k - 32 bits of the forward word's high half
   u32 r = (u32)wv * 2 + (u32)(lane >> 5);
   uint4 nx = make_uint4(0, 0, 0, 0);
   if (r < nRead && cnt > 0) { const u32 *p = rec + (rec0 + r) * 30 + wi; nx = make_uint4(p[0], p[1], p[2], p[3]); }
@@ -257,47 +295,63 @@ void mosh_lds_kernel(const u32 *__restrict__ rec, const u32 *__restrict__ list, 
     const u32 rn = r + pairsPerRound;
     if (rn < nRead && cnt > 0 && !H10X_MOSH_DBG(512)) { const u32 *p = rec + (rec0 + rn) * 30 + wi; nx = make_uint4(p[0], p[1], p[2], p[3]); }
     if (H10X_MOSH_DBG(512)) nx = make_uint4(cw.y * 0x9E3779B1u + r, cw.x ^ 0x85EBCA6Bu, cw.w + cw.x, cw.z * 5u + 1u);
+    const bool live = r < nRead && !H10X_MOSH_DBG(32);
+    if (FAST) {
+      // the run's bases, MSB first (fq2b.c:33-42; the un-justified tail word is consumed as is: SURVEY F6): base i at bits [95 - 2i, 94 - 2i] of (x0, x1, x2)
+      const u32 x0 = __builtin_amdgcn_alignbit(cw.x, cw.y, unal), x1 = __builtin_amdgcn_alignbit(cw.y, cw.z, unal), x2 = __builtin_amdgcn_alignbit(cw.z, cw.w, unal);
+      const u32 inw = __builtin_amdgcn_alignbit(x1, x2, (u32)down);     // base k + j at bits [31 - 2j, 30 - 2j]   (2k - 32 = 32 - down bits into x1)
+      u32 ta[L - 1];                                                    // byte offset of slot j's pair of roll terms
+#pragma unroll
+      for (int j = 0; j < L - 1; ++j) { ta[j] = (((x0 >> (30 - 2 * j)) & 3u) << 6) | (((inw >> (30 - 2 * j)) & 3u) << 4); asm("" : "+v"(ta[j])); }   // (or its two halves are kept and joined twice)
+      // last window -> its reverse complement -> product; then back to slot 0
+      u64 pr[L];
+      {
+        const u32 g0 = __builtin_amdgcn_alignbit(x0, x1, 32 - 2 * (L - 1)), g1 = __builtin_amdgcn_alignbit(x1, x2, 32 - 2 * (L - 1));
+        u32 rl, rh;
+        revcomp_halves(__builtin_amdgcn_alignbit(g0, g1, (u32)down), g0 >> down, down, rl, rh);
+        u32 pl, ph;
+        mul64_lo(rl, rh, fLo, fHi, pl, ph);
+        pr[L - 1] = mk64(ph, pl);
+      }
+#pragma unroll
+      for (int j = L - 2; j >= 0; --j) pr[j] = roll_product(pr[j + 1], *(const u64 *)((const char *)sRoll + ta[j] + 8));
+      u64 pf;
+      { u32 pl, ph; mul64_lo(__builtin_amdgcn_alignbit(x0, x1, (u32)down), x0 >> down, fLo, fHi, pl, ph); pf = mk64(ph, pl); }
+      u32 thr = live && cnt > 0 ? 0xFFFFFFFFu / 31u + 1u : 0u;          // x divisible by 31 <=> x * (1 / 31 mod 2^32) <= (2^32 - 1) / 31
+      asm("" : "+v"(thr));                                              // (kept a per-lane bound: as a condition of its own it costs two more instructions per slot)
+      const u32 r16 = r << 16;
+#pragma unroll
+      for (int j = 0; j < L; ++j) {
+        u64 t = 0;
+        if (j < L - 1) t = *(const u64 *)((const char *)sRoll + ta[j]);   // asked for before the slot's test, used after it
+        u32 mL, mH;
+        min64_halves(lo32(pf), hi32(pf), lo32(pr[j]), hi32(pr[j]), mL, mH);       // seqhash.c:67-68, the shift of :58-59 comes after the min: it is monotone
+        const u32 hL = __builtin_amdgcn_alignbit(mH, mL, (u32)down), hH = mH >> down;
+        bool ok;
+        if (W31) ok = ((hL & 0x3FFFFFFFu) + __builtin_amdgcn_alignbit(hH, hL, 30)) * 0xBDEF7BDFu < thr;   // 2^30 == 1 (mod 31); h < 2^60
+        else ok = (mk64(hH, hL) % (u64)mc.w) == 0 && thr != 0;
+        queue_push(queue, qn, ok, hL, hH, r16);
+        if (H10X_MOSH_DBG(16)) { if (qn > MOSH_QKEEP) qn = 0; }
+        else if (qn > MOSH_QKEEP && !queue_drain(table, mask, queue, qn, lane)) sOverflow = 1;
+        if (j < L - 1) pf = roll_product(pf, t);
+      }
+      continue;
+    }
     // 128-bit shift register, bases MSB first (fq2b.c:33-42; the un-justified tail word is consumed as is: SURVEY F6)
     u64 hi = ((u64)cw.x << 32) | cw.y, lo = ((u64)cw.z << 32) | cw.w;
     if (sh) { hi = (hi << sh) | (lo >> (64 - sh)); lo <<= sh; }
     u64 f = hi >> down;
     u64 rc = revcomp_word(f, mc.k);
-    const bool live = r < nRead && !H10X_MOSH_DBG(32);
-    if (FAST) {
-      u32 fl = lo32(f), fh = hi32(f), rl = lo32(rc), rh = hi32(rc);
-      const u32 inw = hi32((hi << k2) | (lo >> down));       // the bases after the first window: base j + 1 at bits [31 - 2j, 30 - 2j]
-      const u32 cinw = ~inw;
 #pragma unroll
-      for (int j = 0; j < L; ++j) {
-        u32 pfL, pfH, prL, prH;
-        mul64_lo(fl, fh, fLo, fHi, pfL, pfH);                // seqhash.c:58-59, the shift comes after the min: it is monotone
-        mul64_lo(rl, rh, fLo, fHi, prL, prH);
-        const bool flt = mk64(pfH, pfL) < mk64(prH, prL);    // seqhash.c:67-68
-        const u32 mL = flt ? pfL : prL, mH = flt ? pfH : prH;
-        const u32 hL = __builtin_amdgcn_alignbit(mH, mL, (u32)down), hH = mH >> down;
-        bool ok;
-        if (W31) ok = (((hL & 0x3FFFFFFFu) + __builtin_amdgcn_alignbit(hH, hL, 30)) % 31u) == 0;   // 2^30 == 1 (mod 31); h < 2^60
-        else ok = (mk64(hH, hL) % (u64)mc.w) == 0;
-        queue_push(queue, qn, ok && live && j < cnt, hL, hH, r);
-        if (H10X_MOSH_DBG(16)) { if (qn > MOSH_QKEEP) qn = 0; }
-        else if (qn > MOSH_QKEEP && !queue_drain(table, mask, queue, qn, lane)) sOverflow = 1;
-        // next base in
-        const u32 nb = (inw >> (30 - 2 * j)) & 3u, cb = (cinw >> (30 - 2 * j)) & 3u;
-        fh = __builtin_amdgcn_alignbit(fh, fl, 30) & maskHi; fl = (fl << 2) | nb;
-        rl = __builtin_amdgcn_alignbit(rh, rl, 2); rh = (rh >> 2) | (cb << (k2 - 34));
-      }
-    } else {
-#pragma unroll
-      for (int j = 0; j < L; ++j) {
-        const u64 hf = (f * mc.factor1) >> mc.shift1;          // seqhash.c:58-59
-        const u64 hr = (rc * mc.factor1) >> mc.shift1;
-        const u64 h = hf < hr ? hf : hr;                       // seqhash.c:67-68
-        queue_push(queue, qn, divisible<W31>(h, mc.w) && live && j < cnt, lo32(h), hi32(h), r);
-        if (qn > MOSH_QKEEP && !queue_drain(table, mask, queue, qn, lane)) sOverflow = 1;
-        hi = (hi << 2) | (lo >> 62); lo <<= 2;                 // next base in
-        f = hi >> down;
-        rc = (rc >> 2) | ((u64)(3u - ((u32)f & 3u)) << (k2 - 2));
-      }
+    for (int j = 0; j < L; ++j) {
+      const u64 hf = (f * mc.factor1) >> mc.shift1;          // seqhash.c:58-59
+      const u64 hr = (rc * mc.factor1) >> mc.shift1;
+      const u64 h = hf < hr ? hf : hr;                       // seqhash.c:67-68
+      queue_push(queue, qn, divisible<W31>(h, mc.w) && live && j < cnt, lo32(h), hi32(h), r << 16);
+      if (qn > MOSH_QKEEP && !queue_drain(table, mask, queue, qn, lane)) sOverflow = 1;
+      hi = (hi << 2) | (lo >> 62); lo <<= 2;                 // next base in
+      f = hi >> down;
+      rc = (rc >> 2) | ((u64)(3u - ((u32)f & 3u)) << (k2 - 2));
     }
   }
   while (qn) if (!queue_drain(table, mask, queue, qn, lane)) { sOverflow = 1; break; }

@@ -31,19 +31,31 @@ __global__ void seg_scatter_kernel(const u64 *__restrict__ sHash, const u32 *__r
     dHash[d] = sHash[i]; dFirst[d] = sCode[i]; segStart[d] = (u32)i; iota[d] = d;
   }
 }
-// the same from packed entries, which also leaves the barcode lists (the block numbers in sorted order) behind
+// the same from packed entries, which also leaves the barcode lists (the block numbers in sorted order) behind. Round 3: a distinct hash
+// travels through the sort by first barcode as ONE 16-byte value (hash / w, start and end of its barcode list) — the thread at a run's head
+// writes the first two, the thread at its tail the third — so that the index assignment reads its inputs in order instead of gathering
+// hash, start and end of every distinct hash from three arrays in hash order (352 MB fetched for 36 MB of output, r2h).
 __global__ void seg_scatter_packed_kernel(const u64 *__restrict__ sKey, int cb,
-                                          const u32 *__restrict__ ord, u64 n, u64 *__restrict__ dHash, u32 *__restrict__ dFirst,
-                                          u32 *__restrict__ segStart, u32 *__restrict__ iota, u32 *__restrict__ rows) {
+                                          const u32 *__restrict__ ord, u64 n, Val16 *__restrict__ dVal, u32 *__restrict__ dFirst, u32 *__restrict__ rows) {
   u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
   const u64 stride = (u64)gridDim.x * blockDim.x;
   const u64 cmask = ((u64)1 << cb) - 1;
   for (; i < n; i += stride) {
     const u64 k = sKey[i]; const u32 code = (u32)(k & cmask);
     rows[i] = code;
-    const u32 d = ord[i];
-    if (ord[i + 1] != d) { dHash[d] = k >> cb; dFirst[d] = code; segStart[d] = (u32)i; iota[d] = d; }
+    const u32 d = ord[i], d1 = ord[i + 1];                   // d1 != d: a run starts here (its ordinal is d)
+    if (d1 != d) { dVal[d].a = k >> cb; dVal[d].b = (u32)i; dFirst[d] = code; }
+    if (i + 1 == n || ord[i + 2] != d1) dVal[d1 - 1].c = (u32)i + 1;   // a run starts at i + 1 (or the entries end): the run that holds i ends here
   }
+}
+// i-th distinct hash in (firstBarcode, hash) order gets index i + 1: from the sorted values, in order
+__global__ void assign_index_v16_kernel(const Val16 *__restrict__ val, u32 U, u64 w /* val.a holds hash / w */, u64 *__restrict__ hashValue, u32 *__restrict__ hashDepth,
+                                        u64 *__restrict__ rowStart) {
+  const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i == 0) { hashValue[0] = 0; hashDepth[0] = 0; rowStart[0] = 0; }
+  if (i >= U) return;
+  const Val16 v = val[i];
+  hashValue[i + 1] = v.a * w; hashDepth[i + 1] = v.c - v.b; rowStart[i + 1] = v.b;
 }
 
 // i-th distinct hash in (firstBarcode, hash) order gets index i + 1
@@ -272,27 +284,35 @@ int stageB_run(Ctx *c, DevBuf<u64> &entHash, DevBuf<u32> &entCode, DevBuf<u32> &
   // ---- distinct hashes, first barcode, depth
   c->tstart(T_RANK);
   u32 U = 0;
-  DevBuf<u64> dHash; DevBuf<u32> dFirst, segStart, iota, order, dFirstSorted;
+  DevBuf<u64> dHash; DevBuf<u32> dFirst, segStart, iota, order, dFirstSorted; DevBuf<Val16> dVal, dValSorted;
   {
     DevBuf<u32> ord;
-    H10X_HIP(c, ord.alloc(H + 1));
+    H10X_HIP(c, ord.alloc(H + 2));                           // (+ 1: the packed scatter looks two ahead)
     H10X_TRY(prim_run_ordinals_u64(c, pt, sHash.p, cb, ord.p, H));          // (head flags formed inside the scan)
     H10X_TRY(c->readback(&U, ord.p + H, 4));
     H10X_TRY(c->syncReadbacks());
     // hash10x.c:149: die once hashNumber exceeds 2^(B-2) - 2; hashNumber ends at U + 1
     if ((u64)U + 1 > (tableSize >> 2) - 2) return c->fail("hashTableSize is too small");
-    H10X_HIP(c, dHash.alloc(U)); H10X_HIP(c, dFirst.alloc(U)); H10X_HIP(c, segStart.alloc((size_t)U + 1));
-    H10X_HIP(c, iota.alloc(U)); H10X_HIP(c, order.alloc(U)); H10X_HIP(c, dFirstSorted.alloc(U));
-    if (H && cb) seg_scatter_packed_kernel<<<gH, 256, 0, st>>>(sHash.p, cb, ord.p, H, dHash.p, dFirst.p, segStart.p, iota.p, sCode.p);
-    else if (H) seg_scatter_kernel<<<gH, 256, 0, st>>>(sHash.p, sCode.p, ord.p, H, dHash.p, dFirst.p, segStart.p, iota.p);
-    H10X_HIP(c, hipMemsetD32Async((hipDeviceptr_t)(segStart.p + U), (int)(u32)H, 1, st));      // end of the last segment
+    H10X_HIP(c, dFirst.alloc(U)); H10X_HIP(c, dFirstSorted.alloc(U));
+    if (cb) { H10X_HIP(c, dVal.alloc(U)); H10X_HIP(c, dValSorted.alloc(U)); }
+    else { H10X_HIP(c, dHash.alloc(U)); H10X_HIP(c, segStart.alloc((size_t)U + 1)); H10X_HIP(c, iota.alloc(U)); H10X_HIP(c, order.alloc(U)); }
+    if (H && cb) seg_scatter_packed_kernel<<<gH, 256, 0, st>>>(sHash.p, cb, ord.p, H, dVal.p, dFirst.p, sCode.p);
+    else if (H) {
+      seg_scatter_kernel<<<gH, 256, 0, st>>>(sHash.p, sCode.p, ord.p, H, dHash.p, dFirst.p, segStart.p, iota.p);
+      H10X_HIP(c, hipMemsetD32Async((hipDeviceptr_t)(segStart.p + U), (int)(u32)H, 1, st));    // end of the last segment
+    }
   }
   // distinct hashes are in ascending hash order; a stable sort by first barcode gives (first, hash) order
-  H10X_TRY(prim_sort_pairs_u32_u32(c, pt, dFirst.p, dFirstSorted.p, iota.p, order.p, U, 0, bitsFor(nBlocks)));
   c->hashNumber = U + 1; c->depthBound = nBlocks;             // a hash is met at most once per barcode
   H10X_HIP(c, c->hashValue.alloc((size_t)U + 1)); H10X_HIP(c, c->hashDepth.alloc((size_t)U + 1));
   H10X_HIP(c, c->rowStart.alloc((size_t)U + 2));
-  assign_index_kernel<<<divUp((u64)U + 1, 256), 256, 0, st>>>(order.p, dHash.p, segStart.p, U, (u64)c->prm.w, c->hashValue.p, c->hashDepth.p, c->rowStart.p);
+  if (cb) {
+    H10X_TRY(prim_sort_pairs_u32_v16(c, pt, dFirst.p, dFirstSorted.p, dVal.p, dValSorted.p, U, 0, bitsFor(nBlocks)));
+    assign_index_v16_kernel<<<divUp((u64)U + 1, 256), 256, 0, st>>>(dValSorted.p, U, (u64)c->prm.w, c->hashValue.p, c->hashDepth.p, c->rowStart.p);
+  } else {
+    H10X_TRY(prim_sort_pairs_u32_u32(c, pt, dFirst.p, dFirstSorted.p, iota.p, order.p, U, 0, bitsFor(nBlocks)));
+    assign_index_kernel<<<divUp((u64)U + 1, 256), 256, 0, st>>>(order.p, dHash.p, segStart.p, U, (u64)c->prm.w, c->hashValue.p, c->hashDepth.p, c->rowStart.p);
+  }
   c->rows.swap(sCode);                                       // barcode lists, grouped by hash (ascending barcodes)
   c->tstop(T_RANK);
   sHash.release(); dHash.release(); dFirst.release(); iota.release(); dFirstSorted.release();
