@@ -226,27 +226,29 @@ struct Ctx {
     char buf[1024]; va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof buf, fmt, ap); va_end(ap);
     err = buf; return -1;
   }
-  // Small device -> host read-backs (counts, totals) land in a pinned mailbox: a copy into pageable memory is staged by the
-  // runtime and costs ~8 us more per round trip. readback() queues the copy, syncReadbacks() waits for the stream and
-  // hands the values to their destinations.
-  static constexpr size_t MAIL_BYTES = 4096;
-  unsigned char *mail = nullptr; size_t mailUsed = 0;
-  struct PendingRead { void *dst; size_t off, n; };
+  // Small device -> host read-backs (counts, totals: the sizes the next launches are made with) land in a pinned, coherent
+  // mailbox. readback() only notes what is wanted; syncReadbacks() queues ONE small kernel that stores the values and then a
+  // sequence number into the mailbox, and the host spins on that number — a round trip of a few microseconds where a
+  // device-to-host copy followed by hipStreamSynchronize cost 25-40 (the step makes eight of them, each with the GPU idle).
+  // (prim.hip; a read-back that does not fit the mailbox is copied the ordinary way.)
+  static constexpr size_t MAIL_BYTES = 4096, MAIL_ITEMS = 12;
+  unsigned char *mail = nullptr; size_t mailUsed = 0; u32 mailSeq = 0; bool mailDirect = false;
+  struct PendingRead { void *dst; const void *dev; size_t off, n; };
   std::vector<PendingRead> pendingReads;
   int readback(void *dst, const void *dev, size_t n) {
-    if (!mail && hipHostMalloc((void **)&mail, MAIL_BYTES, hipHostMallocDefault) != hipSuccess) { mail = nullptr; return fail("hipHostMalloc of the read-back mailbox failed"); }
+    if (!mail) {
+      if (hipHostMalloc((void **)&mail, MAIL_BYTES + 64, hipHostMallocCoherent | hipHostMallocMapped) != hipSuccess) { mail = nullptr; return fail("hipHostMalloc of the read-back mailbox failed"); }
+      memset(mail, 0, MAIL_BYTES + 64);                    // (the sequence number lives behind the values)
+    }
     const size_t off = mailUsed, step = (n + 7) & ~(size_t)7;
-    if (off + step > MAIL_BYTES) return hipMemcpyAsync(dst, dev, n, hipMemcpyDeviceToHost, stream) == hipSuccess ? 0 : fail("hipMemcpyAsync (device to host) failed");
-    if (hipMemcpyAsync(mail + off, dev, n, hipMemcpyDeviceToHost, stream) != hipSuccess) return fail("hipMemcpyAsync (device to host) failed");
-    mailUsed += step; pendingReads.push_back(PendingRead{dst, off, n});
+    if (off + step > MAIL_BYTES || pendingReads.size() >= MAIL_ITEMS) {
+      mailDirect = true;
+      return hipMemcpyAsync(dst, dev, n, hipMemcpyDeviceToHost, stream) == hipSuccess ? 0 : fail("hipMemcpyAsync (device to host) failed");
+    }
+    mailUsed += step; pendingReads.push_back(PendingRead{dst, dev, off, n});
     return 0;
   }
-  int syncReadbacks() {
-    const hipError_t e = hipStreamSynchronize(stream);
-    for (const PendingRead &r : pendingReads) memcpy(r.dst, mail + r.off, r.n);
-    pendingReads.clear(); mailUsed = 0;
-    return e == hipSuccess ? 0 : fail("HIP error %s at stream synchronisation", hipGetErrorString(e));
-  }
+  int syncReadbacks();
   int forkStreams(int n) {                               // side streams wait for everything issued on the main stream so far
     if (!evFork) {
       if (hipEventCreateWithFlags(&evFork, hipEventDisableTiming) != hipSuccess) return fail("hipEventCreate failed");

@@ -13,7 +13,7 @@ static int enter(Ctx &c) {
   if (hipSetDevice(c.device) != hipSuccess) return c.fail("hipSetDevice(%d) failed", c.device);
   AllocScope::stream() = c.stream; AllocScope::device() = c.device;
   DevCache::noteStream(c.device, c.stream);
-  c.pendingReads.clear(); c.mailUsed = 0;                    // read-backs a failed call left behind point into its dead frame
+  c.pendingReads.clear(); c.mailUsed = 0; c.mailDirect = false;                    // read-backs a failed call left behind point into its dead frame
   return 0;
 }
 

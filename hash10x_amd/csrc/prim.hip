@@ -51,6 +51,42 @@ int prim_sort_pairs_u32_u32(Ctx *c, PrimTemp &t, const u32 *kin, u32 *kout, cons
   PRIM_TWO_PHASE(c, t, rocprim::radix_sort_pairs(tmp, bytes, kin, kout, vin, vout, n, (unsigned)b0, (unsigned)b1, c->stream));
   return 0;
 }
+// ---- the read-back mailbox (common.hpp)
+struct MailArgs { const unsigned char *src[Ctx::MAIL_ITEMS]; u32 off[Ctx::MAIL_ITEMS], n[Ctx::MAIL_ITEMS]; u32 count; };
+__global__ void mail_post_kernel(MailArgs a, unsigned char *mail, u32 *flag, u32 seq) {
+  for (u32 i = 0; i < a.count; ++i)
+    for (u32 b = threadIdx.x; b < a.n[i]; b += blockDim.x) mail[a.off[i] + b] = a.src[i][b];
+  __threadfence_system();
+  __syncthreads();
+  if (threadIdx.x == 0) __hip_atomic_store(flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+int Ctx::syncReadbacks() {
+  hipError_t e = hipSuccess;
+  if (pendingReads.empty() || mailDirect) e = hipStreamSynchronize(stream);     // nothing to post, or an ordinary copy is on its way too
+  if (!pendingReads.empty() && e == hipSuccess) {
+    MailArgs a; a.count = (u32)pendingReads.size();
+    for (u32 i = 0; i < a.count; ++i) { a.src[i] = (const unsigned char *)pendingReads[i].dev; a.off[i] = (u32)pendingReads[i].off; a.n[i] = (u32)pendingReads[i].n; }
+    u32 *flag = (u32 *)(mail + MAIL_BYTES);
+    const u32 seq = ++mailSeq ? mailSeq : ++mailSeq;                            // (never 0: the mailbox starts zeroed)
+    mail_post_kernel<<<1, 64, 0, stream>>>(a, mail, flag, seq);
+    e = hipGetLastError();
+    for (u64 spins = 0; e == hipSuccess && __atomic_load_n(flag, __ATOMIC_ACQUIRE) != seq; ++spins) {
+#if !defined(__HIP_DEVICE_COMPILE__)
+      __builtin_ia32_pause();
+#endif
+      if ((spins & 0xFFF) == 0xFFF) {                                           // every few microseconds: is the stream still alive?
+        const hipError_t q = hipStreamQuery(stream);
+        if (q == hipErrorNotReady) continue;
+        if (q == hipSuccess && __atomic_load_n(flag, __ATOMIC_ACQUIRE) == seq) break;
+        e = q == hipSuccess ? hipErrorUnknown : q;                              // the stream drained without the post, or died
+      }
+    }
+    if (e == hipSuccess) for (const PendingRead &r : pendingReads) memcpy(r.dst, mail + r.off, r.n);
+  }
+  pendingReads.clear(); mailUsed = 0; mailDirect = false;
+  return e == hipSuccess ? 0 : fail("HIP error %s at a read-back", hipGetErrorString(e));
+}
+
 int prim_sort_pairs_u32_v16(Ctx *c, PrimTemp &t, const u32 *kin, u32 *kout, const Val16 *vin, Val16 *vout, size_t n, int b0, int b1) {
   if (!n) return 0;
   PRIM_TWO_PHASE(c, t, rocprim::radix_sort_pairs(tmp, bytes, kin, kout, vin, vout, n, (unsigned)b0, (unsigned)b1, c->stream));

@@ -6,6 +6,6 @@ wl = bench.WORKLOADS["yeast-like-2.5M"]
 recs = bench.generate(wl, 1)
 d = hash10x_amd.DeviceRecords(recs)
 h = hash10x_amd.Hash10x(B=wl["B"])
-for it in range(2):
+for it in range(int(os.environ.get("STEPS", "2"))):
     h.read_fqb_device(d.ptr, d.n_records); h.depth_range(wl["lo"], wl["hi"]); h.cluster(1, 0, wl["ct"])
 print("done", h.sizes())
