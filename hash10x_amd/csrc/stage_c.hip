@@ -1582,6 +1582,16 @@ static int cluster_local_range(Ctx *c, int codeMin, int codeMax, int threshold, 
   {
     ReplayArgs ra{}; ra.blocks = c->blocks.p; ra.blockOff = c->blockOff.p; ra.clusHash = c->clusHash.p; ra.goodPos = c->goodPos.p; ra.nGood = c->nGood.p;
     ra.res = term.p; ra.codeMin = (u32)codeMin; ra.span = span;
+    // the barcodes with more ranks than the common class holds (hc[9] of them, listed by the classification): workgroups for those only,
+    // on a side stream beside the common class (disjoint blocks)
+    if (hc[9]) {
+      H10X_TRY(c->forkStreams(1));
+      ReplayArgs rb = ra; rb.list = listBig.p; rb.span = hc[9];
+      const size_t lds = replayBytes(hmin<u32>(REPLAY_MID, c->maxGood));
+      H10X_HIP(c, hipFuncSetAttribute((const void *)replay_kernel<true, 1024>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      rb.nLo = REPLAY_SMALL; rb.nHi = REPLAY_MID;
+      replay_kernel<true, 1024><<<hc[9], 1024, lds, c->aux[0]>>>(rb);
+    }
 #if H10X_REPLAY_WAVE
     ra.nLo = 0; ra.nHi = hmin<u32>(REPLAY_SMALL, hmax<u32>(c->maxGood, 1));   // (the slice is sized by the launch's largest barcode: more waves per CU on small sets)
     {
@@ -1593,14 +1603,8 @@ static int cluster_local_range(Ctx *c, int codeMin, int codeMax, int threshold, 
     ra.nLo = 0; ra.nHi = REPLAY_SMALL;
     replay_kernel<true, 256><<<span, 256, replayBytes(hmin<u32>(REPLAY_SMALL, hmax<u32>(c->maxGood, 1))), st>>>(ra);
 #endif
-    // the barcodes with more ranks than that (hc[9] of them, listed by the classification): workgroups for those only
     ra.list = listBig.p; ra.span = hc[9];
-    if (hc[9]) {
-      const size_t lds = replayBytes(hmin<u32>(REPLAY_MID, c->maxGood));
-      H10X_HIP(c, hipFuncSetAttribute((const void *)replay_kernel<true, 1024>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-      ra.nLo = REPLAY_SMALL; ra.nHi = REPLAY_MID;
-      replay_kernel<true, 1024><<<hc[9], 1024, lds, st>>>(ra);
-    }
+    if (hc[9]) H10X_TRY(c->joinStreams(1));
     if (hc[9] && c->maxGood > REPLAY_MID) {
       const u32 grid = hmin<u32>(hc[9], (u32)c->numCU);
       ra.scratchStride = (replayBytes(c->maxGood) + 255) & ~(size_t)255;
