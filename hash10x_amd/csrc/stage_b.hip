@@ -251,13 +251,15 @@ static int clusHashByBlocks(Ctx *c, const u64 *entHash, const u32 *entRead, cons
   H10X_TRY(stageB_blockClassLists(c, lists, counts));
   // workgroups per launch: the class's blocks are pulled from its list (count on the device: no round trip); enough workgroups to fill the chip
   const unsigned gridBig = hmin<u32>(nBlocks, (u32)c->numCU * 8), gridSmall = hmin<u32>(nBlocks, 65535u * 4);
-#define H10X_CH_LAUNCH(T, I, LOOK, STREAM) clushash_block_kernel<T, I, LOOK><<<(T == 256 ? gridSmall : gridBig), T, 0, STREAM>>>(entHash, entRead, key, c->blockOff.p, \
-    lists.p + (size_t)(T == 256 ? 0 : (T == 512 ? 1 : 2)) * nBlocks, counts.p + (T == 256 ? 0 : (T == 512 ? 1 : 2)), table64, B, w, qBits, key ? 0 : c->entCodeBits, sortBits, c->clusHash.p)
+#define H10X_CH_LAUNCH(T, I, LOOK, CLS, STREAM) clushash_block_kernel<T, I, LOOK><<<(CLS == 0 ? gridSmall : gridBig), T, 0, STREAM>>>(entHash, entRead, key, c->blockOff.p, \
+    lists.p + (size_t)CLS * nBlocks, counts.p + CLS, table64, B, w, qBits, key ? 0 : c->entCodeBits, sortBits, c->clusHash.p)
   const int side = c->maxBlockHashes > BLOCK_SORT_CAP1 ? 2 : (c->maxBlockHashes > BLOCK_SORT_CAP0 ? 1 : 0);
   ForkGuard forkGuard(c);
   if (side) H10X_TRY(c->forkStreams(side));                  // the few large blocks beside the many small ones
-  if (key) { H10X_CH_LAUNCH(256, 12, false, st); if (side >= 1) H10X_CH_LAUNCH(512, 12, false, c->aux[0]); if (side >= 2) H10X_CH_LAUNCH(1024, 8, false, c->aux[1]); }
-  else { H10X_CH_LAUNCH(256, 12, true, st); if (side >= 1) H10X_CH_LAUNCH(512, 12, true, c->aux[0]); if (side >= 2) H10X_CH_LAUNCH(1024, 8, true, c->aux[1]); }
+  // six entries per lane (512 / 1024 lanes for the 3072 / 6144-entry classes): at twelve the kernel needs 102 registers — four waves per SIMD —
+  // and a block's latency chain (loads, look-up, three sort passes, store) has too few neighbours to hide behind
+  if (key) { H10X_CH_LAUNCH(H10X_BS_T0, H10X_BS_I0, false, 0, st); if (side >= 1) H10X_CH_LAUNCH(H10X_BS_T1, H10X_BS_I1, false, 1, c->aux[0]); if (side >= 2) H10X_CH_LAUNCH(1024, 8, false, 2, c->aux[1]); }
+  else { H10X_CH_LAUNCH(H10X_BS_T0, H10X_BS_I0, true, 0, st); if (side >= 1) H10X_CH_LAUNCH(H10X_BS_T1, H10X_BS_I1, true, 1, c->aux[0]); if (side >= 2) H10X_CH_LAUNCH(1024, 8, true, 2, c->aux[1]); }
 #undef H10X_CH_LAUNCH
   H10X_TRY(c->faultAt(2));
   if (side) H10X_TRY(c->joinStreams(side));
@@ -315,7 +317,7 @@ int stageB_run(Ctx *c, DevBuf<u64> &entHash, DevBuf<u32> &entCode, DevBuf<u32> &
   }
   c->rows.swap(sCode);                                       // barcode lists, grouped by hash (ascending barcodes)
   c->tstop(T_RANK);
-  sHash.release(); dHash.release(); dFirst.release(); iota.release(); dFirstSorted.release();
+  sHash.release(); dHash.release(); dFirst.release(); iota.release(); dFirstSorted.release(); dVal.release(); dValSorted.release();
 
   const bool wideTable = c->keyBits + (B - 2) <= 64 && c->keyBits < 64;   // index < 2^(B-2) (hash10x.c:149)
   DevBuf<u64> table64;

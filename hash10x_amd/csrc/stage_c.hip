@@ -200,13 +200,13 @@ int stageC_depthRange(Ctx *c, int lo, int hi) {
     const int side = c->maxBlockHashes > BLOCK_SORT_CAP1 ? 2 : (c->maxBlockHashes > BLOCK_SORT_CAP0 ? 1 : 0);
     ForkGuard forkGuard(c);
     if (side) H10X_TRY(c->forkStreams(side));
-#define H10X_GOOD_LAUNCH(T, I, STREAM)                                                                                              \
-    { const u32 *const L = lists.p + (size_t)(T == 256 ? 0 : (T == 512 ? 1 : 2)) * nBlocks, *const N = counts.p + (T == 256 ? 0 : (T == 512 ? 1 : 2)); const unsigned grid = T == 256 ? gridSmall : gridBig; \
+#define H10X_GOOD_LAUNCH(T, I, CLS, STREAM)                                                                                         \
+    { const u32 *const L = lists.p + (size_t)CLS * nBlocks, *const N = counts.p + CLS; const unsigned grid = CLS == 0 ? gridSmall : gridBig; \
       if (wdepth8.p) good_block_kernel<T, I, u8><<<grid, T, 0, STREAM>>>(c->clusHash.p, c->blockOff.p, c->blocks.p, L, N, wdepth8.p, sortBits, c->goodPos.p, c->nGood.p, c->goodEntries.p, c->rowStart.p, (u32)c->rowShift, c->goodRow.p); \
       else good_block_kernel<T, I, u32><<<grid, T, 0, STREAM>>>(c->clusHash.p, c->blockOff.p, c->blocks.p, L, N, wdepth.p, sortBits, c->goodPos.p, c->nGood.p, c->goodEntries.p, c->rowStart.p, (u32)c->rowShift, c->goodRow.p); }
-    H10X_GOOD_LAUNCH(256, 12, st)
-    if (side >= 1) H10X_GOOD_LAUNCH(512, 12, c->aux[0])
-    if (side >= 2) H10X_GOOD_LAUNCH(1024, 8, c->aux[1])
+    H10X_GOOD_LAUNCH(H10X_BS_T0, H10X_BS_I0, 0, st)
+    if (side >= 1) H10X_GOOD_LAUNCH(H10X_BS_T1, H10X_BS_I1, 1, c->aux[0])
+    if (side >= 2) H10X_GOOD_LAUNCH(1024, 8, 2, c->aux[1])
 #undef H10X_GOOD_LAUNCH
     H10X_TRY(c->faultAt(3));
     if (side) H10X_TRY(c->joinStreams(side));
