@@ -575,7 +575,7 @@ __device__ __forceinline__ void row_mode_hist(const u32 *__restrict__ row, u32 f
 #if H10X_Q_BALLOT
       if (rb != NONE16) {
 #pragma unroll
-        for (int r = 0; r < RCHUNK; ++r) if ((u32)(r * WAVE) < d) q += (u32)__popcll(__ballot(ok[r] && f[r] == rb));
+        for (int r = 0; r < RCHUNK; ++r) if ((u32)(r * WAVE) < d) q += (u32)__popcll(__ballot(f[r] == rb));   // (rb <= msBest < i: an entry that equals it is a usable one; the bare compare is a ballot as it stands, the conjunction cost two more instructions)
       }
 #else
       if (rb != NONE16) q = (ld_shared<IN_LDS>(&hist[rb >> 2]) >> ((rb & 3) * 8)) & 0xFFu;
