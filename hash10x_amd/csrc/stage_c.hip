@@ -412,7 +412,7 @@ template <bool FIRST_LDS> struct FirstDense {
     return cj;
   }
   __device__ __forceinline__ u32 peek(u32 h) const {         // one read for both widths, no branch
-    if (FIRST_LDS) return *(const u16 *)((const unsigned char *)first + ((size_t)h << (1 + wide)));
+    if (FIRST_LDS) return *(const u16 *)((const unsigned char *)first + (u32)(h << (1 + wide)));
     return ld_shared<FIRST_LDS>(&first[h]);
   }
   __device__ __forceinline__ u32 lookup(u32 cj) const { return peek(cj); }
@@ -423,7 +423,7 @@ struct FirstRanked {
   u32 none;                                                  // handle of a lane without an entry: one slot behind the last barcode present, always unseen
   __device__ __forceinline__ u32 at(u32 cj) const { const u32 w = cj >> 5; return pre[w] + (u32)__popc(bm[w] & ((1u << (cj & 31)) - 1u)); }
   __device__ __forceinline__ u32 update(u32 cj, u32 i) const { const u32 h = at(cj); if (wide) atomicMin(&((u32 *)first)[h], i); else min_u16<true>(first, h, i); return h; }
-  __device__ __forceinline__ u32 peek(u32 h) const { return *(const u16 *)((const unsigned char *)first + ((size_t)h << (1 + wide))); }
+  __device__ __forceinline__ u32 peek(u32 h) const { return *(const u16 *)((const unsigned char *)first + (u32)(h << (1 + wide))); }   // (a 32-bit offset: as size_t the shift is a 64-bit one)
   __device__ __forceinline__ u32 lookup(u32 cj) const { return peek(at(cj)); }
 };
 struct FirstHashed {
