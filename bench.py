@@ -244,8 +244,12 @@ def mosh_int_ops(kmers, ms_per_step):
         return {"u64_multiplies_per_s": None, "kmers_per_step": kmers}
     rate = 2.0 * kmers / (ms_per_step * 1e-3)
     return {"u64_multiplies_per_s": rate, "kmers_per_step": kmers, "int_peak_u64_multiplies_per_s": INT_PEAK_U64_MUL_PER_S, "frac_of_int_peak": rate / INT_PEAK_U64_MUL_PER_S,
+            "what_is_counted": "hashFunc evaluations (seqhash.c:58-59: one 64-bit multiply each, two per k-mer) per second. Since round 3 the kernel does not "
+                               "perform them as multiplies: the products of consecutive k-mers roll (f(j+1) F = 4 f(j) F + a term of the two bases that "
+                               "change, from a 16-entry LDS table; two real multiplies per lane and read pair) - same values mod 2^64, so this is the rate "
+                               "an implementation that multiplies would need",
             "int_peak_derivation": "64 lanes x 1024 SIMDs x 2.4 GHz / (4.9 + 2 x 4.2) SIMD cycles per u64 multiply (v_mad_u64_u32 + 2 v_mul_lo_u32, rates measured by scratch/valu_rate64.hip); "
-                                   "the multiplies are 13 of the ~250 SIMD cycles a wave spends per 64 k-mer slots (DESIGN 3, K1), so the kernel as a whole cannot reach it"}
+                                   "the kernel issues ~35 vector + 23 scalar instructions per 64 k-mer slots all told (profiles/r3c_pmc_sq.json; DESIGN 3, K1); its vector units are busy 61 % of the time by the 4-cycle accounting of SQ_ACTIVE_INST_VALU"}
 
 
 def cpu_model():
