@@ -435,7 +435,7 @@ struct FirstHashed {
   static constexpr u32 SCRAMBLE = 0x9E3779u | 1u;            // odd multiplier: x -> x * SCRAMBLE mod 2^b is a bijection
   static constexpr u32 MAXD = 63;                            // 6-bit displacement (never 63 with tag 1023: that is the empty pattern's low half)
   __device__ __forceinline__ void split(u32 cj, u32 &home, u32 &tag) const {
-    const u32 q = (cj * SCRAMBLE) & bmask;
+    const u32 q = (cj * SCRAMBLE) & bmask;                   // (24-bit multiplies — full rate, the values fit up to 16 M barcodes — change nothing: full-size config 3 1.06 -> 1.08 s)
     tag = __umulhi(q, recip); home = q - tag * NB;
     const bool neg = (int)home < 0, big = !neg && home >= NB;                                     // recip is rounded up: off by one at most; no branch
     tag += big ? 1u : (neg ? ~0u : 0u); home += neg ? NB : (big ? 0u - NB : 0u);
@@ -659,7 +659,7 @@ __device__ __forceinline__ u32 descLoad(const u64 *gr, u32 i0, u32 nLists, u32 n
 }
 
 template <bool IN_LDS, int FIRST_MODE /* 0 dense in LDS, 1 ranked in LDS, 2 dense on an HBM slot, 3 hashed in LDS */, int CL_THREADS, int KLASS>
-__device__ void cluster_one_block(const ClusterArgs &a, u32 code, unsigned char *region, u16 *firstGlobal, u32 *sh /* small shared ints */, u64 (&acc)[4]) {   // code: local block number
+__device__ __forceinline__ void cluster_one_block(const ClusterArgs &a, u32 code, unsigned char *region, u16 *firstGlobal, u32 *sh /* small shared ints */, u64 (&acc)[4]) {   // code: local block number
   constexpr int CL_WAVES = CL_THREADS / WAVE;
   // lists a wave keeps in flight: 4, but 2 where the kernel must stay within 64 VGPRs (two workgroups per CU) AND carries
   // the ranked / hashed lookup: fewer registers spilled is worth more there than the deeper prefetch (8x set: 52.8 -> 41.4 ms);

@@ -153,3 +153,45 @@ def test_fq2b_matches_reference_bytes_and_stats(tmp_path, whitelist):
     assert got.stderr == ref.stderr and b"read pairs 151 + 151 bp packed in 30 word records" in got.stderr
     if whitelist:
         assert len(a) < n * 120 and b"were error corrected" in got.stderr
+
+
+def test_rolling_products_equal_the_multiplies_of_hashFunc():
+    """The arithmetic mosh_lds_kernel (csrc/stage_a.hip, FAST path) relies on, checked with plain integers: with F = factor1 and b(i) base i of
+    a run, the product of the NEXT forward word is 4 x this product + [b(j+k) F - b(j) (F << 2k)] (mod 2^64), and the product of the PREVIOUS
+    reverse-complement word (seqhash.c:75) is 4 x this one + [(3 - b(j)) F - (3 - b(j+k)) (F << 2k)] — the two bracketed terms are what the
+    kernel's 16-entry LDS table holds for the index b(j) << 2 | b(j+k). hashFunc itself (seqhash.c:58-59) = (word * F mod 2^64) >> (64 - 2k)."""
+    import random
+    rng = random.Random(5)
+    M = (1 << 64) - 1
+    for k in (17, 21, 24, 30):
+        F = rng.getrandbits(64) | 1
+        bases = [rng.randrange(4) for _ in range(k + 40)]
+        top = (F << (2 * k)) & M
+        fwd_term = {(a << 2) | b: (b * F - a * top) & M for a in range(4) for b in range(4)}
+        rev_term = {(a << 2) | b: ((3 - a) * F - (3 - b) * top) & M for a in range(4) for b in range(4)}
+
+        def word(j):                                          # bases j .. j+k-1, base j in the top two bits
+            w = 0
+            for i in range(k):
+                w = (w << 2) | bases[j + i]
+            return w
+
+        def revcomp(j):                                       # complement of base j in the lowest two bits (advanceHashRC's word)
+            w = 0
+            for i in range(k):
+                w |= (3 - bases[j + i]) << (2 * i)
+            return w
+
+        n = 8
+        pf = word(0) * F & M
+        for j in range(n - 1):                                # forward walk
+            pf = (4 * pf + fwd_term[(bases[j] << 2) | bases[j + k]]) & M
+            assert pf == word(j + 1) * F & M
+        pr = revcomp(n - 1) * F & M
+        for j in range(n - 2, -1, -1):                        # backward walk
+            pr = (4 * pr + rev_term[(bases[j] << 2) | bases[j + k]]) & M
+            assert pr == revcomp(j) * F & M
+        # min before the shift = the shift of the min (the shift is monotone): what the kernel tests for divisibility by w
+        for j in range(n):
+            a, b = word(j) * F & M, revcomp(j) * F & M
+            assert min(a, b) >> (64 - 2 * k) == min(a >> (64 - 2 * k), b >> (64 - 2 * k))
