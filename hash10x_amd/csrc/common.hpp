@@ -117,6 +117,9 @@ struct Timer { hipEvent_t a = nullptr, b = nullptr; double ms = 0; uint64_t laun
 // of the file's barcodes (segment 0: local l = global codeBase + l, slot 0 unused), and every --clusterSplit appends, per
 // segment that held parents, one segment for the blocks it created: the reference numbers those after ALL existing
 // blocks, in the order of their parents (hash10x.c:961-1003), so in a sharded run they sit behind the blocks of every rank.
+// rows[] (the barcode lists) is allocated with this many entries of slack behind the last list: the cluster kernels read a list's first two
+// 64-entry chunks without looking at its length (a load no lane skips keeps the compiler's wait counts exact: stage_c.hip descLoadU)
+constexpr size_t ROWS_PAD = 128;
 constexpr int MAX_SEGS = 8;
 struct BlockSeg { u32 localStart, count, globalBase; };     // global = globalBase + (l - localStart)
 struct SegMap {

@@ -554,7 +554,7 @@ int shard_exchangeRows(Ctx *c) {
   H10X_TRY(cm->alltoallv(c, gIdx.p, sc.data(), so.data(), aIdx.p, rc.data(), ro.data(), 4));
   H10X_TRY(cm->alltoallv(c, gLen.p, sc.data(), so.data(), aLen.p, rc.data(), ro.data(), 4));
   for (int r = 0; r < N; ++r) { rc[r] = all[2 * r + 1]; nR += rc[r]; }
-  H10X_HIP(c, c->rows.alloc(nR));
+  H10X_HIP(c, c->rows.alloc(nR + ROWS_PAD));
   DevBuf<u64> aOff; H10X_HIP(c, aOff.alloc(nG + 1));
   H10X_HIP(c, hipMemsetAsync(aLen.p + nG, 0, 4, st));
   H10X_TRY(prim_exclusive_scan_u32_u64(c, pt, aLen.p, aOff.p, nG + 1));

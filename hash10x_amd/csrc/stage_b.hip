@@ -278,7 +278,7 @@ int stageB_run(Ctx *c, DevBuf<u64> &entHash, DevBuf<u32> &entCode, DevBuf<u32> &
   c->tstart(T_SORT_HASH);
   DevBuf<u64> sHash; DevBuf<u32> sCode;
   const int cb = c->entCodeBits;                             // > 0: packed entries (common.hpp), keys-only sort
-  H10X_HIP(c, sHash.alloc(H)); H10X_HIP(c, sCode.alloc(H));
+  H10X_HIP(c, sHash.alloc(H)); H10X_HIP(c, sCode.alloc(H + ROWS_PAD));   // (sCode becomes rows[])
   if (cb) H10X_TRY(prim_sort_keys_u64(c, pt, entHash.p, sHash.p, H, cb, cb + c->keyBits));
   else H10X_TRY(prim_sort_pairs_u64_u32(c, pt, entHash.p, sHash.p, entCode.p, sCode.p, H, 0, c->keyBits));
   c->tstop(T_SORT_HASH);
@@ -400,7 +400,7 @@ int stageB_buildCSR(Ctx *c) {
   }
   if (lastOff + lastDepth != H)
     return c->fail("inconsistent hash state: sum of hashDepth %llu != %llu (barcode,hash) entries", (u64)(lastOff + lastDepth), (u64)H);
-  H10X_HIP(c, c->rows.alloc(H));
+  H10X_HIP(c, c->rows.alloc(H + ROWS_PAD));
   if (H) {
     DevBuf<u32> k0, k1, v0;
     H10X_HIP(c, k0.alloc(H)); H10X_HIP(c, k1.alloc(H)); H10X_HIP(c, v0.alloc(H));

@@ -262,6 +262,8 @@ struct ClusterArgs {
   u32 nBlocksFirst;                                         // size of first[]: barcodes of the whole data set + 1
   u32 firstCap;                                             // ranked placement, test knob: cap on the first[] entries of a block (0 = what the budget leaves)
   u32 hashMask, hashMinSlots;                               // hashed placement: 2^b - 1 with 2^b >= barcodes of the data set; slots below which the 8-bit tag is too narrow
+  u32 hashBits;                                             // b
+  u16 *handles; size_t handleStride; u32 hStride;           // translated placement: HBM slot of the workgroup (handleStride u16 each), u16 per list (a power of two >= 64 that holds the longest list)
   const u32 *entries;                                       // per block: entries of its barcode lists (sum of depths of its good hashes)
   u32 *overflow, *overflowCount;                            // ranked / hashed placement: blocks whose table was too small (re-run in the next larger placement)
   unsigned char *scratch; size_t scratchStride;             // global-mode working set per workgroup
@@ -416,6 +418,7 @@ template <bool FIRST_LDS> struct FirstDense {
     return ld_shared<FIRST_LDS>(&first[h]);
   }
   __device__ __forceinline__ u32 lookup(u32 cj) const { return peek(cj); }
+  __device__ __forceinline__ u32 entry(const void *row, u32 j, u32 code) const { const u32 cj = ((const u32 *)row)[j]; return cj != code ? lookup(cj) : (u32)NONE16; }   // first[] of entry j of a list
 };
 struct FirstRanked {
   static constexpr bool SELF = false;
@@ -425,6 +428,7 @@ struct FirstRanked {
   __device__ __forceinline__ u32 update(u32 cj, u32 i) const { const u32 h = at(cj); if (wide) atomicMin(&((u32 *)first)[h], i); else min_u16<true>(first, h, i); return h; }
   __device__ __forceinline__ u32 peek(u32 h) const { return *(const u16 *)((const unsigned char *)first + (u32)(h << (1 + wide))); }   // (a 32-bit offset: as size_t the shift is a 64-bit one)
   __device__ __forceinline__ u32 lookup(u32 cj) const { return peek(at(cj)); }
+  __device__ __forceinline__ u32 entry(const void *row, u32 j, u32 code) const { const u32 cj = ((const u32 *)row)[j]; return cj != code ? lookup(cj) : (u32)NONE16; }
 };
 struct FirstHashed {
   static constexpr bool SELF = false;
@@ -481,7 +485,147 @@ struct FirstHashed {
     }
     return NONE16;
   }
+  __device__ __forceinline__ u32 entry(const void *row, u32 j, u32 code) const { const u32 cj = ((const u32 *)row)[j]; return cj != code ? lookup(cj) : (u32)NONE16; }
 };
+
+// ---- translated placement (round 4), for data sets whose barcodes no longer fit a dense or ranked first[]: the lists of a
+// block are read ONCE, by a pass of their own (pass A) that looks every entry's barcode up in an open-addressing table in LDS
+// (SlotTable: the entry of a barcode holds the lowest rank that met it — the final first[] value, hash10x.c:794-799 — and is
+// inserted the first time the barcode turns up) and parks the entry's SLOT NUMBER, 16 bits, on an HBM slot of the workgroup.
+// The list loop proper (pass B) then runs the dense form on those handles: one ds_read_u16 per entry (FirstSlots), no probing,
+// no update and no barrier per round — first[] is final when it starts. Between the two the table gives its LDS back: pass B
+// needs 2 of its 4 bytes per slot (the ranks, compacted in place), and that is what lets nearly every block of a million-
+// barcode set run two workgroups per CU where the one-pass hashed form needed a whole CU for table + histograms.
+// Table layout as FirstHashed: buckets of 4 words, entry = rank << 16 | bucket displacement << 10 | tag, 0xFFFFFFFF = empty;
+// (home bucket, tag) of barcode cj: x = the b scrambled bits of cj at the top of a word (b = bits of the data set's barcode
+// count), home = floor(x NB / 2^32) (one v_mul_hi), tag = the top bits of the fraction (x NB mod 2^32) — barcodes of one home
+// bucket are consecutive x, their fractions NB apart, so b - floor(log2 NB) <= 10 bits of it tell them apart.
+constexpr u32 TR_QUEUE = 16384;                              // entries of a wave's queue in pass A (8 bytes each, behind the handles on the workgroup's HBM slot)
+constexpr u32 TR_MAX_SLOTS = 65532;                          // handles are 16 bits; slot S (<= 65532) is the handle of "no entry" and reads unseen
+struct SlotTable {
+  u32 *tab; u32 NB /* buckets */, xsh /* 32 - b */, tsh; u32 *ovf; u32 hbase /* handle of the table's slot 0 */;
+  static constexpr u32 SCRAMBLE = 0x9E3779u;                 // odd: cj -> cj * SCRAMBLE mod 2^b is a bijection; 24 bits: full-rate multiply (cj < 2^22)
+  static constexpr u32 MAXD = 63;
+  static constexpr u32 NOTFOUND = 0xFFFFFFFFu;
+  __device__ __forceinline__ void shape(u32 *t, u32 slots, u32 hashBits, u32 *o, u32 hb) {
+    tab = t; NB = slots / 4; xsh = 32 - hashBits; ovf = o; hbase = hb;
+    const u32 lg = 31 - (u32)__clz((int)NB), x = 32 - hashBits + lg; tsh = x < 31 ? x : 31;
+  }
+  // minimum of the barcode's entry with rank i: returns its handle. The barcode is inserted if it is not there yet and `insert` says
+  // so (ins = true then); otherwise NOTFOUND. A table without a free word within MAXD buckets of the barcode's home: *ovf = 1 (the
+  // block is abandoned and re-run in the next larger class) when inserting, NOTFOUND when only looking.
+  __device__ __forceinline__ u32 search(u32 cj, u32 i, bool insert, bool &ins) const {
+    const u32 x = __umul24(cj, SCRAMBLE) << xsh;
+    u32 b = __umulhi(x, NB);
+    const u32 tag = (x * NB) >> tsh;
+    const u32 step = 2 * (tag & 7u) + 1;                     // the probe sequence strides by the tag's low bits: no long runs of full buckets at 7/8 load
+    ins = false;                                             // (displacement d and tag still say which home bucket an entry belongs to: home = b - d * step)
+    for (u32 key = tag; key < (MAXD << 10); key += 1u << 10) {
+      const u32 mine = (i << 16) | key;
+      const uint4 e4 = *(const uint4 *)&tab[4 * b];
+      const u32 e[4] = {e4.x, e4.y, e4.z, e4.w};
+      u32 hit = 4, eh = 0;                                   // already here? (an empty word's low half, displacement 63 with tag 1023, is no key)
+#pragma unroll
+      for (int w = 3; w >= 0; --w) { const bool m = (e[w] & 0xFFFFu) == key; hit = m ? (u32)w : hit; eh = m ? e[w] : eh; }
+      if (hit < 4) { if (eh > (mine | 0xFFFFu)) atomicMin(&tab[4 * b + hit], mine); return hbase + 4 * b + hit; }
+#pragma unroll
+      for (int w = 0; w < 4; ++w)                            // first empty word, in order: every inserter of a barcode walks the same words, and a word never empties
+        if (e[w] == 0xFFFFFFFFu) {
+          if (!insert) return NOTFOUND;                      // (a barcode is never put behind an empty word of its probe sequence)
+          const u32 old = atomicCAS(&tab[4 * b + w], 0xFFFFFFFFu, mine);
+          if (old == 0xFFFFFFFFu) { ins = true; return hbase + 4 * b + w; }
+          if ((old & 0xFFFFu) == key) { if (old > (mine | 0xFFFFu)) atomicMin(&tab[4 * b + w], mine); return hbase + 4 * b + w; }
+        }
+      b += step; if (b >= NB) b -= NB;                       // (NB >= 16 > step: shape())
+    }
+    if (insert) *ovf = 1;
+    return NOTFOUND;
+  }
+  // The same for the home bucket alone, straight-line: 98 in 100 entries meet their barcode there or an empty word. false = the search
+  // must go on (home bucket full of others, the empty word went to another barcode meanwhile, or the barcode is new and the table
+  // closed): the caller parks such entries and runs search() on them 64 at a time — inside the list pass a wave would otherwise loop as
+  // long as the unluckiest of its 64 lanes, for every chunk.
+  __device__ __forceinline__ bool probeHome(u32 cj, u32 i, bool valid /* the lane has an entry */, bool insert, u32 &slot, bool &ins) const {
+    const u32 x = __umul24(cj, SCRAMBLE) << xsh;
+    const u32 b4 = __umulhi(x, NB) << 2;
+    const u32 key = (x * NB) >> tsh;                         // displacement 0
+    const u32 mine = (i << 16) | key, lim = mine | 0xFFFFu;
+    const uint4 e4 = *(const uint4 *)&tab[b4];               // (every lane reads: a lane without an entry holds some barcode of the list all the same)
+    // which word holds the barcode, else which is the first empty one (selects, no branch per word)
+    const bool m0 = (e4.x & 0xFFFFu) == key, m1 = (e4.y & 0xFFFFu) == key, m2 = (e4.z & 0xFFFFu) == key, m3 = (e4.w & 0xFFFFu) == key;
+    const bool z0 = e4.x == 0xFFFFFFFFu, z1 = e4.y == 0xFFFFFFFFu, z2 = e4.z == 0xFFFFFFFFu, z3 = e4.w == 0xFFFFFFFFu;
+    const bool hit = m0 | m1 | m2 | m3;
+    const u32 wh = m0 ? 0u : (m1 ? 1u : (m2 ? 2u : 3u)), wz = z0 ? 0u : (z1 ? 1u : (z2 ? 2u : 3u));
+    u32 seen = m0 ? e4.x : (m1 ? e4.y : (m2 ? e4.z : e4.w));  // the barcode's entry as read (only meaningful on a hit)
+    slot = b4 | (hit ? wh : wz);
+    bool same = false; ins = false;
+    if (valid && insert && !hit && (z0 | z1 | z2 | z3)) {    // claim the first empty word
+      seen = atomicCAS(&tab[slot], 0xFFFFFFFFu, mine);
+      ins = seen == 0xFFFFFFFFu; same = (seen & 0xFFFFu) == key;   // it was empty, or the same barcode got there first
+      seen = ins ? 0u : seen;
+    }
+    const bool done = !valid || hit || ins || same;
+    const bool later = valid && done && seen > lim;          // a later rank got here earlier (waves are a round or two apart at most: rare)
+    if (__builtin_amdgcn_ballot_w64(later)) { if (later) atomicMin(&tab[slot], mine); }
+    return done;
+  }
+};
+struct FirstSlots {                                          // pass B: first[] by handle
+  static constexpr bool SELF = false;
+  const unsigned char *base; u32 sh;                         // value of slot h: the u16 at base + (h << sh) — sh = 1 after the compaction, 2 (base at the words' high halves) without
+  u32 none;
+  __device__ __forceinline__ u32 peek(u32 h) const { return *(const u16 *)(base + (u32)(h << sh)); }
+  __device__ __forceinline__ u32 lookup(u32 h) const { return peek(h); }
+  __device__ __forceinline__ u32 entry(const void *row, u32 j, u32) const { return peek(((const u16 *)row)[j]); }   // row: the list's handles
+};
+// slots of a block's table and what pass B then looks like: S = 0 if the block does not fit `budget`. The table gets every byte
+// pass A can give it (the emptier, the shorter the probes) but no more than twice the entries of the block's lists — a table at
+// most half full cannot overflow — and no more than pass B can keep at 2 bytes per slot beside root[] and five histograms.
+// S2: slots of a SECOND table, should the first fill up (only then: it is "closed" at 7/8 and the barcodes that turn up afterwards
+// are parked): it lives in the half of the first table's LDS that the compaction of its ranks frees, as far as pass B then still
+// has room for 2 bytes per slot of both. 0 = none (the first table holds every barcode the lists can bring, or nothing is left).
+__host__ __device__ inline void translatedShape(u32 n, u32 maxWaves, size_t budget, u32 minSlots, u32 entries, u32 nBarcodes, u32 cap /* test knob */,
+                                                u32 &S, u32 &S2, u32 &nW, bool &compact) {
+  const size_t per = (((size_t)n + 3) / 4) * 4, fixedB = pad16((size_t)n * 2) + 64;
+  S = 0; S2 = 0; nW = 0; compact = false;
+  if (fixedB + MIN_HIST_WAVES * per + 2 * 256 + 64 >= budget) return;
+  const size_t sA = (budget - 64) / 4, sB = (budget - fixedB - MIN_HIST_WAVES * per) / 2 - 16;
+  size_t s = sA < sB ? sA : sB;
+  if (s > TR_MAX_SLOTS) s = TR_MAX_SLOTS;
+  size_t useful = 2 * (size_t)(entries < nBarcodes ? entries : nBarcodes) + 64;
+  if (useful < HASHED_MIN_SLOTS) useful = HASHED_MIN_SLOTS;
+  if (useful < minSlots) useful = minSlots;                  // (the tag's width asks for this many: a block with few entries still gets them)
+  const bool all = s >= useful;                              // holds whatever the lists bring
+  if (all) s = useful;
+  if (cap && s > cap) s = cap;
+  s &= ~(size_t)3;
+  if (s < 64 || s < minSlots) return;                        // (16 buckets at least: the probe stride is below that)
+  S = (u32)s;
+  if (!all || cap) {
+    const long a2 = ((long)budget - (long)pad16(2 * (s + 8)) - 64) / 4, b2 = ((long)budget - (long)fixedB - (long)(MIN_HIST_WAVES * per) - 2 * (long)(s + 8) - 64) / 2;
+    long s2 = a2 < b2 ? a2 : b2;
+    if (s2 > (long)TR_MAX_SLOTS - (long)s - 4) s2 = (long)TR_MAX_SLOTS - (long)s - 4;
+    if (cap && s2 > (long)cap) s2 = (long)cap;
+    s2 &= ~3L;
+    if (s2 >= 64 && s2 >= (long)minSlots) S2 = (u32)s2;
+  }
+  if (pad16(4 * (s + 4)) + fixedB + (size_t)maxWaves * per <= budget) { nW = maxWaves; return; }   // the table stays as it is: every wave has its histogram anyway
+  compact = true;
+  const size_t wv = (budget - fixedB - pad16(2 * (s + 8))) / (per ? per : 1);
+  nW = wv < maxWaves ? (u32)wv : maxWaves;
+}
+__host__ __device__ inline u32 translatedCloseAt(u32 S, u32 S2) { return S2 ? S - S / 8 : 0xFFFFFFFFu; }   // inserts into the first table stop here when there is a second one
+// list-loop waves of pass B when both tables are in use
+__host__ __device__ inline u32 translatedWaves2(u32 n, u32 maxWaves, size_t budget, u32 S, u32 S2) {
+  const size_t per = (((size_t)n + 3) / 4) * 4, fixedB = pad16((size_t)n * 2) + 64, wv = (budget - fixedB - pad16(2 * ((size_t)S + S2 + 16))) / (per ? per : 1);
+  return wv < maxWaves ? (u32)wv : maxWaves;
+}
+__host__ __device__ inline bool translatedFits(u32 S, u32 S2, u32 est, u32 entries, u32 nBarcodes) {      // classification: do the tables hold the barcodes expected in the block's lists?
+  if (!S) return false;
+  if ((size_t)S >= 2 * (size_t)(entries < nBarcodes ? entries : nBarcodes)) return true;
+  const size_t capacity = S2 ? (size_t)(S - S / 8) + (S2 - S2 / 8) : (size_t)S - S / 8;
+  return capacity >= (size_t)est + est / 8;
+}
 
 // wave64 max in registers: DPP row shifts (1,2,4,8) then row broadcasts 15/31 (gfx9 DPP), result in lane 63.
 // Identity 0 (keys are unsigned); no LDS round trips unlike ds_bpermute-based shuffles.
@@ -511,7 +655,7 @@ __device__ __forceinline__ u32 wave_max_u32(u32 v) {
 #define H10X_Q_BALLOT 1       // the count of the root's value is taken from the registers (one compare + ballot per chunk) instead of from the histogram,
 #endif                        // which can then be cleared in the same exec region as its atomics
 template <bool IN_LDS, int RCHUNK, typename FT>
-__device__ __forceinline__ void row_mode_hist(const u32 *__restrict__ row, u32 f0, u32 f1 /* first[] of entries lane, 64 + lane, read for all lists of the round together; NONE16 = no entry */, u32 d, u32 code, u32 i, const FT &ft, u32 *hist,
+__device__ __forceinline__ void row_mode_hist(const void *__restrict__ row /* entries beyond the two chunks held in registers: barcodes, or handles (FirstSlots) */, u32 f0, u32 f1 /* first[] of entries lane, 64 + lane, read for all lists of the round together; NONE16 = no entry */, u32 d, u32 code, u32 i, const FT &ft, u32 *hist,
                                               const u16 *root, u32 thr, u32 &best, u32 &bcnt, u32 &tot, u32 &rb, u32 &q) {
   const int lane = threadIdx.x & (WAVE - 1);
   u32 f[RCHUNK]; bool ok[RCHUNK];
@@ -528,7 +672,7 @@ __device__ __forceinline__ void row_mode_hist(const u32 *__restrict__ row, u32 f
         const u32 h = r == 0 ? f0 : f1; if (H10X_SELF_HANDLE || h != NOHANDLE) { f[r] = ft.peek(h); ok[r] = f[r] < i; }   // (f0 / f1 are handles in this build)
 #endif
       }
-      else if (j < d) { const u32 cj = row[j]; if (cj != code) { f[r] = ft.lookup(cj); ok[r] = f[r] < i; } }
+      else if (j < d) { f[r] = ft.entry(row, j, code); ok[r] = f[r] < i; }
       tot += (u32)__popcll(__ballot(ok[r]));
     }
   }
@@ -593,24 +737,24 @@ __device__ __forceinline__ void row_mode_hist(const u32 *__restrict__ row, u32 f
 }
 // entries of a list whose first[] value equals v (and, in tot, those below i): one wavefront, any length
 template <typename FT>
-__device__ __forceinline__ u32 row_count_value(const u32 *__restrict__ row, u32 d, u32 code, u32 i, const FT &ft, u32 v, u32 &tot) {
+__device__ __forceinline__ u32 row_count_value(const void *__restrict__ row, u32 d, u32 code, u32 i, const FT &ft, u32 v, u32 &tot) {
   const int lane = threadIdx.x & (WAVE - 1);
   u32 q = 0; tot = 0;
   for (u32 b0 = 0; b0 < d; b0 += WAVE) {
     u32 f = NONE16;
-    if (b0 + lane < d) { const u32 cj = row[b0 + lane]; if (cj != code) f = ft.lookup(cj); }
+    if (b0 + lane < d) f = ft.entry(row, b0 + lane, code);
     q += (u32)__popcll(__ballot(f == v && v != NONE16)); tot += (u32)__popcll(__ballot(f < i));
   }
   return q;
 }
 // lists of 256 entries and more (exotic depth ranges): re-gather per candidate
 template <typename FT>
-__device__ void row_mode_long(const u32 *__restrict__ row, u32 d, u32 code, u32 i, const FT &ft, u32 &best, u32 &bcnt, u32 &tot) {
+__device__ void row_mode_long(const void *__restrict__ row, u32 d, u32 code, u32 i, const FT &ft, u32 &best, u32 &bcnt, u32 &tot) {
   const int lane = threadIdx.x & (WAVE - 1);
   best = NONE16; bcnt = 0; tot = 0;
   for (u32 a0 = 0; a0 < d; a0 += WAVE) {
     u32 fa = NONE16; bool va = false;
-    if (a0 + lane < d) { const u32 cj = row[a0 + lane]; if (cj != code) { fa = ft.lookup(cj); va = fa < i; } }
+    if (a0 + lane < d) { fa = ft.entry(row, a0 + lane, code); va = fa < i; }
     u64 rem = __ballot(va); tot += (u32)__popcll(rem);
     while (rem) {
       const int src = __ffsll((long long)rem) - 1;
@@ -619,7 +763,7 @@ __device__ void row_mode_long(const u32 *__restrict__ row, u32 d, u32 code, u32 
       u32 cnt = 0; bool seenBefore = false;
       for (u32 b0 = 0; b0 < d; b0 += WAVE) {
         u32 fb = NONE16;
-        if (b0 + lane < d) { const u32 cj = row[b0 + lane]; if (cj != code) fb = ft.lookup(cj); }
+        if (b0 + lane < d) fb = ft.entry(row, b0 + lane, code);
         const u32 m = (u32)__popcll(__ballot(fb == v));
         if (b0 < a0 && m) { seenBefore = true; break; }
         cnt += m;
@@ -656,6 +800,19 @@ __device__ __forceinline__ Desc descLane(u32 v, int t) { Desc d; d.x = (u32)__bu
 __device__ __forceinline__ u32 descLoad(const u64 *gr, u32 i0, u32 nLists, u32 n) {
   const u32 lane = threadIdx.x & (WAVE - 1), t = lane & 31, i = i0 + t;
   return (t < nLists && i >= 1 && i < n) ? ((const u32 *)gr)[2 * (size_t)i + (lane >> 5)] : 0u;
+}
+
+// The same with a load no lane skips (the index is clamped): a load behind a branch may not have been issued as far as the compiler's
+// wait-count bookkeeping can tell, and every later wait for an OLDER load then becomes s_waitcnt vmcnt(0) — a prefetch pipeline that pays a
+// full memory round trip per round. The offset lanes keep what was loaded (a real list: addresses formed from it are valid), the length
+// lanes read 0 for rank 0 and past the last rank.
+__device__ __forceinline__ u32 descLoadU(const u64 *gr, u32 i0, u32 n) {   // raw: to be passed through descFix() when the round comes up (not before: that would wait for the load)
+  const u32 lane = threadIdx.x & (WAVE - 1), i = i0 + (lane & 31);
+  return ((const u32 *)gr)[2 * (size_t)(i < n ? i : n - 1) + (lane >> 5)];
+}
+__device__ __forceinline__ u32 descFix(u32 v, u32 i0, u32 nLists, u32 n) {
+  const u32 lane = threadIdx.x & (WAVE - 1), t = lane & 31, i = i0 + t;
+  return (lane < 32 || (t < nLists && i >= 1 && i < n)) ? v : 0u;
 }
 
 template <bool IN_LDS, int FIRST_MODE /* 0 dense in LDS, 1 ranked in LDS, 2 dense on an HBM slot, 3 hashed in LDS */, int CL_THREADS, int KLASS>
@@ -1021,6 +1178,330 @@ __device__ __forceinline__ void cluster_one_block(const ClusterArgs &a, u32 code
   STAMP(5);
 }
 
+
+// One block in the translated placement (SlotTable / FirstSlots above): pass A = every list entry -> 16-bit handle on the
+// workgroup's HBM slot, first[] final in the table; pass B = the list loop on handles (msBest / msMax / msTot and the
+// pointToMin counts per rank, hash10x.c:801-821, exactly as cluster_one_block's), then the ranks the loop left open.
+template <int CL_THREADS, int KLASS>
+__device__ __forceinline__ void cluster_one_block_tr(const ClusterArgs &a, u32 code, unsigned char *region, u32 *sh, u64 (&acc)[4]) {
+  constexpr bool IN_LDS = true;
+  constexpr int CL_WAVES = CL_THREADS / WAVE;
+  constexpr int RIF = ROWS_IN_FLIGHT;
+  const int tid = threadIdx.x, lane = tid & (WAVE - 1), wave = tid / WAVE;
+  code = (u32)__builtin_amdgcn_readfirstlane((int)code);
+  const u32 n = (u32)__builtin_amdgcn_readfirstlane((int)a.nGood[code]);
+  if (n == 0) return;                                        // hash10x.c:780: block left untouched
+  const u64 o = a.blockOff[code];
+  const u32 lcode = code; code = a.segs.globalOf(lcode);     // from here on `code` is the global barcode number (what the lists hold)
+  u32 S, S2, nW; bool compact;
+  translatedShape(n, CL_WAVES, a.ldsBudget, a.hashMinSlots, a.entries[lcode], a.nBlocksFirst, a.firstCap, S, S2, nW, compact);
+  if (!S || nW < MIN_HIST_WAVES) {                           // cannot hold this barcode at all: hand it on
+    if (tid == 0) a.overflow[atomicAdd(a.overflowCount, 1u)] = lcode;
+    return;
+  }
+  const u32 closeAt = translatedCloseAt(S, S2);
+  const u32 rsh = a.rowShift;
+#define ROWP(rs) (a.rows + ((size_t)(rs) << rsh))
+  const u64 *const gr = a.goodRow + o;
+  u64 *const res = a.res + o;
+  const u32 thr = (u32)a.threshold;
+  u16 *const hs = a.handles + (size_t)blockIdx.x * a.handleStride;   // this workgroup's handles: list i at hs + i * hst
+  const u32 hst = a.hStride, lgH = 31 - (u32)__clz((int)hst);
+  const u32 uwave = (u32)__builtin_amdgcn_readfirstlane(wave);
+  u64 tPrev = a.phase ? wall_clock64() : 0;
+
+  // ---- pass A
+  u32 *const tab = (u32 *)region;
+  for (u32 i = tid; i <= S; i += CL_THREADS) tab[i] = 0xFFFFFFFFu;   // (+ the word of handle `none`)
+  if (tid == 0) { sh[0] = 0; sh[1] = 0; sh[2] = 0; res[0] = RES_PACK(NONE16, 0, 0); }   // [0] entries left for the second table, [1] barcodes in the first, [2] a table overflowed
+  SYNC();
+  STAMP(0);
+  // entries whose search goes beyond the home bucket (1.5 % on the config-3 sets) are parked — barcode | position of the handle << 22;
+  // hst is a power of two: the rank is the position's top bits — in a queue of the wave's own behind the handles on the HBM slot,
+  // and searched for with search() 64 lanes at a time when the pass is over (or the queue full). What search() cannot settle —
+  // a barcode that is new when the table is closed — stays in the queue, for the second table.
+  unsigned long long *const queue = (unsigned long long *)(hs + a.handleStride - (size_t)CL_WAVES * TR_QUEUE * 4) + (size_t)uwave * TR_QUEUE;
+  u32 qn = 0;                                                // (uniform)
+  SlotTable st; st.shape(tab, S, a.hashBits, &sh[2], 0);
+  // the queue against table `t`: entries [qk, qn) are searched for, 64 at a time (whole batches only unless `all`); settled entries get
+  // their handle, the others — barcodes that are new when the table no longer takes any — are kept at the queue's front, [0, qk)
+  u32 qk = 0;
+  auto settle = [&](const SlotTable &t, bool mayInsert, u32 fillLimit, bool all) {
+    u32 k0 = qk;
+    for (; all ? k0 < qn : k0 + WAVE <= qn; k0 += WAVE) {
+      const bool on = k0 + lane < qn;
+      const unsigned long long e = on ? queue[k0 + lane] : 0ull;
+      const bool insert = mayInsert && *(volatile u32 *)&sh[1] < fillLimit;   // (uniform: one LDS word)
+      u32 h = 0; bool ins = false;
+      if (on) { const u32 dest = (u32)(e >> 22); h = t.search((u32)e & 0x3FFFFFu, dest >> lgH, insert, ins); if (h != SlotTable::NOTFOUND) hs[dest] = (u16)h; }
+      const u64 balI = __ballot(ins);
+      if (balI && lane == 0) atomicAdd(&sh[1], (u32)__popcll(balI));
+      const u64 balU = __ballot(on && h == SlotTable::NOTFOUND);
+      if (balU) {
+        if (on && h == SlotTable::NOTFOUND) queue[qk + (u32)__popcll(balU & ((1ULL << lane) - 1))] = e;   // (qk <= k0: behind what has been read)
+        qk += (u32)__popcll(balU);
+      }
+    }
+    // what is left of [k0, qn) (less than a batch) moves down behind the kept ones
+    const u32 rest = k0 < qn ? qn - k0 : 0u;
+    if (rest && k0 != qk) { const unsigned long long e = (u32)lane < rest ? queue[k0 + lane] : 0ull; if ((u32)lane < rest) queue[qk + lane] = e; }
+    qn = qk + rest;
+  };
+  {
+    u32 dbgQ = 0;
+    bool insert = true;                                      // (uniform) the table takes new barcodes: looked up once per round
+    u32 myIns = 0;                                           // barcodes this wave put into the table since it last said so
+    const u32 laneU = (u32)lane;
+    // one chunk: 64 entries of list i -> 64 handles at hl[0..63] (position dest0 on the slot). Every lane stores — `none` past the list's
+    // end and for the barcode itself, a guess where the search is not over: the queue brings the real one
+    auto place = [&](u32 cj, u32 i, u32 drem /* entries of the list from this chunk on */, u16 *hl, u32 dest0) {
+      const bool valid = laneU < drem && cj != code;
+      u32 slot; bool ins;
+      const bool done = st.probeHome(cj, i, valid, insert, slot, ins);
+      hl[laneU] = (u16)(valid ? slot : S);
+      myIns += (u32)__popcll(__ballot(ins));
+      const u64 bal = __ballot(!done);
+      if (bal) {
+        if (!done) queue[qn + (u32)__popcll(bal & ((1ULL << lane) - 1))] = (unsigned long long)cj | ((unsigned long long)(dest0 + laneU) << 22);
+        qn += (u32)__popcll(bal); dbgQ += (u32)__popcll(bal);
+      }
+    };
+    // both chunks of a wave's RIF lists are requested a round ahead of their probes; descriptors two rounds ahead. Rounds start at
+    // rank 0, which is never processed (hash10x.c:789): its slot gets length 0.
+    constexpr u32 stepA = CL_WAVES * RIF;
+    u32 dv, dvN = descFix(descLoadU(gr, uwave * RIF, n), uwave * RIF, RIF, n), dvNN = descLoadU(gr, uwave * RIF + stepA, n);   // (dvNN: raw)
+    u32 c0N[RIF], c1N[RIF];
+    // (no lane skips a load and none looks at the list's length: rows[] has ROWS_PAD entries of slack, what lies behind a list's end is told
+    // apart when the chunk is used — see descLoadU)
+#define TR_LOAD_C(DV) { _Pragma("unroll") for (int t = 0; t < RIF; ++t) { const u32 *row = ROWP((u32)__builtin_amdgcn_readlane((int)DV, t)); c0N[t] = row[laneU]; c1N[t] = row[WAVE + laneU]; } }
+    TR_LOAD_C(dvN)
+    for (u32 i0 = uwave * RIF;; i0 += stepA) {
+      const bool last = i0 >= n;                             // one more turn behind the last round: the queue's remainder (ONE copy of the search loop in the code)
+      u32 lt = RIF;                                          // first list of the round with more than two chunks (RIF: none)
+      dv = dvN;
+      if (!last) {
+        u32 c0[RIF], c1[RIF];
+        dvN = descFix(dvNN, i0 + stepA, RIF, n);
+#pragma unroll
+        for (int t = 0; t < RIF; ++t) { c0[t] = c0N[t]; c1[t] = c1N[t]; }
+        dvNN = descLoadU(gr, i0 + 2 * stepA, n);             // (in front of the list loads: the next round's first wait is for this one)
+        TR_LOAD_C(dvN)
+        if (S2) {                                            // a table that may fill up: say what this wave has put in, see whether it still takes barcodes
+          if (myIns) { if (lane == 0) atomicAdd(&sh[1], myIns); myIns = 0; }
+          insert = (u32)__builtin_amdgcn_readfirstlane((int)*(volatile u32 *)&sh[1]) < closeAt;
+        }
+#pragma unroll
+        for (int t = RIF - 1; t >= 0; --t) if ((u32)__builtin_amdgcn_readlane((int)dv, 32 + t) > 2u * WAVE) lt = (u32)t;
+#pragma unroll
+        for (int t = 0; t < RIF; ++t) {
+          const u32 d = (u32)__builtin_amdgcn_readlane((int)dv, 32 + t);
+          if (d) {
+            const u32 i = i0 + t, dest0 = i << lgH; u16 *const hl = hs + dest0;
+            place(c0[t], i, d, hl, dest0);
+            if (d > WAVE) place(c1[t], i, d - WAVE, hl + WAVE, dest0 + WAVE);
+          }
+        }
+      }
+      for (u32 lj = 2 * WAVE;;) {                            // further chunks (depth ranges beyond 128), list after list; the queue is emptied in between when it fills up
+        while (lt < RIF) {
+          const u32 d = (u32)__builtin_amdgcn_readlane((int)dv, 32 + (int)lt);
+          if (d <= 2u * WAVE || lj >= d) { ++lt; lj = 2 * WAVE; continue; }
+          const u32 i = i0 + lt; const u32 *row = ROWP((u32)__builtin_amdgcn_readlane((int)dv, (int)lt));
+          place(row[lj + laneU], i, d - lj, hs + (i << lgH) + lj, (i << lgH) + lj);
+          lj += WAVE;
+          if (qn - qk >= WAVE) break;
+        }
+        if (last || qn - qk >= WAVE) {                       // (the next round's loads are under way meanwhile)
+          if (myIns) { if (lane == 0) atomicAdd(&sh[1], myIns); myIns = 0; }
+          settle(st, true, closeAt, last);
+          if (qn > TR_QUEUE - 2 * RIF * WAVE) { sh[2] = 1; qn = qk = 0; }   // more entries wait for the second table than the queue holds: the block is handed on
+        }
+        if (lt >= RIF) break;
+      }
+      if (last) break;
+    }
+#undef TR_LOAD_C
+    STAMP(1);
+    if (qn && lane == 0) sh[0] = 1;
+    if (a.phase && lane == 0) atomicAdd((u64 *)&a.phase[6], (u64)dbgQ);
+  }
+  __syncthreads();                                           // (the handles other waves wrote are plain stores of this CU, read back through its own L1: workgroup scope is
+                                                             // enough — an agent-scope acquire here drops the XCD's L2 for everybody, twice per block)
+  STAMP(2);
+  const bool spill = sh[0] != 0 && !sh[2];                   // (uniform: read after the barrier)
+  if (spill) {                                               // the first table is final now: what is still queued is looked up once more (another wave may have put the barcode in
+    qk = 0; settle(st, false, 0, true);                      // while this one found the table closed); what is still not there goes into the second table
+    SYNC();
+  }
+  if (sh[2]) {
+    if (tid == 0) a.overflow[atomicAdd(a.overflowCount, 1u)] = lcode;
+    if (a.phase && tid == 0) atomicAdd((u64 *)&a.phase[7], 1ull << 20);
+    SYNC();
+    return;
+  }
+  // ---- the table gives its LDS back: the ranks, 2 bytes per slot, compacted in place (a batch of words is read, then — behind a
+  // barrier — written as halves: the halves land below every word still to be read)
+  FirstSlots ft; ft.none = S;
+  size_t firstBytes;
+  auto compactRanks = [&](const u32 *src, u16 *dst, u32 count) {   // dst below src (or equal)
+    for (u32 base = 0; base < count; base += 4 * CL_THREADS) {
+      u32 v[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) { const u32 idx = base + (u32)k * CL_THREADS + tid; v[k] = idx < count ? src[idx] : 0u; }
+      SYNC();
+#pragma unroll
+      for (int k = 0; k < 4; ++k) { const u32 idx = base + (u32)k * CL_THREADS + tid; if (idx < count) dst[idx] = (u16)(v[k] >> 16); }   // (an empty word and the word of `none` read 0xFFFF = unseen)
+    }
+  };
+  if (compact || spill) {
+    compactRanks(tab, (u16 *)region, S + 1);
+    ft.base = region; ft.sh = 1; firstBytes = pad16(2 * ((size_t)S + 8));
+  } else { ft.base = region + 2; ft.sh = 2; firstBytes = pad16(4 * ((size_t)S + 4)); }
+  if (spill) {
+    // ---- the second table, in what the first has freed: the barcodes that turned up after the first was closed
+    u32 *const tab2 = (u32 *)(region + firstBytes);
+    SYNC();
+    for (u32 i = tid; i < S2; i += CL_THREADS) tab2[i] = 0xFFFFFFFFu;
+    if (tid == 0) sh[1] = 0;
+    SYNC();
+    SlotTable st2; st2.shape(tab2, S2, a.hashBits, &sh[2], S + 1);
+    qk = 0; settle(st2, true, 0xFFFFFFFFu, true);
+    if (qn) sh[2] = 1;                                       // (cannot happen: search() inserts or reports the overflow)
+    SYNC();
+    if (sh[2]) {
+      if (tid == 0) a.overflow[atomicAdd(a.overflowCount, 1u)] = lcode;
+      if (a.phase && tid == 0) atomicAdd((u64 *)&a.phase[7], 1ull << 40);
+      SYNC();
+      return;
+    }
+    compactRanks(tab2, (u16 *)region + S + 1, S2);
+    firstBytes = pad16(2 * ((size_t)S + S2 + 16));
+    nW = translatedWaves2(n, CL_WAVES, a.ldsBudget, S, S2);
+    if (a.phase && tid == 0) atomicAdd((u64 *)&a.phase[7], 1ull);
+  }
+  u16 *const root = (u16 *)(region + firstBytes);
+  u32 *const hist = (u32 *)(region + firstBytes + pad16((size_t)n * 2));
+  const u32 histWords = (n + 3) / 4;
+  SYNC();
+  for (u32 i = tid; i < nW * histWords; i += CL_THREADS) hist[i] = 0;
+  for (u32 i = tid; i < n; i += CL_THREADS) root[i] = i ? NONE16 : (u16)0;      // rank 0 is never processed (hash10x.c:789): inactive, its own root
+  SYNC();
+  STAMP(3);
+
+  // ---- pass B: the list loop on handles. No barrier per round: first[] is final; root[] of an earlier rank is either on record or
+  // reads "open" (then the rank is settled behind the loop), whichever wave gets there first.
+  nW = (u32)__builtin_amdgcn_readfirstlane((int)nW);
+  const bool listWave = uwave < nW;
+  const u32 stepR = nW * RIF;
+  u32 sDepth = 0;
+  {
+    const u32 laneU = (u32)lane;
+    u32 hN[RIF], h2N[RIF], hNN[RIF];
+    u32 dvCur, dvN, dvNN, dvD;
+    // the handles of a list's two chunks: all 64 lanes, no test (pass A wrote every lane of a chunk the list has; a second chunk the list
+    // has not reads whatever lies there and is not looked at)
+#define TR_LOAD_A(H, I0) { _Pragma("unroll") for (int t = 0; t < RIF; ++t) { const u32 ic = (I0) + t < n ? (I0) + t : n - 1; H[t] = (hs + ((size_t)ic << lgH))[laneU]; } }
+#define TR_LOAD_B(H2, I0) { _Pragma("unroll") for (int t = 0; t < RIF; ++t) { const u32 ic = (I0) + t < n ? (I0) + t : n - 1; H2[t] = (hs + ((size_t)ic << lgH))[WAVE + laneU]; } }
+    const u32 iw = listWave ? uwave * RIF : n;
+    dvN = descFix(descLoadU(gr, iw, n), iw, RIF, n); dvNN = descLoadU(gr, listWave ? iw + stepR : n, n); dvD = descLoadU(gr, listWave ? iw + 2 * stepR : n, n);   // (dvNN, dvD: raw)
+    TR_LOAD_A(hN, iw)
+    TR_LOAD_B(h2N, iw)
+    TR_LOAD_A(hNN, listWave ? iw + stepR : n)
+    for (u32 r0 = 0; r0 < n; r0 += stepR) {
+      const u32 i0 = listWave ? r0 + uwave * RIF : n;
+      u32 h[RIF], h2[RIF], dl[RIF];
+      dvCur = dvN; dvN = descFix(dvNN, listWave ? i0 + stepR : n, RIF, n); dvNN = dvD;
+#pragma unroll
+      for (int t = 0; t < RIF; ++t) { h[t] = hN[t]; h2[t] = h2N[t]; hN[t] = hNN[t]; dl[t] = (u32)__builtin_amdgcn_readlane((int)dvCur, 32 + t); }
+      dvD = descLoadU(gr, listWave ? i0 + 3 * stepR : n, n);
+      TR_LOAD_B(h2N, listWave ? i0 + stepR : n)
+      TR_LOAD_A(hNN, listWave ? i0 + 2 * stepR : n)
+      u32 rootV = 0; u64 resV = 0;                           // the results of the round's lists, list t in lane t: one LDS and one HBM store per round
+#pragma unroll
+      for (int t = 0; t < RIF; ++t) {
+        const u32 i = i0 + t;
+        if (dl[t]) {                                         // 0 for rank 0 and past the last rank
+          const u32 d = dl[t];
+          u32 best, bcnt, tot, rb, q;
+          const u16 *const hrow = hs + ((size_t)i << lgH);
+          if (d <= WAVE) row_mode_hist<IN_LDS, 1>(nullptr, h[t], NOHANDLE, d, code, i, ft, hist + wave * histWords, root, thr, best, bcnt, tot, rb, q);
+          else if (d <= 2 * WAVE) row_mode_hist<IN_LDS, 2>(nullptr, h[t], h2[t], d, code, i, ft, hist + wave * histWords, root, thr, best, bcnt, tot, rb, q);
+          else if (d < RCHUNK * WAVE) row_mode_hist<IN_LDS, RCHUNK>(hrow, h[t], h2[t], d, code, i, ft, hist + wave * histWords, root, thr, best, bcnt, tot, rb, q);
+          else {
+            row_mode_long(hrow, d, code, i, ft, best, bcnt, tot); rb = NONE16; q = 0;
+            if (bcnt >= thr) { rb = root[best]; if (rb != NONE16) { u32 t2; q = row_count_value(hrow, d, code, i, ft, rb, t2); } }
+          }
+          const bool act = bcnt >= thr;                      // hash10x.c:807
+          if (laneU == (u32)t) { rootV = act ? rb : i; resV = RES_PACK(act ? best : NONE16, q, tot); }
+          sDepth += d;
+        }
+      }
+      { const u32 i = i0 + laneU; if (laneU < (u32)RIF && i >= 1 && i < n) { root[i] = (u16)rootV; res[i] = resV; } }
+    }
+#undef TR_LOAD_A
+#undef TR_LOAD_B
+  }
+  STAMP(4);
+  SYNC();
+  // ---- the ranks left open by the loop (their msBest's root was not on record yet): roots by walking down the msBest chain, then
+  // their lists' handles once more for minShareCount[root] and msTot — as in cluster_one_block
+  {
+    u16 *todo = (u16 *)hist;                                 // the histograms are idle from here on
+    if (tid == 0) sh[2] = 0;
+    SYNC();
+    for (u32 i0 = 0; i0 < n; i0 += CL_THREADS) {
+      const u32 i = i0 + tid;
+      const bool need = i >= 1 && i < n && root[i] == NONE16;
+      const u64 bal = __ballot(need);
+      if (bal) {
+        u32 base = 0;
+        if (lane == 0) base = atomicAdd(&sh[2], (u32)__popcll(bal));
+        base = (u32)__shfl((int)base, 0);
+        if (need) todo[base + (u32)__popcll(bal & ((1ULL << lane) - 1))] = (u16)i;
+      }
+    }
+    SYNC();
+    const u32 nTodo = sh[2];
+    for (u32 k = tid; k < nTodo; k += CL_THREADS) {
+      const u32 i = todo[k];
+      u32 r = (u32)(__hip_atomic_load(&res[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 0xFFFFu);   // msBest: from the rank's result word (read past this CU's L1)
+      for (u32 hop = 0; hop < n && r < n; ++hop) {
+        const u32 rr = *(volatile u16 *)&root[r];
+        if (rr != NONE16) { r = rr; break; }
+        r = (u32)(__hip_atomic_load(&res[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 0xFFFFu);
+      }
+      root[i] = (u16)r;                                      // (a walker passing through i meanwhile reads NONE16 or r: the same answer either way)
+    }
+    SYNC();
+    for (u32 k0 = uwave * RIF; k0 < nTodo; k0 += CL_WAVES * RIF) {
+      u32 ii[RIF], hA[RIF], hB[RIF], dl[RIF], qv[RIF];
+#pragma unroll
+      for (int t = 0; t < RIF; ++t) {
+        const bool on = k0 + t < nTodo;
+        ii[t] = (u32)__builtin_amdgcn_readfirstlane((int)(on ? (u32)todo[k0 + t] : 0u));
+        qv[t] = on ? (u32)root[ii[t]] : NONE16;
+        dl[t] = on ? (u32)__builtin_amdgcn_readfirstlane((int)(u32)(gr[ii[t]] >> 32)) : 0u;
+        const u16 *const hrow = hs + (size_t)ii[t] * hst;
+        hA[t] = dl[t] ? (u32)hrow[lane] : S; hB[t] = dl[t] > (u32)WAVE ? (u32)hrow[WAVE + lane] : S;
+      }
+#pragma unroll
+      for (int t = 0; t < RIF; ++t) {
+        if (dl[t] == 0) continue;
+        const u32 i = ii[t];
+        u32 f = ft.peek(hA[t]);
+        u32 q = (u32)__popcll(__ballot(f == qv[t])), tt = (u32)__popcll(__ballot(f < i));
+        if (dl[t] > WAVE) { f = ft.peek(hB[t]); q += (u32)__popcll(__ballot(f == qv[t])); tt += (u32)__popcll(__ballot(f < i)); }
+        if (dl[t] > 2 * WAVE) { const u16 *const hrow = hs + (size_t)i * hst; for (u32 b0 = 2 * WAVE; b0 < dl[t]; b0 += WAVE) { f = b0 + lane < dl[t] ? ft.peek(hrow[b0 + lane]) : (u32)NONE16; q += (u32)__popcll(__ballot(f == qv[t])); tt += (u32)__popcll(__ballot(f < i)); } }
+        if (lane == 0) res[i] = RES_PACK(__hip_atomic_load(&res[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 0xFFFFu, q, tt);
+      }
+    }
+  }
+  if (lane == 0) acc[1] += sDepth;
+  if (tid == 0) { acc[1] += (u32)(gr[0] >> 32); acc[0] += n; acc[2] += a.blocks[lcode].nHash; acc[3] += 1; }
+  SYNC();
+  STAMP(5);
+}
+
 #undef SYNC
 #undef SYNC_LDS
 #undef ROWP
@@ -1045,7 +1526,8 @@ void cluster_kernel(ClusterArgs a) {
     if (wi >= a.nFront + a.nList) break;                     // every wave of the workgroup leaves together
     // (making the block number scalar with readfirstlane — and with it the rank count and every loop bound — removes a third
     // of the spills and 170 of 6900 instructions, and is 3-4 % SLOWER: 2.49 against 2.41 ms, measured round 2)
-    cluster_one_block<IN_LDS, FIRST_MODE, CL_THREADS, KLASS>(a, wi < a.nFront ? a.front[wi] : a.list[wi - a.nFront], region, firstGlobal, sh, acc);
+    if constexpr (FIRST_MODE == 4) cluster_one_block_tr<CL_THREADS, KLASS>(a, wi < a.nFront ? a.front[wi] : a.list[wi - a.nFront], region, sh, acc);
+    else cluster_one_block<IN_LDS, FIRST_MODE, CL_THREADS, KLASS>(a, wi < a.nFront ? a.front[wi] : a.list[wi - a.nFront], region, firstGlobal, sh, acc);
   }
   u64 depth = acc[1];
   for (int s = 32; s; s >>= 1) depth += __shfl_down(depth, s);
@@ -1361,9 +1843,9 @@ void read_merge_kernel(h10x_block *__restrict__ blocks, const u64 *__restrict__ 
 // launch classes by working-set size: 0 = half a CU's LDS (barcodes with many ranks run their list loop on fewer waves:
 // histWaves), 2 = the whole LDS of a CU, 3 = HBM scratch (class 1 is no longer used)
 __global__ void cluster_classify_kernel(const h10x_block *__restrict__ blocks, const u32 *__restrict__ nGood, const u32 *__restrict__ entries, u32 codeMin, u32 codeMax,
-                                        u32 nBlocks /* LDS entries of first[] (ranked, hashed: barcodes of the data set) */, int ranked /* 1 ranked, 2 hashed */, u32 hashMinSlots, u32 bmWords, u32 waves0, size_t budget0, size_t budgetSmall, size_t budgetBig, u32 bigRanks,
+                                        u32 nBlocks /* LDS entries of first[] (ranked, hashed: barcodes of the data set) */, int ranked /* 1 ranked, 2 hashed, 3 translated */, u32 hashMinSlots, u32 maxTrRanks, u32 firstCap, u32 bmWords, u32 waves0, size_t budget0, size_t budgetSmall, size_t budgetBig, u32 bigRanks,
                                         u32 *__restrict__ list0, u32 *__restrict__ list1, u32 *__restrict__ list2, u32 *__restrict__ list3,
-                                        u32 *__restrict__ listBig /* blocks with more ranks than the small replay class holds: counts[9] */, u32 *__restrict__ counts) {
+                                        u32 *__restrict__ listBig /* blocks with more ranks than the small replay class holds: counts[9] */, u32 *__restrict__ counts, unsigned long long *__restrict__ work) {
   const u32 c = codeMin + blockIdx.x * blockDim.x + threadIdx.x;
   const int lane = threadIdx.x & (WAVE - 1);
   const u32 n = c < codeMax ? nGood[c] : 0;
@@ -1377,6 +1859,15 @@ __global__ void cluster_classify_kernel(const h10x_block *__restrict__ blocks, c
       if (slots >= want) cls = 0;
       else { hashedShape(n, CL_THREADS_HUGE / WAVE, budgetBig, hashMinSlots, want, nW, slots); cls = slots ? 2 : 3; }
     }
+    else if (ranked == 3) {                             // translated placement: the table of pass A must hold the barcodes expected in the block's lists
+      const u32 want = hashedWant(rankedFirstEstimateE(nBlocks, n, entries[c]));
+      u32 S, S2, nW; bool compact;
+      translatedShape(n, waves0, budget0, hashMinSlots, entries[c], nBlocks, firstCap, S, S2, nW, compact);
+      (void)want;
+      if (n > maxTrRanks) cls = 3;                       // (its handles would not fit the workgroup's HBM slot)
+      else if (translatedFits(S, S2, rankedFirstEstimateE(nBlocks, n, entries[c]), entries[c], nBlocks)) cls = 0;
+      else { translatedShape(n, CL_THREADS_HUGE / WAVE, budgetBig, hashMinSlots, entries[c], nBlocks, firstCap, S, S2, nW, compact); cls = S ? 2 : 3; }
+    }
     else if (histWaves(ranked ? rankedFirstEstimateE(nBlocks, n, entries[c]) : nBlocks, n, waves0, bmWords, budget0)) cls = 0;
     else if (histWaves(ranked ? rankedFirstEstimate(nBlocks, n) : nBlocks, n, CL_THREADS_HUGE / WAVE, bmWords, budgetBig)) cls = 2;
     else cls = 3;
@@ -1387,6 +1878,11 @@ __global__ void cluster_classify_kernel(const h10x_block *__restrict__ blocks, c
   if (cls == 0 && n > bigRanks) cls = 1;
   for (int s = 32; s; s >>= 1) nRead = max(nRead, (u32)__shfl_xor((int)nRead, s));
   if (lane == 0 && nRead) atomicMax(&counts[8], nRead);
+  if (work) {                                            // work of the half-CU classes and of the whole-CU class (list entries + a charge per rank): the launches split the CUs by it
+    unsigned long long w0 = (cls == 0 || cls == 1) ? (unsigned long long)entries[c] + 64ull * n : 0ull, w2 = cls == 2 ? (unsigned long long)entries[c] + 64ull * n : 0ull;
+    for (int s = 32; s; s >>= 1) { w0 += __shfl_xor(w0, s); w2 += __shfl_xor(w2, s); }
+    if (lane == 0) { if (w0) atomicAdd(&work[0], w0); if (w2) atomicAdd(&work[1], w2); }
+  }
   {
     const u64 bal = __ballot(n > REPLAY_SMALL);
     if (bal) {
@@ -1418,8 +1914,8 @@ static int cluster_local_range(Ctx *c, int codeMin, int codeMax, int threshold, 
   H10X_HIP(c, list0.alloc(span)); H10X_HIP(c, list1.alloc(span)); H10X_HIP(c, list2.alloc(span)); H10X_HIP(c, list3.alloc(span)); H10X_HIP(c, listBig.alloc(span));
   // every small counter of the command in one buffer, cleared by one memset: counts[0..3] class sizes, [4] [6] [7] work
   // queue positions, [8] largest nRead, [10] [11] overflowed blocks (lists A, B); stats[0..7] the work counters
-  H10X_HIP(c, zeroed.alloc(6 + 8)); H10X_HIP(c, term.alloc(c->nEntries));
-  H10X_HIP(c, hipMemsetAsync(zeroed.p, 0, (6 + 8) * 8, st));
+  H10X_HIP(c, zeroed.alloc(6 + 8 + 2)); H10X_HIP(c, term.alloc(c->nEntries));   // (+ work of the half-CU and the whole-CU classes)
+  H10X_HIP(c, hipMemsetAsync(zeroed.p, 0, (6 + 8 + 2) * 8, st));
   struct { u32 *p; } counts{(u32 *)zeroed.p}; struct { u64 *p; } stats{zeroed.p + 6};
   const size_t budgetSmall = c->optClusterLds > 0 ? (size_t)c->optClusterLds : 80 * 1024 - 1024;
   const size_t budgetBig = c->optClusterLds > 0 ? (size_t)c->optClusterLds : 160 * 1024 - 1024;
@@ -1436,24 +1932,32 @@ static int cluster_local_range(Ctx *c, int codeMin, int codeMax, int threshold, 
   // bitmap + prefix leave the whole-CU class any room (up to 100 KB of them: 546 k barcodes) and kept unless the classification then
   // sends more than a few blocks to the HBM-scratch class; up to 48 KB (262 k barcodes) it is taken as before.
   const bool rankedSure = (size_t)bmWordsAll * 6 <= 48 * 1024, rankedTry = !rankedSure && (size_t)bmWordsAll * 6 <= 100 * 1024 && hashBits <= 22;
-  int firstMode = (size_t)nGlobal * 2 <= 48 * 1024 ? 0 : (rankedSure || rankedTry ? 1 : (hashBits <= 22 ? 3 : 2));
+  int firstMode = (size_t)nGlobal * 2 <= 48 * 1024 ? 0 : (rankedSure || rankedTry ? 1 : (hashBits <= 22 ? 4 : 2));
   if (c->optFirstGlobal == 1) firstMode = 2; else if (c->optFirstGlobal == 2) firstMode = 1; else if (c->optFirstGlobal == 3) firstMode = 3;   // test knobs
+  else if (c->optFirstGlobal == 4 && hashBits <= 22) firstMode = 4;
+  // translated placement: u16 per list on a workgroup's handle slot (a multiple of 64 that holds the longest list), ranks per slot
+  u32 hStride = 64; while (hStride < c->maxGoodDepth && hStride < (1u << 24)) hStride <<= 1;   // (a power of two: a handle's position tells its rank)
+  const size_t trSlotCapBytes = (size_t)32 << 20;
+  const u32 maxTrRanks = (u32)hmin<size_t>(0xFFFFFFFFu, trSlotCapBytes / ((size_t)hStride * 2));
+  const size_t trSlotU16 = (size_t)hmin<u32>(hmax<u32>(c->maxGood, 1u), maxTrRanks) * hStride + (size_t)(CL_THREADS_HUGE / WAVE) * TR_QUEUE * 4;
   const u32 firstCap = c->optFirstCap > 0 ? (u32)c->optFirstCap : 0u;      // test knob only
-  u32 hc[12]; u32 nFirstLds = 0, bmWords = 0;
+  u32 hc[12]; u64 hw[2] = {0, 0}; u32 nFirstLds = 0, bmWords = 0;
   for (int attempt = 0; attempt < 2; ++attempt) {
     nFirstLds = firstMode == 0 ? nGlobal : 0;
     bmWords = firstMode == 1 ? bmWordsAll : 0;
     cluster_classify_kernel<<<divUp(span, 256), 256, 0, st>>>(c->blocks.p, c->nGood.p, c->goodEntries.p, (u32)codeMin, (u32)codeMax,
-                                                            firstMode == 1 || firstMode == 3 ? nGlobal : nFirstLds, firstMode == 1 ? 1 : (firstMode == 3 ? 2 : 0), hashMinSlots,
+                                                            firstMode == 1 || firstMode >= 3 ? nGlobal : nFirstLds, firstMode == 1 ? 1 : (firstMode == 3 ? 2 : (firstMode == 4 ? 3 : 0)), hashMinSlots, maxTrRanks, firstCap,
                                                             bmWords, (u32)threads0 / WAVE, budget0, budgetSmall, budgetBig, c->optBigRanks > 0 ? (u32)c->optBigRanks : c->meanGood + c->meanGood / 2,
-                                                            list0.p, list1.p, list2.p, list3.p, listBig.p, counts.p);
+                                                            list0.p, list1.p, list2.p, list3.p, listBig.p, counts.p, (unsigned long long *)(zeroed.p + 14));
     H10X_TRY(c->readback(hc, counts.p, 48));
+    H10X_TRY(c->readback(hw, zeroed.p + 14, 16));
     H10X_TRY(c->syncReadbacks());
     const u32 classified = hc[0] + hc[1] + hc[2] + hc[3];
     if (attempt || !rankedTry || c->optFirstGlobal || firstMode != 1 || hc[3] <= 16 + classified / 200) break;
-    firstMode = 3;                                           // too many blocks without room beside the bitmap: the hashed table after all
+    firstMode = 4;                                           // too many blocks without room beside the bitmap: the translated placement after all
     H10X_HIP(c, hipMemsetAsync(counts.p, 0, 16, st));        // the four class sizes
     H10X_HIP(c, hipMemsetAsync(counts.p + 9, 0, 4, st));
+    H10X_HIP(c, hipMemsetAsync(zeroed.p + 14, 0, 16, st));
   }
   // (the work queue hands barcodes out in the order the classification appended them, i.e. mixed sizes: sorting the
   // queue by descending rank count was measured 17 % SLOWER — workgroups of like size run their phases in step and
@@ -1466,6 +1970,7 @@ static int cluster_local_range(Ctx *c, int codeMin, int codeMax, int threshold, 
   a.dbgSkip = (u32)c->optDbgSkip; a.narrowFirst = (u32)c->optNarrowFirst;
   a.maxGood = c->maxGood; a.stats = stats.p; a.res = term.p; a.entries = c->goodEntries.p;
   a.firstCap = firstCap; a.hashMask = hashBits >= 32 ? 0xFFFFFFFFu : (1u << hashBits) - 1u; a.hashMinSlots = hashMinSlots;
+  a.hashBits = (u32)hashBits; a.hStride = hStride; a.handleStride = trSlotU16;   // (handles, then the waves' queues)
   // ranked / hashed placement: blocks whose table was too small are re-run — those of the half-CU class (list A) with the
   // whole LDS of a CU, those that fail there as well (list B) with first[] dense on an HBM slot
   DevBuf<u32> ovfA, ovfB; H10X_HIP(c, ovfA.alloc(span)); H10X_HIP(c, ovfB.alloc(span));
@@ -1484,7 +1989,17 @@ static int cluster_local_range(Ctx *c, int codeMin, int codeMax, int threshold, 
   // hybrid placement: one first[] slot per resident workgroup of each LDS class
   DevBuf<unsigned char> firstSlots[3];
   const size_t firstStride = (((size_t)nGlobal * 2 + 255) & ~(size_t)255);
-  const u32 gridOf[3] = {hmin<u32>(hc[0] + hc[1], (u32)c->numCU * (u32)hmax<size_t>(1, (160 * 1024) / (budget0 + 1024))), hmin<u32>(hc[1], (u32)c->numCU * 2), hmin<u32>(hc[2], (u32)c->numCU)};   // class 1 unused
+  u32 gridOf[3] = {hmin<u32>(hc[0] + hc[1], (u32)c->numCU * (u32)hmax<size_t>(1, (160 * 1024) / (budget0 + 1024))), hmin<u32>(hc[1], (u32)c->numCU * 2), hmin<u32>(hc[2], (u32)c->numCU)};   // class 1 unused
+  // Both LDS classes are persistent launches that stay on the CUs they get: a whole-CU workgroup keeps two half-CU workgroups out. Where both have
+  // enough blocks to fill the chip, the CUs are split by the classes' work (the whole-CU class does a list entry at ~0.8 x the rate per CU: measured
+  // on the million-barcode set, where it used to finish 100 ms behind the main launch), so that the two launches end together.
+  if (firstMode == 4 && gridOf[2] == (u32)c->numCU && gridOf[0] >= (u32)c->numCU && hw[0] + hw[1]) {
+    const double share2 = 1.25 * (double)hw[1] / (1.25 * (double)hw[1] + (double)hw[0]);
+    const u32 cu2 = hmin<u32>((u32)c->numCU - 1, hmax<u32>(1u, (u32)(share2 * c->numCU + 0.5)));
+    gridOf[2] = cu2; gridOf[0] = hmin<u32>(gridOf[0], 2 * ((u32)c->numCU - cu2));
+  }
+  DevBuf<u16> trSlots[3];                                  // translated placement: one handle slot per resident workgroup of each LDS class
+  if (firstMode == 4) for (int k = 0; k < 3; k += 2) if (gridOf[k]) H10X_HIP(c, trSlots[k].alloc(trSlotU16 * gridOf[k]));
   if (firstMode == 2) for (int k = 0; k < 3; k += 2) if (gridOf[k]) {       // class 0 serves list 0 AND the front list (hc[1]); class 1 has no launch
     H10X_HIP(c, firstSlots[k].alloc(firstStride * gridOf[k]));
     H10X_HIP(c, hipMemsetAsync(firstSlots[k].p, 0xFF, firstStride * gridOf[k], st));
@@ -1511,6 +2026,7 @@ static int cluster_local_range(Ctx *c, int codeMin, int codeMax, int threshold, 
     if (firstMode == 0) H10X_LAUNCH_ONE(0, K, THREADS, BUDGET, GRID, STREAM)                                                       \
     else if (firstMode == 1) H10X_LAUNCH_ONE(1, K, THREADS, BUDGET, GRID, STREAM)                                                  \
     else if (firstMode == 3) H10X_LAUNCH_ONE(3, K, THREADS, BUDGET, GRID, STREAM)                                                  \
+    else if (firstMode == 4) { g.handles = trSlots[K].p; H10X_LAUNCH_ONE(4, K, THREADS, BUDGET, GRID, STREAM) }                    \
     else { g.scratch = firstSlots[K].p; g.scratchStride = firstStride; H10X_LAUNCH_ONE(2, K, THREADS, BUDGET, GRID, STREAM) }      \
   }
   if (hc[2]) {
@@ -1549,12 +2065,13 @@ static int cluster_local_range(Ctx *c, int codeMin, int codeMax, int threshold, 
   H10X_TRY(c->joinStreams(3));
   u32 nOverflow = 0;
   DevBuf<unsigned char> scratch2;
-  if (firstMode == 1 || firstMode == 3) {
+  if (firstMode == 1 || firstMode == 3 || firstMode == 4) {
     u32 nA = 0, nB = 0;
     H10X_HIP(c, hipMemcpyAsync(&nA, ovfCountA, 4, hipMemcpyDeviceToHost, st));
     H10X_HIP(c, hipStreamSynchronize(st));
     if (nA) {                                                // half-CU tables that were too small: again with the whole LDS of a CU
       H10X_HIP(c, hipMemsetAsync(counts.p + 6, 0, 4, st));
+      if (firstMode == 4 && trSlots[2].n < trSlotU16 * hmin<u32>(nA, (u32)c->numCU)) H10X_HIP(c, trSlots[2].alloc(trSlotU16 * hmin<u32>(nA, (u32)c->numCU)));
       H10X_LAUNCH_LDS(2, CL_THREADS_HUGE, budgetBig, st, ovfA.p, nA, hmin<u32>(nA, (u32)c->numCU), 6, ovfCountB, ovfB.p)
       H10X_HIP(c, hipGetLastError());
     }

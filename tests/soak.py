@@ -78,7 +78,7 @@ def run(n_cases, seed, verbose=False, scale=1):
         lo = rng.choice([1, 2, 3, 4, 6]); hi = lo + rng.choice([1, 3, 10, 30, 100, 100000]); ct = rng.choice([1, 2, 3, 5, 40])
         B = (23 if w < 13 else 21) + (scale - 1).bit_length()
         opts = {}
-        if rng.random() < 0.3: opts["cluster_first_global"] = rng.choice([1, 2, 3])
+        if rng.random() < 0.3: opts["cluster_first_global"] = rng.choice([1, 2, 3, 4, 4])
         if rng.random() < 0.2: opts["cluster_lds_budget"] = rng.choice([2048, 16 * 1024, 24 * 1024, 48 * 1024])
         if rng.random() < 0.15: opts["stage_a_max_slots"] = rng.choice([256, 1024, 4096])
         if rng.random() < 0.15 and "cluster_first_global" in opts: opts["cluster_first_cap"] = rng.choice([64, 500, 1500])

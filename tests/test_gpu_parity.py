@@ -101,11 +101,13 @@ def test_cluster_hbm_scratch_and_big_lds_paths(workdir, budget):
     assert hf.blocks["nSubCluster"].sum() > 0
 
 
-@pytest.mark.parametrize("mode,cap", [(2, 0), (2, 64), (3, 0), (3, 1500), (3, 64)])
+@pytest.mark.parametrize("mode,cap", [(2, 0), (2, 64), (3, 0), (3, 1500), (3, 64), (4, 0), (4, 1500), (4, 200), (4, 64)])
 def test_cluster_ranked_and_hashed_first_tables(workdir, mode, cap):
     """Placements of first[] for data sets with many barcodes, forced on a small set: mode 2 = ranked (presence bitmap +
     popcount prefix, first[] sized by the barcodes present), mode 3 = hashed (open-addressing table in LDS keyed by
-    barcode). A small cap makes the tables overflow: the blocks are re-run with the whole LDS of a CU and, when that
+    barcode), mode 4 = translated (round 4: one pass turns every list entry into the 16-bit slot number of its barcode in
+    such a table, the list loop then runs on those handles; cap 200: the first table is closed at 175 of the ~300 barcodes and the
+    rest goes into a second one). A small cap makes the tables overflow: the blocks are re-run with the whole LDS of a CU and, when that
     fails too, with first[] dense on an HBM slot."""
     orc.gen_fqb(workdir.file("x.fqb"), 60000, 300, 400000, 0.003, 43, 4.0, 150, 6000)
     opts = dict(cluster_first_global=mode)
@@ -131,6 +133,9 @@ def test_more_than_65535_barcodes(workdir):
     hf = _against_oracle(workdir, "x.fqb", ["-ct", 1, "--readFQB", "x.fqb", "--hashDepthRange", 3, 200, "--cluster", 1, 0], B=23)
     assert hf.blocks["nSubCluster"].sum() > 10000 and hf.blocks_max > 65535
     _against_oracle(workdir, "x.fqb", ["-ct", 1, "--readFQB", "x.fqb", "--hashDepthRange", 3, 200, "--cluster", 1, 0], B=23, cluster_first_global=3)
+    _against_oracle(workdir, "x.fqb", ["-ct", 1, "--readFQB", "x.fqb", "--hashDepthRange", 3, 200, "--cluster", 1, 0], B=23, cluster_first_global=4)   # lists of up to 199 entries: four chunks of handles
+    _against_oracle(workdir, "x.fqb", ["-ct", 1, "--readFQB", "x.fqb", "--hashDepthRange", 3, 200, "--cluster", 1, 0], B=23, cluster_first_global=4, cluster_lds_budget=24 * 1024)   # tables compacted, few list-loop waves
+    _against_oracle(workdir, "x.fqb", ["-ct", 1, "--readFQB", "x.fqb", "--hashDepthRange", 3, 200, "--cluster", 1, 0], B=23, cluster_first_global=4, cluster_first_cap=1024)   # second tables, some of them too small as well
     # and sharded over 4 ranks (global barcode numbers beyond 16 bits in every rank's lists)
     exp = open(workdir.file("orc.hash"), "rb").read()
     recs = np.fromfile(workdir.file("x.fqb"), dtype=np.uint32)
@@ -144,7 +149,7 @@ def test_cluster_tiny_set_front_queue_only(workdir):
     any counts as 'large' and sits in the front queue while the ordinary queue is empty (a null first[] slot in the hybrid
     placement, found by tests/soak.py)."""
     orc.gen_fqb(workdir.file("x.fqb"), 60, 15, 40000, 0.001, 1507, 4.0, 150, 2500)
-    for mode in (0, 1, 2, 3):
+    for mode in (0, 1, 2, 3, 4):
         _against_oracle(workdir, "x.fqb", ["-ct", 5, "--readFQB", "x.fqb", "--hashDepthRange", 3, 4, "--cluster", 1, 0],
                         k=24, w=32, r=9, B=21, cluster_first_global=mode)
         _against_oracle(workdir, "x.fqb", ["-ct", 1, "--readFQB", "x.fqb", "--hashDepthRange", 2, 4, "--cluster", 1, 0],
