@@ -403,7 +403,7 @@ def full_config3_block(hash10x_amd, local_rank, steps=3):
            "device_ms_per_step": {k: round(v[0] / steps, 2) for k, v in tm.items() if v[0] > 0},
            "entries_H": c["entries"], "distinct_U": c["distinct"], "hashNumber": z["hashNumber"],
            "sizes_match_reference": z["hashNumber"] == case["hash_number"] and z["nBlocks"] == case["blocks_max"] and z["nClusHash"] == case["sum_nHash"],
-           "first_placement": {0: "dense", 1: "ranked", 2: "hbm-slot", 3: "hashed"}.get(c["cluster_first_mode"]),
+           "first_placement": {0: "dense", 1: "ranked", 2: "hbm-slot", 3: "hashed", 4: "translated"}.get(c["cluster_first_mode"]),
            "cluster_class_counts": c["cluster_class_counts"], "cluster_overflow_blocks": c["cluster_overflow_blocks"],
            "roofline": {"bound": "hbm", "kernel": "all cluster launches", "achieved": alg / (clu_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": alg / (clu_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes": alg, "ms_per_step": clu_ms},
@@ -438,7 +438,7 @@ def secondary_block(hash10x_amd, local_rank):
                 a = tm.setdefault(k, [0.0, 0]); a[0] += ms; a[1] += n
     c = h.counters(); z = h.sizes()
     main_ms = tm["cluster_main"][0] / max(tm["cluster_main"][1], 1)
-    alg = 4.0 * c["cluster_main"][1] + 14.0 * c["cluster_main"][0] + 16.0 * c["cluster_main"][2]
+    alg = 4.0 * c["cluster_main"][1] + 14.0 * c["cluster_main"][0]        # (what the main launch moves: see the headline's cluster_main)
     clu_all_ms = tm["cluster_kernel"][0] / steps
     alg_all = 4.0 * c["sum_good_depth"] + 14.0 * c["sum_good"] + 16.0 * c["sum_hash_clustered"]
     c3_traffic = c3_src = c3_head = c3_build = None          # rocprofv3 --pmc passes of this workload, committed under profiles/
@@ -456,7 +456,7 @@ def secondary_block(hash10x_amd, local_rank):
            "ms_per_step": 1e3 * sum(wall) / len(wall), "read_pairs_per_s": pairs * len(wall) / sum(wall), "steps": steps,
            "device_ms_per_step": {k: round(v[0] / steps, 3) for k, v in tm.items() if v[0] > 0},
            "entries_H": c["entries"], "distinct_U": c["distinct"], "hashNumber": z["hashNumber"],
-           "first_placement": {0: "dense", 1: "ranked", 2: "hbm-slot", 3: "hashed"}.get(c["cluster_first_mode"]),
+           "first_placement": {0: "dense", 1: "ranked", 2: "hbm-slot", 3: "hashed", 4: "translated"}.get(c["cluster_first_mode"]),
            "cluster_class_counts": c["cluster_class_counts"], "cluster_overflow_blocks": c["cluster_overflow_blocks"],
            "roofline": {"bound": "hbm", "kernel": "cluster_main", "achieved": alg / (main_ms * 1e-3) / 1e9 if main_ms else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": alg / (main_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if main_ms else None, "algorithmic_bytes_per_launch": alg, "avg_launch_ms": main_ms,
@@ -592,8 +592,13 @@ def main():
         "sort_by_hash": 20.0 * H, "index_rank": 12.0 * U, "probe_table": 4.0 * U + 4.0 * T, "clushash_build": 8.0 * H,
         # the main cluster_kernel launch alone (its own hipEvent bracket and its own work counters: what rocprofv3 lists as
         # cluster_kernel<true, *, 1024, 0>); the few largest barcodes run beside it in a launch of their own
-        "cluster_main": 4.0 * ctr["cluster_main"][1] + 14.0 * ctr["cluster_main"][0] + 16.0 * ctr["cluster_main"][2],
+        # Charged with what THIS launch moves: the list entries and the 14 bytes per good hash — not the 16 bytes per (barcode, hash)
+        # entry of the read-merge pass, which replay / point_sum / read_merge kernels do behind it (that term flattered the
+        # launch by 11 %); `cluster_all` below has every --cluster launch against all the bytes.
+        "cluster_main": 4.0 * ctr["cluster_main"][1] + 14.0 * ctr["cluster_main"][0],
     }
+    alg_cluster_all = 4.0 * ctr["sum_good_depth"] + 14.0 * ctr["sum_good"] + 16.0 * ctr["sum_hash_clustered"]
+    clu_all_ms = per.get("cluster_kernel", (0, 0, 0))[2]
     index_ms = sum(per.get(k, (0, 0, 0))[2] for k in ("sort_by_hash", "index_rank", "probe_table", "clushash_build"))
     index_alg = 28.0 * H + 16.0 * U + 4.0 * T
     dom = max(("mosh_extract", "sort_by_hash", "cluster_main"), key=lambda k: per.get(k, (0, 0, 0))[2])
@@ -642,6 +647,9 @@ def main():
                      "algorithmic_bytes_per_launch": alg[dom], "avg_launch_ms": dom_ms, "barcodes_in_launch": ctr["cluster_main"][3] if dom == "cluster_main" else None,
                      "other_kernels": {k: {"GB/s": alg[k] / (per[k][2] * 1e-3) / 1e9, "frac": alg[k] / (per[k][2] * 1e-3) / 1e9 / HBM_PEAK_GBS, "ms_per_step": per[k][2],
                                            "algorithmic_bytes": alg[k]} for k in alg if k in per and per[k][2] > 0},
+                     "cluster_all": {"what": "all device work of --cluster (classification, the cluster_kernel launches, replay, point_sum, read_merge; timer cluster_kernel) against 4 sum_depth + 14 sum_good + 16 H_clustered",
+                                     "GB/s": alg_cluster_all / (clu_all_ms * 1e-3) / 1e9 if clu_all_ms else None, "frac": alg_cluster_all / (clu_all_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if clu_all_ms else None,
+                                     "ms_per_step": clu_all_ms, "algorithmic_bytes": alg_cluster_all},
                      "index_build": {"GB/s": index_alg / (index_ms * 1e-3) / 1e9 if index_ms else None, "frac": index_alg / (index_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if index_ms else None,
                                      "ms_per_step": index_ms, "algorithmic_bytes": index_alg, "timers": "sort_by_hash + index_rank + probe_table + clushash_build"},
                      # K1 is bounded by integer ALU, not HBM: 2 x 64-bit multiplies per k-mer (seqhash.c:58-59), 237 k-mers per pair at k = 21;

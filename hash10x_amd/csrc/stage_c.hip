@@ -549,25 +549,23 @@ struct SlotTable {
     const u32 x = __umul24(cj, SCRAMBLE) << xsh;
     const u32 b4 = __umulhi(x, NB) << 2;
     const u32 key = (x * NB) >> tsh;                         // displacement 0
-    const u32 mine = (i << 16) | key, lim = mine | 0xFFFFu;
+    const u32 mine = (i << 16) | key;
     const uint4 e4 = *(const uint4 *)&tab[b4];               // (every lane reads: a lane without an entry holds some barcode of the list all the same)
     // which word holds the barcode, else which is the first empty one (selects, no branch per word)
     const bool m0 = (e4.x & 0xFFFFu) == key, m1 = (e4.y & 0xFFFFu) == key, m2 = (e4.z & 0xFFFFu) == key, m3 = (e4.w & 0xFFFFu) == key;
     const bool z0 = e4.x == 0xFFFFFFFFu, z1 = e4.y == 0xFFFFFFFFu, z2 = e4.z == 0xFFFFFFFFu, z3 = e4.w == 0xFFFFFFFFu;
     const bool hit = m0 | m1 | m2 | m3;
     const u32 wh = m0 ? 0u : (m1 ? 1u : (m2 ? 2u : 3u)), wz = z0 ? 0u : (z1 ? 1u : (z2 ? 2u : 3u));
-    u32 seen = m0 ? e4.x : (m1 ? e4.y : (m2 ? e4.z : e4.w));  // the barcode's entry as read (only meaningful on a hit)
     slot = b4 | (hit ? wh : wz);
     bool same = false; ins = false;
     if (valid && insert && !hit && (z0 | z1 | z2 | z3)) {    // claim the first empty word
-      seen = atomicCAS(&tab[slot], 0xFFFFFFFFu, mine);
+      const u32 seen = atomicCAS(&tab[slot], 0xFFFFFFFFu, mine);
       ins = seen == 0xFFFFFFFFu; same = (seen & 0xFFFFu) == key;   // it was empty, or the same barcode got there first
-      seen = ins ? 0u : seen;
     }
-    const bool done = !valid || hit || ins || same;
-    const bool later = valid && done && seen > lim;          // a later rank got here earlier (waves are a round or two apart at most: rare)
-    if (__builtin_amdgcn_ballot_w64(later)) { if (later) atomicMin(&tab[slot], mine); }
-    return done;
+    // the entry's rank: minimum with this one, looked at or not — a fire-and-forget LDS atomic per chunk costs less than finding out whether
+    // a later rank got here first (four selects, a compare and the masks around a branch; the kernel is bound by its instruction count, LDS is a quarter busy)
+    if (valid && (hit || same)) atomicMin(&tab[slot], mine);
+    return !valid || hit || ins || same;
   }
 };
 struct FirstSlots {                                          // pass B: first[] by handle

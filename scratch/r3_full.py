@@ -21,6 +21,8 @@ del recs
 h = hash10x_amd.Hash10x(B=man["B"]); h.enable_timing(True)
 if os.environ.get("H10X_FIRST_GLOBAL"): h.set_option("cluster_first_global", int(os.environ["H10X_FIRST_GLOBAL"]))
 if stamps: h.set_option("cluster_stamps", 1)
+for kv in filter(None, os.environ.get("H10X_OPTS", "").split(",")):
+    k, v = kv.split("="); h.set_option(k, int(v))
 for it in range(passes):
     hash10x_amd.synchronize(0)
     t0 = time.time(); h.read_fqb_device(dr.ptr, dr.n_records); hash10x_amd.synchronize(0); t1 = time.time()
