@@ -45,6 +45,16 @@ WORKLOADS = {
     # BASELINE configs[2] (500 Mb x 2, 200 M pairs, 1 M barcodes, e = 0.1 %) at 1/10 scale: the `secondary` block of the bench
     # line (ranked placement of first[], several thousand barcodes on the > 255 clusters path). -B 26: the table size that
     # holds its 10.4 M hashes (BASELINE's -B 28 for the full set is too small, see tests "config3_dies...").
+    # BASELINE configs[3]/[4] shape — a 3 Gb genome x 2 haplotypes at -B 30 — at the largest read-pair count whose reference run the build
+    # container's 62 GB of RAM hold (300 M pairs, 1.6 M barcodes; the reference's own cap, 2^28 - 2 distinct hashes, would allow ~380 M:
+    # distinct hashes ~ 103 M of the genome + 0.43 per pair). e = 0.05 %. 15 x coverage per haplotype puts the het /
+    # hom depth peaks at ~11 / ~22 (scratch/r4_g3_hist.py on the 1/10 proxy), hence --hashDepthRange 6 45. Generator v2 (shard-local).
+    # This is the strong-scaling workload: the SAME set on 1, 2, 4, 8 ranks, pinned by the reference binary's digest (manifest "strong_digests").
+    "genome3g-300M": dict(pairs=300000000, barcodes=1600000, genome=3000000000, err=0.0005, mol=10.0, snp=150, mol_len=50000.0,
+                          B=30, lo=6, hi=45, ct=5, seed=3, gen=2),
+    # the same proportions at 1/10 (same coverage, same depth range): the strong-scaling mode's functional check on test boxes (two ranks on one GPU)
+    "genome3g-tenth-30M": dict(pairs=30000000, barcodes=160000, genome=300000000, err=0.0005, mol=10.0, snp=150, mol_len=50000.0,
+                               B=27, lo=6, hi=45, ct=5, seed=3, gen=2),
     "config3-tenth-20M": dict(pairs=20000000, barcodes=100000, genome=50000000, err=0.001, mol=10.0, snp=150, mol_len=50000.0,
                               B=26, lo=30, hi=100, ct=5, seed=2),
 }
@@ -126,18 +136,26 @@ def _mix64(x):
 
 
 def checksum_words(words, first_index, domain):
-    """[sum over i of mix(words[i] ^ mix(first_index + i + salt + domain))] for the two salts, mod 2^64"""
+    """[sum over i of mix(words[i] ^ mix(first_index + i + salt + domain))] for the two salts, mod 2^64 (slices of 2^22 words on a few
+    threads: numpy releases the GIL, and the 3 Gb workload has 2 x 10^9 records to go through)"""
     w = np.ascontiguousarray(words, dtype=np.uint64)
-    out = []
-    with np.errstate(over="ignore"):
-        for salt in _SALTS:
-            tot = np.uint64(0)
-            for a in range(0, w.size, 1 << 24):
-                part = w[a: a + (1 << 24)]
+
+    def one(a):
+        part = w[a: a + (1 << 22)]
+        res = []
+        with np.errstate(over="ignore"):
+            for salt in _SALTS:
                 idx = np.arange(part.size, dtype=np.uint64) + np.uint64((first_index + a + salt + domain * 0x9E3779B97F4A7C15) & 0xFFFFFFFFFFFFFFFF)
-                tot = tot + np.sum(_mix64(part ^ _mix64(idx)), dtype=np.uint64)
-            out.append(int(tot))
-    return out
+                res.append(int(_mix64(part ^ _mix64(idx)).sum(dtype=np.uint64)))
+        return res
+    starts = list(range(0, w.size, 1 << 22))
+    if len(starts) > 4:
+        from concurrent.futures import ThreadPoolExecutor
+        with ThreadPoolExecutor(max_workers=min(16, os.cpu_count() or 1)) as ex:
+            parts = list(ex.map(one, starts))
+    else:
+        parts = [one(a) for a in starts]
+    return [sum(p[k] for p in parts) & 0xFFFFFFFFFFFFFFFF for k in range(2)]
 
 
 def checksum_state(block_bytes, first_block, clushash_bytes, first_entry):
@@ -414,6 +432,63 @@ def full_config3_block(hash10x_amd, local_rank, steps=3):
     return out
 
 
+def genome3g_block(hash10x_amd, local_rank, steps=2):
+    """The 3 Gb workload (BASELINE configs[3] shape at the size the reference's run could be pinned: WORKLOADS["genome3g-300M"]) on ONE GPU — the set
+    `bench.py --workload genome3g-300M --scaling strong --gpus N` scales over 1 / 2 / 4 / 8 ranks: ms per step, roofline of the cluster launches, and the
+    parity gate against the reference binary's digest (composable checksum of all blocks and ClusterHash records)."""
+    name = "genome3g-300M"
+    wl = dict(WORKLOADS[name])
+    t0 = time.perf_counter()
+    recs, _first, _total = generate_v2(wl, wl["seed"])
+    gen_s = time.perf_counter() - t0
+    d = hash10x_amd.DeviceRecords(recs, device=local_rank)
+    pairs = recs.size // 30
+    del recs
+    h = hash10x_amd.Hash10x(B=wl["B"], device=local_rank)
+    h.enable_timing(True)
+    wall, tm = [], {}
+    for it in range(steps + 1):                             # one warm-up
+        hash10x_amd.synchronize(local_rank)
+        t = time.perf_counter()
+        h.read_fqb_device(d.ptr, pairs); h.depth_range(wl["lo"], wl["hi"]); h.cluster(1, 0, wl["ct"])
+        hash10x_amd.synchronize(local_rank)
+        if it:
+            wall.append(time.perf_counter() - t)
+            for k, (ms, n) in h.timings().items():
+                a = tm.setdefault(k, [0.0, 0]); a[0] += ms; a[1] += n
+    c = h.counters(); z = h.sizes()
+    clu_ms = tm["cluster_kernel"][0] / steps
+    alg = 4.0 * c["sum_good_depth"] + 14.0 * c["sum_good"] + 16.0 * c["sum_hash_clustered"]
+    out = {"workload": "%s (3 Gb x 2 haplotypes, 300 M pairs, 1.6 M barcodes, e = 0.05 %%, -B 30, --hashDepthRange %d %d; gen_fqb v2 seed %d)" % (name, wl["lo"], wl["hi"], wl["seed"]),
+           "ms_per_step": 1e3 * sum(wall) / len(wall), "read_pairs_per_s": pairs * len(wall) / sum(wall), "steps": steps,
+           "device_ms_per_step": {k: round(v[0] / steps, 2) for k, v in tm.items() if v[0] > 0},
+           "entries_H": c["entries"], "distinct_U": c["distinct"], "hashNumber": z["hashNumber"],
+           "first_placement": {0: "dense", 1: "ranked", 2: "hbm-slot", 3: "hashed", 4: "translated"}.get(c["cluster_first_mode"]),
+           "cluster_class_counts": c["cluster_class_counts"], "cluster_overflow_blocks": c["cluster_overflow_blocks"],
+           "roofline": {"bound": "hbm", "kernel": "all cluster launches", "achieved": alg / (clu_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": alg / (clu_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes": alg, "ms_per_step": clu_ms},
+           "barcodes_per_s_clustered": wl["barcodes"] / (tm["cluster"][0] / steps * 1e-3),
+           "generate_seconds": round(gen_s, 1), "host_threads": os.cpu_count()}
+    try:
+        t0 = time.perf_counter()
+        cs = checksum_state(h.export_slice(3, 1, z["nBlocks"] - 1), 1, np.zeros(0, dtype=np.uint8), 0)
+        for a in range(0, z["nClusHash"], 1 << 27):
+            part = checksum_state(np.zeros(0, dtype=np.uint8), 0, h.export_slice(4, a, min(1 << 27, z["nClusHash"] - a)), a)
+            cs = [(cs[0] + part[0]) & 0xFFFFFFFFFFFFFFFF, (cs[1] + part[1]) & 0xFFFFFFFFFFFFFFFF]
+        exp = json.load(open(os.path.join(REPO, "tests", "golden", "manifest.json"))).get("strong_digests", {}).get(name)
+        out["state_checksum"] = ["0x%016x" % v for v in cs]
+        out["parity_seconds"] = round(time.perf_counter() - t0, 1)
+        if exp is None:
+            out["parity_vs_reference_digest"] = "no reference digest committed for %s" % name
+        else:
+            same = [int(v, 16) for v in exp["checksum"]] == cs and exp["hash_number"] == z["hashNumber"] and exp["sum_nHash"] == z["nClusHash"]
+            out["parity_vs_reference_digest"] = "identical" if same else "DIFFERENT (reference %s, H %d, hashNumber %d)" % (exp["checksum"], exp["sum_nHash"], exp["hash_number"])
+    except Exception as e:
+        out["parity_vs_reference_digest"] = "check failed: " + str(e)[:200]
+    h.close(); d.free()
+    return out
+
+
 def secondary_block(hash10x_amd, local_rank):
     """The 1/10-scale BASELINE configs[2] set in the same process (single GPU): ms per step and the roofline of the main
     cluster launch in the ranked placement — the regime real data sets are in, next to the yeast-scale headline."""
@@ -480,7 +555,11 @@ def main():
     ap.add_argument("--comm", default="auto", choices=["auto", "rccl", "socket"], help="multi-process backend: RCCL over xGMI (one GPU per rank), or the "
                     "host-staged socket backend where ranks share a GPU (test boxes); auto = socket when there are fewer devices than ranks")
     ap.add_argument("--sharded", action="store_true", help="use the multi-GPU code path (RCCL communicator, shard exchange) even with one rank")
+    ap.add_argument("--scaling", default=None, choices=["weak", "strong"], help="N > 1: weak = N x the workload (every rank generates its share of the N-fold set; "
+                    "default for the yeast-scale set), strong = the SAME set on every N (default for genome3g-300M: the 3 Gb workload of BASELINE configs[3])")
     args = ap.parse_args()
+    if args.scaling is None:
+        args.scaling = "strong" if WORKLOADS[args.workload].get("gen") == 2 else "weak"
 
     # the contract is ONE JSON line on stdout: native libraries (RCCL prints a version banner) must not write there,
     # so fd 1 is pointed at stderr for the life of the process and the JSON line goes to the saved descriptor
@@ -504,7 +583,8 @@ def main():
     if world > 1 or args.sharded:
         # weak scaling: N times the yeast-scale set (N x pairs, barcodes and genome; table bits grow with log2 N),
         # barcodes sharded over the ranks, hash index exchanged by RCCL all-to-all (csrc/shard.hip)
-        wl = scaled_workload(wl, world)
+        if args.scaling == "weak":
+            wl = scaled_workload(wl, world)
         ndev = hash10x_amd.device_count()
         backend = args.comm if args.comm != "auto" else ("socket" if world > max(ndev, 1) else "rccl")
         if backend == "socket":
@@ -514,13 +594,13 @@ def main():
         else:
             comm = hash10x_amd.Comm.rccl(rank, world, rendezvous_unique_id(rank, world, hash10x_amd), local_rank)
     t_gen = time.perf_counter()
-    if comm is None:
+    if comm is None and wl.get("gen") != 2:
         recs = generate(wl, seed=1)                          # N = 1: the v1 set (the one the committed digests and profiles are of)
         total_pairs = recs.size // 30
     else:
-        # N > 1: every rank generates ONLY its shard (generator v2: counter-based streams, OpenMP) — barcodes whose records start in
-        # [P r / N, P (r + 1) / N)
-        recs, first_record, total_pairs = generate_v2(wl, 1, rank, world)
+        # N > 1 (and the generator-v2 workloads on one GPU): every rank generates ONLY its shard (generator v2: counter-based streams,
+        # OpenMP) — barcodes whose records start in [P r / N, P (r + 1) / N)
+        recs, first_record, total_pairs = generate_v2(wl, wl.get("seed", 1), rank if comm is not None else 0, world if comm is not None else 1)
     gen_s = time.perf_counter() - t_gen
     pairs = recs.size // 30
     d_recs = hash10x_amd.DeviceRecords(recs, device=local_rank)   # resident in HBM before the timed region
@@ -627,9 +707,9 @@ def main():
     out = {
         "metric": "read-pairs/s through --readFQB + --hashDepthRange + --cluster (mosh construction + per-barcode clustering)",
         "value": value, "unit": "read-pairs/s", "n_gpus": world, "steps": steps, "warmup": args.warmup,
-        "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": args.scaling if (world > 1 or wl.get("gen") == 2) else "weak", "vs_baseline": None,
         "dtype": "u64", "data": "synthetic",
-        "config": {"workload": args.workload + (" x%d" % world if world > 1 else ""), "read_pairs": total_pairs, "barcodes": wl["barcodes"], "B": wl["B"], "k": 21, "w": 31,
+        "config": {"workload": args.workload + (" x%d" % world if world > 1 and args.scaling == "weak" else ""), "read_pairs": total_pairs, "barcodes": wl["barcodes"], "B": wl["B"], "k": 21, "w": 31,
                    "hashDepthRange": [wl["lo"], wl["hi"]], "clusterThreshold": wl["ct"],
                    "parallelism": ("barcodes sharded over %d ranks, hash index by all-to-all (%s)" % (world, "RCCL over xGMI" if backend == "rccl" else
                                    "host-staged socket backend: ranks share a GPU, a functional run, not a performance figure")) if world > 1 else "single GPU"},
@@ -666,16 +746,34 @@ def main():
             cs = sharded_state_checksum(h, rank)
             ctr_entries_global = h.shard_info()["nEntriesGlobal"]
             man = json.load(open(os.path.join(REPO, "tests", "golden", "manifest.json")))
-            exp = man.get("bench_scale_digests", {}).get(str(world))
+            exp = man.get("strong_digests", {}).get(args.workload) if args.scaling == "strong" else man.get("bench_scale_digests", {}).get(str(world))
             out["state_checksum"] = ["0x%016x" % v for v in cs]
             if exp is None:
-                out["parity_vs_reference_digest"] = "no reference digest committed for x%d" % world
+                out["parity_vs_reference_digest"] = "no reference digest committed for %s" % (args.workload if args.scaling == "strong" else "x%d" % world)
             else:
                 same = [int(v, 16) for v in exp["checksum"]] == cs and exp["hash_number"] == sizes["hashNumber"] and exp["sum_nHash"] == ctr_entries_global
                 out["parity_vs_reference_digest"] = "identical" if same else "DIFFERENT (reference %s, H %d, hashNumber %d)" % (exp["checksum"], exp["sum_nHash"], exp["hash_number"])
         except Exception as e:
             out["parity_vs_reference_digest"] = "check failed: " + str(e)[:200]
-    if rank == 0 and world == 1 and not args.sharded and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.sharded and wl.get("gen") == 2:
+        # a generator-v2 workload on one GPU: the reference needs most of an hour for it — the parity gate is the digest of its .hash made in the
+        # build container (manifest "strong_digests"), checked through the same composable checksum the N-rank runs use
+        try:
+            blocks = h.export_slice(3, 1, sizes["nBlocks"] - 1)
+            cs = checksum_state(blocks, 1, np.zeros(0, dtype=np.uint8), 0)
+            for a in range(0, sizes["nClusHash"], 1 << 27):      # ClusterHash records 1 GB at a time
+                part = checksum_state(np.zeros(0, dtype=np.uint8), 0, h.export_slice(4, a, min(1 << 27, sizes["nClusHash"] - a)), a)
+                cs = [(cs[0] + part[0]) & 0xFFFFFFFFFFFFFFFF, (cs[1] + part[1]) & 0xFFFFFFFFFFFFFFFF]
+            exp = json.load(open(os.path.join(REPO, "tests", "golden", "manifest.json"))).get("strong_digests", {}).get(args.workload)
+            out["state_checksum"] = ["0x%016x" % v for v in cs]
+            if exp is None:
+                out["parity_vs_reference_digest"] = "no reference digest committed for %s" % args.workload
+            else:
+                same = [int(v, 16) for v in exp["checksum"]] == cs and exp["hash_number"] == sizes["hashNumber"] and exp["sum_nHash"] == sizes["nClusHash"]
+                out["parity_vs_reference_digest"] = "identical" if same else "DIFFERENT (reference %s, H %d, hashNumber %d)" % (exp["checksum"], exp["sum_nHash"], exp["hash_number"])
+        except Exception as e:
+            out["parity_vs_reference_digest"] = "check failed: " + str(e)[:200]
+    if rank == 0 and world == 1 and not args.sharded and not args.no_cpu_baseline and wl.get("gen") != 2:
         with tempfile.TemporaryDirectory() as d:
             gp = os.path.join(d, "gpu.hash")
             h.write_hash(gp)
@@ -704,6 +802,10 @@ def main():
             out["full_config3"] = full_config3_block(hash10x_amd, local_rank) if (os.cpu_count() or 1) >= 32 else {"skipped": "fewer than 32 host threads: generating 200 M pairs would take minutes"}
         except Exception as e:
             out["full_config3"] = {"error": str(e)[:300]}
+        try:                                                 # the 3 Gb strong-scaling workload on this one GPU (36 GB of records: generated in ~30 s on a GPU box's host)
+            out["genome3g"] = genome3g_block(hash10x_amd, local_rank) if (os.cpu_count() or 1) >= 32 else {"skipped": "fewer than 32 host threads: generating 300 M pairs would take minutes"}
+        except Exception as e:
+            out["genome3g"] = {"error": str(e)[:300]}
     if rank == 0:
         os.write(json_fd, (json.dumps(out) + "\n").encode())
     if comm is not None:

@@ -139,7 +139,7 @@ def device_count():
 
 
 def build_id():
-    """what libh10x_hip.so was built from: "<git describe or 'nogit'> src:<sha256 of its sources, 16 hex>" (embedded at build time)"""
+    """what libh10x_hip.so was built from: "src:<sha256 over its sources and compile flags, 16 hex>" (embedded at build time by csrc/Makefile)"""
     return load_native()[0].h10x_build_id().decode()
 
 
@@ -281,9 +281,19 @@ class Hash10x:
             raise Hash10xError(self._hip.h10x_last_error(self._ctx()).decode())
         if reserve:
             self._chk_ctx(self._hip.h10x_ingest_reserve(self._ctx(), int(reserve)))
+        fed, cut = 0, False                                  # -N n: the first n records, and then no end-of-file pass (hash10x.c:202-208), as read_fqb does it
         for part in chunks:
             r = np.ascontiguousarray(part, dtype=np.uint32).reshape(-1)
-            self._chk_ctx(self._hip.h10x_ingest_fqb(self._ctx(), r.ctypes.data, r.size // 30, 0))
+            take = r.size // 30
+            if N > 0 and fed + take >= N:
+                take, cut = N - fed, True
+            if take:
+                self._chk_ctx(self._hip.h10x_ingest_fqb(self._ctx(), r.ctypes.data, take, 0))
+            fed += take
+            if cut:
+                break
+        if self._hip.h10x_set_option(self._ctx(), b"chunk_eof_pass", 0 if cut else 1):
+            raise Hash10xError(self._hip.h10x_last_error(self._ctx()).decode())
         self._chk_ctx(self._hip.h10x_ingest_fqb(self._ctx(), None, 0, 1))
         self._chk(self._host.h10x_session_after_read(self._s))
         self._after_init()

@@ -234,6 +234,8 @@ struct Ctx {
   // sequence number into the mailbox, and the host spins on that number — a round trip of a few microseconds where a
   // device-to-host copy followed by hipStreamSynchronize cost 25-40 (the step makes eight of them, each with the GPU idle).
   // (prim.hip; a read-back that does not fit the mailbox is copied the ordinary way.)
+  // NOTE: the source is read when syncReadbacks() runs, not when readback() is called: it must stay valid and unmodified until then (a read-back
+  // that falls back to the ordinary copy captures it at the call instead — callers sync right behind their readback() calls, so both agree).
   static constexpr size_t MAIL_BYTES = 4096, MAIL_ITEMS = 12;
   unsigned char *mail = nullptr; size_t mailUsed = 0; u32 mailSeq = 0; bool mailDirect = false;
   struct PendingRead { void *dst; const void *dev; size_t off, n; };

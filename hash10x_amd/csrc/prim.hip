@@ -1,5 +1,6 @@
 // prim.hip — rocPRIM instantiations (device-wide radix sort, segmented sort, scans, reductions).
 #include "prim.hpp"
+#include <thread>
 #include <rocprim/rocprim.hpp>
 
 namespace h10x {
@@ -72,7 +73,11 @@ int Ctx::syncReadbacks() {
     e = hipGetLastError();
     for (u64 spins = 0; e == hipSuccess && __atomic_load_n(flag, __ATOMIC_ACQUIRE) != seq; ++spins) {
 #if !defined(__HIP_DEVICE_COMPILE__)
+#if defined(__x86_64__) || defined(__i386__)
       __builtin_ia32_pause();
+#else
+      std::this_thread::yield();
+#endif
 #endif
       if ((spins & 0xFFF) == 0xFFF) {                                           // every few microseconds: is the stream still alive?
         const hipError_t q = hipStreamQuery(stream);

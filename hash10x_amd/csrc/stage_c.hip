@@ -168,6 +168,7 @@ static int bitsForC(u64 maxValue) { int b = 1; while (b < 64 && (maxValue >> b))
 int stageC_depthRange(Ctx *c, int lo, int hi) {
   hipStream_t st = c->stream; PrimTemp pt;
   if (!c->haveState) return c->fail("no hash state loaded: use readFQB or readHash first");
+  c->haveGood = false;                                       // (a call that fails half-way must not leave the lists of an earlier one standing: rows[] and the offsets are replaced below)
   c->tstart(T_GOOD);
   const u32 U1 = c->hashNumber; const u32 nBlocks = c->nBlocks; const u64 H = c->nEntries;
   if (!(c->haveRange && lo == c->rangeMin && hi == c->rangeMax)) {       // hash10x.c:530
@@ -1991,10 +1992,14 @@ static int cluster_local_range(Ctx *c, int codeMin, int codeMax, int threshold, 
   // Both LDS classes are persistent launches that stay on the CUs they get: a whole-CU workgroup keeps two half-CU workgroups out. Where both have
   // enough blocks to fill the chip, the CUs are split by the classes' work (the whole-CU class does a list entry at ~0.8 x the rate per CU: measured
   // on the million-barcode set, where it used to finish 100 ms behind the main launch), so that the two launches end together.
-  if (firstMode == 4 && gridOf[2] == (u32)c->numCU && gridOf[0] >= (u32)c->numCU && hw[0] + hw[1]) {
+  if (firstMode == 4 && gridOf[2] && gridOf[0] >= (u32)c->numCU && hw[0] + hw[1]) {
     const double share2 = 1.25 * (double)hw[1] / (1.25 * (double)hw[1] + (double)hw[0]);
-    const u32 cu2 = hmin<u32>((u32)c->numCU - 1, hmax<u32>(1u, (u32)(share2 * c->numCU + 0.5)));
-    gridOf[2] = cu2; gridOf[0] = hmin<u32>(gridOf[0], 2 * ((u32)c->numCU - cu2));
+    // (+ 4 CUs: the blocks of that class are the ones with many ranks, which the work figure flatters; its CUs are not lost when it ends early —
+    // while it is the smaller side, the main launch brings two workgroups for EVERY CU, and those that find no room wait in the dispatcher
+    // for the whole-CU workgroups to leave: 3 Gb set, 2 169 such blocks: 657 ms on one CU behind a main launch of 510 ms before this)
+    const u32 cu2 = hmin<u32>((u32)c->numCU - 1, hmax<u32>(1u, (u32)(share2 * c->numCU + 0.5) + 4u));
+    gridOf[2] = hmin<u32>(hc[2], cu2);
+    gridOf[0] = hmin<u32>(gridOf[0], 2 * cu2 <= (u32)c->numCU ? 2 * (u32)c->numCU : 2 * ((u32)c->numCU - cu2));
   }
   DevBuf<u16> trSlots[3];                                  // translated placement: one handle slot per resident workgroup of each LDS class
   if (firstMode == 4) for (int k = 0; k < 3; k += 2) if (gridOf[k]) H10X_HIP(c, trSlots[k].alloc(trSlotU16 * gridOf[k]));

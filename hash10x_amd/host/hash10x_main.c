@@ -98,12 +98,19 @@ static void set_gpus(int n) {
     const char *want = getenv("H10X_COMM");
     const int canRccl = n <= nDev, wantRccl = want ? !strcmp(want, "rccl") : canRccl;
     if (want && strcmp(want, "rccl") && strcmp(want, "local")) die("H10X_COMM=%s: must be rccl or local", want);
+    int useLocal = !wantRccl;
     if (wantRccl) {
       char err[256] = "";
       if (!canRccl) die("H10X_COMM=rccl: %d ranks need %d devices, %d visible (RCCL refuses two ranks on one device)", n, n, nDev);
-      if (h10x_comm_create_rccl_all(team.comm, n, devs, err, (int)sizeof err)) die("%s", err);
-      teamBackend = "rccl";
-    } else {
+      if (!h10x_comm_create_rccl_all(team.comm, n, devs, err, (int)sizeof err)) teamBackend = "rccl";
+      else if (want) die("%s", err);                       /* RCCL was asked for by name: no silent substitute */
+      else {                                                /* the default picked it and it cannot start here: the in-process communicator does the same exchange */
+        fprintf(stderr, "hash10x-amd: RCCL did not start (%s): the %d ranks use the in-process communicator (peer copies) instead\n", err, n);
+        for (int r = 0; r < n; ++r) team.comm[r] = 0;
+        useLocal = 1;
+      }
+    }
+    if (useLocal) {
       h10x_device_enable_peers(devs, n);
       if (h10x_comm_create_local(team.comm, n)) die("h10x_comm_create_local failed");
       teamBackend = "local";

@@ -8,6 +8,11 @@ import numpy as np, bench, hash10x_amd
 man = json.load(open(os.path.join(R, "tests", "golden", "manifest.json")))["full_digest_cases"][0]
 g = man["gen2"]
 wl = dict(pairs=g["pairs"], barcodes=g["barcodes"], genome=g["genome"], err=g["err"], mol=g["mol"], snp=g["snp"], mol_len=g["mol_len"])
+LO, HI = 30, 100
+if os.environ.get("H10X_WL"):                                  # another generator-v2 workload of bench.py, e.g. genome3g-300M
+    w = bench.WORKLOADS[os.environ["H10X_WL"]]
+    wl = {k: w[k] for k in ("pairs", "barcodes", "genome", "err", "mol", "snp", "mol_len")}; g = dict(g, seed=w["seed"]); man = dict(man, B=w["B"], hash_number=0, blocks_max=0, sum_nHash=0)
+    LO, HI = w["lo"], w["hi"]
 passes = int(sys.argv[1]) if len(sys.argv) > 1 else 2
 stamps = len(sys.argv) > 2
 _stop = threading.Event()
@@ -26,7 +31,7 @@ for kv in filter(None, os.environ.get("H10X_OPTS", "").split(",")):
 for it in range(passes):
     hash10x_amd.synchronize(0)
     t0 = time.time(); h.read_fqb_device(dr.ptr, dr.n_records); hash10x_amd.synchronize(0); t1 = time.time()
-    h.depth_range(30, 100); hash10x_amd.synchronize(0); t2 = time.time(); h.cluster(1, 0, 5); hash10x_amd.synchronize(0); t3 = time.time()
+    h.depth_range(LO, HI); hash10x_amd.synchronize(0); t2 = time.time(); h.cluster(1, 0, 5); hash10x_amd.synchronize(0); t3 = time.time()
     print("pass %d wall s: readFQB %.3f hashDepthRange %.3f cluster %.3f -> %.1f M read pairs/s" % (it, t1 - t0, t2 - t1, t3 - t2, wl["pairs"] / (t3 - t0) / 1e6), flush=True)
     tm = h.timings(); c = h.counters()
     print("   device ms", {k: round(v[0], 1) for k, v in tm.items() if v[0] > 0}, flush=True)

@@ -234,6 +234,26 @@ def test_die_conditions_match_reference_text(workdir):
         hash10x_amd.Hash10x(B=20).read_fqb(big)       # > 2^18 - 2 distinct hashes (hash10x.c:149)
 
 
+@pytest.mark.skipif(not orc.have_ref(), reason="oracle/_ref not present")
+def test_sharded_table_too_small_dies_like_the_reference(workdir):
+    """BASELINE configs[3] as written (1.2 B pairs at -B 30) holds more distinct hashes than 2^28 - 2: the reference dies with
+    "hashTableSize is too small" (hash10x.c:149). A proportional small set — 200 k pairs, 2 % errors, -B 20: 2^18 - 2 hashes allowed —
+    must die the same way when the barcodes are sharded: the distinct hashes are only counted after the owners' exchange
+    (shard.hip), on every rank; the C program prints the reference's message and leaves with its exit code under --gpus 2 / 3."""
+    import subprocess
+    import hash10x_amd
+    recs = orc.gen_fqb(workdir.file("x.fqb"), 200000, 100, 3000000, 0.02, 5, 10.0, 150, 50000)
+    r = orc.run_ref(["-B", 20, "--readFQB", "x.fqb"], workdir.path)
+    assert r.returncode != 0 and b"FATAL ERROR: hashTableSize is too small" in r.stderr
+    for nranks in (2, 3):
+        with pytest.raises(hash10x_amd.Hash10xError, match="hashTableSize is too small"):
+            _run_sharded(recs, nranks, 20, 3, 30, 3, workdir.file("never.hash"))
+        g = subprocess.run([os.path.join(orc.REPO, "bin", "hash10x-amd"), "--gpus", str(nranks), "-B", "20", "--readFQB", "x.fqb"], cwd=workdir.path,
+                           stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=dict(os.environ, H10X_COMM="local"))
+        assert g.returncode == (r.returncode & 0xFF) == 255 and b"FATAL ERROR: hashTableSize is too small" in g.stderr, g.stderr.decode()
+    assert not os.path.exists(workdir.file("never.hash"))
+
+
 def test_context_reuse_is_deterministic(workdir):
     """The C session keeps one device context (stream + recycled device blocks) across --readFQB calls with
     unchanged parameters; every pass must give the same bytes as the first and as the oracle. (A stream-ordered
