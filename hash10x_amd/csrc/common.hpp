@@ -171,6 +171,7 @@ struct Ctx {
   DevBuf<u32> nGood;          // nBlocks
   DevBuf<u64> goodRow;        // H : per good hash of a block, in rank order: (offset of its barcode list in rows[] >> rowShift, its length) — stage_c.hip good_rows_kernel
   DevBuf<u32> goodEntries;    // nBlocks : sum of the depths of a block's good hashes = entries of its barcode lists
+  DevBuf<u32> clusterRaw;     // 2 x nBlocks, after --cluster: clusters before the read merge (bit 31: given up), good hashes labelled — the --verbose figures of codeClusterFind
   bool haveRange = false, haveGood = false; int rangeMin = 0, rangeMax = 0;
   u32 rangeHiMax = 0;             // largest upper limit of the ranges set so far: an in-range depth is below it
   u32 depthBound = 0xFFFFFFFFu;   // no hashDepth[] value exceeds this: barcodes of the data set after --readFQB, the largest value read after --readHash

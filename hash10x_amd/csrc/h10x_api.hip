@@ -553,6 +553,7 @@ int h10x_export_slice(h10x_ctx *h, int table, uint64_t first, uint64_t count, vo
     case H10X_TABLE_HASHDEPTH: src = c.hashDepth.p; eb = 4; limit = c.hashNumber; break;
     case H10X_TABLE_BLOCKS:    src = c.blocks.p; eb = sizeof(h10x_block); limit = c.nBlocks; break;
     case H10X_TABLE_CLUSHASH:  src = c.clusHash.p; eb = sizeof(h10x_clushash); limit = c.nEntries; break;
+    case H10X_TABLE_CLUSTER_RAW: if (!c.clusterRaw.p || c.clusterRaw.n != 2 * (size_t)c.nBlocks) return c.fail("no --cluster has run on these blocks"); src = c.clusterRaw.p; eb = 8; limit = c.nBlocks; break;
     case H10X_TABLE_NGOOD:     if (!c.haveGood) return c.fail("!! you must set hashDepthRange before clusterReport"); src = c.nGood.p; eb = 4; limit = c.nBlocks; break;
     default: return c.fail("h10x_export_slice: unknown table %d", table);
   }

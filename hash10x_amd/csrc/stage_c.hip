@@ -43,9 +43,6 @@ constexpr u32 NOHANDLE = 0xFFFFFFFFu;                        // FirstDense/Ranke
 #ifndef H10X_BATCH
 #define H10X_BATCH 0          // 1: the results of a round's lists are parked in lanes and stored once per round
 #endif
-#ifndef H10X_REPLAY_WAVE
-#define H10X_REPLAY_WAVE 0    // 1: replay with one wave per barcode (no workgroup barriers) for the common sizes
-#endif
 constexpr int ROWS_IN_FLIGHT = H10X_RIF;                          // barcode lists a wavefront keeps in flight
 constexpr int RCHUNK = 4;                                   // register chunks: lists up to 256 entries
 
@@ -1566,6 +1563,8 @@ struct ReplayArgs {
   u32 codeMin, span, nLo, nHi;                               // blocks [codeMin, codeMin + span) with nLo < nGood <= nHi ...
   const u32 *list;                                           // ... or, if not null, the `span` blocks of this list (the few large ones: no workgroup per barcode of the range)
   unsigned char *scratch; size_t scratchStride;              // IN_LDS = false: working set per workgroup
+  u32 *raw;                                                  // out, two words per block: clusters before the read merge (bit 31: given up at the 256th), good hashes with a label —
+                                                             // what the reference's --verbose line of codeClusterFind says (hash10x.c:827-834)
 };
 #define SYNC() do { __syncthreads(); if (!IN_LDS) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); } while (0)
 template <bool IN_LDS, int THREADS>
@@ -1583,6 +1582,7 @@ void replay_kernel(ReplayArgs a) {
     const size_t col = ((size_t)n * 2 + 15) & ~(size_t)15;
     u16 *bst = (u16 *)region, *ptr = (u16 *)(region + col), *ft = (u16 *)(region + 2 * col), *fl = (u16 *)(region + 3 * col);
     SYNC();                                                  // the previous block of this workgroup is done with the region
+    if (tid == 0) sh[2] = 0;
     for (u32 i = tid; i < n; i += THREADS) {
       const u16 m = (u16)(a.res[o + i] & 0xFFFFu);
       bst[i] = m; ptr[i] = m != NONE16 ? m : (u16)i; ft[i] = NONE16; fl[i] = 0;
@@ -1628,15 +1628,20 @@ void replay_kernel(ReplayArgs a) {
       __syncthreads();
       stop = sh[1];                                            // the terms of the turns before it stay in pointToMin
       for (u32 i = tid; i < n; i += THREADS) ch[g[i]].subCluster = 0;
-      if (tid == 0) a.blocks[c].nSubCluster = 0;
+      if (tid == 0) { a.blocks[c].nSubCluster = 0; a.raw[2 * (size_t)c] = 0x80000000u; a.raw[2 * (size_t)c + 1] = 0; }   // (nSubClustered is reset with the labels: hash10x.c:811)
     } else {
+      u32 labelled = 0;
       for (u32 i = tid; i < n; i += THREADS) {
         u32 L = 0;
         if (ld_shared<IN_LDS>(&bst[i]) != NONE16) { const u32 rt = ld_shared<IN_LDS>(&ptr[i]); const u32 t = rt < n ? (u32)ld_shared<IN_LDS>(&ft[rt]) : NONE16; L = t != NONE16 ? (u32)ld_shared<IN_LDS>(&fl[t]) : 0u; }
         else { const u32 t = ld_shared<IN_LDS>(&ft[i]); if (t != NONE16) L = ld_shared<IN_LDS>(&fl[t]); }
         ch[g[i]].subCluster = (u8)L;                         // includes the wipe of hash10x.c:783
+        labelled += L != 0;
       }
-      if (tid == 0) a.blocks[c].nSubCluster = nRoots;
+      for (int sft = 32; sft; sft >>= 1) labelled += (u32)__shfl_down((int)labelled, sft);
+      if (lane == 0 && labelled) atomicAdd(&sh[2], labelled);
+      __syncthreads();
+      if (tid == 0) { a.blocks[c].nSubCluster = nRoots; a.raw[2 * (size_t)c] = nRoots; a.raw[2 * (size_t)c + 1] = sh[2]; }
     }
     // the ranks' pointToMin terms (hash10x.c:821): one IEEE double divide per active rank, written over its result word
     double *term = (double *)(a.res + o);
@@ -1648,83 +1653,6 @@ void replay_kernel(ReplayArgs a) {
   }
 }
 #undef SYNC
-// The same for the common sizes with one WAVE per barcode: the passes above are a dozen short steps with a barrier between them, which
-// a 256-lane workgroup per barcode spends almost entirely waiting (0.25 ms for the 10 000 barcodes of the yeast-scale set); a wave runs
-// them back to back — LDS operations of a wave complete in order, so no barrier is needed at all — and 8192 waves work side by side.
-constexpr int REPLAY_WAVES = 4;                              // barcodes per workgroup
-__global__ __launch_bounds__(REPLAY_WAVES * WAVE)
-void replay_wave_kernel(ReplayArgs a, u32 sliceBytes) {
-  extern __shared__ __align__(16) unsigned char smem[];
-  const int lane = threadIdx.x & (WAVE - 1), wave = threadIdx.x / WAVE;
-  const u32 wi = blockIdx.x * REPLAY_WAVES + wave;
-  if (wi >= a.span) return;
-  const u32 c = a.codeMin + wi;
-  const u32 n = a.nGood[c];
-  if (n == 0 || n <= a.nLo || n > a.nHi) return;             // wave-uniform
-  const u64 o = a.blockOff[c];
-  unsigned char *region = smem + (size_t)wave * sliceBytes;
-  const size_t col = ((size_t)n * 2 + 15) & ~(size_t)15;
-  u16 *bst = (u16 *)region, *ptr = (u16 *)(region + col), *ft = (u16 *)(region + 2 * col), *fl = (u16 *)(region + 3 * col);
-#define WSYNC() __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront")
-  for (u32 i = lane; i < n; i += WAVE) {
-    const u16 m = (u16)(a.res[o + i] & 0xFFFFu);
-    bst[i] = m; ptr[i] = m != NONE16 ? m : (u16)i; ft[i] = NONE16; fl[i] = 0;
-  }
-  WSYNC();
-  for (u32 i = lane; i < n; i += WAVE) {
-    const u32 b = bst[i];
-    if (b != NONE16 && b < n && bst[b] == NONE16) min_u16<true>(ft, b, i);   // b inactive: i's turn may be its founding turn
-  }
-  WSYNC();
-  for (u32 r = 0; r < 20; ++r) {                             // chains only run downwards and are short: until no pointer moves
-    bool moved = false;
-    for (u32 i = lane; i < n; i += WAVE) {
-      const u32 p = ptr[i];
-      if (p < n) { const u32 pp = *(volatile u16 *)&ptr[p]; if (pp != p) { ptr[i] = (u16)pp; moved = true; } }
-    }
-    WSYNC();
-    if (!__ballot(moved)) break;
-  }
-  for (u32 i = lane; i < n; i += WAVE) { const u32 t = ft[i]; if (t != NONE16) fl[t] = 1; }   // founding turns are distinct
-  WSYNC();
-  // inclusive scan of fl[0..n): a lane takes a contiguous piece, the pieces' totals are scanned across the wave
-  const u32 ipt = (n + WAVE - 1) / WAVE, s0 = (u32)lane * ipt < n ? (u32)lane * ipt : n, s1 = s0 + ipt < n ? s0 + ipt : n;
-  u32 mine = 0;
-  for (u32 i = s0; i < s1; ++i) mine += fl[i];
-  u32 inc = mine;
-#pragma unroll
-  for (int d = 1; d < WAVE; d <<= 1) { const u32 o2 = (u32)__shfl_up((int)inc, d); if (lane >= d) inc += o2; }
-  u32 run = inc - mine;
-  for (u32 i = s0; i < s1; ++i) { run += fl[i]; fl[i] = (u16)run; }
-  WSYNC();
-  const u32 nRoots = fl[n - 1];
-  u32 stop = n;
-  h10x_clushash *ch = a.clusHash + o; const u16 *g = a.goodPos + o;
-  if (nRoots > 255) {                                        // hash10x.c:810-816: abandon at the 256th founding turn
-    u32 st = 0xFFFFFFFFu;
-    for (u32 i = lane; i < n; i += WAVE) if (fl[i] == 256 && (i == 0 || fl[i - 1] == 255)) st = i;
-#pragma unroll
-    for (int sft = 32; sft; sft >>= 1) { const u32 o2 = (u32)__shfl_xor((int)st, sft); st = o2 < st ? o2 : st; }
-    stop = st;                                               // the terms of the turns before it stay in pointToMin
-    for (u32 i = lane; i < n; i += WAVE) ch[g[i]].subCluster = 0;
-    if (lane == 0) a.blocks[c].nSubCluster = 0;
-  } else {
-    for (u32 i = lane; i < n; i += WAVE) {
-      u32 L = 0;
-      if (bst[i] != NONE16) { const u32 rt = ptr[i]; const u32 t = rt < n ? (u32)ft[rt] : NONE16; L = t != NONE16 ? (u32)fl[t] : 0u; }
-      else { const u32 t = ft[i]; if (t != NONE16) L = fl[t]; }
-      ch[g[i]].subCluster = (u8)L;                           // includes the wipe of hash10x.c:783
-    }
-    if (lane == 0) a.blocks[c].nSubCluster = nRoots;
-  }
-  double *term = (double *)(a.res + o);                      // hash10x.c:821: one IEEE double divide per active rank, over its result word
-  for (u32 i = lane; i < n; i += WAVE) {
-    const u64 r = a.res[o + i];
-    const bool has = i >= 1 && i < stop && (u32)(r & 0xFFFFu) != NONE16;
-    term[i] = has ? (double)(int)(u32)((r >> 16) & 0xFFFFFFu) / (double)(int)(u32)(r >> 40) : 0.0;
-  }
-#undef WSYNC
-}
 __host__ __device__ inline size_t replayBytes(u32 n) { return 4 * (((size_t)n * 2 + 15) & ~(size_t)15) + 16; }
 constexpr u32 REPLAY_SMALL = 2040, REPLAY_MID = 16376;       // rank counts up to which a block's replay runs in 16 KB / 128 KB of LDS
 
@@ -2100,7 +2028,9 @@ static int cluster_local_range(Ctx *c, int codeMin, int codeMax, int threshold, 
   // (c) labels, cluster counts and the > 255 clusters cut from the msBest column: one workgroup per barcode, classes by rank count
   DevBuf<unsigned char> replayScratch;
   {
-    ReplayArgs ra{}; ra.blocks = c->blocks.p; ra.blockOff = c->blockOff.p; ra.clusHash = c->clusHash.p; ra.goodPos = c->goodPos.p; ra.nGood = c->nGood.p;
+    if (c->clusterRaw.n != 2 * (size_t)c->nBlocks) { H10X_HIP(c, c->clusterRaw.alloc(2 * (size_t)c->nBlocks)); H10X_HIP(c, hipMemsetAsync(c->clusterRaw.p, 0, 8 * (size_t)c->nBlocks, st)); }
+    H10X_HIP(c, hipMemsetAsync(c->clusterRaw.p + 2 * (size_t)codeMin, 0, 8 * (size_t)span, st));   // blocks without good hashes say nothing
+    ReplayArgs ra{}; ra.raw = c->clusterRaw.p; ra.blocks = c->blocks.p; ra.blockOff = c->blockOff.p; ra.clusHash = c->clusHash.p; ra.goodPos = c->goodPos.p; ra.nGood = c->nGood.p;
     ra.res = term.p; ra.codeMin = (u32)codeMin; ra.span = span;
     // the barcodes with more ranks than the common class holds (hc[9] of them, listed by the classification): workgroups for those only,
     // on a side stream beside the common class (disjoint blocks)
@@ -2112,17 +2042,8 @@ static int cluster_local_range(Ctx *c, int codeMin, int codeMax, int threshold, 
       rb.nLo = REPLAY_SMALL; rb.nHi = REPLAY_MID;
       replay_kernel<true, 1024><<<hc[9], 1024, lds, c->aux[0]>>>(rb);
     }
-#if H10X_REPLAY_WAVE
-    ra.nLo = 0; ra.nHi = hmin<u32>(REPLAY_SMALL, hmax<u32>(c->maxGood, 1));   // (the slice is sized by the launch's largest barcode: more waves per CU on small sets)
-    {
-      const u32 slice = (u32)replayBytes(ra.nHi);
-      H10X_HIP(c, hipFuncSetAttribute((const void *)replay_wave_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(REPLAY_WAVES * slice)));
-      replay_wave_kernel<<<divUp(span, REPLAY_WAVES), REPLAY_WAVES * WAVE, (size_t)REPLAY_WAVES * slice, st>>>(ra, slice);
-    }
-#else
     ra.nLo = 0; ra.nHi = REPLAY_SMALL;
     replay_kernel<true, 256><<<span, 256, replayBytes(hmin<u32>(REPLAY_SMALL, hmax<u32>(c->maxGood, 1))), st>>>(ra);
-#endif
     ra.list = listBig.p; ra.span = hc[9];
     if (hc[9]) H10X_TRY(c->joinStreams(1));
     if (hc[9] && c->maxGood > REPLAY_MID) {

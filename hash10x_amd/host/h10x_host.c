@@ -748,6 +748,88 @@ static int report_block_lines(const h10x_session *s, Text *t, uint32_t code, con
    reference's double sum is order dependent). out = NULL on the other ranks. */
 typedef struct { uint32_t first, count; uint64_t textBytes; } RunHead;
 static RunHead run_head(const char *p) { RunHead h; memcpy(&h, p, sizeof h); return h; }   /* packages sit at any byte offset */
+/* The per-barcode lines of the reference's --verbose --cluster (hash10x.c:827-834 codeClusterFind, :867 codeClusterReadMerge) for the blocks
+   [codeMin, codeMax) just clustered, and its "too many clusters" notes (hash10x.c:813-814, printed whether verbose or not): from the blocks, the
+   good-hash counts and the two figures per block the replay kernel left (H10X_TABLE_CLUSTER_RAW). Sharded: every rank formats its own blocks,
+   rank 0 prints the runs by first block. out / err may be null (nothing printed there). */
+int h10x_session_clusterVerbose(h10x_session *s, int codeMin, int codeMax, FILE *out, FILE *err) {
+  if (!s->ctx) return fail(s, "no hash state loaded: use readFQB or readHash first");
+  h10x_shard_info_t z; if (h10x_shard_info(s->ctx, &z)) return fail_ctx(s);
+  if (!codeMin) codeMin = 1;                                                          /* hash10x.c:1243-1244 */
+  if (!codeMax) codeMax = (int)z.nBlocksGlobal;
+  enum { RUN = 65536 };
+  uint64_t wantLines = out != 0;                                                      /* (rank 0 holds the stream: every rank must format if it prints) */
+  if (h10x_shard_allreduce_max_u64(s->ctx, &wantLines, 1)) return fail_ctx(s);
+  int rc = 0; Text pack[2] = {{0, 0, 0}, {0, 0, 0}}, lines[2] = {{0, 0, 0}, {0, 0, 0}};
+  h10x_shard_seg *segs = (h10x_shard_seg *)calloc((size_t)z.nSegs + 1, sizeof *segs);
+  h10x_block *blocks = (h10x_block *)malloc((size_t)RUN * sizeof *blocks);
+  uint32_t *good = (uint32_t *)malloc((size_t)RUN * 4), *raw = (uint32_t *)malloc((size_t)RUN * 8);
+  if (!segs || !blocks || !good || !raw) { rc = fail(s, "out of host memory for the verbose lines"); goto done; }
+  if (h10x_shard_segments(s->ctx, segs, z.nSegs + 1)) { rc = fail_ctx(s); goto done; }
+  for (uint32_t i = 0; i < z.nSegs && !rc; ++i) {
+    if ((int)segs[i].rank != z.rank) continue;
+    int64_t g0 = segs[i].globalBase, g1 = (int64_t)segs[i].globalBase + segs[i].count;
+    if (g0 < codeMin) g0 = codeMin;
+    if (g1 > codeMax) g1 = codeMax;
+    for (int64_t g = g0; g < g1 && !rc; g += RUN) {
+      const uint32_t n = (uint32_t)(g1 - g < RUN ? g1 - g : RUN), local = segs[i].localStart + (uint32_t)(g - segs[i].globalBase);
+      if (h10x_export_slice(s->ctx, H10X_TABLE_CLUSTER_RAW, local, n, raw)) { rc = fail_ctx(s); break; }
+      if (!wantLines) {                                                               /* not verbose: only the notes, i.e. only runs with a block that was given up (8 bytes per block looked at) */
+        int any = 0; for (uint32_t b = 0; b < n && !any; ++b) any = raw[2 * b] >> 31;
+        if (!any) continue;
+      }
+      if (h10x_export_slice(s->ctx, H10X_TABLE_BLOCKS, local, n, blocks) || h10x_export_slice(s->ctx, H10X_TABLE_NGOOD, local, n, good)) { rc = fail_ctx(s); break; }
+      lines[0].n = lines[1].n = 0;
+      for (uint32_t b = 0; b < n && !rc; ++b) {
+        const int code = (int)(g + b); const h10x_block *k = &blocks[b];
+        if (!good[b]) {                                                               /* codeClusterFind returns at once; codeClusterReadMerge still speaks if labels of an earlier clustering stand */
+          if (k->nSubCluster && text_printf(&lines[0], " then %d merged clusters\n", (int)k->nSubCluster)) rc = -1;
+          continue;
+        }
+        const uint32_t rawN = raw[2 * b] & 0x7FFFFFFFu;
+        if (raw[2 * b] >> 31) { if (text_printf(&lines[1], "    code %d with %d good hashes has too many clusters\n", code, (int)good[b])) rc = -1; }
+        if (rawN) { if (text_printf(&lines[0], "  code %d with %d reads %d hashes, %d good hashes, of which %d cluster into %d raw then %d merged clusters\n",
+                                    code, (int)k->nRead, (int)k->nHash, (int)good[b], (int)raw[2 * b + 1], (int)rawN, (int)k->nSubCluster)) rc = -1; }
+        else if (text_printf(&lines[0], "  code %d with %d reads %d hashes, %d good hashes, 0 clusters\n", code, (int)k->nRead, (int)k->nHash, (int)good[b])) rc = -1;
+      }
+      if (rc) { rc = fail(s, "out of host memory for the verbose lines"); break; }
+      for (int w = 0; w < 2; ++w) {
+        const RunHead h = {(uint32_t)g, n, lines[w].n};
+        if (text_bytes(&pack[w], &h, sizeof h) || text_bytes(&pack[w], lines[w].p, lines[w].n)) { rc = fail(s, "out of host memory for the verbose lines"); break; }
+      }
+    }
+  }
+  for (int w = 0; w < 2; ++w) {                                                       /* to rank 0, in any order; printed by first block */
+    uint64_t bad = rc ? 1 : 0, total = pack[w].n;
+    if (h10x_shard_allreduce_max_u64(s->ctx, &bad, 1) || h10x_shard_allreduce_sum_u64(s->ctx, &total, 1)) { rc = fail_ctx(s); goto done; }
+    if (bad) { if (!rc) rc = fail(s, "the verbose lines failed on another rank"); goto done; }
+    char *all = z.rank == 0 ? (char *)malloc(total + 1) : 0; uint64_t *counts = (uint64_t *)calloc((size_t)z.nranks, 8);
+    if ((z.rank == 0 && !all) || !counts) { free(all); free(counts); rc = fail(s, "out of host memory for the verbose lines"); goto done; }
+    if (h10x_shard_gather_bytes(s->ctx, pack[w].p, pack[w].n, all, total, counts)) { free(all); free(counts); rc = fail_ctx(s); goto done; }
+    FILE *to = w ? err : out;
+    if (z.rank == 0 && to) {
+      size_t nRuns = 0, capRuns = 64; const char **runs = (const char **)malloc(capRuns * sizeof *runs);
+      for (uint64_t o = 0; o < total; ) {
+        const RunHead h = run_head(all + o);
+        if (nRuns == capRuns) { capRuns *= 2; runs = (const char **)realloc(runs, capRuns * sizeof *runs); }
+        runs[nRuns++] = all + o;
+        o += sizeof h + h.textBytes;
+      }
+      for (size_t a = 1; a < nRuns; ++a) {                                           /* few runs: insertion sort by first block */
+        const char *r = runs[a]; size_t b = a;
+        while (b > 0 && run_head(runs[b - 1]).first > run_head(r).first) { runs[b] = runs[b - 1]; --b; }
+        runs[b] = r;
+      }
+      for (size_t a = 0; a < nRuns; ++a) { const RunHead h = run_head(runs[a]); fwrite(runs[a] + sizeof h, 1, h.textBytes, to); }
+      free(runs);
+    }
+    free(all); free(counts);
+  }
+done:
+  free(segs); free(blocks); free(good); free(raw); free(pack[0].p); free(pack[1].p); free(lines[0].p); free(lines[1].p);
+  return rc;
+}
+
 int h10x_session_clusterReport(h10x_session *s, int codeMin, int codeMax, FILE *out) {
   if (!s->ctx) return fail(s, "no hash state loaded: use readFQB or readHash first");
   h10x_shard_info_t z; if (h10x_shard_info(s->ctx, &z)) return fail_ctx(s);

@@ -50,6 +50,9 @@ int  h10x_session_codeStats(h10x_session *s, FILE *f);
    (h10x_cluster_report); out = NULL: take part without printing (ranks > 0 of a sharded session). */
 int  h10x_session_cribBuild(h10x_session *s, const char *fa1, const char *fa2, FILE *out, int printTables);
 int  h10x_session_clusterReport(h10x_session *s, int codeMin, int codeMax, FILE *out);
+/* after h10x_session_cluster(codeMin, codeMax): the reference's --verbose lines of those blocks (hash10x.c:827-834, 867) to out, its "too many clusters" notes
+   (hash10x.c:813) to err; either may be null. Collective when sharded (rank 0 prints). */
+int  h10x_session_clusterVerbose(h10x_session *s, int codeMin, int codeMax, FILE *out, FILE *err);
 int  h10x_session_cribSummary(h10x_session *s, FILE *out);
 
 /* --sortFQB <in.fqb> <out.fqb> (addition): the record sort the reference leaves to `bsort -k 4 -r 120` (README.md:26),

@@ -213,10 +213,14 @@ static int soft_or_die(int bad) {
   fprintf(outFile, "%s\n", e); if (outFile != stdout) fprintf(stderr, "%s\n", e);
   return 1;
 }
+static int isVerbose = 0;                                                             /* --verbose (hash10x.c:1180): the per-barcode lines of --cluster */
 static int rank_cluster(h10x_session *s, int r, void *a) { (void)r; const int *v = (const int *)a; return h10x_session_cluster(s, v[0], v[1]); }
+static int rank_verbose(h10x_session *s, int r, void *a) { const int *v = (const int *)a; return h10x_session_clusterVerbose(s, v[0], v[1], r == 0 && isVerbose ? outFile : 0, r == 0 ? stderr : 0); }
+static void cmd_verbose(char **a) { (void)a; isVerbose = 1; }
 static void cmd_cluster(char **a) {
   int v[2] = {atoi(a[0]), atoi(a[1])};
   if (soft_or_die(on_all_ranks(rank_cluster, v))) return;
+  { const int bad = on_all_ranks(rank_verbose, v); if (bad) die_of(bad); }             /* the "too many clusters" notes go to stderr with or without --verbose */
   say("  clustered codes %d to %d\n", v[0] ? v[0] : 1, v[1] ? v[1] : (int)sizes_now().nBlocksGlobal);
 }
 static int rank_split(h10x_session *s, int r, void *a) { (void)r; (void)a; return h10x_session_clusterSplit(s); }
@@ -238,7 +242,6 @@ static void cmd_output(char **a) {
 }
 static void cmd_threads(char **a) { (void)a; fprintf(stderr, "  can't set thread number - clustering runs on the GPU\n"); }
 static void cmd_tables(char **a) { (void)a; printTables = !printTables; }                 /* hash10x.c:1198 */
-static void cmd_nothing(char **a) { (void)a; }
 static void cmd_help(char **a) { (void)a; usage(); }
 static void cmd_gpus(char **a) { set_gpus(atoi(a[0])); fprintf(outFile, "  %d rank(s), communicator: %s\n", team.n, team.n > 1 ? teamBackend : "none (one GPU)"); }
 static void cmd_device(char **a) {
@@ -252,7 +255,7 @@ static const Command commands[] = {
   {"-ct", 1, 0, "ct"}, {"--clusterThreshold", 1, 0, "ct"},
   {"--device", 1, cmd_device, 0}, {"--gpus", 1, cmd_gpus, 0},
   {"-t", 1, cmd_threads, 0}, {"--threads", 1, cmd_threads, 0}, {"-o", 1, cmd_output, 0}, {"--output", 1, cmd_output, 0},
-  {"--tables", 0, cmd_tables, 0}, {"--verbose", 0, cmd_nothing, 0},                      /* --verbose: accepted, no per-barcode text on the device path */
+  {"--tables", 0, cmd_tables, 0}, {"--verbose", 0, cmd_verbose, 0},
   {"--readFQB", 1, cmd_readFQB, 0}, {"--readHash", 1, cmd_readHash, 0}, {"--writeHash", 1, cmd_writeHash, 0},
   {"--hashDepthRange", 2, cmd_hashDepthRange, 0}, {"--cluster", 2, cmd_cluster, 0}, {"--clusterSplit", 0, cmd_clusterSplit, 0},
   {"--sortFQB", 2, cmd_sortFQB, 0}, {"--cribBuild", 2, cmd_cribBuild, 0}, {"--clusterReport", 2, cmd_clusterReport, 0},

@@ -217,7 +217,9 @@ typedef struct {
   uint64_t nEntriesGlobal, nRecordsGlobal;
 } h10x_shard_info_t;
 enum { H10X_TABLE_HASHINDEX = 0, H10X_TABLE_HASHVALUE = 1, H10X_TABLE_HASHDEPTH = 2, H10X_TABLE_BLOCKS = 3, H10X_TABLE_CLUSHASH = 4,
-       H10X_TABLE_NGOOD = 5 };
+       H10X_TABLE_NGOOD = 5,
+       H10X_TABLE_CLUSTER_RAW = 6 /* per block, after h10x_cluster: u32 clusters before the read merge (bit 31: given up at the 256th, hash10x.c:810-816),
+                                     u32 good hashes with a label — the figures of the reference's --verbose line (hash10x.c:827-834) */ };
 int  h10x_shard_info(h10x_ctx *ctx, h10x_shard_info_t *out);
 int  h10x_shard_segments(h10x_ctx *ctx, h10x_shard_seg *out, uint32_t cap);
 int  h10x_shard_prepare_export(h10x_ctx *ctx);

@@ -12,7 +12,7 @@ KEEP = ("HASH_COUNT_", "CODE_SIZE_", "CODE_CLUSTER_", "  crib matches", "    hom
 
 def report(txt):
     return [ln for ln in txt.decode(errors="replace").splitlines()
-            if ln.startswith(KEEP) or " base codes " in ln or " cluster codes " in ln or " in crib genome" in ln]
+            if ln.startswith(KEEP) or ln.startswith("  code ") or ln.startswith(" then ") or " base codes " in ln or " cluster codes " in ln or " in crib genome" in ln]
 
 
 def run(n_cases, seed, verbose=False):
@@ -27,7 +27,7 @@ def run(n_cases, seed, verbose=False):
         lo = rng.choice([2, 3, 4]); hi = lo + rng.choice([3, 10, 30, 100]); ct = rng.choice([1, 2, 3, 5])
         B = 23 if w < 13 else 21
         gpus = rng.choice([1, 1, 2, 3, 4])                    # > 1: the sharded form of every command (ranks share the one GPU of the test box)
-        args = ["-k", k, "-w", w, "-r", r, "-B", B, "-ct", ct, "--readFQB", "x.fqb"]
+        args = ["-k", k, "-w", w, "-r", r, "-B", B, "-ct", ct] + (["--verbose"] if rng.random() < 0.4 else []) + ["--readFQB", "x.fqb"]   # --verbose: the per-barcode lines of --cluster
         if rng.random() < 0.5: args += ["--hashStats"]
         args += ["--hashDepthRange", lo, hi, "--cluster", 1, 0]
         if rng.random() < 0.5: args += ["--codeStats"]

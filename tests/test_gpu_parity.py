@@ -526,6 +526,69 @@ def test_cli_matches_reference_commands_and_reports(workdir):
     assert bad.returncode == 255 and b"FATAL ERROR: hashTableBits 19 out of range 20-30" in bad.stderr
 
 
+def _hash_v2_to_v1(data):
+    """A version-1 .hash from a version-2 one: the same bytes, but hashValue[] is stored as an Array (ArrayStruct header, dim = max = hashNumber,
+    size 8: hash10x.c:286-292, array.c:213-218) instead of a count + the values."""
+    import struct
+    B = struct.unpack_from("<i", data, 12)[0]
+    at = 16 + (4 << B)
+    n = struct.unpack_from("<I", data, at)[0]
+    head = struct.pack("<iiQiiii", 8918274, 0, 0, n, 8, n, 0)                 # magic, pad, base pointer, dim, size, max, pad (array.h:41-50)
+    return data[:4] + struct.pack("<I", 1) + data[8:at] + head + data[at + 4:]
+
+
+@pytest.mark.skipif(not orc.have_ref(), reason="oracle/_ref not present")
+def test_cli_reads_a_version_1_hash_file(workdir):
+    """readHashFile accepts version 1 files, which store hashValue[] as an Array (hash10x.c:286-292): a v1 file made from the small golden .hash
+    goes through --readHash --hashDepthRange --cluster --writeHash of bin/hash10x-amd and of the reference binary with the same bytes out (always v2)."""
+    import subprocess
+    v2 = orc.read_maybe_gz(os.path.join(orc.GOLDEN, "small.hash.gz"))
+    with open(workdir.file("v1.hash"), "wb") as f:
+        f.write(_hash_v2_to_v1(v2))
+    args = ["-B", "20", "-ct", "2", "--readHash", "v1.hash", "--hashDepthRange", "3", "14", "--cluster", "1", "0", "--writeHash", "OUT"]
+    r = orc.run_ref([a if a != "OUT" else "ref.hash" for a in args], workdir.path)
+    assert r.returncode == 0, r.stderr.decode()
+    g = subprocess.run([os.path.join(orc.REPO, "bin", "hash10x-amd")] + [a if a != "OUT" else "hip.hash" for a in args], cwd=workdir.path, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert g.returncode == 0, g.stderr.decode()
+    exp = orc.canonical_hash_bytes(open(workdir.file("ref.hash"), "rb").read())
+    got = open(workdir.file("hip.hash"), "rb").read()
+    assert got == exp, orc.describe_diff(got, exp)
+    assert got[4:8] == b"\x02\x00\x00\x00"
+    # onto several GPUs a v1 file is refused (the sharded reader preads the v2 layout)
+    bad = subprocess.run([os.path.join(orc.REPO, "bin", "hash10x-amd"), "--gpus", "2", "-B", "20", "--readHash", "v1.hash"], cwd=workdir.path, stdout=subprocess.PIPE,
+                         stderr=subprocess.PIPE, env=dict(os.environ, H10X_COMM="local"))
+    assert bad.returncode == 255 and b"only version 2 files" in bad.stderr
+
+
+@pytest.mark.skipif(not orc.have_ref(), reason="oracle/_ref not present")
+@pytest.mark.parametrize("gpus", [1, 3])
+def test_cli_verbose_cluster_lines_match_reference(workdir, gpus):
+    """--verbose: the per-barcode lines of codeClusterFind / codeClusterReadMerge (hash10x.c:827-834, 867: reads, hashes, good hashes, how many of them
+    were labelled, clusters before and after the read merge) equal the reference binary's, and so does its note for a barcode given up at the 256th
+    cluster (hash10x.c:813, stderr, verbose or not) — on one GPU and on three shards."""
+    import subprocess
+    orc.gen_fqb(workdir.file("x.fqb"), 30000, 150, 300000, 0.003, 41, 4.0, 150, 6000)
+    pre = ["--gpus", str(gpus)] if gpus > 1 else []
+    env = dict(os.environ, H10X_COMM="local")
+
+    def lines(txt):
+        return [ln for ln in txt.decode().splitlines() if ln.startswith(("  code ", " then "))]
+    for args in (["-B", "20", "-ct", "3", "--verbose", "--readFQB", "x.fqb", "--hashDepthRange", "4", "30", "--cluster", "1", "0", "--hashDepthRange", "30", "31", "--cluster", "1", "60"],
+                 ["-B", "20", "--verbose", "--readHash", "abort255.hash", "--hashDepthRange", "2", "100", "--cluster", "1", "2"]):
+        if "abort255.hash" in args:
+            with open(workdir.file("abort255.hash"), "wb") as f:
+                f.write(orc.read_maybe_gz(os.path.join(orc.GOLDEN, "abort255.in.hash.gz")))
+        r = orc.run_ref(args, workdir.path)
+        assert r.returncode == 0, r.stderr.decode()
+        g = subprocess.run([os.path.join(orc.REPO, "bin", "hash10x-amd")] + pre + args, cwd=workdir.path, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env)
+        assert g.returncode == 0, g.stderr.decode()
+        assert lines(g.stdout) == lines(r.stdout) and len(lines(r.stdout)) > 0
+        note = [ln for ln in r.stderr.decode().splitlines() if "too many clusters" in ln]
+        assert [ln for ln in g.stderr.decode().splitlines() if "too many clusters" in ln] == note
+        if "abort255.hash" in args:
+            assert len(note) == 1
+
+
 @pytest.mark.skipif(not orc.have_ref(), reason="oracle/_ref not present")
 def test_cli_crib_reports_match_reference(workdir):
     """--cribBuild (both haplotypes hashed and looked up on the device), --clusterReport, --clusterSplit, --cribSummary:
