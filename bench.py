@@ -135,20 +135,20 @@ def _mix64(x):
     return x ^ (x >> np.uint64(31))
 
 
-def checksum_words(words, first_index, domain):
+def checksum_words(words, first_index, domain, slice_words=1 << 22):
     """[sum over i of mix(words[i] ^ mix(first_index + i + salt + domain))] for the two salts, mod 2^64 (slices of 2^22 words on a few
     threads: numpy releases the GIL, and the 3 Gb workload has 2 x 10^9 records to go through)"""
     w = np.ascontiguousarray(words, dtype=np.uint64)
 
     def one(a):
-        part = w[a: a + (1 << 22)]
+        part = w[a: a + slice_words]
         res = []
         with np.errstate(over="ignore"):
             for salt in _SALTS:
                 idx = np.arange(part.size, dtype=np.uint64) + np.uint64((first_index + a + salt + domain * 0x9E3779B97F4A7C15) & 0xFFFFFFFFFFFFFFFF)
                 res.append(int(_mix64(part ^ _mix64(idx)).sum(dtype=np.uint64)))
         return res
-    starts = list(range(0, w.size, 1 << 22))
+    starts = list(range(0, w.size, slice_words))
     if len(starts) > 4:
         from concurrent.futures import ThreadPoolExecutor
         with ThreadPoolExecutor(max_workers=min(16, os.cpu_count() or 1)) as ex:

@@ -206,7 +206,6 @@ struct Ctx {
   int64_t optBigRanks = 0;    // tuning knob: rank count above which a barcode goes to the front of the main work queue (0 = 1.5 x the mean)
   int64_t optNoPack = 0;      // index build with separate key / block arrays even where the packed form fits (A/B, tests)
   int64_t optNarrowFirst = 0; // first[] of the cluster kernel at 2 bytes per entry in every block (default: 4 where the block's working set leaves room)
-  int64_t optDbgSkip = 0;     // diagnostic: what-if timing of cluster_kernel with phases switched off (results wrong)
   int64_t optStamps = 0;      // diagnostic: per-phase wall-clock stamps in cluster_kernel
   int64_t optChunk = 0;       // -c <chunkSize> of the reference's readFQB loop (hash10x.c:202-223): 0 = no chunk semantics (no "chunkSize too small", no
                               // all-A-barcode quirk); set by the session layer for --readFQB
@@ -218,6 +217,7 @@ struct Ctx {
   int64_t optRowsFakeBase = 0; // testing knob: list offsets start at this many entries (multiple of 2^rowShift) in front of the real array: 64-bit offsets on small inputs
   // streaming ingest (h10x_ingest_fqb): the record image grows on the device as the chunks arrive
   DevBuf<u32> ingestBuf; u64 ingestRecords = 0, ingestCap = 0;
+  static constexpr int INGEST_SLOTS = 8; hipEvent_t ingestEv[INGEST_SLOTS] = {};   // h10x_ingest_fqb_async: one event per caller's buffer
   int64_t optFaultInject = 0; // test knob: the fork/join region with this number (1 mosh classes, 2 clusHash classes, 3 good-list classes, 4 cluster
                               // classes, 5 sums beside merges) fails once between its fork and its join, then the knob clears itself
   int faultAt(int region) { if (optFaultInject != region) return 0; optFaultInject = 0; return fail("injected fault in fork/join region %d", region); }

@@ -87,6 +87,7 @@ void h10x_destroy(h10x_ctx *h) {
   for (auto &t : h->c.timers) { if (t.a) (void)hipEventDestroy(t.a); if (t.b) (void)hipEventDestroy(t.b); }
   for (int i = 0; i < 3; ++i) { if (h->c.aux[i]) { (void)hipStreamSynchronize(h->c.aux[i]); (void)hipStreamDestroy(h->c.aux[i]); } if (h->c.evJoin[i]) (void)hipEventDestroy(h->c.evJoin[i]); }
   if (h->c.evFork) (void)hipEventDestroy(h->c.evFork);
+  for (auto &e : h->c.ingestEv) if (e) (void)hipEventDestroy(e);
   if (h->c.startFlags) (void)hipHostFree(h->c.startFlags);
   if (h->c.mail) (void)hipHostFree(h->c.mail);
   hipStream_t own = h->c.ownStream ? h->c.stream : nullptr; const hipStream_t used = h->c.stream; const int dev = h->c.device;
@@ -364,7 +365,31 @@ static int ingest_append(Ctx &c, const uint32_t *hostRec, uint64_t n) {
   }
   return 0;
 }
-static void ingest_drop(Ctx &c) { c.ingestBuf.release(); c.ingestRecords = 0; c.ingestCap = 0; }
+static void ingest_drop(Ctx &c) { (void)hipStreamSynchronize(c.stream); c.ingestBuf.release(); c.ingestRecords = 0; c.ingestCap = 0; }
+void *h10x_pinned_alloc(size_t bytes) { void *p = nullptr; return hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) == hipSuccess ? p : nullptr; }
+void h10x_pinned_free(void *p) { if (p) (void)hipHostFree(p); }
+int h10x_ingest_fqb_async(h10x_ctx *h, const uint32_t *pinnedRec, uint64_t n, int slot) {
+  if (!h) return -1;
+  Ctx &c = h->c;
+  H10X_TRY(enter(c));
+  if (slot < 0 || slot >= Ctx::INGEST_SLOTS) return c.fail("h10x_ingest_fqb_async: slot %d outside 0..%d", slot, Ctx::INGEST_SLOTS - 1);
+  if (n && !pinnedRec) return c.fail("h10x_ingest_fqb_async: null records");
+  if (c.ingestRecords + n > c.ingestCap) return c.fail("h10x_ingest_fqb_async: %llu records beyond the %llu announced by h10x_ingest_reserve (the image cannot move while uploads are queued)",
+                                                     (u64)(c.ingestRecords + n), (u64)c.ingestCap);
+  if (!c.ingestEv[slot] && hipEventCreateWithFlags(&c.ingestEv[slot], hipEventDisableTiming) != hipSuccess) return c.fail("hipEventCreate failed");
+  if (n) H10X_HIP(&c, hipMemcpyAsync(c.ingestBuf.p + c.ingestRecords * 30, pinnedRec, n * 120, hipMemcpyHostToDevice, c.stream));
+  H10X_HIP(&c, hipEventRecord(c.ingestEv[slot], c.stream));
+  c.ingestRecords += n;
+  return 0;
+}
+int h10x_ingest_wait(h10x_ctx *h, int slot) {
+  if (!h) return -1;
+  Ctx &c = h->c;
+  H10X_TRY(enter(c));
+  if (slot < 0 || slot >= Ctx::INGEST_SLOTS) return c.fail("h10x_ingest_wait: slot %d outside 0..%d", slot, Ctx::INGEST_SLOTS - 1);
+  if (c.ingestEv[slot]) H10X_HIP(&c, hipEventSynchronize(c.ingestEv[slot]));
+  return 0;
+}
 int h10x_ingest_reserve(h10x_ctx *h, uint64_t n_records) {
   if (!h) return -1;
   Ctx &c = h->c;
@@ -576,7 +601,6 @@ int h10x_set_option(h10x_ctx *h, const char *name, int64_t value) {
   if (!strcmp(name, "cluster_threads0")) { h->c.optClusterThreads0 = value; return 0; }
   if (!strcmp(name, "cluster_budget0")) { h->c.optClusterBudget0 = value; return 0; }
   if (!strcmp(name, "cluster_big_ranks")) { h->c.optBigRanks = value; return 0; }
-  if (!strcmp(name, "cluster_dbg_skip")) { h->c.optDbgSkip = value; return 0; }
   if (!strcmp(name, "cluster_narrow_first")) { h->c.optNarrowFirst = value; return 0; }
   if (!strcmp(name, "index_no_pack")) { h->c.optNoPack = value; return 0; }
   if (!strcmp(name, "cluster_stamps")) { h->c.optStamps = value; return 0; }

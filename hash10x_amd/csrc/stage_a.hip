@@ -32,13 +32,8 @@ struct MoshConst {
   int n1, n2;            // k-mers per read 1 (127 bases from base 23) and read 2 (150 bases)
   int run;               // consecutive k-mer slots per lane in mosh_lds_kernel: ceil(n1/run) + ceil(n2/run) <= 32
   u64 factor1;
-  int dbg;               // what-if timing switches (results WRONG), honoured only by builds with -DH10X_DBG_SKIP: 16 queue never drained, 32 no survivors, 64 no compaction
 };
-#ifdef H10X_DBG_SKIP
-#define H10X_MOSH_DBG(bit) (mc.dbg & (bit))
-#else
 #define H10X_MOSH_DBG(bit) false
-#endif
 
 // ------------------------------------------------------------------------------------------ helpers
 // 2k-bit big-endian word of bases [p, p+k) from MSB-first packed dwords (fq2b.c:33-42 layout;
@@ -561,7 +556,7 @@ int stageA_run(Ctx *c, const u32 *dRec, u64 nRec, DevBuf<u64> &entHash, DevBuf<u
   hipStream_t st = c->stream;
   PrimTemp pt;
   const int k = c->prm.k;
-  MoshConst mc; mc.k = k; mc.w = c->prm.w; mc.shift1 = 64 - 2 * k; mc.factor1 = c->prm.factor1; mc.dbg = (int)c->optDbgSkip;
+  MoshConst mc; mc.k = k; mc.w = c->prm.w; mc.shift1 = 64 - 2 * k; mc.factor1 = c->prm.factor1;
   mc.n1 = 127 - k + 1 > 0 ? 127 - k + 1 : 0;               // len < k => no k-mer (seqhash.c:162)
   mc.n2 = 150 - k + 1 > 0 ? 150 - k + 1 : 0;
   mc.run = 8; while ((mc.n1 + mc.run - 1) / mc.run + (mc.n2 + mc.run - 1) / mc.run > 32) ++mc.run;   // 8 at k = 21, 9 for k <= 7

@@ -215,9 +215,6 @@ void clushash_block_kernel(const u64 *__restrict__ entHash /* hash / w */, const
           const u64 q = entHash[o + e] >> cb, h = q * w;
           u64 slot = h & mask; const u64 step = ((h >> B) & mask) | 1;
           u64 t;
-#ifdef H10X_DBG_SKIP
-          if (sortBits & 64) { t = (q * 0x9E3779B97F4A7C15ULL) << qBits | q; } else                   // what-if: no table look-up
-#endif
           while ((t = table64[slot]) != SLOT_EMPTY64 && (t & qmask) != q) slot = (slot + step) & mask;
           k[j] = t == SLOT_EMPTY64 ? 0u : (u32)(t >> qBits);
           v[j] = entRead[o + e] & 0xFFFFu;                   // ClusterHash.read is U16 (hash10x.c:37,180)
@@ -225,9 +222,6 @@ void clushash_block_kernel(const u64 *__restrict__ entHash /* hash / w */, const
       }
     }
     __syncthreads();                                         // the storage of the previous block's sort is free again
-#ifdef H10X_DBG_SKIP
-    if (!(sortBits & 128))                                   // what-if: no sort
-#endif
     Sort().sort_to_striped(k, v, storage, 0, sortBits & 63); // padding keys are all ones in sortBits bits: behind every index
 #pragma unroll
     for (int j = 0; j < IPT; ++j) {
@@ -243,9 +237,6 @@ static int clusHashByBlocks(Ctx *c, const u64 *entHash, const u32 *entRead, cons
   H10X_HIP(c, c->clusHash.alloc(c->nEntries));
   if (!c->nEntries || nBlocks < 2) return 0;
   int sortBits = bitsFor(c->hashNumber) + 1 > 32 ? 32 : bitsFor(c->hashNumber) + 1;
-#ifdef H10X_DBG_SKIP
-  sortBits |= (int)(c->optDbgSkip & (1024 | 2048)) >> 4;     // what-if timing (results wrong): 1024 no look-up, 2048 no sort
-#endif
   const int B = c->prm.B; const u64 w = (u64)c->prm.w; const int qBits = c->keyBits;
   DevBuf<u32> lists, counts;
   H10X_TRY(stageB_blockClassLists(c, lists, counts));

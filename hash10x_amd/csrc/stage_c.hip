@@ -32,18 +32,8 @@ namespace h10x {
 constexpr int CL_THREADS_SMALL = 1024;                     // <= 79 KB working sets, two workgroups per CU
 constexpr int CL_THREADS_HUGE = 1024;                      // the whole LDS of a CU, one workgroup per CU
 constexpr u16 NONE16 = 0xFFFF;
-constexpr u32 NOHANDLE = 0xFFFFFFFFu;                        // FirstDense/Ranked/Hashed::update handle of a lane without an entry
-#ifndef H10X_RIF
-#define H10X_RIF 4
-#endif
-// A/B switches of the list loop (scratch/r3_variants.sh builds and times them; the defaults are what measured fastest):
-#ifndef H10X_PREPEEK
-#define H10X_PREPEEK 0        // 1: the first[] values of all lists of a round are read back together, in front of the per-list work
-#endif
-#ifndef H10X_BATCH
-#define H10X_BATCH 0          // 1: the results of a round's lists are parked in lanes and stored once per round
-#endif
-constexpr int ROWS_IN_FLIGHT = H10X_RIF;                          // barcode lists a wavefront keeps in flight
+constexpr u32 NOHANDLE = 0xFFFFFFFFu;                        // (argument of row_mode_hist for a chunk a list does not have)
+constexpr int ROWS_IN_FLIGHT = 4;                                 // barcode lists a wavefront keeps in flight
 constexpr int RCHUNK = 4;                                   // register chunks: lists up to 256 entries
 
 // ------------------------------------------------------------------------------------------ depth range
@@ -259,7 +249,7 @@ struct ClusterArgs {
   u32 rowShift;                                             // rows[]: a list starts at entry (rs << rowShift) — sharded runs with more than 2^32 list entries
   u32 nBlocksFirst;                                         // size of first[]: barcodes of the whole data set + 1
   u32 firstCap;                                             // ranked placement, test knob: cap on the first[] entries of a block (0 = what the budget leaves)
-  u32 hashMask, hashMinSlots;                               // hashed placement: 2^b - 1 with 2^b >= barcodes of the data set; slots below which the 8-bit tag is too narrow
+  u32 hashMinSlots;                                         // translated placement: table slots below which the 10-bit tag is too narrow for the data set's barcode count
   u32 hashBits;                                             // b
   u16 *handles; size_t handleStride; u32 hStride;           // translated placement: HBM slot of the workgroup (handleStride u16 each), u16 per list (a power of two >= 64 that holds the longest list)
   const u32 *entries;                                       // per block: entries of its barcode lists (sum of depths of its good hashes)
@@ -272,7 +262,6 @@ struct ClusterArgs {
   u64 *stats;                                               // [0] sum good, [1] sum good depth, [2] sum nHash, [3] codes
   u64 *phase;                                               // diagnostic per-phase ticks (null = off)
   u32 narrowFirst;                                          // test / A-B knob: keep first[] at 2 bytes per entry in every block
-  u32 dbgSkip;                                              // diagnostic what-if timing (results are WRONG): 1 no first[] update, 2 no mode, 4 no pending pass, 8 no barrier
 };
 
 // Working set of the list loop inside a region (LDS or HBM scratch). Since round 3 the per-rank arrays of the reference's
@@ -310,41 +299,12 @@ __host__ __device__ inline u32 rankedFirstEstimate(u32 nBarcodes, u32 n) { const
 // … and, where the entries of the block's lists are known (classification): a seventh of them (6-8 % on the yeast-like
 // sets, more on deeper ones), whichever is larger. Erring low is cheap: the ranked kernel knows the true number right
 // after its bitmap pass and hands the block on before the list loop.
-#ifndef H10X_EST_DIV
-#define H10X_EST_DIV 7
-#endif
-__host__ __device__ inline u32 rankedFirstEstimateE(u32 nBarcodes, u32 n, u32 entries) { const u32 a = rankedFirstEstimate(nBarcodes, n), b = entries / H10X_EST_DIV; const u32 m = a > b ? a : b; return m < nBarcodes ? m : nBarcodes; }
+__host__ __device__ inline u32 rankedFirstEstimateE(u32 nBarcodes, u32 n, u32 entries) { const u32 a = rankedFirstEstimate(nBarcodes, n), b = entries / 7; const u32 m = a > b ? a : b; return m < nBarcodes ? m : nBarcodes; }
 __host__ __device__ inline u32 histWaves(u32 nFirst, u32 n, u32 maxWaves, u32 bmWords, size_t budget) {
   const size_t fixed = workBytes(nFirst, n, 0, bmWords), per = (((size_t)n + 3) / 4) * 4;
   if (fixed + MIN_HIST_WAVES * per > budget) return 0;
   const size_t wv = (budget - fixed) / (per ? per : 1);
   return wv < maxWaves ? (u32)wv : maxWaves;
-}
-// Hashed placement (FirstHashed): slots wanted for a block = 1.25 x the barcodes expected in its lists (see
-// rankedFirstEstimateE: a seventh of the lists' entries; measured on the 1/10 config-3 set: 12 % on average, 15 % at the 90th
-// percentile, 19 % at most), so that the table stays under ~80 % full. The kernel gives the table every byte the budget
-// leaves; a block whose table still fills up is re-run in the next larger placement (0.2 % of the blocks at 1 M barcodes).
-// Round 3, full-size config 3 (scratch/r3_variants.sh): 1.5 x -> 1155 ms, 1.25 x -> 1094 ms (546 k instead of 407 k blocks in the
-// half-CU class), a ninth of the entries at 1.25 x -> 1296 ms (98 k blocks overflow and run twice).
-constexpr u32 HASHED_MIN_SLOTS = 1024, HASHED_MAX_SLOTS = 1u << 16;
-// list-loop waves and table slots of a block in the hashed placement: all waves if the table then still has `want`
-// slots, else 8, else the minimum (fewer waves => more slots); slots = 0 if nothing fits
-#ifndef H10X_HASHED_WANT_PCT
-#define H10X_HASHED_WANT_PCT 125
-#endif
-__host__ __device__ inline u32 hashedWant(u32 est) { return (u32)(((u64)est * H10X_HASHED_WANT_PCT) / 100); }   // slots asked for per barcode expected in the table
-__host__ __device__ inline void hashedShape(u32 n, u32 maxWaves, size_t budget, u32 minSlots, u32 want, u32 &nW, u32 &slots) {
-  const u32 tryW[3] = {maxWaves, maxWaves < 8 ? maxWaves : 8, MIN_HIST_WAVES};
-  const size_t need = minSlots > HASHED_MIN_SLOTS ? minSlots : HASHED_MIN_SLOTS;
-  nW = 0; slots = 0;
-  for (int t = 0; t < 3; ++t) {
-    const size_t used = workBytes(0, n, tryW[t], 0) + 32;
-    if (used >= budget) continue;
-    size_t sl = (budget - used) / 4; if (sl > HASHED_MAX_SLOTS) sl = HASHED_MAX_SLOTS;
-    if (sl < need) continue;
-    nW = tryW[t]; slots = (u32)sl;
-    if (sl >= want) return;
-  }
 }
 __device__ inline Work carve(unsigned char *base, u32 nFirst, u32 n, u32 bmWords = 0) {
   Work w; size_t o = 0;
@@ -388,23 +348,16 @@ __device__ __forceinline__ void min_u16(u16 *arr, u32 idx, u32 val) {
 //  * FirstDense : a u16 per barcode of the data set — in LDS while that is small, else on a per-workgroup HBM slot;
 //  * FirstRanked: a u16 per barcode PRESENT in this block's lists, found through a presence bitmap over all barcodes and a
 //    per-word popcount prefix (3 LDS reads instead of 1; 1 bit + 1/16 B per barcode of the data set);
-//  * FirstHashed: an open-addressing table in LDS keyed by barcode, for data sets whose bitmap no longer fits — a barcode's
-//    lists only ever meet some thousand others, whatever the data set holds. Buckets of 4 entries, entry = rank << 16 |
-//    bucket displacement << 10 | tag with (home bucket, tag) = (q mod NB, q div NB), q = a bijective scramble of cj: the
-//    bucket and the low 16 bits identify the barcode exactly, so entries of one barcode differ only in the rank and a
-//    plain ds_min_u32 is "minimum rank". Empty words are claimed by CAS, in order; a word never empties, so two waves
-//    inserting the same barcode meet in the same word. A table that fills up (displacement > 62) flags the block, which
-//    is then re-run in a larger placement.
+//  * (data sets whose bitmap no longer fits: the translated placement, SlotTable / FirstSlots below — a barcode's lists only ever
+//    meet some thousand others, whatever the data set holds)
 // update() returns a handle under which peek() finds the entry again without repeating the search: the list loop reads
 // every entry twice (before and after the round's barrier).
 // Dense and ranked placements in LDS come in two widths, chosen per block: a u32 per entry where the block's working set
 // leaves the room (minimum = one fire-and-forget ds_min_u32, no loop), the u16 of the CAS-min otherwise. The list loop is
 // bound by scalar and branch instructions (0.8 per CU cycle), and the CAS loop is mostly those.
-#ifndef H10X_SELF_HANDLE
-#define H10X_SELF_HANDLE 1    // dense placement: a lane without an entry (and the barcode's own number) keeps the barcode's own slot as its handle — first[] of
-#endif                        // the barcode itself is never written and reads "unseen", so the read-back needs no test and no exec mask
 template <bool FIRST_LDS> struct FirstDense {
-  static constexpr bool SELF = H10X_SELF_HANDLE != 0;
+  static constexpr bool SELF = true;                          // a lane without an entry (and the barcode's own number) keeps the barcode's own slot as its handle: first[] of the barcode
+                                                             // itself is never written and reads "unseen", so the read-back needs no test and no exec mask
   u32 none;                                                  // (the barcode's own number: set per barcode)
   u16 *first; u32 wide;                                      // wide: 1 = 4-byte entries (their low half, at the same address, is the value), else 0
   __device__ __forceinline__ u32 update(u32 cj, u32 i) const {
@@ -428,64 +381,6 @@ struct FirstRanked {
   __device__ __forceinline__ u32 lookup(u32 cj) const { return peek(at(cj)); }
   __device__ __forceinline__ u32 entry(const void *row, u32 j, u32 code) const { const u32 cj = ((const u32 *)row)[j]; return cj != code ? lookup(cj) : (u32)NONE16; }
 };
-struct FirstHashed {
-  static constexpr bool SELF = false;
-  u32 none;                                                  // handle of a lane without an entry: one word behind the table, always empty (reads as unseen)
-  // Buckets of 4 entries (one ds_read_b128 shows a whole bucket: at 2/3 load nearly every search ends in its home bucket).
-  // Entry = rank << 16 | bucket displacement << 10 | tag, (home bucket, tag) = (q mod NB, q div NB); 0xFFFFFFFF = empty.
-  u32 *tab; u32 NB /* buckets */, recip /* ceil(2^32 / NB) */, bmask; u32 *ovf;
-  static constexpr u32 SCRAMBLE = 0x9E3779u | 1u;            // odd multiplier: x -> x * SCRAMBLE mod 2^b is a bijection
-  static constexpr u32 MAXD = 63;                            // 6-bit displacement (never 63 with tag 1023: that is the empty pattern's low half)
-  __device__ __forceinline__ void split(u32 cj, u32 &home, u32 &tag) const {
-    const u32 q = (cj * SCRAMBLE) & bmask;                   // (24-bit multiplies — full rate, the values fit up to 16 M barcodes — change nothing: full-size config 3 1.06 -> 1.08 s)
-    tag = __umulhi(q, recip); home = q - tag * NB;
-    const bool neg = (int)home < 0, big = !neg && home >= NB;                                     // recip is rounded up: off by one at most; no branch
-    tag += big ? 1u : (neg ? ~0u : 0u); home += neg ? NB : (big ? 0u - NB : 0u);
-  }
-  __device__ __forceinline__ u32 update(u32 cj, u32 i) const {
-    u32 home, tag; split(cj, home, tag);
-    u32 b = home;
-    for (u32 d = 0; d < MAXD; ++d) {
-      const u32 key = (d << 10) | tag, mine = (i << 16) | key;
-      const uint4 e4 = *(const uint4 *)&tab[4 * b];
-      const u32 e[4] = {e4.x, e4.y, e4.z, e4.w};
-      // already here? (the usual case after a barcode's first list: no branch per word — an empty word's low half, displacement 63 with
-      // tag 1023, is no key)
-      u32 hit = 4, eh = 0;
-#pragma unroll
-      for (int w = 3; w >= 0; --w) { const bool m = (e[w] & 0xFFFFu) == key; hit = m ? (u32)w : hit; eh = m ? e[w] : eh; }
-      if (hit < 4) { if ((eh >> 16) > i) atomicMin(&tab[4 * b + hit], mine); return 4 * b + hit; }
-#pragma unroll
-      for (int w = 0; w < 4; ++w)                            // first empty word, in order: every inserter of a barcode walks the same words
-        if (e[w] == 0xFFFFFFFFu) {
-          const u32 old = atomicCAS(&tab[4 * b + w], 0xFFFFFFFFu, mine);
-          if (old == 0xFFFFFFFFu) return 4 * b + w;
-          if ((old & 0xFFFFu) == key) { if ((old >> 16) > i) atomicMin(&tab[4 * b + w], mine); return 4 * b + w; }
-        }
-      if (++b == NB) b = 0;
-    }
-    *ovf = 1;
-    return 4 * home;                                         // the block is abandoned
-  }
-  __device__ __forceinline__ u32 peek(u32 h) const { return tab[h] >> 16; }
-  __device__ __forceinline__ u32 lookup(u32 cj) const {
-    u32 home, tag; split(cj, home, tag);
-    u32 b = home;
-    for (u32 d = 0; d < MAXD; ++d) {
-      const u32 key = (d << 10) | tag;
-      const uint4 e4 = *(const uint4 *)&tab[4 * b];
-      const u32 e[4] = {e4.x, e4.y, e4.z, e4.w};
-      bool hole = false; u32 r = NONE16;
-#pragma unroll
-      for (int w = 0; w < 4; ++w) { hole |= e[w] == 0xFFFFFFFFu; r = (e[w] & 0xFFFFu) == key ? e[w] >> 16 : r; }   // (an empty word's low half is no key)
-      if (r != NONE16 || hole) return r;                     // a bucket with a hole ends every search that reaches it
-      if (++b == NB) b = 0;
-    }
-    return NONE16;
-  }
-  __device__ __forceinline__ u32 entry(const void *row, u32 j, u32 code) const { const u32 cj = ((const u32 *)row)[j]; return cj != code ? lookup(cj) : (u32)NONE16; }
-};
-
 // ---- translated placement (round 4), for data sets whose barcodes no longer fit a dense or ranked first[]: the lists of a
 // block are read ONCE, by a pass of their own (pass A) that looks every entry's barcode up in an open-addressing table in LDS
 // (SlotTable: the entry of a barcode holds the lowest rank that met it — the final first[] value, hash10x.c:794-799 — and is
@@ -494,11 +389,12 @@ struct FirstHashed {
 // no update and no barrier per round — first[] is final when it starts. Between the two the table gives its LDS back: pass B
 // needs 2 of its 4 bytes per slot (the ranks, compacted in place), and that is what lets nearly every block of a million-
 // barcode set run two workgroups per CU where the one-pass hashed form needed a whole CU for table + histograms.
-// Table layout as FirstHashed: buckets of 4 words, entry = rank << 16 | bucket displacement << 10 | tag, 0xFFFFFFFF = empty;
+// Table layout: buckets of 4 words, entry = rank << 16 | bucket displacement << 10 | tag, 0xFFFFFFFF = empty;
 // (home bucket, tag) of barcode cj: x = the b scrambled bits of cj at the top of a word (b = bits of the data set's barcode
 // count), home = floor(x NB / 2^32) (one v_mul_hi), tag = the top bits of the fraction (x NB mod 2^32) — barcodes of one home
 // bucket are consecutive x, their fractions NB apart, so b - floor(log2 NB) <= 10 bits of it tell them apart.
 constexpr u32 TR_QUEUE = 16384;                              // entries of a wave's queue in pass A (8 bytes each, behind the handles on the workgroup's HBM slot)
+constexpr u32 TR_MIN_SLOTS = 1024;                             // tables are not made smaller than this
 constexpr u32 TR_MAX_SLOTS = 65532;                          // handles are 16 bits; slot S (<= 65532) is the handle of "no entry" and reads unseen
 struct SlotTable {
   u32 *tab; u32 NB /* buckets */, xsh /* 32 - b */, tsh; u32 *ovf; u32 hbase /* handle of the table's slot 0 */;
@@ -589,7 +485,7 @@ __host__ __device__ inline void translatedShape(u32 n, u32 maxWaves, size_t budg
   size_t s = sA < sB ? sA : sB;
   if (s > TR_MAX_SLOTS) s = TR_MAX_SLOTS;
   size_t useful = 2 * (size_t)(entries < nBarcodes ? entries : nBarcodes) + 64;
-  if (useful < HASHED_MIN_SLOTS) useful = HASHED_MIN_SLOTS;
+  if (useful < TR_MIN_SLOTS) useful = TR_MIN_SLOTS;
   if (useful < minSlots) useful = minSlots;                  // (the tag's width asks for this many: a block with few entries still gets them)
   const bool all = s >= useful;                              // holds whatever the lists bring
   if (all) s = useful;
@@ -647,9 +543,6 @@ __device__ __forceinline__ u32 wave_max_u32(u32 v) {
 // the cluster it joins, rb = root[msBest] — known as soon as msBest's own round is over, i.e. for all but the few ranks
 // whose msBest lies in the round being processed (rb = NONE16: settled after the loop). The second gather of round 2's
 // phase (d) is gone for the rest, and with it the need to keep msMax / msTot per rank on chip.
-#ifndef H10X_Q_BALLOT
-#define H10X_Q_BALLOT 1       // the count of the root's value is taken from the registers (one compare + ballot per chunk) instead of from the histogram,
-#endif                        // which can then be cleared in the same exec region as its atomics
 template <bool IN_LDS, int RCHUNK, typename FT>
 __device__ __forceinline__ void row_mode_hist(const void *__restrict__ row /* entries beyond the two chunks held in registers: barcodes, or handles (FirstSlots) */, u32 f0, u32 f1 /* first[] of entries lane, 64 + lane, read for all lists of the round together; NONE16 = no entry */, u32 d, u32 code, u32 i, const FT &ft, u32 *hist,
                                               const u16 *root, u32 thr, u32 &best, u32 &bcnt, u32 &tot, u32 &rb, u32 &q) {
@@ -662,11 +555,7 @@ __device__ __forceinline__ void row_mode_hist(const void *__restrict__ row /* en
     if ((u32)(r * WAVE) < d) {
       const u32 j = r * WAVE + lane;
       if (r < 2) {
-#if H10X_PREPEEK
-        f[r] = r == 0 ? f0 : f1; ok[r] = f[r] < i;
-#else
-        const u32 h = r == 0 ? f0 : f1; if (H10X_SELF_HANDLE || h != NOHANDLE) { f[r] = ft.peek(h); ok[r] = f[r] < i; }   // (f0 / f1 are handles in this build)
-#endif
+        f[r] = ft.peek(r == 0 ? f0 : f1); ok[r] = f[r] < i;   // (f0 / f1 are handles: a lane without an entry holds one that reads "unseen")
       }
       else if (j < d) { f[r] = ft.entry(row, j, code); ok[r] = f[r] < i; }
       tot += (u32)__popcll(__ballot(ok[r]));
@@ -684,14 +573,11 @@ __device__ __forceinline__ void row_mode_hist(const void *__restrict__ row /* en
       const u32 c = ((atomicAdd(&hist[f[r] >> 2], 1u << sh8) >> sh8) & 0xFFu) + 1;
       const u32 k = (c << 16) | (0xFFFFu - f[r]);
       key = k > key ? k : key;
-#if H10X_Q_BALLOT
       if (RCHUNK == 1) {                                     // a one-chunk list is cleared in the exec region of its atomics (ds ops of a wave stay in order)
         if (IN_LDS) hist[f[r] >> 2] = 0;
         else atomicAnd(&hist[f[r] >> 2], 0u);                // HBM scratch: a plain store could be overtaken by the next list's atomics
       }
-#endif
     }
-#if H10X_Q_BALLOT
   if (RCHUNK > 1) {                                          // longer lists: once every chunk has been counted (a value's entries may lie in several chunks)
 #pragma unroll
     for (int r = 0; r < RCHUNK; ++r)
@@ -700,36 +586,20 @@ __device__ __forceinline__ void row_mode_hist(const void *__restrict__ row /* en
         else atomicAnd(&hist[f[r] >> 2], 0u);
       }
   }
-#endif
   // no value reached the threshold (most long lists): the caller only tests msMax >= threshold (hash10x.c:807), so the
   // wave reduction is skipped and the rank is reported inactive
-#ifndef H10X_SKIP_DPP
-#define H10X_SKIP_DPP 0       // 1: also the short lists test "some count reaches the threshold" before the wave reduction
-#endif
-  if ((!(RCHUNK > 2) && !H10X_SKIP_DPP) || __builtin_amdgcn_ballot_w64(key >= (thr << 16))) {
+  if (!(RCHUNK > 2) || __builtin_amdgcn_ballot_w64(key >= (thr << 16))) {
     key = wave_max_u32(key);
     bcnt = key >> 16;
     best = key ? 0xFFFFu - (key & 0xFFFFu) : NONE16;
     if (bcnt >= thr) {                                       // wave-uniform (readlane result)
       rb = ld_shared<IN_LDS>(&root[best]);
-#if H10X_Q_BALLOT
       if (rb != NONE16) {
 #pragma unroll
         for (int r = 0; r < RCHUNK; ++r) if ((u32)(r * WAVE) < d) q += (u32)__popcll(__ballot(f[r] == rb));   // (rb <= msBest < i: an entry that equals it is a usable one; the bare compare is a ballot as it stands, the conjunction cost two more instructions)
       }
-#else
-      if (rb != NONE16) q = (ld_shared<IN_LDS>(&hist[rb >> 2]) >> ((rb & 3) * 8)) & 0xFFu;
-#endif
     }
   }
-#if !H10X_Q_BALLOT
-#pragma unroll
-  for (int r = 0; r < RCHUNK; ++r)
-    if ((u32)(r * WAVE) < d && ok[r]) {
-      if (IN_LDS) hist[f[r] >> 2] = 0;                       // ds ops of a wave stay in order
-      else atomicAnd(&hist[f[r] >> 2], 0u);                  // HBM scratch: a plain store could be overtaken by the next list's atomics
-    }
-#endif
 }
 // entries of a list whose first[] value equals v (and, in tot, those below i): one wavefront, any length
 template <typename FT>
@@ -768,13 +638,6 @@ __device__ void row_mode_long(const void *__restrict__ row, u32 d, u32 code, u32
     }
   }
 }
-// what-if switches of scratch/skip_floor.py (option "cluster_dbg_skip"): compiled in only with -DH10X_DBG_SKIP — a runtime test per list
-// in the loop costs more than the phases they were built to weigh (2.29 -> 2.22 ms without them)
-#ifdef H10X_DBG_SKIP
-#define H10X_DBGSKIP(bit) (a.dbgSkip & (bit))
-#else
-#define H10X_DBGSKIP(bit) false
-#endif
 #define STAMP(k) do { if (a.phase && threadIdx.x == 0) { const u64 t__ = wall_clock64(); atomicAdd((u64 *)&a.phase[k], t__ - tPrev); tPrev = t__; } } while (0)
 
 // Workgroup barrier. In the HBM-scratch instantiation the working set lives in global memory and is re-used
@@ -816,12 +679,7 @@ __device__ __forceinline__ void cluster_one_block(const ClusterArgs &a, u32 code
   constexpr int CL_WAVES = CL_THREADS / WAVE;
   // lists a wave keeps in flight: 4, but 2 where the kernel must stay within 64 VGPRs (two workgroups per CU) AND carries
   // the ranked / hashed lookup: fewer registers spilled is worth more there than the deeper prefetch (8x set: 52.8 -> 41.4 ms);
-  // and 2 for the hashed placement in every class: with 4 its list loop unrolls to 61 KB of code (the compiler then keeps
-  // the block function out of line) against 42 KB — 300 k-barcode set: 0.533 -> 0.507 s
-#ifndef H10X_RIF_SMALL
-#define H10X_RIF_SMALL 2
-#endif
-  constexpr int RIF = ((KLASS == 0 && CL_THREADS == 1024 && FIRST_MODE == 1) || (FIRST_MODE == 3 && KLASS == 0)) ? H10X_RIF_SMALL : ROWS_IN_FLIGHT;
+  constexpr int RIF = (KLASS == 0 && CL_THREADS == 1024 && FIRST_MODE == 1) ? 2 : ROWS_IN_FLIGHT;
   const int tid = threadIdx.x, lane = tid & (WAVE - 1), wave = tid / WAVE;
   code = (u32)__builtin_amdgcn_readfirstlane((int)code);     // (the block number reaches every lane through LDS: say that it is uniform)
   const u32 n = (u32)__builtin_amdgcn_readfirstlane((int)a.nGood[code]);
@@ -829,39 +687,29 @@ __device__ __forceinline__ void cluster_one_block(const ClusterArgs &a, u32 code
   const u64 o = a.blockOff[code];
   constexpr bool FIRST_LDS = IN_LDS && FIRST_MODE != 2;
   constexpr bool RANKED = IN_LDS && FIRST_MODE == 1;
-  constexpr bool HASHED = IN_LDS && FIRST_MODE == 3;
   const u32 bmWords = RANKED ? (a.nBlocksFirst + 31) / 32 : 0;
   // list-loop waves: all of them where the histograms fit, fewer for a barcode with many ranks (one kernel and one
   // work queue then serve nearly every barcode; the phases behind the loop always use the whole workgroup)
-  u32 nW, slots = 0;
-  if constexpr (HASHED) {
-    const u32 want = hashedWant(rankedFirstEstimateE(a.nBlocksFirst, n, a.entries[code]));
-    hashedShape(n, CL_WAVES, a.ldsBudget, a.hashMinSlots, want, nW, slots);
-    if (a.firstCap && slots > a.firstCap) slots = a.firstCap;                  // test knob: small tables, to exercise the overflow chain
-    if (!nW || !slots) {                                     // cannot hold this barcode at all: hand it on
-      if (tid == 0) a.overflow[atomicAdd(a.overflowCount, 1u)] = code;
-      return;
-    }
-  } else if constexpr (RANKED) nW = 0;                       // ranked placement: decided once the bitmap pass has counted the barcodes present
+  u32 nW;
+  if constexpr (RANKED) nW = 0;                       // ranked placement: decided once the bitmap pass has counted the barcodes present
   else nW = IN_LDS ? histWaves(FIRST_LDS ? a.nBlocksFirst : 0, n, CL_WAVES, bmWords, a.ldsBudget) : (u32)CL_WAVES;
   if (!RANKED && !nW) return;                                // cannot happen: the classification sends such a barcode to the HBM-scratch class
   // dense placement in LDS: 4-byte entries where that costs the list loop no wave (see FirstDense)
   bool wideFirst = false;
-  if (FIRST_LDS && !RANKED && !HASHED && a.narrowFirst != 1) {
+  if (FIRST_LDS && !RANKED && a.narrowFirst != 1) {
     const u32 nW4 = histWaves(2 * a.nBlocksFirst, n, CL_WAVES, bmWords, a.ldsBudget);
     wideFirst = nW4 >= nW || (a.narrowFirst >= 2 && nW4 >= a.narrowFirst);   // (A/B: accept down to narrowFirst waves)
     if (wideFirst) nW = nW4;
   }
   // ranked placement: first[] lies BEHIND the histograms and both are laid out after the bitmap pass, when the number of
   // barcodes present is known: the list loop then runs on as many waves as what is left of the budget has room for
-  Work w = carve(region, HASHED ? 2 * slots + 8 : (RANKED ? 0 : (FIRST_LDS || !IN_LDS ? (wideFirst ? 2 * a.nBlocksFirst : a.nBlocksFirst) : 0)), n, bmWords);
+  Work w = carve(region, RANKED ? 0 : (FIRST_LDS || !IN_LDS ? (wideFirst ? 2 * a.nBlocksFirst : a.nBlocksFirst) : 0), n, bmWords);
   if (IN_LDS && FIRST_MODE == 2) w.first = firstGlobal;      // hybrid: first[] on this workgroup's HBM slot, the rest in LDS
-  typename std::conditional<HASHED, FirstHashed, typename std::conditional<RANKED, FirstRanked, FirstDense<FIRST_LDS>>::type>::type ft{};
-  if constexpr (HASHED) { slots &= ~3u; ft.none = slots; ft.tab = (u32 *)w.first; ft.NB = slots / 4; ft.recip = (u32)((0x100000000ULL + ft.NB - 1) / ft.NB); ft.bmask = a.hashMask; ft.ovf = &sh[2]; }
-  else if constexpr (RANKED) { ft.first = w.first; ft.bm = w.bm; ft.pre = w.pre; ft.wide = 0; }
+  typename std::conditional<RANKED, FirstRanked, FirstDense<FIRST_LDS>>::type ft{};
+  if constexpr (RANKED) { ft.first = w.first; ft.bm = w.bm; ft.pre = w.pre; ft.wide = 0; }
   else { ft.first = w.first; ft.wide = wideFirst ? 1u : 0u; }
   const u32 lcode = code; code = a.segs.globalOf(lcode);
-  if constexpr (!HASHED && !RANKED) ft.none = code;     // from here on `code` is the global barcode number (what the lists hold)
+  if constexpr (!RANKED) ft.none = code;     // from here on `code` is the global barcode number (what the lists hold)
   const u32 rsh = a.rowShift;
 #define ROWP(rs) (a.rows + ((size_t)(rs) << rsh))
   const u64 *const gr = a.goodRow + o;
@@ -872,9 +720,8 @@ __device__ __forceinline__ void cluster_one_block(const ClusterArgs &a, u32 code
   // ---- init: clear the tables; nothing is fetched per rank any more
   if (FIRST_LDS && !RANKED) {
     if (wideFirst) for (u32 i = tid; i < a.nBlocksFirst; i += CL_THREADS) ((u32 *)w.first)[i] = NONE16;
-    else for (u32 i = tid; i < (HASHED ? slots + 1 : (a.nBlocksFirst + 1) / 2); i += CL_THREADS) ((u32 *)w.first)[i] = 0xFFFFFFFFu;   // (hashed: + the word of handle `none`)
+    else for (u32 i = tid; i < (a.nBlocksFirst + 1) / 2; i += CL_THREADS) ((u32 *)w.first)[i] = 0xFFFFFFFFu;
   }
-  if (HASHED && tid == 0) sh[2] = 0;
   if (RANKED) for (u32 i = tid; i < bmWords; i += CL_THREADS) w.bm[i] = 0;
   if (!RANKED) for (u32 i = tid; i < nW * w.histWords; i += CL_THREADS) w.hist[i] = 0;
   for (u32 i = tid; i < n; i += CL_THREADS) w.root[i] = i ? NONE16 : (u16)0;   // rank 0 is never processed (hash10x.c:789): inactive, its own root
@@ -890,14 +737,7 @@ __device__ __forceinline__ void cluster_one_block(const ClusterArgs &a, u32 code
     // against the shared aperture base for the volatile look — "Illegal instruction detected" — in the RIF = 2 instantiation)
     typedef __attribute__((address_space(3))) u32 lds_u32;
     lds_u32 *const bm3 = (lds_u32 *)w.bm;
-#ifndef H10X_MARK_DIRECT
-#define H10X_MARK_DIRECT 1    // 1: the bitmap pass ORs every entry's bit in without looking first
-#endif
-#if H10X_MARK_DIRECT
     auto mark = [&](u32 cj) { if (cj != code) __hip_atomic_fetch_or(&bm3[cj >> 5], 1u << (cj & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); };
-#else
-    auto mark = [&](u32 cj) { if (cj != code) { const u32 bit = 1u << (cj & 31); if (!(*(volatile lds_u32 *)&bm3[cj >> 5] & bit)) __hip_atomic_fetch_or(&bm3[cj >> 5], bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); } };
-#endif
     // (both chunks of the eight lists are requested together: met one list at a time, the second chunk — most lists have one where the
     // depth range reaches 100 and the lists are long — was a load waited for per list: a third of the launch on the 1/10 config-3 set)
     constexpr int BIF = 8;                                   // lists in flight per wave in this pass (few live registers here)
@@ -993,18 +833,11 @@ __device__ __forceinline__ void cluster_one_block(const ClusterArgs &a, u32 code
     dvCur = dvN; dvN = dvNN; dvNN = dvD;
 #pragma unroll
     for (int t = 0; t < RIF; ++t) { cj[t] = cjN[t]; cj2[t] = cj2N[t]; cjN[t] = cjNN[t]; dl[t] = (u32)__builtin_amdgcn_readlane((int)dvCur, 32 + t); }
-#ifndef H10X_SKIP_B
-#define H10X_SKIP_B 1         // 1: the second chunks of a round's lists are only asked for when one of the lists has one
-#endif
-#if H10X_SKIP_B
     if constexpr (FIRST_MODE != 0) H10X_LOAD_B(cj2N, dvN) else
     // (dense placement = small data sets, where most lists fit one chunk; lanes 32 .. 32 + RIF - 1 of the descriptor register hold the lengths: one compare and a ballot say whether any list of the next round is longer than
     // a chunk — at yeast scale one list in seven is, so more than half of the rounds skip the RIF address set-ups; the registers then keep stale values that
     // nobody reads: every use of a second chunk is behind `length > 64`)
     if (__builtin_amdgcn_ballot_w64(lane >= 32 && dvN > (u32)WAVE)) H10X_LOAD_B(cj2N, dvN)
-#else
-    H10X_LOAD_B(cj2N, dvN)
-#endif
     H10X_LOAD_A(cjNN, dvNN)
     H10X_LOAD_D(listWave ? i0 + 3 * stepR : n, dvD)
 #define RS_OF(t) ((u32)__builtin_amdgcn_readlane((int)dvCur, t))   /* list offset of this round's list t: only lists of more than two chunks ask */
@@ -1012,30 +845,18 @@ __device__ __forceinline__ void cluster_one_block(const ClusterArgs &a, u32 code
     for (int t = 0; t < RIF; ++t) {
       const u32 i = i0 + t;
       using FTT = decltype(ft);
-      if (H10X_DBGSKIP(1)) { if (!FTT::SELF) cj[t] = cj[t] != code ? cj[t] : (H10X_SELF_HANDLE ? ft.none : NOHANDLE); continue; }
       if constexpr (FTT::SELF) { if (cj[t] != code) ft.update(cj[t], i); }          // dense: the barcode number IS the handle (the barcode's own: reads "unseen")
-      else cj[t] = cj[t] != code ? ft.update(cj[t], i) : (H10X_SELF_HANDLE ? ft.none : NOHANDLE);    // from here on cj / cj2 hold handles
+      else cj[t] = cj[t] != code ? ft.update(cj[t], i) : ft.none;    // from here on cj / cj2 hold handles
       if (dl[t] > WAVE) {
         if constexpr (FTT::SELF) { if (cj2[t] != code) ft.update(cj2[t], i); }
-        else cj2[t] = cj2[t] != code ? ft.update(cj2[t], i) : (H10X_SELF_HANDLE ? ft.none : NOHANDLE);
+        else cj2[t] = cj2[t] != code ? ft.update(cj2[t], i) : ft.none;
         if (dl[t] > 2 * WAVE) { const u32 *row = ROWP(RS_OF(t)); for (u32 j = 2 * WAVE + lane; j < dl[t]; j += WAVE) { const u32 c2 = row[j]; if (c2 != code) ft.update(c2, i); } }
       }
     }
-    if (!H10X_DBGSKIP(8)) SYNC_LDS();
-    if (HASHED && sh[2]) break;                              // the table filled up (uniform: read after the barrier)
-    if (H10X_DBGSKIP(2)) continue;
+    SYNC_LDS();
     // the first[] values of all the round's lists are read back in one go (one wait for up to 2 RIF LDS reads instead of one per list):
     // from here on cj / cj2 hold first[] values, NONE16 where a lane has no entry
-#if H10X_PREPEEK
-#pragma unroll
-    for (int t = 0; t < RIF; ++t) {
-      cj[t] = (dl[t] && cj[t] != NOHANDLE) ? ft.peek(cj[t]) : (u32)NONE16;
-      cj2[t] = (dl[t] > WAVE && cj2[t] != NOHANDLE) ? ft.peek(cj2[t]) : (u32)NONE16;
-    }
-    constexpr u32 NOENTRY = NONE16;
-#else
     constexpr u32 NOENTRY = NOHANDLE;
-#endif
     u32 rootV = 0; u64 resV = 0; bool mine = false;          // results of the round's lists, list t in lane t: one LDS and one HBM store per round (H10X_BATCH)
 #pragma unroll
     for (int t = 0; t < RIF; ++t) {
@@ -1054,31 +875,11 @@ __device__ __forceinline__ void cluster_one_block(const ClusterArgs &a, u32 code
         const bool act = bcnt >= thr;                        // hash10x.c:807
         // rb = NONE16: msBest belongs to this round (or to an earlier list of this wave's round: its root is stored with the round's),
         // settled behind the loop. The quotient is formed by replay_kernel: an fp64 divide per list is 40 instructions in this loop.
-#if H10X_BATCH
-        if (lane == t) { rootV = act ? rb : i; resV = RES_PACK(act ? best : NONE16, q, tot); mine = true; }
-#else
-#ifndef H10X_SCALAR_PACK
-#define H10X_SCALAR_PACK 0    // 1: the result word is put together on the scalar unit (every input is wave-uniform)
-#endif
-#if H10X_SCALAR_PACK
-        {
-          const u32 sBest = (u32)__builtin_amdgcn_readfirstlane((int)(act ? best : (u32)NONE16)), sQ = (u32)__builtin_amdgcn_readfirstlane((int)q), sTot = (u32)__builtin_amdgcn_readfirstlane((int)tot);
-          const u32 sRoot = (u32)__builtin_amdgcn_readfirstlane((int)(act ? rb : i));
-          const u64 word = RES_PACK(sBest, sQ, sTot);
-          if (lane == 0) { w.root[i] = (u16)sRoot; res[i] = word; }
-        }
-#else
         if (lane == 0) { w.root[i] = act ? (u16)rb : (u16)i; res[i] = RES_PACK(act ? best : NONE16, q, tot); }
-#endif
-#endif
         sDepth += d;
       }
     }
-#if H10X_BATCH
-    if (mine) { w.root[i0 + lane] = (u16)rootV; res[i0 + lane] = resV; }
-#else
     (void)rootV; (void)resV; (void)mine;
-#endif
   }
 #undef RS_OF
 #undef H10X_LOAD_D
@@ -1086,11 +887,6 @@ __device__ __forceinline__ void cluster_one_block(const ClusterArgs &a, u32 code
 #undef H10X_LOAD_B
   STAMP(1);
   SYNC();
-  if (HASHED && sh[2]) {                                     // hand the block to the next larger placement; what has been written is written again there
-    if (tid == 0) a.overflow[atomicAdd(a.overflowCount, 1u)] = lcode;
-    SYNC();
-    return;
-  }
   STAMP(2);
 
   // ---- the ranks left open by the loop: active ranks whose msBest was processed in the same round (its root was not on
@@ -1101,7 +897,6 @@ __device__ __forceinline__ void cluster_one_block(const ClusterArgs &a, u32 code
     u16 *todo = (u16 *)w.hist;                               // the histograms are idle from here on
     if (tid == 0) sh[2] = 0;
     SYNC();
-    if (!H10X_DBGSKIP(4))
       for (u32 i0 = 0; i0 < n; i0 += CL_THREADS) {
         const u32 i = i0 + tid;
         bool need = false;
@@ -1244,7 +1039,6 @@ __device__ __forceinline__ void cluster_one_block_tr(const ClusterArgs &a, u32 c
     qn = qk + rest;
   };
   {
-    u32 dbgQ = 0;
     bool insert = true;                                      // (uniform) the table takes new barcodes: looked up once per round
     u32 myIns = 0;                                           // barcodes this wave put into the table since it last said so
     const u32 laneU = (u32)lane;
@@ -1259,7 +1053,7 @@ __device__ __forceinline__ void cluster_one_block_tr(const ClusterArgs &a, u32 c
       const u64 bal = __ballot(!done);
       if (bal) {
         if (!done) queue[qn + (u32)__popcll(bal & ((1ULL << lane) - 1))] = (unsigned long long)cj | ((unsigned long long)(dest0 + laneU) << 22);
-        qn += (u32)__popcll(bal); dbgQ += (u32)__popcll(bal);
+        qn += (u32)__popcll(bal);
       }
     };
     // both chunks of a wave's RIF lists are requested a round ahead of their probes; descriptors two rounds ahead. Rounds start at
@@ -1319,7 +1113,6 @@ __device__ __forceinline__ void cluster_one_block_tr(const ClusterArgs &a, u32 c
 #undef TR_LOAD_C
     STAMP(1);
     if (qn && lane == 0) sh[0] = 1;
-    if (a.phase && lane == 0) atomicAdd((u64 *)&a.phase[6], (u64)dbgQ);
   }
   __syncthreads();                                           // (the handles other waves wrote are plain stores of this CU, read back through its own L1: workgroup scope is
                                                              // enough — an agent-scope acquire here drops the XCD's L2 for everybody, twice per block)
@@ -1331,7 +1124,6 @@ __device__ __forceinline__ void cluster_one_block_tr(const ClusterArgs &a, u32 c
   }
   if (sh[2]) {
     if (tid == 0) a.overflow[atomicAdd(a.overflowCount, 1u)] = lcode;
-    if (a.phase && tid == 0) atomicAdd((u64 *)&a.phase[7], 1ull << 20);
     SYNC();
     return;
   }
@@ -1366,14 +1158,12 @@ __device__ __forceinline__ void cluster_one_block_tr(const ClusterArgs &a, u32 c
     SYNC();
     if (sh[2]) {
       if (tid == 0) a.overflow[atomicAdd(a.overflowCount, 1u)] = lcode;
-      if (a.phase && tid == 0) atomicAdd((u64 *)&a.phase[7], 1ull << 40);
       SYNC();
       return;
     }
     compactRanks(tab2, (u16 *)region + S + 1, S2);
     firstBytes = pad16(2 * ((size_t)S + S2 + 16));
     nW = translatedWaves2(n, CL_WAVES, a.ldsBudget, S, S2);
-    if (a.phase && tid == 0) atomicAdd((u64 *)&a.phase[7], 1ull);
   }
   u16 *const root = (u16 *)(region + firstBytes);
   u32 *const hist = (u32 *)(region + firstBytes + pad16((size_t)n * 2));
@@ -1770,7 +1560,7 @@ void read_merge_kernel(h10x_block *__restrict__ blocks, const u64 *__restrict__ 
 // launch classes by working-set size: 0 = half a CU's LDS (barcodes with many ranks run their list loop on fewer waves:
 // histWaves), 2 = the whole LDS of a CU, 3 = HBM scratch (class 1 is no longer used)
 __global__ void cluster_classify_kernel(const h10x_block *__restrict__ blocks, const u32 *__restrict__ nGood, const u32 *__restrict__ entries, u32 codeMin, u32 codeMax,
-                                        u32 nBlocks /* LDS entries of first[] (ranked, hashed: barcodes of the data set) */, int ranked /* 1 ranked, 2 hashed, 3 translated */, u32 hashMinSlots, u32 maxTrRanks, u32 firstCap, u32 bmWords, u32 waves0, size_t budget0, size_t budgetSmall, size_t budgetBig, u32 bigRanks,
+                                        u32 nBlocks /* LDS entries of first[] (ranked, hashed: barcodes of the data set) */, int ranked /* 1 ranked, 3 translated */, u32 hashMinSlots, u32 maxTrRanks, u32 firstCap, u32 bmWords, u32 waves0, size_t budget0, size_t budgetSmall, size_t budgetBig, u32 bigRanks,
                                         u32 *__restrict__ list0, u32 *__restrict__ list1, u32 *__restrict__ list2, u32 *__restrict__ list3,
                                         u32 *__restrict__ listBig /* blocks with more ranks than the small replay class holds: counts[9] */, u32 *__restrict__ counts, unsigned long long *__restrict__ work) {
   const u32 c = codeMin + blockIdx.x * blockDim.x + threadIdx.x;
@@ -1779,18 +1569,9 @@ __global__ void cluster_classify_kernel(const h10x_block *__restrict__ blocks, c
   int cls = -1; u32 nRead = 0;
   if (n) {
     nRead = blocks[c].nRead;
-    if (ranked == 2) {                                  // hashed placement
-      const u32 want = hashedWant(rankedFirstEstimateE(nBlocks, n, entries[c]));
-      u32 nW, slots;
-      hashedShape(n, waves0, budget0, hashMinSlots, want, nW, slots);
-      if (slots >= want) cls = 0;
-      else { hashedShape(n, CL_THREADS_HUGE / WAVE, budgetBig, hashMinSlots, want, nW, slots); cls = slots ? 2 : 3; }
-    }
-    else if (ranked == 3) {                             // translated placement: the table of pass A must hold the barcodes expected in the block's lists
-      const u32 want = hashedWant(rankedFirstEstimateE(nBlocks, n, entries[c]));
+    if (ranked == 3) {                             // translated placement: the table of pass A must hold the barcodes expected in the block's lists
       u32 S, S2, nW; bool compact;
       translatedShape(n, waves0, budget0, hashMinSlots, entries[c], nBlocks, firstCap, S, S2, nW, compact);
-      (void)want;
       if (n > maxTrRanks) cls = 3;                       // (its handles would not fit the workgroup's HBM slot)
       else if (translatedFits(S, S2, rankedFirstEstimateE(nBlocks, n, entries[c]), entries[c], nBlocks)) cls = 0;
       else { translatedShape(n, CL_THREADS_HUGE / WAVE, budgetBig, hashMinSlots, entries[c], nBlocks, firstCap, S, S2, nW, compact); cls = S ? 2 : 3; }
@@ -1848,20 +1629,20 @@ static int cluster_local_range(Ctx *c, int codeMin, int codeMax, int threshold, 
   const size_t budgetBig = c->optClusterLds > 0 ? (size_t)c->optClusterLds : 160 * 1024 - 1024;
   const int threads0 = c->optClusterThreads0 == 512 ? 512 : 1024;                            // tuning knobs for class 0
   const size_t budget0 = c->optClusterLds > 0 ? (size_t)c->optClusterLds : (c->optClusterBudget0 > 0 ? (size_t)c->optClusterBudget0 : budgetSmall);
-  // Placement of first[] (FirstDense / FirstRanked / FirstHashed): dense in LDS while 2 B per barcode of the data set is
-  // small; ranked in LDS while the presence bitmap + prefix (3/16 B per barcode) leaves room for the rest; hashed in LDS
-  // up to 2^22 barcodes (beyond that the 8-bit tag needs more slots than LDS has); dense on a per-workgroup HBM slot
-  // (L2/MALL resident, atomics + L1-bypassing loads) as the last resort and for blocks whose LDS table filled up twice.
+  // Placement of first[] (FirstDense / FirstRanked / SlotTable + FirstSlots): dense in LDS while 2 B per barcode of the data set is
+  // small; ranked in LDS while the presence bitmap + prefix (3/16 B per barcode) leaves room for the rest; translated (handles
+  // into a table in LDS) up to 2^22 barcodes (beyond that the 10-bit tag needs more slots than LDS has); dense on a per-workgroup
+  // HBM slot (L2/MALL resident, atomics + L1-bypassing loads) as the last resort and for blocks whose LDS tables filled up twice.
   const u32 bmWordsAll = (nGlobal + 31) / 32;
   int hashBits = 1; while (hashBits < 32 && (1ull << hashBits) < (unsigned long long)nGlobal) ++hashBits;
   const u32 hashMinSlots = hashBits > 10 ? 4u << (hashBits - 10) : 0u;       // 10-bit tag: buckets >= 2^(b-10)
-  // The ranked form is 2.2 x faster per list than the hashed one (300 k-barcode set: 172 against 374 ms), so it is TRIED wherever the
+  // The ranked form reads the lists twice but needs no probing (100 k-barcode set: 39 ms against 56 translated), so it is TRIED wherever the
   // bitmap + prefix leave the whole-CU class any room (up to 100 KB of them: 546 k barcodes) and kept unless the classification then
   // sends more than a few blocks to the HBM-scratch class; up to 48 KB (262 k barcodes) it is taken as before.
   const bool rankedSure = (size_t)bmWordsAll * 6 <= 48 * 1024, rankedTry = !rankedSure && (size_t)bmWordsAll * 6 <= 100 * 1024 && hashBits <= 22;
   int firstMode = (size_t)nGlobal * 2 <= 48 * 1024 ? 0 : (rankedSure || rankedTry ? 1 : (hashBits <= 22 ? 4 : 2));
-  if (c->optFirstGlobal == 1) firstMode = 2; else if (c->optFirstGlobal == 2) firstMode = 1; else if (c->optFirstGlobal == 3) firstMode = 3;   // test knobs
-  else if (c->optFirstGlobal == 4 && hashBits <= 22) firstMode = 4;
+  if (c->optFirstGlobal == 1) firstMode = 2; else if (c->optFirstGlobal == 2) firstMode = 1;                                          // test knobs
+  else if ((c->optFirstGlobal == 3 || c->optFirstGlobal == 4) && hashBits <= 22) firstMode = 4;                                        // (3: round 3's one-pass hashed table, replaced by the translated placement)
   // translated placement: u16 per list on a workgroup's handle slot (a multiple of 64 that holds the longest list), ranks per slot
   u32 hStride = 64; while (hStride < c->maxGoodDepth && hStride < (1u << 24)) hStride <<= 1;   // (a power of two: a handle's position tells its rank)
   const size_t trSlotCapBytes = (size_t)32 << 20;
@@ -1873,7 +1654,7 @@ static int cluster_local_range(Ctx *c, int codeMin, int codeMax, int threshold, 
     nFirstLds = firstMode == 0 ? nGlobal : 0;
     bmWords = firstMode == 1 ? bmWordsAll : 0;
     cluster_classify_kernel<<<divUp(span, 256), 256, 0, st>>>(c->blocks.p, c->nGood.p, c->goodEntries.p, (u32)codeMin, (u32)codeMax,
-                                                            firstMode == 1 || firstMode >= 3 ? nGlobal : nFirstLds, firstMode == 1 ? 1 : (firstMode == 3 ? 2 : (firstMode == 4 ? 3 : 0)), hashMinSlots, maxTrRanks, firstCap,
+                                                            firstMode == 1 || firstMode >= 3 ? nGlobal : nFirstLds, firstMode == 1 ? 1 : (firstMode == 4 ? 3 : 0), hashMinSlots, maxTrRanks, firstCap,
                                                             bmWords, (u32)threads0 / WAVE, budget0, budgetSmall, budgetBig, c->optBigRanks > 0 ? (u32)c->optBigRanks : c->meanGood + c->meanGood / 2,
                                                             list0.p, list1.p, list2.p, list3.p, listBig.p, counts.p, (unsigned long long *)(zeroed.p + 14));
     H10X_TRY(c->readback(hc, counts.p, 48));
@@ -1894,9 +1675,9 @@ static int cluster_local_range(Ctx *c, int codeMin, int codeMax, int threshold, 
   a.goodRow = c->goodRow.p; a.rows = c->rows.p; a.nBlocks = c->nBlocks; a.threshold = threshold;
   a.segs = c->segs; a.nBlocksFirst = nGlobal; a.rowShift = (u32)c->rowShift;
   if (c->sharded && c->optRowsFakeBase) a.rows = c->rows.p - (size_t)c->optRowsFakeBase;   // test knob: rowStart[] carries the same offset (shard_exchangeRows)
-  a.dbgSkip = (u32)c->optDbgSkip; a.narrowFirst = (u32)c->optNarrowFirst;
+  a.narrowFirst = (u32)c->optNarrowFirst;
   a.maxGood = c->maxGood; a.stats = stats.p; a.res = term.p; a.entries = c->goodEntries.p;
-  a.firstCap = firstCap; a.hashMask = hashBits >= 32 ? 0xFFFFFFFFu : (1u << hashBits) - 1u; a.hashMinSlots = hashMinSlots;
+  a.firstCap = firstCap; a.hashMinSlots = hashMinSlots;
   a.hashBits = (u32)hashBits; a.hStride = hStride; a.handleStride = trSlotU16;   // (handles, then the waves' queues)
   // ranked / hashed placement: blocks whose table was too small are re-run — those of the half-CU class (list A) with the
   // whole LDS of a CU, those that fail there as well (list B) with first[] dense on an HBM slot
@@ -1956,7 +1737,6 @@ static int cluster_local_range(Ctx *c, int codeMin, int codeMax, int threshold, 
     g.overflow = (OVF); g.overflowCount = (OVFCNT);                                                                                \
     if (firstMode == 0) H10X_LAUNCH_ONE(0, K, THREADS, BUDGET, GRID, STREAM)                                                       \
     else if (firstMode == 1) H10X_LAUNCH_ONE(1, K, THREADS, BUDGET, GRID, STREAM)                                                  \
-    else if (firstMode == 3) H10X_LAUNCH_ONE(3, K, THREADS, BUDGET, GRID, STREAM)                                                  \
     else if (firstMode == 4) { g.handles = trSlots[K].p; H10X_LAUNCH_ONE(4, K, THREADS, BUDGET, GRID, STREAM) }                    \
     else { g.scratch = firstSlots[K].p; g.scratchStride = firstStride; H10X_LAUNCH_ONE(2, K, THREADS, BUDGET, GRID, STREAM) }      \
   }
@@ -1996,7 +1776,7 @@ static int cluster_local_range(Ctx *c, int codeMin, int codeMax, int threshold, 
   H10X_TRY(c->joinStreams(3));
   u32 nOverflow = 0;
   DevBuf<unsigned char> scratch2;
-  if (firstMode == 1 || firstMode == 3 || firstMode == 4) {
+  if (firstMode == 1 || firstMode == 4) {
     u32 nA = 0, nB = 0;
     H10X_HIP(c, hipMemcpyAsync(&nA, ovfCountA, 4, hipMemcpyDeviceToHost, st));
     H10X_HIP(c, hipStreamSynchronize(st));

@@ -8,6 +8,7 @@
 #include <limits.h>
 #include <time.h>
 #include <fcntl.h>
+#include <pthread.h>
 #include <unistd.h>
 #include <sys/types.h>
 #include <sys/stat.h>
@@ -15,7 +16,7 @@
 #define ARRAY_MAGIC 8918274                            /* array.h:56 */
 typedef struct { int32_t magic, pad0; uint64_t base; int32_t dim, size, max, pad1; } array_hdr;   /* array.h:41-50 */
 
-enum { N_KNOBS = 14 };
+enum { N_KNOBS = 13 };
 struct h10x_session {
   int k, w, r, B, N, chunk, ct, device;                /* params (hash10x.c:25-33) */
   int timing;                                          /* measurement hook: enable hipEvent timers on every new context */
@@ -28,7 +29,7 @@ struct h10x_session {
   uint32_t *depthTail; int depthTailFrom;              /* entries [hashNumber, dim) as read from a file (normally zero) */
   char err[1024];
 };
-static const char *const knobName[N_KNOBS] = {"cluster_stamps", "cluster_lds_budget", "cluster_first_global", "cluster_first_cap", "cluster_dbg_skip",
+static const char *const knobName[N_KNOBS] = {"cluster_stamps", "cluster_lds_budget", "cluster_first_global", "cluster_first_cap",
                                               "cluster_big_ranks", "cluster_threads0", "cluster_budget0", "shard_row_shift", "shard_rows_fake_base", "stage_a_max_slots", "cluster_narrow_first", "index_no_pack", "shard_delta_lists"};
 
 static int fail(h10x_session *s, const char *fmt, ...) {
@@ -41,8 +42,8 @@ h10x_session *h10x_session_new(void) {
   h10x_session *s = (h10x_session *)calloc(1, sizeof *s);
   if (!s) return 0;
   s->k = 21; s->w = 31; s->r = 17; s->B = 28; s->N = 0; s->chunk = 100000; s->ct = 5; s->device = 0;
-  s->knob[13] = -1;                                    /* shard_delta_lists: delta-coded list exchange when there is more than one rank */
-  s->knob[8] = -1;                                     /* shard_row_shift: as small as the offsets allow */
+  for (int i = 0; i < N_KNOBS; ++i)                    /* by name: the table above may be reordered */
+    if (!strcmp(knobName[i], "shard_delta_lists") || !strcmp(knobName[i], "shard_row_shift")) s->knob[i] = -1;   /* delta-coded list exchange when there is more than one rank; list alignment as small as the offsets allow */
   s->blocksDim = 1200;                                 /* arrayCreate(1200, ClusterBlock), hash10x.c:1151 */
   return s;
 }
@@ -202,28 +203,62 @@ int h10x_session_readFQB_dev(h10x_session *s, const uint32_t *devRec, uint64_t n
 /* records [first, first + n) of a file through the library's streaming ingest (h10x_ingest_fqb / h10x_shard_ingest_fqb), 64 MiB at a
    time: the file never sits in host memory, and the closing call is the --readFQB itself (collective when sharded). A rank that fails
    here while sharded still makes the closing call's counterpart impossible for the others, so the verdict is agreed on first. */
+/* bytes [off, off + len) of the file into dst, on a few threads (a single pread copies out of the page cache at ~6 GB/s: the file read, not the
+   PCIe transfer, is what a --readFQB of a cached file waits for) */
+typedef struct { int fd; char *dst; uint64_t off, len; int ok; } ReadJob;
+static void *read_job(void *a) {
+  ReadJob *j = (ReadJob *)a; uint64_t got = 0;
+  while (got < j->len) { const ssize_t r = pread(j->fd, j->dst + got, j->len - got, (off_t)(j->off + got)); if (r <= 0) break; got += (uint64_t)r; }
+  j->ok = got == j->len; return 0;
+}
+static int read_parallel(int fd, char *dst, uint64_t off, uint64_t len) {
+  enum { T = 4 };
+  ReadJob job[T]; pthread_t th[T]; int started[T] = {0};
+  const uint64_t per = len < (4u << 20) ? len : (((len + T - 1) / T) + 4095) & ~(uint64_t)4095;
+  int nj = 0;
+  for (uint64_t at = 0; at < len; at += per, ++nj) { job[nj].fd = fd; job[nj].dst = dst + at; job[nj].off = off + at; job[nj].len = len - at < per ? len - at : per; job[nj].ok = 0; }
+  for (int i = 1; i < nj; ++i) started[i] = pthread_create(&th[i], 0, read_job, &job[i]) == 0;
+  read_job(&job[0]);
+  int ok = job[0].ok;
+  for (int i = 1; i < nj; ++i) { if (started[i]) pthread_join(th[i], 0); else read_job(&job[i]); ok = ok && job[i].ok; }
+  return ok ? 0 : -1;
+}
+/* records [first, first + n) of the file into the context's image: the reference's fread loop (hash10x.c:202-209) as a pipeline — three page-locked
+   slabs; while one is on its way to the device (h10x_ingest_fqb_async) the next is read from the file. Without page-locked memory: one slab, one
+   copy at a time, as before. */
 static int stream_records(h10x_session *s, const char *path, uint64_t first, uint64_t n, int sharded) {
-  enum { SLAB = ((64 << 20) / 120) * 120 };                                          /* whole records per read */
+  enum { SLAB = ((16 << 20) / 120) * 120, NSLAB = 3 };                                /* whole records per read */
   int rc = 0;
+  struct timespec t0, t1, t2, t3; clock_gettime(CLOCK_MONOTONIC, &t0);
   const int fd = open(path, O_RDONLY);
-  char *slab = (char *)malloc(SLAB);
+  char *slab[NSLAB] = {0, 0, 0}; int pinned = 1;
+  for (int k = 0; k < NSLAB && pinned; ++k) if (!(slab[k] = (char *)h10x_pinned_alloc(SLAB))) pinned = 0;
+  if (!pinned) { for (int k = 0; k < NSLAB; ++k) { h10x_pinned_free(slab[k]); slab[k] = 0; } slab[0] = (char *)malloc(SLAB); }
   if (fd < 0) rc = fail(s, "failed to open fqb file %s", path);                       /* hash10x.c:1201 */
-  else if (!slab) rc = fail(s, "out of memory for a %d MiB read buffer", SLAB >> 20);
+  else if (!slab[0]) rc = fail(s, "out of memory for a %d MiB read buffer", SLAB >> 20);
   else if (h10x_ingest_reserve(s->ctx, n)) rc = fail_ctx(s);
   const uint64_t bytes = n * 120; uint64_t done = 0;
-  while (!rc && done < bytes) {
+  clock_gettime(CLOCK_MONOTONIC, &t1);
+  for (uint64_t k = 0; !rc && done < bytes; ++k) {
     const uint64_t want = bytes - done < SLAB ? bytes - done : SLAB;
-    uint64_t got = 0;
-    while (got < want) { const ssize_t r = pread(fd, slab + got, want - got, (off_t)(first * 120 + done + got)); if (r <= 0) break; got += (uint64_t)r; }
-    if (got != want) { rc = fail(s, "file read problem"); break; }                   /* hash10x.c:209 */
-    if (sharded ? h10x_shard_ingest_fqb(s->ctx, (const uint32_t *)slab, want / 120, 0) : h10x_ingest_fqb(s->ctx, (const uint32_t *)slab, want / 120, 0)) { rc = fail_ctx(s); break; }
+    const int slot = pinned ? (int)(k % NSLAB) : 0;
+    if (pinned && k >= NSLAB && h10x_ingest_wait(s->ctx, slot)) { rc = fail_ctx(s); break; }   /* the slab's earlier upload has landed */
+    if (read_parallel(fd, slab[slot], first * 120 + done, want)) { rc = fail(s, "file read problem"); break; }   /* hash10x.c:209 */
+    if (pinned ? h10x_ingest_fqb_async(s->ctx, (const uint32_t *)slab[slot], want / 120, slot)
+               : (sharded ? h10x_shard_ingest_fqb(s->ctx, (const uint32_t *)slab[0], want / 120, 0) : h10x_ingest_fqb(s->ctx, (const uint32_t *)slab[0], want / 120, 0))) { rc = fail_ctx(s); break; }
     done += want;
   }
   if (fd >= 0) close(fd);
-  free(slab);
+  if (pinned) { for (int k = 0; k < NSLAB; ++k) { h10x_ingest_wait(s->ctx, k); h10x_pinned_free(slab[k]); } } else free(slab[0]);
   if (sharded) { int allOk = 0; if (h10x_shard_agree(s->ctx, !rc, &allOk)) return fail_ctx(s); if (!allOk && !rc) rc = fail(s, "another rank failed to read its part of %s", path); }
   if (rc) { h10x_ingest_reserve(s->ctx, 0); return rc; }
+  clock_gettime(CLOCK_MONOTONIC, &t2);
   if (sharded ? h10x_shard_ingest_fqb(s->ctx, 0, 0, 1) : h10x_ingest_fqb(s->ctx, 0, 0, 1)) return fail_ctx(s);
+  clock_gettime(CLOCK_MONOTONIC, &t3);
+  if (getenv("H10X_INGEST_TIMING"))                                                    /* where a --readFQB spends its wall time */
+    fprintf(stderr, "  ingest of %.2f GB: buffers + image %.3f s, read + upload %.3f s (%.1f GB/s), hashing + index %.3f s\n", (double)bytes / 1e9,
+            (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec), (double)(t2.tv_sec - t1.tv_sec) + 1e-9 * (double)(t2.tv_nsec - t1.tv_nsec),
+            (double)bytes / 1e9 / ((double)(t2.tv_sec - t1.tv_sec) + 1e-9 * (double)(t2.tv_nsec - t1.tv_nsec) + 1e-9), (double)(t3.tv_sec - t2.tv_sec) + 1e-9 * (double)(t3.tv_nsec - t2.tv_nsec));
   return 0;
 }
 static int file_records(h10x_session *s, const char *path, uint64_t *n, int *cutByN) {
@@ -295,10 +330,24 @@ int h10x_session_clusterSplit(h10x_session *s) {
  * rank pwrites its share — a slice of each replicated table, and the blocks / ClusterHash records of its own segments at
  * their place in file order. One rank (unsharded) is the same code. Heap-pointer fields are written as 0.
  * ------------------------------------------------------------------------------------------------------------------- */
+typedef struct { int fd; const char *src; uint64_t at, len; int ok; } WriteJob;
+static void *write_job(void *a) {
+  WriteJob *j = (WriteJob *)a; uint64_t done = 0;
+  while (done < j->len) { const ssize_t w = pwrite(j->fd, j->src + done, j->len - done > (1u << 30) ? (1u << 30) : j->len - done, (off_t)(j->at + done)); if (w <= 0) break; done += (uint64_t)w; }
+  j->ok = done == j->len; return 0;
+}
+/* n bytes to the file at `at`, on a few threads when there are many (a single pwrite copies into the page cache at a few GB/s) */
 static int put(int fd, const void *p, uint64_t n, uint64_t at) {
-  const char *c = (const char *)p;
-  while (n) { const ssize_t w = pwrite(fd, c, n > (1u << 30) ? (1u << 30) : n, (off_t)at); if (w <= 0) return -1; c += w; at += (uint64_t)w; n -= (uint64_t)w; }
-  return 0;
+  enum { T = 4 };
+  WriteJob job[T]; pthread_t th[T]; int started[T] = {0};
+  const uint64_t per = n < (4u << 20) ? (n ? n : 1) : (((n + T - 1) / T) + 4095) & ~(uint64_t)4095;
+  int nj = 0;
+  for (uint64_t o = 0; o < n; o += per, ++nj) { job[nj].fd = fd; job[nj].src = (const char *)p + o; job[nj].at = at + o; job[nj].len = n - o < per ? n - o : per; job[nj].ok = 0; }
+  for (int i = 1; i < nj; ++i) started[i] = pthread_create(&th[i], 0, write_job, &job[i]) == 0;
+  int ok = 1;
+  if (nj) { write_job(&job[0]); ok = job[0].ok; }
+  for (int i = 1; i < nj; ++i) { if (started[i]) pthread_join(th[i], 0); else write_job(&job[i]); ok = ok && job[i].ok; }
+  return ok ? 0 : -1;
 }
 /* elements [first, first + count) of a device table to the file at byte `at`, through a bounded host buffer */
 static int put_table(h10x_session *s, int fd, int table, size_t elem, uint64_t first, uint64_t count, uint64_t at, void *buf, size_t bufBytes, const char *what) {
@@ -320,7 +369,8 @@ int h10x_session_writeHash(h10x_session *s, const char *path) {
   const uint64_t depthDim = (uint64_t)s->depthDim, blocksDim = (uint64_t)s->blocksDim > z.nBlocksGlobal ? (uint64_t)s->blocksDim : z.nBlocksGlobal;
   const uint64_t oIndex = 16, oNumber = oIndex + 4 * T, oValue = oNumber + 4, oDepthHdr = oValue + 8 * (uint64_t)z.hashNumber, oDepth = oDepthHdr + 32,
                  oBlocksHdr = oDepth + 4 * depthDim, oBlocks = oBlocksHdr + 32, oClus = oBlocks + 32 * blocksDim, total = oClus + 8 * z.nEntriesGlobal;
-  int fd = -1, rc = 0; enum { BUF = 32 << 20 }; void *buf = malloc(BUF);
+  int fd = -1, rc = 0; enum { BUF = 32 << 20 }; int bufPinned = 1; void *buf = h10x_pinned_alloc(BUF);   /* page-locked: the slices come off the device at DMA speed */
+  if (!buf) { bufPinned = 0; buf = malloc(BUF); }
   h10x_shard_seg *segs = (h10x_shard_seg *)calloc((size_t)z.nSegs + 1, sizeof *segs);
   /* (a failure of one rank up to here is carried into the agreement below: nobody skips a collective) */
   if (!buf || !segs) rc = fail(s, "out of host memory for .hash export");
@@ -368,7 +418,8 @@ int h10x_session_writeHash(h10x_session *s, const char *path) {
   }
 done:
   if (fd >= 0) close(fd);
-  free(buf); free(segs);
+  if (bufPinned) h10x_pinned_free(buf); else free(buf);
+  free(segs);
   return rc;
 }
 

@@ -98,6 +98,15 @@ int  h10x_read_fqb(h10x_ctx *ctx, const uint32_t *host_records, uint64_t n_recor
    gives up an ingest that will not be closed. */
 int  h10x_ingest_reserve(h10x_ctx *ctx, uint64_t n_records_total);
 int  h10x_ingest_fqb(h10x_ctx *ctx, const uint32_t *host_records, uint64_t n_records, int final_chunk);
+/* The same as a pipeline (round 4): the chunk lies in page-locked memory from h10x_pinned_alloc and its upload is only QUEUED — the call returns
+   while the DMA runs, so the caller reads the next chunk of the file into another buffer meanwhile (hash10x.c:202-209's fread loop, with the file
+   read and the PCIe transfer side by side). The buffer must not be touched until h10x_ingest_wait(ctx, slot) has returned for the slot (0..7)
+   the chunk was queued under. The ingest is closed as before, by h10x_ingest_fqb / h10x_shard_ingest_fqb with final_chunk = 1 (which waits for
+   every queued upload). */
+void *h10x_pinned_alloc(size_t bytes);
+void  h10x_pinned_free(void *p);
+int  h10x_ingest_fqb_async(h10x_ctx *ctx, const uint32_t *pinned_records, uint64_t n_records, int slot);
+int  h10x_ingest_wait(h10x_ctx *ctx, int slot);
 int  h10x_read_fqb_device(h10x_ctx *ctx, const uint32_t *dev_records, uint64_t n_records);
 
 /* replaces the external record sort between fq2b and hash10x (README.md:26 `bsort -k 4 -r 120 x.fqb`): orders the
@@ -288,7 +297,7 @@ typedef struct {
   uint64_t sum_hash_clustered; /* sum nHash over barcodes with good hashes          */
   uint64_t fallback_blocks;  /* barcodes that took the global-memory path in stage A */
   uint64_t cluster_class_counts[4]; /* barcodes clustered in: half-CU LDS with 1024 lanes, half-CU LDS with 512 lanes, full-CU LDS (512 lanes), HBM scratch */
-  uint64_t cluster_first_mode;     /* placement of the first[] table: 0 dense in LDS, 1 ranked (bitmap) in LDS, 2 per-workgroup HBM slot */
+  uint64_t cluster_first_mode;     /* placement of the first[] table: 0 dense in LDS, 1 ranked (bitmap) in LDS, 2 per-workgroup HBM slot, 4 translated (16-bit handles into a table in LDS) */
   uint64_t cluster_overflow_blocks; /* ranked placement: barcodes re-run on the HBM path because too many barcodes were present */
   uint64_t cluster_main[4];        /* work of the main cluster launch alone (timer "cluster_main"): good hashes, gathered list entries, nHash, barcodes */
   uint64_t cluster_phase_ticks[8]; /* diagnostic (option "cluster_stamps"): 100 MHz ticks per phase summed over workgroups:
@@ -303,7 +312,6 @@ int  h10x_get_counters(h10x_ctx *ctx, h10x_counters *out);
    cluster kernel at 2 bytes per entry in every block, w >= 2 = 4 bytes down to w list-loop waves (default 0: 4 bytes where that
    costs no wave); "cluster_lds_budget", "cluster_first_global", "cluster_first_cap", "cluster_big_ranks", "cluster_threads0",
    "cluster_budget0" (placement and launch-class overrides of the tests), "cluster_stamps" (phase stamps into h10x_counters),
-   "cluster_dbg_skip" (what-if timing switches, honoured only by a library built with -DH10X_DBG_SKIP: results are then wrong),
    "shard_row_shift", "shard_rows_fake_base" (sharded list offsets beyond 32 bits on small inputs), "shard_delta_lists" (-1 default:
    the in-range barcode lists travel delta-coded when there is more than one rank; 0 never; 1 always). Unknown name: -1. */
 int  h10x_set_option(h10x_ctx *ctx, const char *name, int64_t value);

@@ -8,7 +8,6 @@ recs = bench.generate(wl, wl["seed"])
 d = hash10x_amd.DeviceRecords(recs); del recs
 h = hash10x_amd.Hash10x(B=wl["B"])
 if os.environ.get("H10X_FIRST_GLOBAL"): h.set_option("cluster_first_global", int(os.environ["H10X_FIRST_GLOBAL"]))
-if os.environ.get("H10X_DBG_SKIP_OPT"): h.set_option("cluster_dbg_skip", int(os.environ["H10X_DBG_SKIP_OPT"]))
 for it in range(int(os.environ.get("STEPS", "2"))):
     h.read_fqb_device(d.ptr, d.n_records); h.depth_range(wl["lo"], wl["hi"]); h.cluster(1, 0, wl["ct"])
 print("done", h.sizes(), h.counters()["cluster_first_mode"], h.counters()["cluster_class_counts"])

@@ -1,6 +1,6 @@
 """BASELINE configs[2] at its own size on ONE GPU (gen_fqb v2 set: 200 M pairs, 1 M barcodes, 500 Mb x 2, -B 29 — the set whose reference digest is in
 tests/golden/manifest.json "full_digest_cases"): per-command wall time, per-kernel device time, cluster classes, phase shares.
-   python scratch/r3_full.py [passes] [stamps]          env H10X_FIRST_GLOBAL = 2 ranked / 3 hashed placement override"""
+   python scratch/full_step.py [passes] [stamps]          env H10X_FIRST_GLOBAL = 2 ranked / 3 hashed placement override"""
 import sys, os, time, json, threading
 R = os.environ.get("GRAFT_REPO_ROOT", "/root/repo")
 sys.path.insert(0, R)

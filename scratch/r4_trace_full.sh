@@ -1,9 +1,9 @@
 #!/bin/bash
-# kernel trace of the full-size config-3 run (scratch/r3_full.py <passes>): durations of everything --cluster launches
+# kernel trace of the full-size config-3 run (scratch/full_step.py <passes>): durations of everything --cluster launches
 export TMPDIR=/tmp
 TAG=$1; shift
 rm -rf gpurun_out/${TAG}_trace
-rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${TAG}_trace -o runc -- python3 scratch/r3_full.py "$@" > gpurun_out/${TAG}_trace.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${TAG}_trace -o runc -- python3 scratch/full_step.py "$@" > gpurun_out/${TAG}_trace.log 2>&1
 python3 - <<PY
 import csv, glob
 f = glob.glob("gpurun_out/${TAG}_trace/**/*kernel_trace.csv", recursive=True)[0]

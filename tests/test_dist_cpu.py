@@ -93,3 +93,53 @@ def test_rccl_unique_id_rendezvous_three_ranks(tmp_path):
         so, se = p.communicate(timeout=120)
         assert p.returncode == 0, se.decode()[-1500:]
         assert so.decode().startswith("ok")
+
+
+STRONG_WORKER = r"""
+import os, sys, json
+import numpy as np
+import torch, torch.distributed as dist
+sys.path.insert(0, os.environ["H10X_REPO"]); sys.path.insert(0, os.path.join(os.environ["H10X_REPO"], "tests"))
+import bench
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+wl = dict(pairs=6000, barcodes=40, genome=60000, err=0.001, mol=3.0, snp=150, mol_len=4000.0)
+mine, first, total = bench.generate_v2(wl, 3, rank, world)          # strong scaling: the SAME set, every rank builds only its shard
+n = mine.size // 30
+# a composable checksum over the shard's records at their place in the whole set: what bench.py sums over the ranks for its parity gate
+cs = bench.checksum_words(mine.view(np.uint64), first * 15, 7, slice_words=1000)
+t = torch.tensor([n, first] + [c >> 32 for c in cs] + [c & 0xFFFFFFFF for c in cs], dtype=torch.int64)
+allv = [torch.zeros_like(t) for _ in range(world)]
+dist.all_gather(allv, t)
+dist.barrier()
+if rank == 0:
+    whole, f0, tot = bench.generate_v2(wl, 3)
+    ref = bench.checksum_words(whole.view(np.uint64), 0, 7)
+    summed = [sum(((int(v[2 + k]) << 32) | int(v[4 + k])) for v in allv) & 0xFFFFFFFFFFFFFFFF for k in range(2)]
+    starts = [int(v[1]) for v in allv]; counts = [int(v[0]) for v in allv]
+    print(json.dumps({"pairs": tot, "whole": whole.size // 30, "counts": counts, "starts": starts, "sum_ok": summed == ref,
+                      "serial_ok": bench.checksum_words(whole.view(np.uint64), 0, 7, slice_words=777) == ref}))
+dist.destroy_process_group()
+"""
+
+
+def test_strong_scaling_shards_of_one_set_add_up(tmp_path):
+    """bench.py --scaling strong: the ranks generate disjoint, contiguous shards of ONE fixed generator-v2 set (not N copies of a set), and the
+    composable checksum the parity gate sums over the ranks equals the one of the whole set — here over the records, two ranks on gloo."""
+    import json
+    orc.build_gen()
+    subprocess.run(["gcc", "-O2", "-ffp-contract=off", "-fopenmp", "-fPIC", "-shared", "-DH10X_GEN_NO_MAIN", "-o", os.path.join(orc.REPO, "build", "libgen_fqb.so"),
+                    os.path.join(orc.REPO, "hash10x_amd", "tools", "gen_fqb.c"), "-lm"], check=True)
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    wf = tmp_path / "strong_worker.py"
+    wf.write_text(STRONG_WORKER)
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), H10X_REPO=orc.REPO, OMP_NUM_THREADS="1")
+        procs.append(subprocess.Popen([sys.executable, str(wf)], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE))
+    outs = [p.communicate(timeout=300) for p in procs]
+    for p, (so, se) in zip(procs, outs):
+        assert p.returncode == 0, se.decode()[-2000:]
+    res = json.loads(outs[0][0].decode().strip().splitlines()[-1])
+    assert res["whole"] == res["pairs"] == sum(res["counts"]) and res["starts"] == [0, res["counts"][0]]
+    assert res["sum_ok"] and res["serial_ok"]

@@ -773,12 +773,12 @@ def test_config3_proportions_match_reference_digests(case, tmp_path_factory, wor
     assert z["hashNumber"] == case["hash_number"] and z["nBlocks"] == case["blocks_max"] and z["nClusHash"] == case["sum_nHash"]
     assert c["cluster_first_mode"] == 1
     h.write_hash(workdir.file("big.hash"))
-    if case["gen"]["barcodes"] > 262144:                      # the hashed placement on the same state
+    if case["gen"]["barcodes"] > 262144:                      # the translated placement (what a million barcodes get) on the same state
         first = hashlib.sha256(h.export_blocks().tobytes() + h.export_clushash().tobytes()).hexdigest()
-        h.set_option("cluster_first_global", 3)
+        h.set_option("cluster_first_global", 4)
         h.depth_range(int(a[1]), int(a[2]))
         h.cluster(int(a[4]), int(a[5]), 5)
-        assert h.counters()["cluster_first_mode"] == 3
+        assert h.counters()["cluster_first_mode"] == 4
         assert hashlib.sha256(h.export_blocks().tobytes() + h.export_clushash().tobytes()).hexdigest() == first
     h.close()
     sha = hashlib.sha256()
