@@ -1063,7 +1063,9 @@ __device__ __forceinline__ void cluster_one_block_tr(const ClusterArgs &a, u32 c
     u32 c0N[RIF], c1N[RIF];
     // (no lane skips a load and none looks at the list's length: rows[] has ROWS_PAD entries of slack, what lies behind a list's end is told
     // apart when the chunk is used — see descLoadU)
-#define TR_LOAD_C(DV) { _Pragma("unroll") for (int t = 0; t < RIF; ++t) { const u32 *row = ROWP((u32)__builtin_amdgcn_readlane((int)DV, t)); c0N[t] = row[laneU]; c1N[t] = row[WAVE + laneU]; } }
+    // (a list without a second chunk asks for its first one again: a load that is always issued, yet no bytes from HBM that nobody looks at)
+#define TR_LOAD_C(DV) { _Pragma("unroll") for (int t = 0; t < RIF; ++t) { const u32 *row = ROWP((u32)__builtin_amdgcn_readlane((int)DV, t)); c0N[t] = row[laneU]; \
+      c1N[t] = row[((u32)__builtin_amdgcn_readlane((int)DV, 32 + t) > (u32)WAVE ? (u32)WAVE : 0u) + laneU]; } }
     TR_LOAD_C(dvN)
     for (u32 i0 = uwave * RIF;; i0 += stepA) {
       const bool last = i0 >= n;                             // one more turn behind the last round: the queue's remainder (ONE copy of the search loop in the code)
@@ -1184,14 +1186,14 @@ __device__ __forceinline__ void cluster_one_block_tr(const ClusterArgs &a, u32 c
     const u32 laneU = (u32)lane;
     u32 hN[RIF], h2N[RIF], hNN[RIF];
     u32 dvCur, dvN, dvNN, dvD;
-    // the handles of a list's two chunks: all 64 lanes, no test (pass A wrote every lane of a chunk the list has; a second chunk the list
-    // has not reads whatever lies there and is not looked at)
+    // the handles of a list's two chunks: all 64 lanes, no test (pass A wrote every lane of a chunk the list has)
 #define TR_LOAD_A(H, I0) { _Pragma("unroll") for (int t = 0; t < RIF; ++t) { const u32 ic = (I0) + t < n ? (I0) + t : n - 1; H[t] = (hs + ((size_t)ic << lgH))[laneU]; } }
-#define TR_LOAD_B(H2, I0) { _Pragma("unroll") for (int t = 0; t < RIF; ++t) { const u32 ic = (I0) + t < n ? (I0) + t : n - 1; H2[t] = (hs + ((size_t)ic << lgH))[WAVE + laneU]; } }
+#define TR_LOAD_B(H2, I0, DV) { _Pragma("unroll") for (int t = 0; t < RIF; ++t) { const u32 ic = (I0) + t < n ? (I0) + t : n - 1; \
+      H2[t] = (hs + ((size_t)ic << lgH))[((u32)__builtin_amdgcn_readlane((int)DV, 32 + t) > (u32)WAVE ? (u32)WAVE : 0u) + laneU]; } }   /* (no second chunk: the first again, from the caches) */
     const u32 iw = listWave ? uwave * RIF : n;
     dvN = descFix(descLoadU(gr, iw, n), iw, RIF, n); dvNN = descLoadU(gr, listWave ? iw + stepR : n, n); dvD = descLoadU(gr, listWave ? iw + 2 * stepR : n, n);   // (dvNN, dvD: raw)
     TR_LOAD_A(hN, iw)
-    TR_LOAD_B(h2N, iw)
+    TR_LOAD_B(h2N, iw, dvN)
     TR_LOAD_A(hNN, listWave ? iw + stepR : n)
     for (u32 r0 = 0; r0 < n; r0 += stepR) {
       const u32 i0 = listWave ? r0 + uwave * RIF : n;
@@ -1200,7 +1202,7 @@ __device__ __forceinline__ void cluster_one_block_tr(const ClusterArgs &a, u32 c
 #pragma unroll
       for (int t = 0; t < RIF; ++t) { h[t] = hN[t]; h2[t] = h2N[t]; hN[t] = hNN[t]; dl[t] = (u32)__builtin_amdgcn_readlane((int)dvCur, 32 + t); }
       dvD = descLoadU(gr, listWave ? i0 + 3 * stepR : n, n);
-      TR_LOAD_B(h2N, listWave ? i0 + stepR : n)
+      TR_LOAD_B(h2N, listWave ? i0 + stepR : n, dvN)
       TR_LOAD_A(hNN, listWave ? i0 + 2 * stepR : n)
       u32 rootV = 0; u64 resV = 0;                           // the results of the round's lists, list t in lane t: one LDS and one HBM store per round
 #pragma unroll

@@ -338,42 +338,46 @@ def main():
     # set from <dir> (g3.fqb + g3.ref.hash, made there by bigdata/run_g3.sh: build/gen_fqb -v 2 ... and oracle/_ref/hash10x_omp -t 8 -B 30; 36 + 24 GB,
     # about an hour in the build container) and commits its sizes, the sha256 of its canonical form and the composable checksum of bench.checksum_state
     # over all blocks and ClusterHash records — what `bench.py --workload genome3g-300M --gpus N` sums over its ranks.
-    if "--g3" in sys.argv:
+    try:
+        with open(os.path.join(HERE, "manifest.json")) as f:
+            man["strong_digests"] = json.load(f).get("strong_digests", {})
+    except OSError:
+        man["strong_digests"] = {}
+    if "--g3" in sys.argv:                                   # (a set whose files are not in <dir> keeps its committed entry; "--only <workload>" limits the run to one)
         import hashlib
         sys.path.insert(0, orc.REPO)
         import bench
         d = sys.argv[sys.argv.index("--g3") + 1]
-        wl = bench.WORKLOADS["genome3g-300M"]
-        fq = np.memmap(os.path.join(d, "g3.fqb"), dtype=np.uint32, mode="r")
-        assert fq.size == 30 * wl["pairs"]
-        path = os.path.join(d, "g3.ref.hash")
-        digest, info = orc.canonical_file_digest(path)
-        off_depth = 16 + (4 << info["B"]) + 4 + 8 * info["hash_number"]                       # ArrayStruct of hashDepth: its dim at +16
-        with open(path, "rb") as f:
-            f.seek(off_depth + 16); depth_dim = int.from_bytes(f.read(4), "little")
-        off_blocks = off_depth + 32 + 4 * depth_dim + 32                                       # behind the ArrayStruct of clusterBlocks
-        blocks = np.fromfile(path, dtype=np.uint8, count=32 * (info["blocks_max"] - 1), offset=off_blocks + 32)      # slot 0 is nobody's block
-        cs = bench.checksum_state(blocks, 1, np.zeros(0, dtype=np.uint8), 0)
-        off_ch = off_blocks + 32 * info["blocks_dim"]
-        for a in range(0, info["sum_nHash"], 1 << 27):
-            ch = np.fromfile(path, dtype=np.uint8, count=8 * min(1 << 27, info["sum_nHash"] - a), offset=off_ch + 8 * a)
-            part = bench.checksum_state(np.zeros(0, dtype=np.uint8), 0, ch, a)
-            cs = [(cs[0] + part[0]) & 0xFFFFFFFFFFFFFFFF, (cs[1] + part[1]) & 0xFFFFFFFFFFFFFFFF]
-        man["strong_digests"] = {"genome3g-300M": {
-            "gen2": {k: wl[k] for k in ("pairs", "barcodes", "genome", "err", "seed", "mol", "snp", "mol_len")}, "B": wl["B"],
-            "args": ["--hashDepthRange", str(wl["lo"]), str(wl["hi"]), "--cluster", "1", "0"],
-            "input": {"head_sha256": hashlib.sha256(fq[: 30 << 20].tobytes()).hexdigest(), "tail_sha256": hashlib.sha256(fq[-(30 << 20):].tobytes()).hexdigest()},
-            "sha256": digest, "size": info["size"], "hash_number": info["hash_number"], "blocks_max": info["blocks_max"], "sum_nHash": info["sum_nHash"],
-            "sum_nSubCluster": info["sum_nSubCluster"], "checksum": ["0x%016x" % v for v in cs],
-            "note": "300 M pairs is what the build container's 62 GB of RAM hold of the reference's run (its own cap, 2^28 - 2 distinct hashes at -B 30, would allow ~380 M pairs on 3 Gb x 2)",
-            "reference": "oracle/_ref/hash10x_omp -t 8 -B 30 --readFQB g3.fqb --hashDepthRange %d %d --cluster 1 0 --writeHash g3.ref.hash (MALLOC_PERTURB_=255, tcache off); "
-                         "gen: build/gen_fqb -v 2 -P 300000000 -C 1600000 -G 3000000000 -e 0.0005 -s 3" % (wl["lo"], wl["hi"])}}
-    else:
-        try:
-            with open(os.path.join(HERE, "manifest.json")) as f:
-                man["strong_digests"] = json.load(f).get("strong_digests", {})
-        except OSError:
-            man["strong_digests"] = {}
+        only = sys.argv[sys.argv.index("--only") + 1] if "--only" in sys.argv else None
+        for name, stem, note in (("genome3g-300M", "g3", "300 M pairs is what the build container's 62 GB of RAM hold of the reference's run (peak RSS 43.8 GB; its own cap, 2^28 - 2 distinct hashes at -B 30, "
+                                                         "would allow ~380 M pairs on 3 Gb x 2); 42 minutes: readFQB 28 min, hashDepthRange 6 min, cluster 3161 CPU-s on 8 threads"),
+                                 ("genome3g-tenth-30M", "g3t", "the same proportions at 1/10: the functional check of bench.py --scaling strong on test boxes")):
+            path = os.path.join(d, stem + ".ref.hash")
+            if not os.path.exists(path) or (only and only != name):
+                continue
+            wl = bench.WORKLOADS[name]
+            fq = np.memmap(os.path.join(d, stem + ".fqb"), dtype=np.uint32, mode="r")
+            assert fq.size == 30 * wl["pairs"]
+            digest, info = orc.canonical_file_digest(path)
+            off_depth = 16 + (4 << info["B"]) + 4 + 8 * info["hash_number"]                       # ArrayStruct of hashDepth: its dim at +16
+            with open(path, "rb") as f:
+                f.seek(off_depth + 16); depth_dim = int.from_bytes(f.read(4), "little")
+            off_blocks = off_depth + 32 + 4 * depth_dim + 32                                       # behind the ArrayStruct of clusterBlocks
+            blocks = np.fromfile(path, dtype=np.uint8, count=32 * (info["blocks_max"] - 1), offset=off_blocks + 32)      # slot 0 is nobody's block
+            cs = bench.checksum_state(blocks, 1, np.zeros(0, dtype=np.uint8), 0)
+            off_ch = off_blocks + 32 * info["blocks_dim"]
+            for a in range(0, info["sum_nHash"], 1 << 27):
+                ch = np.fromfile(path, dtype=np.uint8, count=8 * min(1 << 27, info["sum_nHash"] - a), offset=off_ch + 8 * a)
+                part = bench.checksum_state(np.zeros(0, dtype=np.uint8), 0, ch, a)
+                cs = [(cs[0] + part[0]) & 0xFFFFFFFFFFFFFFFF, (cs[1] + part[1]) & 0xFFFFFFFFFFFFFFFF]
+            man["strong_digests"][name] = {
+                "gen2": {k: wl[k] for k in ("pairs", "barcodes", "genome", "err", "seed", "mol", "snp", "mol_len")}, "B": wl["B"],
+                "args": ["--hashDepthRange", str(wl["lo"]), str(wl["hi"]), "--cluster", "1", "0"],
+                "input": {"head_sha256": hashlib.sha256(fq[: min(fq.size, 30 << 20)].tobytes()).hexdigest(), "tail_sha256": hashlib.sha256(fq[-min(fq.size, 30 << 20):].tobytes()).hexdigest()},
+                "sha256": digest, "size": info["size"], "hash_number": info["hash_number"], "blocks_max": info["blocks_max"], "sum_nHash": info["sum_nHash"],
+                "sum_nSubCluster": info["sum_nSubCluster"], "checksum": ["0x%016x" % v for v in cs], "note": note,
+                "reference": "oracle/_ref/hash10x_omp -t 8 -B %d --readFQB %s.fqb --hashDepthRange %d %d --cluster 1 0 --writeHash %s.ref.hash (MALLOC_PERTURB_=255, tcache off); "
+                             "gen: build/gen_fqb -v 2 -P %d -C %d -G %d -e %g -s %d" % (wl["B"], stem, wl["lo"], wl["hi"], stem, wl["pairs"], wl["barcodes"], wl["genome"], wl["err"], wl["seed"])}
     man["big_note"] = ("big_digest_cases: BASELINE configs[2] proportions at 1/10 and 1/4 scale, generated by `make_golden.py --big` from "
                        "oracle/_ref (4.5 and 12.5 minutes of the reference); only the GPU tests run them")
     with open(os.path.join(HERE, "manifest.json"), "w") as f:

@@ -1025,8 +1025,30 @@ def test_bench_with_two_ranks_carries_a_parity_gate(workdir):
     assert outs[1][0].decode().strip() == ""                # one JSON line, on rank 0
 
 
+@pytest.mark.skipif("genome3g-tenth-30M" not in MAN.get("strong_digests", {}), reason="no strong-scaling digest in the manifest")
+@pytest.mark.parametrize("world", [1, 2])
+def test_bench_strong_scaling_on_one_fixed_set(workdir, world):
+    """bench.py --workload genome3g-tenth-30M --scaling strong (the 3 Gb workload of BASELINE configs[3] at 1/10: the same proportions and depth range): the SAME
+    30 M-pair set on one rank and on two (socket backend: both share this box's GPU; every rank generates only its shard), and in both cases the line's checksum
+    of all blocks and ClusterHash records equals the one of the REFERENCE binary's .hash of that set (manifest "strong_digests", make_golden.py --g3)."""
+    import subprocess, sys
+    port = 34000 + os.getpid() % 2000
+    ps = []
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        ps.append(subprocess.Popen([sys.executable, os.path.join(orc.REPO, "bench.py"), "--workload", "genome3g-tenth-30M", "--gpus", str(world), "--comm", "socket", "--steps", "1", "--warmup", "1",
+                                    "--no-secondary"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env, cwd=workdir.path))
+    outs = [p.communicate(timeout=900) for p in ps]
+    for p, (so, se) in zip(ps, outs):
+        assert p.returncode == 0, se.decode()[-1500:]
+    line = json.loads(outs[0][0].decode().strip().splitlines()[-1])
+    assert line["n_gpus"] == world and line["scaling"] == "strong" and line["config"]["read_pairs"] == 30000000 and line["config"]["workload"] == "genome3g-tenth-30M"
+    assert line["parity_vs_reference_digest"] == "identical", line
+
+
 def test_cli_streams_files_larger_than_one_slab(workdir):
-    """bin/hash10x-amd reads the .fqb in 64 MiB slabs through h10x_ingest_fqb: a file of more than one slab (72 MB; the slab is a whole
+    """bin/hash10x-amd reads the .fqb in 16 MiB page-locked slabs through h10x_ingest_fqb_async (three in flight: the file read beside the
+    uploads): a file of several slabs (72 MB; a slab is a whole
     number of 120-byte records, which a round-3 build got wrong — bench.py's end-to-end check caught it) gives the bytes of the library
     path on the same records, on one GPU and on 2 shards (every shard's range larger or smaller than a slab)."""
     import subprocess
