@@ -356,6 +356,7 @@ __device__ __forceinline__ void min_u16(u16 *arr, u32 idx, u32 val) {
 // leaves the room (minimum = one fire-and-forget ds_min_u32, no loop), the u16 of the CAS-min otherwise. The list loop is
 // bound by scalar and branch instructions (0.8 per CU cycle), and the CAS loop is mostly those.
 template <bool FIRST_LDS> struct FirstDense {
+  static constexpr bool MASK_TAIL = false;
   static constexpr bool SELF = true;                          // a lane without an entry (and the barcode's own number) keeps the barcode's own slot as its handle: first[] of the barcode
                                                              // itself is never written and reads "unseen", so the read-back needs no test and no exec mask
   u32 none;                                                  // (the barcode's own number: set per barcode)
@@ -373,6 +374,7 @@ template <bool FIRST_LDS> struct FirstDense {
 };
 struct FirstRanked {
   static constexpr bool SELF = false;
+  static constexpr bool MASK_TAIL = false;
   u16 *first; const u32 *bm; const u16 *pre; u32 wide;
   u32 none;                                                  // handle of a lane without an entry: one slot behind the last barcode present, always unseen
   __device__ __forceinline__ u32 at(u32 cj) const { const u32 w = cj >> 5; return pre[w] + (u32)__popc(bm[w] & ((1u << (cj & 31)) - 1u)); }
@@ -464,6 +466,7 @@ struct SlotTable {
 };
 struct FirstSlots {                                          // pass B: first[] by handle
   static constexpr bool SELF = false;
+  static constexpr bool MASK_TAIL = true;                    // lanes past a list's end hold a real handle (clamped loads)
   const unsigned char *base; u32 sh;                         // value of slot h: the u16 at base + (h << sh) — sh = 1 after the compaction, 2 (base at the words' high halves) without
   u32 none;
   __device__ __forceinline__ u32 peek(u32 h) const { return *(const u16 *)(base + (u32)(h << sh)); }
@@ -555,7 +558,9 @@ __device__ __forceinline__ void row_mode_hist(const void *__restrict__ row /* en
     if ((u32)(r * WAVE) < d) {
       const u32 j = r * WAVE + lane;
       if (r < 2) {
-        f[r] = ft.peek(r == 0 ? f0 : f1); ok[r] = f[r] < i;   // (f0 / f1 are handles: a lane without an entry holds one that reads "unseen")
+        f[r] = ft.peek(r == 0 ? f0 : f1);                     // (f0 / f1 are handles: a lane without an entry holds one that reads "unseen" — or, FirstSlots, the list's
+        if (FT::MASK_TAIL && j >= d) f[r] = NONE16;           //  last handle again: told apart here)
+        ok[r] = f[r] < i;
       }
       else if (j < d) { f[r] = ft.entry(row, j, code); ok[r] = f[r] < i; }
       tot += (u32)__popcll(__ballot(ok[r]));
@@ -1042,13 +1047,13 @@ __device__ __forceinline__ void cluster_one_block_tr(const ClusterArgs &a, u32 c
     bool insert = true;                                      // (uniform) the table takes new barcodes: looked up once per round
     u32 myIns = 0;                                           // barcodes this wave put into the table since it last said so
     const u32 laneU = (u32)lane;
-    // one chunk: 64 entries of list i -> 64 handles at hl[0..63] (position dest0 on the slot). Every lane stores — `none` past the list's
-    // end and for the barcode itself, a guess where the search is not over: the queue brings the real one
+    // one chunk: up to 64 entries of list i -> their handles at hl[0..] (position dest0 on the slot): `none` for the barcode itself, a guess where the
+    // search is not over (the queue brings the real one)
     auto place = [&](u32 cj, u32 i, u32 drem /* entries of the list from this chunk on */, u16 *hl, u32 dest0) {
       const bool valid = laneU < drem && cj != code;
       u32 slot; bool ins;
       const bool done = st.probeHome(cj, i, valid, insert, slot, ins);
-      hl[laneU] = (u16)(valid ? slot : S);
+      if (laneU < drem) hl[laneU] = (u16)(valid ? slot : S);   // (only lanes with an entry: a chunk's line is written as far as the list goes)
       myIns += (u32)__popcll(__ballot(ins));
       const u64 bal = __ballot(!done);
       if (bal) {
@@ -1187,14 +1192,15 @@ __device__ __forceinline__ void cluster_one_block_tr(const ClusterArgs &a, u32 c
     u32 hN[RIF], h2N[RIF], hNN[RIF];
     u32 dvCur, dvN, dvNN, dvD;
     // the handles of a list's two chunks: all 64 lanes, no test (pass A wrote every lane of a chunk the list has)
-#define TR_LOAD_A(H, I0) { _Pragma("unroll") for (int t = 0; t < RIF; ++t) { const u32 ic = (I0) + t < n ? (I0) + t : n - 1; H[t] = (hs + ((size_t)ic << lgH))[laneU]; } }
+#define TR_LOAD_A(H, I0, DV) { _Pragma("unroll") for (int t = 0; t < RIF; ++t) { const u32 ic = (I0) + t < n ? (I0) + t : n - 1; const u32 d = (u32)__builtin_amdgcn_readlane((int)DV, 32 + t), dm = d ? d - 1 : 0u; \
+      H[t] = (hs + ((size_t)ic << lgH))[laneU < dm ? laneU : dm]; } }   /* (a lane past the list's end reads the last handle again: no load is skipped, no byte moved that was not written) */
 #define TR_LOAD_B(H2, I0, DV) { _Pragma("unroll") for (int t = 0; t < RIF; ++t) { const u32 ic = (I0) + t < n ? (I0) + t : n - 1; \
-      H2[t] = (hs + ((size_t)ic << lgH))[((u32)__builtin_amdgcn_readlane((int)DV, 32 + t) > (u32)WAVE ? (u32)WAVE : 0u) + laneU]; } }   /* (no second chunk: the first again, from the caches) */
+      const u32 d = (u32)__builtin_amdgcn_readlane((int)DV, 32 + t), dm = d ? d - 1 : 0u, j = (d > (u32)WAVE ? (u32)WAVE : 0u) + laneU; H2[t] = (hs + ((size_t)ic << lgH))[j < dm ? j : dm]; } }   /* (no second chunk: the first again, from the caches) */
     const u32 iw = listWave ? uwave * RIF : n;
     dvN = descFix(descLoadU(gr, iw, n), iw, RIF, n); dvNN = descLoadU(gr, listWave ? iw + stepR : n, n); dvD = descLoadU(gr, listWave ? iw + 2 * stepR : n, n);   // (dvNN, dvD: raw)
-    TR_LOAD_A(hN, iw)
+    TR_LOAD_A(hN, iw, dvN)
     TR_LOAD_B(h2N, iw, dvN)
-    TR_LOAD_A(hNN, listWave ? iw + stepR : n)
+    TR_LOAD_A(hNN, listWave ? iw + stepR : n, dvNN)
     for (u32 r0 = 0; r0 < n; r0 += stepR) {
       const u32 i0 = listWave ? r0 + uwave * RIF : n;
       u32 h[RIF], h2[RIF], dl[RIF];
@@ -1203,7 +1209,7 @@ __device__ __forceinline__ void cluster_one_block_tr(const ClusterArgs &a, u32 c
       for (int t = 0; t < RIF; ++t) { h[t] = hN[t]; h2[t] = h2N[t]; hN[t] = hNN[t]; dl[t] = (u32)__builtin_amdgcn_readlane((int)dvCur, 32 + t); }
       dvD = descLoadU(gr, listWave ? i0 + 3 * stepR : n, n);
       TR_LOAD_B(h2N, listWave ? i0 + stepR : n, dvN)
-      TR_LOAD_A(hNN, listWave ? i0 + 2 * stepR : n)
+      TR_LOAD_A(hNN, listWave ? i0 + 2 * stepR : n, dvNN)
       u32 rootV = 0; u64 resV = 0;                           // the results of the round's lists, list t in lane t: one LDS and one HBM store per round
 #pragma unroll
       for (int t = 0; t < RIF; ++t) {
@@ -1270,7 +1276,7 @@ __device__ __forceinline__ void cluster_one_block_tr(const ClusterArgs &a, u32 c
         qv[t] = on ? (u32)root[ii[t]] : NONE16;
         dl[t] = on ? (u32)__builtin_amdgcn_readfirstlane((int)(u32)(gr[ii[t]] >> 32)) : 0u;
         const u16 *const hrow = hs + (size_t)ii[t] * hst;
-        hA[t] = dl[t] ? (u32)hrow[lane] : S; hB[t] = dl[t] > (u32)WAVE ? (u32)hrow[WAVE + lane] : S;
+        hA[t] = (u32)lane < dl[t] ? (u32)hrow[lane] : S; hB[t] = (u32)(WAVE + lane) < dl[t] ? (u32)hrow[WAVE + lane] : S;   // (only the list's own entries have a handle)
       }
 #pragma unroll
       for (int t = 0; t < RIF; ++t) {
