@@ -361,7 +361,7 @@ def cpu_baseline(wl, recs, workdir, gpu_hash_path):
             cli_same = open(os.path.join(workdir, "cli.hash"), "rb").read() == gpu_canon
             os.remove(os.path.join(workdir, "cli.hash"))
             e2e = {"command": "hash10x-amd -B %d --readFQB bench.fqb --hashDepthRange %d %d --cluster 1 0 --writeHash cli.hash" % (wl["B"], wl["lo"], wl["hi"]),
-                   "wall_seconds": best, "read_pairs_per_s": pairs / best, "includes": "process start, HIP context, file read (page cache) + H2D in 64 MB slabs, all kernels, D2H + file write of the .hash",
+                   "wall_seconds": best, "read_pairs_per_s": pairs / best, "includes": "process start, HIP context, file read (page cache, 4 reader threads) beside H2D from three 16 MiB page-locked slabs, all kernels, D2H + file write of the .hash",
                    "per_command_wall_seconds": walls, "reference_two_processes_wall_seconds": w_read + w_clu, "speedup_vs_reference_1thread": (w_read + w_clu) / best,
                    "reference_omp_wall_seconds": (o_read + o_clu) if omp else None, "hash_identical_to_library_path": cli_same}
         one["end_to_end"] = e2e
@@ -416,6 +416,10 @@ def full_config3_block(hash10x_amd, local_rank, steps=3):
     c = h.counters(); z = h.sizes()
     clu_ms = tm["cluster_kernel"][0] / steps
     alg = 4.0 * c["sum_good_depth"] + 14.0 * c["sum_good"] + 16.0 * c["sum_hash_clustered"]
+    try:
+        tr = profile_traffic("*config3full_pmc_traffic.json", "cluster_kernel")
+    except Exception:
+        tr = None
     out = {"workload": "config3-full-200M (BASELINE configs[2] at its own size: 200 M pairs, 1 M barcodes, 500 Mb x 2, e = 0.1 %%, -B 29; gen_fqb v2 seed %d)" % g["seed"],
            "ms_per_step": 1e3 * sum(wall) / len(wall), "read_pairs_per_s": pairs * len(wall) / sum(wall), "steps": steps,
            "device_ms_per_step": {k: round(v[0] / steps, 2) for k, v in tm.items() if v[0] > 0},
@@ -426,10 +430,32 @@ def full_config3_block(hash10x_amd, local_rank, steps=3):
            "roofline": {"bound": "hbm", "kernel": "all cluster launches", "achieved": alg / (clu_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": alg / (clu_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes": alg, "ms_per_step": clu_ms},
            "barcodes_per_s_clustered": wl["barcodes"] / (tm["cluster"][0] / steps * 1e-3),
+           "traffic": tr["traffic"] if tr else None, "traffic_of": "all cluster_kernel launches at full size", "traffic_raw": tr, "traffic_note": TRAFFIC_NOTE if tr else None,
+           "traffic_stale": (tr["traffic_build_id"] != hash10x_amd.build_id()) if tr else None,
            "generate_seconds": round(gen_s, 1), "upload_seconds": round(up_s, 2), "host_threads": os.cpu_count(),
            "parity": "tests/test_gpu_parity.py::test_config3_full_size_matches_reference_digest: the whole 15 GB .hash of this set has the reference binary's sha256"}
     h.close(); d.free()
     return out
+
+
+TRAFFIC_NOTE = ("HBM bytes per step from the committed rocprofv3 --pmc passes (FETCH_SIZE and WRITE_SIZE in passes of their own), corrected as MI355X_MICROARCH.md prescribes for gfx950: "
+                "FETCH_SIZE doubled — calibrated on this kernel's own access widths by scratch/cal_widths.hip (4-byte gathers of 256-byte pieces and contiguous 2-byte loads both read 1/2 of the "
+                "bytes fetched; a 256-byte piece at a random 4-byte alignment fetches 1.48 x its bytes) — WRITE_SIZE as it is (2-byte and 8-byte stores read exactly)")
+
+
+def profile_traffic(pattern, match, exclude=None):
+    """(corrected bytes per step, raw FETCH_SIZE, raw WRITE_SIZE, file, head, build id) of the kernels whose name contains `match` in the newest profiles/<pattern>"""
+    import glob
+    cands = sorted(f for f in glob.glob(os.path.join(REPO, "profiles", pattern)) if not exclude or exclude not in os.path.basename(f))
+    if not cands:
+        return None
+    pm = json.load(open(cands[-1]))
+    fetch = sum(v.get("FETCH_SIZE", {}).get("bytes_per_step", 0.0) for k, v in pm["kernels"].items() if match in k)
+    write = sum(v.get("WRITE_SIZE", {}).get("bytes_per_step", 0.0) for k, v in pm["kernels"].items() if match in k)
+    if not fetch and not write:
+        return None
+    return {"traffic": 2.0 * fetch + write, "raw_fetch_size": fetch, "raw_write_size": write, "traffic_source": os.path.basename(cands[-1]),
+            "traffic_head": pm.get("head"), "traffic_build_id": pm.get("build_id")}
 
 
 def genome3g_block(hash10x_amd, local_rank, steps=2):
@@ -516,17 +542,11 @@ def secondary_block(hash10x_amd, local_rank):
     alg = 4.0 * c["cluster_main"][1] + 14.0 * c["cluster_main"][0]        # (what the main launch moves: see the headline's cluster_main)
     clu_all_ms = tm["cluster_kernel"][0] / steps
     alg_all = 4.0 * c["sum_good_depth"] + 14.0 * c["sum_good"] + 16.0 * c["sum_hash_clustered"]
-    c3_traffic = c3_src = c3_head = c3_build = None          # rocprofv3 --pmc passes of this workload, committed under profiles/
+    tr = None                                                # rocprofv3 --pmc passes of this workload, committed under profiles/
     try:
-        import glob
-        cands = sorted(glob.glob(os.path.join(REPO, "profiles", "*config3*_pmc_traffic.json")))
-        if cands:
-            pm = json.load(open(cands[-1]))
-            tb = sum(sum(x["bytes_per_step"] for x in v.values()) for k, v in pm["kernels"].items() if pm.get("dominant", "cluster_kernel") in k)
-            if tb:
-                c3_traffic, c3_src, c3_head, c3_build = tb, os.path.basename(cands[-1]), pm.get("head"), pm.get("build_id")
+        tr = profile_traffic("*config3_pmc_traffic.json", "cluster_kernel")
     except Exception:
-        pass
+        tr = None
     out = {"workload": "config3-tenth-20M (BASELINE configs[2] proportions at 1/10: 20 M pairs, 100 k barcodes, 50 Mb x 2, e = 0.1 %, -B 26)",
            "ms_per_step": 1e3 * sum(wall) / len(wall), "read_pairs_per_s": pairs * len(wall) / sum(wall), "steps": steps,
            "device_ms_per_step": {k: round(v[0] / steps, 3) for k, v in tm.items() if v[0] > 0},
@@ -537,8 +557,9 @@ def secondary_block(hash10x_amd, local_rank):
                         "frac": alg / (main_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if main_ms else None, "algorithmic_bytes_per_launch": alg, "avg_launch_ms": main_ms,
                         "barcodes_in_launch": c["cluster_main"][3],
                         "all_cluster_launches": {"GB/s": alg_all / (clu_all_ms * 1e-3) / 1e9 if clu_all_ms else None, "ms_per_step": clu_all_ms, "algorithmic_bytes": alg_all}},
-           "generate_seconds": gen_s, "traffic": c3_traffic, "traffic_source": c3_src, "traffic_head": c3_head, "traffic_build_id": c3_build,
-           "traffic_stale": (c3_build != hash10x_amd.build_id()) if c3_traffic is not None else None,
+           "generate_seconds": gen_s, "traffic": tr["traffic"] if tr else None, "traffic_of": "all cluster_kernel launches (compare with all_cluster_launches.algorithmic_bytes less 16 H)",
+           "traffic_raw": tr, "traffic_note": TRAFFIC_NOTE if tr else None,
+           "traffic_stale": (tr["traffic_build_id"] != hash10x_amd.build_id()) if tr else None,
            "parity": "tests/test_gpu_parity.py::test_config3_proportions_match_reference_digests pins this exact set (sha256 of the reference binary's .hash)"}
     h.close(); d.free()
     return out
@@ -691,18 +712,14 @@ def main():
 
     # HBM traffic of the dominant kernel: PMC counters cannot be read from inside this process; the figure is the
     # one measured by the committed rocprofv3 --pmc passes (profiles/*_pmc_traffic.json), per step, raw counters
-    traffic = traffic_src = traffic_head = traffic_build = None
+    tr = None
     try:
-        import glob
-        cands = sorted(f for f in glob.glob(os.path.join(REPO, "profiles", "*_pmc_traffic.json")) if "config3" not in os.path.basename(f))
-        if cands and args.workload == "yeast-like-2.5M" and world == 1:
-            pm = json.load(open(cands[-1]))
-            tb = sum(sum(c["bytes_per_step"] for c in v.values()) for k, v in pm["kernels"].items() if (pm.get("dominant") or dom.split("_")[0]) in k)
-            if tb:
-                traffic, traffic_src = tb, os.path.basename(cands[-1])
-                traffic_head, traffic_build = pm.get("head"), pm.get("build_id")
+        if args.workload == "yeast-like-2.5M" and world == 1:
+            pm_match = "cluster_kernel<true, 0, 1024, 0>" if dom == "cluster_main" else dom.split("_")[0]
+            tr = profile_traffic("*_pmc_traffic.json", pm_match, exclude="config3")
     except Exception:
-        traffic = None
+        tr = None
+    traffic = tr["traffic"] if tr else None
 
     out = {
         "metric": "read-pairs/s through --readFQB + --hashDepthRange + --cluster (mosh construction + per-barcode clustering)",
@@ -719,11 +736,10 @@ def main():
         "host_wall_ms_per_step": {k: round(1e3 * v / steps, 3) for k, v in wall.items()},
         "entries_H": H, "distinct_U": U, "hashNumber": sizes["hashNumber"], "fallback_blocks": ctr["fallback_blocks"],
         "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_raw": tr, "traffic_note": TRAFFIC_NOTE if tr else None,
                      # the counters are collected by rocprofv3 --pmc passes of their own (they cannot be read in this process): the figure is of
                      # the build recorded beside it, and stale when that is not the library running now
-                     "traffic_head": traffic_head, "traffic_build_id": traffic_build,
-                     "traffic_stale": (traffic_build != hash10x_amd.build_id()) if traffic is not None else None,
+                     "traffic_stale": (tr["traffic_build_id"] != hash10x_amd.build_id()) if tr else None,
                      "algorithmic_bytes_per_launch": alg[dom], "avg_launch_ms": dom_ms, "barcodes_in_launch": ctr["cluster_main"][3] if dom == "cluster_main" else None,
                      "other_kernels": {k: {"GB/s": alg[k] / (per[k][2] * 1e-3) / 1e9, "frac": alg[k] / (per[k][2] * 1e-3) / 1e9 / HBM_PEAK_GBS, "ms_per_step": per[k][2],
                                            "algorithmic_bytes": alg[k]} for k in alg if k in per and per[k][2] > 0},
