@@ -7,6 +7,7 @@
 #include <cstdarg>
 #include <cstring>
 #include <cstdlib>
+#include <ctime>
 #include <string>
 #include <vector>
 #include <map>
@@ -92,8 +93,11 @@ template <typename T> struct DevBuf {
     hipError_t e = hipSuccess;
     void *q = DevCache::disabled() ? nullptr : DevCache::take(dev, st, bytes, cap);
     if (!q) {
+      static const bool log = getenv("H10X_ALLOC_LOG") != nullptr;   // debug knob: every block the cache could not serve, with the time hipMalloc took
+      timespec t0, t1; if (log) clock_gettime(CLOCK_MONOTONIC, &t0);
       cap = bytes; e = hipMalloc(&q, bytes);
       if (e != hipSuccess && !DevCache::disabled()) { DevCache::trim(dev); e = hipMalloc(&q, bytes); }   // give parked blocks back and retry
+      if (log) { clock_gettime(CLOCK_MONOTONIC, &t1); fprintf(stderr, "h10x alloc: %.1f MB fresh, %.3f ms\n", bytes / 1e6, (t1.tv_sec - t0.tv_sec) * 1e3 + (t1.tv_nsec - t0.tv_nsec) / 1e6); }
     }
     if (e == hipSuccess) { p = (T *)q; n = count; } else { p = nullptr; cap = 0; }
     if (e == hipSuccess && DevCache::poison()) (void)hipMemsetAsync(p, 0xA5, bytes, AllocScope::stream());
@@ -332,6 +336,7 @@ int stageA_runStarts(Ctx *c, const u32 *dRec, u64 nRec, std::vector<u64> &starts
 // start a run but not a block (an all-A barcode's run ended exactly at a chunk boundary: hash10x.c:212)
 int replayChunks(const std::vector<u64> &starts, const std::vector<u32> &zeroRuns, u64 chunk, std::vector<u64> &merges, bool eofPass);   // stable sort of .fqb records by their first 4 bytes
 int stageB_run(Ctx *c, DevBuf<u64> &entHash, DevBuf<u32> &entCode, DevBuf<u32> &entRead);
+void warm_prim(hipStream_t), warm_stageA(hipStream_t), warm_stageB(hipStream_t), warm_stageC(hipStream_t), warm_stageD(hipStream_t), warm_stageE(hipStream_t), warm_shard(hipStream_t);   // h10x_warm
 int stageB_buildCSR(Ctx *c);                   // rows/rowStart from clusHash + hashDepth (fillHashTable)
 int stageB_finishClusHash(Ctx *c, DevBuf<u64> &key);   // key[e] = index << 32 | read16 in block order -> clusHash sorted per block
 // workgroup-local sorts of a block's entries (clushash_block_kernel, good_block_kernel): three launch classes, side by side on

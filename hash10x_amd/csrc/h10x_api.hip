@@ -102,6 +102,11 @@ const char *h10x_last_error(const h10x_ctx *h) { return h ? h->c.err.c_str() : "
 static void reset_state(Ctx &c) {
   c.haveState = false; c.haveRange = false; c.haveGood = false; c.rangeMin = c.rangeMax = 0; c.depthBound = 0xFFFFFFFFu; c.rangeHiMax = 0;
   c.within.release(); c.goodPos.release(); c.nGood.release(); c.goodEntries.release(); c.goodRow.release();
+  // the tables of the state being replaced go back to the block cache NOW, not when their successors are swapped in: the second --readFQB of a
+  // context then finds every block of the first one parked and allocates nothing (kept until the swap, rows[] and clusHash had no twin in the
+  // cache, took larger blocks, and those were allocated afresh behind them: 50-150 ms of hipMalloc inside the sort at 200 M read pairs)
+  c.hashIndex.release(); c.hashValue.release(); c.hashDepth.release(); c.rowStart.release(); c.rows.release();
+  c.blocks.release(); c.blockOff.release(); c.clusHash.release(); c.clusterRaw.release();
   c.hashNumber = 1; c.nBlocks = 0; c.nEntries = 0; c.nRecords = 0; c.maxBlockHashes = 0xFFFFFFFFu;
   c.sharded = false; c.codeBase = 0; c.nBlocksGlobal = 0; c.oRows.release(); c.oSegStart.release(); c.oIndex.release(); c.oU = 0; c.oM = 0;
   c.oHash.release(); c.tablesPending = false;
@@ -366,6 +371,17 @@ static int ingest_append(Ctx &c, const uint32_t *hostRec, uint64_t n) {
   return 0;
 }
 static void ingest_drop(Ctx &c) { (void)hipStreamSynchronize(c.stream); c.ingestBuf.release(); c.ingestRecords = 0; c.ingestCap = 0; }
+// Device code is loaded on first use, a translation unit at a time (the sorts' alone is 21 MB): called from a thread of its own while the caller reads
+// its input, this takes that out of the first command's time. Stream and device of its own choosing; touches no context.
+int h10x_warm(int device) {
+  if (hipSetDevice(device) != hipSuccess) return -1;
+  hipStream_t st = nullptr;
+  if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) return -1;
+  warm_stageA(st); warm_prim(st); warm_stageB(st); warm_stageC(st); warm_stageD(st); warm_stageE(st); warm_shard(st);   // in the order a run needs them
+  const hipError_t e = hipStreamSynchronize(st);
+  (void)hipStreamDestroy(st);
+  return e == hipSuccess && hipGetLastError() == hipSuccess ? 0 : -1;
+}
 void *h10x_pinned_alloc(size_t bytes) { void *p = nullptr; return hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) == hipSuccess ? p : nullptr; }
 void h10x_pinned_free(void *p) { if (p) (void)hipHostFree(p); }
 int h10x_ingest_fqb_async(h10x_ctx *h, const uint32_t *pinnedRec, uint64_t n, int slot) {

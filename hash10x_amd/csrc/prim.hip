@@ -122,4 +122,8 @@ int prim_reduce_sum_u32_u64(Ctx *c, PrimTemp &t, const u32 *in, u64 *out, size_t
   return 0;
 }
 
+// h10x_warm: the first launch of a kernel loads the code object of its translation unit (HIP loads them on first use); this one is launched ahead of time
+__global__ void warm_prim_kernel() {}
+void warm_prim(hipStream_t st) { warm_prim_kernel<<<1, 1, 0, st>>>(); }
+
 }  // namespace h10x

@@ -842,4 +842,8 @@ int shard_gather(Ctx *c) {
   return 0;
 }
 
+// h10x_warm: the first launch of a kernel loads the code object of its translation unit (HIP loads them on first use); this one is launched ahead of time
+__global__ void warm_shard_kernel() {}
+void warm_shard(hipStream_t st) { warm_shard_kernel<<<1, 1, 0, st>>>(); }
+
 }  // namespace h10x

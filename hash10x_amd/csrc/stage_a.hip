@@ -759,4 +759,8 @@ int stageA_run(Ctx *c, const u32 *dRec, u64 nRec, DevBuf<u64> &entHash, DevBuf<u
   return 0;
 }
 
+// h10x_warm: the first launch of a kernel loads the code object of its translation unit (HIP loads them on first use); this one is launched ahead of time
+__global__ void warm_stageA_kernel() {}
+void warm_stageA(hipStream_t st) { warm_stageA_kernel<<<1, 1, 0, st>>>(); }
+
 }  // namespace h10x

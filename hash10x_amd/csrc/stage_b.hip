@@ -403,4 +403,8 @@ int stageB_buildCSR(Ctx *c) {
   return 0;
 }
 
+// h10x_warm: the first launch of a kernel loads the code object of its translation unit (HIP loads them on first use); this one is launched ahead of time
+__global__ void warm_stageB_kernel() {}
+void warm_stageB(hipStream_t st) { warm_stageB_kernel<<<1, 1, 0, st>>>(); }
+
 }  // namespace h10x

@@ -1997,4 +1997,8 @@ int stageC_split(Ctx *c) {
   return 0;
 }
 
+// h10x_warm: the first launch of a kernel loads the code object of its translation unit (HIP loads them on first use); this one is launched ahead of time
+__global__ void warm_stageC_kernel() {}
+void warm_stageC(hipStream_t st) { warm_stageC_kernel<<<1, 1, 0, st>>>(); }
+
 }  // namespace h10x

@@ -143,4 +143,8 @@ int stageD_cribFinish(Ctx *c) {
   return 0;
 }
 
+// h10x_warm: the first launch of a kernel loads the code object of its translation unit (HIP loads them on first use); this one is launched ahead of time
+__global__ void warm_stageD_kernel() {}
+void warm_stageD(hipStream_t st) { warm_stageD_kernel<<<1, 1, 0, st>>>(); }
+
 }  // namespace h10x

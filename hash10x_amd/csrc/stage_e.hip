@@ -295,4 +295,8 @@ int shard_gatherBytes(Ctx *c, const void *send, u64 nbytes, void *recv, u64 cap,
   return 0;
 }
 
+// h10x_warm: the first launch of a kernel loads the code object of its translation unit (HIP loads them on first use); this one is launched ahead of time
+__global__ void warm_stageE_kernel() {}
+void warm_stageE(hipStream_t st) { warm_stageE_kernel<<<1, 1, 0, st>>>(); }
+
 }  // namespace h10x

@@ -226,10 +226,14 @@ static int read_parallel(int fd, char *dst, uint64_t off, uint64_t len) {
 /* records [first, first + n) of the file into the context's image: the reference's fread loop (hash10x.c:202-209) as a pipeline — three page-locked
    slabs; while one is on its way to the device (h10x_ingest_fqb_async) the next is read from the file. Without page-locked memory: one slab, one
    copy at a time, as before. */
+static void *warm_job(void *a) { (void)h10x_warm(*(int *)a); return 0; }           /* a failure here shows up in the first command proper */
 static int stream_records(h10x_session *s, const char *path, uint64_t first, uint64_t n, int sharded) {
   enum { SLAB = ((16 << 20) / 120) * 120, NSLAB = 3 };                                /* whole records per read */
   int rc = 0;
   struct timespec t0, t1, t2, t3; clock_gettime(CLOCK_MONOTONIC, &t0);
+  static int warmed[64];                                                              /* the device code loads while the file is read (once per process and device; ranks may be threads) */
+  pthread_t warmTh; int warmDev = s->device;
+  const int warming = warmDev >= 0 && warmDev < 64 && !__sync_lock_test_and_set(&warmed[warmDev], 1) && pthread_create(&warmTh, 0, warm_job, &warmDev) == 0;
   const int fd = open(path, O_RDONLY);
   char *slab[NSLAB] = {0, 0, 0}; int pinned = 1;
   for (int k = 0; k < NSLAB && pinned; ++k) if (!(slab[k] = (char *)h10x_pinned_alloc(SLAB))) pinned = 0;
@@ -250,6 +254,7 @@ static int stream_records(h10x_session *s, const char *path, uint64_t first, uin
   }
   if (fd >= 0) close(fd);
   if (pinned) { for (int k = 0; k < NSLAB; ++k) { h10x_ingest_wait(s->ctx, k); h10x_pinned_free(slab[k]); } } else free(slab[0]);
+  if (warming) pthread_join(warmTh, 0);
   if (sharded) { int allOk = 0; if (h10x_shard_agree(s->ctx, !rc, &allOk)) return fail_ctx(s); if (!allOk && !rc) rc = fail(s, "another rank failed to read its part of %s", path); }
   if (rc) { h10x_ingest_reserve(s->ctx, 0); return rc; }
   clock_gettime(CLOCK_MONOTONIC, &t2);

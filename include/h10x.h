@@ -103,6 +103,10 @@ int  h10x_ingest_fqb(h10x_ctx *ctx, const uint32_t *host_records, uint64_t n_rec
    read and the PCIe transfer side by side). The buffer must not be touched until h10x_ingest_wait(ctx, slot) has returned for the slot (0..7)
    the chunk was queued under. The ingest is closed as before, by h10x_ingest_fqb / h10x_shard_ingest_fqb with final_chunk = 1 (which waits for
    every queued upload). */
+/* Loads the library's device code on `device` ahead of its first use (HIP loads a code object when the first of its kernels is launched — some tens
+   of milliseconds for this library, otherwise spent inside the first command). Thread-safe; meant to be called from a thread of its own while the
+   caller opens and reads its input. 0 on success. No counterpart in the reference (a CPU program has no such step). */
+int  h10x_warm(int device);
 void *h10x_pinned_alloc(size_t bytes);
 void  h10x_pinned_free(void *p);
 int  h10x_ingest_fqb_async(h10x_ctx *ctx, const uint32_t *pinned_records, uint64_t n_records, int slot);
