@@ -115,6 +115,8 @@ def load_native():
     hip.h10x_device_upload.argtypes = [ci, vp, vp, cu64]
     hip.h10x_device_synchronize.argtypes = [ci]
     hip.h10x_device_count.restype = ci
+    hip.h10x_warm.restype = ci; hip.h10x_warm.argtypes = [ci]
+    hip.h10x_alloc_stats.restype = None; hip.h10x_alloc_stats.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
     hip.h10x_abi_version.restype = ci
     hip.h10x_factor1_from_seed.restype = cu64
     hip.h10x_factor1_from_seed.argtypes = [ctypes.c_int32]
@@ -136,6 +138,18 @@ def load_native():
 
 def device_count():
     return load_native()[0].h10x_device_count()
+
+
+def warm(device=0):
+    """load the library's device code on `device` ahead of its first use (h10x_warm): 0 on success"""
+    return load_native()[0].h10x_warm(int(device))
+
+
+def alloc_stats():
+    """(blocks, bytes) this process has obtained from hipMalloc so far (h10x_alloc_stats)"""
+    a, b = ctypes.c_uint64(0), ctypes.c_uint64(0)
+    load_native()[0].h10x_alloc_stats(ctypes.byref(a), ctypes.byref(b))
+    return a.value, b.value
 
 
 def build_id():

@@ -41,6 +41,8 @@ struct DevCache {
   // (device, nullptr) holds blocks whose stream has been synchronised (context destroyed): anyone may take those
   static DevCache &of(int device, hipStream_t st) { static std::map<std::pair<int, hipStream_t>, DevCache> m; return m[{device, st}]; }
   static bool disabled() { static int v = -1; if (v < 0) v = getenv("H10X_NOPOOL") != nullptr; return v != 0; }
+  static unsigned long long &freshCalls() { static unsigned long long v = 0; return v; }   // blocks the cache could not serve (h10x_alloc_stats)
+  static unsigned long long &freshBytes() { static unsigned long long v = 0; return v; }
   static int poison() { static int p = -1; if (p < 0) { const char *e = getenv("H10X_POISON"); p = e ? atoi(e) : 0; } return p; }
   void *takeLocked(size_t bytes, size_t &got) {
     auto it = parked.lower_bound(bytes);
@@ -97,6 +99,7 @@ template <typename T> struct DevBuf {
       timespec t0, t1; if (log) clock_gettime(CLOCK_MONOTONIC, &t0);
       cap = bytes; e = hipMalloc(&q, bytes);
       if (e != hipSuccess && !DevCache::disabled()) { DevCache::trim(dev); e = hipMalloc(&q, bytes); }   // give parked blocks back and retry
+      if (e == hipSuccess) { __atomic_fetch_add(&DevCache::freshCalls(), 1, __ATOMIC_RELAXED); __atomic_fetch_add(&DevCache::freshBytes(), (unsigned long long)bytes, __ATOMIC_RELAXED); }
       if (log) { clock_gettime(CLOCK_MONOTONIC, &t1); fprintf(stderr, "h10x alloc: %.1f MB fresh, %.3f ms\n", bytes / 1e6, (t1.tv_sec - t0.tv_sec) * 1e3 + (t1.tv_nsec - t0.tv_nsec) / 1e6); }
     }
     if (e == hipSuccess) { p = (T *)q; n = count; } else { p = nullptr; cap = 0; }

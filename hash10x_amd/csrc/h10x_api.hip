@@ -382,6 +382,10 @@ int h10x_warm(int device) {
   (void)hipStreamDestroy(st);
   return e == hipSuccess && hipGetLastError() == hipSuccess ? 0 : -1;
 }
+void h10x_alloc_stats(uint64_t *calls, uint64_t *bytes) {
+  if (calls) *calls = __atomic_load_n(&DevCache::freshCalls(), __ATOMIC_RELAXED);
+  if (bytes) *bytes = __atomic_load_n(&DevCache::freshBytes(), __ATOMIC_RELAXED);
+}
 void *h10x_pinned_alloc(size_t bytes) { void *p = nullptr; return hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) == hipSuccess ? p : nullptr; }
 void h10x_pinned_free(void *p) { if (p) (void)hipHostFree(p); }
 int h10x_ingest_fqb_async(h10x_ctx *h, const uint32_t *pinnedRec, uint64_t n, int slot) {

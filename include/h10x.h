@@ -107,6 +107,9 @@ int  h10x_ingest_fqb(h10x_ctx *ctx, const uint32_t *host_records, uint64_t n_rec
    of milliseconds for this library, otherwise spent inside the first command). Thread-safe; meant to be called from a thread of its own while the
    caller opens and reads its input. 0 on success. No counterpart in the reference (a CPU program has no such step). */
 int  h10x_warm(int device);
+/* Device blocks this process has obtained from hipMalloc so far (count, bytes): the library keeps freed blocks and hands them out again, so a
+   repeated command on one context should add nothing here — a measurement hook (tests/test_gpu_parity.py), no counterpart in the reference. */
+void h10x_alloc_stats(uint64_t *calls, uint64_t *bytes);
 void *h10x_pinned_alloc(size_t bytes);
 void  h10x_pinned_free(void *p);
 int  h10x_ingest_fqb_async(h10x_ctx *ctx, const uint32_t *pinned_records, uint64_t n_records, int slot);
