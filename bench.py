@@ -344,7 +344,7 @@ def cpu_baseline(wl, recs, workdir, gpu_hash_path):
         if os.path.exists(exe):
             cmd = [exe, "-B", str(wl["B"]), "-ct", str(wl["ct"]), "--readFQB", "bench.fqb", "--hashDepthRange", str(wl["lo"]), str(wl["hi"]), "--cluster", "1", "0", "--writeHash", "cli.hash"]
             best = None
-            for _ in range(2):                               # the second run has the file in the page cache, like the reference's runs above
+            for _ in range(4):                               # best of four: from the second on the file is in the page cache, like the reference's runs above (creating the HIP context alone varies 70-260 ms between runs)
                 t0 = time.perf_counter()
                 g = subprocess.run(cmd, cwd=workdir, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
                 dt = time.perf_counter() - t0

@@ -233,7 +233,7 @@ static int stream_records(h10x_session *s, const char *path, uint64_t first, uin
   struct timespec t0, t1, t2, t3; clock_gettime(CLOCK_MONOTONIC, &t0);
   static int warmed[64];                                                              /* the device code loads while the file is read (once per process and device; ranks may be threads) */
   pthread_t warmTh; int warmDev = s->device;
-  const int warming = warmDev >= 0 && warmDev < 64 && !__sync_lock_test_and_set(&warmed[warmDev], 1) && pthread_create(&warmTh, 0, warm_job, &warmDev) == 0;
+  const int warming = warmDev >= 0 && warmDev < 64 && !getenv("H10X_NOWARM") && !__sync_lock_test_and_set(&warmed[warmDev], 1) && pthread_create(&warmTh, 0, warm_job, &warmDev) == 0;
   const int fd = open(path, O_RDONLY);
   char *slab[NSLAB] = {0, 0, 0}; int pinned = 1;
   for (int k = 0; k < NSLAB && pinned; ++k) if (!(slab[k] = (char *)h10x_pinned_alloc(SLAB))) pinned = 0;
