@@ -341,7 +341,8 @@ static void *write_job(void *a) {
   while (done < j->len) { const ssize_t w = pwrite(j->fd, j->src + done, j->len - done > (1u << 30) ? (1u << 30) : j->len - done, (off_t)(j->at + done)); if (w <= 0) break; done += (uint64_t)w; }
   j->ok = done == j->len; return 0;
 }
-/* n bytes to the file at `at`, on a few threads when there are many (a single pwrite copies into the page cache at a few GB/s) */
+/* n bytes to the file at `at`, on a few threads when there are many (the page cache of a GPU box takes ~10 GB/s from one thread as from thirty-two —
+   scratch/pwrite_rate.py — so the threads only cover for a slow one; what matters is that the next slice comes off the device meanwhile: Writer below) */
 static int put(int fd, const void *p, uint64_t n, uint64_t at) {
   enum { T = 4 };
   WriteJob job[T]; pthread_t th[T]; int started[T] = {0};
@@ -354,14 +355,30 @@ static int put(int fd, const void *p, uint64_t n, uint64_t at) {
   for (int i = 1; i < nj; ++i) { if (started[i]) pthread_join(th[i], 0); else write_job(&job[i]); ok = ok && job[i].ok; }
   return ok ? 0 : -1;
 }
-/* elements [first, first + count) of a device table to the file at byte `at`, through a bounded host buffer */
-static int put_table(h10x_session *s, int fd, int table, size_t elem, uint64_t first, uint64_t count, uint64_t at, void *buf, size_t bufBytes, const char *what) {
+/* --writeHash as a pipeline: two host buffers; while one is being written to the file (put, on a thread of its own) the next slice comes off the
+   device into the other. */
+static double profWait, profExport;                                                 /* H10X_HOSTPROF: where --writeHash spends its time */
+typedef struct { int fd; void *buf; uint64_t n, at; int rc, busy; pthread_t th; } Writer;
+static void *writer_job(void *a) { Writer *w = (Writer *)a; w->rc = put(w->fd, w->buf, w->n, w->at); return 0; }
+static int writer_wait(Writer *w) { if (w->busy) { pthread_join(w->th, 0); w->busy = 0; } const int rc = w->rc; w->rc = 0; return rc; }
+static int writer_start(Writer *w, int fd, uint64_t n, uint64_t at) {
+  w->fd = fd; w->n = n; w->at = at; w->rc = 0;
+  if (pthread_create(&w->th, 0, writer_job, w) == 0) { w->busy = 1; return 0; }
+  return put(fd, w->buf, n, at);                                                     /* no thread: write here */
+}
+/* elements [first, first + count) of a device table to the file at byte `at`, through the two bounded host buffers (*turn: which is next) */
+static int put_table(h10x_session *s, int fd, int table, size_t elem, uint64_t first, uint64_t count, uint64_t at, Writer w[2], int *turn, size_t bufBytes, const char *what) {
   const uint64_t step = bufBytes / elem;
   for (uint64_t done = 0; done < count; ) {
     const uint64_t n = count - done < step ? count - done : step;
-    if (h10x_export_slice(s->ctx, table, first + done, n, buf)) return fail_ctx(s);
-    if (table == H10X_TABLE_BLOCKS) for (uint64_t i = 0; i < n; ++i) ((h10x_block *)buf)[i].clusHash = 0;
-    if (put(fd, buf, n * elem, at + done * elem)) return fail(s, "%s", what);
+    Writer *const k = &w[*turn]; *turn ^= 1;
+    const double tw = hostprof() ? now_ms() : 0;
+    if (writer_wait(k)) return fail(s, "%s", what);                                  /* the buffer's previous slice is in the file */
+    const double te = hostprof() ? now_ms() : 0;
+    if (h10x_export_slice(s->ctx, table, first + done, n, k->buf)) return fail_ctx(s);
+    if (hostprof()) { profWait += te - tw; profExport += now_ms() - te; }
+    if (table == H10X_TABLE_BLOCKS) for (uint64_t i = 0; i < n; ++i) ((h10x_block *)k->buf)[i].clusHash = 0;
+    if (writer_start(k, fd, n * elem, at + done * elem)) return fail(s, "%s", what);
     done += n;
   }
   return 0;
@@ -374,11 +391,15 @@ int h10x_session_writeHash(h10x_session *s, const char *path) {
   const uint64_t depthDim = (uint64_t)s->depthDim, blocksDim = (uint64_t)s->blocksDim > z.nBlocksGlobal ? (uint64_t)s->blocksDim : z.nBlocksGlobal;
   const uint64_t oIndex = 16, oNumber = oIndex + 4 * T, oValue = oNumber + 4, oDepthHdr = oValue + 8 * (uint64_t)z.hashNumber, oDepth = oDepthHdr + 32,
                  oBlocksHdr = oDepth + 4 * depthDim, oBlocks = oBlocksHdr + 32, oClus = oBlocks + 32 * blocksDim, total = oClus + 8 * z.nEntriesGlobal;
-  int fd = -1, rc = 0; enum { BUF = 32 << 20 }; int bufPinned = 1; void *buf = h10x_pinned_alloc(BUF);   /* page-locked: the slices come off the device at DMA speed */
-  if (!buf) { bufPinned = 0; buf = malloc(BUF); }
+  const double tp0 = hostprof() ? now_ms() : 0; profWait = profExport = 0;
+  int fd = -1, rc = 0, turn = 0; enum { BUF = 32 << 20 }; int bufPinned = 1;
+  Writer w[2]; memset(w, 0, sizeof w);
+  w[0].buf = h10x_pinned_alloc(BUF); w[1].buf = h10x_pinned_alloc(BUF);             /* page-locked: the slices come off the device at DMA speed */
+  if (!w[0].buf || !w[1].buf) { bufPinned = 0; h10x_pinned_free(w[0].buf); h10x_pinned_free(w[1].buf); w[0].buf = malloc(BUF); w[1].buf = malloc(BUF); }
   h10x_shard_seg *segs = (h10x_shard_seg *)calloc((size_t)z.nSegs + 1, sizeof *segs);
   /* (a failure of one rank up to here is carried into the agreement below: nobody skips a collective) */
-  if (!buf || !segs) rc = fail(s, "out of host memory for .hash export");
+  const double tp01 = hostprof() ? now_ms() : 0;
+  if (!w[0].buf || !w[1].buf || !segs) rc = fail(s, "out of host memory for .hash export");
   else if (h10x_shard_segments(s->ctx, segs, z.nSegs + 1)) rc = fail_ctx(s);
   if (!rc && z.rank == 0) {
     fd = open(path, O_WRONLY | O_CREAT | O_TRUNC, 0666);
@@ -400,21 +421,26 @@ int h10x_session_writeHash(h10x_session *s, const char *path) {
     if (h10x_shard_allreduce_max_u64(s->ctx, &bad, 1)) { rc = fail_ctx(s); goto done; }
     if (bad) { if (!rc) rc = fail(s, "another rank could not prepare the export of %s", path); goto done; }
   }
+  const double tp02 = hostprof() ? now_ms() : 0;
   if (z.rank != 0 && (fd = open(path, O_WRONLY)) < 0) rc = fail(s, "failed to open hash file %s", path);
   if (!rc) {                                                                         /* replicated tables: rank r writes the r-th part of each */
     const uint64_t R = (uint64_t)z.nranks, me = (uint64_t)z.rank;
     const uint64_t i0 = T * me / R, i1 = T * (me + 1) / R, v0 = (uint64_t)z.hashNumber * me / R, v1 = (uint64_t)z.hashNumber * (me + 1) / R;
     const uint64_t dLimit = (uint64_t)z.hashNumber < depthDim ? z.hashNumber : depthDim, d0 = dLimit * me / R, d1 = dLimit * (me + 1) / R;
-    rc = put_table(s, fd, H10X_TABLE_HASHINDEX, 4, i0, i1 - i0, oIndex + 4 * i0, buf, BUF, "write fail 2");
-    if (!rc) rc = put_table(s, fd, H10X_TABLE_HASHVALUE, 8, v0, v1 - v0, oValue + 8 * v0, buf, BUF, "failed to write hashValue");
-    if (!rc) rc = put_table(s, fd, H10X_TABLE_HASHDEPTH, 4, d0, d1 - d0, oDepth + 4 * d0, buf, BUF, "failed to write hashDepth array");
+    rc = put_table(s, fd, H10X_TABLE_HASHINDEX, 4, i0, i1 - i0, oIndex + 4 * i0, w, &turn, BUF, "write fail 2");
+    if (!rc) rc = put_table(s, fd, H10X_TABLE_HASHVALUE, 8, v0, v1 - v0, oValue + 8 * v0, w, &turn, BUF, "failed to write hashValue");
+    if (!rc) rc = put_table(s, fd, H10X_TABLE_HASHDEPTH, 4, d0, d1 - d0, oDepth + 4 * d0, w, &turn, BUF, "failed to write hashDepth array");
   }
   for (uint32_t i = 0; !rc && i < z.nSegs; ++i) {                                    /* my blocks and their ClusterHash records */
     if ((int)segs[i].rank != z.rank) continue;
-    rc = put_table(s, fd, H10X_TABLE_BLOCKS, 32, segs[i].localStart, segs[i].count, oBlocks + 32 * (uint64_t)segs[i].globalBase, buf, BUF, "failed to write clusterBlocks array");
-    if (!rc) rc = put_table(s, fd, H10X_TABLE_CLUSHASH, 8, segs[i].localEntryStart, segs[i].entries, oClus + 8 * segs[i].globalEntryStart, buf, BUF, "write fail 3");
+    rc = put_table(s, fd, H10X_TABLE_BLOCKS, 32, segs[i].localStart, segs[i].count, oBlocks + 32 * (uint64_t)segs[i].globalBase, w, &turn, BUF, "failed to write clusterBlocks array");
+    if (!rc) rc = put_table(s, fd, H10X_TABLE_CLUSHASH, 8, segs[i].localEntryStart, segs[i].entries, oClus + 8 * segs[i].globalEntryStart, w, &turn, BUF, "write fail 3");
   }
+  for (int k = 0; k < 2; ++k) if (writer_wait(&w[k]) && !rc) rc = fail(s, "write fail 3");   /* the last slices are in the file */
+  const double tp1 = hostprof() ? now_ms() : 0;
   if (fd >= 0 && close(fd) && !rc) rc = fail(s, "write fail 3");
+  if (hostprof()) fprintf(stderr, "hostprof: writeHash %.1f ms to the last slice (buffers %.1f ms, file + headers %.1f ms, device -> host %.1f ms, waiting for the file %.1f ms), close %.1f ms, %.2f GB\n",
+                          tp1 - tp0, tp01 - tp0, tp02 - tp01, profExport, profWait, now_ms() - tp1, (double)total / 1e9);
   fd = -1;
   {
     uint64_t bad = rc ? 1 : 0;
@@ -422,8 +448,9 @@ int h10x_session_writeHash(h10x_session *s, const char *path) {
     if (bad && !rc) rc = fail(s, "another rank failed to write %s", path);
   }
 done:
+  for (int k = 0; k < 2; ++k) (void)writer_wait(&w[k]);
   if (fd >= 0) close(fd);
-  if (bufPinned) h10x_pinned_free(buf); else free(buf);
+  for (int k = 0; k < 2; ++k) { if (bufPinned) h10x_pinned_free(w[k].buf); else free(w[k].buf); }
   free(segs);
   return rc;
 }
