@@ -350,10 +350,11 @@ def cpu_baseline(wl, recs, workdir, gpu_hash_path):
                 dt = time.perf_counter() - t0
                 if g.returncode != 0:
                     raise RuntimeError("hash10x-amd failed: " + g.stderr.decode()[-300:])
-                best = dt if best is None or dt < best else best
+                if best is None or dt < best:
+                    best, gbest = dt, g
             walls = {}
             cmdname = None
-            for line in g.stdout.decode().splitlines():     # the program's own per-command wall seconds (its resource lines)
+            for line in gbest.stdout.decode().splitlines():  # the program's own per-command wall seconds (its resource lines), of the best run
                 if line.startswith("COMMAND "):
                     cmdname = line.split()[1]
                 elif line.strip().startswith("user") and cmdname and "wall" in line:
