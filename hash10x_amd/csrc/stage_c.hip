@@ -453,20 +453,26 @@ struct SlotTable {
     const bool hit = m0 | m1 | m2 | m3;
     const u32 wh = m0 ? 0u : (m1 ? 1u : (m2 ? 2u : 3u)), wz = z0 ? 0u : (z1 ? 1u : (z2 ? 2u : 3u));
     slot = b4 | (hit ? wh : wz);
-    bool same = false; ins = false;
-    if (valid && insert && !hit && (z0 | z1 | z2 | z3)) {    // claim the first empty word
-      const u32 seen = atomicCAS(&tab[slot], 0xFFFFFFFFu, mine);
-      ins = seen == 0xFFFFFFFFu; same = (seen & 0xFFFFu) == key;   // it was empty, or the same barcode got there first
-    }
-    // the entry's rank: minimum with this one, looked at or not — a fire-and-forget LDS atomic per chunk costs less than finding out whether
-    // a later rank got here first (four selects, a compare and the masks around a branch; the kernel is bound by its instruction count, LDS is a quarter busy)
-    if (valid && (hit || same)) atomicMin(&tab[slot], mine);
-    return !valid || hit || ins || same;
+    // the masks the wave's scalar unit has to form are what this code costs (the pass issues as many scalar as vector instructions): ONE flag leaves
+    // the insertion branch — settled: the word was empty, or the same barcode got there first — and the minimum is queued where the flag is known
+    bool settled = hit; ins = false;
+    if (valid && !hit) {
+      settled = false;
+      if (insert && (z0 | z1 | z2 | z3)) {                    // claim the first empty word
+        const u32 seen = atomicCAS(&tab[slot], 0xFFFFFFFFu, mine);
+        ins = seen == 0xFFFFFFFFu;
+        const bool same = (seen & 0xFFFFu) == key;           // the same barcode got there first: its rank takes part in the minimum
+        if (same) atomicMin(&tab[slot], mine);
+        settled = ins | same;
+      }
+    } else if (valid) atomicMin(&tab[slot], mine);           // the entry's rank: minimum with this one, looked at or not — a fire-and-forget LDS atomic per chunk costs less than
+                                                             // finding out whether a later rank got here first
+    return !valid || settled;
   }
 };
 struct FirstSlots {                                          // pass B: first[] by handle
   static constexpr bool SELF = false;
-  static constexpr bool MASK_TAIL = true;                    // lanes past a list's end hold a real handle (clamped loads)
+  static constexpr bool MASK_TAIL = false;                   // lanes past a list's end hold the handle of `none` (pass A writes whole chunks)
   const unsigned char *base; u32 sh;                         // value of slot h: the u16 at base + (h << sh) — sh = 1 after the compaction, 2 (base at the words' high halves) without
   u32 none;
   __device__ __forceinline__ u32 peek(u32 h) const { return *(const u16 *)(base + (u32)(h << sh)); }
@@ -1053,7 +1059,8 @@ __device__ __forceinline__ void cluster_one_block_tr(const ClusterArgs &a, u32 c
       const bool valid = laneU < drem && cj != code;
       u32 slot; bool ins;
       const bool done = st.probeHome(cj, i, valid, insert, slot, ins);
-      if (laneU < drem) hl[laneU] = (u16)(valid ? slot : S);   // (only lanes with an entry: a chunk's line is written as far as the list goes)
+      hl[laneU] = (u16)(valid ? slot : S);                    // all 64 lanes (a list's row is a power of two >= 64 wide): past the list's end the handle of `none`, which reads unseen — pass B
+                                                             // then loads and counts a chunk without looking at the list's length, and no exec mask is formed here
       myIns += (u32)__popcll(__ballot(ins));
       const u64 bal = __ballot(!done);
       if (bal) {
@@ -1191,11 +1198,10 @@ __device__ __forceinline__ void cluster_one_block_tr(const ClusterArgs &a, u32 c
     const u32 laneU = (u32)lane;
     u32 hN[RIF], h2N[RIF], hNN[RIF];
     u32 dvCur, dvN, dvNN, dvD;
-    // the handles of a list's two chunks: all 64 lanes, no test (pass A wrote every lane of a chunk the list has)
-#define TR_LOAD_A(H, I0, DV) { _Pragma("unroll") for (int t = 0; t < RIF; ++t) { const u32 ic = (I0) + t < n ? (I0) + t : n - 1; const u32 d = (u32)__builtin_amdgcn_readlane((int)DV, 32 + t), dm = d ? d - 1 : 0u; \
-      H[t] = (hs + ((size_t)ic << lgH))[laneU < dm ? laneU : dm]; } }   /* (a lane past the list's end reads the last handle again: no load is skipped, no byte moved that was not written) */
+    // the handles of a list's two chunks: all 64 lanes, no test and no clamp (pass A wrote every lane of a chunk the list has: `none` past the list's end)
+#define TR_LOAD_A(H, I0, DV) { _Pragma("unroll") for (int t = 0; t < RIF; ++t) { const u32 ic = (I0) + t < n ? (I0) + t : n - 1; H[t] = (hs + ((size_t)ic << lgH))[laneU]; } }
 #define TR_LOAD_B(H2, I0, DV) { _Pragma("unroll") for (int t = 0; t < RIF; ++t) { const u32 ic = (I0) + t < n ? (I0) + t : n - 1; \
-      const u32 d = (u32)__builtin_amdgcn_readlane((int)DV, 32 + t), dm = d ? d - 1 : 0u, j = (d > (u32)WAVE ? (u32)WAVE : 0u) + laneU; H2[t] = (hs + ((size_t)ic << lgH))[j < dm ? j : dm]; } }   /* (no second chunk: the first again, from the caches) */
+      H2[t] = (hs + ((size_t)ic << lgH))[((u32)__builtin_amdgcn_readlane((int)DV, 32 + t) > (u32)WAVE ? (u32)WAVE : 0u) + laneU]; } }   /* (no second chunk: the first again, from the caches) */
     const u32 iw = listWave ? uwave * RIF : n;
     dvN = descFix(descLoadU(gr, iw, n), iw, RIF, n); dvNN = descLoadU(gr, listWave ? iw + stepR : n, n); dvD = descLoadU(gr, listWave ? iw + 2 * stepR : n, n);   // (dvNN, dvD: raw)
     TR_LOAD_A(hN, iw, dvN)
