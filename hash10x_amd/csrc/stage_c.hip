@@ -1006,7 +1006,9 @@ __device__ __forceinline__ void cluster_one_block_tr(const ClusterArgs &a, u32 c
 #define ROWP(rs) (a.rows + ((size_t)(rs) << rsh))
   const u64 *const gr = a.goodRow + o;
   u64 *const res = a.res + o;
-  const u32 thr = (u32)a.threshold;
+  u32 thr = (u32)a.threshold;
+  asm volatile("" : "+s"(thr));                              // (a value of its own from here on: left as a kernel argument, the compiler reloads it for every list — two v_readlane for the
+                                                             // spilled argument pointer, an s_load and a wait that also covers the list's LDS traffic — rather than keep a register for it)
   u16 *const hs = a.handles + (size_t)blockIdx.x * a.handleStride;   // this workgroup's handles: list i at hs + i * hst
   const u32 hst = a.hStride, lgH = 31 - (u32)__clz((int)hst);
   const u32 uwave = (u32)__builtin_amdgcn_readfirstlane(wave);
