@@ -299,7 +299,7 @@ __host__ __device__ inline u32 rankedFirstEstimate(u32 nBarcodes, u32 n) { const
 // … and, where the entries of the block's lists are known (classification): a seventh of them (6-8 % on the yeast-like
 // sets, more on deeper ones), whichever is larger. Erring low is cheap: the ranked kernel knows the true number right
 // after its bitmap pass and hands the block on before the list loop.
-__host__ __device__ inline u32 rankedFirstEstimateE(u32 nBarcodes, u32 n, u32 entries) { const u32 a = rankedFirstEstimate(nBarcodes, n), b = entries / 7; const u32 m = a > b ? a : b; return m < nBarcodes ? m : nBarcodes; }
+__host__ __device__ inline u32 rankedFirstEstimateE(u32 nBarcodes, u32 n, u32 entries, u32 div = 7) { const u32 a = rankedFirstEstimate(nBarcodes, n), b = entries / div; const u32 m = a > b ? a : b; return m < nBarcodes ? m : nBarcodes; }
 __host__ __device__ inline u32 histWaves(u32 nFirst, u32 n, u32 maxWaves, u32 bmWords, size_t budget) {
   const size_t fixed = workBytes(nFirst, n, 0, bmWords), per = (((size_t)n + 3) / 4) * 4;
   if (fixed + MIN_HIST_WAVES * per > budget) return 0;
@@ -988,7 +988,7 @@ template <int CL_THREADS, int KLASS>
 __device__ __forceinline__ void cluster_one_block_tr(const ClusterArgs &a, u32 code, unsigned char *region, u32 *sh, u64 (&acc)[4]) {
   constexpr bool IN_LDS = true;
   constexpr int CL_WAVES = CL_THREADS / WAVE;
-  constexpr int RIF = ROWS_IN_FLIGHT;
+  constexpr int RIF = KLASS == 2 ? 8 : ROWS_IN_FLIGHT;         // (the whole-CU class has 128 registers per lane and only four waves per SIMD to hide latency behind: twice the lists in flight)
   const int tid = threadIdx.x, lane = tid & (WAVE - 1), wave = tid / WAVE;
   code = (u32)__builtin_amdgcn_readfirstlane((int)code);
   const u32 n = (u32)__builtin_amdgcn_readfirstlane((int)a.nGood[code]);
@@ -1589,7 +1589,10 @@ __global__ void cluster_classify_kernel(const h10x_block *__restrict__ blocks, c
       u32 S, S2, nW; bool compact;
       translatedShape(n, waves0, budget0, hashMinSlots, entries[c], nBlocks, firstCap, S, S2, nW, compact);
       if (n > maxTrRanks) cls = 3;                       // (its handles would not fit the workgroup's HBM slot)
-      else if (translatedFits(S, S2, rankedFirstEstimateE(nBlocks, n, entries[c]), entries[c], nBlocks)) cls = 0;
+      // (a sixth of the entries, not a seventh as in the ranked placement: the blocks in between would run in the half-CU class on a second table and
+      //  with few list-loop waves — they are faster with a CU to themselves: full configs[2] 583 -> 567 ms, 17 % of the blocks in the whole-CU class
+      //  instead of 8 %; at a fifth the whole-CU class holds more than half of the CUs and the launches no longer overlap: 890 ms)
+      else if (translatedFits(S, S2, rankedFirstEstimateE(nBlocks, n, entries[c], 6), entries[c], nBlocks)) cls = 0;
       else { translatedShape(n, CL_THREADS_HUGE / WAVE, budgetBig, hashMinSlots, entries[c], nBlocks, firstCap, S, S2, nW, compact); cls = S ? 2 : 3; }
     }
     else if (histWaves(ranked ? rankedFirstEstimateE(nBlocks, n, entries[c]) : nBlocks, n, waves0, bmWords, budget0)) cls = 0;
