@@ -1720,17 +1720,24 @@ static int cluster_local_range(Ctx *c, int codeMin, int codeMax, int threshold, 
   // Both LDS classes are persistent launches that stay on the CUs they get: a whole-CU workgroup keeps two half-CU workgroups out. Where both have
   // enough blocks to fill the chip, the CUs are split by the classes' work (the whole-CU class does a list entry at ~0.8 x the rate per CU: measured
   // on the million-barcode set, where it used to finish 100 ms behind the main launch), so that the two launches end together.
+  u32 secondWind = 0;
   if (firstMode == 4 && gridOf[2] && gridOf[0] >= (u32)c->numCU && hw[0] + hw[1]) {
     const double share2 = 1.25 * (double)hw[1] / (1.25 * (double)hw[1] + (double)hw[0]);
     // (+ 4 CUs: the blocks of that class are the ones with many ranks, which the work figure flatters; its CUs are not lost when it ends early —
     // while it is the smaller side, the main launch brings two workgroups for EVERY CU, and those that find no room wait in the dispatcher
     // for the whole-CU workgroups to leave: 3 Gb set, 2 169 such blocks: 657 ms on one CU behind a main launch of 510 ms before this)
-    const u32 cu2 = hmin<u32>((u32)c->numCU - 1, hmax<u32>(1u, (u32)(share2 * c->numCU + 0.5) + 4u));
+    // Whichever side the split errs on corrects itself: the main launch always brings two workgroups for every CU (they take over the whole-CU class's
+    // CUs when that ends first), and behind the main launch, on its stream, the whole-CU class is launched a SECOND time on the same work queue
+    // (secondWind): workgroups for every CU, which find the queue empty — or the CUs the main launch has just left free. (Before this the main launch
+    // was held to the CUs the split gave it once the whole-CU class had more than half of them: 890 ms instead of 570 on a set classified that way.)
+    const u32 cu2 = hmin<u32>((u32)c->numCU > 16 ? (u32)c->numCU - 8 : (u32)c->numCU - 1, hmax<u32>(1u, (u32)(share2 * c->numCU + 0.5) + 4u));
     gridOf[2] = hmin<u32>(hc[2], cu2);
-    gridOf[0] = hmin<u32>(gridOf[0], 2 * cu2 <= (u32)c->numCU ? 2 * (u32)c->numCU : 2 * ((u32)c->numCU - cu2));
+    gridOf[0] = hmin<u32>(gridOf[0], 2 * (u32)c->numCU);
+    secondWind = hc[2] > gridOf[2] ? hmin<u32>(hc[2] - gridOf[2], (u32)c->numCU) : 0u;
   }
   DevBuf<u16> trSlots[3];                                  // translated placement: one handle slot per resident workgroup of each LDS class
   if (firstMode == 4) for (int k = 0; k < 3; k += 2) if (gridOf[k]) H10X_HIP(c, trSlots[k].alloc(trSlotU16 * gridOf[k]));
+  if (secondWind) H10X_HIP(c, trSlots[1].alloc(trSlotU16 * secondWind));
   if (firstMode == 2) for (int k = 0; k < 3; k += 2) if (gridOf[k]) {       // class 0 serves list 0 AND the front list (hc[1]); class 1 has no launch
     H10X_HIP(c, firstSlots[k].alloc(firstStride * gridOf[k]));
     H10X_HIP(c, hipMemsetAsync(firstSlots[k].p, 0xFF, firstStride * gridOf[k], st));
@@ -1769,7 +1776,7 @@ static int cluster_local_range(Ctx *c, int codeMin, int codeMax, int threshold, 
     // (only while that class is a side show: when it holds most of the barcodes its persistent workgroups would keep every
     // CU to themselves until their queue is empty, and the two launches share the chip better by racing for the CUs —
     // 1 M-barcode set: 2.20 s against 2.52 s)
-    a.started = gridOf[2] * 2 <= (u32)c->numCU ? c->startFlags : nullptr;
+    a.started = (gridOf[2] * 2 <= (u32)c->numCU || secondWind) && gridOf[2] <= 1024 ? c->startFlags : nullptr;
     H10X_LAUNCH_LDS(2, CL_THREADS_HUGE, budgetBig, c->aux[1], list2.p, hc[2], gridOf[2], 6, ovfCountB, ovfB.p)
     if (a.started) {
       const auto t0 = std::chrono::steady_clock::now();
@@ -1789,6 +1796,11 @@ static int cluster_local_range(Ctx *c, int codeMin, int codeMax, int threshold, 
     if (threads0 == 512) H10X_LAUNCH_LDS(0, 512, budget0, st, list0.p, hc[0], gridOf[0], 4, ovfCountA, ovfA.p) else H10X_LAUNCH_LDS(0, CL_THREADS_SMALL, budget0, st, list0.p, hc[0], gridOf[0], 4, ovfCountA, ovfA.p)
     c->tstop(T_CLUSTER_MAIN);
     a.stats = stats.p; a.front = nullptr; a.nFront = 0;
+  }
+  if (secondWind) {                                          // (see the split above) same work queue, counters and overflow list as the first launch of the class; handle slots of its own
+    ClusterArgs g = a; g.list = list2.p; g.nList = hc[2]; g.workCounter = counts.p + 6; g.ldsBudget = (u32)budgetBig;
+    g.overflow = ovfB.p; g.overflowCount = ovfCountB; g.handles = trSlots[1].p;
+    H10X_LAUNCH_ONE(4, 2, CL_THREADS_HUGE, budgetBig, secondWind, st)
   }
   H10X_HIP(c, hipGetLastError());
   H10X_TRY(c->faultAt(4));
