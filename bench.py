@@ -345,6 +345,8 @@ def cpu_baseline(wl, recs, workdir, gpu_hash_path):
             cmd = [exe, "-B", str(wl["B"]), "-ct", str(wl["ct"]), "--readFQB", "bench.fqb", "--hashDepthRange", str(wl["lo"]), str(wl["hi"]), "--cluster", "1", "0", "--writeHash", "cli.hash"]
             best = None
             for _ in range(4):                               # best of four: from the second on the file is in the page cache, like the reference's runs above (creating the HIP context alone varies 70-260 ms between runs)
+                if os.path.exists(os.path.join(workdir, "cli.hash")):
+                    os.remove(os.path.join(workdir, "cli.hash"))   # every run writes a NEW file (truncating the previous 250 MB and ext4's flush at close of a replaced file cost 50 ms)
                 t0 = time.perf_counter()
                 g = subprocess.run(cmd, cwd=workdir, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
                 dt = time.perf_counter() - t0
