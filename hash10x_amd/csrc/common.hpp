@@ -211,6 +211,7 @@ struct Ctx {
   int64_t optFirstCap = 0;    // testing knob: entries of the ranked first[]
   int64_t optClusterThreads0 = 0, optClusterBudget0 = 0;   // tuning knobs: lanes and LDS bytes of the first cluster class
   int64_t optBigRanks = 0;    // tuning knob: rank count above which a barcode goes to the front of the main work queue (0 = 1.5 x the mean)
+  int64_t optPrivTable = 0;   // entry look-ups of the index build: 0 = the table of this library's own where key + index do not fit the 64-bit reference-shaped one, 1 = always (tests), 2 = never, 3 = always and too small (tests: the fall-back)
   int64_t optNoPack = 0;      // index build with separate key / block arrays even where the packed form fits (A/B, tests)
   int64_t optNarrowFirst = 0; // first[] of the cluster kernel at 2 bytes per entry in every block (default: 4 where the block's working set leaves room)
   int64_t optStamps = 0;      // diagnostic: per-phase wall-clock stamps in cluster_kernel

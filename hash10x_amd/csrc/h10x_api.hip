@@ -623,6 +623,7 @@ int h10x_set_option(h10x_ctx *h, const char *name, int64_t value) {
   if (!strcmp(name, "cluster_big_ranks")) { h->c.optBigRanks = value; return 0; }
   if (!strcmp(name, "cluster_narrow_first")) { h->c.optNarrowFirst = value; return 0; }
   if (!strcmp(name, "index_no_pack")) { h->c.optNoPack = value; return 0; }
+  if (!strcmp(name, "index_priv_table")) { if (value < 0 || value > 3) return h->c.fail("index_priv_table must be 0..3"); h->c.optPrivTable = value; return 0; }
   if (!strcmp(name, "cluster_stamps")) { h->c.optStamps = value; return 0; }
   if (!strcmp(name, "chunk_size")) { if (value < 0) return h->c.fail("chunk_size must be >= 0"); h->c.optChunk = value; return 0; }
   if (!strcmp(name, "chunk_eof_pass")) { h->c.optChunkEof = value ? 1 : 0; return 0; }

@@ -137,6 +137,35 @@ __global__ void lookup_pack64_kernel(const u64 *__restrict__ entHash /* hash / w
   }
 }
 
+// Where key and index do not fit one 64-bit word of the reference-shaped table (k = 21, w = 31: B >= 29) the entries are looked up in a table of this
+// library's own: 2^T slots >= twice the distinct hashes, home slot = the low T bits of q = hash / w, linear probing, and an entry says how far from home it
+// sits — entry = index << 32 | (q >> T) << 8 | displacement, all ones = empty — so slot and entry together ARE q: one random 8-byte read per probe step
+// (neighbouring slots share a 64-byte sector) instead of hashIndex[slot] and then hashValue[index] behind it, each a sector of its own: the look-ups of
+// 1.47 G entries took 56 ms of the 82 ms of clushash_build at 200 M read pairs. Entries never move; a hash that finds no free slot within 256 of its home
+// is simply not in the table, and a look-up that does not find its hash within 256 slots asks the reference-shaped pair instead.
+constexpr u32 PRIV_MAX_DISP = 256;
+__global__ void priv_insert_kernel(const u64 *__restrict__ hashValue, u32 hashNumber, u64 w, int T, u64 *__restrict__ table) {
+  const u32 first = blockIdx.x * blockDim.x + threadIdx.x + 1;
+  const u64 mask = ((u64)1 << T) - 1;
+  for (u32 i = first; i < hashNumber; i += gridDim.x * blockDim.x) {
+    const u64 q = hashValue[i] / w, low = ((q >> T) << 8);
+    u64 slot = q & mask;
+    for (u32 d = 0; d < PRIV_MAX_DISP; ++d, slot = (slot + 1) & mask)
+      if (atomicCAS((unsigned long long *)&table[slot], (unsigned long long)SLOT_EMPTY64, (unsigned long long)(((u64)i << 32) | low | d)) == SLOT_EMPTY64) break;
+  }
+}
+__device__ __forceinline__ u32 priv_find(const u64 *__restrict__ table, int T, u64 q, const u32 *__restrict__ hashIndex, const u64 *__restrict__ hashValue, int B, u64 w) {
+  const u64 mask = ((u64)1 << T) - 1;
+  const u32 want = (u32)((q >> T) << 8);
+  u64 slot = q & mask;
+  for (u32 d = 0; d < PRIV_MAX_DISP; ++d, slot = (slot + 1) & mask) {
+    const u64 e = table[slot];
+    if ((u32)e == (want | d)) return (u32)(e >> 32);
+    if (e == SLOT_EMPTY64) break;                            // (not behind an empty slot of its probe sequence — unless it was never put in)
+  }
+  return probe_find(hashIndex, hashValue, B, q * w);
+}
+
 // ------------------------------------------------------------------------------------------ clusHash
 __global__ void lookup_pack_kernel(const u64 *__restrict__ entHash, const u32 *__restrict__ entRead, u64 n,
                                    const u32 *__restrict__ table, const u64 *__restrict__ hashValue, int B, u64 w /* entHash holds hash / w */, int cb, u64 *__restrict__ key) {
@@ -195,7 +224,8 @@ __global__ __launch_bounds__(THREADS)
 void clushash_block_kernel(const u64 *__restrict__ entHash /* hash / w */, const u32 *__restrict__ entRead, const u64 *__restrict__ key /* !LOOKUP: index << 32 | read */,
                            const u64 *__restrict__ blockOff, const u32 *__restrict__ list, const u32 *__restrict__ count /* this class's blocks */,
                            const u64 *__restrict__ table64, int B, u64 w, int qBits, int cb /* packed entries */, int sortBits,
-                           h10x_clushash *__restrict__ out) {
+                           h10x_clushash *__restrict__ out, int privT = 0 /* > 0: table64 is the private table of 2^privT slots (priv_find) */,
+                           const u32 *__restrict__ hashIndex = nullptr, const u64 *__restrict__ hashValue = nullptr) {
   using Sort = rocprim::block_radix_sort<u32, THREADS, IPT, u32>;
   __shared__ typename Sort::storage_type storage;
   const u32 nList = *count;
@@ -213,10 +243,13 @@ void clushash_block_kernel(const u64 *__restrict__ entHash /* hash / w */, const
       if (e < n) {
         if (LOOKUP) {
           const u64 q = entHash[o + e] >> cb, h = q * w;
-          u64 slot = h & mask; const u64 step = ((h >> B) & mask) | 1;
-          u64 t;
-          while ((t = table64[slot]) != SLOT_EMPTY64 && (t & qmask) != q) slot = (slot + step) & mask;
-          k[j] = t == SLOT_EMPTY64 ? 0u : (u32)(t >> qBits);
+          if (privT) k[j] = priv_find(table64, privT, q, hashIndex, hashValue, B, w);   // (uniform)
+          else {
+            u64 slot = h & mask; const u64 step = ((h >> B) & mask) | 1;
+            u64 t;
+            while ((t = table64[slot]) != SLOT_EMPTY64 && (t & qmask) != q) slot = (slot + step) & mask;
+            k[j] = t == SLOT_EMPTY64 ? 0u : (u32)(t >> qBits);
+          }
           v[j] = entRead[o + e] & 0xFFFFu;                   // ClusterHash.read is U16 (hash10x.c:37,180)
         } else { const u64 t = key[o + e]; k[j] = (u32)(t >> 32); v[j] = (u32)t & 0xFFFFu; }
       }
@@ -232,7 +265,7 @@ void clushash_block_kernel(const u64 *__restrict__ entHash /* hash / w */, const
 }
 
 // clusHash of every block by workgroup-local sorts; needs maxBlockHashes <= BLOCK_SORT_MAX. key = nullptr: look the entries up in table64
-static int clusHashByBlocks(Ctx *c, const u64 *entHash, const u32 *entRead, const u64 *key, const u64 *table64) {
+static int clusHashByBlocks(Ctx *c, const u64 *entHash, const u32 *entRead, const u64 *key, const u64 *table64, int privT = 0) {
   hipStream_t st = c->stream; const u32 nBlocks = c->nBlocks;
   H10X_HIP(c, c->clusHash.alloc(c->nEntries));
   if (!c->nEntries || nBlocks < 2) return 0;
@@ -243,7 +276,7 @@ static int clusHashByBlocks(Ctx *c, const u64 *entHash, const u32 *entRead, cons
   // workgroups per launch: the class's blocks are pulled from its list (count on the device: no round trip); enough workgroups to fill the chip
   const unsigned gridBig = hmin<u32>(nBlocks, (u32)c->numCU * 8), gridSmall = hmin<u32>(nBlocks, 65535u * 4);
 #define H10X_CH_LAUNCH(T, I, LOOK, CLS, STREAM) clushash_block_kernel<T, I, LOOK><<<(CLS == 0 ? gridSmall : gridBig), T, 0, STREAM>>>(entHash, entRead, key, c->blockOff.p, \
-    lists.p + (size_t)CLS * nBlocks, counts.p + CLS, table64, B, w, qBits, key ? 0 : c->entCodeBits, sortBits, c->clusHash.p)
+    lists.p + (size_t)CLS * nBlocks, counts.p + CLS, table64, B, w, qBits, key ? 0 : c->entCodeBits, sortBits, c->clusHash.p, privT, c->hashIndex.p, c->hashValue.p)
   const int side = c->maxBlockHashes > BLOCK_SORT_CAP1 ? 2 : (c->maxBlockHashes > BLOCK_SORT_CAP0 ? 1 : 0);
   ForkGuard forkGuard(c);
   if (side) H10X_TRY(c->forkStreams(side));                  // the few large blocks beside the many small ones
@@ -310,7 +343,8 @@ int stageB_run(Ctx *c, DevBuf<u64> &entHash, DevBuf<u32> &entCode, DevBuf<u32> &
   c->tstop(T_RANK);
   sHash.release(); dHash.release(); dFirst.release(); iota.release(); dFirstSorted.release(); dVal.release(); dValSorted.release();
 
-  const bool wideTable = c->keyBits + (B - 2) <= 64 && c->keyBits < 64;   // index < 2^(B-2) (hash10x.c:149)
+  const bool forcePriv = (c->optPrivTable == 1 || c->optPrivTable == 3) && c->keyBits <= 40;
+  const bool wideTable = !forcePriv && c->keyBits + (B - 2) <= 64 && c->keyBits < 64;   // index < 2^(B-2) (hash10x.c:149)
   DevBuf<u64> table64;
   if (wideTable) {
     c->tstart(T_PROBE);
@@ -326,6 +360,16 @@ int stageB_run(Ctx *c, DevBuf<u64> &entHash, DevBuf<u32> &entCode, DevBuf<u32> &
   if (H && wideTable && c->maxBlockHashes <= BLOCK_SORT_MAX) {
     H10X_TRY(clusHashByBlocks(c, entHash.p, entRead.p, nullptr, table64.p));
     table64.release();
+  } else if (H && !wideTable && c->maxBlockHashes <= BLOCK_SORT_MAX && c->keyBits <= 40 && c->optPrivTable != 2) {
+    // the look-up table of this library's own (priv_insert_kernel): 2^T slots >= 2 (U + 1), T >= keyBits - 24 so that q >> T fits the entry's 24 bits
+    int T = 16; while (((u64)1 << T) < 2 * ((u64)U + 1) && T < 32) ++T;
+    if (c->optPrivTable == 3) { T = 4; while (((u64)1 << T) < ((u64)U + 1) / 2 && T < 32) ++T; }   // (test knob: half the hashes find no slot and are looked up the old way)
+    if (T < c->keyBits - 24) T = c->keyBits - 24;
+    DevBuf<u64> priv;
+    H10X_HIP(c, priv.alloc((size_t)1 << T));
+    H10X_HIP(c, hipMemsetAsync(priv.p, 0xFF, ((size_t)1 << T) * 8, st));
+    if (U) priv_insert_kernel<<<hmin<u32>(divUp(U, 256), 16384), 256, 0, st>>>(c->hashValue.p, U + 1, (u64)c->prm.w, T, priv.p);
+    H10X_TRY(clusHashByBlocks(c, entHash.p, entRead.p, nullptr, priv.p, T));
   } else if (H) {
     DevBuf<u64> key; H10X_HIP(c, key.alloc(H));
     if (wideTable) lookup_pack64_kernel<<<gH, 256, 0, st>>>(entHash.p, entRead.p, H, table64.p, B, (u64)c->prm.w, c->keyBits, cb, key.p);

@@ -315,7 +315,9 @@ typedef struct {
 int  h10x_get_counters(h10x_ctx *ctx, h10x_counters *out);
 /* test / tuning knobs (none changes a result): "stage_a_max_slots" caps the LDS hash-set slots per barcode in stage A (0 =
    default) so that the global-memory fallback can be exercised on small inputs; "chunk_size" (above); "index_no_pack" 1 = index
-   build with separate key / block arrays even where the packed one-word entries fit; "cluster_narrow_first" 1 = first[] of the
+   build with separate key / block arrays even where the packed one-word entries fit; "index_priv_table" 1 = the entry look-ups of the
+   index build through the library's own one-read table also where the reference-shaped 64-bit table fits (default 0: only where it
+   does not, i.e. -B 29 / 30 at k = 21), 2 = never, 3 = always and undersized (exercises its fall-back); "cluster_narrow_first" 1 = first[] of the
    cluster kernel at 2 bytes per entry in every block, w >= 2 = 4 bytes down to w list-loop waves (default 0: 4 bytes where that
    costs no wave); "cluster_lds_budget", "cluster_first_global", "cluster_first_cap", "cluster_big_ranks", "cluster_threads0",
    "cluster_budget0" (placement and launch-class overrides of the tests), "cluster_stamps" (phase stamps into h10x_counters),

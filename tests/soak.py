@@ -84,6 +84,7 @@ def run(n_cases, seed, verbose=False, scale=1):
         if rng.random() < 0.15 and "cluster_first_global" in opts: opts["cluster_first_cap"] = rng.choice([64, 500, 1500])
         if opts.get("cluster_first_global") == 4 and rng.random() < 0.5: opts["cluster_first_cap"] = rng.choice([64, 128, 200, 300, 500, 1500])   # translated placement: tables that close, second tables, overflow chain
         if rng.random() < 0.2: opts["index_no_pack"] = 1
+        if rng.random() < 0.3: opts["index_priv_table"] = rng.choice([1, 1, 3])
         if rng.random() < 0.25: opts["cluster_narrow_first"] = rng.choice([1, 5, 12])
         tail = ["-ct", ct, "--readFQB", "x.fqb", "--hashDepthRange", lo, hi, "--cluster", 1, 0]
         simple = True

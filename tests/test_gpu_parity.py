@@ -192,11 +192,13 @@ def test_random_sets_end_to_end(workdir, seed, pairs, barcodes, genome, mol, mol
 
 
 @pytest.mark.parametrize("opts", [dict(index_no_pack=1), dict(cluster_narrow_first=1), dict(cluster_narrow_first=5),
-                                  dict(cluster_first_global=2, cluster_narrow_first=1), dict(cluster_first_global=2, cluster_lds_budget=40 * 1024)])
+                                  dict(cluster_first_global=2, cluster_narrow_first=1), dict(cluster_first_global=2, cluster_lds_budget=40 * 1024),
+                                  dict(index_priv_table=1), dict(index_priv_table=3), dict(index_priv_table=1, index_no_pack=1), dict(index_priv_table=2)])
 def test_alternative_layouts_give_the_same_bytes(workdir, opts):
     """The forms the default build does not take on a small set: index build with separate key / block arrays (default: one packed
     word per entry), first[] of the cluster kernel at 2 bytes per entry everywhere / at 4 bytes even where that costs list-loop
-    waves (default: 4 bytes where free), in the dense and in the ranked placement."""
+    waves (default: 4 bytes where free), in the dense and in the ranked placement; the entry look-ups of the index build through the library's
+    own one-read table (default only at -B 29 / 30), also undersized so that half the hashes take its fall-back."""
     orc.gen_fqb(workdir.file("x.fqb"), 40000, 120, 250000, 0.003, 77, 4.0, 150, 6000)
     hf = _against_oracle(workdir, "x.fqb", ["-ct", 3, "--readFQB", "x.fqb", "--hashDepthRange", 4, 40, "--cluster", 1, 0], **opts)
     assert hf.blocks["nSubCluster"].sum() > 0
