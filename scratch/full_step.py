@@ -11,7 +11,7 @@ wl = dict(pairs=g["pairs"], barcodes=g["barcodes"], genome=g["genome"], err=g["e
 LO, HI = 30, 100
 if os.environ.get("H10X_WL"):                                  # another generator-v2 workload of bench.py, e.g. genome3g-300M
     w = bench.WORKLOADS[os.environ["H10X_WL"]]
-    wl = {k: w[k] for k in ("pairs", "barcodes", "genome", "err", "mol", "snp", "mol_len")}; g = dict(g, seed=w["seed"]); man = dict(man, B=w["B"], hash_number=0, blocks_max=0, sum_nHash=0)
+    wl = {k: w[k] for k in ("pairs", "barcodes", "genome", "err", "mol", "snp", "mol_len")}; g = dict(g, seed=w.get("seed", 1)); man = dict(man, B=w["B"], hash_number=0, blocks_max=0, sum_nHash=0)
     LO, HI = w["lo"], w["hi"]
 passes = int(sys.argv[1]) if len(sys.argv) > 1 else 2
 stamps = len(sys.argv) > 2
