@@ -19,6 +19,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _HIP_SO = os.path.join(_HERE, "libh10x_hip.so")
 _HOST_SO = os.path.join(_HERE, "libh10x_host.so")
+ABI_VERSION = 2          # include/h10x.h H10X_ABI_VERSION this binding was written for (load_native checks the library's)
 
 
 class Hash10xError(RuntimeError):
@@ -132,6 +133,9 @@ def load_native():
     hip.h10x_last_error.restype = cs
     hip.h10x_last_error.argtypes = [vp]
     hip.h10x_export.argtypes = [vp, vp, vp, vp, vp, vp]
+    if hip.h10x_abi_version() != ABI_VERSION:
+        raise RuntimeError("libh10x_hip.so speaks ABI %d, hash10x_amd/__init__.py was written for %d (include/h10x.h H10X_ABI_VERSION): rebuild with "
+                           "`python -c 'import __graft_entry__ as g; g.build()'`" % (hip.h10x_abi_version(), ABI_VERSION))
     _libs = (hip, host)
     return _libs
 

@@ -224,7 +224,7 @@ struct Ctx {
   int64_t optDeltaLists = -1; // in-range barcode lists travel delta-coded between ranks: -1 = when there is more than one rank, 0 never, 1 always (tests)
   int64_t optRowsFakeBase = 0; // testing knob: list offsets start at this many entries (multiple of 2^rowShift) in front of the real array: 64-bit offsets on small inputs
   // streaming ingest (h10x_ingest_fqb): the record image grows on the device as the chunks arrive
-  DevBuf<u32> ingestBuf; u64 ingestRecords = 0, ingestCap = 0;
+  DevBuf<u32> ingestBuf; u64 ingestRecords = 0, ingestCap = 0; bool ingestAsync = false;   // ingestAsync: chunks came through h10x_ingest_fqb_async (the closing call then checks the count)
   static constexpr int INGEST_SLOTS = 8; hipEvent_t ingestEv[INGEST_SLOTS] = {};   // h10x_ingest_fqb_async: one event per caller's buffer
   int64_t optFaultInject = 0; // test knob: the fork/join region with this number (1 mosh classes, 2 clusHash classes, 3 good-list classes, 4 cluster
                               // classes, 5 sums beside merges) fails once between its fork and its join, then the knob clears itself

@@ -370,7 +370,15 @@ static int ingest_append(Ctx &c, const uint32_t *hostRec, uint64_t n) {
   }
   return 0;
 }
-static void ingest_drop(Ctx &c) { (void)hipStreamSynchronize(c.stream); c.ingestBuf.release(); c.ingestRecords = 0; c.ingestCap = 0; }
+static void ingest_drop(Ctx &c) { (void)hipStreamSynchronize(c.stream); c.ingestBuf.release(); c.ingestRecords = 0; c.ingestCap = 0; c.ingestAsync = false; }
+// closing call of an ingest fed by h10x_ingest_fqb_async: the image was announced as a whole (the uploads were queued into it where it stood) — fewer
+// records than announced means the caller lost a chunk, and hashing the short image would pass silently
+static int ingest_close_check(Ctx &c) {
+  if (!c.ingestAsync || c.ingestRecords == c.ingestCap) { c.ingestAsync = false; return 0; }
+  const u64 got = c.ingestRecords, want = c.ingestCap;
+  ingest_drop(c);
+  return c.fail("ingest closed with %llu records where h10x_ingest_reserve announced %llu", got, want);
+}
 // Device code is loaded on first use, a translation unit at a time (the sorts' alone is 21 MB): called from a thread of its own while the caller reads
 // its input, this takes that out of the first command's time. Stream and device of its own choosing; touches no context.
 int h10x_warm(int device) {
@@ -396,10 +404,13 @@ int h10x_ingest_fqb_async(h10x_ctx *h, const uint32_t *pinnedRec, uint64_t n, in
   if (n && !pinnedRec) return c.fail("h10x_ingest_fqb_async: null records");
   if (c.ingestRecords + n > c.ingestCap) return c.fail("h10x_ingest_fqb_async: %llu records beyond the %llu announced by h10x_ingest_reserve (the image cannot move while uploads are queued)",
                                                      (u64)(c.ingestRecords + n), (u64)c.ingestCap);
-  if (!c.ingestEv[slot] && hipEventCreateWithFlags(&c.ingestEv[slot], hipEventDisableTiming) != hipSuccess) return c.fail("hipEventCreate failed");
-  if (n) H10X_HIP(&c, hipMemcpyAsync(c.ingestBuf.p + c.ingestRecords * 30, pinnedRec, n * 120, hipMemcpyHostToDevice, c.stream));
-  H10X_HIP(&c, hipEventRecord(c.ingestEv[slot], c.stream));
-  c.ingestRecords += n;
+  // a failure from here on drops the image like the synchronous call does (h10x_ingest_fqb): queued uploads are waited for first, the image must not
+  // go back to the block cache under a running DMA
+  auto giveUp = [&](const char *what) { ingest_drop(c); return c.fail("h10x_ingest_fqb_async: %s failed", what); };
+  if (!c.ingestEv[slot] && hipEventCreateWithFlags(&c.ingestEv[slot], hipEventDisableTiming) != hipSuccess) return giveUp("hipEventCreate");
+  if (n && hipMemcpyAsync(c.ingestBuf.p + c.ingestRecords * 30, pinnedRec, n * 120, hipMemcpyHostToDevice, c.stream) != hipSuccess) return giveUp("hipMemcpyAsync (host to device)");
+  if (hipEventRecord(c.ingestEv[slot], c.stream) != hipSuccess) return giveUp("hipEventRecord");
+  c.ingestRecords += n; c.ingestAsync = true;
   return 0;
 }
 int h10x_ingest_wait(h10x_ctx *h, int slot) {
@@ -427,6 +438,7 @@ int h10x_ingest_fqb(h10x_ctx *h, const uint32_t *hostRec, uint64_t n, int final_
   H10X_TRY(enter(c));
   if (const int rc = ingest_append(c, hostRec, n)) { ingest_drop(c); return rc; }
   if (!final_chunk) return 0;
+  H10X_TRY(ingest_close_check(c));
   DevBuf<u32> image; image.swap(c.ingestBuf);                // released when this returns, whatever happens
   const u64 total = c.ingestRecords; c.ingestRecords = 0; c.ingestCap = 0;
   return h10x_read_fqb_device(h, image.p, total);
@@ -437,6 +449,7 @@ int h10x_shard_ingest_fqb(h10x_ctx *h, const uint32_t *hostRec, uint64_t n, int 
   H10X_TRY(enter(c));
   if (const int rc = ingest_append(c, hostRec, n)) { ingest_drop(c); return rc; }
   if (!final_chunk) return 0;
+  H10X_TRY(ingest_close_check(c));
   DevBuf<u32> image; image.swap(c.ingestBuf);
   const u64 total = c.ingestRecords; c.ingestRecords = 0; c.ingestCap = 0;
   return h10x_shard_read_fqb_device(h, image.p, total);

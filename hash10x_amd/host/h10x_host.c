@@ -39,6 +39,10 @@ static int fail(h10x_session *s, const char *fmt, ...) {
 static int fail_ctx(h10x_session *s) { snprintf(s->err, sizeof s->err, "%s", h10x_last_error(s->ctx)); return -1; }
 
 h10x_session *h10x_session_new(void) {
+  if (h10x_abi_version() != H10X_ABI_VERSION) {          /* libh10x_hip.so built from another include/h10x.h than this file: structs and tables would not line up */
+    fprintf(stderr, "h10x: libh10x_hip.so speaks ABI %d, this host layer was built for %d: rebuild both (make -C hash10x_amd/csrc && make -C hash10x_amd/host)\n", h10x_abi_version(), H10X_ABI_VERSION);
+    return 0;
+  }
   h10x_session *s = (h10x_session *)calloc(1, sizeof *s);
   if (!s) return 0;
   s->k = 21; s->w = 31; s->r = 17; s->B = 28; s->N = 0; s->chunk = 100000; s->ct = 5; s->device = 0;
@@ -357,8 +361,7 @@ static int put(int fd, const void *p, uint64_t n, uint64_t at) {
 }
 /* --writeHash as a pipeline: two host buffers; while one is being written to the file (put, on a thread of its own) the next slice comes off the
    device into the other. */
-static double profWait, profExport;                                                 /* H10X_HOSTPROF: where --writeHash spends its time */
-typedef struct { int fd; void *buf; uint64_t n, at; int rc, busy; pthread_t th; } Writer;
+typedef struct { int fd; void *buf; uint64_t n, at; int rc, busy; pthread_t th; double profWait, profExport; /* H10X_HOSTPROF: where --writeHash spends its time (per call: ranks of one process write side by side) */ } Writer;
 static void *writer_job(void *a) { Writer *w = (Writer *)a; w->rc = put(w->fd, w->buf, w->n, w->at); return 0; }
 static int writer_wait(Writer *w) { if (w->busy) { pthread_join(w->th, 0); w->busy = 0; } const int rc = w->rc; w->rc = 0; return rc; }
 static int writer_start(Writer *w, int fd, uint64_t n, uint64_t at) {
@@ -376,7 +379,7 @@ static int put_table(h10x_session *s, int fd, int table, size_t elem, uint64_t f
     if (writer_wait(k)) return fail(s, "%s", what);                                  /* the buffer's previous slice is in the file */
     const double te = hostprof() ? now_ms() : 0;
     if (h10x_export_slice(s->ctx, table, first + done, n, k->buf)) return fail_ctx(s);
-    if (hostprof()) { profWait += te - tw; profExport += now_ms() - te; }
+    if (hostprof()) { k->profWait += te - tw; k->profExport += now_ms() - te; }
     if (table == H10X_TABLE_BLOCKS) for (uint64_t i = 0; i < n; ++i) ((h10x_block *)k->buf)[i].clusHash = 0;
     if (writer_start(k, fd, n * elem, at + done * elem)) return fail(s, "%s", what);
     done += n;
@@ -391,7 +394,7 @@ int h10x_session_writeHash(h10x_session *s, const char *path) {
   const uint64_t depthDim = (uint64_t)s->depthDim, blocksDim = (uint64_t)s->blocksDim > z.nBlocksGlobal ? (uint64_t)s->blocksDim : z.nBlocksGlobal;
   const uint64_t oIndex = 16, oNumber = oIndex + 4 * T, oValue = oNumber + 4, oDepthHdr = oValue + 8 * (uint64_t)z.hashNumber, oDepth = oDepthHdr + 32,
                  oBlocksHdr = oDepth + 4 * depthDim, oBlocks = oBlocksHdr + 32, oClus = oBlocks + 32 * blocksDim, total = oClus + 8 * z.nEntriesGlobal;
-  const double tp0 = hostprof() ? now_ms() : 0; profWait = profExport = 0;
+  const double tp0 = hostprof() ? now_ms() : 0;
   int fd = -1, rc = 0, turn = 0; enum { BUF = 32 << 20 }; int bufPinned = 1;
   Writer w[2]; memset(w, 0, sizeof w);
   w[0].buf = h10x_pinned_alloc(BUF); w[1].buf = h10x_pinned_alloc(BUF);             /* page-locked: the slices come off the device at DMA speed */
@@ -440,7 +443,7 @@ int h10x_session_writeHash(h10x_session *s, const char *path) {
   const double tp1 = hostprof() ? now_ms() : 0;
   if (fd >= 0 && close(fd) && !rc) rc = fail(s, "write fail 3");
   if (hostprof()) fprintf(stderr, "hostprof: writeHash %.1f ms to the last slice (buffers %.1f ms, file + headers %.1f ms, device -> host %.1f ms, waiting for the file %.1f ms), close %.1f ms, %.2f GB\n",
-                          tp1 - tp0, tp01 - tp0, tp02 - tp01, profExport, profWait, now_ms() - tp1, (double)total / 1e9);
+                          tp1 - tp0, tp01 - tp0, tp02 - tp01, w[0].profExport + w[1].profExport, w[0].profWait + w[1].profWait, now_ms() - tp1, (double)total / 1e9);
   fd = -1;
   {
     uint64_t bad = rc ? 1 : 0;

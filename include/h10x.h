@@ -22,7 +22,9 @@
 extern "C" {
 #endif
 
-#define H10X_ABI_VERSION 1
+/* 2 (round 5): h10x_warm, h10x_alloc_stats, h10x_pinned_*, h10x_ingest_fqb_async / _wait, H10X_TABLE_CLUSTER_RAW, the exchange counters of
+   h10x_counters; option "cluster_dbg_skip" gone. libh10x_host.so and the Python loader refuse a libh10x_hip.so of another version. */
+#define H10X_ABI_VERSION 2
 
 typedef struct h10x_ctx h10x_ctx;
 
