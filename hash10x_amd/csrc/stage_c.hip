@@ -1312,7 +1312,7 @@ __device__ __forceinline__ void cluster_one_block_tr(const ClusterArgs &a, u32 c
 // bound (chains of LDS round trips per list), so the second workgroup is worth far more than the few loop-invariant
 // values the compiler then keeps in scratch (measured: 4.3 -> 3.4 ms on the yeast-scale set).
 template <bool IN_LDS, int FIRST_MODE, int CL_THREADS, int KLASS = 0 /* distinct functions per launch class */>
-__global__ __launch_bounds__(CL_THREADS) __attribute__((amdgpu_waves_per_eu(CL_THREADS == 1024 && KLASS == 0 ? 8 : 4)))   // classes 2, 3: one workgroup per CU anyway
+__global__ __launch_bounds__(CL_THREADS) __attribute__((amdgpu_waves_per_eu(KLASS == 0 ? (CL_THREADS == 1024 ? 8 : (CL_THREADS == 768 ? 6 : 4)) : 4)))   // classes 2, 3: one workgroup per CU anyway
 void cluster_kernel(ClusterArgs a) {
   extern __shared__ __align__(16) unsigned char smem[];
   __shared__ u32 sh[4 + 128];                               // [0..3] scalars, then per-wave scan totals
@@ -1646,7 +1646,7 @@ static int cluster_local_range(Ctx *c, int codeMin, int codeMax, int threshold, 
   struct { u32 *p; } counts{(u32 *)zeroed.p}; struct { u64 *p; } stats{zeroed.p + 6};
   const size_t budgetSmall = c->optClusterLds > 0 ? (size_t)c->optClusterLds : 80 * 1024 - 1024;
   const size_t budgetBig = c->optClusterLds > 0 ? (size_t)c->optClusterLds : 160 * 1024 - 1024;
-  const int threads0 = c->optClusterThreads0 == 512 ? 512 : 1024;                            // tuning knobs for class 0
+  const int threads0 = c->optClusterThreads0 == 512 ? 512 : (c->optClusterThreads0 == 768 ? 768 : 1024);   // tuning knobs for class 0
   const size_t budget0 = c->optClusterLds > 0 ? (size_t)c->optClusterLds : (c->optClusterBudget0 > 0 ? (size_t)c->optClusterBudget0 : budgetSmall);
   // Placement of first[] (FirstDense / FirstRanked / SlotTable + FirstSlots): dense in LDS while 2 B per barcode of the data set is
   // small; ranked in LDS while the presence bitmap + prefix (3/16 B per barcode) leaves room for the rest; translated (handles
@@ -1793,7 +1793,9 @@ static int cluster_local_range(Ctx *c, int codeMin, int codeMax, int threshold, 
   if (hc[0] || hc[1]) {
     a.stats = stats.p + 4; a.front = list1.p; a.nFront = hc[1];
     c->tstart(T_CLUSTER_MAIN);
-    if (threads0 == 512) H10X_LAUNCH_LDS(0, 512, budget0, st, list0.p, hc[0], gridOf[0], 4, ovfCountA, ovfA.p) else H10X_LAUNCH_LDS(0, CL_THREADS_SMALL, budget0, st, list0.p, hc[0], gridOf[0], 4, ovfCountA, ovfA.p)
+    if (threads0 == 512) H10X_LAUNCH_LDS(0, 512, budget0, st, list0.p, hc[0], gridOf[0], 4, ovfCountA, ovfA.p)
+    else if (threads0 == 768) H10X_LAUNCH_LDS(0, 768, budget0, st, list0.p, hc[0], gridOf[0], 4, ovfCountA, ovfA.p)
+    else H10X_LAUNCH_LDS(0, CL_THREADS_SMALL, budget0, st, list0.p, hc[0], gridOf[0], 4, ovfCountA, ovfA.p)
     c->tstop(T_CLUSTER_MAIN);
     a.stats = stats.p; a.front = nullptr; a.nFront = 0;
   }

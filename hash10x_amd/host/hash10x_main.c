@@ -275,6 +275,11 @@ int main(int argc, char **argv) {
     fprintf(outFile, "COMMAND %s", *argv);
     for (int i = 1; i < argc && *argv[i] != '-'; ++i) fprintf(outFile, " %s", argv[i]);
     fputc('\n', outFile);
+    if (outFile != stdout) {                                  /* hash10x.c:1166-1171 as it stands: the echo on stdout carries the command alone, its arguments go to the -o file a second time */
+      printf("COMMAND %s", *argv);
+      for (int i = 1; i < argc && *argv[i] != '-'; ++i) fprintf(outFile, " %s", argv[i]);
+      putchar('\n');
+    }
     if (!strcmp(*argv, "--quit") || !strcmp(*argv, "--exit")) break;
     const Command *c = commands;
     while (c->name && (strcmp(c->name, *argv) || argc < 1 + c->nArgs)) ++c;            /* too few arguments left: not a match, like ARGMATCH */

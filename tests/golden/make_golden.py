@@ -378,6 +378,76 @@ def main():
                 "sum_nSubCluster": info["sum_nSubCluster"], "checksum": ["0x%016x" % v for v in cs], "note": note,
                 "reference": "oracle/_ref/hash10x_omp -t 8 -B %d --readFQB %s.fqb --hashDepthRange %d %d --cluster 1 0 --writeHash %s.ref.hash (MALLOC_PERTURB_=255, tcache off); "
                              "gen: build/gen_fqb -v 2 -P %d -C %d -G %d -e %g -s %d" % (wl["B"], stem, wl["lo"], wl["hi"], stem, wl["pairs"], wl["barcodes"], wl["genome"], wl["err"], wl["seed"])}
+    # BASELINE configs[4] on the 3 Gb-shaped sets: --hashDepthRange --cluster, then the crib (both truth haplotypes, gen_fqb -fa), --clusterReport over
+    # every barcode, --clusterSplit, --cribSummary and --writeHash of the split state. `make_golden.py --g3split <dir>` runs the reference chain on the sets whose
+    # .fqb lies in <dir> (g3t.fqb: from --readFQB, 7 minutes; g3.fqb: from --readHash of g3.ref.hash — the same state, SURVEY B.2 — without --cribSummary, whose ten
+    # hash objects over 226 M indices do not fit the container beside the split state) and commits: sha256 + composable checksum of the split .hash, sha256 of the report
+    # text (the -o file: COMMAND echoes, crib matches, CLUSTER_SUMMARY / CODE_CLUSTER lines, MIN_POINT_DENSITY, the split line, the summary), and the accuracy figures
+    # read off the CODE_CLUSTER lines as integer sums. Outputs go through FIFOs where the disk would not hold them (14 GB of report text at 300 M pairs).
+    # Command order: --clusterReport BEFORE --clusterSplit. Behind a split the reference's report reads nGoodHashes[] past its end for the new blocks (hash10x.c:919:
+    # the array was sized by the --hashDepthRange before the split) — undefined there, refused here until a new --hashDepthRange.
+    try:
+        with open(os.path.join(HERE, "manifest.json")) as f:
+            man["split_digests"] = json.load(f).get("split_digests", {})
+    except OSError:
+        man["split_digests"] = {}
+    if "--g3split" in sys.argv:
+        import threading
+        sys.path.insert(0, orc.REPO)
+        import bench
+        d = sys.argv[sys.argv.index("--g3split") + 1]
+        only = sys.argv[sys.argv.index("--only") + 1] if "--only" in sys.argv else None
+        for name, stem, from_hash, summary in (("genome3g-tenth-30M", "g3t", False, True), ("genome3g-300M", "g3", True, False)):
+            if not os.path.exists(os.path.join(d, stem + ".fqb")) or (only and only != name):
+                continue
+            wl = bench.WORKLOADS[name]
+            if not os.path.exists(os.path.join(d, stem + ".A.fa")):
+                subprocess.run([orc.build_gen(), "-v", "2", "-P", str(wl["pairs"]), "-C", str(wl["barcodes"]), "-G", str(wl["genome"]), "-e", str(wl["err"]), "-s", str(wl["seed"]),
+                                "--barcodes", "0:0", "-o", "/dev/null", "-fa", os.path.join(d, stem)], check=True)
+            fa_sha = {}
+            for hap in ("A", "B"):
+                sha = __import__("hashlib").sha256()
+                with open(os.path.join(d, "%s.%s.fa" % (stem, hap)), "rb") as f:
+                    for blk in iter(lambda: f.read(1 << 24), b""):
+                        sha.update(blk)
+                fa_sha[hap] = sha.hexdigest()
+            rep, out = os.path.join(d, stem + ".report.fifo"), os.path.join(d, stem + ".split.fifo")
+            for q in (rep, out):
+                if os.path.exists(q):
+                    os.remove(q)
+                os.mkfifo(q)
+            head = (["-B", wl["B"], "--readHash", stem + ".ref.hash", "--hashDepthRange", wl["lo"], wl["hi"]] if from_hash else
+                    ["-B", wl["B"], "--readFQB", stem + ".fqb", "--hashDepthRange", wl["lo"], wl["hi"], "--cluster", 1, 0])
+            tail = ["-o", os.path.basename(rep), "--cribBuild", stem + ".A.fa", stem + ".B.fa", "--clusterReport", 1, 0, "--clusterSplit"] + (["--cribSummary"] if summary else []) + \
+                   ["-o", "-", "--writeHash", os.path.basename(out)]
+            res = {}
+            th = [threading.Thread(target=lambda: res.__setitem__("report", orc.report_digest(rep))),
+                  threading.Thread(target=lambda: res.__setitem__("hash", orc.canonical_file_digest(out, checksum=bench.checksum_state)))]
+            for t in th:
+                t.start()
+            t0 = __import__("time").time()
+            r = orc.run_ref(["-t", os.cpu_count()] + head + tail, d, binary="hash10x_omp", timeout=6 * 3600)
+            secs = __import__("time").time() - t0
+            if r.returncode != 0:                            # (the readers end with the writer's side of the FIFOs; if it never opened them, open and close here)
+                for q in (rep, out):
+                    try:
+                        os.close(os.open(q, os.O_WRONLY | os.O_NONBLOCK))
+                    except OSError:
+                        pass
+            for t in th:
+                t.join()
+            for q in (rep, out):
+                os.remove(q)
+            if r.returncode != 0:
+                man["split_digests"][name] = {"failed": "the reference ended with code %d after %.0f s: %s" % (r.returncode, secs, r.stderr.decode()[-300:])}
+                continue
+            (rep_sha, rep_info), (h_sha, h_info) = res["report"], res["hash"]
+            man["split_digests"][name] = {
+                "gen2": {k: wl[k] for k in ("pairs", "barcodes", "genome", "err", "seed", "mol", "snp", "mol_len")}, "B": wl["B"], "fasta_sha256": fa_sha,
+                "commands_after_cluster": [str(a) for a in tail], "report_sha256": rep_sha, "report": rep_info,
+                "sha256": h_sha, "size": h_info["size"], "hash_number": h_info["hash_number"], "blocks_max": h_info["blocks_max"], "sum_nHash": h_info["sum_nHash"],
+                "checksum": h_info["checksum"], "reference_seconds": round(secs),
+                "reference": "oracle/_ref/hash10x_omp -t %d %s (MALLOC_PERTURB_=255, tcache off)" % (os.cpu_count(), " ".join(str(a) for a in head + tail))}
     man["big_note"] = ("big_digest_cases: BASELINE configs[2] proportions at 1/10 and 1/4 scale, generated by `make_golden.py --big` from "
                        "oracle/_ref (4.5 and 12.5 minutes of the reference); only the GPU tests run them")
     with open(os.path.join(HERE, "manifest.json"), "w") as f:

@@ -386,13 +386,14 @@ def leading_options(extra):
     return list(extra[:n])
 
 
-def canonical_file_digest(path, chunk=1 << 26):
+def canonical_file_digest(path, chunk=1 << 26, checksum=None):
     """sha256 of the CANONICAL form of a .hash file (heap-pointer fields zeroed) without holding it in memory — files of
     10+ GB (full-size BASELINE configs[2]). Also returns the sizes read on the way: (hexdigest, {hash_number, blocks_max, blocks_dim, sum_nHash,
     sum_nSubCluster, size})."""
     sha = hashlib.sha256()
     info = {}
-    with open(path, "rb") as f:
+    with open(path, "rb") as raw:
+        f = _CountingReader(raw)                             # (bytes counted on the way: the input may be a FIFO the reference writes into, which cannot tell())
         head = f.read(16); sha.update(head)
         assert head[:4] == b"10XH" and int.from_bytes(head[4:8], "little") == 2
         B = int.from_bytes(head[12:16], "little")
@@ -412,6 +413,7 @@ def canonical_file_digest(path, chunk=1 << 26):
         bdim, bmax = int.from_bytes(hdr[16:20], "little"), int.from_bytes(hdr[24:28], "little")
         sum_hash = sum_sub = 0
         done = 0
+        cs = [0, 0]
         while done < bdim:                                   # ClusterBlock[dim]: clusHash pointer zeroed
             nb = min(chunk // 32, bdim - done)
             blk = np.frombuffer(bytearray(f.read(32 * nb)), dtype=BLOCK).copy()
@@ -419,11 +421,102 @@ def canonical_file_digest(path, chunk=1 << 26):
             lo, hi = max(1 - done, 0), max(min(bmax - done, nb), 0)
             if hi > lo:
                 sum_hash += int(blk["nHash"][lo:hi].sum(dtype=np.uint64)); sum_sub += int(blk["nSubCluster"][lo:hi].sum(dtype=np.uint64))
-            sha.update(blk.tobytes()); done += nb
+            sha.update(blk.tobytes())
+            if checksum is not None and hi > lo:             # bench.checksum_state over blocks 1 .. max - 1 (slot 0 is nobody's block), composable over ranks and slices
+                part = checksum(np.frombuffer(blk[lo:hi].tobytes(), dtype=np.uint8), done + lo, np.zeros(0, dtype=np.uint8), 0)
+                cs = [(cs[0] + part[0]) & 0xFFFFFFFFFFFFFFFF, (cs[1] + part[1]) & 0xFFFFFFFFFFFFFFFF]
+            done += nb
+        at = 0
         while True:                                          # ClusterHash records
             b = f.read(chunk)
             if not b:
                 break
             sha.update(b)
-        info = {"B": B, "hash_number": hash_number, "blocks_max": bmax, "blocks_dim": bdim, "sum_nHash": sum_hash, "sum_nSubCluster": sum_sub, "size": f.tell()}
+            if checksum is not None:
+                part = checksum(np.zeros(0, dtype=np.uint8), 0, np.frombuffer(b, dtype=np.uint8), at)
+                cs = [(cs[0] + part[0]) & 0xFFFFFFFFFFFFFFFF, (cs[1] + part[1]) & 0xFFFFFFFFFFFFFFFF]
+            at += len(b) // 8
+        info = {"B": B, "hash_number": hash_number, "blocks_max": bmax, "blocks_dim": bdim, "sum_nHash": sum_hash, "sum_nSubCluster": sum_sub, "size": f.n}
+        if checksum is not None:
+            info["checksum"] = ["0x%016x" % v for v in cs]
     return sha.hexdigest(), info
+
+
+class _CountingReader:
+    def __init__(self, f):
+        self.f, self.n = f, 0
+
+    def read(self, k):
+        out = bytearray()
+        while len(out) < k:                                  # a pipe hands over what it has: ask until k bytes or the end
+            b = self.f.read(k - len(out))
+            if not b:
+                break
+            out += b
+        self.n += len(out)
+        return bytes(out)
+
+
+def report_digest(path, chunk=1 << 24):
+    """sha256 of a report text (the -o file of --cribBuild / --clusterReport / --clusterSplit / --cribSummary) and the accuracy figures read off
+    its CODE_CLUSTER lines (hash10x.c:926-946): clusters, clusters located on one chromosome only (no 'OTHER' hashes), mean span in crib position
+    units (pos >> 10 of the k-mer offset, hash10x.c:440) of the located ones, reads and hashes per cluster."""
+    sha = hashlib.sha256()
+    n = pure = located = 0
+    span = reads = hashes = size = 0
+    tail = b""
+    with open(path, "rb") as f:                              # (may be a FIFO)
+        while True:
+            b = f.read(chunk)
+            if not b:
+                break
+            sha.update(b); size += len(b)
+            lines = (tail + b).split(b"\n")
+            tail = lines.pop()
+            for ln in lines:
+                if not ln.startswith(b"    CODE_CLUSTER "):
+                    continue
+                n += 1
+                w = ln.split()
+                reads += int(w[4]); hashes += int(w[6])
+                if b" OTHER " not in ln:
+                    pure += 1
+                if b" chr " in ln:
+                    k = w.index(b"chr"); located += 1; span += int(w[k + 4])
+    return sha.hexdigest(), {"clusters": n, "clusters_without_OTHER": pure, "clusters_located": located, "sum_span": span, "sum_reads": reads, "sum_hashes": hashes,
+                             "purity": (pure / n) if n else None, "mean_span": (span / located) if located else None, "size": size}
+
+
+def slice_digest(h, step=1 << 25):
+    """sha256 + size of the canonical .hash a single-GPU state would be written as (hash10x.c:244-267), assembled from h10x_export_slice in file order without a
+    file: header, hashIndex[2^B], hashNumber, hashValue[], ArrayStruct + hashDepth[dim], ArrayStruct + ClusterBlock[dim], ClusterHash records. The Array dims
+    follow arrayExtend (array.c:144-170) through the host library's own helper."""
+    import hash10x_amd
+    hip, host = hash10x_amd.load_native()
+    z = h.sizes()
+    sha = hashlib.sha256(); size = 0
+
+    def put(b):
+        nonlocal size
+        sha.update(b); size += len(b)
+    put(b"10XH" + (2).to_bytes(4, "little") + (8).to_bytes(2, "little") + (32).to_bytes(2, "little") + int(z["B"]).to_bytes(4, "little"))
+
+    def table(t, first, count, zero_ptr=False):
+        for a in range(0, count, step):
+            n = min(step, count - a)
+            b = h.export_slice(t, first + a, n)
+            if zero_ptr:
+                b = np.frombuffer(bytes(b), dtype=BLOCK).copy(); b["ptr"] = 0
+            put(b.tobytes())
+    table(0, 0, 1 << z["B"])
+    put(int(z["hashNumber"]).to_bytes(4, "little"))
+    table(1, 0, z["hashNumber"])
+    depth_dim = host.h10x_host_array_dim(1 << 20, 4, z["hashNumber"] - 1)
+    blocks_dim = host.h10x_host_array_dim(1200, 32, z["nBlocks"] - 1)
+    hdr = np.zeros(1, dtype="<i4,<i4,<u8,<i4,<i4,<i4,<i4")
+    hdr[0] = (8918274, 0, 0, depth_dim, 4, z["hashNumber"], 0); put(hdr.tobytes())
+    table(2, 0, z["hashNumber"]); put(bytes(4 * (depth_dim - z["hashNumber"])))
+    hdr[0] = (8918274, 0, 0, blocks_dim, 32, z["nBlocks"], 0); put(hdr.tobytes())
+    table(3, 0, z["nBlocks"], zero_ptr=True); put(bytes(32 * (blocks_dim - z["nBlocks"])))
+    table(4, 0, z["nClusHash"])
+    return sha.hexdigest(), size

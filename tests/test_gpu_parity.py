@@ -1202,3 +1202,92 @@ def test_cli_read_hash_onto_several_gpus(workdir, gpus):
     open(workdir.file("bad.hash"), "wb").write(bad)
     g = subprocess.run([exe, "--gpus", str(gpus), "-B", "20", "--readHash", "bad.hash"], cwd=workdir.path, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
     assert g.returncode == 255 and b"FATAL ERROR" in g.stderr
+
+
+# ---------------------------------------------------------------------------------------- BASELINE configs[4]: split + crib accuracy on the 3 Gb-shaped set
+@pytest.mark.skipif("sha256" not in MAN.get("split_digests", {}).get("genome3g-tenth-30M", {}), reason="no split digest in the manifest")
+def test_config5_split_crib_report_match_reference_digests(tmp_path_factory):
+    """BASELINE configs[4] (-B .. --hashDepthRange --cluster --clusterSplit with the --cribBuild accuracy check) on the 3 Gb-shaped set at 1/10
+    (30 M read pairs, 160 k barcodes, 300 Mb x 2, -B 27): bin/hash10x-amd runs the chain the reference ran in the build container (make_golden.py --g3split:
+    --readFQB, --hashDepthRange 6 45, --cluster 1 0, --cribBuild of both truth haplotypes, --clusterReport over every barcode, --clusterSplit — 14.6 M new
+    blocks —, --cribSummary, --writeHash), on one GPU and as --gpus 2 and 3 (ranks share this box's GPU; no gather). Expected, from the REFERENCE binary:
+    sha256 of the whole -o text (1.45 GB: crib matches, every CLUSTER_SUMMARY / CODE_CLUSTER line, MIN_POINT_DENSITY, the split line, the summary), the
+    accuracy figures read off it, and sha256 of the canonical split .hash (3.06 GB). hash10x.c:426-521, 870-952, 956-1061."""
+    import hashlib
+    import subprocess
+    case = MAN["split_digests"]["genome3g-tenth-30M"]
+    g = case["gen2"]
+    d = str(tmp_path_factory.mktemp("c5"))
+    subprocess.run([orc.build_gen(), "-v", "2", "-P", str(g["pairs"]), "-C", str(g["barcodes"]), "-G", str(g["genome"]), "-e", str(g["err"]), "-s", str(g["seed"]),
+                    "-m", str(g["mol"]), "-S", str(g["snp"]), "-L", str(g["mol_len"]), "-o", os.path.join(d, "g3t.fqb"), "-fa", os.path.join(d, "g3t")], check=True, stderr=subprocess.DEVNULL)
+    for hap in ("A", "B"):
+        sha = hashlib.sha256()
+        with open(os.path.join(d, "g3t.%s.fa" % hap), "rb") as f:
+            for blk in iter(lambda: f.read(1 << 24), b""):
+                sha.update(blk)
+        assert sha.hexdigest() == case["fasta_sha256"][hap], "gen_fqb -fa is not reproducing the truth genome %s" % hap
+    tail = [a if not a.endswith(".fifo") else a.replace(".report.fifo", ".report.txt").replace(".split.fifo", ".split.hash") for a in case["commands_after_cluster"]]
+    try:
+        for gpus in (1, 2, 3):
+            cmd = [os.path.join(orc.REPO, "bin", "hash10x-amd")] + (["--gpus", str(gpus)] if gpus > 1 else []) + \
+                  ["-B", str(case["B"]), "--readFQB", "g3t.fqb", "--hashDepthRange", "6", "45", "--cluster", "1", "0"] + tail
+            r = subprocess.run(cmd, cwd=d, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+            assert r.returncode == 0, "--gpus %d: %s" % (gpus, r.stderr.decode()[-1500:])
+            rep_sha, rep = orc.report_digest(os.path.join(d, "g3t.report.txt"))
+            for k in ("clusters", "clusters_without_OTHER", "clusters_located", "sum_span", "sum_reads", "sum_hashes", "size"):
+                assert rep[k] == case["report"][k], "--gpus %d: report figure %s = %r, reference %r" % (gpus, k, rep[k], case["report"][k])
+            assert rep_sha == case["report_sha256"], "--gpus %d: report text differs from the reference's" % gpus
+            digest, info = orc.canonical_file_digest(os.path.join(d, "g3t.split.hash"))
+            assert (info["hash_number"], info["blocks_max"], info["sum_nHash"], info["size"]) == (case["hash_number"], case["blocks_max"], case["sum_nHash"], case["size"]), (gpus, info)
+            assert digest == case["sha256"], "--gpus %d: split .hash differs from the reference's" % gpus
+            os.remove(os.path.join(d, "g3t.split.hash")); os.remove(os.path.join(d, "g3t.report.txt"))
+    finally:
+        import shutil
+        shutil.rmtree(d, ignore_errors=True)
+
+
+# ---------------------------------------------------------------------------------------- the whole .hash at -B 30
+@pytest.mark.skipif("genome3g-300M" not in MAN.get("strong_digests", {}) or (os.cpu_count() or 1) < 16, reason="no digest in the manifest / too few host threads to generate 300 M pairs")
+def test_genome3g_full_size_matches_reference_digest(tmp_path_factory):
+    """The 3 Gb workload at the size its reference run is pinned (300 M read pairs, 1.6 M barcodes, -B 30, --hashDepthRange 6 45 --cluster 1 0): the WHOLE
+    canonical .hash — hashIndex[2^30] (exactly 2^32 bytes: where a 32-bit byte offset wraps), hashValue[], both Array headers, hashDepth[], the blocks and 2.2 G
+    ClusterHash records, 24.7 GB — has the sha256 and the size of the REFERENCE binary's (manifest "strong_digests", make_golden.py --g3: 42 minutes there).
+    writeHashFile, hash10x.c:244-267. The file goes to the test's temporary directory; where that cannot hold it the five sections are digested from
+    h10x_export_slice in file order instead (the same bytes without the file)."""
+    import hashlib
+    import hash10x_amd
+    sys.path.insert(0, orc.REPO)
+    import bench
+    case = MAN["strong_digests"]["genome3g-300M"]
+    wl = bench.WORKLOADS["genome3g-300M"]
+    recs, _first, total = bench.generate_v2(wl, wl["seed"])
+    assert total == wl["pairs"] and recs.size == 30 * wl["pairs"]
+    for key, sl in (("head_sha256", recs[: 30 << 20]), ("tail_sha256", recs[-(30 << 20):])):
+        assert hashlib.sha256(sl.tobytes()).hexdigest() == case["input"][key], "gen_fqb v2 is not reproducing the seeded input (%s)" % key
+    d = hash10x_amd.DeviceRecords(recs)
+    del recs
+    h = hash10x_amd.Hash10x(B=case["B"])
+    h.read_fqb_device(d.ptr, d.n_records)
+    d.free()
+    a = case["args"]
+    h.depth_range(int(a[1]), int(a[2]))
+    h.cluster(int(a[4]), int(a[5]), 5)
+    z = h.sizes()
+    assert z["hashNumber"] == case["hash_number"] and z["nBlocks"] == case["blocks_max"] and z["nClusHash"] == case["sum_nHash"]
+    tmp = tmp_path_factory.mktemp("g3")
+    out = str(tmp / "g3.hash")
+    st = os.statvfs(str(tmp))
+    if st.f_bavail * st.f_frsize > case["size"] + (4 << 30):
+        try:
+            h.write_hash(out)
+            h.close()
+            digest, info = orc.canonical_file_digest(out)
+        finally:
+            if os.path.exists(out):
+                os.remove(out)
+        assert info["sum_nSubCluster"] == case["sum_nSubCluster"] and info["size"] == case["size"]
+    else:
+        digest, size = orc.slice_digest(h)
+        h.close()
+        assert size == case["size"]
+    assert digest == case["sha256"]
