@@ -214,6 +214,7 @@ struct Ctx {
   int64_t optPrivTable = 0;   // entry look-ups of the index build: 0 = the table of this library's own where key + index do not fit the 64-bit reference-shaped one, 1 = always (tests), 2 = never, 3 = always and too small (tests: the fall-back)
   int64_t optNoPack = 0;      // index build with separate key / block arrays even where the packed form fits (A/B, tests)
   int64_t optNarrowFirst = 0; // first[] of the cluster kernel at 2 bytes per entry in every block (default: 4 where the block's working set leaves room)
+  int64_t optTrPacked = -1;   // translated placement of the cluster kernel: -1 / 1 = packed (several lists per wave instruction), 0 = one list per wave instruction (round 4's form: A/B, tests)
   int64_t optStamps = 0;      // diagnostic: per-phase wall-clock stamps in cluster_kernel
   int64_t optChunk = 0;       // -c <chunkSize> of the reference's readFQB loop (hash10x.c:202-223): 0 = no chunk semantics (no "chunkSize too small", no
                               // all-A-barcode quirk); set by the session layer for --readFQB

@@ -649,7 +649,7 @@ __device__ void row_mode_long(const void *__restrict__ row, u32 d, u32 code, u32
     }
   }
 }
-#define STAMP(k) do { if (a.phase && threadIdx.x == 0) { const u64 t__ = wall_clock64(); atomicAdd((u64 *)&a.phase[k], t__ - tPrev); tPrev = t__; } } while (0)
+#define STAMP(k) do { if (a.phase && threadIdx.x == 0) { const u64 t__ = wall_clock64(); atomicAdd((u64 *)&a.phase[k], t__ - (u64)acc.s[4]); acc.s[4] = t__; } } while (0)   /* (the previous stamp lives in LDS: diagnostic code must not cost the kernels a register pair) */
 
 // Workgroup barrier. In the HBM-scratch instantiation the working set lives in global memory and is re-used
 // by successive phases: drop this CU's vector-L1 copies after every barrier (buffer_inv sc1) so that no phase
@@ -685,8 +685,12 @@ __device__ __forceinline__ u32 descFix(u32 v, u32 i0, u32 nLists, u32 n) {
   return (lane < 32 || (t < nLists && i >= 1 && i < n)) ? v : 0u;
 }
 
+// work counters of a workgroup: the list entries gathered are summed per lane (32 bits: a wave's share of a launch) and posted when the kernel ends; what thread 0
+// alone counts — good hashes, nHash, barcodes, the lengths of the rank-0 lists — lives in LDS (the four 64-bit registers per lane these took were a tenth of the
+// 64 a wave has where two 1024-lane workgroups share a CU)
+struct WorkAcc { u32 depth; unsigned long long *s; };
 template <bool IN_LDS, int FIRST_MODE /* 0 dense in LDS, 1 ranked in LDS, 2 dense on an HBM slot, 3 hashed in LDS */, int CL_THREADS, int KLASS>
-__device__ __forceinline__ void cluster_one_block(const ClusterArgs &a, u32 code, unsigned char *region, u16 *firstGlobal, u32 *sh /* small shared ints */, u64 (&acc)[4]) {   // code: local block number
+__device__ __forceinline__ void cluster_one_block(const ClusterArgs &a, u32 code, unsigned char *region, u16 *firstGlobal, u32 *sh /* small shared ints */, WorkAcc &acc) {   // code: local block number
   constexpr int CL_WAVES = CL_THREADS / WAVE;
   // lists a wave keeps in flight: 4, but 2 where the kernel must stay within 64 VGPRs (two workgroups per CU) AND carries
   // the ranked / hashed lookup: fewer registers spilled is worth more there than the deeper prefetch (8x set: 52.8 -> 41.4 ms);
@@ -727,7 +731,7 @@ __device__ __forceinline__ void cluster_one_block(const ClusterArgs &a, u32 code
   u64 *const res = a.res + o;
   const u32 thr = (u32)a.threshold;
 
-  u64 tPrev = a.phase ? wall_clock64() : 0;
+  if (a.phase && threadIdx.x == 0) acc.s[4] = wall_clock64();
   // ---- init: clear the tables; nothing is fetched per rank any more
   if (FIRST_LDS && !RANKED) {
     if (wideFirst) for (u32 i = tid; i < a.nBlocksFirst; i += CL_THREADS) ((u32 *)w.first)[i] = NONE16;
@@ -966,8 +970,8 @@ __device__ __forceinline__ void cluster_one_block(const ClusterArgs &a, u32 code
   // clusters cut, the quotients), point_sum_kernel and read_merge_kernel finish the block.
   // work counters: kept per lane over the barcodes of the workgroup, posted once when the kernel ends (19 atomics per
   // barcode on four shared words would queue up in L2 behind those of every other workgroup)
-  if (lane == 0) acc[1] += sDepth;
-  if (tid == 0) { acc[1] += (u32)(gr[0] >> 32); acc[0] += n; acc[2] += a.blocks[lcode].nHash; acc[3] += 1; }
+  if (lane == 0) acc.depth += sDepth;
+  if (tid == 0) { acc.s[3] += (u32)(gr[0] >> 32); acc.s[0] += n; acc.s[1] += a.blocks[lcode].nHash; acc.s[2] += 1; }
   if (!FIRST_LDS) {                                          // leave first[] clean for the next barcode of this workgroup
     SYNC();
     const u32 uw = (u32)__builtin_amdgcn_readfirstlane(wave);
@@ -985,7 +989,7 @@ __device__ __forceinline__ void cluster_one_block(const ClusterArgs &a, u32 code
 // workgroup's HBM slot, first[] final in the table; pass B = the list loop on handles (msBest / msMax / msTot and the
 // pointToMin counts per rank, hash10x.c:801-821, exactly as cluster_one_block's), then the ranks the loop left open.
 template <int CL_THREADS, int KLASS>
-__device__ __forceinline__ void cluster_one_block_tr(const ClusterArgs &a, u32 code, unsigned char *region, u32 *sh, u64 (&acc)[4]) {
+__device__ __forceinline__ void cluster_one_block_tr(const ClusterArgs &a, u32 code, unsigned char *region, u32 *sh, WorkAcc &acc) {
   constexpr bool IN_LDS = true;
   constexpr int CL_WAVES = CL_THREADS / WAVE;
   constexpr int RIF = KLASS == 2 ? 8 : ROWS_IN_FLIGHT;         // (the whole-CU class has 128 registers per lane and only four waves per SIMD to hide latency behind: twice the lists in flight)
@@ -1012,7 +1016,7 @@ __device__ __forceinline__ void cluster_one_block_tr(const ClusterArgs &a, u32 c
   u16 *const hs = a.handles + (size_t)blockIdx.x * a.handleStride;   // this workgroup's handles: list i at hs + i * hst
   const u32 hst = a.hStride, lgH = 31 - (u32)__clz((int)hst);
   const u32 uwave = (u32)__builtin_amdgcn_readfirstlane(wave);
-  u64 tPrev = a.phase ? wall_clock64() : 0;
+  if (a.phase && threadIdx.x == 0) acc.s[4] = wall_clock64();
 
   // ---- pass A
   u32 *const tab = (u32 *)region;
@@ -1298,8 +1302,437 @@ __device__ __forceinline__ void cluster_one_block_tr(const ClusterArgs &a, u32 c
       }
     }
   }
-  if (lane == 0) acc[1] += sDepth;
-  if (tid == 0) { acc[1] += (u32)(gr[0] >> 32); acc[0] += n; acc[2] += a.blocks[lcode].nHash; acc[3] += 1; }
+  if (lane == 0) acc.depth += sDepth;
+  if (tid == 0) { acc.s[3] += (u32)(gr[0] >> 32); acc.s[0] += n; acc.s[1] += a.blocks[lcode].nHash; acc.s[2] += 1; }
+  SYNC();
+  STAMP(5);
+}
+
+
+// ---- translated placement, PACKED (round 5) -------------------------------------------------------------------------------------
+// The ranks of a block ascend in list length (the good list is ordered by depth: hash10x.c:726-730,758), so its lists fall into
+// contiguous rank classes: Q up to 16 entries, H up to 32, F up to 64, D up to 128, X beyond. A wave instruction serves FOUR lists of
+// class Q (one per 16-lane DPP row), TWO of class H, one of class F / D; every per-list quantity — rank, length, msBest / msMax / msTot
+// (hash10x.c:801-806), the founding rank and the two counts of the pointToMin term (hash10x.c:819-821) — lives in the lanes of the
+// list's segment: segmented DPP maximum, per-segment popcounts of ballots, per-segment histogram regions. Nothing per list goes through
+// the scalar unit, which is what bounded the per-list form (one list per wave instruction: 130 scalar + 126 vector instructions per list,
+// a third of the lanes in use where the depth range is 6-45), and the units of a round carry no branches, so their LDS round trips overlap.
+// Handles lie packed in the same order on the workgroup's HBM slot: class Q at 16 u16 per rank, H 32, F 64, D 128, X the slot's stride;
+// pass B loads a unit's 64 handles with one coalesced load and needs no list descriptor at all (pass A writes `none` where a lane has no entry).
+struct TpShape { u32 m16, m32, m64, m128, posH, posF, posD, posX; };
+__device__ __forceinline__ u32 tpPos(const TpShape &s, u32 i, u32 hst) {        // where the handles of rank i start
+  if (i < s.m16) return 16u * i;
+  if (i < s.m32) return s.posH + 32u * (i - s.m16);
+  if (i < s.m64) return s.posF + 64u * (i - s.m32);
+  if (i < s.m128) return s.posD + 128u * (i - s.m64);
+  return s.posX + hst * (i - s.m128);
+}
+// maximum over the lanes of a segment (16, 32 or 64 lanes), handed to every lane of the segment: DPP prefix maxima inside the rows, row broadcasts
+// across them (as far as the segment reaches), then one LDS-crossbar permute from the segment's last lane
+template <int SEGW> __device__ __forceinline__ u32 seg_max_u32(u32 v, u32 laneU) {
+#define H10X_DPP_MAX(ctrl, rowmask) { const u32 o = (u32)__builtin_amdgcn_update_dpp(0, (int)v, ctrl, rowmask, 0xf, false); v = o > v ? o : v; }
+  H10X_DPP_MAX(0x111, 0xf) H10X_DPP_MAX(0x112, 0xf) H10X_DPP_MAX(0x114, 0xf) H10X_DPP_MAX(0x118, 0xf)
+  if (SEGW >= 32) H10X_DPP_MAX(0x142, 0xa)
+  if (SEGW >= 64) H10X_DPP_MAX(0x143, 0xc)
+#undef H10X_DPP_MAX
+  if (SEGW == 64) return (u32)__builtin_amdgcn_readlane((int)v, 63);
+  return (u32)__builtin_amdgcn_ds_bpermute((int)((laneU | (u32)(SEGW - 1)) << 2), (int)v);
+}
+// bits of a ballot that belong to the lane's segment, counted
+template <int SEGW> __device__ __forceinline__ u32 seg_popc(u64 bal, u32 laneU) {
+  if (SEGW == 64) return (u32)__popcll(bal);
+  if (SEGW == 32) { const u32 lo = (u32)__popc((u32)bal), hi = (u32)__popc((u32)(bal >> 32)); return laneU < 32 ? lo : hi; }
+  return (u32)__popc((u32)(bal >> (laneU & 48u)) & 0xFFFFu);
+}
+
+template <int CL_THREADS, int KLASS>
+__device__ __forceinline__ void cluster_one_block_tp(const ClusterArgs &a, u32 code, unsigned char *region, u32 *sh, WorkAcc &acc) {
+  constexpr bool IN_LDS = true;
+  constexpr int CL_WAVES = CL_THREADS / WAVE;
+#ifndef H10X_TP_RIF0
+#define H10X_TP_RIF0 2
+#define H10X_TP_RIF2 4
+#endif
+  constexpr int RIF = KLASS == 2 ? H10X_TP_RIF2 : H10X_TP_RIF0;        // units a wave keeps in flight
+  const int tid = threadIdx.x, lane = tid & (WAVE - 1), wave = tid / WAVE;
+  const u32 laneU = (u32)lane;
+  code = (u32)__builtin_amdgcn_readfirstlane((int)code);
+  const u32 n = (u32)__builtin_amdgcn_readfirstlane((int)a.nGood[code]);
+  if (n == 0) return;                                        // hash10x.c:780: block left untouched
+  const u64 o = a.blockOff[code];
+  const u32 lcode = code; code = a.segs.globalOf(lcode);     // from here on `code` is the global barcode number (what the lists hold)
+  u32 S, S2, nW; bool compactUnused;
+  translatedShape(n, CL_WAVES, a.ldsBudget, a.hashMinSlots, a.entries[lcode], a.nBlocksFirst, a.firstCap, S, S2, nW, compactUnused);
+  if (!S || nW < MIN_HIST_WAVES) {                           // cannot hold this barcode at all: hand it on
+    if (tid == 0) a.overflow[atomicAdd(a.overflowCount, 1u)] = lcode;
+    return;
+  }
+  const u32 closeAt = translatedCloseAt(S, S2);
+  const u32 rsh = a.rowShift;
+#define ROWP(rs) (a.rows + ((size_t)(rs) << rsh))
+  const u64 *const gr = a.goodRow + o;
+  u64 *const res = a.res + o;
+  u32 thr = (u32)a.threshold;
+  asm volatile("" : "+s"(thr));
+  u16 *const hs = a.handles + (size_t)blockIdx.x * a.handleStride;
+  const u32 hst = a.hStride;
+  const u32 uwave = (u32)__builtin_amdgcn_readfirstlane(wave);
+  if (a.phase && threadIdx.x == 0) acc.s[4] = wall_clock64();
+
+  // ---- the table of pass A is cleared, and meanwhile the classes are counted: ranks ascend in list length, so `lists of at most L entries` is a rank
+  u32 *const tab = (u32 *)region;
+  for (u32 i = tid; i <= S; i += CL_THREADS) tab[i] = 0xFFFFFFFFu;   // (+ the word of handle `none`)
+  if (tid < 8) sh[tid] = 0;                                  // [0] entries left for the second table, [1] barcodes in the first, [2] a table overflowed, [4..7] class counts
+  if (tid == 0) res[0] = RES_PACK(NONE16, 0, 0);
+  SYNC();
+  {
+    u32 c16 = 0, c32 = 0, c64 = 0, c128 = 0;                 // (uniform)
+    for (u32 i0 = uwave * WAVE; i0 < n; i0 += CL_THREADS) {
+      const u32 i = i0 + laneU;
+      const u32 d = i < n ? (u32)(gr[i] >> 32) : 0xFFFFFFFFu;
+      c16 += (u32)__popcll(__ballot(d <= 16u)); c32 += (u32)__popcll(__ballot(d <= 32u)); c64 += (u32)__popcll(__ballot(d <= 64u)); c128 += (u32)__popcll(__ballot(d <= 128u));
+    }
+    if (lane == 0 && c128) { atomicAdd(&sh[4], c16); atomicAdd(&sh[5], c32); atomicAdd(&sh[6], c64); atomicAdd(&sh[7], c128); }
+  }
+  SYNC();
+  STAMP(0);
+  // ---- how the lists are packed: four / two to a wave instruction where the histogram regions of that many segments fit beside first[] and root[]
+  // (pass B: first[] at 2 bytes per slot, root[] 2 bytes per rank, one region per segment and wave). Decided here, before pass A: the handles are laid out by it.
+  TpShape tp;
+  u32 histBytes;                                             // per wave in pass B
+  {
+    const u32 c16 = sh[4], c32 = sh[5];
+    tp.m64 = sh[6]; tp.m128 = sh[7];
+    auto p4 = [](u32 x) { return (x + 3u) & ~3u; };
+    const long fixedB = (long)pad16((size_t)n * 2) + 64;
+    const long space = (long)a.ldsBudget - (long)pad16(2 * ((size_t)S + 8)) - fixedB;
+    const long spaceSpill = S2 ? (long)a.ldsBudget - (long)pad16(2 * ((size_t)S + S2 + 16)) - fixedB : space;
+    const u32 nD = tp.m128 - tp.m64;
+    u32 bestW = 0, bestU = 1; tp.m16 = 0; tp.m32 = 0; histBytes = p4(n);
+    for (int opt = 0; opt < 3; ++opt) {
+      const u32 q = opt == 0 ? c16 : 0u, h = opt <= 1 ? c32 : 0u;
+      u32 R = p4(n); if (4u * p4(q) > R) R = 4u * p4(q); if (2u * p4(h) > R) R = 2u * p4(h);
+      if ((long)R > spaceSpill) continue;
+      u32 w = (u32)(space / (long)R); if (w > (u32)CL_WAVES) w = CL_WAVES;
+      if (w < MIN_HIST_WAVES) continue;
+      const u32 units = (q + 3) / 4 + (h - q + 1) / 2 + (n - h) + nD;
+      if (!bestW || (u64)w * bestU > (u64)bestW * units) { bestW = w; bestU = units ? units : 1; tp.m16 = q; tp.m32 = h; histBytes = R; }
+    }
+    if (tp.m32 > tp.m64) tp.m32 = tp.m64;                    // (cannot happen: counts of <= 32 and <= 64)
+    nW = bestW ? bestW : (u32)MIN_HIST_WAVES;                // (option 2 always qualifies: translatedShape left room for MIN_HIST_WAVES regions of n bytes)
+    tp.posH = (16u * tp.m16 + 63u) & ~63u;
+    tp.posF = tp.posH + ((32u * (tp.m32 - tp.m16) + 63u) & ~63u);
+    tp.posD = tp.posF + 64u * (tp.m64 - tp.m32);
+    tp.posX = tp.posD + 128u * (tp.m128 - tp.m64);
+  }
+  // entries whose search goes beyond the home bucket are parked — barcode | rank << 22 | position of the handle << 38 — in a queue of the wave's own
+  // behind the handles on the HBM slot, and searched for with search() 64 lanes at a time when the pass is over (or the queue full). What search()
+  // cannot settle — a barcode that is new when the table is closed — stays in the queue, for the second table.
+  unsigned long long *const queue = (unsigned long long *)(hs + a.handleStride - (size_t)CL_WAVES * TR_QUEUE * 4) + (size_t)uwave * TR_QUEUE;
+  u32 qn = 0, qk = 0;                                        // (uniform)
+  SlotTable st; st.shape(tab, S, a.hashBits, &sh[2], 0);
+  auto settle = [&](const SlotTable &t, bool mayInsert, u32 fillLimit, bool all) {
+    u32 k0 = qk;
+    for (; all ? k0 < qn : k0 + WAVE <= qn; k0 += WAVE) {
+      const bool on = k0 + laneU < qn;
+      const unsigned long long e = on ? queue[k0 + laneU] : 0ull;
+      const bool insert = mayInsert && *(volatile u32 *)&sh[1] < fillLimit;   // (uniform: one LDS word)
+      u32 h = 0; bool ins = false;
+      if (on) { h = t.search((u32)e & 0x3FFFFFu, (u32)(e >> 22) & 0xFFFFu, insert, ins); if (h != SlotTable::NOTFOUND) hs[(u32)(e >> 38)] = (u16)h; }
+      const u64 balI = __ballot(ins);
+      if (balI && lane == 0) atomicAdd(&sh[1], (u32)__popcll(balI));
+      const u64 balU = __ballot(on && h == SlotTable::NOTFOUND);
+      if (balU) {
+        if (on && h == SlotTable::NOTFOUND) queue[qk + (u32)__popcll(balU & ((1ULL << lane) - 1))] = e;   // (qk <= k0: behind what has been read)
+        qk += (u32)__popcll(balU);
+      }
+    }
+    const u32 rest = k0 < qn ? qn - k0 : 0u;
+    if (rest && k0 != qk) { const unsigned long long e = laneU < rest ? queue[k0 + laneU] : 0ull; if (laneU < rest) queue[qk + laneU] = e; }
+    qn = qk + rest;
+  };
+  // ---- pass A
+  {
+    bool insert = true;                                      // (uniform) the table takes new barcodes: looked up once per round
+    u32 myIns = 0;
+    // one chunk: 64 entries (of up to four lists) -> their handles at position pos + lane; i, drem: the lane's rank and what its list holds from this chunk's first lane of the segment on
+    auto place = [&](u32 cj, u32 i, bool valid, u32 pos) {
+      u32 slot; bool ins;
+      const bool done = st.probeHome(cj, i, valid, insert, slot, ins);
+      hs[pos + laneU] = (u16)(valid ? slot : S);             // every lane: `none` where the lane has no entry — pass B loads and counts a chunk without looking at a length
+      myIns += (u32)__popcll(__ballot(ins));
+      const u64 bal = __ballot(!done);
+      if (bal) {
+        if (!done) queue[qn + (u32)__popcll(bal & ((1ULL << lane) - 1))] = (unsigned long long)cj | ((unsigned long long)i << 22) | ((unsigned long long)(pos + laneU) << 38);
+        qn += (u32)__popcll(bal);
+      }
+    };
+    auto roundEnd = [&](bool last) {
+      if (last || qn - qk >= WAVE) {
+        if (myIns) { if (lane == 0) atomicAdd(&sh[1], myIns); myIns = 0; }
+        settle(st, true, closeAt, last);
+        if (qn > TR_QUEUE - 4 * RIF * WAVE) { sh[2] = 1; qn = qk = 0; }   // more entries wait for the second table than the queue holds: the block is handed on
+      }
+    };
+    // the units of one class: SEGW lanes per list, NCH chunks per unit (2: the lists of 65 .. 128 entries, one per unit)
+    auto classA = [&](auto segw_, auto nch_, const u32 firstRank, const u32 endRank, const u32 posBase) {
+      constexpr u32 SEGW = decltype(segw_)::value, NCH = decltype(nch_)::value, LPU = WAVE / SEGW;
+      const u32 nUnits = (endRank - firstRank + LPU - 1) / LPU;
+      if (uwave * RIF >= nUnits) return;
+      constexpr u32 stepA = CL_WAVES * RIF;
+      const u32 seg = laneU / SEGW, jl = laneU & (SEGW - 1);
+      // descriptors of the RIF * LPU lists of a round in ONE register: lane t the offset, lane 32 + t the length of the round's t-th list (clamped index: no lane skips the load)
+      auto descBatch = [&](u32 u0) { const u32 i = firstRank + u0 * LPU + (laneU & 31u); return ((const u32 *)gr)[2 * (size_t)(i < n ? i : n - 1) + (laneU >> 5)]; };
+      u32 cN[RIF][NCH], lenN[RIF];
+      auto issue = [&](u32 dv, u32 u0) {                     // the entry loads of a round (no lane skips one: rows[] has ROWS_PAD entries of slack)
+#pragma unroll
+        for (int t = 0; t < RIF; ++t) {
+          u32 lo, hi;
+          if (SEGW == 64) { lo = (u32)__builtin_amdgcn_readlane((int)dv, t); hi = (u32)__builtin_amdgcn_readlane((int)dv, 32 + t); }
+          else { const u32 src = (u32)t * LPU + seg; lo = (u32)__builtin_amdgcn_ds_bpermute((int)(src << 2), (int)dv); hi = (u32)__builtin_amdgcn_ds_bpermute((int)((32u + src) << 2), (int)dv); }
+          const u32 r = firstRank + (u0 + (u32)t) * LPU + seg;
+          lenN[t] = (r >= 1 && r < endRank) ? hi : 0u;        // rank 0 is never processed (hash10x.c:789); ranks of the next class and past the last rank: no entries
+          const u32 *row = ROWP(lo) + jl;
+#pragma unroll
+          for (u32 c = 0; c < NCH; ++c) cN[t][c] = row[c * WAVE];
+        }
+      };
+      u32 u0 = uwave * RIF;
+      u32 dvN = descBatch(u0), dvNN = descBatch(u0 + stepA);
+      issue(dvN, u0);
+      for (; u0 < nUnits; u0 += stepA) {
+        u32 c0[RIF][NCH], len[RIF];
+#pragma unroll
+        for (int t = 0; t < RIF; ++t) { len[t] = lenN[t];
+#pragma unroll
+          for (u32 c = 0; c < NCH; ++c) c0[t][c] = cN[t][c]; }
+        dvN = dvNN; dvNN = descBatch(u0 + 2 * stepA);
+        issue(dvN, u0 + stepA);
+        if (S2) {                                            // a table that may fill up: say what this wave has put in, see whether it still takes barcodes
+          if (myIns) { if (lane == 0) atomicAdd(&sh[1], myIns); myIns = 0; }
+          insert = (u32)__builtin_amdgcn_readfirstlane((int)*(volatile u32 *)&sh[1]) < closeAt;
+        }
+#pragma unroll
+        for (int t = 0; t < RIF; ++t) {
+          if (u0 + (u32)t >= nUnits) break;                  // (uniform) the class region ends here: what lies behind belongs to the next class
+          const u32 r = firstRank + (u0 + (u32)t) * LPU + seg;
+          acc.depth += jl == 0 ? len[t] : 0u;
+#pragma unroll
+          for (u32 c = 0; c < NCH; ++c) place(c0[t][c], r, jl + c * WAVE < len[t] && c0[t][c] != code, posBase + (u0 + (u32)t) * (WAVE * NCH) + c * WAVE);
+        }
+        roundEnd(false);
+      }
+    };
+    classA(std::integral_constant<u32, 16>{}, std::integral_constant<u32, 1>{}, 0u, tp.m16, 0u);
+    classA(std::integral_constant<u32, 32>{}, std::integral_constant<u32, 1>{}, tp.m16, tp.m32, tp.posH);
+    classA(std::integral_constant<u32, 64>{}, std::integral_constant<u32, 1>{}, tp.m32, tp.m64, tp.posF);
+    classA(std::integral_constant<u32, 64>{}, std::integral_constant<u32, 2>{}, tp.m64, tp.m128, tp.posD);
+    for (u32 i = tp.m128 + uwave; i < n; i += CL_WAVES) {     // class X (depth ranges beyond 128): list after list, chunk after chunk
+      if (i == 0) continue;
+      const u64 g2 = gr[i]; const u32 d = (u32)__builtin_amdgcn_readfirstlane((int)(u32)(g2 >> 32)); const u32 *row = ROWP((u32)__builtin_amdgcn_readfirstlane((int)(u32)g2));
+      const u32 pos = tp.posX + hst * (i - tp.m128);
+      if (lane == 0) acc.depth += d;
+      for (u32 lj = 0; lj < d; lj += WAVE) {
+        const u32 cj = row[lj + laneU];
+        place(cj, i, lj + laneU < d && cj != code, pos + lj);
+        roundEnd(false);
+      }
+    }
+    roundEnd(true);
+    STAMP(1);
+    if (qn && lane == 0) sh[0] = 1;
+  }
+  __syncthreads();                                           // (the handles other waves wrote are plain stores of this CU, read back through its own L1: workgroup scope is enough)
+  STAMP(2);
+  const bool spill = sh[0] != 0 && !sh[2];                   // (uniform: read after the barrier)
+  if (spill) {                                               // the first table is final now: what is still queued is looked up once more; what is still not there goes into the second table
+    qk = 0; settle(st, false, 0, true);
+    SYNC();
+  }
+  if (sh[2]) {
+    if (tid == 0) a.overflow[atomicAdd(a.overflowCount, 1u)] = lcode;
+    SYNC();
+    return;
+  }
+  // ---- the table gives its LDS back: the ranks, 2 bytes per slot, compacted in place
+  FirstSlots ft; ft.none = S;
+  size_t firstBytes;
+  auto compactRanks = [&](const u32 *src, u16 *dst, u32 count) {   // dst below src (or equal)
+    for (u32 base = 0; base < count; base += 4 * CL_THREADS) {
+      u32 v[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) { const u32 idx = base + (u32)k * CL_THREADS + tid; v[k] = idx < count ? src[idx] : 0u; }
+      SYNC();
+#pragma unroll
+      for (int k = 0; k < 4; ++k) { const u32 idx = base + (u32)k * CL_THREADS + tid; if (idx < count) dst[idx] = (u16)(v[k] >> 16); }
+    }
+  };
+  compactRanks(tab, (u16 *)region, S + 1);
+  ft.base = region; ft.sh = 1; firstBytes = pad16(2 * ((size_t)S + 8));
+  if (spill) {
+    u32 *const tab2 = (u32 *)(region + firstBytes);
+    SYNC();
+    for (u32 i = tid; i < S2; i += CL_THREADS) tab2[i] = 0xFFFFFFFFu;
+    if (tid == 0) sh[1] = 0;
+    SYNC();
+    SlotTable st2; st2.shape(tab2, S2, a.hashBits, &sh[2], S + 1);
+    qk = 0; settle(st2, true, 0xFFFFFFFFu, true);
+    if (qn) sh[2] = 1;                                       // (cannot happen: search() inserts or reports the overflow)
+    SYNC();
+    if (sh[2]) {
+      if (tid == 0) a.overflow[atomicAdd(a.overflowCount, 1u)] = lcode;
+      SYNC();
+      return;
+    }
+    compactRanks(tab2, (u16 *)region + S + 1, S2);
+    firstBytes = pad16(2 * ((size_t)S + S2 + 16));
+    const long space = (long)a.ldsBudget - (long)firstBytes - (long)pad16((size_t)n * 2) - 64;
+    nW = (u32)(space / (long)histBytes); if (nW > (u32)CL_WAVES) nW = CL_WAVES; if (nW < 1) nW = 1;   // (histBytes <= spaceSpill: at least one region set)
+  }
+  u16 *const root = (u16 *)(region + firstBytes);
+  u32 *const hist = (u32 *)(region + firstBytes + pad16((size_t)n * 2));
+  const u32 histWords = histBytes / 4;
+  SYNC();
+  for (u32 i = tid; i < nW * histWords; i += CL_THREADS) hist[i] = 0;
+  for (u32 i = tid; i < n; i += CL_THREADS) root[i] = i ? NONE16 : (u16)0;      // rank 0 is never processed (hash10x.c:789): inactive, its own root
+  SYNC();
+  STAMP(3);
+
+  // ---- pass B: the list loop on handles, a unit (64 handles of up to four lists) per step. No barrier: first[] is final; root[] of an earlier rank is
+  // either on record or reads "open" (then the rank is settled behind the loop), whichever wave gets there first.
+  nW = (u32)__builtin_amdgcn_readfirstlane((int)nW);
+  const bool listWave = uwave < nW;
+  if (listWave) {
+    u32 *const myHist = hist + uwave * histWords;
+    auto classB = [&](auto segw_, auto nch_, const u32 firstRank, const u32 endRank, const u32 posBase) {
+      constexpr u32 SEGW = decltype(segw_)::value, NCH = decltype(nch_)::value, LPU = WAVE / SEGW;
+      const u32 nUnits = (endRank - firstRank + LPU - 1) / LPU;
+      if (uwave * RIF >= nUnits) return;
+      const u32 stepB = nW * RIF;
+      const u32 seg = laneU / SEGW, jl = laneU & (SEGW - 1);
+      u32 *const segHist = myHist + seg * ((endRank + 3u) / 4u);   // a first[] value counted here is below the list's rank, i.e. below the class's last rank
+      u32 hN[RIF][NCH];
+      auto issue = [&](u32 u0) {                             // (uniform base + 32-bit position: no 64-bit pointer per lane to keep across the loop)
+#pragma unroll
+        for (int t = 0; t < RIF; ++t) { const u32 u = u0 + (u32)t < nUnits ? u0 + (u32)t : nUnits - 1;   // (past the class: its last unit again, from the caches)
+#pragma unroll
+          for (u32 c = 0; c < NCH; ++c) hN[t][c] = hs[posBase + u * (WAVE * NCH) + c * WAVE + laneU]; }
+      };
+      u32 u0 = uwave * RIF;
+      issue(u0);
+      for (; u0 < nUnits; u0 += stepB) {
+        u32 h[RIF][NCH];
+#pragma unroll
+        for (int t = 0; t < RIF; ++t) {
+#pragma unroll
+          for (u32 c = 0; c < NCH; ++c) h[t][c] = hN[t][c]; }
+        issue(u0 + stepB);
+#pragma unroll
+        for (int t = 0; t < RIF; ++t) {
+          if (u0 + (u32)t >= nUnits) break;                  // (uniform)
+          const u32 r = firstRank + (u0 + (u32)t) * LPU + seg;   // the lane's rank
+          const bool live = r >= 1 && r < endRank;
+          u32 f[NCH]; bool ok[NCH]; u32 tot = 0, key = 0;
+#pragma unroll
+          for (u32 c = 0; c < NCH; ++c) { f[c] = ft.peek(h[t][c]); ok[c] = f[c] < r; tot += seg_popc<SEGW>(__ballot(ok[c]), laneU); }   // (`none` reads 0xFFFF: never below a rank)
+#pragma unroll
+          for (u32 c = 0; c < NCH; ++c)
+            if (ok[c]) {
+              const int sh8 = (f[c] & 3) * 8;
+              const u32 cnt = ((atomicAdd(&segHist[f[c] >> 2], 1u << sh8) >> sh8) & 0xFFu) + 1;   // the lane that arrives last at a value sees its full count
+              const u32 k = (cnt << 16) | (0xFFFFu - f[c]);
+              key = k > key ? k : key;
+            }
+#pragma unroll
+          for (u32 c = 0; c < NCH; ++c) if (ok[c]) segHist[f[c] >> 2] = 0;   // (ds ops of a wave stay in order: behind every count of the unit)
+          key = seg_max_u32<SEGW>(key, laneU);               // msMax << 16 | ~msBest: the mode, ties to the lowest rank (hash10x.c:801-806)
+          const u32 bcnt = key >> 16, best = 0xFFFFu - (key & 0xFFFFu);       // (no usable entry: key 0 -> best NONE16, bcnt 0)
+          const bool act = bcnt >= thr;                      // hash10x.c:807
+          const u32 rbv = root[act ? best : 0u];             // founding rank of the cluster the rank joins (NONE16: not on record yet — settled behind the loop)
+          const u32 rb = act ? rbv : (u32)NONE16;
+          u32 q = 0;
+#pragma unroll
+          for (u32 c = 0; c < NCH; ++c) q += seg_popc<SEGW>(__ballot(f[c] == rb), laneU);
+          if (rb == NONE16) q = 0;
+          if (live && jl == 0) { root[r] = (u16)(act ? rb : r); res[r] = RES_PACK(act ? best : (u32)NONE16, q, tot); }
+        }
+      }
+    };
+    classB(std::integral_constant<u32, 16>{}, std::integral_constant<u32, 1>{}, 0u, tp.m16, 0u);
+    classB(std::integral_constant<u32, 32>{}, std::integral_constant<u32, 1>{}, tp.m16, tp.m32, tp.posH);
+    classB(std::integral_constant<u32, 64>{}, std::integral_constant<u32, 1>{}, tp.m32, tp.m64, tp.posF);
+    classB(std::integral_constant<u32, 64>{}, std::integral_constant<u32, 2>{}, tp.m64, tp.m128, tp.posD);
+    for (u32 i = tp.m128 + uwave; i < n; i += nW) {          // class X
+      if (i == 0) continue;
+      const u32 d = (u32)__builtin_amdgcn_readfirstlane((int)(u32)(gr[i] >> 32));
+      const u16 *const hrow = hs + tp.posX + (size_t)hst * (i - tp.m128);
+      u32 best, bcnt, tot, rb, q;
+      if (d < RCHUNK * WAVE) row_mode_hist<IN_LDS, RCHUNK>(hrow, (u32)hrow[laneU], (u32)hrow[WAVE + laneU], d, code, i, ft, myHist, root, thr, best, bcnt, tot, rb, q);
+      else {
+        row_mode_long(hrow, d, code, i, ft, best, bcnt, tot); rb = NONE16; q = 0;
+        if (bcnt >= thr) { rb = root[best]; if (rb != NONE16) { u32 t2; q = row_count_value(hrow, d, code, i, ft, rb, t2); } }
+      }
+      const bool act = bcnt >= thr;
+      if (lane == 0) { root[i] = (u16)(act ? rb : i); res[i] = RES_PACK(act ? best : (u32)NONE16, q, tot); }
+    }
+  }
+  STAMP(4);
+  SYNC();
+  // ---- the ranks left open by the loop (their msBest's root was not on record yet): roots by walking down the msBest chain, then
+  // their lists' handles once more for minShareCount[root] and msTot — as in cluster_one_block
+  {
+    u16 *todo = (u16 *)hist;                                 // the histograms are idle from here on
+    if (tid == 0) sh[2] = 0;
+    SYNC();
+    for (u32 i0 = 0; i0 < n; i0 += CL_THREADS) {
+      const u32 i = i0 + tid;
+      const bool need = i >= 1 && i < n && root[i] == NONE16;
+      const u64 bal = __ballot(need);
+      if (bal) {
+        u32 base = 0;
+        if (lane == 0) base = atomicAdd(&sh[2], (u32)__popcll(bal));
+        base = (u32)__shfl((int)base, 0);
+        if (need) todo[base + (u32)__popcll(bal & ((1ULL << lane) - 1))] = (u16)i;
+      }
+    }
+    SYNC();
+    const u32 nTodo = sh[2];
+    for (u32 k = tid; k < nTodo; k += CL_THREADS) {
+      const u32 i = todo[k];
+      u32 r = (u32)(__hip_atomic_load(&res[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 0xFFFFu);   // msBest: from the rank's result word (read past this CU's L1)
+      for (u32 hop = 0; hop < n && r < n; ++hop) {
+        const u32 rr = *(volatile u16 *)&root[r];
+        if (rr != NONE16) { r = rr; break; }
+        r = (u32)(__hip_atomic_load(&res[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 0xFFFFu);
+      }
+      root[i] = (u16)r;                                      // (a walker passing through i meanwhile reads NONE16 or r: the same answer either way)
+    }
+    SYNC();
+    constexpr int TIF = ROWS_IN_FLIGHT;
+    for (u32 k0 = uwave * TIF; k0 < nTodo; k0 += CL_WAVES * TIF) {
+      u32 ii[TIF], hA[TIF], hB[TIF], dl[TIF], qv[TIF];
+#pragma unroll
+      for (int t = 0; t < TIF; ++t) {
+        const bool on = k0 + t < nTodo;
+        ii[t] = (u32)__builtin_amdgcn_readfirstlane((int)(on ? (u32)todo[k0 + t] : 0u));
+        qv[t] = on ? (u32)root[ii[t]] : NONE16;
+        dl[t] = on ? (u32)__builtin_amdgcn_readfirstlane((int)(u32)(gr[ii[t]] >> 32)) : 0u;
+        const u16 *const hrow = hs + tpPos(tp, ii[t], hst);
+        hA[t] = laneU < dl[t] ? (u32)hrow[laneU] : S; hB[t] = WAVE + laneU < dl[t] ? (u32)hrow[WAVE + laneU] : S;   // (only the list's own entries: the neighbours in the chunk are other lists')
+      }
+#pragma unroll
+      for (int t = 0; t < TIF; ++t) {
+        if (dl[t] == 0) continue;
+        const u32 i = ii[t];
+        u32 f = ft.peek(hA[t]);
+        u32 q = (u32)__popcll(__ballot(f == qv[t])), tt = (u32)__popcll(__ballot(f < i));
+        if (dl[t] > WAVE) { f = ft.peek(hB[t]); q += (u32)__popcll(__ballot(f == qv[t])); tt += (u32)__popcll(__ballot(f < i)); }
+        if (dl[t] > 2 * WAVE) { const u16 *const hrow = hs + tpPos(tp, i, hst); for (u32 b0 = 2 * WAVE; b0 < dl[t]; b0 += WAVE) { f = b0 + laneU < dl[t] ? ft.peek(hrow[b0 + laneU]) : (u32)NONE16; q += (u32)__popcll(__ballot(f == qv[t])); tt += (u32)__popcll(__ballot(f < i)); } }
+        if (lane == 0) res[i] = RES_PACK(__hip_atomic_load(&res[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 0xFFFFu, q, tt);
+      }
+    }
+  }
+  if (tid == 0) { acc.s[3] += (u32)(gr[0] >> 32); acc.s[0] += n; acc.s[1] += a.blocks[lcode].nHash; acc.s[2] += 1; }
   SYNC();
   STAMP(5);
 }
@@ -1318,7 +1751,9 @@ void cluster_kernel(ClusterArgs a) {
   __shared__ u32 sh[4 + 128];                               // [0..3] scalars, then per-wave scan totals
   unsigned char *region = IN_LDS ? smem : a.scratch + (size_t)blockIdx.x * a.scratchStride;
   u16 *firstGlobal = (IN_LDS && FIRST_MODE == 2) ? (u16 *)(a.scratch + (size_t)blockIdx.x * a.scratchStride) : nullptr;
-  u64 acc[4] = {0, 0, 0, 0};                                 // good hashes, gathered list entries, nHash, barcodes
+  __shared__ unsigned long long accS[5];
+  WorkAcc acc{0u, accS};
+  if (threadIdx.x < 4) accS[threadIdx.x] = 0;               // (the work loop starts with a barrier)
   if (a.started && threadIdx.x == 0) { __hip_atomic_store(&a.started[blockIdx.x], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
   for (;;) {
     __syncthreads();
@@ -1328,13 +1763,14 @@ void cluster_kernel(ClusterArgs a) {
     if (wi >= a.nFront + a.nList) break;                     // every wave of the workgroup leaves together
     // (making the block number scalar with readfirstlane — and with it the rank count and every loop bound — removes a third
     // of the spills and 170 of 6900 instructions, and is 3-4 % SLOWER: 2.49 against 2.41 ms, measured round 2)
-    if constexpr (FIRST_MODE == 4) cluster_one_block_tr<CL_THREADS, KLASS>(a, wi < a.nFront ? a.front[wi] : a.list[wi - a.nFront], region, sh, acc);
+    if constexpr (FIRST_MODE == 5) cluster_one_block_tp<CL_THREADS, KLASS>(a, wi < a.nFront ? a.front[wi] : a.list[wi - a.nFront], region, sh, acc);
+    else if constexpr (FIRST_MODE == 4) cluster_one_block_tr<CL_THREADS, KLASS>(a, wi < a.nFront ? a.front[wi] : a.list[wi - a.nFront], region, sh, acc);
     else cluster_one_block<IN_LDS, FIRST_MODE, CL_THREADS, KLASS>(a, wi < a.nFront ? a.front[wi] : a.list[wi - a.nFront], region, firstGlobal, sh, acc);
   }
-  u64 depth = acc[1];
+  u64 depth = acc.depth;
   for (int s = 32; s; s >>= 1) depth += __shfl_down(depth, s);
   if ((threadIdx.x & (WAVE - 1)) == 0 && depth) atomicAdd((u64 *)&a.stats[1], depth);
-  if (threadIdx.x == 0 && acc[3]) { atomicAdd((u64 *)&a.stats[0], acc[0]); atomicAdd((u64 *)&a.stats[2], acc[2]); atomicAdd((u64 *)&a.stats[3], acc[3]); }
+  if (threadIdx.x == 0 && accS[2]) { atomicAdd((u64 *)&a.stats[0], (u64)accS[0]); atomicAdd((u64 *)&a.stats[1], (u64)accS[3]); atomicAdd((u64 *)&a.stats[2], (u64)accS[1]); atomicAdd((u64 *)&a.stats[3], (u64)accS[2]); }
 }
 
 // ---- list descriptors: per good hash of a block, in rank order, where its barcode list starts in rows[] and how long it is.
@@ -1666,7 +2102,8 @@ static int cluster_local_range(Ctx *c, int codeMin, int codeMax, int threshold, 
   u32 hStride = 64; while (hStride < c->maxGoodDepth && hStride < (1u << 24)) hStride <<= 1;   // (a power of two: a handle's position tells its rank)
   const size_t trSlotCapBytes = (size_t)32 << 20;
   const u32 maxTrRanks = (u32)hmin<size_t>(0xFFFFFFFFu, trSlotCapBytes / ((size_t)hStride * 2));
-  const size_t trSlotU16 = (size_t)hmin<u32>(hmax<u32>(c->maxGood, 1u), maxTrRanks) * hStride + (size_t)(CL_THREADS_HUGE / WAVE) * TR_QUEUE * 4;
+  const bool packed = c->optTrPacked != 0;                   // translated placement: the packed form (several lists per wave instruction, round 5) unless the knob says 0
+  const size_t trSlotU16 = (size_t)hmin<u32>(hmax<u32>(c->maxGood, 1u), maxTrRanks) * hStride + 256 /* packed form: the classes' regions start at multiples of 64 */ + (size_t)(CL_THREADS_HUGE / WAVE) * TR_QUEUE * 4;
   const u32 firstCap = c->optFirstCap > 0 ? (u32)c->optFirstCap : 0u;      // test knob only
   u32 hc[12]; u64 hw[2] = {0, 0}; u32 nFirstLds = 0, bmWords = 0;
   for (int attempt = 0; attempt < 2; ++attempt) {
@@ -1763,7 +2200,7 @@ static int cluster_local_range(Ctx *c, int codeMin, int codeMax, int threshold, 
     g.overflow = (OVF); g.overflowCount = (OVFCNT);                                                                                \
     if (firstMode == 0) H10X_LAUNCH_ONE(0, K, THREADS, BUDGET, GRID, STREAM)                                                       \
     else if (firstMode == 1) H10X_LAUNCH_ONE(1, K, THREADS, BUDGET, GRID, STREAM)                                                  \
-    else if (firstMode == 4) { g.handles = trSlots[K].p; H10X_LAUNCH_ONE(4, K, THREADS, BUDGET, GRID, STREAM) }                    \
+    else if (firstMode == 4) { g.handles = trSlots[K].p; if (packed) H10X_LAUNCH_ONE(5, K, THREADS, BUDGET, GRID, STREAM) else H10X_LAUNCH_ONE(4, K, THREADS, BUDGET, GRID, STREAM) } \
     else { g.scratch = firstSlots[K].p; g.scratchStride = firstStride; H10X_LAUNCH_ONE(2, K, THREADS, BUDGET, GRID, STREAM) }      \
   }
   if (hc[2]) {
@@ -1802,7 +2239,7 @@ static int cluster_local_range(Ctx *c, int codeMin, int codeMax, int threshold, 
   if (secondWind) {                                          // (see the split above) same work queue, counters and overflow list as the first launch of the class; handle slots of its own
     ClusterArgs g = a; g.list = list2.p; g.nList = hc[2]; g.workCounter = counts.p + 6; g.ldsBudget = (u32)budgetBig;
     g.overflow = ovfB.p; g.overflowCount = ovfCountB; g.handles = trSlots[1].p;
-    H10X_LAUNCH_ONE(4, 2, CL_THREADS_HUGE, budgetBig, secondWind, st)
+    if (packed) H10X_LAUNCH_ONE(5, 2, CL_THREADS_HUGE, budgetBig, secondWind, st) else H10X_LAUNCH_ONE(4, 2, CL_THREADS_HUGE, budgetBig, secondWind, st)
   }
   H10X_HIP(c, hipGetLastError());
   H10X_TRY(c->faultAt(4));

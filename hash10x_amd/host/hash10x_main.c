@@ -224,7 +224,15 @@ static void cmd_cluster(char **a) {
   say("  clustered codes %d to %d\n", v[0] ? v[0] : 1, v[1] ? v[1] : (int)sizes_now().nBlocksGlobal);
 }
 static int rank_split(h10x_session *s, int r, void *a) { (void)r; (void)a; return h10x_session_clusterSplit(s); }
-static void cmd_clusterSplit(char **a) { (void)a; const int bad = on_all_ranks(rank_split, 0); if (bad) die_of(bad); }
+static void cmd_clusterSplit(char **a) {                                              /* the lines of clusterSplitCodes (hash10x.c:998-1012): count, a time line on stdout, fillHashTable's line */
+  (void)a;
+  const h10x_shard_info_t before = sizes_now();
+  const int bad = on_all_ranks(rank_split, 0); if (bad) die_of(bad);
+  const h10x_shard_info_t after = sizes_now();
+  say("  made %d additional new barcodes from clusters in %d original barcodes\n", (int)(after.nBlocksGlobal - before.nBlocksGlobal), (int)before.nBlocksGlobal);
+  printf("  cluster timepoint: "); timeUpdate(stdout, 0);
+  say_filled(&after);
+}
 static int rank_crib(h10x_session *s, int r, void *a) { char **f = (char **)a; return h10x_session_cribBuild(s, f[0], f[1], r == 0 ? outFile : 0, printTables); }
 static void cmd_cribBuild(char **a) { const int bad = on_all_ranks(rank_crib, a); if (bad) die_of(bad); }
 static int rank_report(h10x_session *s, int r, void *a) { const int *v = (const int *)a; return h10x_session_clusterReport(s, v[0], v[1], r == 0 ? outFile : 0); }

@@ -321,7 +321,8 @@ int  h10x_get_counters(h10x_ctx *ctx, h10x_counters *out);
    index build through the library's own one-read table also where the reference-shaped 64-bit table fits (default 0: only where it
    does not, i.e. -B 29 / 30 at k = 21), 2 = never, 3 = always and undersized (exercises its fall-back); "cluster_narrow_first" 1 = first[] of the
    cluster kernel at 2 bytes per entry in every block, w >= 2 = 4 bytes down to w list-loop waves (default 0: 4 bytes where that
-   costs no wave); "cluster_lds_budget", "cluster_first_global", "cluster_first_cap", "cluster_big_ranks", "cluster_threads0",
+   costs no wave); "cluster_tr_packed" (translated placement of first[]: -1 / 1 = several lists per wave instruction, the default; 0 = round 4's
+   one list per wave instruction), "cluster_lds_budget", "cluster_first_global", "cluster_first_cap", "cluster_big_ranks", "cluster_threads0",
    "cluster_budget0" (placement and launch-class overrides of the tests), "cluster_stamps" (phase stamps into h10x_counters),
    "shard_row_shift", "shard_rows_fake_base" (sharded list offsets beyond 32 bits on small inputs), "shard_delta_lists" (-1 default:
    the in-range barcode lists travel delta-coded when there is more than one rank; 0 never; 1 always). Unknown name: -1. */

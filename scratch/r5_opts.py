@@ -16,9 +16,10 @@ recs = bench.generate_v2(wl, wl["seed"])[0] if wl.get("gen") == 2 else bench.gen
 print("generated %d pairs in %.1f s" % (recs.size // 30, time.time() - t), flush=True)
 dr = hash10x_amd.DeviceRecords(recs); del recs
 h = hash10x_amd.Hash10x(B=wl["B"]); h.enable_timing(True)
+if os.environ.get("STAMPS"): h.set_option("cluster_stamps", 1)
 used = set()
 for s in sets:
-    for k in used: h.set_option(k, 0)
+    for k in used: h.set_option(k, -1 if k in ("cluster_tr_packed", "shard_delta_lists", "shard_row_shift") else 0)
     if s not in ("base", "again"):
         for kv in s.split(","):
             k, v = kv.split("="); h.set_option(k, int(v)); used.add(k)
@@ -30,4 +31,7 @@ for s in sets:
         tm = h.timings()
         if it and (best is None or tm["cluster_kernel"][0] < best[0]): best = (tm["cluster_kernel"][0], tm.get("cluster_main", (0, 0))[0], dt, {k: round(v[0], 2) for k, v in tm.items() if v[0] > 0})
     c = h.counters()
+    if os.environ.get("STAMPS"):
+        tk = c["cluster_phase_ticks"]; tot = float(sum(tk)) or 1.0
+        print("      phase shares: init %.3f passA %.3f barrier %.3f compact %.3f passB %.3f settle %.3f" % tuple(x / tot for x in tk[:6]))
     print("%-40s cluster_kernel %.2f ms main %.2f step %.1f ms classes %s ovf %s mode %s\n      %s" % (s, best[0], best[1], 1e3 * best[2], c["cluster_class_counts"], c["cluster_overflow_blocks"], c["cluster_first_mode"], best[3]), flush=True)

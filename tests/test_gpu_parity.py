@@ -101,20 +101,31 @@ def test_cluster_hbm_scratch_and_big_lds_paths(workdir, budget):
     assert hf.blocks["nSubCluster"].sum() > 0
 
 
-@pytest.mark.parametrize("mode,cap", [(2, 0), (2, 64), (3, 0), (3, 1500), (3, 64), (4, 0), (4, 1500), (4, 200), (4, 64)])
-def test_cluster_ranked_and_hashed_first_tables(workdir, mode, cap):
+@pytest.mark.parametrize("mode,cap,packed", [(2, 0, 1), (2, 64, 1), (4, 0, 0), (4, 1500, 0), (4, 200, 0), (4, 64, 0), (4, 0, 1), (4, 1500, 1), (4, 200, 1), (4, 64, 1)])
+def test_cluster_ranked_and_hashed_first_tables(workdir, mode, cap, packed):
     """Placements of first[] for data sets with many barcodes, forced on a small set: mode 2 = ranked (presence bitmap +
-    popcount prefix, first[] sized by the barcodes present), mode 3 = hashed (open-addressing table in LDS keyed by
-    barcode), mode 4 = translated (round 4: one pass turns every list entry into the 16-bit slot number of its barcode in
+    popcount prefix, first[] sized by the barcodes present), mode 4 = translated (round 4: one pass turns every list entry into the 16-bit slot number of its barcode in
     such a table, the list loop then runs on those handles; cap 200: the first table is closed at 175 of the ~300 barcodes and the
-    rest goes into a second one). A small cap makes the tables overflow: the blocks are re-run with the whole LDS of a CU and, when that
-    fails too, with first[] dense on an HBM slot."""
+    rest goes into a second one; packed = round 5's form of it: the ranks ascend in list length, so four lists of up to 16 entries, two of
+    up to 32 share a wave instruction — the depth range 4-40 puts lists into the classes Q, H and F). A small cap makes the tables overflow:
+    the blocks are re-run with the whole LDS of a CU and, when that fails too, with first[] dense on an HBM slot."""
     orc.gen_fqb(workdir.file("x.fqb"), 60000, 300, 400000, 0.003, 43, 4.0, 150, 6000)
-    opts = dict(cluster_first_global=mode)
+    opts = dict(cluster_first_global=mode, cluster_tr_packed=packed)
     if cap:
         opts["cluster_first_cap"] = cap
     hf = _against_oracle(workdir, "x.fqb", ["-ct", 3, "--readFQB", "x.fqb", "--hashDepthRange", 4, 40, "--cluster", 1, 0], **opts)
     assert hf.blocks["nSubCluster"].sum() > 0
+
+
+@pytest.mark.parametrize("packed", [0, 1])
+def test_cluster_translated_long_lists(workdir, packed):
+    """The translated placement on lists of every class of the packed form at once: a small genome under 400 barcodes puts hashes into 4 .. 345
+    barcodes, so one block holds lists of up to 16, 32, 64, 128 entries (Q, H, F, D: four, two, one list per wave instruction, one list in two
+    chunks) and beyond (X: the per-list loop, incl. lists of 256 entries and more — row_mode_long)."""
+    orc.gen_fqb(workdir.file("x.fqb"), 100000, 400, 30000, 0.003, 45, 12.0, 150, 6000)
+    hf = _against_oracle(workdir, "x.fqb", ["-ct", 3, "--readFQB", "x.fqb", "--hashDepthRange", 4, 400, "--cluster", 1, 0], cluster_first_global=4, cluster_tr_packed=packed)
+    assert hf.blocks["nSubCluster"].sum() > 0
+    assert hf.hash_depth[1: hf.hash_number].max() > 256
 
 
 def test_cluster_first_table_on_hbm_slots(workdir):
@@ -635,7 +646,7 @@ def test_cli_crib_reports_match_reference(workdir):
     r = orc.run_ref(args, workdir.path)
     assert r.returncode == 0, r.stderr.decode()
     def report(txt):
-        keep = ("  crib matches", "    hom", "    het", "    mul", "    err", "CRIB_TABLE", "  CLUSTER_SUMMARY", "    CODE_CLUSTER",
+        keep = ("  crib matches", "    hom", "    het", "    mul", "    err", "CRIB_TABLE", "  CLUSTER_SUMMARY", "    CODE_CLUSTER", "  made ", "  filled hash table",
                 "  MIN_POINT_DENSITY", "CODE_SIZE_", "CODE_CLUSTER_", "HASH_COUNT_")
         return [ln for ln in txt.decode().splitlines() if ln.startswith(keep) or " base codes " in ln or " cluster codes " in ln or " in crib genome" in ln]
     exp = report(r.stdout)
