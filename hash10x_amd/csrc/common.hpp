@@ -367,6 +367,7 @@ int stageE_histMax(Ctx *c, int which, u64 first, u64 count, u32 *maxValue);
 int stageE_histogram(Ctx *c, int which, u64 first, u64 count, u32 bins, u64 *hist);
 int stageE_clusterReport(Ctx *c, u32 firstBlock, u32 nBlk, h10x_block_rep *hostB, h10x_cluster_rep *hostC, u64 clusterCap, u64 *nClusters);
 int stageE_cribSummary(Ctx *c, u64 *counts12, u32 *hostSeenBase, u32 *hostSeenCluster);
+int stageE_cribWords(Ctx *c, u64 first, u64 count, u32 *hostOut);
 int shard_allreduceU64(Ctx *c, u64 *v, u32 n, int op);
 int shard_gatherBytes(Ctx *c, const void *send, u64 nbytes, void *recv, u64 cap, u64 *counts);
 int shard_exchangeRows(Ctx *c);

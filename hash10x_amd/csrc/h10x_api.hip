@@ -486,6 +486,10 @@ int h10x_crib_summary(h10x_ctx *h, uint64_t counts[12], uint32_t *seenBase, uint
   if (!h || !counts || !seenBase || !seenCluster) return -1; H10X_TRY(enter(h->c)); return stageE_cribSummary(&h->c, (u64 *)counts, seenBase, seenCluster);
 }
 
+int h10x_crib_words(h10x_ctx *h, uint64_t first, uint64_t count, uint32_t *words) {
+  if (!h || (count && !words)) return -1; H10X_TRY(enter(h->c)); return stageE_cribWords(&h->c, first, count, words);
+}
+
 int h10x_timing_enable(h10x_ctx *h, int on) { if (!h) return -1; h->c.timing = on != 0; return 0; }
 int h10x_timing_count(const h10x_ctx *) { return T_COUNT; }
 const char *h10x_timing_name(const h10x_ctx *, int i) { return (i >= 0 && i < T_COUNT) ? kTimerNames[i] : ""; }

@@ -252,6 +252,37 @@ int stageE_cribSummary(Ctx *c, u64 *counts12, u32 *hostSeenBase, u32 *hostSeenCl
   return 0;
 }
 
+// The entries of cribSummary's walk over the blocks (hash10x.c:1030-1046) as one word each, in clusHash order: bit 31 = the block was made by
+// --clusterSplit (clusterParent != 0), bits 28-30 the crib type of the hash, bits 0-27 its index (indices stay below 2^28: -B <= 30). The host feeds them
+// to a restatement of the reference's HASH objects, whose counts depend on the order of insertion (host/h10x_host.c: RefHash). One wave per block.
+__global__ __launch_bounds__(256)
+void crib_words_kernel(const h10x_block *__restrict__ blocks, const u64 *__restrict__ blockOff, const h10x_clushash *__restrict__ ch, u32 nBlocks,
+                       const u8 *__restrict__ cribType, u64 first, u64 count, u32 *__restrict__ out) {
+  const u32 lane = threadIdx.x & (WAVE - 1), wavesPerGrid = gridDim.x * (blockDim.x / WAVE);
+  for (u32 b = 1 + blockIdx.x * (blockDim.x / WAVE) + threadIdx.x / WAVE; b < nBlocks; b += wavesPerGrid) {
+    u64 e0 = blockOff[b], e1 = blockOff[b + 1];
+    if (e1 <= first || e0 >= first + count) continue;
+    if (e0 < first) e0 = first;
+    if (e1 > first + count) e1 = first + count;
+    const u32 kind = blocks[b].clusterParent != 0 ? 0x80000000u : 0u;
+    for (u64 e = e0 + lane; e < e1; e += WAVE) { const u32 h = ch[e].hash; const u32 t = cribType[h]; out[e - first] = kind | ((t < 5 ? t : 0u) << 28) | h; }
+  }
+}
+int stageE_cribWords(Ctx *c, u64 first, u64 count, u32 *hostOut) {
+  hipStream_t st = c->stream;
+  if (!c->haveState) return c->fail("no hash state loaded: use readFQB or readHash first");
+  if (!c->haveCrib) return c->fail("no crib: use cribBuild first");
+  if (first > c->nEntries || count > c->nEntries - first) return c->fail("h10x_crib_words: range %llu + %llu outside %llu", first, count, (u64)c->nEntries);
+  if (c->hashNumber > (1u << 28)) return c->fail("h10x_crib_words: %u hash indices do not fit the word's 28 bits", c->hashNumber);
+  if (!count) return 0;
+  DevBuf<u32> out; H10X_HIP(c, out.alloc(count));
+  if (c->nBlocks > 1) crib_words_kernel<<<hmin<u32>(divUp(c->nBlocks, 4), 65535u), 256, 0, st>>>(c->blocks.p, c->blockOff.p, c->clusHash.p, c->nBlocks, c->cribType.p, first, count, out.p);
+  H10X_HIP(c, hipGetLastError());
+  H10X_HIP(c, hipMemcpyAsync(hostOut, out.p, count * 4, hipMemcpyDeviceToHost, st));
+  H10X_HIP(c, hipStreamSynchronize(st));
+  return 0;
+}
+
 // ------------------------------------------------------------------------------------------ host collectives for launchers
 // (sums / maxima of small host arrays and a gather of byte strings to rank 0: what the host layer needs to assemble the
 // reports and the sharded .hash header; no-ops on an unsharded context)

@@ -1003,39 +1003,108 @@ done:
   return rc;
 }
 
-/* cribSummary (hash10x.c:1017-1061): per crib type, hash entries and distinct hashes in base barcodes and in the barcodes
-   --clusterSplit made (clusterParent != 0). Entries are counted on the device; which hashes occur where comes back as two
-   bitmaps per rank, OR-ed on rank 0 and counted by type. */
+/* ---- the reference's HASH object (hash.c) as far as cribSummary uses it — hashCreate(1 << 20), hashAdd of int keys, hashCount — restated with its two oddities,
+   because the second figure of every type in the summary is its hashCount():
+   (1) when a table doubles (hash.c:123-160) the bounce stride is worked out once, for the first key that bounces, and reused for every later key of that doubling: keys
+       re-inserted off their own probe sequence are not found by a later hashAdd of the same key, which inserts them a second time, so the count runs ahead of the
+       number of distinct keys (3 Gb-shaped set at 1/10: 1 460 918 "htA hashes" where 1 340 473 are distinct) — by how much depends on the ORDER of the insertions;
+   (2) the marker of a removed key, (INT_MAX - 1) ^ INT_MAX, is 1: a slot holding key 1 counts as free (keys are hash index ^ INT_MAX, hash.h:41: no index below
+       2^28 maps to it, the rule is kept for the restatement's sake).
+   No table doubles below 524 288 keys, where the figures are plain distinct counts (what the small-set tests compare). */
+typedef struct { int nbits, n, guard; unsigned mask; int *keys; } RefHash;
+static int rh_init(RefHash *h) { h->nbits = 20; h->mask = (1u << 20) - 1; h->guard = 1 << 19; h->n = 0; h->keys = (int *)calloc((size_t)1 << 20, sizeof(int)); return h->keys ? 0 : -1; }
+static inline long rh_fold(int key, int step, int times, unsigned mask) { long v = key; int x = key >> step; while (times--) { v ^= x; x >>= step; } return v & (long)mask; }
+static inline long rh_home(const RefHash *h, int key) { return rh_fold(key, 5, 12, h->mask); }             /* HASH_FUNC: sizeof(long) * 8 / 5 folds */
+static inline long rh_stride(const RefHash *h, int key) { return rh_fold(key, 7, 9, h->mask) | 1; }        /* DELTA: odd, so coprime to the table size */
+static int rh_double(RefHash *h) {
+  const size_t oldSize = (size_t)1 << h->nbits;
+  int *old = h->keys, *fresh = (int *)calloc(oldSize * 2, sizeof(int));
+  if (!fresh) return -1;
+  ++h->nbits; h->mask = (1u << h->nbits) - 1; h->guard = 1 << (h->nbits - 1); h->keys = fresh;
+  long stride = 0;                                                                  /* (1): one stride for the whole doubling */
+  for (size_t i = 0; i < oldSize; ++i) {
+    const int k = old[i];
+    if (!k || k == 1) continue;                                                     /* (2): key 1 is dropped as "removed" */
+    long p = rh_home(h, k);
+    while (fresh[p]) { if (!stride) stride = rh_stride(h, k); p = (p + stride) & (long)h->mask; }
+    fresh[p] = k; --h->guard;
+  }
+  free(old);
+  return 0;
+}
+static int rh_add(RefHash *h, int key) {
+  if (!h->guard && rh_double(h)) return -1;
+  long p = rh_home(h, key), stride = 0;
+  for (;;) {
+    const int cur = h->keys[p];
+    if (cur == 0 || cur == 1) { if (!cur) --h->guard; h->keys[p] = key; ++h->n; return 0; }
+    if (cur == key) return 0;
+    if (!stride) stride = rh_stride(h, key);
+    p = (p + stride) & (long)h->mask;
+  }
+}
+typedef struct { RefHash *h; const uint32_t *w; uint64_t n; uint32_t sel; int rc; } RhJob;
+static void *rh_job(void *a) {
+  RhJob *j = (RhJob *)a;
+  for (uint64_t i = 0; i < j->n; ++i)                                               /* HASH_INT(x): the key is x ^ INT_MAX (hash.h:41) */
+    if ((j->w[i] & 0xF0000000u) == j->sel && rh_add(j->h, (int)((j->w[i] & 0x0FFFFFFFu) ^ 0x7FFFFFFFu))) { j->rc = -1; break; }
+  return 0;
+}
+
+/* --cribSummary (hash10x.c:1017-1061): entries per crib type in base blocks and in the blocks --clusterSplit made — counted on the device — and, per type, the
+   reference's hashCount() of the hash indices met there: the records go through RefHash in the order of the reference's walk (blocks in file order, rank after rank
+   on shards: every rank's words travel to rank 0, 128 MB at a time; ten tables, a thread each). */
 int h10x_session_cribSummary(h10x_session *s, FILE *out) {
   if (!s->ctx) return fail(s, "no hash state loaded: use readFQB or readHash first");
   uint32_t dim = 0;
   if (h10x_crib_sizes(s->ctx, &dim, 0)) { if (out) fprintf(stderr, "cribSummary requires crib\n"); return 0; }
   h10x_shard_info_t z; if (h10x_shard_info(s->ctx, &z)) return fail_ctx(s);
-  if (crib_fetch(s, z.hashNumber)) return -1;
   const size_t words = ((size_t)z.hashNumber + 31) / 32;
   uint32_t *seen = (uint32_t *)calloc(2 * words + 1, 4); uint64_t counts[12]; int rc = 0;
   if (!seen) return fail(s, "out of host memory for cribSummary");
   if (h10x_crib_summary(s->ctx, counts, seen, seen + words)) { free(seen); return fail_ctx(s); }
+  free(seen);
   if (out) fprintf(stderr, "made hash objects\n");
-  if (h10x_shard_allreduce_sum_u64(s->ctx, counts, 12)) { free(seen); return fail_ctx(s); }
-  uint32_t *all = z.rank == 0 ? (uint32_t *)malloc((size_t)z.nranks * 2 * words * 4 + 4) : 0; uint64_t *cnt = (uint64_t *)calloc((size_t)z.nranks, 8);
-  if ((z.rank == 0 && !all) || !cnt) { free(seen); free(all); free(cnt); return fail(s, "out of host memory for cribSummary"); }
-  if (h10x_shard_gather_bytes(s->ctx, seen, 2 * words * 4, all, (uint64_t)z.nranks * 2 * words * 4, cnt)) rc = fail_ctx(s);
-  if (!rc && z.rank == 0 && out) {
-    int distinct[2][5] = {{0}};
-    for (size_t w = 0; w < words; ++w)
-      for (int kind = 0; kind < 2; ++kind) {
-        uint32_t bits = 0;
-        for (int r = 0; r < z.nranks; ++r) bits |= all[(size_t)r * 2 * words + (size_t)kind * words + w];
-        while (bits) { const int b = __builtin_ctz(bits); bits &= bits - 1; const size_t h = w * 32 + (size_t)b; if (h < z.hashNumber) ++distinct[kind][s->cribType[h] < 5 ? s->cribType[h] : 0]; }
+  if (h10x_shard_allreduce_sum_u64(s->ctx, counts, 12)) return fail_ctx(s);
+  enum { CH = 32 << 20 };
+  RefHash tab[10]; memset(tab, 0, sizeof tab);
+  h10x_shard_seg *segs = (h10x_shard_seg *)calloc((size_t)z.nSegs + 1, sizeof *segs);
+  uint32_t *mine = (uint32_t *)malloc((size_t)CH * 4), *got = z.nranks > 1 && z.rank == 0 ? (uint32_t *)malloc((size_t)CH * 4) : 0;
+  uint64_t *cnt = (uint64_t *)calloc((size_t)z.nranks, 8);
+  if (!segs || !mine || !cnt || (z.nranks > 1 && z.rank == 0 && !got)) rc = fail(s, "out of host memory for cribSummary");
+  if (!rc && z.rank == 0) for (int i = 0; i < 10; ++i) if (rh_init(&tab[i])) { rc = fail(s, "out of host memory for cribSummary"); break; }
+  if (!rc && h10x_shard_segments(s->ctx, segs, z.nSegs + 1)) rc = fail_ctx(s);
+  { uint64_t bad = rc ? 1 : 0; if (h10x_shard_allreduce_max_u64(s->ctx, &bad, 1)) rc = fail_ctx(s); else if (bad && !rc) rc = fail(s, "cribSummary failed on another rank"); }
+  for (uint32_t g = 0; !rc && g < z.nSegs; ++g) {                                    /* segments in file order; every rank walks the same list (the gathers are collective) */
+    const int own = (int)segs[g].rank == z.rank;
+    for (uint64_t at = 0; !rc && at < segs[g].entries; at += CH) {
+      const uint64_t n = segs[g].entries - at < CH ? segs[g].entries - at : CH;
+      if (own && h10x_crib_words(s->ctx, segs[g].localEntryStart + at, n, mine)) { rc = fail_ctx(s); }
+      const uint32_t *w = mine;
+      if (z.nranks > 1) {
+        uint64_t bad = rc ? 1 : 0;
+        if (h10x_shard_allreduce_max_u64(s->ctx, &bad, 1)) { rc = fail_ctx(s); break; }
+        if (bad) { if (!rc) rc = fail(s, "cribSummary failed on another rank"); break; }
+        if (h10x_shard_gather_bytes(s->ctx, mine, own ? n * 4 : 0, got, (uint64_t)CH * 4, cnt)) { rc = fail_ctx(s); break; }
+        w = got;
       }
+      if (z.rank == 0) {
+        RhJob job[10]; pthread_t th[10]; int started[10];
+        for (int i = 0; i < 10; ++i) { job[i].h = &tab[i]; job[i].w = w; job[i].n = n; job[i].sel = (i >= 5 ? 0x80000000u : 0u) | ((uint32_t)(i % 5) << 28); job[i].rc = 0;
+                                       started[i] = pthread_create(&th[i], 0, rh_job, &job[i]) == 0; }
+        for (int i = 0; i < 10; ++i) { if (started[i]) pthread_join(th[i], 0); else rh_job(&job[i]); if (job[i].rc) rc = fail(s, "out of host memory for cribSummary"); }
+      }
+    }
+  }
+  if (!rc && z.rank == 0 && out) {
     fprintf(out, "  %d base codes ", (int)counts[10] + 1);                           /* block 0 counts as a base code */
-    for (int i = 0; i < 5; ++i) fprintf(out, " %s %llu %d %.1f", cribTypeName[i], (unsigned long long)counts[i], distinct[0][i], counts[i] / (double)distinct[0][i]);
+    for (int i = 0; i < 5; ++i) fprintf(out, " %s %llu %d %.1f", cribTypeName[i], (unsigned long long)counts[i], tab[i].n, counts[i] / (double)tab[i].n);
     fprintf(out, "\n  %d cluster codes ", (int)counts[11]);
-    for (int i = 0; i < 5; ++i) fprintf(out, " %s %llu %d %.1f", cribTypeName[i], (unsigned long long)counts[5 + i], distinct[1][i], counts[5 + i] / (double)distinct[1][i]);
+    for (int i = 0; i < 5; ++i) fprintf(out, " %s %llu %d %.1f", cribTypeName[i], (unsigned long long)counts[5 + i], tab[5 + i].n, counts[5 + i] / (double)tab[5 + i].n);
     fputc('\n', out);
   }
-  free(seen); free(all); free(cnt);
+  for (int i = 0; i < 10; ++i) free(tab[i].keys);
+  free(segs); free(mine); free(got); free(cnt);
   return rc;
 }
 

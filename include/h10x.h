@@ -277,6 +277,11 @@ int  h10x_report_histogram(h10x_ctx *ctx, int which, uint64_t first, uint64_t co
 int  h10x_cluster_report(h10x_ctx *ctx, uint32_t firstBlock, uint32_t nBlocks, h10x_block_rep *blocks,
                          h10x_cluster_rep *clusters, uint64_t clusterCap, uint64_t *nClusters);
 int  h10x_crib_summary(h10x_ctx *ctx, uint64_t counts[12], uint32_t *seenBase, uint32_t *seenCluster);
+/* cribSummary's walk over the blocks (hash10x.c:1030-1046) as one word per ClusterHash record [first, first + count) of THIS rank, in clusHash order: bit 31 = the
+   record's block was made by --clusterSplit, bits 28-30 = cribType of its hash, bits 0-27 = the hash index. The second and third figure of every type in the
+   reference's summary is hashCount() of a HASH object fed in exactly this order (hash.c) — and that count depends on the order once such an object has doubled
+   (see RefHash in host/h10x_host.c) — so the host layer replays the words through a restatement of it. */
+int  h10x_crib_words(h10x_ctx *ctx, uint64_t first, uint64_t count, uint32_t *words);
 
 /* ---- device memory plumbing for callers that keep the input resident in HBM (bench, pipelines) ----
    plain hipMalloc / hipMemcpy / hipDeviceSynchronize on `device`; return NULL / non-zero on failure */
