@@ -122,6 +122,25 @@ def generate_v2(wl, seed, part=0, parts=1):
         g.h10x_gen2_free(plan)
 
 
+def haplotypes_v2(wl, seed):
+    """the two truth haplotypes of a generator-v2 workload as base codes 0..3 (what the FASTAs of `gen_fqb -fa` hold): the input of --cribBuild"""
+    g = _gen_lib()
+    g.h10x_gen2_haplotype.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
+    p = GenParams(wl["pairs"], wl["barcodes"], wl["genome"], wl["err"], seed, wl["mol"], wl["snp"], wl["mol_len"])
+    plan = g.h10x_gen2_plan_new(ctypes.byref(p))
+    if not plan:
+        raise MemoryError("gen_fqb v2: plan")
+    try:
+        out = []
+        for hap in (0, 1):
+            a = np.empty(wl["genome"], dtype=np.uint8)
+            g.h10x_gen2_haplotype(plan, hap, a.ctypes.data)
+            out.append(a)
+        return out
+    finally:
+        g.h10x_gen2_free(plan)
+
+
 # ---- a checksum of a clustered state that ranks can add up: every 8-byte word of the ClusterBlock array (heap-pointer word zeroed) and of
 # the ClusterHash records, in the FILE's numbering, goes through a 64-bit mixer together with its position, and the results are summed
 # mod 2^64 under two different salts. A rank sums over its own segments; the sum over ranks is what the same function gives for the
@@ -403,6 +422,11 @@ def full_config3_block(hash10x_amd, local_rank, steps=3):
     d = hash10x_amd.DeviceRecords(recs, device=local_rank)
     up_s = time.perf_counter() - t0
     pairs = recs.size // 30
+    e2e = None
+    try:
+        e2e = cli_end_to_end(recs, case["B"], 30, 100, 5, expect_sha256=case["sha256"], expect_size=case["size"])
+    except Exception as e:
+        e2e = {"error": str(e)[:300]}
     del recs
     h = hash10x_amd.Hash10x(B=case["B"], device=local_rank)
     h.enable_timing(True)
@@ -435,10 +459,61 @@ def full_config3_block(hash10x_amd, local_rank, steps=3):
            "barcodes_per_s_clustered": wl["barcodes"] / (tm["cluster"][0] / steps * 1e-3),
            "traffic": tr["traffic"] if tr else None, "traffic_of": "all cluster_kernel launches at full size", "traffic_raw": tr, "traffic_note": TRAFFIC_NOTE if tr else None,
            "traffic_stale": (tr["traffic_build_id"] != hash10x_amd.build_id()) if tr else None,
-           "generate_seconds": round(gen_s, 1), "upload_seconds": round(up_s, 2), "host_threads": os.cpu_count(),
+           "generate_seconds": round(gen_s, 1), "upload_seconds": round(up_s, 2), "host_threads": os.cpu_count(), "end_to_end": e2e,
            "parity": "tests/test_gpu_parity.py::test_config3_full_size_matches_reference_digest: the whole 15 GB .hash of this set has the reference binary's sha256"}
     h.close(); d.free()
     return out
+
+
+def cli_end_to_end(recs, B, lo, hi, ct, expect_sha256=None, expect_size=None):
+    """File in, file out, one process, as a user runs it: bin/hash10x-amd -B b --readFQB x.fqb --hashDepthRange lo hi --cluster 1 0 --writeHash x.hash on a .fqb in memory-backed
+    storage (/dev/shm where it has room: the disk of a GPU box is not what is measured), per-command wall seconds from the program's own resource lines, and the sha256 of
+    the canonical .hash it wrote against the reference binary's (manifest)."""
+    sys.path.insert(0, os.path.join(REPO, "tests"))
+    import orc
+    import shutil
+    exe = os.path.join(REPO, "bin", "hash10x-amd")
+    if not os.path.exists(exe):
+        return {"skipped": "bin/hash10x-amd not built"}
+    need = recs.nbytes + (expect_size or recs.nbytes) + (2 << 30)
+    base = None
+    for cand in ("/dev/shm", tempfile.gettempdir()):
+        try:
+            st = os.statvfs(cand)
+            if st.f_bavail * st.f_frsize > need:
+                base = cand
+                break
+        except OSError:
+            pass
+    if base is None:
+        return {"skipped": "no room for %.0f GB of files" % (need / 1e9)}
+    d = tempfile.mkdtemp(prefix="h10x_e2e_", dir=base)
+    try:
+        t0 = time.perf_counter(); recs.tofile(os.path.join(d, "x.fqb")); write_in_s = time.perf_counter() - t0
+        cmd = [exe, "-B", str(B), "-ct", str(ct), "--readFQB", "x.fqb", "--hashDepthRange", str(lo), str(hi), "--cluster", "1", "0", "--writeHash", "x.hash"]
+        t0 = time.perf_counter()
+        g = subprocess.run(cmd, cwd=d, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+        wall = time.perf_counter() - t0
+        if g.returncode != 0:
+            raise RuntimeError("hash10x-amd failed: " + g.stderr.decode()[-300:])
+        walls, cmdname = {}, None
+        for line in g.stdout.decode().splitlines():
+            if line.startswith("COMMAND "):
+                cmdname = line.split()[1]
+            elif line.strip().startswith("user") and cmdname and "wall" in line:
+                walls[cmdname] = walls.get(cmdname, 0.0) + float(line.split()[-1])
+        t0 = time.perf_counter()
+        digest, info = orc.canonical_file_digest(os.path.join(d, "x.hash"))
+        digest_s = time.perf_counter() - t0
+        pairs = recs.size // 30
+        io = walls.get("--readFQB", 0.0) + walls.get("--writeHash", 0.0)
+        return {"command": " ".join(["hash10x-amd"] + cmd[1:]), "storage": base, "fqb_bytes": int(recs.nbytes), "hash_bytes": info["size"], "wall_seconds": wall, "read_pairs_per_s": pairs / wall,
+                "per_command_wall_seconds": walls, "io_commands_share": (io / wall) if wall else None,
+                "io_commands_note": "--readFQB (file read beside the uploads, hashing and index build) + --writeHash (device -> host beside the file writes) as a share of the process's wall time",
+                "hash_sha256": digest, "hash_identical_to_reference": (digest == expect_sha256 and info["size"] == expect_size) if expect_sha256 else None,
+                "write_input_seconds": round(write_in_s, 1), "digest_seconds": round(digest_s, 1)}
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
 
 
 TRAFFIC_NOTE = ("HBM bytes per step from the committed rocprofv3 --pmc passes (FETCH_SIZE and WRITE_SIZE in passes of their own), corrected as MI355X_MICROARCH.md prescribes for gfx950: "
@@ -461,11 +536,10 @@ def profile_traffic(pattern, match, exclude=None):
             "traffic_head": pm.get("head"), "traffic_build_id": pm.get("build_id")}
 
 
-def genome3g_block(hash10x_amd, local_rank, steps=2):
+def genome3g_block(hash10x_amd, local_rank, steps=2, name="genome3g-300M"):
     """The 3 Gb workload (BASELINE configs[3] shape at the size the reference's run could be pinned: WORKLOADS["genome3g-300M"]) on ONE GPU — the set
     `bench.py --workload genome3g-300M --scaling strong --gpus N` scales over 1 / 2 / 4 / 8 ranks: ms per step, roofline of the cluster launches, and the
     parity gate against the reference binary's digest (composable checksum of all blocks and ClusterHash records)."""
-    name = "genome3g-300M"
     wl = dict(WORKLOADS[name])
     t0 = time.perf_counter()
     recs, _first, _total = generate_v2(wl, wl["seed"])
@@ -488,7 +562,7 @@ def genome3g_block(hash10x_amd, local_rank, steps=2):
     c = h.counters(); z = h.sizes()
     clu_ms = tm["cluster_kernel"][0] / steps
     alg = 4.0 * c["sum_good_depth"] + 14.0 * c["sum_good"] + 16.0 * c["sum_hash_clustered"]
-    out = {"workload": "%s (3 Gb x 2 haplotypes, 300 M pairs, 1.6 M barcodes, e = 0.05 %%, -B 30, --hashDepthRange %d %d; gen_fqb v2 seed %d)" % (name, wl["lo"], wl["hi"], wl["seed"]),
+    out = {"workload": "%s (%.1f Gb x 2 haplotypes, %d M pairs, %d k barcodes, e = 0.05 %%, -B %d, --hashDepthRange %d %d; gen_fqb v2 seed %d)" % (name, wl["genome"] / 1e9, wl["pairs"] // 1000000, wl["barcodes"] // 1000, wl["B"], wl["lo"], wl["hi"], wl["seed"]),
            "ms_per_step": 1e3 * sum(wall) / len(wall), "read_pairs_per_s": pairs * len(wall) / sum(wall), "steps": steps,
            "device_ms_per_step": {k: round(v[0] / steps, 2) for k, v in tm.items() if v[0] > 0},
            "entries_H": c["entries"], "distinct_U": c["distinct"], "hashNumber": z["hashNumber"],
@@ -499,12 +573,26 @@ def genome3g_block(hash10x_amd, local_rank, steps=2):
            "barcodes_per_s_clustered": wl["barcodes"] / (tm["cluster"][0] / steps * 1e-3),
            "generate_seconds": round(gen_s, 1), "host_threads": os.cpu_count()}
     try:
+        tr = profile_traffic("*genome3g_pmc_traffic.json", "cluster_kernel")
+    except Exception:
+        tr = None
+    out["traffic"] = tr["traffic"] if tr else None
+    out["traffic_of"] = "all cluster_kernel launches of a step"
+    out["traffic_raw"] = tr
+    out["traffic_stale"] = (tr["traffic_build_id"] != hash10x_amd.build_id()) if tr else None
+    man = json.load(open(os.path.join(REPO, "tests", "golden", "manifest.json")))
+
+    def state_checksum():
+        zz = h.sizes()
+        c2 = checksum_state(h.export_slice(3, 1, zz["nBlocks"] - 1), 1, np.zeros(0, dtype=np.uint8), 0)
+        for a in range(0, zz["nClusHash"], 1 << 27):
+            part = checksum_state(np.zeros(0, dtype=np.uint8), 0, h.export_slice(4, a, min(1 << 27, zz["nClusHash"] - a)), a)
+            c2 = [(c2[0] + part[0]) & 0xFFFFFFFFFFFFFFFF, (c2[1] + part[1]) & 0xFFFFFFFFFFFFFFFF]
+        return c2
+    try:
         t0 = time.perf_counter()
-        cs = checksum_state(h.export_slice(3, 1, z["nBlocks"] - 1), 1, np.zeros(0, dtype=np.uint8), 0)
-        for a in range(0, z["nClusHash"], 1 << 27):
-            part = checksum_state(np.zeros(0, dtype=np.uint8), 0, h.export_slice(4, a, min(1 << 27, z["nClusHash"] - a)), a)
-            cs = [(cs[0] + part[0]) & 0xFFFFFFFFFFFFFFFF, (cs[1] + part[1]) & 0xFFFFFFFFFFFFFFFF]
-        exp = json.load(open(os.path.join(REPO, "tests", "golden", "manifest.json"))).get("strong_digests", {}).get(name)
+        cs = state_checksum()
+        exp = man.get("strong_digests", {}).get(name)
         out["state_checksum"] = ["0x%016x" % v for v in cs]
         out["parity_seconds"] = round(time.perf_counter() - t0, 1)
         if exp is None:
@@ -514,6 +602,42 @@ def genome3g_block(hash10x_amd, local_rank, steps=2):
             out["parity_vs_reference_digest"] = "identical" if same else "DIFFERENT (reference %s, H %d, hashNumber %d)" % (exp["checksum"], exp["sum_nHash"], exp["hash_number"])
     except Exception as e:
         out["parity_vs_reference_digest"] = "check failed: " + str(e)[:200]
+    # BASELINE configs[4] on the same state: the crib (both truth haplotypes, 3 Gb each, hashed and looked up on the device), the report's figures over all barcodes
+    # (the accuracy check: clusters whose located hashes all lie on one chromosome, mean span), then --clusterSplit; HBM high-water mark along the way
+    try:
+        total = hash10x_amd.device_mem_info(local_rank)[1]
+        low = [hash10x_amd.device_mem_info(local_rank)[0]]
+        t0 = time.perf_counter(); hap_a, hap_b = haplotypes_v2(wl, wl["seed"]); hap_s = time.perf_counter() - t0
+        t0 = time.perf_counter(); known = h.crib_genomes(hap_a, hap_b); hash10x_amd.synchronize(local_rank); crib_s = time.perf_counter() - t0
+        del hap_a, hap_b
+        low.append(hash10x_amd.device_mem_info(local_rank)[0])
+        t0 = time.perf_counter(); fig = h.cluster_report_figures(); rep_s = time.perf_counter() - t0
+        low.append(hash10x_amd.device_mem_info(local_rank)[0])
+        t0 = time.perf_counter(); h.cluster_split(); hash10x_amd.synchronize(local_rank); split_s = time.perf_counter() - t0
+        low.append(hash10x_amd.device_mem_info(local_rank)[0])
+        z2 = h.sizes()
+        exp4 = man.get("split_digests", {}).get(name, {})
+        c4 = {"commands": "--cribBuild A.fa B.fa (through h10x_crib_genome: no FASTA files) --clusterReport 1 0 (figures, no text) --clusterSplit, on the clustered state of the step above",
+              "cribBuild_seconds": round(crib_s, 3), "cribBuild_note": "both haplotypes (2 x %.1f Gb of base codes from host memory: upload + mosh extraction + look-ups + classification)" % (wl["genome"] / 1e9),
+              "crib_known_unknown_moshes": known, "haplotype_generation_seconds": round(hap_s, 1),
+              "clusterReport_seconds": round(rep_s, 3), "clusterReport_note": "h10x_cluster_report over all %d barcodes: per-barcode and per-cluster figures reduced on the device, 80 B per cluster over PCIe, summed on the host" % (z["nBlocks"] - 1),
+              "clusterSplit_seconds": round(split_s, 3), "blocks_after_split": z2["nBlocks"],
+              "accuracy": {"clusters": fig["clusters"], "clusters_without_OTHER": fig["clusters_without_OTHER"], "purity": fig["clusters_without_OTHER"] / fig["clusters"] if fig["clusters"] else None,
+                           "clusters_located": fig["clusters_located"], "mean_span_kb": fig["sum_span"] / fig["clusters_located"] if fig["clusters_located"] else None,
+                           "mean_reads_per_cluster": fig["sum_reads"] / fig["clusters"] if fig["clusters"] else None, "mean_hashes_per_cluster": fig["sum_hashes"] / fig["clusters"] if fig["clusters"] else None,
+                           "what": "purity = share of CODE_CLUSTER lines without an OTHER list (every located hash of the cluster on one chromosome, hash10x.c:905-913); span in crib position units (pos >> 10)"},
+              "hbm_high_water_GB": round((total - min(low)) / 1e9, 1), "hbm_total_GB": round(total / 1e9, 1)}
+        if "report" in exp4:
+            same = all(fig[k] == exp4["report"][k] for k in ("clusters", "clusters_without_OTHER", "clusters_located", "sum_span", "sum_reads", "sum_hashes"))
+            c4["accuracy_vs_reference_report"] = "identical" if same else "DIFFERENT (reference %r)" % {k: exp4["report"][k] for k in ("clusters", "clusters_without_OTHER", "clusters_located", "sum_span", "sum_reads", "sum_hashes")}
+        else:
+            c4["accuracy_vs_reference_report"] = exp4.get("failed", "no reference report for this set in the manifest") if exp4 else "no reference report for this set in the manifest"
+        if "checksum" in exp4:
+            cs4 = state_checksum()
+            c4["split_state_vs_reference_digest"] = "identical" if [int(v, 16) for v in exp4["checksum"]] == cs4 and exp4["blocks_max"] == z2["nBlocks"] else "DIFFERENT"
+        out["config5"] = c4
+    except Exception as e:
+        out["config5"] = {"error": str(e)[:300]}
     h.close(); d.free()
     return out
 
@@ -825,6 +949,21 @@ def main():
             out["genome3g"] = genome3g_block(hash10x_amd, local_rank) if (os.cpu_count() or 1) >= 32 else {"skipped": "fewer than 32 host threads: generating 300 M pairs would take minutes"}
         except Exception as e:
             out["genome3g"] = {"error": str(e)[:300]}
+    if rank == 0 and world == 1:
+        # the figures that matter at scale, where the driver's parser keeps them: the roofline object. The yeast-scale kernel stays the object's own
+        # achieved / frac; at_scale = BASELINE configs[2] at its own size (the config that names the roofline), genome3g = the 3 Gb strong-scaling workload
+        def scale_entry(blk, label):
+            if not isinstance(blk, dict) or "roofline" not in blk:
+                return {"config": label, "skipped": (blk or {}).get("skipped") or (blk or {}).get("error") or "not run"}
+            r = blk["roofline"]
+            return {"config": label, "kernel": r["kernel"], "frac": r["frac"], "achieved": r["achieved"], "unit": "GB/s", "ms": r["ms_per_step"], "algorithmic_bytes": r["algorithmic_bytes"],
+                    "traffic": blk.get("traffic"), "traffic_stale": blk.get("traffic_stale"), "step_ms": blk["ms_per_step"], "read_pairs_per_s": blk["read_pairs_per_s"]}
+        if "full_config3" in out:
+            out["roofline"]["at_scale"] = scale_entry(out["full_config3"], "BASELINE configs[2] at its own size: 200 M pairs, 1 M barcodes, 500 Mb x 2, -B 29 (config3-full-200M)")
+            out["config"]["at_scale_workload"] = "config3-full-200M (see roofline.at_scale, full_config3)"
+        if "genome3g" in out:
+            out["roofline"]["genome3g"] = scale_entry(out["genome3g"], "3 Gb x 2, 300 M pairs, 1.6 M barcodes, -B 30, --hashDepthRange 6 45 (genome3g-300M: BASELINE configs[3] / [4] shape)")
+            out["config"]["genome3g_workload"] = "genome3g-300M (see roofline.genome3g, genome3g, genome3g.config5)"
     if rank == 0:
         os.write(json_fd, (json.dumps(out) + "\n").encode())
     if comm is not None:

@@ -47,6 +47,10 @@ class _ShardSeg(ctypes.Structure):
                 ("entries", ctypes.c_uint64), ("localEntryStart", ctypes.c_uint64), ("globalEntryStart", ctypes.c_uint64)]
 
 
+_BLOCK_REP = np.dtype([("nGood", "<u4"), ("nClusHash", "<u4"), ("nClusRead", "<u4"), ("reserved", "<u4")])
+_CLUSTER_REP = np.dtype([("n", "<u4"), ("nRead", "<u4"), ("nt", "<u4", (5,)), ("nBad", "<u4"), ("chr", "<i2"), ("pMin", "<u2"), ("pMax", "<u2"), ("nOtherListed", "<u2"), ("other", "<u4", (10,))])
+assert _BLOCK_REP.itemsize == 16 and _CLUSTER_REP.itemsize == 80       # h10x_block_rep / h10x_cluster_rep (include/h10x.h)
+
 _libs = None
 
 
@@ -115,6 +119,10 @@ def load_native():
     hip.h10x_device_free.argtypes = [ci, vp]
     hip.h10x_device_upload.argtypes = [ci, vp, vp, cu64]
     hip.h10x_device_synchronize.argtypes = [ci]
+    hip.h10x_device_mem_info.argtypes = [ci, ctypes.POINTER(cu64), ctypes.POINTER(cu64)]
+    hip.h10x_crib_genome.argtypes = [vp, vp, vp, ctypes.c_uint32, ci, ctypes.POINTER(cu64), ctypes.POINTER(cu64)]
+    hip.h10x_crib_finish.argtypes = [vp]
+    hip.h10x_cluster_report.argtypes = [vp, ctypes.c_uint32, ctypes.c_uint32, vp, vp, cu64, ctypes.POINTER(cu64)]
     hip.h10x_device_count.restype = ci
     hip.h10x_warm.restype = ci; hip.h10x_warm.argtypes = [ci]
     hip.h10x_alloc_stats.restype = None; hip.h10x_alloc_stats.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
@@ -142,6 +150,15 @@ def load_native():
 
 def device_count():
     return load_native()[0].h10x_device_count()
+
+
+def device_mem_info(device=0):
+    """(free, total) bytes of the device's memory as the driver reports them"""
+    hip, _ = load_native()
+    f, t = ctypes.c_uint64(0), ctypes.c_uint64(0)
+    if hip.h10x_device_mem_info(int(device), ctypes.byref(f), ctypes.byref(t)):
+        raise Hash10xError("h10x_device_mem_info failed")
+    return f.value, t.value
 
 
 def warm(device=0):
@@ -404,6 +421,51 @@ class Hash10x:
 
     def crib_build(self, fa1, fa2, out=None, tables=False):
         self._with_file(out, lambda f: self._host.h10x_session_cribBuild(self._s, os.fsencode(fa1), os.fsencode(fa2), f, 1 if tables else 0))
+
+    def crib_genomes(self, codes_a, codes_b, piece=60000000):
+        """--cribBuild through the C ABI without FASTA files (h10x_crib_genome x 2 + h10x_crib_finish, hash10x.c:426-494): each haplotype as base codes 0..3, cut into
+        sequences of `piece` bases as the truth FASTAs of gen_fqb are. Returns [(known, unknown) moshes of genome 1, of genome 2]."""
+        out = []
+        for which, codes in enumerate((codes_a, codes_b)):
+            codes = np.ascontiguousarray(codes, dtype=np.uint8)
+            starts = np.arange(0, codes.size + piece, piece, dtype=np.uint64)
+            starts[-1] = codes.size
+            if starts.size >= 2 and starts[-2] >= codes.size:
+                starts = starts[:-1]; starts[-1] = codes.size
+            known, unknown = ctypes.c_uint64(0), ctypes.c_uint64(0)
+            self._chk_ctx(self._hip.h10x_crib_genome(self._ctx(), codes.ctypes.data, starts.ctypes.data, int(starts.size - 1), which, ctypes.byref(known), ctypes.byref(unknown)))
+            out.append((known.value, unknown.value))
+        self._chk_ctx(self._hip.h10x_crib_finish(self._ctx()))
+        return out
+
+    def cluster_report_figures(self, first_block=1, n_blocks=None, run=1 << 16):
+        """codeClusterReport's figures (hash10x.c:870-952) reduced over blocks [first, first + n) of THIS rank without forming the text: the sums tests/orc.report_digest reads
+        off the reference's CODE_CLUSTER lines — clusters printed (n > 0), those without an OTHER list, those with a location, the sums of their spans, reads and hashes —
+        plus the sum of nGoodHash and of nClusHash over the blocks."""
+        z = self.sizes()
+        if n_blocks is None:
+            n_blocks = z["nBlocks"] - first_block
+        tot = dict(clusters=0, clusters_without_OTHER=0, clusters_located=0, sum_span=0, sum_reads=0, sum_hashes=0, sum_nGood=0, sum_nClusHash=0)
+        brep = np.zeros(run, dtype=_BLOCK_REP)
+        crep = np.zeros(run * 16, dtype=_CLUSTER_REP)
+        at = first_block
+        while at < first_block + n_blocks:
+            nb = min(run, first_block + n_blocks - at)
+            ncl = ctypes.c_uint64(0)
+            rc = self._hip.h10x_cluster_report(self._ctx(), int(at), int(nb), brep.ctypes.data, crep.ctypes.data, ctypes.c_uint64(crep.size), ctypes.byref(ncl))
+            if rc and ncl.value > crep.size:                 # more clusters than the buffer holds: the call says how many
+                crep = np.zeros(int(ncl.value) + 1024, dtype=_CLUSTER_REP)
+                rc = self._hip.h10x_cluster_report(self._ctx(), int(at), int(nb), brep.ctypes.data, crep.ctypes.data, ctypes.c_uint64(crep.size), ctypes.byref(ncl))
+            self._chk_ctx(rc)
+            c = crep[: ncl.value]
+            c = c[c["n"] > 0]
+            loc = c["chr"] != 0
+            tot["clusters"] += int(c.size); tot["clusters_without_OTHER"] += int((c["nBad"] == 0).sum()); tot["clusters_located"] += int(loc.sum())
+            tot["sum_span"] += int((c["pMax"][loc].astype(np.int64) - c["pMin"][loc].astype(np.int64) + 1).sum())
+            tot["sum_reads"] += int(c["nRead"].sum(dtype=np.int64)); tot["sum_hashes"] += int(c["n"].sum(dtype=np.int64))
+            tot["sum_nGood"] += int(brep["nGood"][:nb].sum(dtype=np.int64)); tot["sum_nClusHash"] += int(brep["nClusHash"][:nb].sum(dtype=np.int64))
+            at += nb
+        return tot
 
     def cluster_report(self, code_min, code_max, out=None):
         self._with_file(out, lambda f: self._host.h10x_session_clusterReport(self._s, int(code_min), int(code_max), f))

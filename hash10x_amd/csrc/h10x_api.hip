@@ -310,6 +310,14 @@ int h10x_export(h10x_ctx *h, uint32_t *hashIndex, uint64_t *hashValue, uint32_t 
   return 0;
 }
 
+int h10x_device_mem_info(int device, uint64_t *freeBytes, uint64_t *totalBytes) {
+  if (hipSetDevice(device) != hipSuccess) return -1;
+  size_t f = 0, t = 0;
+  if (hipMemGetInfo(&f, &t) != hipSuccess) return -1;
+  if (freeBytes) *freeBytes = f;
+  if (totalBytes) *totalBytes = t;
+  return 0;
+}
 void *h10x_device_malloc(int device, uint64_t bytes) {
   void *p = nullptr;
   if (hipSetDevice(device) != hipSuccess) return nullptr;

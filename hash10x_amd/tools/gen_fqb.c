@@ -392,6 +392,14 @@ static void gen2_write_fasta(const h10x_gen2_plan *pl, const char *path, int hap
   free(h);
 }
 
+/* one haplotype of the truth genome as base codes 0..3 — what readSequence() hands cribAddGenome (hash10x.c:426-453) for the FASTA gen2_write_fasta writes, whose
+   sequences are the 60 Mb pieces [k * 60e6, (k + 1) * 60e6) of it: out[genome]. For callers that feed the crib through the C ABI without a file (bench.py). */
+void h10x_gen2_haplotype(const h10x_gen2_plan *pl, int hap, uint8_t *out) {
+  const int64_t G = (int64_t)pl->p.genome;
+#pragma omp parallel for schedule(dynamic, 16)
+  for (int64_t i = 0; i < G; i += 1 << 20) { const int64_t n = G - i < (1 << 20) ? G - i : (1 << 20); gen2_fetch(pl, hap, (uint64_t)i, (int)n, out + i); }
+}
+
 /* in-process entry point (ctypes): fills out[30*pairs]; keeps genome until h10x_gen_free() */
 uint64_t h10x_gen_fqb(const h10x_gen_params *p, uint32_t *out) {
   if (g_hapA) { free(g_hapA); free(g_hapB); g_hapA = g_hapB = 0; }

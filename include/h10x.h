@@ -286,6 +286,8 @@ int  h10x_crib_words(h10x_ctx *ctx, uint64_t first, uint64_t count, uint32_t *wo
 /* ---- device memory plumbing for callers that keep the input resident in HBM (bench, pipelines) ----
    plain hipMalloc / hipMemcpy / hipDeviceSynchronize on `device`; return NULL / non-zero on failure */
 void *h10x_device_malloc(int device, uint64_t bytes);
+/* free and total bytes of the device's memory as the driver sees them (hipMemGetInfo; blocks parked in the library's cache count as used) */
+int   h10x_device_mem_info(int device, uint64_t *freeBytes, uint64_t *totalBytes);
 int   h10x_device_free(int device, void *ptr);
 int   h10x_device_upload(int device, void *dst, const void *src, uint64_t bytes);
 int   h10x_device_synchronize(int device);
