@@ -44,11 +44,11 @@ __global__ void within_kernel(const u32 *__restrict__ depth, u32 hashNumber, int
   if (n >= lo && n < hi) within[i] = 1;                     // only ever set (hash10x.c:535)
 }
 __global__ void within_depth_kernel(const u32 *__restrict__ depth, const u8 *__restrict__ within, u32 hashNumber, u32 *__restrict__ out,
-                                    u8 *__restrict__ out8 /* the same in a byte where every in-range depth is below 255, else null */) {
+                                    const u64 *__restrict__ rowStart, u32 rowShift, u64 *__restrict__ rowInfo /* null, or per hash: where its barcode list starts (>> rowShift) | (depth + 1, 0 outside the range) << 32 */) {
   const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < hashNumber) {
     const u32 wd = within[i] ? depth[i] + 1 : 0;             // 0 = outside the range(s); depth + 1 otherwise (one word tells both)
-    out[i] = wd; if (out8) out8[i] = (u8)wd;
+    out[i] = wd; if (rowInfo) rowInfo[i] = (u64)(u32)(rowStart[i] >> rowShift) | ((u64)wd << 32);
   }
 }
 
@@ -99,16 +99,17 @@ __global__ void offsets32c_kernel(const u64 *__restrict__ off, u32 n, u32 *__res
 // The good list of a block in one workgroup: the in-range hashes' depths as keys, their positions as values, sorted in LDS
 // (rocPRIM block radix sort, stable), positions written out — instead of key kernel + device-wide segmented sort + position
 // kernel. Blocks up to BLOCK_SORT_MAX entries, depths below 2^16; three launch classes by block size like clushash_block_kernel.
-// (WT = u8 where the depths allow: the table every entry looks its hash up in is then a quarter the size — 7.6 MB instead of
-// 30 MB at yeast scale, against 4 MB of L2 per XCD)
-template <int THREADS, int IPT, typename WT>
+// Round 5: ONE random read per entry. The chip does some 55 G independent random reads a second whatever the table's size (scratch/r5_gather_rate.hip: 64 MB .. 4 GB
+// tables, 1 .. 8 byte entries, all within 15 %), and this kernel used to make two — the depth byte of every entry, then the list offset of every good one: 4.1 G look-ups
+// in 72 ms on the 3 Gb set, i.e. at that wall. rowInfo[] (within_depth_kernel) holds both in a word; the offset rides through the sort as part of the value.
+template <int THREADS, int IPT>
 __global__ __launch_bounds__(THREADS)
 void good_block_kernel(const h10x_clushash *__restrict__ ch, const u64 *__restrict__ blockOff, const h10x_block *__restrict__ blocks,
                        const u32 *__restrict__ list, const u32 *__restrict__ count /* this class's blocks: stageB_blockClassLists */,
-                       const WT *__restrict__ wdepth /* 0 = not in range, else depth + 1 */, int sortBits,
+                       const u64 *__restrict__ rowInfo /* per hash: list offset | (0 = not in range, else depth + 1) << 32 */, int sortBits,
                        u16 *__restrict__ goodPos, u32 *__restrict__ nGood, u32 *__restrict__ entries /* sum of depths, saturating */,
-                       const u64 *__restrict__ rowStart, u32 rowShift, u64 *__restrict__ goodRow /* list descriptor per rank: see good_rows_kernel */) {
-  using Sort = rocprim::block_radix_sort<u32, THREADS, IPT, u32>;
+                       u64 *__restrict__ goodRow /* list descriptor per rank: see good_rows_kernel */) {
+  using Sort = rocprim::block_radix_sort<u32, THREADS, IPT, u64>;
   __shared__ typename Sort::storage_type storage;
   __shared__ u32 sCount; __shared__ unsigned long long sDepth;
   const u32 nList = *count;
@@ -122,12 +123,12 @@ void good_block_kernel(const h10x_clushash *__restrict__ ch, const u64 *__restri
     // blocked arrangement: a thread holds IPT consecutive positions, so the positions are ascending in the order the sort
     // takes as given, and a STABLE sort on the depth bits alone (one 8-bit pass for depths below 128, where depth and
     // position in one key needed three) leaves equal depths in ascending position
-    u32 k[IPT], v[IPT]; u32 mine = 0; unsigned long long myDepth = 0;
+    u32 k[IPT]; u64 v[IPT]; u32 mine = 0; unsigned long long myDepth = 0;
 #pragma unroll
     for (int j = 0; j < IPT; ++j) {
       const u32 p = threadIdx.x * IPT + (u32)j;
       k[j] = 0xFFFFFFFFu; v[j] = p;
-      if (p < nHash) { const u32 wd = wdepth[ch[o + p].hash]; if (wd) { k[j] = wd - 1; ++mine; myDepth += wd - 1; } }
+      if (p < nHash) { const u64 ri = rowInfo[ch[o + p].hash]; const u32 wd = (u32)(ri >> 32); if (wd) { k[j] = wd - 1; ++mine; myDepth += wd - 1; v[j] = (u64)p | ((ri & 0xFFFFFFFFull) << 16); } }   // value: position (16 bits: blocks of at most BLOCK_SORT_MAX entries) | list offset << 16
     }
     for (int sft = 32; sft; sft >>= 1) { mine += (u32)__shfl_down((int)mine, sft); myDepth += __shfl_down(myDepth, sft); }
     if ((threadIdx.x & (WAVE - 1)) == 0 && mine) { atomicAdd(&sCount, mine); atomicAdd(&sDepth, myDepth); }
@@ -141,7 +142,7 @@ void good_block_kernel(const h10x_clushash *__restrict__ ch, const u64 *__restri
         goodPos[o + e] = (u16)v[j];
         // where the rank's barcode list lies and how long it is (the sort key IS the depth): the cluster kernel streams these
         // instead of gathering position -> hash index -> offset, depth per barcode
-        goodRow[o + e] = (u64)(u32)(rowStart[ch[o + v[j]].hash] >> rowShift) | ((u64)k[j] << 32);
+        goodRow[o + e] = (u64)(u32)(v[j] >> 16) | ((u64)k[j] << 32);
       }
     }
     if (threadIdx.x == 0) { nGood[c] = nG; entries[c] = sDepth > 0xFFFFFFFFull ? 0xFFFFFFFFu : (u32)sDepth; }
@@ -176,8 +177,8 @@ int stageC_depthRange(Ctx *c, int lo, int hi) {
   const u32 goodDepthBound = hmin<u32>(c->depthBound, c->rangeHiMax ? c->rangeHiMax - 1 : 0);
   const bool narrow = goodDepthBound <= 65535u;
   const bool byBlocks = narrow && c->maxBlockHashes <= BLOCK_SORT_MAX;       // every block's list is built and sorted by one workgroup
-  DevBuf<u8> wdepth8; if (byBlocks && goodDepthBound <= 254u) H10X_HIP(c, wdepth8.alloc(U1));
-  within_depth_kernel<<<divUp(U1, 256), 256, 0, st>>>(c->hashDepth.p, c->within.p, U1, wdepth.p, wdepth8.p);
+  DevBuf<u64> rowInfo; if (byBlocks) H10X_HIP(c, rowInfo.alloc(U1));
+  within_depth_kernel<<<divUp(U1, 256), 256, 0, st>>>(c->hashDepth.p, c->within.p, U1, wdepth.p, c->rowStart.p, (u32)c->rowShift, rowInfo.p);
   H10X_TRY(prim_reduce_max_u32(c, pt, wdepth.p, red.p, U1));
   if (byBlocks) {
     int db = 1; while (db < 16 && (goodDepthBound >> db)) ++db;
@@ -190,8 +191,7 @@ int stageC_depthRange(Ctx *c, int lo, int hi) {
     if (side) H10X_TRY(c->forkStreams(side));
 #define H10X_GOOD_LAUNCH(T, I, CLS, STREAM)                                                                                         \
     { const u32 *const L = lists.p + (size_t)CLS * nBlocks, *const N = counts.p + CLS; const unsigned grid = CLS == 0 ? gridSmall : gridBig; \
-      if (wdepth8.p) good_block_kernel<T, I, u8><<<grid, T, 0, STREAM>>>(c->clusHash.p, c->blockOff.p, c->blocks.p, L, N, wdepth8.p, sortBits, c->goodPos.p, c->nGood.p, c->goodEntries.p, c->rowStart.p, (u32)c->rowShift, c->goodRow.p); \
-      else good_block_kernel<T, I, u32><<<grid, T, 0, STREAM>>>(c->clusHash.p, c->blockOff.p, c->blocks.p, L, N, wdepth.p, sortBits, c->goodPos.p, c->nGood.p, c->goodEntries.p, c->rowStart.p, (u32)c->rowShift, c->goodRow.p); }
+      good_block_kernel<T, I><<<grid, T, 0, STREAM>>>(c->clusHash.p, c->blockOff.p, c->blocks.p, L, N, rowInfo.p, sortBits, c->goodPos.p, c->nGood.p, c->goodEntries.p, c->goodRow.p); }
     H10X_GOOD_LAUNCH(H10X_BS_T0, H10X_BS_I0, 0, st)
     if (side >= 1) H10X_GOOD_LAUNCH(H10X_BS_T1, H10X_BS_I1, 1, c->aux[0])
     if (side >= 2) H10X_GOOD_LAUNCH(1024, 8, 2, c->aux[1])
@@ -1268,6 +1268,7 @@ __device__ __forceinline__ void cluster_one_block_tr(const ClusterArgs &a, u32 c
     }
     SYNC();
     const u32 nTodo = sh[2];
+    if (a.phase && tid == 0) { atomicAdd((u64 *)&a.phase[6], (u64)nTodo); atomicAdd((u64 *)&a.phase[7], (u64)n); }   // diagnostic: ranks settled behind the loop / ranks
     for (u32 k = tid; k < nTodo; k += CL_THREADS) {
       const u32 i = todo[k];
       u32 r = (u32)(__hip_atomic_load(&res[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 0xFFFFu);   // msBest: from the rank's result word (read past this CU's L1)
@@ -1697,6 +1698,7 @@ __device__ __forceinline__ void cluster_one_block_tp(const ClusterArgs &a, u32 c
     }
     SYNC();
     const u32 nTodo = sh[2];
+    if (a.phase && tid == 0) { atomicAdd((u64 *)&a.phase[6], (u64)nTodo); atomicAdd((u64 *)&a.phase[7], (u64)n); }   // diagnostic: ranks settled behind the loop / ranks
     for (u32 k = tid; k < nTodo; k += CL_THREADS) {
       const u32 i = todo[k];
       u32 r = (u32)(__hip_atomic_load(&res[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 0xFFFFu);   // msBest: from the rank's result word (read past this CU's L1)

@@ -32,6 +32,6 @@ for s in sets:
         if it and (best is None or tm["cluster_kernel"][0] < best[0]): best = (tm["cluster_kernel"][0], tm.get("cluster_main", (0, 0))[0], dt, {k: round(v[0], 2) for k, v in tm.items() if v[0] > 0})
     c = h.counters()
     if os.environ.get("STAMPS"):
-        tk = c["cluster_phase_ticks"]; tot = float(sum(tk)) or 1.0
-        print("      phase shares: init %.3f passA %.3f barrier %.3f compact %.3f passB %.3f settle %.3f" % tuple(x / tot for x in tk[:6]))
+        tk = c["cluster_phase_ticks"]; tot = float(sum(tk[:6])) or 1.0
+        print("      phase shares: init %.3f passA %.3f barrier %.3f compact %.3f passB %.3f settle %.3f; ranks settled behind the loop %.3f" % (tuple(x / tot for x in tk[:6]) + (tk[6] / float(tk[7] or 1),)))
     print("%-40s cluster_kernel %.2f ms main %.2f step %.1f ms classes %s ovf %s mode %s\n      %s" % (s, best[0], best[1], 1e3 * best[2], c["cluster_class_counts"], c["cluster_overflow_blocks"], c["cluster_first_mode"], best[3]), flush=True)
