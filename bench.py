@@ -632,6 +632,8 @@ def genome3g_block(hash10x_amd, local_rank, steps=2, name="genome3g-300M"):
             c4["accuracy_vs_reference_report"] = "identical" if same else "DIFFERENT (reference %r)" % {k: exp4["report"][k] for k in ("clusters", "clusters_without_OTHER", "clusters_located", "sum_span", "sum_reads", "sum_hashes")}
         else:
             c4["accuracy_vs_reference_report"] = exp4.get("failed", "no reference report for this set in the manifest") if exp4 else "no reference report for this set in the manifest"
+        if "no_split_digest" in exp4:
+            c4["split_state_vs_reference_digest"] = "none: " + exp4["no_split_digest"]
         if "checksum" in exp4:
             cs4 = state_checksum()
             c4["split_state_vs_reference_digest"] = "identical" if [int(v, 16) for v in exp4["checksum"]] == cs4 and exp4["blocks_max"] == z2["nBlocks"] else "DIFFERENT"
@@ -639,6 +641,101 @@ def genome3g_block(hash10x_amd, local_rank, steps=2, name="genome3g-300M"):
     except Exception as e:
         out["config5"] = {"error": str(e)[:300]}
     h.close(); d.free()
+    return out
+
+
+XGMI_LINK_GBS = 153.0          # per direction and link, 7 links per GPU (MI355X_MICROARCH.md); the model below charges 80 % of it
+STAGE_TIMERS = ("block_runs", "mosh_extract", "mosh_fallback", "compact_entries", "sort_by_hash", "index_rank", "probe_table", "clushash_build", "csr_build", "good_hashes", "cluster")
+
+
+def rank_figures(h):
+    """compute and exchange figures of one rank's last step: stage timers (device ms), the exchanges' bytes and waits, compute = stages less the waits inside them"""
+    tm = {k: v[0] for k, v in h.timings().items() if v[0] > 0}
+    ex = h.exchanges()
+    stages = sum(tm.get(k, 0.0) for k in STAGE_TIMERS)
+    waits = sum(e["ms_in_stages"] for e in ex.values())
+    return {"stage_ms": {k: round(v, 3) for k, v in tm.items()}, "exchanges": ex, "compute_ms": stages - waits}
+
+
+def scaling_model(per_rank, single_ms):
+    """A MODEL of the N-GPU step from figures measured on ONE GPU (ranks taking turns): max over ranks of their compute + per kind of exchange the largest per-peer
+    share any rank sends, over one xGMI link at 80 % of its rate (the all-to-alls are grouped point-to-point sends: every link of a rank works at once, the busiest
+    pair bounds the call), + 30 us per call. No overlap of exchange and compute is assumed (there is none in the code). Not a measurement."""
+    n = len(per_rank)
+    comp = [r["compute_ms"] for r in per_rank]
+    kinds = sorted({k for r in per_rank for k in r["exchanges"]})
+    ex = {}
+    xfer_ms = 0.0
+    for k in kinds:
+        peer = max(r["exchanges"].get(k, {}).get("max_peer_out", 0) for r in per_rank)
+        out = [r["exchanges"].get(k, {}).get("bytes_out", 0) for r in per_rank]
+        calls = max(r["exchanges"].get(k, {}).get("calls", 0) for r in per_rank)
+        ms = peer / (0.8 * XGMI_LINK_GBS * 1e9) * 1e3 + 0.03 * calls
+        xfer_ms += ms
+        ex[k] = {"calls_per_step": calls, "max_rank_bytes_out": max(out), "sum_bytes_out": sum(out), "busiest_peer_share_bytes": peer, "modelled_ms": round(ms, 3)}
+    step = max(comp) + xfer_ms
+    return {"ranks": n, "max_rank_compute_ms": round(max(comp), 3), "mean_rank_compute_ms": round(sum(comp) / n, 3), "compute_imbalance": round(max(comp) / (sum(comp) / n), 3) if sum(comp) else None,
+            "modelled_exchange_ms": round(xfer_ms, 3), "modelled_step_ms": round(step, 3), "single_gpu_step_ms": round(single_ms, 3),
+            "modelled_speedup_vs_1_gpu": round(single_ms / step, 2) if step else None, "exchanges": ex,
+            "model": "max rank compute (stage timers less the waits inside them, ranks taking turns on one GPU) + sum over exchanges of busiest-peer bytes / (0.8 x %.0f GB/s) + 30 us per call; "
+                     "no overlap assumed; a MODEL, not a measurement" % XGMI_LINK_GBS}
+
+
+def virtual_ranks_block(hash10x_amd, name, n, local_rank=0, steps=1):
+    """`n` ranks as threads on ONE GPU (in-process communicator, ranks taking turns: h10x_comm_local_serialize), each with its shard of the generator-v2 workload `name`:
+    per rank the compute of a step and every exchange's bytes; the same set on one unsharded context for the single-GPU step; scaling_model() on top."""
+    import threading
+    wl = dict(WORKLOADS[name])
+    # one GPU, unsharded: the step the speed-up is quoted against
+    recs, _f, total = generate_v2(wl, wl["seed"])
+    d = hash10x_amd.DeviceRecords(recs, device=local_rank); pairs = recs.size // 30; del recs
+    h = hash10x_amd.Hash10x(B=wl["B"], device=local_rank); h.enable_timing(True)
+    single = []
+    for it in range(steps + 1):
+        hash10x_amd.synchronize(local_rank); t = time.perf_counter()
+        h.read_fqb_device(d.ptr, pairs); h.depth_range(wl["lo"], wl["hi"]); h.cluster(1, 0, wl["ct"]); hash10x_amd.synchronize(local_rank)
+        if it:
+            single.append(1e3 * (time.perf_counter() - t))
+    single_stage = {k: round(v[0], 3) for k, v in h.timings().items() if v[0] > 0}
+    h.close(); d.free()
+    comms = hash10x_amd.Comm.local(n)
+    comms[0].serialize(True)
+    res, err = [None] * n, [None] * n
+
+    def work(r):
+        try:
+            rr, _first, _tot = generate_v2(wl, wl["seed"], r, n)
+            dr = hash10x_amd.DeviceRecords(rr, device=local_rank); np_ = rr.size // 30; del rr
+            hh = hash10x_amd.Hash10x(B=wl["B"], device=local_rank); hh.enable_timing(True)
+            for it in range(steps + 1):
+                comms[r].turn_begin()
+                try:
+                    hh.shard_read_fqb_device(comms[r], dr.ptr, np_); hh.depth_range(wl["lo"], wl["hi"]); hh.cluster(1, 0, wl["ct"])
+                finally:
+                    comms[r].turn_end(local_rank)
+            res[r] = rank_figures(hh); res[r]["read_pairs"] = np_
+            comms[r].turn_begin()
+            try:
+                hh.shard_barrier()
+            finally:
+                comms[r].turn_end(local_rank)
+            hh.close(); dr.free()
+        except Exception as e:                              # a rank that dies leaves the others waiting in a collective: say so and let the caller's timeout end it
+            err[r] = str(e)
+    th = [threading.Thread(target=work, args=(r,)) for r in range(n)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    for c in comms:
+        c.destroy()
+    if any(err):
+        return {"error": "; ".join("rank %d: %s" % (i, e) for i, e in enumerate(err) if e)[:400]}
+    out = scaling_model(res, sum(single) / len(single))
+    out["workload"] = name
+    out["single_gpu_stage_ms"] = single_stage
+    out["per_rank"] = [{"read_pairs": r["read_pairs"], "compute_ms": round(r["compute_ms"], 3), "stage_ms": r["stage_ms"],
+                        "exchange_wait_ms": round(sum(e["ms"] for e in r["exchanges"].values()), 3)} for r in res]
     return out
 
 
@@ -703,6 +800,8 @@ def main():
     ap.add_argument("--comm", default="auto", choices=["auto", "rccl", "socket"], help="multi-process backend: RCCL over xGMI (one GPU per rank), or the "
                     "host-staged socket backend where ranks share a GPU (test boxes); auto = socket when there are fewer devices than ranks")
     ap.add_argument("--sharded", action="store_true", help="use the multi-GPU code path (RCCL communicator, shard exchange) even with one rank")
+    ap.add_argument("--virtual-ranks", type=int, default=0, help="model an N-GPU step on ONE GPU: N ranks as threads taking turns on the device (generator-v2 workloads: genome3g-*); prints "
+                    "per-rank compute, every exchange's bytes and the modelled step instead of the benchmark line")
     ap.add_argument("--scaling", default=None, choices=["weak", "strong"], help="N > 1: weak = N x the workload (every rank generates its share of the N-fold set; "
                     "default for the yeast-scale set), strong = the SAME set on every N (default for genome3g-300M: the 3 Gb workload of BASELINE configs[3])")
     args = ap.parse_args()
@@ -716,6 +815,14 @@ def main():
     os.dup2(2, 1)
 
     import hash10x_amd
+
+    if args.virtual_ranks:
+        if WORKLOADS[args.workload].get("gen") != 2:
+            raise SystemExit("--virtual-ranks needs a generator-v2 workload (genome3g-tenth-30M, genome3g-300M)")
+        blk = virtual_ranks_block(hash10x_amd, args.workload, args.virtual_ranks, steps=max(1, min(args.steps, 2)))
+        blk["mode"] = "virtual ranks: a model of the %d-GPU step from one GPU, see `model`" % args.virtual_ranks
+        os.write(json_fd, (json.dumps(blk) + "\n").encode())
+        return
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -882,6 +989,21 @@ def main():
     out["generate_seconds"] = round(gen_s, 2)
     out["build_id"] = hash10x_amd.build_id()
     if world > 1 or args.sharded:
+        # what every kind of exchange moved and how long this rank waited in it, and the ranks' compute: max / sum over the ranks (so that a scaling curve can be read)
+        try:
+            fig = rank_figures(h)
+            kinds = sorted(fig["exchanges"])
+            vals = [int(fig["exchanges"][k][f]) for k in kinds for f in ("bytes_out", "max_peer_out")] + [int(1e3 * fig["exchanges"][k]["ms"]) for k in kinds] + [int(1e3 * fig["compute_ms"])]
+            mx = h.shard_allreduce_max_u64(list(vals)) if hasattr(h, "shard_allreduce_max_u64") else vals
+            sm = h.shard_allreduce_sum_u64(list(vals))
+            nk = len(kinds)
+            out["exchanges"] = {k: {"calls_per_step": fig["exchanges"][k]["calls"], "max_rank_bytes_out": mx[2 * i], "sum_bytes_out": sm[2 * i], "busiest_peer_share_bytes": mx[2 * i + 1],
+                                    "max_rank_wait_ms": mx[2 * nk + i] / 1e3} for i, k in enumerate(kinds)}
+            out["max_rank_compute_ms"] = mx[3 * nk] / 1e3
+            out["mean_rank_compute_ms"] = sm[3 * nk] / 1e3 / world
+            out["exchanges_note"] = "of the last timed step; wait = from the call to its completion on the rank's stream (slower ranks included); compute = stage timers less the waits inside them"
+        except Exception as e:
+            out["exchanges"] = {"error": str(e)[:200]}
         # correctness gate of a sharded run: a checksum of every rank's blocks and ClusterHash records in file numbering,
         # summed over the ranks, against the one of the REFERENCE binary's .hash of this data set (tests/golden/manifest.json,
         # "bench_scale_digests", made in the build container by make_golden.py --scale)
@@ -949,6 +1071,10 @@ def main():
             out["genome3g"] = genome3g_block(hash10x_amd, local_rank) if (os.cpu_count() or 1) >= 32 else {"skipped": "fewer than 32 host threads: generating 300 M pairs would take minutes"}
         except Exception as e:
             out["genome3g"] = {"error": str(e)[:300]}
+        try:                                                 # what 8 GPUs would make of the 3 Gb-shaped set, modelled from this one (ranks as threads taking turns; 1/10 set: seconds)
+            out["scaling_model_8_ranks"] = virtual_ranks_block(hash10x_amd, "genome3g-tenth-30M", 8, local_rank) if (os.cpu_count() or 1) >= 16 else {"skipped": "fewer than 16 host threads"}
+        except Exception as e:
+            out["scaling_model_8_ranks"] = {"error": str(e)[:300]}
     if rank == 0 and world == 1:
         # the figures that matter at scale, where the driver's parser keeps them: the roofline object. The yeast-scale kernel stays the object's own
         # achieved / frac; at_scale = BASELINE configs[2] at its own size (the config that names the roofline), genome3g = the 3 Gb strong-scaling workload

@@ -111,6 +111,7 @@ def load_native():
     hip.h10x_shard_barrier.argtypes = [vp]
     hip.h10x_shard_allreduce_max.argtypes = [vp, ctypes.POINTER(ctypes.c_double)]
     hip.h10x_shard_allreduce_sum_u64.argtypes = [vp, vp, ctypes.c_uint32]
+    hip.h10x_shard_allreduce_max_u64.argtypes = [vp, vp, ctypes.c_uint32]
     hip.h10x_ingest_fqb.argtypes = [vp, vp, cu64, ci]
     hip.h10x_ingest_reserve.argtypes = [vp, cu64]
     hip.h10x_build_id.restype = cs
@@ -135,6 +136,11 @@ def load_native():
     hip.h10x_timing_name.argtypes = [vp, ci]
     hip.h10x_timing_get.argtypes = [vp, ci, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(cu64)]
     hip.h10x_timing_reset.argtypes = [vp]
+    hip.h10x_exchange_name.restype = cs; hip.h10x_exchange_name.argtypes = [ci]
+    hip.h10x_exchange_get.argtypes = [vp, ci, ctypes.POINTER(cu64), ctypes.POINTER(cu64), ctypes.POINTER(cu64), ctypes.POINTER(cu64), ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]
+    hip.h10x_comm_local_serialize.argtypes = [vp, ci]
+    hip.h10x_comm_turn_begin.argtypes = [vp]
+    hip.h10x_comm_turn_end.argtypes = [vp, ci]
     hip.h10x_get_counters.argtypes = [vp, ctypes.POINTER(_Counters)]
     hip.h10x_get_sizes.argtypes = [vp, ctypes.POINTER(_Sizes)]
     hip.h10x_set_option.argtypes = [vp, cs, ctypes.c_int64]
@@ -242,6 +248,17 @@ class Comm:
         arr = (ctypes.c_void_p * size)()
         load_native()[0].h10x_comm_create_local(arr, size)
         return [Comm(ctypes.c_void_p(arr[i]), i, size) for i in range(size)]
+
+    def serialize(self, on=True):
+        """in-process communicators: the ranks take turns on the device they share (h10x_comm_local_serialize); bracket every command with turn_begin / turn_end"""
+        if load_native()[0].h10x_comm_local_serialize(self.handle, 1 if on else 0):
+            raise Hash10xError("not an in-process communicator")
+
+    def turn_begin(self):
+        load_native()[0].h10x_comm_turn_begin(self.handle)
+
+    def turn_end(self, device=0):
+        load_native()[0].h10x_comm_turn_end(self.handle, int(device))
 
     def destroy(self):
         if self.handle:
@@ -388,6 +405,12 @@ class Hash10x:
         self._chk_ctx(self._hip.h10x_shard_allreduce_sum_u64(self._ctx(), v.ctypes.data, len(v)))
         return [int(x) for x in v]
 
+    def shard_allreduce_max_u64(self, values):
+        """maxima over the ranks of a small list of integers; the identity on an unsharded context"""
+        v = np.array([int(x) & 0xFFFFFFFFFFFFFFFF for x in values], dtype=np.uint64)
+        self._chk_ctx(self._hip.h10x_shard_allreduce_max_u64(self._ctx(), v.ctypes.data, len(v)))
+        return [int(x) for x in v]
+
     def export_slice(self, table, first, count):
         """elements [first, first + count) of one table of THIS rank (h10x_export_slice; works on shards): 3 = blocks (32 B), 4 = ClusterHash (8 B)"""
         width = {0: 4, 1: 8, 2: 4, 3: 32, 4: 8, 5: 4}[table]
@@ -517,6 +540,16 @@ class Hash10x:
             ms, n = ctypes.c_double(), ctypes.c_uint64()
             self._hip.h10x_timing_get(ctx, i, ctypes.byref(ms), ctypes.byref(n))
             out[self._hip.h10x_timing_name(ctx, i).decode()] = (ms.value, n.value)
+        return out
+
+    def exchanges(self):
+        """per kind of collective of the sharded path: calls, bytes to / from other ranks, bytes the busiest peer got, ms (waits included) and the part of it inside stage timers"""
+        out = {}
+        for i in range(self._hip.h10x_exchange_count()):
+            v = [ctypes.c_uint64(0) for _ in range(4)]; ms, ms_in = ctypes.c_double(0), ctypes.c_double(0)
+            self._hip.h10x_exchange_get(self._ctx(), i, ctypes.byref(v[0]), ctypes.byref(v[1]), ctypes.byref(v[2]), ctypes.byref(v[3]), ctypes.byref(ms), ctypes.byref(ms_in))
+            if v[0].value:
+                out[self._hip.h10x_exchange_name(i).decode()] = {"calls": v[0].value, "bytes_out": v[1].value, "bytes_in": v[2].value, "max_peer_out": v[3].value, "ms": ms.value, "ms_in_stages": ms_in.value}
         return out
 
     def reset_timings(self):

@@ -51,6 +51,11 @@ struct RcclComm : Comm {
 // ------------------------------------------------------------------------------------------ in-process group
 struct LocalGroup {
   int n; std::mutex mu; std::condition_variable cv; int arrived = 0; unsigned long gen = 0;
+  // "virtual ranks" (bench.py --virtual-ranks): the ranks of the group share ONE device and take turns on it — a rank computes only while it holds the token, hands it on
+  // whenever it waits for the others, and its stage timers then read as if it had the GPU to itself (a turnstile with tickets: std::mutex may not change hands between threads)
+  bool serialize = false; std::mutex tokMu; std::condition_variable tokCv; int tokHolder = -1;
+  void tokAcquire(int r) { std::unique_lock<std::mutex> lk(tokMu); tokCv.wait(lk, [&] { return tokHolder < 0 || tokHolder == r; }); tokHolder = r; }
+  void tokRelease(int r) { std::lock_guard<std::mutex> lk(tokMu); if (tokHolder == r) { tokHolder = -1; tokCv.notify_all(); } }
   int failed = 0, failedPrev = 0;                            // a rank's failure in a collective is seen by every rank at the closing barrier
   std::vector<const void *> sendPtr; std::vector<const u64 *> sendCnt, sendOff; std::vector<std::vector<unsigned char>> host;
   std::vector<double> dbl;
@@ -67,9 +72,13 @@ struct LocalGroup {
 };
 struct LocalComm : Comm {
   std::shared_ptr<LocalGroup> g;
+  void yield(Ctx *c) { if (g->serialize) { if (c) (void)hipStreamSynchronize(c->stream); g->tokRelease(rank); } }   // my kernels are done: somebody else's turn
+  void resume() { if (g->serialize) g->tokAcquire(rank); }
   int alltoallv(Ctx *c, const void *dSend, const u64 *sendCnt, const u64 *sendOff, void *dRecv, const u64 *recvCnt, const u64 *recvOff,
                 size_t eb) override {
     H10X_HIP(c, hipStreamSynchronize(c->stream));            // my send buffer is complete
+    yield(c);
+    struct Back { LocalComm *l; ~Back() { l->resume(); } } back{this};
     g->sendPtr[rank] = dSend; g->sendCnt[rank] = sendCnt; g->sendOff[rank] = sendOff;
     g->wait();
     int rc = 0;
@@ -85,18 +94,21 @@ struct LocalComm : Comm {
     if (g->wait(rc != 0) && !rc) rc = c->fail("alltoallv failed on another rank");
     return rc;
   }
-  int allgatherHost(Ctx *, const void *send, void *recv, size_t bytes) override {
+  int allgatherHost(Ctx *c, const void *send, void *recv, size_t bytes) override {
+    yield(c);
     g->host[rank].assign((const unsigned char *)send, (const unsigned char *)send + bytes);
     g->wait();
     for (int p = 0; p < n; ++p) memcpy((char *)recv + (size_t)p * bytes, g->host[p].data(), bytes);
     g->wait();
+    resume();
     return 0;
   }
-  int barrier(Ctx *) override { g->wait(); return 0; }
-  int allreduceMaxHost(Ctx *, double *v) override {
+  int barrier(Ctx *c) override { yield(c); g->wait(); resume(); return 0; }
+  int allreduceMaxHost(Ctx *c, double *v) override {
+    yield(c);
     g->dbl[rank] = *v; g->wait();
     double m = g->dbl[0]; for (int p = 1; p < n; ++p) m = g->dbl[p] > m ? g->dbl[p] : m;
-    g->wait(); *v = m; return 0;
+    g->wait(); *v = m; resume(); return 0;
   }
 };
 
@@ -263,6 +275,19 @@ int h10x_device_enable_peers(const int *devices, int n) {
 int h10x_comm_create_local(h10x_comm **outs, int nranks) {
   auto g = std::make_shared<LocalGroup>(nranks);
   for (int i = 0; i < nranks; ++i) { LocalComm *l = new LocalComm(); l->rank = i; l->n = nranks; l->g = g; outs[i] = new h10x_comm{l}; }
+  return 0;
+}
+
+int h10x_comm_local_serialize(h10x_comm *c, int on) {
+  LocalComm *l = c ? dynamic_cast<LocalComm *>(c->impl) : nullptr;
+  if (!l) return -1;
+  l->g->serialize = on != 0;
+  return 0;
+}
+int h10x_comm_turn_begin(h10x_comm *c) { LocalComm *l = c ? dynamic_cast<LocalComm *>(c->impl) : nullptr; if (!l) return -1; l->resume(); return 0; }
+int h10x_comm_turn_end(h10x_comm *c, int device) {
+  LocalComm *l = c ? dynamic_cast<LocalComm *>(c->impl) : nullptr; if (!l) return -1;
+  if (l->g->serialize) { if (hipSetDevice(device) == hipSuccess) (void)hipDeviceSynchronize(); l->g->tokRelease(l->rank); }
   return 0;
 }
 

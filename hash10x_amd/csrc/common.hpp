@@ -119,6 +119,17 @@ static const char *const kTimerNames[T_COUNT] = {
 
 struct Timer { hipEvent_t a = nullptr, b = nullptr; double ms = 0; uint64_t launches = 0; bool pending = false; };
 
+// ---- the exchanges of the sharded path, one entry per KIND of collective (shard.hip goes through xchg_a2a / xchg_hostGather): calls, bytes that left this rank for
+// other ranks and arrived from them (the part a rank keeps is a device copy, not counted), the largest share one peer got — what a single xGMI link carries, since
+// the all-to-alls are grouped point-to-point sends — and, with timing on, the time from the call to its completion on the context's stream (the wait for slower
+// ranks included: a rank's compute is its stage timers less these). h10x_exchange_get; bench.py --scaling strong and --virtual-ranks print them.
+enum XchgId { X_HOST_COUNTS = 0, X_ENTRIES, X_FIRST_COUNTS, X_INDEX_BACK, X_INDEX_DEPTH, X_LIST_HEADS, X_LIST_DATA, X_TABLES, X_OWNER_LISTS, X_GATHER, X_COUNT };
+static const char *const kXchgNames[X_COUNT] = {
+  "host_counts (small host allgathers: sizes, counts)", "entries_to_hash_owners (all-to-all)", "first_seen_counts (allgather)", "indices_back (all-to-all)",
+  "index_depth (allgather)", "list_heads (allgather: index + length of the in-range hashes)", "list_data (allgather: the in-range barcode lists)",
+  "hash_tables (allgather: hashValue, for --writeHash / the crib)", "owner_lists_rebuild (after --clusterSplit)", "gather_to_rank0" };
+struct XchgStat { u64 calls = 0, bytesOut = 0, bytesIn = 0, maxPeerOut = 0; Timer t, tIn; };   // tIn: the calls made inside a stage timer's bracket (their time is part of that stage's figure)
+
 // ---- local block number -> global block number ------------------------------------------------------
 // An unsharded context numbers its blocks as the reference does (one segment, identity). A shard owns a contiguous range
 // of the file's barcodes (segment 0: local l = global codeBase + l, slot 0 unused), and every --clusterSplit appends, per
@@ -233,6 +244,7 @@ struct Ctx {
   bool timing = false;
   u32 *startFlags = nullptr;   // pinned host words a side-stream kernel's workgroups set when they start (stageC_cluster)
   Timer timers[T_COUNT];
+  XchgStat xs[X_COUNT];
   h10x_counters ctr{};
 
   int fail(const char *fmt, ...) {
@@ -283,22 +295,23 @@ struct Ctx {
     }
     return 0;
   }
-  void tstart(TimerId t) {
+  void tstart(Timer &x) {
     if (!timing) return;
-    Timer &x = timers[t];
     if (!x.a) { (void)hipEventCreate(&x.a); (void)hipEventCreate(&x.b); }
-    flush(t);
+    flush(x);
     (void)hipEventRecord(x.a, stream);
   }
-  void tstop(TimerId t) {
+  void tstop(Timer &x) {
     if (!timing) return;
-    Timer &x = timers[t];
     (void)hipEventRecord(x.b, stream); x.pending = true; ++x.launches;
   }
-  void flush(TimerId t) {
-    Timer &x = timers[t];
+  void flush(Timer &x) {
     if (x.pending) { float ms = 0; (void)hipEventSynchronize(x.b); (void)hipEventElapsedTime(&ms, x.a, x.b); x.ms += ms; x.pending = false; }
   }
+  int stageOpen = 0;          // stage timers open right now (the exchange wrappers of shard.hip ask)
+  void tstart(TimerId t) { ++stageOpen; tstart(timers[t]); }
+  void tstop(TimerId t) { if (stageOpen > 0) --stageOpen; tstop(timers[t]); }
+  void flush(TimerId t) { flush(timers[t]); }
 };
 
 // A fork/join region: side streams run kernels on buffers that go back to the per-stream block cache when the function returns (the

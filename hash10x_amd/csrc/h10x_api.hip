@@ -511,6 +511,20 @@ int h10x_timing_get(h10x_ctx *h, int i, double *ms, uint64_t *launches) {
 int h10x_timing_reset(h10x_ctx *h) {
   if (!h) return -1;
   for (int i = 0; i < T_COUNT; ++i) { h->c.flush((TimerId)i); h->c.timers[i].ms = 0; h->c.timers[i].launches = 0; }
+  for (int i = 0; i < X_COUNT; ++i) { XchgStat &x = h->c.xs[i]; h->c.flush(x.t); h->c.flush(x.tIn); x.t.ms = x.tIn.ms = 0; x.t.launches = x.tIn.launches = 0; x.calls = x.bytesOut = x.bytesIn = x.maxPeerOut = 0; }
+  return 0;
+}
+int h10x_exchange_count(void) { return X_COUNT; }
+const char *h10x_exchange_name(int i) { return (i >= 0 && i < X_COUNT) ? kXchgNames[i] : ""; }
+int h10x_exchange_get(h10x_ctx *h, int i, uint64_t *calls, uint64_t *bytesOut, uint64_t *bytesIn, uint64_t *maxPeerOut, double *ms, double *msInStages) {
+  if (!h || i < 0 || i >= X_COUNT) return -1;
+  XchgStat &x = h->c.xs[i]; h->c.flush(x.t); h->c.flush(x.tIn);
+  if (msInStages) *msInStages = x.tIn.ms;
+  if (calls) *calls = x.calls;
+  if (bytesOut) *bytesOut = x.bytesOut;
+  if (bytesIn) *bytesIn = x.bytesIn;
+  if (maxPeerOut) *maxPeerOut = x.maxPeerOut;
+  if (ms) *ms = x.t.ms + x.tIn.ms;
   return 0;
 }
 int h10x_sort_fqb_device(h10x_ctx *h, const uint32_t *dIn, uint64_t n, uint32_t *dOut) {

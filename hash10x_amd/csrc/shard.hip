@@ -163,6 +163,26 @@ __global__ void scatter_value_kernel(const u32 *__restrict__ idx, const u64 *__r
   for (; i < n; i += stride) hashValue[idx[i]] = hash[i] * w;
 }
 
+// every collective of this file goes through these two: byte and time accounting per kind of exchange (common.hpp XchgStat)
+static int xchg_a2a(Ctx *c, Comm *cm, XchgId id, const void *dSend, const u64 *sendCnt, const u64 *sendOff, void *dRecv, const u64 *recvCnt, const u64 *recvOff, size_t eb) {
+  XchgStat &x = c->xs[id]; ++x.calls;
+  u64 peer = 0;
+  for (int p = 0; p < cm->n; ++p) if (p != cm->rank) { x.bytesOut += sendCnt[p] * eb; x.bytesIn += recvCnt[p] * eb; if (sendCnt[p] * eb > peer) peer = sendCnt[p] * eb; }
+  x.maxPeerOut += peer;
+  Timer &t = c->stageOpen > 0 ? x.tIn : x.t;
+  c->tstart(t);
+  const int rc = cm->alltoallv(c, dSend, sendCnt, sendOff, dRecv, recvCnt, recvOff, eb);
+  c->tstop(t);
+  return rc;
+}
+static int xchg_hostGather(Ctx *c, Comm *cm, const void *send, void *recv, size_t bytes) {
+  XchgStat &x = c->xs[X_HOST_COUNTS]; ++x.calls; x.bytesOut += (u64)bytes * (u64)(cm->n - 1); x.bytesIn += (u64)bytes * (u64)(cm->n - 1); x.maxPeerOut += bytes;
+  Timer &t = c->stageOpen > 0 ? x.tIn : x.t;
+  c->tstart(t);
+  const int rc = cm->allgatherHost(c, send, recv, bytes);
+  c->tstop(t);
+  return rc;
+}
 static int bitsForS(u64 v) { int b = 1; while (b < 64 && (v >> b)) ++b; return b; }
 static unsigned gridFor(u64 n) { return (unsigned)hmin<u64>(divUp(n ? n : 1, 256), 65535u * 2); }
 
@@ -174,7 +194,7 @@ int shard_readFqb(Ctx *c, Comm *cm, const u32 *dRec, u64 nRec) {
   // ---- 1. local mosh extraction. The file's last barcode is never hashed: that is the last barcode of the last
   //         shard that holds any record (with fewer barcodes than ranks the trailing shards are empty). A shard without
   //         records holds no barcode; if every shard is empty, rank 0 keeps the reference's empty block 1 (hash10x.c:200-201).
-  std::vector<u64> recsOf((size_t)N); { u64 mineRec = nRec; H10X_TRY(cm->allgatherHost(c, &mineRec, recsOf.data(), 8)); }
+  std::vector<u64> recsOf((size_t)N); { u64 mineRec = nRec; H10X_TRY(xchg_hostGather(c, cm, &mineRec, recsOf.data(), 8)); }
   bool laterRecords = false, anyRecords = false;
   for (int r = 0; r < N; ++r) { if (recsOf[r]) { anyRecords = true; if (r > me) laterRecords = true; } }
   if (c->optChunk > 0) {
@@ -183,12 +203,12 @@ int shard_readFqb(Ctx *c, Comm *cm, const u32 *dRec, u64 nRec) {
     std::vector<u64> st; std::vector<u32> zr;
     H10X_TRY(stageA_runStarts(c, dRec, nRec, st, zr));
     u64 mineN[2] = {(u64)st.size() - 1, (u64)zr.size()}; std::vector<u64> allN((size_t)2 * N);
-    H10X_TRY(cm->allgatherHost(c, mineN, allN.data(), 16));
+    H10X_TRY(xchg_hostGather(c, cm, mineN, allN.data(), 16));
     u64 maxRuns = 0, maxZero = 0; for (int r = 0; r < N; ++r) { maxRuns = hmax(maxRuns, allN[2 * r]); maxZero = hmax(maxZero, allN[2 * r + 1]); }
     std::vector<u64> pad((size_t)maxRuns + maxZero + 1, 0), allPad((size_t)N * (maxRuns + maxZero + 1));
     for (size_t i = 0; i + 1 < st.size(); ++i) pad[i] = st[i];
     for (size_t i = 0; i < zr.size(); ++i) pad[maxRuns + i] = zr[i];
-    H10X_TRY(cm->allgatherHost(c, pad.data(), allPad.data(), pad.size() * 8));
+    H10X_TRY(xchg_hostGather(c, cm, pad.data(), allPad.data(), pad.size() * 8));
     std::vector<u64> starts; std::vector<u32> zeroRuns; std::vector<u64> recBase((size_t)N + 1, 0);
     for (int r = 0; r < N; ++r) {
       const u64 *p = allPad.data() + (size_t)r * pad.size(); const u32 runBase = (u32)starts.size();
@@ -211,7 +231,7 @@ int shard_readFqb(Ctx *c, Comm *cm, const u32 *dRec, u64 nRec) {
   H10X_TRY(stageA_run(c, dRec, nRec, entHash, entCode, entRead, laterRecords, anyRecords || me != 0));
   const u64 H = c->nEntries;
   ShardInfo mine{(u64)c->nBlocks - 1, H, nRec}; std::vector<ShardInfo> all((size_t)N);
-  H10X_TRY(cm->allgatherHost(c, &mine, all.data(), sizeof mine));
+  H10X_TRY(xchg_hostGather(c, cm, &mine, all.data(), sizeof mine));
   u64 codeBase = 0, totalBarcodes = 0;
   for (int r = 0; r < N; ++r) { if (r < me) codeBase += all[r].barcodes; totalBarcodes += all[r].barcodes; }
   if (totalBarcodes + 1 >= (1ULL << 32)) return c->fail("too many barcodes for this build");
@@ -255,14 +275,14 @@ int shard_readFqb(Ctx *c, Comm *cm, const u32 *dRec, u64 nRec) {
   }
   std::vector<u64> sendCnt((size_t)N), sendOff((size_t)N), matrix((size_t)N * N), recvCnt((size_t)N), recvOff((size_t)N);
   for (int o = 0; o < N; ++o) { sendOff[o] = bound[o]; sendCnt[o] = bound[o + 1] - bound[o]; }
-  H10X_TRY(cm->allgatherHost(c, sendCnt.data(), matrix.data(), (size_t)N * 8));
+  H10X_TRY(xchg_hostGather(c, cm, sendCnt.data(), matrix.data(), (size_t)N * 8));
   u64 M = 0;
   for (int r = 0; r < N; ++r) { recvCnt[r] = matrix[(size_t)r * N + me]; recvOff[r] = M; M += recvCnt[r]; }
   if (M >= (1ULL << 32)) return c->fail("%llu entries land on hash owner %d: over this build's 2^32 limit", (u64)M, me);
   DevBuf<u64> rHash; DevBuf<u32> rCode;
   H10X_HIP(c, rHash.alloc(M)); if (!pk) H10X_HIP(c, rCode.alloc(M));
-  H10X_TRY(cm->alltoallv(c, sHash.p, sendCnt.data(), sendOff.data(), rHash.p, recvCnt.data(), recvOff.data(), 8));
-  if (!pk) H10X_TRY(cm->alltoallv(c, sCodeG.p, sendCnt.data(), sendOff.data(), rCode.p, recvCnt.data(), recvOff.data(), 4));
+  H10X_TRY(xchg_a2a(c, cm, X_ENTRIES, sHash.p, sendCnt.data(), sendOff.data(), rHash.p, recvCnt.data(), recvOff.data(), 8));
+  if (!pk) H10X_TRY(xchg_a2a(c, cm, X_ENTRIES, sCodeG.p, sendCnt.data(), sendOff.data(), rCode.p, recvCnt.data(), recvOff.data(), 4));
   sHash.release(); sCodeG.release();
 
   // ---- 3. owner side: received runs are in rank (= barcode) order, a stable sort by hash keeps barcodes ascending
@@ -299,7 +319,7 @@ int shard_readFqb(Ctx *c, Comm *cm, const u32 *dRec, u64 nRec) {
   first_runs_kernel<<<divUp(nB, 256), 256, 0, st>>>(dFirstSorted.p, Uo, nB, myStart.p, cntFirst.p);
   { std::vector<u64> sc((size_t)N, nB), so((size_t)N, 0), rc((size_t)N, nB), ro((size_t)N);
     for (int r = 0; r < N; ++r) ro[r] = (u64)r * nB;
-    H10X_TRY(cm->alltoallv(c, cntFirst.p, sc.data(), so.data(), allFirst.p, rc.data(), ro.data(), 4)); }   // allgather
+    H10X_TRY(xchg_a2a(c, cm, X_FIRST_COUNTS, cntFirst.p, sc.data(), so.data(), allFirst.p, rc.data(), ro.data(), 4)); }   // allgather
   first_totals_kernel<<<divUp(nB, 256), 256, 0, st>>>(allFirst.p, N, me, nB, total.p, before.p);
   H10X_HIP(c, hipMemsetAsync(total.p + nB, 0, 4, st));
   H10X_TRY(prim_exclusive_scan_u32(c, pt, total.p, base.p, (size_t)nB + 1));
@@ -313,7 +333,7 @@ int shard_readFqb(Ctx *c, Comm *cm, const u32 *dRec, u64 nRec) {
   // ---- 5. the index of every entry goes back to the rank that sent it, in the order it was sent
   DevBuf<u32> reply, rIdx; H10X_HIP(c, reply.alloc(M)); H10X_HIP(c, rIdx.alloc(H));
   if (M) reply_kernel<<<gridFor(M), 256, 0, st>>>(ord.p, flags.p, oQ.p, M, c->oIndex.p, reply.p);
-  H10X_TRY(cm->alltoallv(c, reply.p, recvCnt.data(), recvOff.data(), rIdx.p, sendCnt.data(), sendOff.data(), 4));
+  H10X_TRY(xchg_a2a(c, cm, X_INDEX_BACK, reply.p, recvCnt.data(), recvOff.data(), rIdx.p, sendCnt.data(), sendOff.data(), 4));
   c->hashNumber = U + 1; c->depthBound = nB;
   c->tstop(T_RANK);
   c->tstart(T_CLUSHASH);
@@ -327,15 +347,15 @@ int shard_readFqb(Ctx *c, Comm *cm, const u32 *dRec, u64 nRec) {
   //         not on every rank after every --readFQB (at N = 8: 24 M hash values allgathered and inserted into a 512 MB
   //         table per rank, for nothing on the clustering path)
   c->tstart(T_PROBE);
-  std::vector<u64> uo((size_t)N); { u64 u = Uo; H10X_TRY(cm->allgatherHost(c, &u, uo.data(), 8)); }
+  std::vector<u64> uo((size_t)N); { u64 u = Uo; H10X_TRY(xchg_hostGather(c, cm, &u, uo.data(), 8)); }
   std::vector<u64> sc((size_t)N, Uo), so((size_t)N, 0), rc((size_t)N), ro((size_t)N); u64 Utot = 0;
   for (int r = 0; r < N; ++r) { rc[r] = uo[r]; ro[r] = Utot; Utot += uo[r]; }
   if (Utot != U) return c->fail("sharded index: %llu distinct hashes gathered, %u numbered", (u64)Utot, U);
   DevBuf<u32> dDepth, gIdx, gDepth;
   H10X_HIP(c, dDepth.alloc(Uo)); H10X_HIP(c, gIdx.alloc(U)); H10X_HIP(c, gDepth.alloc(U));
   if (Uo) depth_of_kernel<<<divUp(Uo, 256), 256, 0, st>>>(c->oSegStart.p, Uo, dDepth.p);
-  H10X_TRY(cm->alltoallv(c, c->oIndex.p, sc.data(), so.data(), gIdx.p, rc.data(), ro.data(), 4));
-  H10X_TRY(cm->alltoallv(c, dDepth.p, sc.data(), so.data(), gDepth.p, rc.data(), ro.data(), 4));
+  H10X_TRY(xchg_a2a(c, cm, X_INDEX_DEPTH, c->oIndex.p, sc.data(), so.data(), gIdx.p, rc.data(), ro.data(), 4));
+  H10X_TRY(xchg_a2a(c, cm, X_INDEX_DEPTH, dDepth.p, sc.data(), so.data(), gDepth.p, rc.data(), ro.data(), 4));
   H10X_HIP(c, c->hashDepth.alloc((size_t)U + 1));
   H10X_HIP(c, hipMemsetAsync(c->hashDepth.p, 0, 4, st));
   if (U) scatter_depth_kernel<<<gridFor(U), 256, 0, st>>>(gIdx.p, gDepth.p, U, c->hashDepth.p);
@@ -372,7 +392,7 @@ int shard_refreshLayout(Ctx *c) {
   H10X_TRY(c->syncReadbacks());
   for (int k = 0; k < c->segs.n; ++k) m.entries[k] = ends[2 * k + 1] - ends[2 * k];
   std::vector<LayoutMsg> all((size_t)N);
-  H10X_TRY(cm->allgatherHost(c, &m, all.data(), sizeof m));
+  H10X_TRY(xchg_hostGather(c, cm, &m, all.data(), sizeof m));
   c->allSegs.clear();
   u64 blocks = 1, entries = 0, records = 0;
   for (int r = 0; r < N; ++r) {
@@ -396,13 +416,13 @@ int shard_materializeTables(Ctx *c) {
   if (!c->tablesPending) return 0;
   hipStream_t st = c->stream; Comm *cm = c->comm;
   const int N = cm->n; const u32 Uo = c->oU, U = c->hashNumber - 1;
-  std::vector<u64> uo((size_t)N); { u64 u = Uo; H10X_TRY(cm->allgatherHost(c, &u, uo.data(), 8)); }
+  std::vector<u64> uo((size_t)N); { u64 u = Uo; H10X_TRY(xchg_hostGather(c, cm, &u, uo.data(), 8)); }
   std::vector<u64> sc((size_t)N, Uo), so((size_t)N, 0), rc((size_t)N), ro((size_t)N); u64 Utot = 0;
   for (int r = 0; r < N; ++r) { rc[r] = uo[r]; ro[r] = Utot; Utot += uo[r]; }
   DevBuf<u32> gIdx; DevBuf<u64> gHash;
   H10X_HIP(c, gIdx.alloc(U)); H10X_HIP(c, gHash.alloc(U));
-  H10X_TRY(cm->alltoallv(c, c->oIndex.p, sc.data(), so.data(), gIdx.p, rc.data(), ro.data(), 4));
-  H10X_TRY(cm->alltoallv(c, c->oHash.p, sc.data(), so.data(), gHash.p, rc.data(), ro.data(), 8));
+  H10X_TRY(xchg_a2a(c, cm, X_TABLES, c->oIndex.p, sc.data(), so.data(), gIdx.p, rc.data(), ro.data(), 4));
+  H10X_TRY(xchg_a2a(c, cm, X_TABLES, c->oHash.p, sc.data(), so.data(), gHash.p, rc.data(), ro.data(), 8));
   H10X_HIP(c, c->hashValue.alloc((size_t)U + 1));
   H10X_HIP(c, hipMemsetAsync(c->hashValue.p, 0, 8, st));
   if (U) scatter_value_kernel<<<gridFor(U), 256, 0, st>>>(gIdx.p, gHash.p, U, (u64)c->prm.w, c->hashValue.p);
@@ -527,7 +547,7 @@ int shard_exchangeRows(Ctx *c) {
   H10X_TRY(c->syncReadbacks());
   // the list alignment: the smallest shift that keeps every offset, in 2^shift-entry units, below 2^32 — the same on every rank
   u64 mine[2] = {nGoodMine, rawMine}; std::vector<u64> all((size_t)2 * N);
-  H10X_TRY(cm->allgatherHost(c, mine, all.data(), 16));
+  H10X_TRY(xchg_hostGather(c, cm, mine, all.data(), 16));
   u64 totG = 0, totRaw = 0; for (int r = 0; r < N; ++r) { totG += all[2 * r]; totRaw += all[2 * r + 1]; }
   const u64 fake = c->optRowsFakeBase > 0 ? (u64)c->optRowsFakeBase : 0;
   int shift = c->optRowShift >= 0 ? (int)c->optRowShift : 0;
@@ -540,7 +560,7 @@ int shard_exchangeRows(Ctx *c) {
     H10X_TRY(prim_exclusive_scan_u32_u64(c, pt, len.p, off.p, (size_t)Uo + 1));
     H10X_TRY(c->readback(&mine[1], off.p + Uo, 8));
     H10X_TRY(c->syncReadbacks());
-    H10X_TRY(cm->allgatherHost(c, mine, all.data(), 16));
+    H10X_TRY(xchg_hostGather(c, cm, mine, all.data(), 16));
   }
   const bool delta = c->optDeltaLists > 0 || (c->optDeltaLists < 0 && N > 1);
   const u32 nGoodU = (u32)mine[0];
@@ -551,8 +571,8 @@ int shard_exchangeRows(Ctx *c) {
   std::vector<u64> sc((size_t)N), so((size_t)N, 0), rc((size_t)N), ro((size_t)N); u64 nG = 0, nR = 0;
   for (int r = 0; r < N; ++r) { sc[r] = mine[0]; rc[r] = all[2 * r]; ro[r] = nG; nG += rc[r]; }
   DevBuf<u32> aIdx, aLen; H10X_HIP(c, aIdx.alloc(nG)); H10X_HIP(c, aLen.alloc(nG + 1));
-  H10X_TRY(cm->alltoallv(c, gIdx.p, sc.data(), so.data(), aIdx.p, rc.data(), ro.data(), 4));
-  H10X_TRY(cm->alltoallv(c, gLen.p, sc.data(), so.data(), aLen.p, rc.data(), ro.data(), 4));
+  H10X_TRY(xchg_a2a(c, cm, X_LIST_HEADS, gIdx.p, sc.data(), so.data(), aIdx.p, rc.data(), ro.data(), 4));
+  H10X_TRY(xchg_a2a(c, cm, X_LIST_HEADS, gLen.p, sc.data(), so.data(), aLen.p, rc.data(), ro.data(), 4));
   for (int r = 0; r < N; ++r) { rc[r] = all[2 * r + 1]; nR += rc[r]; }
   H10X_HIP(c, c->rows.alloc(nR + ROWS_PAD));
   DevBuf<u64> aOff; H10X_HIP(c, aOff.alloc(nG + 1));
@@ -560,7 +580,7 @@ int shard_exchangeRows(Ctx *c) {
   H10X_TRY(prim_exclusive_scan_u32_u64(c, pt, aLen.p, aOff.p, nG + 1));
   if (!delta) {
     nR = 0; for (int r = 0; r < N; ++r) { sc[r] = mine[1]; ro[r] = nR; nR += rc[r]; }
-    H10X_TRY(cm->alltoallv(c, gRows.p, sc.data(), so.data(), c->rows.p, rc.data(), ro.data(), 4));
+    H10X_TRY(xchg_a2a(c, cm, X_LIST_DATA, gRows.p, sc.data(), so.data(), c->rows.p, rc.data(), ro.data(), 4));
   } else {
     // coded lengths, coded stream, the same allgather-shaped exchange, decode into the padded layout (see delta_len_kernel)
     DevBuf<u32> encLen, gEnc, enc, aEnc, encAll, aWords; DevBuf<u64> encOff, eOff;
@@ -568,15 +588,15 @@ int shard_exchangeRows(Ctx *c) {
     delta_len_kernel<<<hmin<u32>(nGoodU + 1, 65535u * 2), WAVE, 0, st>>>(c->oSegStart.p, c->oRows.p, goodId.p, nGoodU, encLen.p, gEnc.p);
     H10X_TRY(prim_exclusive_scan_u32_u64(c, pt, encLen.p, encOff.p, (size_t)nGoodU + 1));
     u64 encMine = 0; H10X_TRY(c->readback(&encMine, encOff.p + nGoodU, 8)); H10X_TRY(c->syncReadbacks());
-    std::vector<u64> encTot((size_t)N); H10X_TRY(cm->allgatherHost(c, &encMine, encTot.data(), 8));
+    std::vector<u64> encTot((size_t)N); H10X_TRY(xchg_hostGather(c, cm, &encMine, encTot.data(), 8));
     H10X_HIP(c, enc.alloc(encMine));
     if (nGoodU) delta_pack_kernel<<<hmin<u32>(nGoodU, 65535u * 2), WAVE, 0, st>>>(c->oSegStart.p, c->oRows.p, goodId.p, nGoodU, encOff.p, gEnc.p, enc.p);
     H10X_HIP(c, aEnc.alloc(nG + 1));
     { u64 o = 0; for (int r = 0; r < N; ++r) { sc[r] = mine[0]; rc[r] = all[2 * r]; ro[r] = o; o += rc[r]; } }
-    H10X_TRY(cm->alltoallv(c, gEnc.p, sc.data(), so.data(), aEnc.p, rc.data(), ro.data(), 4));
+    H10X_TRY(xchg_a2a(c, cm, X_LIST_HEADS, gEnc.p, sc.data(), so.data(), aEnc.p, rc.data(), ro.data(), 4));
     u64 nE = 0; for (int r = 0; r < N; ++r) { sc[r] = encMine; rc[r] = encTot[r]; ro[r] = nE; nE += rc[r]; }
     H10X_HIP(c, encAll.alloc(nE));
-    H10X_TRY(cm->alltoallv(c, enc.p, sc.data(), so.data(), encAll.p, rc.data(), ro.data(), 4));
+    H10X_TRY(xchg_a2a(c, cm, X_LIST_DATA, enc.p, sc.data(), so.data(), encAll.p, rc.data(), ro.data(), 4));
     H10X_HIP(c, eOff.alloc(nG + 1));
     H10X_HIP(c, hipMemsetAsync(aEnc.p + nG, 0, 4, st));
     H10X_HIP(c, aWords.alloc(nG + 1));
@@ -652,14 +672,14 @@ int shard_rebuildOwnerLists(Ctx *c) {
   if (N > PART_MAX_OWNERS) return c->fail("clusterSplit on %d ranks: at most %d are supported", N, PART_MAX_OWNERS);
   c->tstart(T_CSR);
   // who owns which index: allgather of every owner's indices
-  std::vector<u64> uo((size_t)N); { u64 u = Uo; H10X_TRY(cm->allgatherHost(c, &u, uo.data(), 8)); }
+  std::vector<u64> uo((size_t)N); { u64 u = Uo; H10X_TRY(xchg_hostGather(c, cm, &u, uo.data(), 8)); }
   std::vector<u64> sc((size_t)N, Uo), so((size_t)N, 0), rc((size_t)N), ro((size_t)N), bound((size_t)N + 1); u64 Utot = 0;
   for (int r = 0; r < N; ++r) { rc[r] = uo[r]; ro[r] = Utot; bound[r] = Utot; Utot += uo[r]; }
   bound[N] = Utot;
   if (Utot != U) return c->fail("sharded index: %llu distinct hashes gathered, %u numbered", (u64)Utot, U);
   DevBuf<u32> gIdx; DevBuf<u64> dBound; DevBuf<u16> idxOwner; DevBuf<u32> ordOf;
   H10X_HIP(c, gIdx.alloc(U)); H10X_HIP(c, dBound.alloc((size_t)N + 1)); H10X_HIP(c, idxOwner.alloc((size_t)U + 1)); H10X_HIP(c, ordOf.alloc((size_t)U + 1));
-  H10X_TRY(cm->alltoallv(c, c->oIndex.p, sc.data(), so.data(), gIdx.p, rc.data(), ro.data(), 4));
+  H10X_TRY(xchg_a2a(c, cm, X_OWNER_LISTS, c->oIndex.p, sc.data(), so.data(), gIdx.p, rc.data(), ro.data(), 4));
   H10X_HIP(c, hipMemcpyAsync(dBound.p, bound.data(), ((size_t)N + 1) * 8, hipMemcpyHostToDevice, st));
   H10X_HIP(c, hipMemsetAsync(idxOwner.p, 0, ((size_t)U + 1) * 2, st));
   if (U) owner_of_index_kernel<<<gridFor(U), 256, 0, st>>>(gIdx.p, dBound.p, N, U, idxOwner.p);
@@ -678,13 +698,13 @@ int shard_rebuildOwnerLists(Ctx *c) {
   H10X_HIP(c, hipMemcpyAsync(cursor.p, sendOff.data(), (size_t)N * 8, hipMemcpyHostToDevice, st));
   DevBuf<u64> sPair; H10X_HIP(c, sPair.alloc(H));
   if (H) entry_owner_kernel<1><<<grid, 256, 0, st>>>(c->clusHash.p, c->blockOff.p, nBl, c->segs, idxOwner.p, N, cursor.p, sPair.p);
-  H10X_TRY(cm->allgatherHost(c, sendCnt.data(), matrix.data(), (size_t)N * 8));
+  H10X_TRY(xchg_hostGather(c, cm, sendCnt.data(), matrix.data(), (size_t)N * 8));
   u64 M = 0; bool bad = false;
   for (int r = 0; r < N; ++r) { recvCnt[r] = matrix[(size_t)r * N + me]; recvOff[r] = M; M += recvCnt[r]; }
   for (int o = 0; o < N; ++o) { u64 m = 0; for (int r = 0; r < N; ++r) m += matrix[(size_t)r * N + o]; if (m >= (1ULL << 32)) bad = true; }   // the same verdict on every rank
   if (bad) return c->fail("more than 2^32 entries land on one hash owner: over this build's per-GPU limit");
   DevBuf<u64> rPair, rSorted; H10X_HIP(c, rPair.alloc(M)); H10X_HIP(c, rSorted.alloc(M));
-  H10X_TRY(cm->alltoallv(c, sPair.p, sendCnt.data(), sendOff.data(), rPair.p, recvCnt.data(), recvOff.data(), 8));
+  H10X_TRY(xchg_a2a(c, cm, X_OWNER_LISTS, sPair.p, sendCnt.data(), sendOff.data(), rPair.p, recvCnt.data(), recvOff.data(), 8));
   sPair.release();
   if (M != c->oM) return c->fail("owner lists: %llu entries arrived for %llu list slots", (u64)M, (u64)c->oM);
   if (M) owner_key_of_kernel<<<gridFor(M), 256, 0, st>>>(rPair.p, M, ordOf.p);
@@ -715,7 +735,7 @@ int shard_split(Ctx *c, const u32 *dSubBefore, u32 totalSubLocal) {
   H10X_TRY(c->syncReadbacks());
   for (int k = 0; k < c->segs.n; ++k) { m.globalBase[k] = c->segs.s[k].globalBase; m.children[k] = edge[2 * k + 1] - edge[2 * k]; }
   std::vector<SplitMsg> all((size_t)N);
-  H10X_TRY(cm->allgatherHost(c, &m, all.data(), sizeof m));
+  H10X_TRY(xchg_hostGather(c, cm, &m, all.data(), sizeof m));
   struct Par { u32 base, children; int rank, k; };
   std::vector<Par> pars; u64 added = 0; bool tooMany = false;
   for (int r = 0; r < N; ++r) {
@@ -766,7 +786,7 @@ int shard_adoptLoadedState(Ctx *c, Comm *cm, u32 codeBase, u32 nBlocksGlobal) {
   u64 M = 0;
   H10X_TRY(c->readback(&M, off.p + Uo, 8));
   H10X_TRY(c->syncReadbacks());
-  u64 worst = M; { std::vector<u64> all((size_t)N); H10X_TRY(cm->allgatherHost(c, &M, all.data(), 8)); for (u64 x : all) worst = x > worst ? x : worst; }
+  u64 worst = M; { std::vector<u64> all((size_t)N); H10X_TRY(xchg_hostGather(c, cm, &M, all.data(), 8)); for (u64 x : all) worst = x > worst ? x : worst; }
   if (worst >= (1ULL << 32)) return c->fail("more than 2^32 entries land on one hash owner: over this build's per-GPU limit");   // the same verdict on every rank
   add_base_kernel<<<divUp((u64)Uo + 1, 256), 256, 0, st>>>(off.p, Uo + 1, c->oSegStart.p);
   c->oU = Uo; c->oM = M;
@@ -821,8 +841,8 @@ int shard_gather(Ctx *c) {
       u64 e0 = 0; H10X_HIP(c, hipMemcpyAsync(&e0, c->blockOff.p + g.localStart, 8, hipMemcpyDeviceToHost, st)); H10X_HIP(c, hipStreamSynchronize(st));
       sc[0] = g.count; so[0] = g.localStart; sc2[0] = g.entries; so2[0] = e0;
     }
-    H10X_TRY(cm->alltoallv(c, c->blocks.p, sc.data(), so.data(), gBlocks.p, rc.data(), ro.data(), sizeof(h10x_block)));
-    H10X_TRY(cm->alltoallv(c, c->clusHash.p, sc2.data(), so2.data(), gClus.p, rc2.data(), ro2.data(), sizeof(h10x_clushash)));
+    H10X_TRY(xchg_a2a(c, cm, X_GATHER, c->blocks.p, sc.data(), so.data(), gBlocks.p, rc.data(), ro.data(), sizeof(h10x_block)));
+    H10X_TRY(xchg_a2a(c, cm, X_GATHER, c->clusHash.p, sc2.data(), so2.data(), gClus.p, rc2.data(), ro2.data(), sizeof(h10x_clushash)));
   }
   if (me == 0) {
     c->blocks.swap(gBlocks); c->clusHash.swap(gClus);

@@ -188,6 +188,13 @@ int  h10x_device_enable_peers(const int *devices, int n);
 /* one process per rank like RCCL, but host-staged over TCP (rank r listens on basePort + r at addr): for exercising the
    multi-process launch path where RCCL cannot run — several ranks sharing one GPU on a test box. Not a production path. */
 int  h10x_comm_create_socket(h10x_comm **comm, int rank, int nranks, const char *addr, int basePort, char *err, int errlen);
+/* "Virtual ranks": the ranks of an in-process communicator share one device and take turns on it. With serialize on, a rank's thread computes only between
+   h10x_comm_turn_begin and h10x_comm_turn_end (its caller brackets every command with them) and hands the device on inside every collective while it waits for the
+   others — so its stage timers read as if it had the GPU to itself, and its exchange timers (h10x_exchange_get) hold all the waiting. A measuring device for
+   `bench.py --virtual-ranks N` on one-GPU boxes; the results are those of any other N-rank run. -1 on a communicator that is not in-process. */
+int  h10x_comm_local_serialize(h10x_comm *comm, int on);
+int  h10x_comm_turn_begin(h10x_comm *comm);
+int  h10x_comm_turn_end(h10x_comm *comm, int device);
 void h10x_comm_destroy(h10x_comm *comm);
 int  h10x_comm_rank(const h10x_comm *comm);
 int  h10x_comm_size(const h10x_comm *comm);
@@ -301,6 +308,13 @@ int  h10x_timing_count(const h10x_ctx *ctx);
 const char *h10x_timing_name(const h10x_ctx *ctx, int i);
 int  h10x_timing_get(h10x_ctx *ctx, int i, double *total_ms, uint64_t *launches);
 int  h10x_timing_reset(h10x_ctx *ctx);
+/* The exchanges of a sharded context, per kind of collective (names: h10x_exchange_name(i), i < h10x_exchange_count()): calls; bytes this rank sent to and received
+   from OTHER ranks; maxPeerOut = the sum over the calls of the largest share one peer received (grouped point-to-point sends: what one xGMI link carried); ms = from
+   each call to its completion on the context's stream, waits for slower ranks included (collected while timing is enabled; a rank's compute is its stage timers less
+   these). Cleared by h10x_timing_reset. What `bench.py --scaling strong` and `--virtual-ranks` print so that a scaling curve can be read. */
+int  h10x_exchange_count(void);
+const char *h10x_exchange_name(int i);
+int  h10x_exchange_get(h10x_ctx *ctx, int i, uint64_t *calls, uint64_t *bytesOut, uint64_t *bytesIn, uint64_t *maxPeerOut, double *ms, double *msInStages);
 /* algorithmic work counters of the last commands: see DESIGN.md */
 typedef struct {
   uint64_t pairs;            /* read pairs hashed                                   */

@@ -1302,3 +1302,55 @@ def test_genome3g_full_size_matches_reference_digest(tmp_path_factory):
         h.close()
         assert size == case["size"]
     assert digest == case["sha256"]
+
+
+def test_virtual_ranks_model_and_exchange_accounting(workdir):
+    """bench.virtual_ranks_block on a small generator-v2 set: 4 ranks as threads taking turns on this GPU (h10x_comm_local_serialize). Every kind of exchange of the
+    sharded --readFQB / --hashDepthRange reports bytes (h10x_exchange_get), the per-peer share never exceeds a rank's total, the ranks' compute sums to no less than
+    the single-GPU step's device time would allow (nothing is lost in the subtraction of the waits), and the model's figures are there. The sharded RESULTS under the
+    turnstile equal the unsharded ones (checksum of all blocks and records)."""
+    import sys
+    sys.path.insert(0, orc.REPO)
+    import bench
+    import hash10x_amd
+    name = "vr-test"
+    bench.WORKLOADS[name] = dict(pairs=400000, barcodes=2000, genome=4000000, err=0.001, mol=10.0, snp=150, mol_len=50000.0, B=22, lo=4, hi=40, ct=3, seed=5, gen=2)
+    try:
+        blk = bench.virtual_ranks_block(hash10x_amd, name, 4)
+    finally:
+        wl = bench.WORKLOADS.pop(name)
+    assert "error" not in blk, blk
+    assert blk["ranks"] == 4 and len(blk["per_rank"]) == 4 and sum(r["read_pairs"] for r in blk["per_rank"]) == wl["pairs"]
+    for kind in ("entries_to_hash_owners (all-to-all)", "indices_back (all-to-all)", "index_depth (allgather)", "list_data (allgather: the in-range barcode lists)"):
+        e = blk["exchanges"][kind]
+        assert e["sum_bytes_out"] > 0 and 0 < e["busiest_peer_share_bytes"] <= e["max_rank_bytes_out"] <= e["sum_bytes_out"], (kind, e)
+    assert all(r["compute_ms"] > 0 for r in blk["per_rank"]) and blk["max_rank_compute_ms"] >= blk["mean_rank_compute_ms"] > 0
+    assert blk["modelled_step_ms"] >= blk["max_rank_compute_ms"] and blk["modelled_speedup_vs_1_gpu"] > 0
+    # the same 4 ranks without the turnstile, against the unsharded state
+    recs, _f, _t = bench.generate_v2(wl, wl["seed"])
+    h = hash10x_amd.Hash10x(B=wl["B"]); h.read_fqb(recs); h.depth_range(wl["lo"], wl["hi"]); h.cluster(1, 0, wl["ct"])
+    z = h.sizes()
+    exp = bench.checksum_state(h.export_slice(3, 1, z["nBlocks"] - 1), 1, h.export_slice(4, 0, z["nClusHash"]), 0)
+    h.close()
+    import threading
+    comms = hash10x_amd.Comm.local(4); comms[0].serialize(True)
+    got, errs = [None] * 4, []
+
+    def work(r):
+        try:
+            rr, _first, _tot = bench.generate_v2(wl, wl["seed"], r, 4)
+            hh = hash10x_amd.Hash10x(B=wl["B"])
+            d = hash10x_amd.DeviceRecords(rr)
+            comms[r].turn_begin()
+            try:
+                hh.shard_read_fqb_device(comms[r], d.ptr, rr.size // 30); hh.depth_range(wl["lo"], wl["hi"]); hh.cluster(1, 0, wl["ct"])
+                got[r] = bench.sharded_state_checksum(hh, r)
+            finally:
+                comms[r].turn_end(0)
+            hh.close(); d.free()
+        except Exception as e:
+            errs.append(str(e))
+    th = [threading.Thread(target=work, args=(r,)) for r in range(4)]
+    [t.start() for t in th]; [t.join() for t in th]
+    assert not errs, errs
+    assert got[0] == exp and all(g == got[0] for g in got)
