@@ -654,7 +654,9 @@ def rank_figures(h):
     ex = h.exchanges()
     stages = sum(tm.get(k, 0.0) for k in STAGE_TIMERS)
     waits = sum(e["ms_in_stages"] for e in ex.values())
-    return {"stage_ms": {k: round(v, 3) for k, v in tm.items()}, "exchanges": ex, "compute_ms": stages - waits}
+    sw = h.stage_waits()
+    return {"stage_ms": {k: round(v, 3) for k, v in tm.items()}, "stage_compute_ms": {k: round(tm[k] - sw.get(k, 0.0), 3) for k in STAGE_TIMERS if k in tm},
+            "exchanges": ex, "compute_ms": stages - waits}
 
 
 def scaling_model(per_rank, single_ms):
@@ -734,7 +736,8 @@ def virtual_ranks_block(hash10x_amd, name, n, local_rank=0, steps=1):
     out = scaling_model(res, sum(single) / len(single))
     out["workload"] = name
     out["single_gpu_stage_ms"] = single_stage
-    out["per_rank"] = [{"read_pairs": r["read_pairs"], "compute_ms": round(r["compute_ms"], 3), "stage_ms": r["stage_ms"],
+    out["max_rank_stage_compute_ms"] = {k: max(r["stage_compute_ms"].get(k, 0.0) for r in res) for k in STAGE_TIMERS if any(k in r["stage_compute_ms"] for r in res)}
+    out["per_rank"] = [{"read_pairs": r["read_pairs"], "compute_ms": round(r["compute_ms"], 3), "stage_compute_ms": r["stage_compute_ms"],
                         "exchange_wait_ms": round(sum(e["ms"] for e in r["exchanges"].values()), 3)} for r in res]
     return out
 

@@ -137,6 +137,7 @@ def load_native():
     hip.h10x_timing_get.argtypes = [vp, ci, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(cu64)]
     hip.h10x_timing_reset.argtypes = [vp]
     hip.h10x_exchange_name.restype = cs; hip.h10x_exchange_name.argtypes = [ci]
+    hip.h10x_timing_wait_get.argtypes = [vp, ci, ctypes.POINTER(ctypes.c_double)]
     hip.h10x_exchange_get.argtypes = [vp, ci, ctypes.POINTER(cu64), ctypes.POINTER(cu64), ctypes.POINTER(cu64), ctypes.POINTER(cu64), ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]
     hip.h10x_comm_local_serialize.argtypes = [vp, ci]
     hip.h10x_comm_turn_begin.argtypes = [vp]
@@ -540,6 +541,16 @@ class Hash10x:
             ms, n = ctypes.c_double(), ctypes.c_uint64()
             self._hip.h10x_timing_get(ctx, i, ctypes.byref(ms), ctypes.byref(n))
             out[self._hip.h10x_timing_name(ctx, i).decode()] = (ms.value, n.value)
+        return out
+
+    def stage_waits(self):
+        """per stage timer: the ms of it spent inside exchanges (sharded contexts)"""
+        out = {}
+        for i in range(self._hip.h10x_timing_count(self._ctx())):
+            ms = ctypes.c_double(0)
+            self._hip.h10x_timing_wait_get(self._ctx(), i, ctypes.byref(ms))
+            if ms.value:
+                out[self._hip.h10x_timing_name(self._ctx(), i).decode()] = ms.value
         return out
 
     def exchanges(self):

@@ -309,8 +309,10 @@ struct Ctx {
     if (x.pending) { float ms = 0; (void)hipEventSynchronize(x.b); (void)hipEventElapsedTime(&ms, x.a, x.b); x.ms += ms; x.pending = false; }
   }
   int stageOpen = 0;          // stage timers open right now (the exchange wrappers of shard.hip ask)
-  void tstart(TimerId t) { ++stageOpen; tstart(timers[t]); }
-  void tstop(TimerId t) { if (stageOpen > 0) --stageOpen; tstop(timers[t]); }
+  TimerId stageTop = T_COUNT; // the innermost of them
+  Timer stageWait[T_COUNT];   // per stage: the exchange waits inside its bracket (a stage's compute = its timer less this)
+  void tstart(TimerId t) { ++stageOpen; stageTop = t; tstart(timers[t]); }
+  void tstop(TimerId t) { if (stageOpen > 0) --stageOpen; if (!stageOpen) stageTop = T_COUNT; tstop(timers[t]); }
   void flush(TimerId t) { flush(timers[t]); }
 };
 

@@ -510,8 +510,14 @@ int h10x_timing_get(h10x_ctx *h, int i, double *ms, uint64_t *launches) {
 }
 int h10x_timing_reset(h10x_ctx *h) {
   if (!h) return -1;
-  for (int i = 0; i < T_COUNT; ++i) { h->c.flush((TimerId)i); h->c.timers[i].ms = 0; h->c.timers[i].launches = 0; }
+  for (int i = 0; i < T_COUNT; ++i) { h->c.flush((TimerId)i); h->c.timers[i].ms = 0; h->c.timers[i].launches = 0; h->c.flush(h->c.stageWait[i]); h->c.stageWait[i].ms = 0; h->c.stageWait[i].launches = 0; }
   for (int i = 0; i < X_COUNT; ++i) { XchgStat &x = h->c.xs[i]; h->c.flush(x.t); h->c.flush(x.tIn); x.t.ms = x.tIn.ms = 0; x.t.launches = x.tIn.launches = 0; x.calls = x.bytesOut = x.bytesIn = x.maxPeerOut = 0; }
+  return 0;
+}
+int h10x_timing_wait_get(h10x_ctx *h, int i, double *ms) {
+  if (!h || i < 0 || i >= T_COUNT) return -1;
+  h->c.flush(h->c.stageWait[i]);
+  if (ms) *ms = h->c.stageWait[i].ms;
   return 0;
 }
 int h10x_exchange_count(void) { return X_COUNT; }

@@ -170,17 +170,23 @@ static int xchg_a2a(Ctx *c, Comm *cm, XchgId id, const void *dSend, const u64 *s
   for (int p = 0; p < cm->n; ++p) if (p != cm->rank) { x.bytesOut += sendCnt[p] * eb; x.bytesIn += recvCnt[p] * eb; if (sendCnt[p] * eb > peer) peer = sendCnt[p] * eb; }
   x.maxPeerOut += peer;
   Timer &t = c->stageOpen > 0 ? x.tIn : x.t;
+  Timer *const ts = c->stageTop < T_COUNT ? &c->stageWait[c->stageTop] : nullptr;
+  if (ts) c->tstart(*ts);
   c->tstart(t);
   const int rc = cm->alltoallv(c, dSend, sendCnt, sendOff, dRecv, recvCnt, recvOff, eb);
   c->tstop(t);
+  if (ts) c->tstop(*ts);
   return rc;
 }
 static int xchg_hostGather(Ctx *c, Comm *cm, const void *send, void *recv, size_t bytes) {
   XchgStat &x = c->xs[X_HOST_COUNTS]; ++x.calls; x.bytesOut += (u64)bytes * (u64)(cm->n - 1); x.bytesIn += (u64)bytes * (u64)(cm->n - 1); x.maxPeerOut += bytes;
   Timer &t = c->stageOpen > 0 ? x.tIn : x.t;
+  Timer *const ts = c->stageTop < T_COUNT ? &c->stageWait[c->stageTop] : nullptr;
+  if (ts) c->tstart(*ts);
   c->tstart(t);
   const int rc = cm->allgatherHost(c, send, recv, bytes);
   c->tstop(t);
+  if (ts) c->tstop(*ts);
   return rc;
 }
 static int bitsForS(u64 v) { int b = 1; while (b < 64 && (v >> b)) ++b; return b; }

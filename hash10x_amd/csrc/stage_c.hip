@@ -2043,6 +2043,11 @@ __global__ void cluster_classify_kernel(const h10x_block *__restrict__ blocks, c
   if (cls == 0 && n > bigRanks) cls = 1;
   for (int s = 32; s; s >>= 1) nRead = max(nRead, (u32)__shfl_xor((int)nRead, s));
   if (lane == 0 && nRead) atomicMax(&counts[8], nRead);
+  {                                                          // most ranks of a block per LDS class: the translated placement sizes its handle slots by them
+    u32 n0 = (cls == 0 || cls == 1) ? n : 0u, n2 = cls == 2 ? n : 0u;
+    for (int s = 32; s; s >>= 1) { n0 = max(n0, (u32)__shfl_xor((int)n0, s)); n2 = max(n2, (u32)__shfl_xor((int)n2, s)); }
+    if (lane == 0) { if (n0) atomicMax(&counts[12], n0); if (n2) atomicMax(&counts[13], n2); }
+  }
   if (work) {                                            // work of the half-CU classes and of the whole-CU class (list entries + a charge per rank): the launches split the CUs by it
     unsigned long long w0 = (cls == 0 || cls == 1) ? (unsigned long long)entries[c] + 64ull * n : 0ull, w2 = cls == 2 ? (unsigned long long)entries[c] + 64ull * n : 0ull;
     for (int s = 32; s; s >>= 1) { w0 += __shfl_xor(w0, s); w2 += __shfl_xor(w2, s); }
@@ -2079,9 +2084,9 @@ static int cluster_local_range(Ctx *c, int codeMin, int codeMax, int threshold, 
   H10X_HIP(c, list0.alloc(span)); H10X_HIP(c, list1.alloc(span)); H10X_HIP(c, list2.alloc(span)); H10X_HIP(c, list3.alloc(span)); H10X_HIP(c, listBig.alloc(span));
   // every small counter of the command in one buffer, cleared by one memset: counts[0..3] class sizes, [4] [6] [7] work
   // queue positions, [8] largest nRead, [10] [11] overflowed blocks (lists A, B); stats[0..7] the work counters
-  H10X_HIP(c, zeroed.alloc(6 + 8 + 2)); H10X_HIP(c, term.alloc(c->nEntries));   // (+ work of the half-CU and the whole-CU classes)
-  H10X_HIP(c, hipMemsetAsync(zeroed.p, 0, (6 + 8 + 2) * 8, st));
-  struct { u32 *p; } counts{(u32 *)zeroed.p}; struct { u64 *p; } stats{zeroed.p + 6};
+  H10X_HIP(c, zeroed.alloc(8 + 8 + 2)); H10X_HIP(c, term.alloc(c->nEntries));   // (+ work of the half-CU and the whole-CU classes)
+  H10X_HIP(c, hipMemsetAsync(zeroed.p, 0, (8 + 8 + 2) * 8, st));
+  struct { u32 *p; } counts{(u32 *)zeroed.p}; struct { u64 *p; } stats{zeroed.p + 8};   // counts[12] [13]: most ranks of a block in the half-CU classes / the whole-CU class (sizes the handle slots)
   const size_t budgetSmall = c->optClusterLds > 0 ? (size_t)c->optClusterLds : 80 * 1024 - 1024;
   const size_t budgetBig = c->optClusterLds > 0 ? (size_t)c->optClusterLds : 160 * 1024 - 1024;
   const int threads0 = c->optClusterThreads0 == 512 ? 512 : (c->optClusterThreads0 == 768 ? 768 : 1024);   // tuning knobs for class 0
@@ -2105,25 +2110,29 @@ static int cluster_local_range(Ctx *c, int codeMin, int codeMax, int threshold, 
   const size_t trSlotCapBytes = (size_t)32 << 20;
   const u32 maxTrRanks = (u32)hmin<size_t>(0xFFFFFFFFu, trSlotCapBytes / ((size_t)hStride * 2));
   const bool packed = c->optTrPacked != 0;                   // translated placement: the packed form (several lists per wave instruction, round 5) unless the knob says 0
-  const size_t trSlotU16 = (size_t)hmin<u32>(hmax<u32>(c->maxGood, 1u), maxTrRanks) * hStride + 256 /* packed form: the classes' regions start at multiples of 64 */ + (size_t)(CL_THREADS_HUGE / WAVE) * TR_QUEUE * 4;
+  // a workgroup's handle slot: the handles of its largest block (ranks x the slot's list stride; + 256: the packed form's class regions start at multiples of 64), then the waves' queues.
+  // Sized per launch class by the largest block THAT class holds and by its waves (round 4 took the context's largest block and 16 waves for every class: tens of GB on sets
+  // with a few giant barcodes that never run here); blocks handed on by the half-CU class run in the whole-CU class, whose slots therefore cover both
+  auto trSlotFor = [&](u32 maxRanks, u32 waves) { return (size_t)hmin<u32>(hmax<u32>(maxRanks, 1u), maxTrRanks) * hStride + 256 + (size_t)waves * TR_QUEUE * 4; };
   const u32 firstCap = c->optFirstCap > 0 ? (u32)c->optFirstCap : 0u;      // test knob only
-  u32 hc[12]; u64 hw[2] = {0, 0}; u32 nFirstLds = 0, bmWords = 0;
+  u32 hc[14]; u64 hw[2] = {0, 0}; u32 nFirstLds = 0, bmWords = 0;
   for (int attempt = 0; attempt < 2; ++attempt) {
     nFirstLds = firstMode == 0 ? nGlobal : 0;
     bmWords = firstMode == 1 ? bmWordsAll : 0;
     cluster_classify_kernel<<<divUp(span, 256), 256, 0, st>>>(c->blocks.p, c->nGood.p, c->goodEntries.p, (u32)codeMin, (u32)codeMax,
                                                             firstMode == 1 || firstMode >= 3 ? nGlobal : nFirstLds, firstMode == 1 ? 1 : (firstMode == 4 ? 3 : 0), hashMinSlots, maxTrRanks, firstCap,
                                                             bmWords, (u32)threads0 / WAVE, budget0, budgetSmall, budgetBig, c->optBigRanks > 0 ? (u32)c->optBigRanks : c->meanGood + c->meanGood / 2,
-                                                            list0.p, list1.p, list2.p, list3.p, listBig.p, counts.p, (unsigned long long *)(zeroed.p + 14));
-    H10X_TRY(c->readback(hc, counts.p, 48));
-    H10X_TRY(c->readback(hw, zeroed.p + 14, 16));
+                                                            list0.p, list1.p, list2.p, list3.p, listBig.p, counts.p, (unsigned long long *)(zeroed.p + 16));
+    H10X_TRY(c->readback(hc, counts.p, 56));
+    H10X_TRY(c->readback(hw, zeroed.p + 16, 16));
     H10X_TRY(c->syncReadbacks());
     const u32 classified = hc[0] + hc[1] + hc[2] + hc[3];
     if (attempt || !rankedTry || c->optFirstGlobal || firstMode != 1 || hc[3] <= 16 + classified / 200) break;
     firstMode = 4;                                           // too many blocks without room beside the bitmap: the translated placement after all
     H10X_HIP(c, hipMemsetAsync(counts.p, 0, 16, st));        // the four class sizes
     H10X_HIP(c, hipMemsetAsync(counts.p + 9, 0, 4, st));
-    H10X_HIP(c, hipMemsetAsync(zeroed.p + 14, 0, 16, st));
+    H10X_HIP(c, hipMemsetAsync(zeroed.p + 16, 0, 16, st));
+    H10X_HIP(c, hipMemsetAsync(counts.p + 12, 0, 8, st));
   }
   // (the work queue hands barcodes out in the order the classification appended them, i.e. mixed sizes: sorting the
   // queue by descending rank count was measured 17 % SLOWER — workgroups of like size run their phases in step and
@@ -2136,7 +2145,8 @@ static int cluster_local_range(Ctx *c, int codeMin, int codeMax, int threshold, 
   a.narrowFirst = (u32)c->optNarrowFirst;
   a.maxGood = c->maxGood; a.stats = stats.p; a.res = term.p; a.entries = c->goodEntries.p;
   a.firstCap = firstCap; a.hashMinSlots = hashMinSlots;
-  a.hashBits = (u32)hashBits; a.hStride = hStride; a.handleStride = trSlotU16;   // (handles, then the waves' queues)
+  a.hashBits = (u32)hashBits; a.hStride = hStride;
+  const size_t trStride[3] = {trSlotFor(hc[12], (u32)threads0 / WAVE), trSlotFor(hmax<u32>(hc[12], hc[13]), CL_THREADS_HUGE / WAVE), trSlotFor(hmax<u32>(hc[12], hc[13]), CL_THREADS_HUGE / WAVE)};   // [1]: the whole-CU class's second launch
   // ranked / hashed placement: blocks whose table was too small are re-run — those of the half-CU class (list A) with the
   // whole LDS of a CU, those that fail there as well (list B) with first[] dense on an HBM slot
   DevBuf<u32> ovfA, ovfB; H10X_HIP(c, ovfA.alloc(span)); H10X_HIP(c, ovfB.alloc(span));
@@ -2175,8 +2185,17 @@ static int cluster_local_range(Ctx *c, int codeMin, int codeMax, int threshold, 
     secondWind = hc[2] > gridOf[2] ? hmin<u32>(hc[2] - gridOf[2], (u32)c->numCU) : 0u;
   }
   DevBuf<u16> trSlots[3];                                  // translated placement: one handle slot per resident workgroup of each LDS class
-  if (firstMode == 4) for (int k = 0; k < 3; k += 2) if (gridOf[k]) H10X_HIP(c, trSlots[k].alloc(trSlotU16 * gridOf[k]));
-  if (secondWind) H10X_HIP(c, trSlots[1].alloc(trSlotU16 * secondWind));
+  // (no room for a class's slots: fewer workgroups — down to one — before giving up; the launches are persistent, a smaller grid is only slower)
+  auto trAlloc = [&](int k, u32 &grid) -> int {
+    for (;;) {
+      if (trSlots[k].alloc(trStride[k] * grid) == hipSuccess) return 0;
+      (void)hipGetLastError();
+      if (grid <= 1) return c->fail("no device memory for the handle slots of the cluster kernel (%.1f MB per workgroup)", trStride[k] * 2 / 1e6);
+      grid = (grid + 1) / 2;
+    }
+  };
+  if (firstMode == 4) for (int k = 0; k < 3; k += 2) if (gridOf[k]) H10X_TRY(trAlloc(k, gridOf[k]));
+  if (secondWind) H10X_TRY(trAlloc(1, secondWind));
   if (firstMode == 2) for (int k = 0; k < 3; k += 2) if (gridOf[k]) {       // class 0 serves list 0 AND the front list (hc[1]); class 1 has no launch
     H10X_HIP(c, firstSlots[k].alloc(firstStride * gridOf[k]));
     H10X_HIP(c, hipMemsetAsync(firstSlots[k].p, 0xFF, firstStride * gridOf[k], st));
@@ -2202,7 +2221,7 @@ static int cluster_local_range(Ctx *c, int codeMin, int codeMax, int threshold, 
     g.overflow = (OVF); g.overflowCount = (OVFCNT);                                                                                \
     if (firstMode == 0) H10X_LAUNCH_ONE(0, K, THREADS, BUDGET, GRID, STREAM)                                                       \
     else if (firstMode == 1) H10X_LAUNCH_ONE(1, K, THREADS, BUDGET, GRID, STREAM)                                                  \
-    else if (firstMode == 4) { g.handles = trSlots[K].p; if (packed) H10X_LAUNCH_ONE(5, K, THREADS, BUDGET, GRID, STREAM) else H10X_LAUNCH_ONE(4, K, THREADS, BUDGET, GRID, STREAM) } \
+    else if (firstMode == 4) { g.handles = trSlots[K].p; g.handleStride = trStride[K]; if (packed) H10X_LAUNCH_ONE(5, K, THREADS, BUDGET, GRID, STREAM) else H10X_LAUNCH_ONE(4, K, THREADS, BUDGET, GRID, STREAM) } \
     else { g.scratch = firstSlots[K].p; g.scratchStride = firstStride; H10X_LAUNCH_ONE(2, K, THREADS, BUDGET, GRID, STREAM) }      \
   }
   if (hc[2]) {
@@ -2240,7 +2259,7 @@ static int cluster_local_range(Ctx *c, int codeMin, int codeMax, int threshold, 
   }
   if (secondWind) {                                          // (see the split above) same work queue, counters and overflow list as the first launch of the class; handle slots of its own
     ClusterArgs g = a; g.list = list2.p; g.nList = hc[2]; g.workCounter = counts.p + 6; g.ldsBudget = (u32)budgetBig;
-    g.overflow = ovfB.p; g.overflowCount = ovfCountB; g.handles = trSlots[1].p;
+    g.overflow = ovfB.p; g.overflowCount = ovfCountB; g.handles = trSlots[1].p; g.handleStride = trStride[1];
     if (packed) H10X_LAUNCH_ONE(5, 2, CL_THREADS_HUGE, budgetBig, secondWind, st) else H10X_LAUNCH_ONE(4, 2, CL_THREADS_HUGE, budgetBig, secondWind, st)
   }
   H10X_HIP(c, hipGetLastError());
@@ -2254,8 +2273,9 @@ static int cluster_local_range(Ctx *c, int codeMin, int codeMax, int threshold, 
     H10X_HIP(c, hipStreamSynchronize(st));
     if (nA) {                                                // half-CU tables that were too small: again with the whole LDS of a CU
       H10X_HIP(c, hipMemsetAsync(counts.p + 6, 0, 4, st));
-      if (firstMode == 4 && trSlots[2].n < trSlotU16 * hmin<u32>(nA, (u32)c->numCU)) H10X_HIP(c, trSlots[2].alloc(trSlotU16 * hmin<u32>(nA, (u32)c->numCU)));
-      H10X_LAUNCH_LDS(2, CL_THREADS_HUGE, budgetBig, st, ovfA.p, nA, hmin<u32>(nA, (u32)c->numCU), 6, ovfCountB, ovfB.p)
+      u32 gridA = hmin<u32>(nA, (u32)c->numCU);
+      if (firstMode == 4 && trSlots[2].n < trStride[2] * gridA) H10X_TRY(trAlloc(2, gridA));
+      H10X_LAUNCH_LDS(2, CL_THREADS_HUGE, budgetBig, st, ovfA.p, nA, gridA, 6, ovfCountB, ovfB.p)
       H10X_HIP(c, hipGetLastError());
     }
     H10X_HIP(c, hipMemcpyAsync(&nB, ovfCountB, 4, hipMemcpyDeviceToHost, st));

@@ -312,6 +312,8 @@ int  h10x_timing_reset(h10x_ctx *ctx);
    from OTHER ranks; maxPeerOut = the sum over the calls of the largest share one peer received (grouped point-to-point sends: what one xGMI link carried); ms = from
    each call to its completion on the context's stream, waits for slower ranks included (collected while timing is enabled; a rank's compute is its stage timers less
    these). Cleared by h10x_timing_reset. What `bench.py --scaling strong` and `--virtual-ranks` print so that a scaling curve can be read. */
+/* sharded contexts: the part of stage timer i (h10x_timing_name) spent inside exchanges — waiting for other ranks and moving bytes; the stage's own compute is the rest */
+int  h10x_timing_wait_get(h10x_ctx *ctx, int i, double *ms);
 int  h10x_exchange_count(void);
 const char *h10x_exchange_name(int i);
 int  h10x_exchange_get(h10x_ctx *ctx, int i, uint64_t *calls, uint64_t *bytesOut, uint64_t *bytesIn, uint64_t *maxPeerOut, double *ms, double *msInStages);
