@@ -1352,9 +1352,11 @@ __device__ __forceinline__ void cluster_one_block_tp(const ClusterArgs &a, u32 c
   constexpr int CL_WAVES = CL_THREADS / WAVE;
 #ifndef H10X_TP_RIF0
 #define H10X_TP_RIF0 2
+#define H10X_TP_RIF0F 3
 #define H10X_TP_RIF2 4
 #endif
-  constexpr int RIF = KLASS == 2 ? H10X_TP_RIF2 : H10X_TP_RIF0;        // units a wave keeps in flight
+  constexpr int RIF_Q = KLASS == 2 ? H10X_TP_RIF2 : H10X_TP_RIF0, RIF_F = KLASS == 2 ? H10X_TP_RIF2 : H10X_TP_RIF0F;   // units a wave keeps in flight (classes Q, H / F, D)
+  constexpr int RIF = RIF_F > RIF_Q ? RIF_F : RIF_Q;          // (the queue's margin)
   const int tid = threadIdx.x, lane = tid & (WAVE - 1), wave = tid / WAVE;
   const u32 laneU = (u32)lane;
   code = (u32)__builtin_amdgcn_readfirstlane((int)code);
@@ -1478,6 +1480,7 @@ __device__ __forceinline__ void cluster_one_block_tp(const ClusterArgs &a, u32 c
     // the units of one class: SEGW lanes per list, NCH chunks per unit (2: the lists of 65 .. 128 entries, one per unit)
     auto classA = [&](auto segw_, auto nch_, const u32 firstRank, const u32 endRank, const u32 posBase) {
       constexpr u32 SEGW = decltype(segw_)::value, NCH = decltype(nch_)::value, LPU = WAVE / SEGW;
+      constexpr int RIF = SEGW == 64 ? RIF_F : RIF_Q;     // units in flight: the whole-wave lists of F and D gain from a third (3 % on the config-3 sets), the short lists of Q and H lose (4 %)
       const u32 nUnits = (endRank - firstRank + LPU - 1) / LPU;
       if (uwave * RIF >= nUnits) return;
       constexpr u32 stepA = CL_WAVES * RIF;
@@ -1607,6 +1610,7 @@ __device__ __forceinline__ void cluster_one_block_tp(const ClusterArgs &a, u32 c
     u32 *const myHist = hist + uwave * histWords;
     auto classB = [&](auto segw_, auto nch_, const u32 firstRank, const u32 endRank, const u32 posBase) {
       constexpr u32 SEGW = decltype(segw_)::value, NCH = decltype(nch_)::value, LPU = WAVE / SEGW;
+      constexpr int RIF = SEGW == 64 ? RIF_F : RIF_Q;
       const u32 nUnits = (endRank - firstRank + LPU - 1) / LPU;
       if (uwave * RIF >= nUnits) return;
       const u32 stepB = nW * RIF;
