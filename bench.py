@@ -524,7 +524,8 @@ TRAFFIC_NOTE = ("HBM bytes per step from the committed rocprofv3 --pmc passes (F
 def profile_traffic(pattern, match, exclude=None):
     """(corrected bytes per step, raw FETCH_SIZE, raw WRITE_SIZE, file, head, build id) of the kernels whose name contains `match` in the newest profiles/<pattern>"""
     import glob
-    cands = sorted(f for f in glob.glob(os.path.join(REPO, "profiles", pattern)) if not exclude or exclude not in os.path.basename(f))
+    excl = (exclude,) if isinstance(exclude, str) else tuple(exclude or ())
+    cands = sorted(f for f in glob.glob(os.path.join(REPO, "profiles", pattern)) if not any(x in os.path.basename(f) for x in excl))
     if not cands:
         return None
     pm = json.load(open(cands[-1]))
@@ -709,6 +710,8 @@ def virtual_ranks_block(hash10x_amd, name, n, local_rank=0, steps=1):
             rr, _first, _tot = generate_v2(wl, wl["seed"], r, n)
             dr = hash10x_amd.DeviceRecords(rr, device=local_rank); np_ = rr.size // 30; del rr
             hh = hash10x_amd.Hash10x(B=wl["B"], device=local_rank); hh.enable_timing(True)
+            for kv in filter(None, os.environ.get("H10X_OPTS", "").split(",")):      # tuning knobs for A/B runs of the model (e.g. shard_delta_lists=0)
+                hh.set_option(kv.split("=")[0], int(kv.split("=")[1]))
             for it in range(steps + 1):
                 comms[r].turn_begin()
                 try:
@@ -771,7 +774,7 @@ def secondary_block(hash10x_amd, local_rank):
     alg_all = 4.0 * c["sum_good_depth"] + 14.0 * c["sum_good"] + 16.0 * c["sum_hash_clustered"]
     tr = None                                                # rocprofv3 --pmc passes of this workload, committed under profiles/
     try:
-        tr = profile_traffic("*config3_pmc_traffic.json", "cluster_kernel")
+        tr = profile_traffic("*_config3_pmc_traffic.json", "cluster_kernel")
     except Exception:
         tr = None
     out = {"workload": "config3-tenth-20M (BASELINE configs[2] proportions at 1/10: 20 M pairs, 100 k barcodes, 50 Mb x 2, e = 0.1 %, -B 26)",
@@ -953,7 +956,7 @@ def main():
     try:
         if args.workload == "yeast-like-2.5M" and world == 1:
             pm_match = "cluster_kernel<true, 0, 1024, 0>" if dom == "cluster_main" else dom.split("_")[0]
-            tr = profile_traffic("*_pmc_traffic.json", pm_match, exclude="config3")
+            tr = profile_traffic("*_pmc_traffic.json", pm_match, exclude=("config3", "genome3g"))
     except Exception:
         tr = None
     traffic = tr["traffic"] if tr else None

@@ -129,6 +129,7 @@ struct LocalComm : Comm {
 namespace h10x {
 struct SockComm : Comm {
   std::vector<int> fd;                                       // fd[p] = connection to rank p (-1 for myself)
+  bool slowLinks() const override { return true; }
   ~SockComm() override { for (int f : fd) if (f >= 0) close(f); }
   // send nOut bytes to fdOut while receiving nIn bytes from fdIn (either may be -1 / 0): never blocks on one direction
   static int duplex(int fdOut, const char *out, size_t nOut, int fdIn, char *in, size_t nIn) {

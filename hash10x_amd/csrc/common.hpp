@@ -225,6 +225,7 @@ struct Ctx {
   int64_t optPrivTable = 0;   // entry look-ups of the index build: 0 = the table of this library's own where key + index do not fit the 64-bit reference-shaped one, 1 = always (tests), 2 = never, 3 = always and too small (tests: the fall-back)
   int64_t optNoPack = 0;      // index build with separate key / block arrays even where the packed form fits (A/B, tests)
   int64_t optNarrowFirst = 0; // first[] of the cluster kernel at 2 bytes per entry in every block (default: 4 where the block's working set leaves room)
+  int64_t optTrEstDiv = 0;    // tuning knob: translated placement, classification: a block's barcodes estimated as entries / this (0 = 6)
   int64_t optTrPacked = -1;   // translated placement of the cluster kernel: -1 / 1 = packed (several lists per wave instruction), 0 = one list per wave instruction (round 4's form: A/B, tests)
   int64_t optStamps = 0;      // diagnostic: per-phase wall-clock stamps in cluster_kernel
   int64_t optChunk = 0;       // -c <chunkSize> of the reference's readFQB loop (hash10x.c:202-223): 0 = no chunk semantics (no "chunkSize too small", no
@@ -233,7 +234,7 @@ struct Ctx {
                               // block holds chunkSize records (hash10x.c:205-208); 0 = -N ended the loop
   std::vector<u64> mergePoints; bool replayDone = false;     // records whose barcode change does NOT start a block (chunk replay; consumed by stageA_run)
   int64_t optRowShift = -1;   // testing knob: force the list alignment of the sharded rows[] (-1 = as small as the offsets allow)
-  int64_t optDeltaLists = -1; // in-range barcode lists travel delta-coded between ranks: -1 = when there is more than one rank, 0 never, 1 always (tests)
+  int64_t optDeltaLists = -1; // in-range barcode lists travel delta-coded between ranks: -1 = where bytes are dear (more than one rank on the host-staged TCP backend; not over xGMI: DESIGN 5), 0 never, 1 always (tests)
   int64_t optRowsFakeBase = 0; // testing knob: list offsets start at this many entries (multiple of 2^rowShift) in front of the real array: 64-bit offsets on small inputs
   // streaming ingest (h10x_ingest_fqb): the record image grows on the device as the chunks arrive
   DevBuf<u32> ingestBuf; u64 ingestRecords = 0, ingestCap = 0; bool ingestAsync = false;   // ingestAsync: chunks came through h10x_ingest_fqb_async (the closing call then checks the count)

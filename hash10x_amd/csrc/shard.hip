@@ -568,7 +568,7 @@ int shard_exchangeRows(Ctx *c) {
     H10X_TRY(c->syncReadbacks());
     H10X_TRY(xchg_hostGather(c, cm, mine, all.data(), 16));
   }
-  const bool delta = c->optDeltaLists > 0 || (c->optDeltaLists < 0 && N > 1);
+  const bool delta = c->optDeltaLists > 0 || (c->optDeltaLists < 0 && N > 1 && cm->slowLinks());
   const u32 nGoodU = (u32)mine[0];
   DevBuf<u32> gIdx, gLen, gRows, goodId;
   H10X_HIP(c, gIdx.alloc(mine[0])); H10X_HIP(c, gLen.alloc(mine[0])); H10X_HIP(c, goodId.alloc(mine[0])); if (!delta) H10X_HIP(c, gRows.alloc(mine[1]));

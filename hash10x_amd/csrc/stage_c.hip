@@ -2018,7 +2018,7 @@ void read_merge_kernel(h10x_block *__restrict__ blocks, const u64 *__restrict__ 
 // launch classes by working-set size: 0 = half a CU's LDS (barcodes with many ranks run their list loop on fewer waves:
 // histWaves), 2 = the whole LDS of a CU, 3 = HBM scratch (class 1 is no longer used)
 __global__ void cluster_classify_kernel(const h10x_block *__restrict__ blocks, const u32 *__restrict__ nGood, const u32 *__restrict__ entries, u32 codeMin, u32 codeMax,
-                                        u32 nBlocks /* LDS entries of first[] (ranked, hashed: barcodes of the data set) */, int ranked /* 1 ranked, 3 translated */, u32 hashMinSlots, u32 maxTrRanks, u32 firstCap, u32 bmWords, u32 waves0, size_t budget0, size_t budgetSmall, size_t budgetBig, u32 bigRanks,
+                                        u32 nBlocks /* LDS entries of first[] (ranked, hashed: barcodes of the data set) */, int ranked /* 1 ranked, 3 translated */, u32 hashMinSlots, u32 maxTrRanks, u32 firstCap, u32 bmWords, u32 waves0, size_t budget0, size_t budgetSmall, size_t budgetBig, u32 bigRanks, u32 estDiv /* translated placement: a block's barcodes are taken to be this fraction of its list entries */,
                                         u32 *__restrict__ list0, u32 *__restrict__ list1, u32 *__restrict__ list2, u32 *__restrict__ list3,
                                         u32 *__restrict__ listBig /* blocks with more ranks than the small replay class holds: counts[9] */, u32 *__restrict__ counts, unsigned long long *__restrict__ work) {
   const u32 c = codeMin + blockIdx.x * blockDim.x + threadIdx.x;
@@ -2034,7 +2034,7 @@ __global__ void cluster_classify_kernel(const h10x_block *__restrict__ blocks, c
       // (a sixth of the entries, not a seventh as in the ranked placement: the blocks in between would run in the half-CU class on a second table and
       //  with few list-loop waves — they are faster with a CU to themselves: full configs[2] 583 -> 567 ms, 17 % of the blocks in the whole-CU class
       //  instead of 8 %; at a fifth the whole-CU class holds more than half of the CUs and the launches no longer overlap: 890 ms)
-      else if (translatedFits(S, S2, rankedFirstEstimateE(nBlocks, n, entries[c], 6), entries[c], nBlocks)) cls = 0;
+      else if (translatedFits(S, S2, rankedFirstEstimateE(nBlocks, n, entries[c], estDiv), entries[c], nBlocks)) cls = 0;
       else { translatedShape(n, CL_THREADS_HUGE / WAVE, budgetBig, hashMinSlots, entries[c], nBlocks, firstCap, S, S2, nW, compact); cls = S ? 2 : 3; }
     }
     else if (histWaves(ranked ? rankedFirstEstimateE(nBlocks, n, entries[c]) : nBlocks, n, waves0, bmWords, budget0)) cls = 0;
@@ -2125,7 +2125,7 @@ static int cluster_local_range(Ctx *c, int codeMin, int codeMax, int threshold, 
     bmWords = firstMode == 1 ? bmWordsAll : 0;
     cluster_classify_kernel<<<divUp(span, 256), 256, 0, st>>>(c->blocks.p, c->nGood.p, c->goodEntries.p, (u32)codeMin, (u32)codeMax,
                                                             firstMode == 1 || firstMode >= 3 ? nGlobal : nFirstLds, firstMode == 1 ? 1 : (firstMode == 4 ? 3 : 0), hashMinSlots, maxTrRanks, firstCap,
-                                                            bmWords, (u32)threads0 / WAVE, budget0, budgetSmall, budgetBig, c->optBigRanks > 0 ? (u32)c->optBigRanks : c->meanGood + c->meanGood / 2,
+                                                            bmWords, (u32)threads0 / WAVE, budget0, budgetSmall, budgetBig, c->optBigRanks > 0 ? (u32)c->optBigRanks : c->meanGood + c->meanGood / 2, c->optTrEstDiv > 0 ? (u32)c->optTrEstDiv : 6u,
                                                             list0.p, list1.p, list2.p, list3.p, listBig.p, counts.p, (unsigned long long *)(zeroed.p + 16));
     H10X_TRY(c->readback(hc, counts.p, 56));
     H10X_TRY(c->readback(hw, zeroed.p + 16, 16));

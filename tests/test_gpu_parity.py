@@ -373,8 +373,10 @@ def test_sharded_equals_single_gpu_and_oracle(workdir, nranks):
 
 @pytest.mark.parametrize("nranks,delta", [(1, 1), (3, 0), (3, 1), (4, -1)])
 def test_sharded_lists_travel_delta_coded(workdir, nranks, delta):
-    """The in-range barcode lists go between ranks as 16-bit steps (a list with a step beyond 16 bits goes as it is): forced on one
-    rank, off and on with three, by default with four; the words received must be about half the plain ones where it is on."""
+    """The in-range barcode lists can go between ranks as 16-bit steps (a list with a step beyond 16 bits goes as it is): forced on one
+    rank, off and on with three; the words received must be about half the plain ones where it is on. By default (four ranks, -1) they travel
+    coded only where bytes are dear — the host-staged TCP backend — and plain between the ranks of one process as over xGMI (round 5: at 8 ranks
+    the coding costs every rank more compute than it saves link time, bench.py --virtual-ranks)."""
     import hash10x_amd
     orc.gen_fqb(workdir.file("x.fqb"), 60000, 300, 400000, 0.003, 43, 4.0, 150, 6000)
     run_commands(lambda k, w, r, B: orc.Oracle(k, w, r, B), ["-B", 22, "-ct", 3, "--readFQB", "x.fqb", "--hashDepthRange", 4, 40, "--cluster", 1, 0, "--writeHash", "orc.hash"], workdir.path)
@@ -386,7 +388,7 @@ def test_sharded_lists_travel_delta_coded(workdir, nranks, delta):
     got = open(workdir.file("sh.hash"), "rb").read()
     assert got == exp, orc.describe_diff(got, exp)
     plain, coded = words[0]
-    if delta == 0:
+    if delta <= 0:
         assert plain == 0 and coded == 0
     else:
         assert plain > 0 and 0.5 * plain <= coded <= 0.62 * plain, (plain, coded)
