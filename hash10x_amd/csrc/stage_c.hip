@@ -1006,6 +1006,9 @@ __device__ __forceinline__ void cluster_one_block_tr(const ClusterArgs &a, u32 c
     return;
   }
   const u32 closeAt = translatedCloseAt(S, S2);
+  // the table's fill count, read as LDS: through the generic pointer the volatile read is a FLAT load followed by s_waitcnt vmcnt(0) — every round of pass A then waited
+  // for the list loads it had just issued for the NEXT round (seen in the ISA, round 5)
+  auto shFill = [&]() { typedef __attribute__((address_space(3))) u32 lds_u32; return *(volatile lds_u32 *)(lds_u32 *)&sh[1]; };
   const u32 rsh = a.rowShift;
 #define ROWP(rs) (a.rows + ((size_t)(rs) << rsh))
   const u64 *const gr = a.goodRow + o;
@@ -1039,7 +1042,7 @@ __device__ __forceinline__ void cluster_one_block_tr(const ClusterArgs &a, u32 c
     for (; all ? k0 < qn : k0 + WAVE <= qn; k0 += WAVE) {
       const bool on = k0 + lane < qn;
       const unsigned long long e = on ? queue[k0 + lane] : 0ull;
-      const bool insert = mayInsert && *(volatile u32 *)&sh[1] < fillLimit;   // (uniform: one LDS word)
+      const bool insert = mayInsert && shFill() < fillLimit;   // (uniform: one LDS word)
       u32 h = 0; bool ins = false;
       if (on) { const u32 dest = (u32)(e >> 22); h = t.search((u32)e & 0x3FFFFFu, dest >> lgH, insert, ins); if (h != SlotTable::NOTFOUND) hs[dest] = (u16)h; }
       const u64 balI = __ballot(ins);
@@ -1098,7 +1101,7 @@ __device__ __forceinline__ void cluster_one_block_tr(const ClusterArgs &a, u32 c
         TR_LOAD_C(dvN)
         if (S2) {                                            // a table that may fill up: say what this wave has put in, see whether it still takes barcodes
           if (myIns) { if (lane == 0) atomicAdd(&sh[1], myIns); myIns = 0; }
-          insert = (u32)__builtin_amdgcn_readfirstlane((int)*(volatile u32 *)&sh[1]) < closeAt;
+          insert = (u32)__builtin_amdgcn_readfirstlane((int)shFill()) < closeAt;
         }
 #pragma unroll
         for (int t = RIF - 1; t >= 0; --t) if ((u32)__builtin_amdgcn_readlane((int)dv, 32 + t) > 2u * WAVE) lt = (u32)t;
@@ -1371,12 +1374,20 @@ __device__ __forceinline__ void cluster_one_block_tp(const ClusterArgs &a, u32 c
     return;
   }
   const u32 closeAt = translatedCloseAt(S, S2);
+  // the table's fill count, read as LDS: through the generic pointer the volatile read is a FLAT load followed by s_waitcnt vmcnt(0) — every round of pass A then waited
+  // for the list loads it had just issued for the NEXT round (seen in the ISA, round 5)
+  auto shFill = [&]() { typedef __attribute__((address_space(3))) u32 lds_u32; return *(volatile lds_u32 *)(lds_u32 *)&sh[1]; };
   const u32 rsh = a.rowShift;
 #define ROWP(rs) (a.rows + ((size_t)(rs) << rsh))
   const u64 *const gr = a.goodRow + o;
-  u64 *const res = a.res + o;
   u32 thr = (u32)a.threshold;
   asm volatile("" : "+s"(thr));
+  // Where this block's result words go: kept in LDS, fetched where a result is written. As a kernel-long value the pointer ended up in a spilled VGPR pair, and its reload
+  // in pass B's writer branch brought an s_waitcnt vmcnt(0) with it — a wait for the handle loads just issued for the next round (ISA, round 5). An LDS read waits for LDS only.
+  typedef __attribute__((address_space(3))) u32 lds_u32;
+  if (tid == 0) { const u64 rp = (u64)(a.res + o); sh[16] = (u32)rp; sh[17] = (u32)(rp >> 32); a.res[o] = RES_PACK(NONE16, 0, 0); }
+  auto resPtr = [&]() { volatile lds_u32 *const q = (volatile lds_u32 *)(lds_u32 *)&sh[16];
+                        return (u64 *)(((u64)(u32)__builtin_amdgcn_readfirstlane((int)q[1]) << 32) | (u64)(u32)__builtin_amdgcn_readfirstlane((int)q[0])); };
   u16 *const hs = a.handles + (size_t)blockIdx.x * a.handleStride;
   const u32 hst = a.hStride;
   const u32 uwave = (u32)__builtin_amdgcn_readfirstlane(wave);
@@ -1385,8 +1396,7 @@ __device__ __forceinline__ void cluster_one_block_tp(const ClusterArgs &a, u32 c
   // ---- the table of pass A is cleared, and meanwhile the classes are counted: ranks ascend in list length, so `lists of at most L entries` is a rank
   u32 *const tab = (u32 *)region;
   for (u32 i = tid; i <= S; i += CL_THREADS) tab[i] = 0xFFFFFFFFu;   // (+ the word of handle `none`)
-  if (tid < 8) sh[tid] = 0;                                  // [0] entries left for the second table, [1] barcodes in the first, [2] a table overflowed, [4..7] class counts
-  if (tid == 0) res[0] = RES_PACK(NONE16, 0, 0);
+  if (tid < 8) sh[tid] = 0;                                  // [0] entries left for the second table, [1] barcodes in the first, [2] a table overflowed, [4..7] class counts; [16] [17] the result pointer
   SYNC();
   {
     u32 c16 = 0, c32 = 0, c64 = 0, c128 = 0;                 // (uniform)
@@ -1439,7 +1449,7 @@ __device__ __forceinline__ void cluster_one_block_tp(const ClusterArgs &a, u32 c
     for (; all ? k0 < qn : k0 + WAVE <= qn; k0 += WAVE) {
       const bool on = k0 + laneU < qn;
       const unsigned long long e = on ? queue[k0 + laneU] : 0ull;
-      const bool insert = mayInsert && *(volatile u32 *)&sh[1] < fillLimit;   // (uniform: one LDS word)
+      const bool insert = mayInsert && shFill() < fillLimit;   // (uniform: one LDS word)
       u32 h = 0; bool ins = false;
       if (on) { h = t.search((u32)e & 0x3FFFFFu, (u32)(e >> 22) & 0xFFFFu, insert, ins); if (h != SlotTable::NOTFOUND) hs[(u32)(e >> 38)] = (u16)h; }
       const u64 balI = __ballot(ins);
@@ -1484,9 +1494,12 @@ __device__ __forceinline__ void cluster_one_block_tp(const ClusterArgs &a, u32 c
       const u32 nUnits = (endRank - firstRank + LPU - 1) / LPU;
       if (uwave * RIF >= nUnits) return;
       constexpr u32 stepA = CL_WAVES * RIF;
-      const u32 seg = laneU / SEGW, jl = laneU & (SEGW - 1);
+      // (seg / jl — the lane's segment and place in it — are formed from an opaque copy of the lane number wherever they are used: as function-long values the compiler kept a set of
+      //  them per class in registers it did not have, and reloaded them from scratch inside the loops with a wait for every outstanding load)
+      u32 lu = laneU, seg = 0, jl = 0;
+      auto lanes = [&]() { asm volatile("" : "+v"(lu)); seg = lu / SEGW; jl = lu & (SEGW - 1); };
       // descriptors of the RIF * LPU lists of a round in ONE register: lane t the offset, lane 32 + t the length of the round's t-th list (clamped index: no lane skips the load)
-      auto descBatch = [&](u32 u0) { const u32 i = firstRank + u0 * LPU + (laneU & 31u); return ((const u32 *)gr)[2 * (size_t)(i < n ? i : n - 1) + (laneU >> 5)]; };
+      auto descBatch = [&](u32 u0) { const u32 i = firstRank + u0 * LPU + (lu & 31u); return ((const u32 *)gr)[2 * (size_t)(i < n ? i : n - 1) + (lu >> 5)]; };
       u32 cN[RIF][NCH], lenN[RIF];
       auto issue = [&](u32 dv, u32 u0) {                     // the entry loads of a round (no lane skips one: rows[] has ROWS_PAD entries of slack)
 #pragma unroll
@@ -1503,8 +1516,10 @@ __device__ __forceinline__ void cluster_one_block_tp(const ClusterArgs &a, u32 c
       };
       u32 u0 = uwave * RIF;
       u32 dvN = descBatch(u0), dvNN = descBatch(u0 + stepA);
+      lanes();
       issue(dvN, u0);
       for (; u0 < nUnits; u0 += stepA) {
+        lanes();
         u32 c0[RIF][NCH], len[RIF];
 #pragma unroll
         for (int t = 0; t < RIF; ++t) { len[t] = lenN[t];
@@ -1514,7 +1529,7 @@ __device__ __forceinline__ void cluster_one_block_tp(const ClusterArgs &a, u32 c
         issue(dvN, u0 + stepA);
         if (S2) {                                            // a table that may fill up: say what this wave has put in, see whether it still takes barcodes
           if (myIns) { if (lane == 0) atomicAdd(&sh[1], myIns); myIns = 0; }
-          insert = (u32)__builtin_amdgcn_readfirstlane((int)*(volatile u32 *)&sh[1]) < closeAt;
+          insert = (u32)__builtin_amdgcn_readfirstlane((int)shFill()) < closeAt;
         }
 #pragma unroll
         for (int t = 0; t < RIF; ++t) {
@@ -1614,18 +1629,20 @@ __device__ __forceinline__ void cluster_one_block_tp(const ClusterArgs &a, u32 c
       const u32 nUnits = (endRank - firstRank + LPU - 1) / LPU;
       if (uwave * RIF >= nUnits) return;
       const u32 stepB = nW * RIF;
-      const u32 seg = laneU / SEGW, jl = laneU & (SEGW - 1);
-      u32 *const segHist = myHist + seg * ((endRank + 3u) / 4u);   // a first[] value counted here is below the list's rank, i.e. below the class's last rank
+      u32 lu = laneU, seg = 0, jl = 0; u32 *segHist = myHist;    // (formed per round from an opaque copy of the lane number: see pass A)
+      auto lanes = [&]() { asm volatile("" : "+v"(lu)); seg = lu / SEGW; jl = lu & (SEGW - 1);
+                           segHist = myHist + seg * ((endRank + 3u) / 4u); };   // a first[] value counted here is below the list's rank, i.e. below the class's last rank
       u32 hN[RIF][NCH];
       auto issue = [&](u32 u0) {                             // (uniform base + 32-bit position: no 64-bit pointer per lane to keep across the loop)
 #pragma unroll
         for (int t = 0; t < RIF; ++t) { const u32 u = u0 + (u32)t < nUnits ? u0 + (u32)t : nUnits - 1;   // (past the class: its last unit again, from the caches)
 #pragma unroll
-          for (u32 c = 0; c < NCH; ++c) hN[t][c] = hs[posBase + u * (WAVE * NCH) + c * WAVE + laneU]; }
+          for (u32 c = 0; c < NCH; ++c) hN[t][c] = hs[posBase + u * (WAVE * NCH) + c * WAVE + lu]; }
       };
       u32 u0 = uwave * RIF;
       issue(u0);
       for (; u0 < nUnits; u0 += stepB) {
+        lanes();
         u32 h[RIF][NCH];
 #pragma unroll
         for (int t = 0; t < RIF; ++t) {
@@ -1639,7 +1656,7 @@ __device__ __forceinline__ void cluster_one_block_tp(const ClusterArgs &a, u32 c
           const bool live = r >= 1 && r < endRank;
           u32 f[NCH]; bool ok[NCH]; u32 tot = 0, key = 0;
 #pragma unroll
-          for (u32 c = 0; c < NCH; ++c) { f[c] = ft.peek(h[t][c]); ok[c] = f[c] < r; tot += seg_popc<SEGW>(__ballot(ok[c]), laneU); }   // (`none` reads 0xFFFF: never below a rank)
+          for (u32 c = 0; c < NCH; ++c) { f[c] = ft.peek(h[t][c]); ok[c] = f[c] < r; tot += seg_popc<SEGW>(__ballot(ok[c]), lu); }   // (`none` reads 0xFFFF: never below a rank)
 #pragma unroll
           for (u32 c = 0; c < NCH; ++c)
             if (ok[c]) {
@@ -1650,16 +1667,16 @@ __device__ __forceinline__ void cluster_one_block_tp(const ClusterArgs &a, u32 c
             }
 #pragma unroll
           for (u32 c = 0; c < NCH; ++c) if (ok[c]) segHist[f[c] >> 2] = 0;   // (ds ops of a wave stay in order: behind every count of the unit)
-          key = seg_max_u32<SEGW>(key, laneU);               // msMax << 16 | ~msBest: the mode, ties to the lowest rank (hash10x.c:801-806)
+          key = seg_max_u32<SEGW>(key, lu);               // msMax << 16 | ~msBest: the mode, ties to the lowest rank (hash10x.c:801-806)
           const u32 bcnt = key >> 16, best = 0xFFFFu - (key & 0xFFFFu);       // (no usable entry: key 0 -> best NONE16, bcnt 0)
           const bool act = bcnt >= thr;                      // hash10x.c:807
           const u32 rbv = root[act ? best : 0u];             // founding rank of the cluster the rank joins (NONE16: not on record yet — settled behind the loop)
           const u32 rb = act ? rbv : (u32)NONE16;
           u32 q = 0;
 #pragma unroll
-          for (u32 c = 0; c < NCH; ++c) q += seg_popc<SEGW>(__ballot(f[c] == rb), laneU);
+          for (u32 c = 0; c < NCH; ++c) q += seg_popc<SEGW>(__ballot(f[c] == rb), lu);
           if (rb == NONE16) q = 0;
-          if (live && jl == 0) { root[r] = (u16)(act ? rb : r); res[r] = RES_PACK(act ? best : (u32)NONE16, q, tot); }
+          if (live && jl == 0) { root[r] = (u16)(act ? rb : r); resPtr()[r] = RES_PACK(act ? best : (u32)NONE16, q, tot); }
         }
       }
     };
@@ -1678,7 +1695,7 @@ __device__ __forceinline__ void cluster_one_block_tp(const ClusterArgs &a, u32 c
         if (bcnt >= thr) { rb = root[best]; if (rb != NONE16) { u32 t2; q = row_count_value(hrow, d, code, i, ft, rb, t2); } }
       }
       const bool act = bcnt >= thr;
-      if (lane == 0) { root[i] = (u16)(act ? rb : i); res[i] = RES_PACK(act ? best : (u32)NONE16, q, tot); }
+      if (lane == 0) { root[i] = (u16)(act ? rb : i); resPtr()[i] = RES_PACK(act ? best : (u32)NONE16, q, tot); }
     }
   }
   STAMP(4);
@@ -1702,6 +1719,7 @@ __device__ __forceinline__ void cluster_one_block_tp(const ClusterArgs &a, u32 c
     }
     SYNC();
     const u32 nTodo = sh[2];
+    u64 *const res = resPtr();
     if (a.phase && tid == 0) { atomicAdd((u64 *)&a.phase[6], (u64)nTodo); atomicAdd((u64 *)&a.phase[7], (u64)n); }   // diagnostic: ranks settled behind the loop / ranks
     for (u32 k = tid; k < nTodo; k += CL_THREADS) {
       const u32 i = todo[k];
