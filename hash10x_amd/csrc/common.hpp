@@ -362,13 +362,13 @@ int stageB_buildCSR(Ctx *c);                   // rows/rowStart from clusHash + 
 int stageB_finishClusHash(Ctx *c, DevBuf<u64> &key);   // key[e] = index << 32 | read16 in block order -> clusHash sorted per block
 // workgroup-local sorts of a block's entries (clushash_block_kernel, good_block_kernel): three launch classes, side by side on
 // forked streams — 256 lanes x 12 items (blocks up to 3072 entries: 98 % of them at 250 read pairs per barcode), 512 x 12, 1024 x 8
-constexpr u32 BLOCK_SORT_CAP0 = 3072, BLOCK_SORT_CAP1 = 6144, BLOCK_SORT_MAX = 8192;
 #ifndef H10X_BS_T0
 #define H10X_BS_T0 512     // lanes x entries per lane of the workgroup-local sorts of the first two classes (CAP0 = T0 x I0, CAP1 = T1 x I1)
 #define H10X_BS_I0 6
 #define H10X_BS_T1 1024
 #define H10X_BS_I1 6
 #endif
+constexpr u32 BLOCK_SORT_CAP0 = H10X_BS_T0 * H10X_BS_I0, BLOCK_SORT_CAP1 = H10X_BS_T1 * H10X_BS_I1, BLOCK_SORT_MAX = 8192;
 int stageB_buildProbeTable(Ctx *c);            // hashIndex[] from hashValue[1..hashNumber)
 // the blocks of the three workgroup-local-sort classes as lists: lists[k * nBlocks ..] holds counts[k] block numbers (entries up to CAP0 — incl. the
 // empty blocks and slot 0 —, up to CAP1, up to BLOCK_SORT_MAX); larger blocks are in none. A class's kernel then starts workgroups for ITS blocks
