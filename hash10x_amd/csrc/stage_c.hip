@@ -455,19 +455,16 @@ struct SlotTable {
     slot = b4 | (hit ? wh : wz);
     // the masks the wave's scalar unit has to form are what this code costs (the pass issues as many scalar as vector instructions): ONE flag leaves
     // the insertion branch — settled: the word was empty, or the same barcode got there first — and the minimum is queued where the flag is known
-    bool settled = hit; ins = false;
-    if (valid && !hit) {
-      settled = false;
-      if (insert && (z0 | z1 | z2 | z3)) {                    // claim the first empty word
-        const u32 seen = atomicCAS(&tab[slot], 0xFFFFFFFFu, mine);
-        ins = seen == 0xFFFFFFFFu;
-        const bool same = (seen & 0xFFFFu) == key;           // the same barcode got there first: its rank takes part in the minimum
-        if (same) atomicMin(&tab[slot], mine);
-        settled = ins | same;
-      }
-    } else if (valid) atomicMin(&tab[slot], mine);           // the entry's rank: minimum with this one, looked at or not — a fire-and-forget LDS atomic per chunk costs less than
+    // (round 5) two flat exec regions and no flag that lives across a branch: a claim for the lanes whose barcode is new here and that see an empty word, then ONE minimum for
+    // the lanes that found their barcode — before or through the claim. (Flags set inside nested branches came back as 0 / 1 registers that were compared again to form the masks.)
+    const bool claim = valid && !hit && insert && (z0 | z1 | z2 | z3);
+    u32 seen = 0x0000FFFFu;                                  // (neither empty nor anybody's key: displacement 63 with tag 1023 is never stored)
+    if (claim) seen = atomicCAS(&tab[slot], 0xFFFFFFFFu, mine);   // claim the first empty word
+    ins = seen == 0xFFFFFFFFu;
+    const bool same = (seen & 0xFFFFu) == key;               // the same barcode got there first: its rank takes part in the minimum
+    if ((valid && hit) || same) atomicMin(&tab[slot], mine); // the entry's rank: minimum with this one, looked at or not — a fire-and-forget LDS atomic per chunk costs less than
                                                              // finding out whether a later rank got here first
-    return !valid || settled;
+    return !valid || hit || ins || same;
   }
 };
 struct FirstSlots {                                          // pass B: first[] by handle
@@ -1472,7 +1469,8 @@ __device__ __forceinline__ void cluster_one_block_tp(const ClusterArgs &a, u32 c
     auto place = [&](u32 cj, u32 i, bool valid, u32 pos) {
       u32 slot; bool ins;
       const bool done = st.probeHome(cj, i, valid, insert, slot, ins);
-      hs[pos + laneU] = (u16)(valid ? slot : S);             // every lane: `none` where the lane has no entry — pass B loads and counts a chunk without looking at a length
+      *(u16 *)((char *)hs + ((pos + laneU) << 1)) = (u16)(valid ? slot : S);   // every lane: `none` where the lane has no entry — pass B loads and counts a chunk without looking at a length
+                                                             // (a 32-bit byte offset from the uniform base: no 64-bit address arithmetic per lane; a slot holds at most 2^24 handles)
       myIns += (u32)__popcll(__ballot(ins));
       const u64 bal = __ballot(!done);
       if (bal) {
@@ -1661,12 +1659,16 @@ __device__ __forceinline__ void cluster_one_block_tp(const ClusterArgs &a, u32 c
           for (u32 c = 0; c < NCH; ++c)
             if (ok[c]) {
               const int sh8 = (f[c] & 3) * 8;
-              const u32 cnt = ((atomicAdd(&segHist[f[c] >> 2], 1u << sh8) >> sh8) & 0xFFu) + 1;   // the lane that arrives last at a value sees its full count
+              u32 *const cell = &segHist[f[c] >> 2];
+              const u32 cnt = ((atomicAdd(cell, 1u << sh8) >> sh8) & 0xFFu) + 1;   // the lane that arrives last at a value sees its full count
+              if (NCH == 1) *cell = 0;                       // cleared in the exec region of its count (ds ops of a wave stay in order); two chunks: behind both counts, below
               const u32 k = (cnt << 16) | (0xFFFFu - f[c]);
               key = k > key ? k : key;
             }
+          if (NCH > 1) {
 #pragma unroll
-          for (u32 c = 0; c < NCH; ++c) if (ok[c]) segHist[f[c] >> 2] = 0;   // (ds ops of a wave stay in order: behind every count of the unit)
+            for (u32 c = 0; c < NCH; ++c) if (ok[c]) segHist[f[c] >> 2] = 0;
+          }
           key = seg_max_u32<SEGW>(key, lu);               // msMax << 16 | ~msBest: the mode, ties to the lowest rank (hash10x.c:801-806)
           const u32 bcnt = key >> 16, best = 0xFFFFu - (key & 0xFFFFu);       // (no usable entry: key 0 -> best NONE16, bcnt 0)
           const bool act = bcnt >= thr;                      // hash10x.c:807
