@@ -1043,6 +1043,15 @@ static int rh_add(RefHash *h, int key) {
     p = (p + stride) & (long)h->mask;
   }
 }
+/* test hook (tests/test_host_cpu.py, against the reference's own hash.c through oracle/_ref/refhash): hashCount() after hashAdd(HASH_INT(key)) of n keys; -1 without memory */
+int h10x_host_refhash_count(const int32_t *keys, uint64_t n) {
+  RefHash h; if (rh_init(&h)) return -1;
+  int rc = 0;
+  for (uint64_t i = 0; i < n && !rc; ++i) rc = rh_add(&h, (int)((uint32_t)keys[i] ^ 0x7FFFFFFFu));
+  const int count = rc ? -1 : h.n;
+  free(h.keys);
+  return count;
+}
 typedef struct { RefHash *h; const uint32_t *w; uint64_t n; uint32_t sel; int rc; } RhJob;
 static void *rh_job(void *a) {
   RhJob *j = (RhJob *)a;

@@ -75,6 +75,8 @@ int  h10x_session_shardGather(h10x_session *s);
 /* dimension the reference's Array reaches when elements are first touched in ascending order up to
    lastIndex, starting from initialDim (array.c:144-185) */
 int  h10x_host_array_dim(int initialDim, int elemSize, int64_t lastIndex);
+/* test hook: what the reference's HASH object (hash.c) counts after hashAdd(HASH_INT(key)) of these keys — the restatement behind --cribSummary's second figures */
+int  h10x_host_refhash_count(const int32_t *keys, uint64_t n);
 /* readFQB's chunk loop (hash10x.c:202-223) replayed on the barcode column: returns the number of
    records it would consume (honours -N), or -1 with "chunkSize too small" in err */
 int64_t h10x_host_check_chunks(const uint32_t *records, uint64_t nRecords, int N, int chunkSize, char *err, int errlen);

@@ -196,3 +196,36 @@ def test_rolling_products_equal_the_multiplies_of_hashFunc():
         for j in range(n):
             a, b = word(j) * F & M, revcomp(j) * F & M
             assert min(a, b) >> (64 - 2 * k) == min(a >> (64 - 2 * k), b >> (64 - 2 * k))
+
+
+REFHASH_GOLDEN = {(3000000, 400000, 1): 399806, (6000000, 1500000, 2): 1472343, (5000000, 3000000, 3): 2439655}     # oracle/_ref/refhash (the reference's hash.c), build container
+
+
+def _splitmix_keys(n, distinct, seed):
+    x = (np.uint64(seed) + np.arange(1, n + 1, dtype=np.uint64) * np.uint64(0x9E3779B97F4A7C15))
+    with np.errstate(over="ignore"):
+        z = (x ^ (x >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        z = z ^ (z >> np.uint64(31))
+    return (1 + (z % np.uint64(distinct))).astype(np.int32)
+
+
+@pytest.mark.parametrize("case", sorted(REFHASH_GOLDEN))
+def test_refhash_restatement_counts_like_the_reference(native, case):
+    """--cribSummary's "distinct hashes" figures are hashCount() of the reference's HASH object (hash.c), which over-counts once a table has doubled (its doubling
+    re-inserts keys with one stride for all: hash.c:123-160) — by an amount that depends on the order of insertion. host/h10x_host.c restates it (RefHash); here the
+    restatement meets the reference's own hash.c (oracle/_ref/refhash, a driver of ours around it) on seeded key sequences below and beyond the first doubling: golden
+    counts from the build container, and the live binary where it is present. The third case counts 2 439 655 keys where 2 433 166 are distinct."""
+    import ctypes
+    import subprocess
+    _hip, host = native
+    host.h10x_host_refhash_count.argtypes = [ctypes.c_void_p, ctypes.c_uint64]
+    n, distinct, seed = case
+    keys = _splitmix_keys(n, distinct, seed)
+    got = host.h10x_host_refhash_count(keys.ctypes.data, n)
+    assert got == REFHASH_GOLDEN[case]
+    if case == (5000000, 3000000, 3):
+        assert got > np.unique(keys).size == 2433166
+    exe = os.path.join(orc.REF_DIR, "refhash")
+    if os.path.exists(exe):
+        assert int(subprocess.run([exe, str(n), str(distinct), str(seed)], stdout=subprocess.PIPE, check=True).stdout) == got
