@@ -696,7 +696,7 @@ __device__ __forceinline__ void cluster_one_block(const ClusterArgs &a, u32 code
   code = (u32)__builtin_amdgcn_readfirstlane((int)code);     // (the block number reaches every lane through LDS: say that it is uniform)
   const u32 n = (u32)__builtin_amdgcn_readfirstlane((int)a.nGood[code]);
   if (n == 0) return;                                        // hash10x.c:780: block left untouched
-  const u64 o = a.blockOff[code];
+  const u64 o = a.blockOff[code];                            // (made scalar with readfirstlane as in the packed form: dense unchanged, ranked 0.8 % slower — left as it is)
   constexpr bool FIRST_LDS = IN_LDS && FIRST_MODE != 2;
   constexpr bool RANKED = IN_LDS && FIRST_MODE == 1;
   const u32 bmWords = RANKED ? (a.nBlocksFirst + 31) / 32 : 0;
@@ -1362,7 +1362,8 @@ __device__ __forceinline__ void cluster_one_block_tp(const ClusterArgs &a, u32 c
   code = (u32)__builtin_amdgcn_readfirstlane((int)code);
   const u32 n = (u32)__builtin_amdgcn_readfirstlane((int)a.nGood[code]);
   if (n == 0) return;                                        // hash10x.c:780: block left untouched
-  const u64 o = a.blockOff[code];
+  u64 o = a.blockOff[code];
+  o = ((u64)(u32)__builtin_amdgcn_readfirstlane((int)(u32)(o >> 32)) << 32) | (u64)(u32)__builtin_amdgcn_readfirstlane((int)(u32)o);   // (uniform: say so — the pointers formed from it are then scalar)
   const u32 lcode = code; code = a.segs.globalOf(lcode);     // from here on `code` is the global barcode number (what the lists hold)
   u32 S, S2, nW; bool compactUnused;
   translatedShape(n, CL_WAVES, a.ldsBudget, a.hashMinSlots, a.entries[lcode], a.nBlocksFirst, a.firstCap, S, S2, nW, compactUnused);
@@ -1379,12 +1380,9 @@ __device__ __forceinline__ void cluster_one_block_tp(const ClusterArgs &a, u32 c
   const u64 *const gr = a.goodRow + o;
   u32 thr = (u32)a.threshold;
   asm volatile("" : "+s"(thr));
-  // Where this block's result words go: kept in LDS, fetched where a result is written. As a kernel-long value the pointer ended up in a spilled VGPR pair, and its reload
-  // in pass B's writer branch brought an s_waitcnt vmcnt(0) with it — a wait for the handle loads just issued for the next round (ISA, round 5). An LDS read waits for LDS only.
-  typedef __attribute__((address_space(3))) u32 lds_u32;
-  if (tid == 0) { const u64 rp = (u64)(a.res + o); sh[16] = (u32)rp; sh[17] = (u32)(rp >> 32); a.res[o] = RES_PACK(NONE16, 0, 0); }
-  auto resPtr = [&]() { volatile lds_u32 *const q = (volatile lds_u32 *)(lds_u32 *)&sh[16];
-                        return (u64 *)(((u64)(u32)__builtin_amdgcn_readfirstlane((int)q[1]) << 32) | (u64)(u32)__builtin_amdgcn_readfirstlane((int)q[0])); };
+  // (the result words go to a.res + o, formed where a result is written: as a kernel-long value of a NON-scalar o the pointer once sat in a spilled VGPR pair, and its reload in
+  //  pass B's writer branch brought an s_waitcnt vmcnt(0) with it — a wait for the handle loads just issued for the next round)
+  if (tid == 0) a.res[o] = RES_PACK(NONE16, 0, 0);
   u16 *const hs = a.handles + (size_t)blockIdx.x * a.handleStride;
   const u32 hst = a.hStride;
   const u32 uwave = (u32)__builtin_amdgcn_readfirstlane(wave);
@@ -1393,7 +1391,7 @@ __device__ __forceinline__ void cluster_one_block_tp(const ClusterArgs &a, u32 c
   // ---- the table of pass A is cleared, and meanwhile the classes are counted: ranks ascend in list length, so `lists of at most L entries` is a rank
   u32 *const tab = (u32 *)region;
   for (u32 i = tid; i <= S; i += CL_THREADS) tab[i] = 0xFFFFFFFFu;   // (+ the word of handle `none`)
-  if (tid < 8) sh[tid] = 0;                                  // [0] entries left for the second table, [1] barcodes in the first, [2] a table overflowed, [4..7] class counts; [16] [17] the result pointer
+  if (tid < 8) sh[tid] = 0;                                  // [0] entries left for the second table, [1] barcodes in the first, [2] a table overflowed, [4..7] class counts
   SYNC();
   {
     u32 c16 = 0, c32 = 0, c64 = 0, c128 = 0;                 // (uniform)
@@ -1678,7 +1676,7 @@ __device__ __forceinline__ void cluster_one_block_tp(const ClusterArgs &a, u32 c
 #pragma unroll
           for (u32 c = 0; c < NCH; ++c) q += seg_popc<SEGW>(__ballot(f[c] == rb), lu);
           if (rb == NONE16) q = 0;
-          if (live && jl == 0) { root[r] = (u16)(act ? rb : r); resPtr()[r] = RES_PACK(act ? best : (u32)NONE16, q, tot); }
+          if (live && jl == 0) { root[r] = (u16)(act ? rb : r); (a.res + o)[r] = RES_PACK(act ? best : (u32)NONE16, q, tot); }
         }
       }
     };
@@ -1697,7 +1695,7 @@ __device__ __forceinline__ void cluster_one_block_tp(const ClusterArgs &a, u32 c
         if (bcnt >= thr) { rb = root[best]; if (rb != NONE16) { u32 t2; q = row_count_value(hrow, d, code, i, ft, rb, t2); } }
       }
       const bool act = bcnt >= thr;
-      if (lane == 0) { root[i] = (u16)(act ? rb : i); resPtr()[i] = RES_PACK(act ? best : (u32)NONE16, q, tot); }
+      if (lane == 0) { root[i] = (u16)(act ? rb : i); (a.res + o)[i] = RES_PACK(act ? best : (u32)NONE16, q, tot); }
     }
   }
   STAMP(4);
@@ -1721,7 +1719,7 @@ __device__ __forceinline__ void cluster_one_block_tp(const ClusterArgs &a, u32 c
     }
     SYNC();
     const u32 nTodo = sh[2];
-    u64 *const res = resPtr();
+    u64 *const res = a.res + o;
     if (a.phase && tid == 0) { atomicAdd((u64 *)&a.phase[6], (u64)nTodo); atomicAdd((u64 *)&a.phase[7], (u64)n); }   // diagnostic: ranks settled behind the loop / ranks
     for (u32 k = tid; k < nTodo; k += CL_THREADS) {
       const u32 i = todo[k];
