@@ -154,12 +154,13 @@ __global__ void priv_insert_kernel(const u64 *__restrict__ hashValue, u32 hashNu
       if (atomicCAS((unsigned long long *)&table[slot], (unsigned long long)SLOT_EMPTY64, (unsigned long long)(((u64)i << 32) | low | d)) == SLOT_EMPTY64) break;
   }
 }
-__device__ __forceinline__ u32 priv_find(const u64 *__restrict__ table, int T, u64 q, const u32 *__restrict__ hashIndex, const u64 *__restrict__ hashValue, int B, u64 w) {
+// (e0: the entry at the home slot, read by the caller — who has the home reads of all its entries in flight together)
+__device__ __forceinline__ u32 priv_find(const u64 *__restrict__ table, int T, u64 q, const u32 *__restrict__ hashIndex, const u64 *__restrict__ hashValue, int B, u64 w, u64 e0) {
   const u64 mask = ((u64)1 << T) - 1;
   const u32 want = (u32)((q >> T) << 8);
   u64 slot = q & mask;
   for (u32 d = 0; d < PRIV_MAX_DISP; ++d, slot = (slot + 1) & mask) {
-    const u64 e = table[slot];
+    const u64 e = d ? table[slot] : e0;
     if ((u32)e == (want | d)) return (u32)(e >> 32);
     if (e == SLOT_EMPTY64) break;                            // (not behind an empty slot of its probe sequence — unless it was never put in)
   }
@@ -219,6 +220,90 @@ int stageB_blockClassLists(Ctx *c, DevBuf<u32> &lists, DevBuf<u32> &counts) {
   return 0;
 }
 
+// A block's entries ordered by hash index in ONE counting pass (round 5; rocPRIM's block radix sort took four 8-bit passes over the 29-bit indices and was 2/3 of
+// clushash_build — the look-ups inside the kernel already ran at the chip's random-read rate). What the keys of a block look like (scratch/r5_bucket_stats.py):
+//   * they are distinct (a barcode's mosh set holds a hash once);
+//   * the hashes FIRST seen in this barcode got consecutive indices (stage B numbers by first barcode, then hash): 8-17 % of the entries, nearly all of them in the
+//     first barcodes of a file, form a run of consecutive integers that ends at the block's largest key — their place follows from their value alone;
+//   * the rest is spread over [1, run start) with a bias towards low indices (repeats are met early): cut into NB buckets by a shift, a key shares its bucket with 8
+//     others on average (the largest bucket of a block: 20-70 keys).
+// So: largest key -> bitmap of (largest - key) -> length of the top run (first clear bit); the other keys are counted into buckets (returning LDS add = arrival rank),
+// the counts scanned, the keys dropped into their bucket's range, and every key finds its rank by comparing with the keys of its bucket. Equal keys (cannot happen on
+// consistent data) are ordered by arrival, so the result is a permutation whatever comes in. In: striped or any arrangement, n valid entries (entry e = j * THREADS + tid
+// valid iff e < n); out: sorted, striped.
+template <int THREADS, int IPT> struct BlockIndexSort {
+  static constexpr int CAP = THREADS * IPT;
+  static constexpr int NB = 4096, LOGNB = 12;               // (64 KB of static LDS at most: 16 KB of counters beside 6 bytes per entry)
+  static constexpr int CPT = NB / THREADS;                   // counters per lane in the scan
+  static constexpr int WAVES = THREADS / WAVE;
+  struct Storage { u32 cnt[NB + 4]; u32 key[CAP]; u16 val[CAP]; u32 bm[CAP / 32]; u32 waveTot[WAVES]; u32 kmax, firstZero; };
+  __device__ __forceinline__ static void sort(u32 (&k)[IPT], u32 (&v)[IPT], u32 n, Storage &s) {
+    const u32 tid = threadIdx.x, lane = tid & (WAVE - 1), wave = tid / WAVE;
+#pragma unroll
+    for (int i = 0; i < CPT; ++i) s.cnt[(u32)i * THREADS + tid] = 0;
+    if (tid < 4) s.cnt[NB + tid] = 0;
+    if (tid < CAP / 32) s.bm[tid] = 0;
+    if (tid == 0) { s.kmax = 0; s.firstZero = CAP; }
+    u32 m = 0;
+#pragma unroll
+    for (int j = 0; j < IPT; ++j) if ((u32)j * THREADS + tid < n) m = k[j] > m ? k[j] : m;
+#pragma unroll
+    for (int d = 32; d; d >>= 1) { const u32 o2 = (u32)__shfl_xor((int)m, d); m = o2 > m ? o2 : m; }
+    __syncthreads();
+    if (lane == 0) atomicMax(&s.kmax, m);
+    __syncthreads();
+    const u32 kmax = s.kmax;
+#pragma unroll
+    for (int j = 0; j < IPT; ++j) if ((u32)j * THREADS + tid < n) { const u32 d = kmax - k[j]; if (d < (u32)CAP) atomicOr(&s.bm[d >> 5], 1u << (d & 31)); }
+    __syncthreads();
+    if (tid < CAP / 32) { const u32 w = ~s.bm[tid]; if (w) atomicMin(&s.firstZero, tid * 32 + (u32)__ffs((int)w) - 1u); }
+    __syncthreads();
+    const u32 run = s.firstZero;                              // keys with kmax - key < run are the top run; kmax - run is in no entry
+    const u32 lim = kmax >= run ? kmax - run : 0;             // the other keys are below this
+    const int sh = lim > (u32)NB ? (32 - __clz((int)(lim - 1))) - LOGNB : 0;      // (lim - 1) >> sh < NB
+    u32 r[IPT];
+#pragma unroll
+    for (int j = 0; j < IPT; ++j) { r[j] = 0; if ((u32)j * THREADS + tid < n && kmax - k[j] > run) r[j] = atomicAdd(&s.cnt[k[j] >> sh], 1u); }
+    __syncthreads();
+    {                                                         // exclusive scan of the counts, in place; cnt[NB] = their sum
+      u32 c[CPT], t = 0;
+#pragma unroll
+      for (int i = 0; i < CPT; ++i) { c[i] = s.cnt[tid * CPT + (u32)i]; t += c[i]; }
+      u32 inc = t;
+#pragma unroll
+      for (int d = 1; d < WAVE; d <<= 1) { const u32 o2 = (u32)__shfl_up((int)inc, d); if (lane >= (u32)d) inc += o2; }
+      if (lane == WAVE - 1) s.waveTot[wave] = inc;
+      __syncthreads();
+      u32 base = inc - t;
+      for (u32 q = 0; q < wave; ++q) base += s.waveTot[q];
+#pragma unroll
+      for (int i = 0; i < CPT; ++i) { s.cnt[tid * CPT + (u32)i] = base; base += c[i]; }
+      if (tid == THREADS - 1) s.cnt[NB] = base;
+      __syncthreads();
+    }
+#pragma unroll
+    for (int j = 0; j < IPT; ++j) if ((u32)j * THREADS + tid < n && kmax - k[j] > run) { r[j] += s.cnt[k[j] >> sh]; s.key[r[j]] = k[j]; }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < IPT; ++j) if ((u32)j * THREADS + tid < n) {
+      const u32 d = kmax - k[j];
+      if (d < run) r[j] = n - 1u - d;
+      else {
+        const u32 b = k[j] >> sh, st = s.cnt[b], en = s.cnt[b + 1];
+        u32 rank = 0;
+        for (u32 q = st; q < en; ++q) { const u32 x = s.key[q]; rank += (x < k[j] || (x == k[j] && q < r[j])) ? 1u : 0u; }
+        r[j] = st + rank;
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < IPT; ++j) if ((u32)j * THREADS + tid < n) { s.key[r[j]] = k[j]; s.val[r[j]] = (u16)v[j]; }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < IPT; ++j) { const u32 e = (u32)j * THREADS + tid; if (e < n) { k[j] = s.key[e]; v[j] = s.val[e]; } }
+  }
+};
+
 template <int THREADS, int IPT, bool LOOKUP>
 __global__ __launch_bounds__(THREADS)
 void clushash_block_kernel(const u64 *__restrict__ entHash /* hash / w */, const u32 *__restrict__ entRead, const u64 *__restrict__ key /* !LOOKUP: index << 32 | read */,
@@ -226,8 +311,8 @@ void clushash_block_kernel(const u64 *__restrict__ entHash /* hash / w */, const
                            const u64 *__restrict__ table64, int B, u64 w, int qBits, int cb /* packed entries */, int sortBits,
                            h10x_clushash *__restrict__ out, int privT = 0 /* > 0: table64 is the private table of 2^privT slots (priv_find) */,
                            const u32 *__restrict__ hashIndex = nullptr, const u64 *__restrict__ hashValue = nullptr) {
-  using Sort = rocprim::block_radix_sort<u32, THREADS, IPT, u32>;
-  __shared__ typename Sort::storage_type storage;
+  using Sort = BlockIndexSort<THREADS, IPT>;
+  __shared__ typename Sort::Storage storage;
   const u32 nList = *count;
   for (u32 wi = blockIdx.x; wi < nList; wi += gridDim.x) {
     const u32 c = list[wi];
@@ -236,26 +321,49 @@ void clushash_block_kernel(const u64 *__restrict__ entHash /* hash / w */, const
     const u32 n = (u32)n64;
     u32 k[IPT], v[IPT];
     const u64 mask = ((u64)1 << B) - 1, qmask = qBits >= 64 ? ~0ULL : ((u64)1 << qBits) - 1;
+    if (LOOKUP) {
+      // the first probe of every entry of the lane is issued before any is looked at: met one entry at a time (a probe loop per entry) a lane waited for IPT random
+      // reads in a row — 6 x 3 us of a block's 29 us on the 1/10 3 Gb set, the look-ups then ran at 36 G/s where the chip does 55-59 G/s
+      // (entries past the block's end read its last entry: loads without a branch around them — a predicated load is a branch and a wait of its own — and the same
+      // table slot for all of them, i.e. one request)
+      u64 q[IPT];
 #pragma unroll
-    for (int j = 0; j < IPT; ++j) {
-      const u32 e = (u32)j * THREADS + threadIdx.x;
-      k[j] = 0xFFFFFFFFu; v[j] = 0;
-      if (e < n) {
-        if (LOOKUP) {
-          const u64 q = entHash[o + e] >> cb, h = q * w;
-          if (privT) k[j] = priv_find(table64, privT, q, hashIndex, hashValue, B, w);   // (uniform)
-          else {
-            u64 slot = h & mask; const u64 step = ((h >> B) & mask) | 1;
-            u64 t;
-            while ((t = table64[slot]) != SLOT_EMPTY64 && (t & qmask) != q) slot = (slot + step) & mask;
-            k[j] = t == SLOT_EMPTY64 ? 0u : (u32)(t >> qBits);
+      for (int j = 0; j < IPT; ++j) { const u32 e = (u32)j * THREADS + threadIdx.x; q[j] = entHash[o + (e < n ? e : n - 1)] >> cb; }
+#pragma unroll
+      for (int j = 0; j < IPT; ++j) { const u32 e = (u32)j * THREADS + threadIdx.x; v[j] = entRead[o + (e < n ? e : n - 1)] & 0xFFFFu; }   // ClusterHash.read is U16 (hash10x.c:37,180)
+      constexpr int LKG = IPT;                            // (groups of 2: the same; the chip's rate of random reads bounds the phase either way)
+#pragma unroll
+      for (int j0 = 0; j0 < IPT; j0 += LKG) {
+        u64 t[LKG];
+#pragma unroll
+        for (int g = 0; g < LKG; ++g) { const int j = j0 + g < IPT ? j0 + g : IPT - 1; t[g] = table64[privT ? (q[j] & (((u64)1 << privT) - 1)) : ((q[j] * w) & mask)]; }
+#pragma unroll
+        for (int g = 0; g < LKG; ++g) {
+          const int j = j0 + g;
+          if (j < IPT) {
+            const u32 e = (u32)j * THREADS + threadIdx.x;
+            u32 kk;
+            if (privT) kk = priv_find(table64, privT, q[j], hashIndex, hashValue, B, w, t[g]);   // (uniform)
+            else {
+              const u64 h = q[j] * w; u64 slot = h & mask; const u64 step = ((h >> B) & mask) | 1;
+              u64 tt = t[g];
+              while (tt != SLOT_EMPTY64 && (tt & qmask) != q[j]) { slot = (slot + step) & mask; tt = table64[slot]; }
+              kk = tt == SLOT_EMPTY64 ? 0u : (u32)(tt >> qBits);
+            }
+            k[j] = e < n ? kk : 0xFFFFFFFFu;
           }
-          v[j] = entRead[o + e] & 0xFFFFu;                   // ClusterHash.read is U16 (hash10x.c:37,180)
-        } else { const u64 t = key[o + e]; k[j] = (u32)(t >> 32); v[j] = (u32)t & 0xFFFFu; }
+        }
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < IPT; ++j) {
+        const u32 e = (u32)j * THREADS + threadIdx.x;
+        k[j] = 0xFFFFFFFFu; v[j] = 0;
+        if (e < n) { const u64 t = key[o + e]; k[j] = (u32)(t >> 32); v[j] = (u32)t & 0xFFFFu; }
       }
     }
     __syncthreads();                                         // the storage of the previous block's sort is free again
-    Sort().sort_to_striped(k, v, storage, 0, sortBits & 63); // padding keys are all ones in sortBits bits: behind every index
+    Sort::sort(k, v, n, storage);
 #pragma unroll
     for (int j = 0; j < IPT; ++j) {
       const u32 e = (u32)j * THREADS + threadIdx.x;          // sorted, striped arrangement: a wave's store covers 512 contiguous bytes

@@ -125,10 +125,20 @@ void good_block_kernel(const h10x_clushash *__restrict__ ch, const u64 *__restri
     // position in one key needed three) leaves equal depths in ascending position
     u32 k[IPT]; u64 v[IPT]; u32 mine = 0; unsigned long long myDepth = 0;
 #pragma unroll
-    for (int j = 0; j < IPT; ++j) {
-      const u32 p = threadIdx.x * IPT + (u32)j;
-      k[j] = 0xFFFFFFFFu; v[j] = p;
-      if (p < nHash) { const u64 ri = rowInfo[ch[o + p].hash]; const u32 wd = (u32)(ri >> 32); if (wd) { k[j] = wd - 1; ++mine; myDepth += wd - 1; v[j] = (u64)p | ((ri & 0xFFFFFFFFull) << 16); } }   // value: position (16 bits: blocks of at most BLOCK_SORT_MAX entries) | list offset << 16
+    for (int j = 0; j < IPT; ++j) { k[j] = 0xFFFFFFFFu; v[j] = threadIdx.x * IPT + (u32)j; }
+    if (nHash) {
+      // (positions past the block's end read its last record: loads without a branch around them — written as `if (p < nHash) load` every entry was a branch, a load and a
+      // wait of its own, twelve memory latencies in a row per lane — the IPT records and then the IPT look-ups are in flight together)
+      u32 hs[IPT]; u64 ri[IPT];
+#pragma unroll
+      for (int j = 0; j < IPT; ++j) { const u32 p = threadIdx.x * IPT + (u32)j; hs[j] = ch[o + (p < nHash ? p : nHash - 1)].hash; }
+#pragma unroll
+      for (int j = 0; j < IPT; ++j) ri[j] = rowInfo[hs[j]];
+#pragma unroll
+      for (int j = 0; j < IPT; ++j) {
+        const u32 p = threadIdx.x * IPT + (u32)j; const u32 wd = (u32)(ri[j] >> 32);
+        if (p < nHash && wd) { k[j] = wd - 1; ++mine; myDepth += wd - 1; v[j] = (u64)p | ((ri[j] & 0xFFFFFFFFull) << 16); }   // value: position (16 bits: blocks of at most BLOCK_SORT_MAX entries) | list offset << 16
+      }
     }
     for (int sft = 32; sft; sft >>= 1) { mine += (u32)__shfl_down((int)mine, sft); myDepth += __shfl_down(myDepth, sft); }
     if ((threadIdx.x & (WAVE - 1)) == 0 && mine) { atomicAdd(&sCount, mine); atomicAdd(&sDepth, myDepth); }
