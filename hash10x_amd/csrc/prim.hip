@@ -97,9 +97,13 @@ int prim_sort_pairs_u32_v16(Ctx *c, PrimTemp &t, const u32 *kin, u32 *kout, cons
   PRIM_TWO_PHASE(c, t, rocprim::radix_sort_pairs(tmp, bytes, kin, kout, vin, vout, n, (unsigned)b0, (unsigned)b1, c->stream));
   return 0;
 }
+// (the index build's big sort. rocPRIM's tuned default for 64-bit keys on gfx950 is 512 lanes x 12 keys; 1024 x 8 is 8-12 % faster on this chip for 36 M and 730 M keys alike
+// — scratch/r5_sort_cfg.hip, ten configurations; the library's onesweep moves 3 TB/s here either way)
+using SortKeys64Config = rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config,
+    rocprim::radix_sort_onesweep_config<rocprim::kernel_config<1024, 8>, rocprim::kernel_config<1024, 8>, 8, rocprim::block_radix_rank_algorithm::match>, 1024 * 1024>;
 int prim_sort_keys_u64(Ctx *c, PrimTemp &t, const u64 *kin, u64 *kout, size_t n, int b0, int b1) {
   if (!n) return 0;
-  PRIM_TWO_PHASE(c, t, rocprim::radix_sort_keys(tmp, bytes, kin, kout, n, (unsigned)b0, (unsigned)(b1 > 64 ? 64 : b1), c->stream));
+  PRIM_TWO_PHASE(c, t, rocprim::radix_sort_keys<SortKeys64Config>(tmp, bytes, kin, kout, n, (unsigned)b0, (unsigned)(b1 > 64 ? 64 : b1), c->stream));
   return 0;
 }
 int prim_seg_sort_keys_u64(Ctx *c, PrimTemp &t, const u64 *kin, u64 *kout, u32 n, u32 nSeg, const u32 *begin, const u32 *end, int b0, int b1) {
