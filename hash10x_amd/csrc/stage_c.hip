@@ -1859,9 +1859,16 @@ void replay_kernel(ReplayArgs a) {
     u16 *bst = (u16 *)region, *ptr = (u16 *)(region + col), *ft = (u16 *)(region + 2 * col), *fl = (u16 *)(region + 3 * col);
     SYNC();                                                  // the previous block of this workgroup is done with the region
     if (tid == 0) sh[2] = 0;
-    for (u32 i = tid; i < n; i += THREADS) {
-      const u16 m = (u16)(a.res[o + i] & 0xFFFFu);
-      bst[i] = m; ptr[i] = m != NONE16 ? m : (u16)i; ft[i] = NONE16; fl[i] = 0;
+    // (global loads four rounds at a time, the index clamped instead of a branch around the load: a loop of `if (i < n) load` waits for every load alone)
+    for (u32 i0 = tid; i0 < n; i0 += 4 * THREADS) {
+      u64 rw[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) { const u32 i = i0 + (u32)k * THREADS; rw[k] = a.res[o + (i < n ? i : n - 1)]; }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const u32 i = i0 + (u32)k * THREADS;
+        if (i < n) { const u16 m = (u16)(rw[k] & 0xFFFFu); bst[i] = m; ptr[i] = m != NONE16 ? m : (u16)i; ft[i] = NONE16; fl[i] = 0; }
+      }
     }
     SYNC();
     for (u32 i = tid; i < n; i += THREADS) {
@@ -1903,16 +1910,31 @@ void replay_kernel(ReplayArgs a) {
         if (ld_shared<IN_LDS>(&fl[i]) == 256 && (i == 0 || ld_shared<IN_LDS>(&fl[i - 1]) == 255)) sh[1] = i;
       __syncthreads();
       stop = sh[1];                                            // the terms of the turns before it stay in pointToMin
-      for (u32 i = tid; i < n; i += THREADS) ch[g[i]].subCluster = 0;
+      for (u32 i0 = tid; i0 < n; i0 += 4 * THREADS) {
+        u32 gp[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { const u32 i = i0 + (u32)k * THREADS; gp[k] = g[i < n ? i : n - 1]; }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) if (i0 + (u32)k * THREADS < n) ch[gp[k]].subCluster = 0;
+      }
       if (tid == 0) { a.blocks[c].nSubCluster = 0; a.raw[2 * (size_t)c] = 0x80000000u; a.raw[2 * (size_t)c + 1] = 0; }   // (nSubClustered is reset with the labels: hash10x.c:811)
     } else {
       u32 labelled = 0;
-      for (u32 i = tid; i < n; i += THREADS) {
-        u32 L = 0;
-        if (ld_shared<IN_LDS>(&bst[i]) != NONE16) { const u32 rt = ld_shared<IN_LDS>(&ptr[i]); const u32 t = rt < n ? (u32)ld_shared<IN_LDS>(&ft[rt]) : NONE16; L = t != NONE16 ? (u32)ld_shared<IN_LDS>(&fl[t]) : 0u; }
-        else { const u32 t = ld_shared<IN_LDS>(&ft[i]); if (t != NONE16) L = ld_shared<IN_LDS>(&fl[t]); }
-        ch[g[i]].subCluster = (u8)L;                         // includes the wipe of hash10x.c:783
-        labelled += L != 0;
+      for (u32 i0 = tid; i0 < n; i0 += 4 * THREADS) {
+        u32 gp[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { const u32 i = i0 + (u32)k * THREADS; gp[k] = g[i < n ? i : n - 1]; }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const u32 i = i0 + (u32)k * THREADS;
+          if (i < n) {
+            u32 L = 0;
+            if (ld_shared<IN_LDS>(&bst[i]) != NONE16) { const u32 rt = ld_shared<IN_LDS>(&ptr[i]); const u32 t = rt < n ? (u32)ld_shared<IN_LDS>(&ft[rt]) : NONE16; L = t != NONE16 ? (u32)ld_shared<IN_LDS>(&fl[t]) : 0u; }
+            else { const u32 t = ld_shared<IN_LDS>(&ft[i]); if (t != NONE16) L = ld_shared<IN_LDS>(&fl[t]); }
+            ch[gp[k]].subCluster = (u8)L;                    // includes the wipe of hash10x.c:783
+            labelled += L != 0;
+          }
+        }
       }
       for (int sft = 32; sft; sft >>= 1) labelled += (u32)__shfl_down((int)labelled, sft);
       if (lane == 0 && labelled) atomicAdd(&sh[2], labelled);
@@ -1921,10 +1943,16 @@ void replay_kernel(ReplayArgs a) {
     }
     // the ranks' pointToMin terms (hash10x.c:821): one IEEE double divide per active rank, written over its result word
     double *term = (double *)(a.res + o);
-    for (u32 i = tid; i < n; i += THREADS) {
-      const u64 r = a.res[o + i];
-      const bool has = i >= 1 && i < stop && (u32)(r & 0xFFFFu) != NONE16;
-      term[i] = has ? (double)(int)(u32)((r >> 16) & 0xFFFFFFu) / (double)(int)(u32)(r >> 40) : 0.0;
+    for (u32 i0 = tid; i0 < n; i0 += 4 * THREADS) {
+      u64 rw[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) { const u32 i = i0 + (u32)k * THREADS; rw[k] = a.res[o + (i < n ? i : n - 1)]; }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const u32 i = i0 + (u32)k * THREADS; const u64 r = rw[k];
+        const bool has = i >= 1 && i < stop && (u32)(r & 0xFFFFu) != NONE16;
+        if (i < n) term[i] = has ? (double)(int)(u32)((r >> 16) & 0xFFFFFFu) / (double)(int)(u32)(r >> 40) : 0.0;
+      }
     }
   }
 }
@@ -1990,7 +2018,7 @@ void read_merge_kernel(h10x_block *__restrict__ blocks, const u64 *__restrict__ 
   constexpr int MERGE_KEEP = 8;
   h10x_clushash keep[MERGE_KEEP];
 #pragma unroll
-  for (int j = 0; j < MERGE_KEEP; ++j) { const u32 p = tid + j * MERGE_THREADS; if (p < nHash) keep[j] = ch[p]; }
+  for (int j = 0; j < MERGE_KEEP; ++j) { const u32 p = tid + j * MERGE_THREADS; keep[j] = ch[p < nHash ? p : nHash - 1]; }   // (clamped, not predicated: the loads are in flight together; nSub != 0 => nHash >= 1)
 #define H10X_FOR_ENTRIES(...)                                                                                          \
   { _Pragma("unroll") for (int j = 0; j < MERGE_KEEP; ++j) { const u32 p = tid + j * MERGE_THREADS; if (p < nHash) { const h10x_clushash e = keep[j]; __VA_ARGS__ } } \
     for (u32 p = tid + MERGE_KEEP * MERGE_THREADS; p < nHash; p += MERGE_THREADS) { const h10x_clushash e = ch[p]; __VA_ARGS__ } }
