@@ -226,6 +226,7 @@ struct Ctx {
   int64_t optNoPack = 0;      // index build with separate key / block arrays even where the packed form fits (A/B, tests)
   int64_t optNarrowFirst = 0; // first[] of the cluster kernel at 2 bytes per entry in every block (default: 4 where the block's working set leaves room)
   int64_t optTrEstDiv = 0;    // tuning knob: translated placement, classification: a block's barcodes estimated as entries / this (0 = 6)
+  int64_t optTrClassT = -1;   // packed translated placement: -1 / 1 = lists of 65 .. 96 entries run two to a unit (a whole chunk each + one shared by their tails: class T), 0 = as class D, a unit of two chunks each (A/B, tests)
   int64_t optTrPacked = -1;   // translated placement of the cluster kernel: -1 / 1 = packed (several lists per wave instruction), 0 = one list per wave instruction (round 4's form: A/B, tests)
   int64_t optStamps = 0;      // diagnostic: per-phase wall-clock stamps in cluster_kernel
   int64_t optChunk = 0;       // -c <chunkSize> of the reference's readFQB loop (hash10x.c:202-223): 0 = no chunk semantics (no "chunkSize too small", no

@@ -272,6 +272,7 @@ struct ClusterArgs {
   u64 *stats;                                               // [0] sum good, [1] sum good depth, [2] sum nHash, [3] codes
   u64 *phase;                                               // diagnostic per-phase ticks (null = off)
   u32 narrowFirst;                                          // test / A-B knob: keep first[] at 2 bytes per entry in every block
+  u32 tpClassT;                                             // packed translated placement: class T (lists of 65 .. 96 entries, two to a unit of three chunks) in use
 };
 
 // Working set of the list loop inside a region (LDS or HBM scratch). Since round 3 the per-rank arrays of the reference's
@@ -1330,13 +1331,22 @@ __device__ __forceinline__ void cluster_one_block_tr(const ClusterArgs &a, u32 c
 // a third of the lanes in use where the depth range is 6-45), and the units of a round carry no branches, so their LDS round trips overlap.
 // Handles lie packed in the same order on the workgroup's HBM slot: class Q at 16 u16 per rank, H 32, F 64, D 128, X the slot's stride;
 // pass B loads a unit's 64 handles with one coalesced load and needs no list descriptor at all (pass A writes `none` where a lane has no entry).
-struct TpShape { u32 m16, m32, m64, m128, posH, posF, posD, posX; };
+// Class T (round 5, last): lists of 65 .. 96 entries — four in five of all lists where the depth range is 30 - 100 and the homozygous peak sits in the eighties
+// (BASELINE configs[2]: scratch/r5_c3_lengths.py) — run TWO to a unit of THREE chunks: a whole chunk for the first 64 entries of each and one chunk shared by their tails
+// (lanes 0-31 the first list's entries 64 .. 95, lanes 32-63 the second's). As class D they took two chunks each, the second one a quarter full: 22 % fewer chunks
+// on that set, lanes in use 66 % -> 85 %. Handles: 192 u16 per unit (first list | second list | tails); both lists count in the wave's one histogram region, one after the other.
+struct TpShape { u32 m16, m32, m64, m96, m128, posH, posF, posT, posD, posX; };
 __device__ __forceinline__ u32 tpPos(const TpShape &s, u32 i, u32 hst) {        // where the handles of rank i start
   if (i < s.m16) return 16u * i;
   if (i < s.m32) return s.posH + 32u * (i - s.m16);
   if (i < s.m64) return s.posF + 64u * (i - s.m32);
-  if (i < s.m128) return s.posD + 128u * (i - s.m64);
+  if (i < s.m96) { const u32 k = i - s.m64; return s.posT + 192u * (k >> 1) + 64u * (k & 1u); }
+  if (i < s.m128) return s.posD + 128u * (i - s.m96);
   return s.posX + hst * (i - s.m128);
+}
+__device__ __forceinline__ u32 tpPos64(const TpShape &s, u32 i, u32 hst) {      // where the handles of rank i's entries 64 .. start (class T: in the unit's third chunk)
+  if (i >= s.m64 && i < s.m96) { const u32 k = i - s.m64; return s.posT + 192u * (k >> 1) + 128u + 32u * (k & 1u); }
+  return tpPos(s, i, hst) + 64u;
 }
 // maximum over the lanes of a segment (16, 32 or 64 lanes), handed to every lane of the segment: DPP prefix maxima inside the rows, row broadcasts
 // across them (as far as the segment reaches), then one LDS-crossbar permute from the segment's last lane
@@ -1367,6 +1377,7 @@ __device__ __forceinline__ void cluster_one_block_tp(const ClusterArgs &a, u32 c
 #endif
   constexpr int RIF_Q = KLASS == 2 ? H10X_TP_RIF2 : H10X_TP_RIF0, RIF_F = KLASS == 2 ? H10X_TP_RIF2 : H10X_TP_RIF0F;   // units a wave keeps in flight (classes Q, H / F, D)
   constexpr int RIF = RIF_F > RIF_Q ? RIF_F : RIF_Q;          // (the queue's margin)
+  constexpr int RIF_T = KLASS == 2 ? 3 : 2;                   // class T: units of three chunks (six / nine chunks of a wave in flight, as in class D)
   const int tid = threadIdx.x, lane = tid & (WAVE - 1), wave = tid / WAVE;
   const u32 laneU = (u32)lane;
   code = (u32)__builtin_amdgcn_readfirstlane((int)code);
@@ -1401,16 +1412,16 @@ __device__ __forceinline__ void cluster_one_block_tp(const ClusterArgs &a, u32 c
   // ---- the table of pass A is cleared, and meanwhile the classes are counted: ranks ascend in list length, so `lists of at most L entries` is a rank
   u32 *const tab = (u32 *)region;
   for (u32 i = tid; i <= S; i += CL_THREADS) tab[i] = 0xFFFFFFFFu;   // (+ the word of handle `none`)
-  if (tid < 8) sh[tid] = 0;                                  // [0] entries left for the second table, [1] barcodes in the first, [2] a table overflowed, [4..7] class counts
+  if (tid < 8) sh[tid] = 0;                                  // [0] entries left for the second table, [1] barcodes in the first, [2] a table overflowed, [3..7] class counts (96, 16, 32, 64, 128)
   SYNC();
   {
-    u32 c16 = 0, c32 = 0, c64 = 0, c128 = 0;                 // (uniform)
+    u32 c16 = 0, c32 = 0, c64 = 0, c96 = 0, c128 = 0;        // (uniform)
     for (u32 i0 = uwave * WAVE; i0 < n; i0 += CL_THREADS) {
       const u32 i = i0 + laneU;
       const u32 d = i < n ? (u32)(gr[i] >> 32) : 0xFFFFFFFFu;
-      c16 += (u32)__popcll(__ballot(d <= 16u)); c32 += (u32)__popcll(__ballot(d <= 32u)); c64 += (u32)__popcll(__ballot(d <= 64u)); c128 += (u32)__popcll(__ballot(d <= 128u));
+      c16 += (u32)__popcll(__ballot(d <= 16u)); c32 += (u32)__popcll(__ballot(d <= 32u)); c64 += (u32)__popcll(__ballot(d <= 64u)); c96 += (u32)__popcll(__ballot(d <= 96u)); c128 += (u32)__popcll(__ballot(d <= 128u));
     }
-    if (lane == 0 && c128) { atomicAdd(&sh[4], c16); atomicAdd(&sh[5], c32); atomicAdd(&sh[6], c64); atomicAdd(&sh[7], c128); }
+    if (lane == 0 && c128) { atomicAdd(&sh[4], c16); atomicAdd(&sh[5], c32); atomicAdd(&sh[6], c64); atomicAdd(&sh[3], c96); atomicAdd(&sh[7], c128); }
   }
   SYNC();
   STAMP(0);
@@ -1420,12 +1431,14 @@ __device__ __forceinline__ void cluster_one_block_tp(const ClusterArgs &a, u32 c
   u32 histBytes;                                             // per wave in pass B
   {
     const u32 c16 = sh[4], c32 = sh[5];
-    tp.m64 = sh[6]; tp.m128 = sh[7];
+    tp.m64 = sh[6]; tp.m128 = sh[7]; tp.m96 = a.tpClassT ? sh[3] : tp.m64;
+    if (tp.m96 < tp.m64) tp.m96 = tp.m64;                    // (cannot happen: counts of <= 64 and <= 96)
+    if (tp.m96 > tp.m128) tp.m96 = tp.m128;
     auto p4 = [](u32 x) { return (x + 3u) & ~3u; };
     const long fixedB = (long)pad16((size_t)n * 2) + 64;
     const long space = (long)a.ldsBudget - (long)pad16(2 * ((size_t)S + 8)) - fixedB;
     const long spaceSpill = S2 ? (long)a.ldsBudget - (long)pad16(2 * ((size_t)S + S2 + 16)) - fixedB : space;
-    const u32 nD = tp.m128 - tp.m64;
+    const u32 nD = tp.m128 - tp.m96, nT = tp.m96 - tp.m64;
     u32 bestW = 0, bestU = 1; tp.m16 = 0; tp.m32 = 0; histBytes = p4(n);
     for (int opt = 0; opt < 3; ++opt) {
       const u32 q = opt == 0 ? c16 : 0u, h = opt <= 1 ? c32 : 0u;
@@ -1433,15 +1446,16 @@ __device__ __forceinline__ void cluster_one_block_tp(const ClusterArgs &a, u32 c
       if ((long)R > spaceSpill) continue;
       u32 w = (u32)(space / (long)R); if (w > (u32)CL_WAVES) w = CL_WAVES;
       if (w < MIN_HIST_WAVES) continue;
-      const u32 units = (q + 3) / 4 + (h - q + 1) / 2 + (n - h) + nD;
+      const u32 units = (q + 3) / 4 + (h - q + 1) / 2 + (n - h) + nD + (nT + 1) / 2;   // (chunks: F one, T three to two lists, D two)
       if (!bestW || (u64)w * bestU > (u64)bestW * units) { bestW = w; bestU = units ? units : 1; tp.m16 = q; tp.m32 = h; histBytes = R; }
     }
     if (tp.m32 > tp.m64) tp.m32 = tp.m64;                    // (cannot happen: counts of <= 32 and <= 64)
     nW = bestW ? bestW : (u32)MIN_HIST_WAVES;                // (option 2 always qualifies: translatedShape left room for MIN_HIST_WAVES regions of n bytes)
     tp.posH = (16u * tp.m16 + 63u) & ~63u;
     tp.posF = tp.posH + ((32u * (tp.m32 - tp.m16) + 63u) & ~63u);
-    tp.posD = tp.posF + 64u * (tp.m64 - tp.m32);
-    tp.posX = tp.posD + 128u * (tp.m128 - tp.m64);
+    tp.posT = tp.posF + 64u * (tp.m64 - tp.m32);
+    tp.posD = tp.posT + 192u * ((tp.m96 - tp.m64 + 1u) / 2u);
+    tp.posX = tp.posD + 128u * (tp.m128 - tp.m96);
   }
   // entries whose search goes beyond the home bucket are parked — barcode | rank << 22 | position of the handle << 38 — in a queue of the wave's own
   // behind the handles on the HBM slot, and searched for with search() 64 lanes at a time when the pass is over (or the queue full). What search()
@@ -1548,10 +1562,63 @@ __device__ __forceinline__ void cluster_one_block_tp(const ClusterArgs &a, u32 c
         roundEnd(false);
       }
     };
+    // class T: two lists of 65 .. 96 entries to a unit — chunk 0 the first list's entries 0 .. 63, chunk 1 the second's, chunk 2 their tails (lanes 0-31 / 32-63)
+    auto classAT = [&](const u32 firstRank, const u32 endRank, const u32 posBase) {
+      constexpr int RIF = RIF_T;
+      const u32 nUnits = (endRank - firstRank + 1u) / 2u;
+      if (uwave * RIF >= nUnits) return;
+      constexpr u32 stepA = CL_WAVES * RIF;
+      u32 lu = laneU;
+      auto descBatch = [&](u32 u0) { const u32 i = firstRank + u0 * 2u + (lu & 31u); return ((const u32 *)gr)[2 * (size_t)(i < n ? i : n - 1) + (lu >> 5)]; };
+      u32 cN[RIF][3], lenAN[RIF], lenBN[RIF];                // (the lengths: uniform)
+      auto issue = [&](u32 dv, u32 u0) {
+#pragma unroll
+        for (int t = 0; t < RIF; ++t) {
+          const u32 loA = (u32)__builtin_amdgcn_readlane((int)dv, 2 * t), hiA = (u32)__builtin_amdgcn_readlane((int)dv, 32 + 2 * t);
+          const u32 loB = (u32)__builtin_amdgcn_readlane((int)dv, 2 * t + 1), hiB = (u32)__builtin_amdgcn_readlane((int)dv, 32 + 2 * t + 1);
+          const u32 rA = firstRank + (u0 + (u32)t) * 2u, rB = rA + 1u;
+          lenAN[t] = (rA >= 1 && rA < endRank) ? hiA : 0u;    // rank 0 is never processed (hash10x.c:789); past the class: no entries
+          lenBN[t] = rB < endRank ? hiB : 0u;
+          const u32 *rowA = ROWP(loA), *rowB = ROWP(loB);
+          cN[t][0] = rowA[lu]; cN[t][1] = rowB[lu];
+          cN[t][2] = (lu >= 32u ? rowB : rowA)[64u + (lu & 31u)];   // (rows[] has ROWS_PAD entries of slack: no lane skips a load)
+        }
+      };
+      u32 u0 = uwave * RIF;
+      u32 dvN = descBatch(u0), dvNN = descBatch(u0 + stepA);
+      issue(dvN, u0);
+      for (; u0 < nUnits; u0 += stepA) {
+        asm volatile("" : "+v"(lu));
+        u32 c0[RIF][3], lenA[RIF], lenB[RIF];
+#pragma unroll
+        for (int t = 0; t < RIF; ++t) { lenA[t] = lenAN[t]; lenB[t] = lenBN[t];
+#pragma unroll
+          for (u32 c = 0; c < 3; ++c) c0[t][c] = cN[t][c]; }
+        dvN = dvNN; dvNN = descBatch(u0 + 2 * stepA);
+        issue(dvN, u0 + stepA);
+        if (S2) {                                            // a table that may fill up: say what this wave has put in, see whether it still takes barcodes
+          if (myIns) { if (lane == 0) atomicAdd(&sh[1], myIns); myIns = 0; }
+          insert = (u32)__builtin_amdgcn_readfirstlane((int)shFill()) < closeAt;
+        }
+#pragma unroll
+        for (int t = 0; t < RIF; ++t) {
+          if (u0 + (u32)t >= nUnits) break;                  // (uniform)
+          const u32 rA = firstRank + (u0 + (u32)t) * 2u, rB = rA + 1u;
+          const bool up = lu >= 32u; const u32 jl = lu & 31u;
+          const u32 posU = posBase + (u0 + (u32)t) * 192u;
+          acc.depth += lu == 0 ? lenA[t] : (lu == 32u ? lenB[t] : 0u);
+          place(c0[t][0], rA, lu < lenA[t] && c0[t][0] != code, posU);
+          place(c0[t][1], rB, lu < lenB[t] && c0[t][1] != code, posU + 64u);
+          place(c0[t][2], up ? rB : rA, 64u + jl < (up ? lenB[t] : lenA[t]) && c0[t][2] != code, posU + 128u);
+        }
+        roundEnd(false);
+      }
+    };
     classA(std::integral_constant<u32, 16>{}, std::integral_constant<u32, 1>{}, 0u, tp.m16, 0u);
     classA(std::integral_constant<u32, 32>{}, std::integral_constant<u32, 1>{}, tp.m16, tp.m32, tp.posH);
     classA(std::integral_constant<u32, 64>{}, std::integral_constant<u32, 1>{}, tp.m32, tp.m64, tp.posF);
-    classA(std::integral_constant<u32, 64>{}, std::integral_constant<u32, 2>{}, tp.m64, tp.m128, tp.posD);
+    classAT(tp.m64, tp.m96, tp.posT);
+    classA(std::integral_constant<u32, 64>{}, std::integral_constant<u32, 2>{}, tp.m96, tp.m128, tp.posD);
     for (u32 i = tp.m128 + uwave; i < n; i += CL_WAVES) {     // class X (depth ranges beyond 128): list after list, chunk after chunk
       if (i == 0) continue;
       const u64 g2 = gr[i]; const u32 d = (u32)__builtin_amdgcn_readfirstlane((int)(u32)(g2 >> 32)); const u32 *row = ROWP((u32)__builtin_amdgcn_readfirstlane((int)(u32)g2));
@@ -1690,10 +1757,77 @@ __device__ __forceinline__ void cluster_one_block_tp(const ClusterArgs &a, u32 c
         }
       }
     };
+    // class T: the unit's two lists count in the wave's one region one after the other (ds operations of a wave stay in order: the second list's counts find the
+    // first one's cells cleared); per-list quantities are uniform — the first list's in chunk 0 and lanes 0-31 of chunk 2, the second's in chunk 1 and lanes 32-63
+    auto classBT = [&](const u32 firstRank, const u32 endRank, const u32 posBase) {
+      constexpr int RIF = RIF_T;
+      const u32 nUnits = (endRank - firstRank + 1u) / 2u;
+      if (uwave * RIF >= nUnits) return;
+      const u32 stepB = nW * RIF;
+      u32 lu = laneU;
+      u32 hN[RIF][3];
+      auto issue = [&](u32 u0) {
+#pragma unroll
+        for (int t = 0; t < RIF; ++t) { const u32 u = u0 + (u32)t < nUnits ? u0 + (u32)t : nUnits - 1;
+#pragma unroll
+          for (u32 c = 0; c < 3; ++c) hN[t][c] = hs[posBase + u * 192u + c * WAVE + lu]; }
+      };
+      auto count = [&](u32 f, bool on, u32 &key) {             // one more of value f in the region: the lane that arrives last at a value sees its full count
+        if (on) {
+          const int sh8 = (f & 3) * 8;
+          const u32 cnt = ((atomicAdd(&myHist[f >> 2], 1u << sh8) >> sh8) & 0xFFu) + 1;
+          const u32 k = (cnt << 16) | (0xFFFFu - f);
+          key = k > key ? k : key;
+        }
+      };
+      u32 u0 = uwave * RIF;
+      issue(u0);
+      for (; u0 < nUnits; u0 += stepB) {
+        asm volatile("" : "+v"(lu));
+        u32 h[RIF][3];
+#pragma unroll
+        for (int t = 0; t < RIF; ++t) {
+#pragma unroll
+          for (u32 c = 0; c < 3; ++c) h[t][c] = hN[t][c]; }
+        issue(u0 + stepB);
+#pragma unroll
+        for (int t = 0; t < RIF; ++t) {
+          if (u0 + (u32)t >= nUnits) break;                  // (uniform)
+          const u32 rA = firstRank + (u0 + (u32)t) * 2u, rB = rA + 1u;       // (uniform)
+          const bool liveA = rA >= 1, liveB = rB < endRank, up = lu >= 32u;
+          const u32 f0 = ft.peek(h[t][0]), f1 = ft.peek(h[t][1]), f2 = ft.peek(h[t][2]);   // (`none` reads 0xFFFF: never below a rank; a list that is not live has nothing but `none`)
+          const bool ok0 = f0 < rA, ok1 = f1 < rB, ok2 = f2 < (up ? rB : rA);
+          const u64 bal2 = __ballot(ok2);
+          const u32 totA = (u32)__popcll(__ballot(ok0)) + (u32)__popc((u32)bal2), totB = (u32)__popcll(__ballot(ok1)) + (u32)__popc((u32)(bal2 >> 32));
+          u32 keyA = 0, keyB = 0;
+          count(f0, ok0, keyA); count(f2, ok2 && !up, keyA);
+          if (ok0) myHist[f0 >> 2] = 0;
+          if (ok2 && !up) myHist[f2 >> 2] = 0;
+          count(f1, ok1, keyB); count(f2, ok2 && up, keyB);
+          if (ok1) myHist[f1 >> 2] = 0;
+          if (ok2 && up) myHist[f2 >> 2] = 0;
+          keyA = wave_max_u32(keyA); keyB = wave_max_u32(keyB);   // msMax << 16 | ~msBest: the mode, ties to the lowest rank (hash10x.c:801-806)
+          const u32 bcntA = keyA >> 16, bestA = 0xFFFFu - (keyA & 0xFFFFu), bcntB = keyB >> 16, bestB = 0xFFFFu - (keyB & 0xFFFFu);
+          const bool actA = bcntA >= thr, actB = bcntB >= thr;   // hash10x.c:807
+          const u32 rbvA = root[actA ? bestA : 0u], rbvB = root[actB ? bestB : 0u];
+          const u32 rbA = actA ? rbvA : (u32)NONE16;
+          const u32 rootA = actA ? rbA : rA;                 // what goes on record for the first list
+          u32 rbB = actB ? rbvB : (u32)NONE16;
+          if (actB && bestB == rA && liveA) rbB = rootA;     // the second list joins the first: its root is known here, not yet on record
+          const u64 balq = __ballot(f2 == (up ? rbB : rbA));
+          u32 qA = (u32)__popcll(__ballot(f0 == rbA)) + (u32)__popc((u32)balq), qB = (u32)__popcll(__ballot(f1 == rbB)) + (u32)__popc((u32)(balq >> 32));
+          if (rbA == NONE16) qA = 0;
+          if (rbB == NONE16) qB = 0;
+          if (liveA && lu == 0) { root[rA] = (u16)rootA; (a.res + o)[rA] = RES_PACK(actA ? bestA : (u32)NONE16, qA, totA); }
+          if (liveB && lu == 32u) { root[rB] = (u16)(actB ? rbB : rB); (a.res + o)[rB] = RES_PACK(actB ? bestB : (u32)NONE16, qB, totB); }
+        }
+      }
+    };
     classB(std::integral_constant<u32, 16>{}, std::integral_constant<u32, 1>{}, 0u, tp.m16, 0u);
     classB(std::integral_constant<u32, 32>{}, std::integral_constant<u32, 1>{}, tp.m16, tp.m32, tp.posH);
     classB(std::integral_constant<u32, 64>{}, std::integral_constant<u32, 1>{}, tp.m32, tp.m64, tp.posF);
-    classB(std::integral_constant<u32, 64>{}, std::integral_constant<u32, 2>{}, tp.m64, tp.m128, tp.posD);
+    classBT(tp.m64, tp.m96, tp.posT);
+    classB(std::integral_constant<u32, 64>{}, std::integral_constant<u32, 2>{}, tp.m96, tp.m128, tp.posD);
     for (u32 i = tp.m128 + uwave; i < n; i += nW) {          // class X
       if (i == 0) continue;
       const u32 d = (u32)__builtin_amdgcn_readfirstlane((int)(u32)(gr[i] >> 32));
@@ -1751,8 +1885,8 @@ __device__ __forceinline__ void cluster_one_block_tp(const ClusterArgs &a, u32 c
         ii[t] = (u32)__builtin_amdgcn_readfirstlane((int)(on ? (u32)todo[k0 + t] : 0u));
         qv[t] = on ? (u32)root[ii[t]] : NONE16;
         dl[t] = on ? (u32)__builtin_amdgcn_readfirstlane((int)(u32)(gr[ii[t]] >> 32)) : 0u;
-        const u16 *const hrow = hs + tpPos(tp, ii[t], hst);
-        hA[t] = laneU < dl[t] ? (u32)hrow[laneU] : S; hB[t] = WAVE + laneU < dl[t] ? (u32)hrow[WAVE + laneU] : S;   // (only the list's own entries: the neighbours in the chunk are other lists')
+        const u16 *const hrow = hs + tpPos(tp, ii[t], hst), *const hrow64 = hs + tpPos64(tp, ii[t], hst);   // (class T keeps entries 64 .. in the unit's third chunk)
+        hA[t] = laneU < dl[t] ? (u32)hrow[laneU] : S; hB[t] = WAVE + laneU < dl[t] ? (u32)hrow64[laneU] : S;   // (only the list's own entries: the neighbours in the chunk are other lists')
       }
 #pragma unroll
       for (int t = 0; t < TIF; ++t) {
@@ -2202,7 +2336,7 @@ static int cluster_local_range(Ctx *c, int codeMin, int codeMax, int threshold, 
   a.goodRow = c->goodRow.p; a.rows = c->rows.p; a.nBlocks = c->nBlocks; a.threshold = threshold;
   a.segs = c->segs; a.nBlocksFirst = nGlobal; a.rowShift = (u32)c->rowShift;
   if (c->sharded && c->optRowsFakeBase) a.rows = c->rows.p - (size_t)c->optRowsFakeBase;   // test knob: rowStart[] carries the same offset (shard_exchangeRows)
-  a.narrowFirst = (u32)c->optNarrowFirst;
+  a.narrowFirst = (u32)c->optNarrowFirst; a.tpClassT = c->optTrClassT != 0 ? 1u : 0u;
   a.maxGood = c->maxGood; a.stats = stats.p; a.res = term.p; a.entries = c->goodEntries.p;
   a.firstCap = firstCap; a.hashMinSlots = hashMinSlots;
   a.hashBits = (u32)hashBits; a.hStride = hStride;

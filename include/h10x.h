@@ -345,7 +345,8 @@ int  h10x_get_counters(h10x_ctx *ctx, h10x_counters *out);
    does not, i.e. -B 29 / 30 at k = 21), 2 = never, 3 = always and undersized (exercises its fall-back); "cluster_narrow_first" 1 = first[] of the
    cluster kernel at 2 bytes per entry in every block, w >= 2 = 4 bytes down to w list-loop waves (default 0: 4 bytes where that
    costs no wave); "cluster_tr_packed" (translated placement of first[]: -1 / 1 = several lists per wave instruction, the default; 0 = round 4's
-   one list per wave instruction), "cluster_lds_budget", "cluster_first_global", "cluster_first_cap", "cluster_big_ranks", "cluster_threads0",
+   one list per wave instruction), "cluster_tr_class_t" (packed form: -1 / 1 = lists of 65 .. 96 entries run two to a unit of three chunks, the default; 0 = one to a
+   unit of two chunks like the lists of 97 .. 128), "cluster_lds_budget", "cluster_first_global", "cluster_first_cap", "cluster_big_ranks", "cluster_threads0",
    "cluster_budget0" (placement and launch-class overrides of the tests), "cluster_stamps" (phase stamps into h10x_counters),
    "shard_row_shift", "shard_rows_fake_base" (sharded list offsets beyond 32 bits on small inputs), "shard_delta_lists" (-1 default:
    the in-range barcode lists travel delta-coded where bytes are dear — more than one rank on the host-staged TCP backend, not over xGMI; 0 never; 1 always). Unknown name: -1. */

@@ -19,7 +19,7 @@ h = hash10x_amd.Hash10x(B=wl["B"]); h.enable_timing(True)
 if os.environ.get("STAMPS"): h.set_option("cluster_stamps", 1)
 used = set()
 for s in sets:
-    for k in used: h.set_option(k, -1 if k in ("cluster_tr_packed", "shard_delta_lists", "shard_row_shift") else 0)
+    for k in used: h.set_option(k, -1 if k in ("cluster_tr_packed", "cluster_tr_class_t", "shard_delta_lists", "shard_row_shift") else 0)
     if s not in ("base", "again"):
         for kv in s.split(","):
             k, v = kv.split("="); h.set_option(k, int(v)); used.add(k)

@@ -117,15 +117,32 @@ def test_cluster_ranked_and_hashed_first_tables(workdir, mode, cap, packed):
     assert hf.blocks["nSubCluster"].sum() > 0
 
 
-@pytest.mark.parametrize("packed", [0, 1])
-def test_cluster_translated_long_lists(workdir, packed):
+@pytest.mark.parametrize("packed,class_t", [(0, 1), (1, 1), (1, 0)])
+def test_cluster_translated_long_lists(workdir, packed, class_t):
     """The translated placement on lists of every class of the packed form at once: a small genome under 400 barcodes puts hashes into 4 .. 345
-    barcodes, so one block holds lists of up to 16, 32, 64, 128 entries (Q, H, F, D: four, two, one list per wave instruction, one list in two
-    chunks) and beyond (X: the per-list loop, incl. lists of 256 entries and more — row_mode_long)."""
+    barcodes, so one block holds lists of up to 16, 32, 64, 96, 128 entries (Q, H, F, T, D: four, two, one list per wave instruction, two lists in
+    three chunks, one list in two chunks; class_t = 0: the lists of 65 .. 96 entries as class D) and beyond (X: the per-list loop, incl. lists of
+    256 entries and more — row_mode_long)."""
     orc.gen_fqb(workdir.file("x.fqb"), 100000, 400, 30000, 0.003, 45, 12.0, 150, 6000)
-    hf = _against_oracle(workdir, "x.fqb", ["-ct", 3, "--readFQB", "x.fqb", "--hashDepthRange", 4, 400, "--cluster", 1, 0], cluster_first_global=4, cluster_tr_packed=packed)
+    hf = _against_oracle(workdir, "x.fqb", ["-ct", 3, "--readFQB", "x.fqb", "--hashDepthRange", 4, 400, "--cluster", 1, 0], cluster_first_global=4, cluster_tr_packed=packed,
+                         cluster_tr_class_t=class_t)
+    d = hf.hash_depth[1: hf.hash_number]
+    assert ((d > 64) & (d <= 96)).sum() > 16                   # class T has work to do (a few lists per block here: the next test is about it)
     assert hf.blocks["nSubCluster"].sum() > 0
     assert hf.hash_depth[1: hf.hash_number].max() > 256
+
+
+@pytest.mark.parametrize("opts", [{}, {"cluster_tr_class_t": 0}, {"cluster_first_cap": 120}, {"cluster_lds_budget": 24 * 1024}, {"cluster_first_cap": 64}],
+                         ids=["default", "as_class_D", "second_tables", "few_list_waves", "tables_overflow"])
+def test_cluster_translated_class_t(workdir, opts):
+    """Class T of the packed translated placement (lists of 65 .. 96 entries two to a unit: a whole chunk each and one chunk shared by their tails — four lists in
+    five on BASELINE configs[2]): 200 barcodes that each cover ~40 % of a 30 kb genome put 400 hashes into 65 .. 96 barcodes (and a few hundred each into the
+    classes Q, H, F, D), so most blocks hold dozens of such lists, an odd number of them in half of the blocks. Also with a capped first table (second tables; the
+    ranks left open by the list loop read their handles again from the shared chunk), few list-loop waves, and tables that overflow (whole-CU class, HBM slot)."""
+    orc.gen_fqb(workdir.file("x.fqb"), 16000, 200, 30000, 0.003, 45, 12.0, 150, 6000)
+    hf = _against_oracle(workdir, "x.fqb", ["-ct", 3, "--readFQB", "x.fqb", "--hashDepthRange", 4, 130, "--cluster", 1, 0], cluster_first_global=4, **opts)
+    d = hf.hash_depth[1: hf.hash_number]
+    assert ((d > 64) & (d <= 96)).sum() > 300 and ((d > 96) & (d <= 128)).sum() > 100 and hf.blocks["nSubCluster"].sum() > 0
 
 
 def test_cluster_first_table_on_hbm_slots(workdir):
