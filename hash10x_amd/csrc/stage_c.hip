@@ -29,6 +29,7 @@
 
 namespace h10x {
 
+
 constexpr int CL_THREADS_SMALL = 1024;                     // <= 79 KB working sets, two workgroups per CU
 constexpr int CL_THREADS_HUGE = 1024;                      // the whole LDS of a CU, one workgroup per CU
 constexpr u16 NONE16 = 0xFFFF;
@@ -411,13 +412,20 @@ constexpr u32 TR_MIN_SLOTS = 1024;                             // tables are not
 constexpr u32 TR_MAX_SLOTS = 65532;                          // handles are 16 bits; slot S (<= 65532) is the handle of "no entry" and reads unseen
 struct SlotTable {
   u32 *tab; u32 NB /* buckets */, xsh /* 32 - b */, tsh; u32 *ovf; u32 hbase /* handle of the table's slot 0 */;
+  u32 base3;                                                 // the table's LDS byte address (probeHome; 0 = the table is not in LDS), kept in a scalar register
+  typedef __attribute__((address_space(3))) u32 lds_u32;
+  typedef u32 u32x4 __attribute__((ext_vector_type(4)));
+  typedef __attribute__((address_space(3))) u32x4 lds_u32x4;
   static constexpr u32 SCRAMBLE = 0x9E3779u;                 // odd: cj -> cj * SCRAMBLE mod 2^b is a bijection; 24 bits: full-rate multiply (cj < 2^22)
   static constexpr u32 MAXD = 63;
   static constexpr u32 NOTFOUND = 0xFFFFFFFFu;
   __device__ __forceinline__ void shape(u32 *t, u32 slots, u32 hashBits, u32 *o, u32 hb) {
-    tab = t; NB = slots / 4; xsh = 32 - hashBits; ovf = o; hbase = hb;
+    tab = t; NB = slots / 4; xsh = 32 - hashBits; ovf = o; hbase = hb; base3 = 0;
     const u32 lg = 31 - (u32)__clz((int)NB), x = 32 - hashBits + lg; tsh = x < 31 ? x : 31;
   }
+  // (probeHome addresses the table as LDS: the claim / minimum address is the bucket's plus the word. Kept as an opaque SCALAR the base went straight into the shift-adds —
+  //  2 vector instructions per chunk instead of 6 — and the kernel was 0.7 % SLOWER on full configs[2]: one more scalar register to spill. HISTORY §9)
+  __device__ __forceinline__ void inLds() { base3 = (u32)(size_t)(lds_u32 *)tab; }
   // minimum of the barcode's entry with rank i: returns its handle. The barcode is inserted if it is not there yet and `insert` says
   // so (ins = true then); otherwise NOTFOUND. A table without a free word within MAXD buckets of the barcode's home: *ovf = 1 (the
   // block is abandoned and re-run in the next larger class) when inserting, NOTFOUND when only looking.
@@ -457,24 +465,27 @@ struct SlotTable {
     const u32 b4 = __umulhi(x, NB) << 2;
     const u32 key = (x * NB) >> tsh;                         // displacement 0
     const u32 mine = (i << 16) | key;
-    const uint4 e4 = *(const uint4 *)&tab[b4];               // (every lane reads: a lane without an entry holds some barcode of the list all the same)
+    const u32 aBucket = base3 + (b4 << 2);
+    const u32x4 e4 = *(const lds_u32x4 *)(uintptr_t)aBucket;   // (every lane reads: a lane without an entry holds some barcode of the list all the same)
     // which word holds the barcode, else which is the first empty one (selects, no branch per word)
     const bool m0 = (e4.x & 0xFFFFu) == key, m1 = (e4.y & 0xFFFFu) == key, m2 = (e4.z & 0xFFFFu) == key, m3 = (e4.w & 0xFFFFu) == key;
     const bool z0 = e4.x == 0xFFFFFFFFu, z1 = e4.y == 0xFFFFFFFFu, z2 = e4.z == 0xFFFFFFFFu, z3 = e4.w == 0xFFFFFFFFu;
     const bool hit = m0 | m1 | m2 | m3;
     const u32 wh = m0 ? 0u : (m1 ? 1u : (m2 ? 2u : 3u)), wz = z0 ? 0u : (z1 ? 1u : (z2 ? 2u : 3u));
-    slot = b4 | (hit ? wh : wz);
+    const u32 word = hit ? wh : wz;
+    slot = b4 | word;
+    lds_u32 *const pSlot = (lds_u32 *)(uintptr_t)(aBucket + (word << 2));
     // the masks the wave's scalar unit has to form are what this code costs (the pass issues as many scalar as vector instructions): ONE flag leaves
     // the insertion branch — settled: the word was empty, or the same barcode got there first — and the minimum is queued where the flag is known
     // (round 5) two flat exec regions and no flag that lives across a branch: a claim for the lanes whose barcode is new here and that see an empty word, then ONE minimum for
     // the lanes that found their barcode — before or through the claim. (Flags set inside nested branches came back as 0 / 1 registers that were compared again to form the masks.)
     const bool claim = valid && !hit && insert && (z0 | z1 | z2 | z3);
-    u32 seen = 0x0000FFFFu;                                  // (neither empty nor anybody's key: displacement 63 with tag 1023 is never stored)
-    if (claim) seen = atomicCAS(&tab[slot], 0xFFFFFFFFu, mine);   // claim the first empty word
+    u32 seen = 0xFFFFFFFEu;                                  // (neither empty nor anybody's key: displacement 63 is never stored; -2 is an inline constant, 0xFFFF was a v_mov of a literal)
+    if (claim) { u32 expect = 0xFFFFFFFFu; __hip_atomic_compare_exchange_strong(pSlot, &expect, mine, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); seen = expect; }   // claim the first empty word
     ins = seen == 0xFFFFFFFFu;
     const bool same = (seen & 0xFFFFu) == key;               // the same barcode got there first: its rank takes part in the minimum
-    if ((valid && hit) || same) atomicMin(&tab[slot], mine); // the entry's rank: minimum with this one, looked at or not — a fire-and-forget LDS atomic per chunk costs less than
-                                                             // finding out whether a later rank got here first
+    if ((valid && hit) || same) (void)__hip_atomic_fetch_min(pSlot, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // the entry's rank: minimum with this one, looked at or not — a fire-and-forget
+                                                             // LDS atomic per chunk costs less than finding out whether a later rank got here first
     return !valid || hit || ins || same;
   }
 };
@@ -1041,7 +1052,7 @@ __device__ __forceinline__ void cluster_one_block_tr(const ClusterArgs &a, u32 c
   // a barcode that is new when the table is closed — stays in the queue, for the second table.
   unsigned long long *const queue = (unsigned long long *)(hs + a.handleStride - (size_t)CL_WAVES * TR_QUEUE * 4) + (size_t)uwave * TR_QUEUE;
   u32 qn = 0;                                                // (uniform)
-  SlotTable st; st.shape(tab, S, a.hashBits, &sh[2], 0);
+  SlotTable st; st.shape(tab, S, a.hashBits, &sh[2], 0); st.inLds();
   // the queue against table `t`: entries [qk, qn) are searched for, 64 at a time (whole batches only unless `all`); settled entries get
   // their handle, the others — barcodes that are new when the table no longer takes any — are kept at the queue's front, [0, qk)
   u32 qk = 0;
@@ -1377,7 +1388,7 @@ __device__ __forceinline__ void cluster_one_block_tp(const ClusterArgs &a, u32 c
 #endif
   constexpr int RIF_Q = KLASS == 2 ? H10X_TP_RIF2 : H10X_TP_RIF0, RIF_F = KLASS == 2 ? H10X_TP_RIF2 : H10X_TP_RIF0F;   // units a wave keeps in flight (classes Q, H / F, D)
   constexpr int RIF = RIF_F > RIF_Q ? RIF_F : RIF_Q;          // (the queue's margin)
-  constexpr int RIF_T = KLASS == 2 ? 3 : 2;                   // class T: units of three chunks (six / nine chunks of a wave in flight, as in class D)
+  constexpr int RIF_T = KLASS == 2 ? 3 : 2;                    // class T: units of three chunks (six / nine chunks of a wave in flight, as in class D)
   const int tid = threadIdx.x, lane = tid & (WAVE - 1), wave = tid / WAVE;
   const u32 laneU = (u32)lane;
   code = (u32)__builtin_amdgcn_readfirstlane((int)code);
@@ -1462,7 +1473,7 @@ __device__ __forceinline__ void cluster_one_block_tp(const ClusterArgs &a, u32 c
   // cannot settle — a barcode that is new when the table is closed — stays in the queue, for the second table.
   unsigned long long *const queue = (unsigned long long *)(hs + a.handleStride - (size_t)CL_WAVES * TR_QUEUE * 4) + (size_t)uwave * TR_QUEUE;
   u32 qn = 0, qk = 0;                                        // (uniform)
-  SlotTable st; st.shape(tab, S, a.hashBits, &sh[2], 0);
+  SlotTable st; st.shape(tab, S, a.hashBits, &sh[2], 0); st.inLds();
   auto settle = [&](const SlotTable &t, bool mayInsert, u32 fillLimit, bool all) {
     u32 k0 = qk;
     for (; all ? k0 < qn : k0 + WAVE <= qn; k0 += WAVE) {
@@ -1555,7 +1566,6 @@ __device__ __forceinline__ void cluster_one_block_tp(const ClusterArgs &a, u32 c
         for (int t = 0; t < RIF; ++t) {
           if (u0 + (u32)t >= nUnits) break;                  // (uniform) the class region ends here: what lies behind belongs to the next class
           const u32 r = firstRank + (u0 + (u32)t) * LPU + seg;
-          acc.depth += jl == 0 ? len[t] : 0u;
 #pragma unroll
           for (u32 c = 0; c < NCH; ++c) place(c0[t][c], r, jl + c * WAVE < len[t] && c0[t][c] != code, posBase + (u0 + (u32)t) * (WAVE * NCH) + c * WAVE);
         }
@@ -1606,7 +1616,6 @@ __device__ __forceinline__ void cluster_one_block_tp(const ClusterArgs &a, u32 c
           const u32 rA = firstRank + (u0 + (u32)t) * 2u, rB = rA + 1u;
           const bool up = lu >= 32u; const u32 jl = lu & 31u;
           const u32 posU = posBase + (u0 + (u32)t) * 192u;
-          acc.depth += lu == 0 ? lenA[t] : (lu == 32u ? lenB[t] : 0u);
           place(c0[t][0], rA, lu < lenA[t] && c0[t][0] != code, posU);
           place(c0[t][1], rB, lu < lenB[t] && c0[t][1] != code, posU + 64u);
           place(c0[t][2], up ? rB : rA, 64u + jl < (up ? lenB[t] : lenA[t]) && c0[t][2] != code, posU + 128u);
@@ -1623,7 +1632,6 @@ __device__ __forceinline__ void cluster_one_block_tp(const ClusterArgs &a, u32 c
       if (i == 0) continue;
       const u64 g2 = gr[i]; const u32 d = (u32)__builtin_amdgcn_readfirstlane((int)(u32)(g2 >> 32)); const u32 *row = ROWP((u32)__builtin_amdgcn_readfirstlane((int)(u32)g2));
       const u32 pos = tp.posX + hst * (i - tp.m128);
-      if (lane == 0) acc.depth += d;
       for (u32 lj = 0; lj < d; lj += WAVE) {
         const u32 cj = row[lj + laneU];
         place(cj, i, lj + laneU < d && cj != code, pos + lj);
@@ -1900,7 +1908,7 @@ __device__ __forceinline__ void cluster_one_block_tp(const ClusterArgs &a, u32 c
       }
     }
   }
-  if (tid == 0) { acc.s[3] += (u32)(gr[0] >> 32); acc.s[0] += n; acc.s[1] += a.blocks[lcode].nHash; acc.s[2] += 1; }
+  if (tid == 0) { acc.s[3] += a.entries[lcode]; acc.s[0] += n; acc.s[1] += a.blocks[lcode].nHash; acc.s[2] += 1; }   // (the work counter: the block's list entries as --hashDepthRange summed them — per chunk it was two vector instructions)
   SYNC();
   STAMP(5);
 }
