@@ -645,7 +645,7 @@ __device__ __forceinline__ u32 row_count_value(const void *__restrict__ row, u32
 }
 // lists of 256 entries and more (exotic depth ranges): re-gather per candidate
 template <typename FT>
-__device__ void row_mode_long(const void *__restrict__ row, u32 d, u32 code, u32 i, const FT &ft, u32 &best, u32 &bcnt, u32 &tot) {
+__device__ __forceinline__ void row_mode_long(const void *__restrict__ row, u32 d, u32 code, u32 i, const FT &ft, u32 &best, u32 &bcnt, u32 &tot) {
   const int lane = threadIdx.x & (WAVE - 1);
   best = NONE16; bcnt = 0; tot = 0;
   for (u32 a0 = 0; a0 < d; a0 += WAVE) {
