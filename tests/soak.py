@@ -86,6 +86,12 @@ def run(n_cases, seed, verbose=False, scale=1):
         if rng.random() < 0.2: opts["index_no_pack"] = 1
         if rng.random() < 0.3: opts["index_priv_table"] = rng.choice([1, 1, 3])
         if rng.random() < 0.25: opts["cluster_narrow_first"] = rng.choice([1, 5, 12])
+        if os.environ.get("H10X_SOAK_TRANSLATED"): opts["cluster_first_global"] = 4   # every case in the translated placement (python tests/soak.py with this set: a soak of its forms)
+        if opts.get("cluster_first_global") == 4:              # forms of the translated placement (a generator of their own: the cases of a seed stay what they were)
+            rng2 = random.Random((seed << 20) ^ case)
+            if rng2.random() < 0.3: opts["cluster_tr_class_t"] = 0
+            if rng2.random() < 0.2: opts["cluster_tr_packed"] = 0
+            if rng2.random() < 0.3: opts["cluster_threads0"] = rng2.choice([512, 768])
         tail = ["-ct", ct, "--readFQB", "x.fqb", "--hashDepthRange", lo, hi, "--cluster", 1, 0]
         simple = True
         u = rng.random()
