@@ -55,6 +55,9 @@ WORKLOADS = {
     # the same proportions at 1/10 (same coverage, same depth range): the strong-scaling mode's functional check on test boxes (two ranks on one GPU)
     "genome3g-tenth-30M": dict(pairs=30000000, barcodes=160000, genome=300000000, err=0.0005, mol=10.0, snp=150, mol_len=50000.0,
                                B=27, lo=6, hi=45, ct=5, seed=3, gen=2),
+    # the same proportions at 1/4: the virtual-rank model at a second size (how much of the modelled 8-rank step is fixed cost) — no digest, parity is pinned at 1/10 and at full size
+    "genome3g-quarter-75M": dict(pairs=75000000, barcodes=400000, genome=750000000, err=0.0005, mol=10.0, snp=150, mol_len=50000.0,
+                                 B=28, lo=6, hi=45, ct=5, seed=3, gen=2),
     "config3-tenth-20M": dict(pairs=20000000, barcodes=100000, genome=50000000, err=0.001, mol=10.0, snp=150, mol_len=50000.0,
                               B=26, lo=30, hi=100, ct=5, seed=2),
 }
