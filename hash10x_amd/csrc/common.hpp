@@ -235,6 +235,7 @@ struct Ctx {
                               // block holds chunkSize records (hash10x.c:205-208); 0 = -N ended the loop
   std::vector<u64> mergePoints; bool replayDone = false;     // records whose barcode change does NOT start a block (chunk replay; consumed by stageA_run)
   int64_t optRowShift = -1;   // testing knob: force the list alignment of the sharded rows[] (-1 = as small as the offsets allow)
+  int64_t optReplySort = 0;   // sharded index build, how an owner answers: 0 = by look-up in a table of its distinct hashes (packed entries), 1 = by scattering from the sorted order (the sort carries arrival positions; round 4's form), 2 = test: look up, then answer the old way
   int64_t optDeltaLists = -1; // in-range barcode lists travel delta-coded between ranks: -1 = where bytes are dear (more than one rank on the host-staged TCP backend; not over xGMI: DESIGN 5), 0 never, 1 always (tests)
   int64_t optRowsFakeBase = 0; // testing knob: list offsets start at this many entries (multiple of 2^rowShift) in front of the real array: 64-bit offsets on small inputs
   // streaming ingest (h10x_ingest_fqb): the record image grows on the device as the chunks arrive

@@ -677,6 +677,7 @@ int h10x_set_option(h10x_ctx *h, const char *name, int64_t value) {
   if (!strcmp(name, "chunk_eof_pass")) { h->c.optChunkEof = value ? 1 : 0; return 0; }
   if (!strcmp(name, "fault_inject")) { h->c.optFaultInject = value; return 0; }
   if (!strcmp(name, "shard_row_shift")) { if (value < -1 || value > 8) return h->c.fail("shard_row_shift must be -1..8"); h->c.optRowShift = value; return 0; }
+  if (!strcmp(name, "shard_reply_sort")) { if (value < 0 || value > 2) return h->c.fail("shard_reply_sort must be 0, 1 or 2"); h->c.optReplySort = value; return 0; }
   if (!strcmp(name, "shard_delta_lists")) { if (value < -1 || value > 1) return h->c.fail("shard_delta_lists must be -1, 0 or 1"); h->c.optDeltaLists = value; return 0; }
   if (!strcmp(name, "shard_rows_fake_base")) { if (value < 0) return h->c.fail("shard_rows_fake_base must be >= 0"); h->c.optRowsFakeBase = value; return 0; }
   return h->c.fail("unknown option %s", name);

@@ -146,6 +146,39 @@ __global__ void reply_kernel(const u32 *__restrict__ ord /* distinct ordinal per
   u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; const u64 stride = (u64)gridDim.x * blockDim.x;
   for (; i < n; i += stride) reply[q[i]] = dIndex[ord[i] + flags[i] - 1];
 }
+// Replies by LOOK-UP (round 5): the owner's distinct hashes go into a table of its own — 2^T slots >= twice their number, home = the key's low T bits, linear probing,
+// entry = index << 32 | (key >> T) << 8 | displacement (slot and entry together ARE the key: one 8-byte read per probe step; T >= keyBits - 24), the layout of the single-GPU
+// index build's private table (stage_b.hip priv_insert_kernel) — and every received entry, in ARRIVAL order, reads its index there. The sort then carries no arrival positions
+// (keys only: 16 instead of 24 bytes per entry and pass), and the transposition from hash order back to arrival order is 220 M random READS instead of reply_kernel's
+// random 4-byte WRITES, which this chip does at half the rate (1/10 3 Gb set on one rank: 7.7 ms). A key that finds no slot within 256 of its home raises *fail: the caller
+// then answers the old way.
+constexpr u32 OWNER_MAX_DISP = 256;
+constexpr u64 OWNER_EMPTY = ~0ULL;
+__global__ void owner_table_insert_kernel(const u64 *__restrict__ dHash, const u32 *__restrict__ dIndex, u32 U, int T, u64 *__restrict__ table, u32 *__restrict__ fail) {
+  const u64 mask = ((u64)1 << T) - 1;
+  for (u32 d = blockIdx.x * blockDim.x + threadIdx.x; d < U; d += gridDim.x * blockDim.x) {
+    const u64 q = dHash[d], low = (q >> T) << 8, val = (u64)dIndex[d] << 32;
+    u64 slot = q & mask; u32 disp = 0;
+    for (; disp < OWNER_MAX_DISP; ++disp, slot = (slot + 1) & mask)
+      if (atomicCAS((unsigned long long *)&table[slot], (unsigned long long)OWNER_EMPTY, (unsigned long long)(val | low | disp)) == OWNER_EMPTY) break;
+    if (disp == OWNER_MAX_DISP) *fail = 1;
+  }
+}
+__global__ void reply_lookup_kernel(const u64 *__restrict__ rKey /* arrival order: key << cb | block */, int cb, u64 n, const u64 *__restrict__ table, int T, u32 *__restrict__ reply, u32 *__restrict__ fail) {
+  u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; const u64 stride = (u64)gridDim.x * blockDim.x;
+  const u64 mask = ((u64)1 << T) - 1;
+  for (; i < n; i += stride) {
+    const u64 q = rKey[i] >> cb; const u32 want = (u32)((q >> T) << 8);
+    u64 slot = q & mask; u32 disp = 0, ix = 0;
+    for (; disp < OWNER_MAX_DISP; ++disp, slot = (slot + 1) & mask) {
+      const u64 e = table[slot];
+      if ((u32)e == (want | disp)) { ix = (u32)(e >> 32); break; }
+      if (e == OWNER_EMPTY) { disp = OWNER_MAX_DISP; break; }   // (never behind an empty slot of its probe sequence)
+    }
+    if (disp == OWNER_MAX_DISP) *fail = 1;
+    reply[i] = ix;
+  }
+}
 __global__ void scatter_key_kernel(const u32 *__restrict__ rIdx, const u32 *__restrict__ perm, const u32 *__restrict__ entRead, u64 n, u64 *__restrict__ key) {
   u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; const u64 stride = (u64)gridDim.x * blockDim.x;
   for (; i < n; i += stride) { const u32 e = perm[i]; key[e] = ((u64)rIdx[i] << 32) | (u64)(entRead[e] & 0xFFFFu); }
@@ -292,9 +325,17 @@ int shard_readFqb(Ctx *c, Comm *cm, const u32 *dRec, u64 nRec) {
   sHash.release(); sCodeG.release();
 
   // ---- 3. owner side: received runs are in rank (= barcode) order, a stable sort by hash keeps barcodes ascending
-  DevBuf<u64> oHash; DevBuf<u32> oQ; H10X_HIP(c, oHash.alloc(M)); H10X_HIP(c, oQ.alloc(M));
-  { DevBuf<u32> qio; H10X_HIP(c, qio.alloc(M)); if (M) iota_kernel<<<gridFor(M), 256, 0, st>>>(qio.p, M);
-    H10X_TRY(prim_sort_pairs_u64_u32(c, pt, rHash.p, oHash.p, qio.p, oQ.p, M, pk, pk + c->keyBits)); H10X_HIP(c, hipStreamSynchronize(st)); }
+  // (packed entries: the replies are looked up, the sort carries nothing — see reply_lookup_kernel; the arrival positions ride along only in the unpacked form and when the knob asks)
+  const bool byLookup = pk && c->optReplySort == 0 && c->keyBits <= 56;
+  DevBuf<u64> oHash; DevBuf<u32> oQ; H10X_HIP(c, oHash.alloc(M));
+  auto sortWithPositions = [&]() -> int {
+    H10X_HIP(c, oQ.alloc(M));
+    DevBuf<u32> qio; H10X_HIP(c, qio.alloc(M)); if (M) iota_kernel<<<gridFor(M), 256, 0, st>>>(qio.p, M);
+    H10X_TRY(prim_sort_pairs_u64_u32(c, pt, rHash.p, oHash.p, qio.p, oQ.p, M, pk, pk + c->keyBits)); H10X_HIP(c, hipStreamSynchronize(st));
+    return 0;
+  };
+  if (byLookup) H10X_TRY(prim_sort_keys_u64(c, pt, rHash.p, oHash.p, M, pk, pk + c->keyBits));
+  else H10X_TRY(sortWithPositions());
   H10X_HIP(c, c->oRows.alloc(M));
   if (M && !pk) gather_u32_kernel<<<gridFor(M), 256, 0, st>>>(rCode.p, oQ.p, M, c->oRows.p);
   c->tstop(T_SORT_HASH);
@@ -338,7 +379,23 @@ int shard_readFqb(Ctx *c, Comm *cm, const u32 *dRec, u64 nRec) {
 
   // ---- 5. the index of every entry goes back to the rank that sent it, in the order it was sent
   DevBuf<u32> reply, rIdx; H10X_HIP(c, reply.alloc(M)); H10X_HIP(c, rIdx.alloc(H));
-  if (M) reply_kernel<<<gridFor(M), 256, 0, st>>>(ord.p, flags.p, oQ.p, M, c->oIndex.p, reply.p);
+  bool looked = false;
+  if (byLookup && M) {
+    int T = 16; while (((u64)1 << T) < 2 * ((u64)Uo + 1) && T < 40) ++T;
+    if (T < c->keyBits - 24) T = c->keyBits - 24;
+    DevBuf<u64> table; DevBuf<u32> failFlag; u32 failed = 0;
+    H10X_HIP(c, table.alloc((size_t)1 << T)); H10X_HIP(c, failFlag.alloc(1));
+    H10X_HIP(c, hipMemsetAsync(table.p, 0xFF, ((size_t)1 << T) * 8, st)); H10X_HIP(c, hipMemsetAsync(failFlag.p, 0, 4, st));
+    if (Uo) owner_table_insert_kernel<<<hmin<u32>(divUp(Uo, 256), 16384), 256, 0, st>>>(dHash.p, c->oIndex.p, Uo, T, table.p, failFlag.p);
+    reply_lookup_kernel<<<gridFor(M), 256, 0, st>>>(rHash.p, pk, M, table.p, T, reply.p, failFlag.p);
+    H10X_TRY(c->readback(&failed, failFlag.p, 4));
+    H10X_TRY(c->syncReadbacks());
+    looked = !failed && c->optReplySort != 2;                 // (2 = test knob: look up, then answer the old way all the same — the path a full table takes)
+  }
+  if (M && !looked) {
+    if (byLookup) H10X_TRY(sortWithPositions());              // (oHash is written again with what it holds: same keys, stable — ord / flags stand)
+    reply_kernel<<<gridFor(M), 256, 0, st>>>(ord.p, flags.p, oQ.p, M, c->oIndex.p, reply.p);
+  }
   H10X_TRY(xchg_a2a(c, cm, X_INDEX_BACK, reply.p, recvCnt.data(), recvOff.data(), rIdx.p, sendCnt.data(), sendOff.data(), 4));
   c->hashNumber = U + 1; c->depthBound = nB;
   c->tstop(T_RANK);

@@ -348,6 +348,7 @@ int  h10x_get_counters(h10x_ctx *ctx, h10x_counters *out);
    one list per wave instruction), "cluster_tr_class_t" (packed form: -1 / 1 = lists of 65 .. 96 entries run two to a unit of three chunks, the default; 0 = one to a
    unit of two chunks like the lists of 97 .. 128), "cluster_lds_budget", "cluster_first_global", "cluster_first_cap", "cluster_big_ranks", "cluster_threads0",
    "cluster_budget0" (placement and launch-class overrides of the tests), "cluster_stamps" (phase stamps into h10x_counters),
+   "shard_reply_sort" (sharded index build: 0 default = a hash owner answers by look-up in a table of its distinct hashes, 1 = by scattering from its sorted order, 2 = test: both),
    "shard_row_shift", "shard_rows_fake_base" (sharded list offsets beyond 32 bits on small inputs), "shard_delta_lists" (-1 default:
    the in-range barcode lists travel delta-coded where bytes are dear — more than one rank on the host-staged TCP backend, not over xGMI; 0 never; 1 always). Unknown name: -1. */
 int  h10x_set_option(h10x_ctx *ctx, const char *name, int64_t value);

@@ -119,6 +119,7 @@ def run(n_cases, seed, verbose=False, scale=1):
             nr = rng.choice([1, 2, 3, 4, 8])
             if ok and "--readHash" not in tail and rng.random() < 0.6:   # the same commands sharded, ranks as threads
                 sopts = dict(opts)
+                if random.Random((seed << 21) ^ case).random() < 0.35: sopts["shard_reply_sort"] = 1 + case % 2   # (own generator: the cases of a seed stay what they were)
                 if rng.random() < 0.4: sopts["shard_row_shift"] = rng.choice([0, 1, 3])
                 if rng.random() < 0.3: sopts["shard_rows_fake_base"] = rng.choice([1 << 32, (5 << 32) + 24, 1 << 35])
                 gather = "--clusterSplit" not in tail and rng.random() < 0.3

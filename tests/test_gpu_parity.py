@@ -428,6 +428,22 @@ def test_sharded_list_offsets_beyond_32_bits(workdir, shift, fake):
     assert got == exp, orc.describe_diff(got, exp)
 
 
+@pytest.mark.parametrize("mode", [0, 1, 2], ids=["lookup", "scatter", "lookup_then_scatter"])
+def test_sharded_owner_replies(workdir, mode):
+    """How a hash owner tells every entry its index (shard.hip step 5): by look-up in a table of its distinct hashes, arrival order (the default where entries travel packed),
+    by scattering from its sorted order (the sort carries arrival positions: round 4's form, still what unpacked entries take), and the path a full table takes (look up,
+    then answer by scatter all the same). 3 ranks and 1 rank, each byte-equal to the oracle."""
+    recs = orc.gen_fqb(workdir.file("x.fqb"), 40000, 180, 300000, 0.003, 61, 4.0, 150, 6000)
+    o = orc.Oracle(B=20)
+    o.read_fqb(recs); o.depth_range(4, 30); o.cluster(1, 0, 3)
+    o.write_hash(workdir.file("orc.hash"))
+    exp = open(workdir.file("orc.hash"), "rb").read()
+    for nranks in (3, 1):
+        _run_sharded(recs, nranks, 20, 4, 30, 3, workdir.file("hip.hash"), opts={"shard_reply_sort": mode})
+        got = open(workdir.file("hip.hash"), "rb").read()
+        assert got == exp, orc.describe_diff(got, exp)
+
+
 def test_gather_then_continue_on_one_gpu(workdir):
     """h10x_shard_gather leaves rank 0 a complete single-GPU context: its barcode lists are rebuilt, so a new depth range and
     another clustering on rank 0 alone give what one GPU gives from the start (the lists used to be stale)."""
