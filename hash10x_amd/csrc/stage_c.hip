@@ -1382,7 +1382,7 @@ __device__ __forceinline__ void cluster_one_block_tp(const ClusterArgs &a, u32 c
   constexpr bool IN_LDS = true;
   constexpr int CL_WAVES = CL_THREADS / WAVE;
 #ifndef H10X_TP_RIF0
-#define H10X_TP_RIF0 2
+#define H10X_TP_RIF0 3                                        /* (2 until the end of round 5: tuned on the 1/10 sets, where 3 lost 1 %; on the full 3 Gb set 3 is 5.6 % ahead: cluster 301.4 -> 284.5 ms, 4 the same, 1 351) */
 #define H10X_TP_RIF0F 3
 #define H10X_TP_RIF2 4
 #endif
@@ -1521,7 +1521,7 @@ __device__ __forceinline__ void cluster_one_block_tp(const ClusterArgs &a, u32 c
     // the units of one class: SEGW lanes per list, NCH chunks per unit (2: the lists of 65 .. 128 entries, one per unit)
     auto classA = [&](auto segw_, auto nch_, const u32 firstRank, const u32 endRank, const u32 posBase) {
       constexpr u32 SEGW = decltype(segw_)::value, NCH = decltype(nch_)::value, LPU = WAVE / SEGW;
-      constexpr int RIF = SEGW == 64 ? RIF_F : RIF_Q;     // units in flight: the whole-wave lists of F and D gain from a third (3 % on the config-3 sets), the short lists of Q and H lose (4 %)
+      constexpr int RIF = SEGW == 64 ? RIF_F : RIF_Q;     // units in flight: three in every class of the half-CU kernel (class T: two units of three chunks) — see H10X_TP_RIF0
       const u32 nUnits = (endRank - firstRank + LPU - 1) / LPU;
       if (uwave * RIF >= nUnits) return;
       constexpr u32 stepA = CL_WAVES * RIF;

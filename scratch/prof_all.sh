@@ -11,8 +11,10 @@ mkdir -p $O
 python3 -c "import json, os, sys; sys.path.insert(0, '.'); import hash10x_amd; json.dump({'head': os.environ.get('H10X_HEAD'), 'build_id': hash10x_amd.build_id(), 'script': '$SCRIPT'}, open('$O/${TAG}_meta.json', 'w'))"
 if [ -n "$ONLY_SQ" ]; then :                      # counters only (no bench, no kernel trace): quick look at one script
 elif [ -z "$SKIP_BENCH" ]; then
-  python3 bench.py --steps 10 --warmup 2 > $O/${TAG}_bench.json 2> $O/${TAG}_bench.err
-  echo "bench done"
+  if [ -z "$NO_FIRST_BENCH" ]; then                 # (NO_FIRST_BENCH=1: the bench line is taken afterwards, once the folds are in profiles/ — `traffic_stale: false`)
+    python3 bench.py --steps 10 --warmup 2 > $O/${TAG}_bench.json 2> $O/${TAG}_bench.err
+    echo "bench done"
+  fi
   rocprofv3 --kernel-trace --stats --output-format csv -d $O/${TAG}_stats -o runc -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-secondary > $O/${TAG}_bench_under_rocprof.json 2> $O/${TAG}_rocprof.err
 else                                            # another workload than the bench's: trace the script itself
   rocprofv3 --kernel-trace --stats --output-format csv -d $O/${TAG}_stats -o runc -- python3 $SCRIPT > $O/${TAG}_trace.log 2> $O/${TAG}_rocprof.err
