@@ -143,6 +143,14 @@ def test_cluster_translated_class_t(workdir, opts):
     hf = _against_oracle(workdir, "x.fqb", ["-ct", 3, "--readFQB", "x.fqb", "--hashDepthRange", 4, 130, "--cluster", 1, 0], cluster_first_global=4, **opts)
     d = hf.hash_depth[1: hf.hash_number]
     assert ((d > 64) & (d <= 96)).sum() > 300 and ((d > 96) & (d <= 128)).sum() > 100 and hf.blocks["nSubCluster"].sum() > 0
+    if not opts:                                              # and on three ranks with the lists padded to 8-entry units (the tail chunk of a class-T unit reads behind a padded list's first 64 entries)
+        recs = np.fromfile(workdir.file("x.fqb"), dtype=np.uint32)
+        o = orc.Oracle(B=20)
+        o.read_fqb(recs); o.depth_range(4, 130); o.cluster(1, 0, 3)
+        o.write_hash(workdir.file("orc3.hash"))
+        _run_sharded(recs, 3, 20, 4, 130, 3, workdir.file("sh.hash"), opts={"cluster_first_global": 4, "shard_row_shift": 3})
+        got = open(workdir.file("sh.hash"), "rb").read(); exp = open(workdir.file("orc3.hash"), "rb").read()
+        assert got == exp, orc.describe_diff(got, exp)
 
 
 def test_cluster_first_table_on_hbm_slots(workdir):
