@@ -451,7 +451,7 @@ def full_config3_block(hash10x_amd, local_rank, steps=3):
     except Exception:
         tr = None
     out = {"workload": "config3-full-200M (BASELINE configs[2] at its own size: 200 M pairs, 1 M barcodes, 500 Mb x 2, e = 0.1 %%, -B 29; gen_fqb v2 seed %d)" % g["seed"],
-           "ms_per_step": 1e3 * sum(wall) / len(wall), "read_pairs_per_s": pairs * len(wall) / sum(wall), "steps": steps,
+           "read_pairs": pairs, "B": case["B"], "ms_per_step": 1e3 * sum(wall) / len(wall), "read_pairs_per_s": pairs * len(wall) / sum(wall), "steps": steps,
            "device_ms_per_step": {k: round(v[0] / steps, 2) for k, v in tm.items() if v[0] > 0},
            "entries_H": c["entries"], "distinct_U": c["distinct"], "hashNumber": z["hashNumber"],
            "sizes_match_reference": z["hashNumber"] == case["hash_number"] and z["nBlocks"] == case["blocks_max"] and z["nClusHash"] == case["sum_nHash"],
@@ -567,7 +567,7 @@ def genome3g_block(hash10x_amd, local_rank, steps=2, name="genome3g-300M"):
     clu_ms = tm["cluster_kernel"][0] / steps
     alg = 4.0 * c["sum_good_depth"] + 14.0 * c["sum_good"] + 16.0 * c["sum_hash_clustered"]
     out = {"workload": "%s (%.1f Gb x 2 haplotypes, %d M pairs, %d k barcodes, e = 0.05 %%, -B %d, --hashDepthRange %d %d; gen_fqb v2 seed %d)" % (name, wl["genome"] / 1e9, wl["pairs"] // 1000000, wl["barcodes"] // 1000, wl["B"], wl["lo"], wl["hi"], wl["seed"]),
-           "ms_per_step": 1e3 * sum(wall) / len(wall), "read_pairs_per_s": pairs * len(wall) / sum(wall), "steps": steps,
+           "read_pairs": pairs, "B": wl["B"], "ms_per_step": 1e3 * sum(wall) / len(wall), "read_pairs_per_s": pairs * len(wall) / sum(wall), "steps": steps,
            "device_ms_per_step": {k: round(v[0] / steps, 2) for k, v in tm.items() if v[0] > 0},
            "entries_H": c["entries"], "distinct_U": c["distinct"], "hashNumber": z["hashNumber"],
            "first_placement": {0: "dense", 1: "ranked", 2: "hbm-slot", 3: "hashed", 4: "translated"}.get(c["cluster_first_mode"]),
@@ -730,15 +730,24 @@ def virtual_ranks_block(hash10x_amd, name, n, local_rank=0, steps=1):
             hh.close(); dr.free()
         except Exception as e:                              # a rank that dies leaves the others waiting in a collective: say so and let the caller's timeout end it
             err[r] = str(e)
-    th = [threading.Thread(target=work, args=(r,)) for r in range(n)]
+    th = [threading.Thread(target=work, args=(r,), daemon=True) for r in range(n)]
     for t in th:
         t.start()
+    # a rank that raises outside a collective leaves the others waiting in LocalGroup::wait(): the joins are bounded, the threads daemons, and the caller reports
+    # what the dead rank said instead of hanging behind a headline that was already computed
+    deadline = time.time() + float(os.environ.get("H10X_VRANK_TIMEOUT", "600"))
     for t in th:
-        t.join()
+        while t.is_alive() and time.time() < deadline and not any(err):
+            t.join(0.5)
+    if any(err) or any(t.is_alive() for t in th):
+        for t in th:
+            t.join(2.0)
+        if any(t.is_alive() for t in th):
+            globals()["_HUNG_THREADS"] = True
+        said = "; ".join("rank %d: %s" % (i, e) for i, e in enumerate(err) if e) or "no rank reported an error"
+        return {"error": ("virtual ranks did not finish (%s)" % said)[:400]}
     for c in comms:
         c.destroy()
-    if any(err):
-        return {"error": "; ".join("rank %d: %s" % (i, e) for i, e in enumerate(err) if e)[:400]}
     out = scaling_model(res, sum(single) / len(single))
     out["workload"] = name
     out["single_gpu_stage_ms"] = single_stage
@@ -796,6 +805,143 @@ def secondary_block(hash10x_amd, local_rank):
            "parity": "tests/test_gpu_parity.py::test_config3_proportions_match_reference_digests pins this exact set (sha256 of the reference binary's .hash)"}
     h.close(); d.free()
     return out
+
+
+_HUNG_THREADS = False        # set when virtual-rank threads were left behind in a collective: main() then leaves through os._exit
+HEADLINE_MAX_BYTES = 6000      # the driver keeps the LAST stdout line and parses it; round 5's 21 KB line did not fit its capture
+
+
+def _r(x, nd=4):
+    """numbers to `nd` significant digits (the detail file keeps them whole)"""
+    if isinstance(x, bool) or x is None or isinstance(x, (int, str)):
+        return x
+    if isinstance(x, float):
+        return float("%.*g" % (nd + 2, x))
+    if isinstance(x, dict):
+        return {k: _r(v, nd) for k, v in x.items()}
+    if isinstance(x, (list, tuple)):
+        return [_r(v, nd) for v in x]
+    return x
+
+
+def step_bytes(pairs, H, U, B, cluster_bytes):
+    """ALL of SURVEY 8d's algorithmic bytes of one step: hashing 120 P + 16 H, index build 28 H + 16 U + 4 2^B, clustering 4 sum d + 14 sum G + 16 H_clustered"""
+    return 120.0 * pairs + 16.0 * H + 28.0 * H + 16.0 * U + 4.0 * float(1 << B) + cluster_bytes
+
+
+def headline(out, detail_file="bench_detail.json"):
+    """The ONE line the driver parses: the contract's keys, `roofline` (dominant kernel of the headline workload on its own bytes; `at_scale` = BASELINE configs[2] at its own
+    size, `genome3g` = the 3 Gb set, `step` = the WHOLE step against all SURVEY 8d bytes for each of the three), `cpu_baseline`, the parity strings and one-number summaries of
+    the side blocks. Everything else (per-rank figures, exchanges, device times of the side blocks, notes) is in `detail_file`. Never longer than HEADLINE_MAX_BYTES."""
+    keep = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data")
+    h = {k: out.get(k) for k in keep}
+    cfg = out.get("config", {})
+    h["config"] = {k: cfg[k] for k in ("workload", "read_pairs", "barcodes", "B", "k", "w", "hashDepthRange", "clusterThreshold", "parallelism") if k in cfg}
+    r = out.get("roofline", {})
+    ro = {k: r.get(k) for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "traffic_stale")}
+    ro["algorithmic_bytes"] = r.get("algorithmic_bytes_per_launch")
+    ro["avg_launch_ms"] = r.get("avg_launch_ms")
+    if r.get("traffic_raw"):
+        ro["traffic_source"] = "profiles/" + r["traffic_raw"].get("traffic_source", "?")
+    for k in ("cluster_all", "index_build"):
+        if isinstance(r.get(k), dict):
+            ro[k] = {"frac": r[k].get("frac"), "ms": r[k].get("ms_per_step")}
+    if isinstance(r.get("other_kernels"), dict) and "mosh_extract" in r["other_kernels"]:
+        ro["mosh_extract"] = {"frac": r["other_kernels"]["mosh_extract"].get("frac"), "ms": r["other_kernels"]["mosh_extract"].get("ms_per_step")}
+
+    def scale(e):
+        if not isinstance(e, dict):
+            return None
+        if "frac" not in e:
+            return {"config": e.get("config", "")[:60], "skipped": str(e.get("skipped"))[:120]}
+        return {"config": e.get("config", "")[:60], "kernel": e.get("kernel"), "frac": e.get("frac"), "achieved": e.get("achieved"), "ms": e.get("ms"),
+                "algorithmic_bytes": e.get("algorithmic_bytes"), "traffic": e.get("traffic"), "traffic_stale": e.get("traffic_stale"), "step_ms": e.get("step_ms")}
+    for k in ("at_scale", "genome3g"):
+        if k in r:
+            ro[k] = scale(r[k])
+    if isinstance(r.get("step"), dict):
+        ro["step"] = r["step"]
+    h["roofline"] = ro
+    cb = out.get("cpu_baseline")
+    if isinstance(cb, dict):
+        h["cpu_baseline"] = {k: (cb[k][:260] if k == "sample" and isinstance(cb[k], str) else cb[k]) for k in
+                             ("value", "unit", "cores", "kind", "cpu_model", "sample", "cluster_seconds", "read_pairs_per_s_hashed", "barcodes_per_s_clustered") if k in cb}
+    for k in ("parity_vs_cpu_on_bench_input", "parity_vs_reference_digest", "cluster_speedup_vs_cpu_1thread", "cluster_speedup_vs_cpu_all_cores", "read_pairs_per_s_hashed",
+              "barcodes_per_s_clustered", "build_id", "max_rank_compute_ms", "mean_rank_compute_ms"):
+        if out.get(k) is not None:
+            h[k] = out[k][:200] if isinstance(out[k], str) else out[k]
+    if isinstance(out.get("device_ms_per_step"), dict):
+        h["device_ms_per_step"] = {k: round(v, 3) for k, v in out["device_ms_per_step"].items()}
+    s = {}
+    omp = out.get("cpu_baseline_omp")
+    if isinstance(omp, dict):
+        s["cpu_baseline_omp"] = {"value": omp.get("value"), "cores": omp.get("cores")}
+    e2e = out.get("end_to_end")
+    if isinstance(e2e, dict):
+        s["end_to_end_wall_seconds"] = e2e.get("wall_seconds")
+    sm = out.get("scaling_model_8_ranks")
+    if isinstance(sm, dict):
+        s["scaling_model_8_ranks"] = ({"workload": sm.get("workload"), "modelled_speedup_vs_1_gpu": sm.get("modelled_speedup_vs_1_gpu"), "modelled_step_ms": sm.get("modelled_step_ms"),
+                                       "single_gpu_step_ms": sm.get("single_gpu_step_ms"), "max_rank_compute_ms": sm.get("max_rank_compute_ms"), "mean_rank_compute_ms": sm.get("mean_rank_compute_ms"),
+                                       "modelled_exchange_ms": sm.get("modelled_exchange_ms"), "busiest_owner_share": sm.get("busiest_owner_share"), "a MODEL": "ranks as threads taking turns on one GPU"}
+                                      if "modelled_speedup_vs_1_gpu" in sm else {"skipped": str(sm.get("skipped") or sm.get("error"))[:160]})
+    fc = out.get("full_config3")
+    if isinstance(fc, dict):
+        e = fc.get("end_to_end") if isinstance(fc.get("end_to_end"), dict) else {}
+        s["full_config3"] = ({"ms_per_step": fc.get("ms_per_step"), "read_pairs_per_s": fc.get("read_pairs_per_s"), "sizes_match_reference": fc.get("sizes_match_reference"),
+                              "end_to_end": {"wall_seconds": e.get("wall_seconds"), "per_command_wall_seconds": e.get("per_command_wall_seconds"),
+                                             "hash_identical_to_reference": e.get("hash_identical_to_reference"), "error": (e.get("error") or e.get("skipped"))}}
+                             if "ms_per_step" in fc else {"skipped": str(fc.get("skipped") or fc.get("error"))[:160]})
+    g3 = out.get("genome3g")
+    if isinstance(g3, dict):
+        if "ms_per_step" in g3:
+            c5 = g3.get("config5") if isinstance(g3.get("config5"), dict) else {}
+            acc = c5.get("accuracy") if isinstance(c5.get("accuracy"), dict) else {}
+            s["genome3g"] = {"ms_per_step": g3.get("ms_per_step"), "read_pairs_per_s": g3.get("read_pairs_per_s"), "parity_vs_reference_digest": g3.get("parity_vs_reference_digest"),
+                             "config5": {"purity": acc.get("purity"), "clusters": acc.get("clusters"), "mean_span_kb": acc.get("mean_span_kb"),
+                                         "accuracy_vs_reference_report": c5.get("accuracy_vs_reference_report"), "cribBuild_seconds": c5.get("cribBuild_seconds"),
+                                         "clusterReport_seconds": c5.get("clusterReport_seconds"), "clusterSplit_seconds": c5.get("clusterSplit_seconds"),
+                                         "hbm_high_water_GB": c5.get("hbm_high_water_GB"), "error": c5.get("error")}}
+        else:
+            s["genome3g"] = {"skipped": str(g3.get("skipped") or g3.get("error"))[:160]}
+    sec = out.get("secondary")
+    if isinstance(sec, dict) and "ms_per_step" in sec:
+        s["config3_tenth"] = {"ms_per_step": sec["ms_per_step"], "cluster_main_frac": (sec.get("roofline") or {}).get("frac"), "traffic_stale": sec.get("traffic_stale")}
+    if isinstance(out.get("exchanges"), dict) and "error" not in out["exchanges"]:
+        s["exchanges_max_rank_bytes_out"] = {k: v.get("max_rank_bytes_out") for k, v in out["exchanges"].items()}
+    h["summary"] = s
+    h["detail"] = detail_file
+
+    def drop_none(x):
+        if isinstance(x, dict):
+            return {k: drop_none(v) for k, v in x.items() if v is not None or k in ("vs_baseline", "traffic")}
+        return x
+    h = drop_none(_r(h))
+    line = json.dumps(h, separators=(",", ":"))
+    # a belt for the braces: shed the optional blocks, largest first, until the line fits
+    for victim in ("device_ms_per_step", "summary", "cpu_baseline.sample"):
+        if len(line) <= HEADLINE_MAX_BYTES:
+            break
+        if "." in victim:
+            a, b = victim.split(".")
+            h.get(a, {}).pop(b, None)
+        else:
+            h.pop(victim, None)
+        line = json.dumps(h, separators=(",", ":"))
+    assert len(line) <= HEADLINE_MAX_BYTES, len(line)
+    return line
+
+
+def write_detail(out):
+    """the whole of what the run measured: bench_detail.json at the repo root and under gpurun_out/ (both untracked scratch; the copy cited by DESIGN.md is committed under profiles/)"""
+    txt = json.dumps(out, indent=1)
+    for d in (REPO, os.path.join(REPO, "gpurun_out")):
+        try:
+            os.makedirs(d, exist_ok=True)
+            with open(os.path.join(d, "bench_detail.json"), "w") as f:
+                f.write(txt + "\n")
+        except OSError:
+            pass
 
 
 def main():
@@ -1099,10 +1245,26 @@ def main():
         if "genome3g" in out:
             out["roofline"]["genome3g"] = scale_entry(out["genome3g"], "3 Gb x 2, 300 M pairs, 1.6 M barcodes, -B 30, --hashDepthRange 6 45 (genome3g-300M: BASELINE configs[3] / [4] shape)")
             out["config"]["genome3g_workload"] = "genome3g-300M (see roofline.genome3g, genome3g, genome3g.config5)"
+        # the WHOLE step against ALL of SURVEY 8d's bytes (hashing + index build + clustering): where everything that is not --cluster shows
+        sb = step_bytes(total_pairs, H, U, wl["B"], alg_cluster_all)
+        out["roofline"]["step"] = {"what": "all SURVEY 8d bytes of a step / ms_per_step / 8 TB/s",
+                                   args.workload: {"frac": sb / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, "bytes": sb, "ms": ms_per_step}}
+        for key, label, Bk in (("full_config3", "config3-full-200M", None), ("genome3g", "genome3g-300M", WORKLOADS["genome3g-300M"]["B"])):
+            blk = out.get(key)
+            if isinstance(blk, dict) and "roofline" in blk:
+                b = blk.get("B", Bk)
+                sbk = step_bytes(blk["read_pairs"], blk["entries_H"], blk["distinct_U"], b, blk["roofline"]["algorithmic_bytes"])
+                out["roofline"]["step"][label] = {"frac": sbk / (blk["ms_per_step"] * 1e-3) / 1e9 / HBM_PEAK_GBS, "bytes": sbk, "ms": blk["ms_per_step"]}
     if rank == 0:
-        os.write(json_fd, (json.dumps(out) + "\n").encode())
+        # the whole record first (file + an EARLIER line on stderr), then — last thing this process writes to stdout — the compact line the driver parses
+        write_detail(out)
+        sys.stderr.write("bench detail: " + json.dumps(out) + "\n")
+        sys.stderr.flush()
+        os.write(json_fd, (headline(out) + "\n").encode())
     if comm is not None:
         comm.destroy()
+    if _HUNG_THREADS:
+        os._exit(0)
 
 
 if __name__ == "__main__":
