@@ -680,9 +680,11 @@ def scaling_model(per_rank, single_ms):
         xfer_ms += ms
         ex[k] = {"calls_per_step": calls, "max_rank_bytes_out": max(out), "sum_bytes_out": sum(out), "busiest_peer_share_bytes": peer, "modelled_ms": round(ms, 3)}
     step = max(comp) + xfer_ms
+    back = [r["exchanges"].get("indices_back (all-to-all)", {}).get("bytes_out", 0) for r in per_rank]      # what an owner answers = the entries it owns
     return {"ranks": n, "max_rank_compute_ms": round(max(comp), 3), "mean_rank_compute_ms": round(sum(comp) / n, 3), "compute_imbalance": round(max(comp) / (sum(comp) / n), 3) if sum(comp) else None,
             "modelled_exchange_ms": round(xfer_ms, 3), "modelled_step_ms": round(step, 3), "single_gpu_step_ms": round(single_ms, 3),
             "modelled_speedup_vs_1_gpu": round(single_ms / step, 2) if step else None, "exchanges": ex,
+            "busiest_owner_share": round(max(back) / sum(back), 4) if sum(back) else None,
             "model": "max rank compute (stage timers less the waits inside them, ranks taking turns on one GPU) + sum over exchanges of busiest-peer bytes / (0.8 x %.0f GB/s) + 30 us per call; "
                      "no overlap assumed; a MODEL, not a measurement" % XGMI_LINK_GBS}
 

@@ -235,7 +235,9 @@ struct Ctx {
                               // block holds chunkSize records (hash10x.c:205-208); 0 = -N ended the loop
   std::vector<u64> mergePoints; bool replayDone = false;     // records whose barcode change does NOT start a block (chunk replay; consumed by stageA_run)
   int64_t optRowShift = -1;   // testing knob: force the list alignment of the sharded rows[] (-1 = as small as the offsets allow)
-  int64_t optReplySort = 0;   // sharded index build, how an owner answers: 0 = by look-up in a table of its distinct hashes (packed entries), 1 = by scattering from the sorted order (the sort carries arrival positions; round 4's form), 2 = test: look up, then answer the old way
+  int64_t optReplySort = 0;   // sharded index build, how an owner answers: 0 = by look-up in a table of its distinct hashes (packed entries), 1 = by scattering from the sorted order (the sort carries arrival positions; round 4's form),
+                              // tests of the look-up's fall-back: 2 = look up, then answer by scatter all the same, 3 = a table whose displacement limit is 1 (it FAILS), 4 = as if the table did not fit the free memory
+  int64_t optOwnerCut = 0;    // sharded index build, where the hash owners' value ranges are cut: 0 = at the quantiles of the canonical-hash density 2 (1 - x) (equal shares), 1 = equal value ranges (round 5: owner 0 of 8 holds 23.4 %)
   int64_t optDeltaLists = -1; // in-range barcode lists travel delta-coded between ranks: -1 = where bytes are dear (more than one rank on the host-staged TCP backend; not over xGMI: DESIGN 5), 0 never, 1 always (tests)
   int64_t optRowsFakeBase = 0; // testing knob: list offsets start at this many entries (multiple of 2^rowShift) in front of the real array: 64-bit offsets on small inputs
   // streaming ingest (h10x_ingest_fqb): the record image grows on the device as the chunks arrive
@@ -311,11 +313,20 @@ struct Ctx {
   void flush(Timer &x) {
     if (x.pending) { float ms = 0; (void)hipEventSynchronize(x.b); (void)hipEventElapsedTime(&ms, x.a, x.b); x.ms += ms; x.pending = false; }
   }
-  int stageOpen = 0;          // stage timers open right now (the exchange wrappers of shard.hip ask)
-  TimerId stageTop = T_COUNT; // the innermost of them
+  // Stage timers open right now, innermost last (the exchange wrappers of shard.hip charge their waits to the innermost one). A STACK: when a nested timer closes
+  // (cluster > cluster_kernel > cluster_main) the parent is the innermost again; a command that returned early between a tstart and its tstop cannot leave stages open
+  // for the context's lifetime — stageReset() runs on every command entry and in h10x_timing_reset.
+  static constexpr int STAGE_DEPTH = 8;
+  TimerId stageStack[STAGE_DEPTH]; int stageOpen = 0;
+  TimerId stageTop = T_COUNT; // the innermost open stage (T_COUNT: none)
   Timer stageWait[T_COUNT];   // per stage: the exchange waits inside its bracket (a stage's compute = its timer less this)
-  void tstart(TimerId t) { ++stageOpen; stageTop = t; tstart(timers[t]); }
-  void tstop(TimerId t) { if (stageOpen > 0) --stageOpen; if (!stageOpen) stageTop = T_COUNT; tstop(timers[t]); }
+  void stageReset() { stageOpen = 0; stageTop = T_COUNT; }
+  void tstart(TimerId t) { if (stageOpen < STAGE_DEPTH) stageStack[stageOpen] = t; ++stageOpen; stageTop = t; tstart(timers[t]); }
+  void tstop(TimerId t) {
+    if (stageOpen > 0) --stageOpen;
+    stageTop = stageOpen > 0 && stageOpen <= STAGE_DEPTH ? stageStack[stageOpen - 1] : T_COUNT;
+    tstop(timers[t]);
+  }
   void flush(TimerId t) { flush(timers[t]); }
 };
 

@@ -14,6 +14,7 @@ static int enter(Ctx &c) {
   AllocScope::stream() = c.stream; AllocScope::device() = c.device;
   DevCache::noteStream(c.device, c.stream);
   c.pendingReads.clear(); c.mailUsed = 0; c.mailDirect = false;                    // read-backs a failed call left behind point into its dead frame
+  c.stageReset();                                                                   // (and so do the stage timers a failed call left open)
   return 0;
 }
 
@@ -512,6 +513,7 @@ int h10x_timing_reset(h10x_ctx *h) {
   if (!h) return -1;
   for (int i = 0; i < T_COUNT; ++i) { h->c.flush((TimerId)i); h->c.timers[i].ms = 0; h->c.timers[i].launches = 0; h->c.flush(h->c.stageWait[i]); h->c.stageWait[i].ms = 0; h->c.stageWait[i].launches = 0; }
   for (int i = 0; i < X_COUNT; ++i) { XchgStat &x = h->c.xs[i]; h->c.flush(x.t); h->c.flush(x.tIn); x.t.ms = x.tIn.ms = 0; x.t.launches = x.tIn.launches = 0; x.calls = x.bytesOut = x.bytesIn = x.maxPeerOut = 0; }
+  h->c.stageReset();
   return 0;
 }
 int h10x_timing_wait_get(h10x_ctx *h, int i, double *ms) {
@@ -677,7 +679,8 @@ int h10x_set_option(h10x_ctx *h, const char *name, int64_t value) {
   if (!strcmp(name, "chunk_eof_pass")) { h->c.optChunkEof = value ? 1 : 0; return 0; }
   if (!strcmp(name, "fault_inject")) { h->c.optFaultInject = value; return 0; }
   if (!strcmp(name, "shard_row_shift")) { if (value < -1 || value > 8) return h->c.fail("shard_row_shift must be -1..8"); h->c.optRowShift = value; return 0; }
-  if (!strcmp(name, "shard_reply_sort")) { if (value < 0 || value > 2) return h->c.fail("shard_reply_sort must be 0, 1 or 2"); h->c.optReplySort = value; return 0; }
+  if (!strcmp(name, "shard_reply_sort")) { if (value < 0 || value > 4) return h->c.fail("shard_reply_sort must be 0..4"); h->c.optReplySort = value; return 0; }
+  if (!strcmp(name, "shard_owner_cut")) { if (value < 0 || value > 1) return h->c.fail("shard_owner_cut must be 0 or 1"); h->c.optOwnerCut = value; return 0; }
   if (!strcmp(name, "shard_delta_lists")) { if (value < -1 || value > 1) return h->c.fail("shard_delta_lists must be -1, 0 or 1"); h->c.optDeltaLists = value; return 0; }
   if (!strcmp(name, "shard_rows_fake_base")) { if (value < 0) return h->c.fail("shard_rows_fake_base must be >= 0"); h->c.optRowsFakeBase = value; return 0; }
   return h->c.fail("unknown option %s", name);

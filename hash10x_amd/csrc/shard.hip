@@ -154,28 +154,28 @@ __global__ void reply_kernel(const u32 *__restrict__ ord /* distinct ordinal per
 // then answers the old way.
 constexpr u32 OWNER_MAX_DISP = 256;
 constexpr u64 OWNER_EMPTY = ~0ULL;
-__global__ void owner_table_insert_kernel(const u64 *__restrict__ dHash, const u32 *__restrict__ dIndex, u32 U, int T, u64 *__restrict__ table, u32 *__restrict__ fail) {
+__global__ void owner_table_insert_kernel(const u64 *__restrict__ dHash, const u32 *__restrict__ dIndex, u32 U, int T, u64 *__restrict__ table, u32 *__restrict__ fail, u32 maxDisp) {
   const u64 mask = ((u64)1 << T) - 1;
   for (u32 d = blockIdx.x * blockDim.x + threadIdx.x; d < U; d += gridDim.x * blockDim.x) {
     const u64 q = dHash[d], low = (q >> T) << 8, val = (u64)dIndex[d] << 32;
     u64 slot = q & mask; u32 disp = 0;
-    for (; disp < OWNER_MAX_DISP; ++disp, slot = (slot + 1) & mask)
+    for (; disp < maxDisp; ++disp, slot = (slot + 1) & mask)
       if (atomicCAS((unsigned long long *)&table[slot], (unsigned long long)OWNER_EMPTY, (unsigned long long)(val | low | disp)) == OWNER_EMPTY) break;
-    if (disp == OWNER_MAX_DISP) *fail = 1;
+    if (disp == maxDisp) *fail = 1;
   }
 }
-__global__ void reply_lookup_kernel(const u64 *__restrict__ rKey /* arrival order: key << cb | block */, int cb, u64 n, const u64 *__restrict__ table, int T, u32 *__restrict__ reply, u32 *__restrict__ fail) {
+__global__ void reply_lookup_kernel(const u64 *__restrict__ rKey /* arrival order: key << cb | block */, int cb, u64 n, const u64 *__restrict__ table, int T, u32 *__restrict__ reply, u32 *__restrict__ fail, u32 maxDisp) {
   u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; const u64 stride = (u64)gridDim.x * blockDim.x;
   const u64 mask = ((u64)1 << T) - 1;
   for (; i < n; i += stride) {
     const u64 q = rKey[i] >> cb; const u32 want = (u32)((q >> T) << 8);
     u64 slot = q & mask; u32 disp = 0, ix = 0;
-    for (; disp < OWNER_MAX_DISP; ++disp, slot = (slot + 1) & mask) {
+    for (; disp < maxDisp; ++disp, slot = (slot + 1) & mask) {
       const u64 e = table[slot];
       if ((u32)e == (want | disp)) { ix = (u32)(e >> 32); break; }
-      if (e == OWNER_EMPTY) { disp = OWNER_MAX_DISP; break; }   // (never behind an empty slot of its probe sequence)
+      if (e == OWNER_EMPTY) { disp = maxDisp; break; }         // (never behind an empty slot of its probe sequence)
     }
-    if (disp == OWNER_MAX_DISP) *fail = 1;
+    if (disp == maxDisp) *fail = 1;
     reply[i] = ix;
   }
 }
@@ -226,6 +226,29 @@ static int bitsForS(u64 v) { int b = 1; while (b < 64 && (v >> b)) ++b; return b
 static unsigned gridFor(u64 n) { return (unsigned)hmin<u64>(divUp(n ? n : 1, 256), 65535u * 2); }
 
 struct ShardInfo { u64 barcodes, entries, records; };
+
+// Where the hash owners' value ranges are cut. A canonical hash is min(hashF, hashR) (seqhash.c:67-68) of two values that are each uniform over the 2^(2k) hash values, so
+// its density over x = key / nKeys is 2 (1 - x), NOT flat: equal value ranges (round 5) gave owner 0 of 8 the share 1 - (7/8)^2 = 23.4 % of all entries and distinct hashes
+// and owner 7 1.6 % (bench line of round 5: indices_back max / sum = 0.2344; the owners' sort, numbering and list packing fell linearly with the rank). Equal SHARES are the
+// quantiles of that density: F(x) = 1 - (1 - x)^2 = o / N  =>  x_o = 1 - sqrt(1 - o / N). Owner ranges stay value ranges (owner o's hashes all precede owner o + 1's), so nothing
+// downstream changes; any monotone cut gives the same result, this one balances it. Integer arithmetic only (every rank must cut at the same values): sqrt((N - o) / N) as a
+// 0.32 fixed-point number from a 64-bit integer square root.
+static u64 isqrt64(u64 v) {
+  u64 r = (u64)sqrtl((long double)v);
+  while (r > 0xFFFFFFFFull || r * r > v) --r;
+  while (r < 0xFFFFFFFFull && (r + 1) * (r + 1) <= v) ++r;
+  return r;
+}
+static void ownerCuts(u64 nKeys, int N, bool equalRanges, u64 *low /* N + 1 */) {
+  for (int o = 0; o <= N; ++o) {
+    if (equalRanges || o == 0 || o == N) { low[o] = (u64)(((unsigned __int128)o * nKeys + (unsigned)N - 1) / (unsigned)N); continue; }    // ceil(o * nKeys / N)
+    const u64 frac = (u64)((((unsigned __int128)(unsigned)(N - o)) << 64) / (unsigned)N);     // (N - o) / N as a 0.64 fixed-point number (o >= 1: below 2^64)
+    const u64 root = isqrt64(frac);                                                             // sqrt of it as 0.32
+    const u64 upper = (u64)(((unsigned __int128)nKeys * root) >> 32);                           // nKeys sqrt(1 - o / N), rounded down
+    low[o] = nKeys - hmin<u64>(upper, nKeys);
+  }
+  for (int o = 1; o <= N; ++o) if (low[o] < low[o - 1]) low[o] = low[o - 1];                   // (monotone whatever the rounding did)
+}
 
 int shard_readFqb(Ctx *c, Comm *cm, const u32 *dRec, u64 nRec) {
   hipStream_t st = c->stream; PrimTemp pt;
@@ -289,7 +312,7 @@ int shard_readFqb(Ctx *c, Comm *cm, const u32 *dRec, u64 nRec) {
   std::vector<u64> lowHash((size_t)N + 1), bound((size_t)N + 1);
   // (the entries hold hash / w, Ctx::keyInv: the owner ranges are cut in that space)
   const u64 nKeys = ((2 * k >= 64 ? ~0ULL : ((u64)1 << (2 * k)) - 1) / (u64)c->prm.w) + 1;
-  for (int o = 0; o <= N; ++o) lowHash[o] = (u64)(((unsigned __int128)o * nKeys + (unsigned)N - 1) / (unsigned)N);          // ceil(o * nKeys / N)
+  ownerCuts(nKeys, N, c->optOwnerCut != 0, lowHash.data());
   DevBuf<u64> dLow, dBound; H10X_HIP(c, dLow.alloc((size_t)N + 1)); H10X_HIP(c, dBound.alloc((size_t)N + 1));
   H10X_HIP(c, hipMemcpyAsync(dLow.p, lowHash.data(), ((size_t)N + 1) * 8, hipMemcpyHostToDevice, st));
   if (N <= PART_MAX_OWNERS) {
@@ -326,7 +349,7 @@ int shard_readFqb(Ctx *c, Comm *cm, const u32 *dRec, u64 nRec) {
 
   // ---- 3. owner side: received runs are in rank (= barcode) order, a stable sort by hash keeps barcodes ascending
   // (packed entries: the replies are looked up, the sort carries nothing — see reply_lookup_kernel; the arrival positions ride along only in the unpacked form and when the knob asks)
-  const bool byLookup = pk && c->optReplySort == 0 && c->keyBits <= 56;
+  const bool byLookup = pk && c->optReplySort != 1 && c->keyBits <= 56;
   DevBuf<u64> oHash; DevBuf<u32> oQ; H10X_HIP(c, oHash.alloc(M));
   auto sortWithPositions = [&]() -> int {
     H10X_HIP(c, oQ.alloc(M));
@@ -380,17 +403,29 @@ int shard_readFqb(Ctx *c, Comm *cm, const u32 *dRec, u64 nRec) {
   // ---- 5. the index of every entry goes back to the rank that sent it, in the order it was sent
   DevBuf<u32> reply, rIdx; H10X_HIP(c, reply.alloc(M)); H10X_HIP(c, rIdx.alloc(H));
   bool looked = false;
+  c->ctr.shard_reply_path = M ? 2 : 0;                       // what answered: 1 the look-up, 2 the scatter, 3 the scatter after a look-up that failed or was not affordable
   if (byLookup && M) {
     int T = 16; while (((u64)1 << T) < 2 * ((u64)Uo + 1) && T < 40) ++T;
     if (T < c->keyBits - 24) T = c->keyBits - 24;
+    // knob 3 (tests): a displacement limit of 1 — the first key that finds its home slot taken fails the table, which is how a table that overflows looks
+    const u32 maxDisp = c->optReplySort == 3 ? 1u : OWNER_MAX_DISP;
     DevBuf<u64> table; DevBuf<u32> failFlag; u32 failed = 0;
-    H10X_HIP(c, table.alloc((size_t)1 << T)); H10X_HIP(c, failFlag.alloc(1));
-    H10X_HIP(c, hipMemsetAsync(table.p, 0xFF, ((size_t)1 << T) * 8, st)); H10X_HIP(c, hipMemsetAsync(failFlag.p, 0, 4, st));
-    if (Uo) owner_table_insert_kernel<<<hmin<u32>(divUp(Uo, 256), 16384), 256, 0, st>>>(dHash.p, c->oIndex.p, Uo, T, table.p, failFlag.p);
-    reply_lookup_kernel<<<gridFor(M), 256, 0, st>>>(rHash.p, pk, M, table.p, T, reply.p, failFlag.p);
-    H10X_TRY(c->readback(&failed, failFlag.p, 4));
-    H10X_TRY(c->syncReadbacks());
-    looked = !failed && c->optReplySort != 2;                 // (2 = test knob: look up, then answer the old way all the same — the path a full table takes)
+    // the table is an optimisation with a fall-back behind it: where it does not fit what is free at this, the index build's memory peak (rHash, oHash, oRows, flags, ord,
+    // reply and rIdx are all live; 8 B x 2^T is 16 GB for 700 M distinct hashes), or its allocation fails, the owner answers by scatter instead of failing --readFQB
+    size_t freeB = 0, totalB = 0; const size_t want = ((size_t)1 << T) * 8;
+    bool fits = hipMemGetInfo(&freeB, &totalB) == hipSuccess && want <= freeB / 2;
+    if (c->optReplySort == 4) fits = false;                   // (knob 4, tests: as if the table did not fit)
+    if (fits && table.alloc((size_t)1 << T) != hipSuccess) { (void)hipGetLastError(); fits = false; }
+    if (fits) {
+      H10X_HIP(c, failFlag.alloc(1));
+      H10X_HIP(c, hipMemsetAsync(table.p, 0xFF, want, st)); H10X_HIP(c, hipMemsetAsync(failFlag.p, 0, 4, st));
+      if (Uo) owner_table_insert_kernel<<<hmin<u32>(divUp(Uo, 256), 16384), 256, 0, st>>>(dHash.p, c->oIndex.p, Uo, T, table.p, failFlag.p, maxDisp);
+      reply_lookup_kernel<<<gridFor(M), 256, 0, st>>>(rHash.p, pk, M, table.p, T, reply.p, failFlag.p, maxDisp);
+      H10X_TRY(c->readback(&failed, failFlag.p, 4));
+      H10X_TRY(c->syncReadbacks());
+      looked = !failed && c->optReplySort != 2;               // (knob 2, tests: a look-up that succeeded, answered by scatter all the same)
+    }
+    c->ctr.shard_reply_path = looked ? 1 : 3;
   }
   if (M && !looked) {
     if (byLookup) H10X_TRY(sortWithPositions());              // (oHash is written again with what it holds: same keys, stable — ord / flags stand)

@@ -229,21 +229,22 @@ int stageB_blockClassLists(Ctx *c, DevBuf<u32> &lists, DevBuf<u32> &counts) {
 //     others on average (the largest bucket of a block: 20-70 keys).
 // So: largest key -> bitmap of (largest - key) -> length of the top run (first clear bit); the other keys are counted into buckets (returning LDS add = arrival rank),
 // the counts scanned, the keys dropped into their bucket's range, and every key finds its rank by comparing with the keys of its bucket. Equal keys (cannot happen on
-// consistent data) are ordered by arrival, so the result is a permutation whatever comes in. In: striped or any arrangement, n valid entries (entry e = j * THREADS + tid
+// consistent data: several look-ups that find nothing and return 0, corrupt indices) are ordered by arrival inside a bucket; the top run places by VALUE, so its members are
+// counted and a run that holds a key twice is given up (every key then goes through the buckets): the result is a permutation whatever comes in. In: striped or any arrangement, n valid entries (entry e = j * THREADS + tid
 // valid iff e < n); out: sorted, striped.
 template <int THREADS, int IPT> struct BlockIndexSort {
   static constexpr int CAP = THREADS * IPT;
   static constexpr int NB = 4096, LOGNB = 12;               // (64 KB of static LDS at most: 16 KB of counters beside 6 bytes per entry)
   static constexpr int CPT = NB / THREADS;                   // counters per lane in the scan
   static constexpr int WAVES = THREADS / WAVE;
-  struct Storage { u32 cnt[NB + 4]; u32 key[CAP]; u16 val[CAP]; u32 bm[CAP / 32]; u32 waveTot[WAVES]; u32 kmax, firstZero; };
+  struct Storage { u32 cnt[NB + 4]; u32 key[CAP]; u16 val[CAP]; u32 bm[CAP / 32]; u32 waveTot[WAVES]; u32 kmax, firstZero, runCount; };
   __device__ __forceinline__ static void sort(u32 (&k)[IPT], u32 (&v)[IPT], u32 n, Storage &s) {
     const u32 tid = threadIdx.x, lane = tid & (WAVE - 1), wave = tid / WAVE;
 #pragma unroll
     for (int i = 0; i < CPT; ++i) s.cnt[(u32)i * THREADS + tid] = 0;
     if (tid < 4) s.cnt[NB + tid] = 0;
     if (tid < CAP / 32) s.bm[tid] = 0;
-    if (tid == 0) { s.kmax = 0; s.firstZero = CAP; }
+    if (tid == 0) { s.kmax = 0; s.firstZero = CAP; s.runCount = 0; }
     u32 m = 0;
 #pragma unroll
     for (int j = 0; j < IPT; ++j) if ((u32)j * THREADS + tid < n) m = k[j] > m ? k[j] : m;
@@ -258,12 +259,22 @@ template <int THREADS, int IPT> struct BlockIndexSort {
     __syncthreads();
     if (tid < CAP / 32) { const u32 w = ~s.bm[tid]; if (w) atomicMin(&s.firstZero, tid * 32 + (u32)__ffs((int)w) - 1u); }
     __syncthreads();
-    const u32 run = s.firstZero;                              // keys with kmax - key < run are the top run; kmax - run is in no entry
-    const u32 lim = kmax >= run ? kmax - run : 0;             // the other keys are below this
+    u32 run = s.firstZero;                                    // keys with kmax - key < run are the top run; kmax - run is in no entry
+    {                                                         // distinct keys put exactly `run` entries there; more = a key twice: no run then
+      u32 mineInRun = 0;
+#pragma unroll
+      for (int j = 0; j < IPT; ++j) if ((u32)j * THREADS + tid < n && kmax - k[j] < run) ++mineInRun;
+#pragma unroll
+      for (int d = 32; d; d >>= 1) mineInRun += (u32)__shfl_xor((int)mineInRun, d);
+      if (lane == 0 && mineInRun) atomicAdd(&s.runCount, mineInRun);
+      __syncthreads();
+      if (s.runCount != run) run = 0;
+    }
+    const u32 lim = run ? (kmax >= run ? kmax - run : 0) : kmax + 1u;   // the other keys are below this
     const int sh = lim > (u32)NB ? (32 - __clz((int)(lim - 1))) - LOGNB : 0;      // (lim - 1) >> sh < NB
     u32 r[IPT];
 #pragma unroll
-    for (int j = 0; j < IPT; ++j) { r[j] = 0; if ((u32)j * THREADS + tid < n && kmax - k[j] > run) r[j] = atomicAdd(&s.cnt[k[j] >> sh], 1u); }
+    for (int j = 0; j < IPT; ++j) { r[j] = 0; if ((u32)j * THREADS + tid < n && kmax - k[j] >= run) r[j] = atomicAdd(&s.cnt[k[j] >> sh], 1u); }
     __syncthreads();
     {                                                         // exclusive scan of the counts, in place; cnt[NB] = their sum
       u32 c[CPT], t = 0;
@@ -282,7 +293,7 @@ template <int THREADS, int IPT> struct BlockIndexSort {
       __syncthreads();
     }
 #pragma unroll
-    for (int j = 0; j < IPT; ++j) if ((u32)j * THREADS + tid < n && kmax - k[j] > run) { r[j] += s.cnt[k[j] >> sh]; s.key[r[j]] = k[j]; }
+    for (int j = 0; j < IPT; ++j) if ((u32)j * THREADS + tid < n && kmax - k[j] >= run) { r[j] += s.cnt[k[j] >> sh]; s.key[r[j]] = k[j]; }
     __syncthreads();
 #pragma unroll
     for (int j = 0; j < IPT; ++j) if ((u32)j * THREADS + tid < n) {

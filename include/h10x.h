@@ -24,7 +24,7 @@ extern "C" {
 
 /* 2 (round 5): h10x_warm, h10x_alloc_stats, h10x_pinned_*, h10x_ingest_fqb_async / _wait, H10X_TABLE_CLUSTER_RAW, the exchange counters of
    h10x_counters; option "cluster_dbg_skip" gone. libh10x_host.so and the Python loader refuse a libh10x_hip.so of another version. */
-#define H10X_ABI_VERSION 2
+#define H10X_ABI_VERSION 3
 
 typedef struct h10x_ctx h10x_ctx;
 
@@ -336,6 +336,8 @@ typedef struct {
                                       [0] init (+ bitmap), [1] list loop, [2] barrier, [3] replay, [4] quotient, [5] output */
   uint64_t list_words[2];          /* sharded --hashDepthRange: 32-bit words of in-range barcode lists this rank received, [0] as plain
                                       numbers, [1] as they travelled (delta-coded: option "shard_delta_lists"); 0 0 if sent plain */
+  uint64_t shard_reply_path;       /* sharded --readFQB, how this hash owner answered its entries: 0 nothing to answer, 1 by look-up, 2 by scatter, 3 by scatter after a look-up
+                                      that failed or did not fit (option "shard_reply_sort") */
 } h10x_counters;
 int  h10x_get_counters(h10x_ctx *ctx, h10x_counters *out);
 /* test / tuning knobs (none changes a result): "stage_a_max_slots" caps the LDS hash-set slots per barcode in stage A (0 =
@@ -348,7 +350,9 @@ int  h10x_get_counters(h10x_ctx *ctx, h10x_counters *out);
    one list per wave instruction), "cluster_tr_class_t" (packed form: -1 / 1 = lists of 65 .. 96 entries run two to a unit of three chunks, the default; 0 = one to a
    unit of two chunks like the lists of 97 .. 128), "cluster_lds_budget", "cluster_first_global", "cluster_first_cap", "cluster_big_ranks", "cluster_threads0",
    "cluster_budget0" (placement and launch-class overrides of the tests), "cluster_stamps" (phase stamps into h10x_counters),
-   "shard_reply_sort" (sharded index build: 0 default = a hash owner answers by look-up in a table of its distinct hashes, 1 = by scattering from its sorted order, 2 = test: both),
+   "shard_reply_sort" (sharded index build: 0 default = a hash owner answers by look-up in a table of its distinct hashes, 1 = by scattering from its sorted order; tests of the
+   fall-back, reported in h10x_counters.shard_reply_path: 2 = look up, then scatter all the same, 3 = a look-up table that fails, 4 = one that does not fit),
+   "shard_owner_cut" (0 default = hash owners' value ranges cut at the quantiles of the canonical-hash density, equal shares; 1 = equal value ranges),
    "shard_row_shift", "shard_rows_fake_base" (sharded list offsets beyond 32 bits on small inputs), "shard_delta_lists" (-1 default:
    the in-range barcode lists travel delta-coded where bytes are dear — more than one rank on the host-staged TCP backend, not over xGMI; 0 never; 1 always). Unknown name: -1. */
 int  h10x_set_option(h10x_ctx *ctx, const char *name, int64_t value);

@@ -33,7 +33,7 @@ def _factory(**opts):
 def test_native_library_is_the_path():
     import hash10x_amd
     hip, host = hash10x_amd.load_native()
-    assert hip.h10x_abi_version() == hash10x_amd.ABI_VERSION == 2
+    assert hip.h10x_abi_version() == hash10x_amd.ABI_VERSION == 3
     assert hash10x_amd.device_count() >= 1
     assert hip.h10x_factor1_from_seed(17) == 0x49308BB9003CB3AD
     # the library that is mapped was built from the sources of this tree (the .so files are git-ignored and ship prebuilt)
@@ -436,20 +436,46 @@ def test_sharded_list_offsets_beyond_32_bits(workdir, shift, fake):
     assert got == exp, orc.describe_diff(got, exp)
 
 
-@pytest.mark.parametrize("mode", [0, 1, 2], ids=["lookup", "scatter", "lookup_then_scatter"])
+@pytest.mark.parametrize("mode", [0, 1, 2, 3, 4], ids=["lookup", "scatter", "lookup_then_scatter", "lookup_table_fails", "lookup_table_does_not_fit"])
 def test_sharded_owner_replies(workdir, mode):
     """How a hash owner tells every entry its index (shard.hip step 5): by look-up in a table of its distinct hashes, arrival order (the default where entries travel packed),
-    by scattering from its sorted order (the sort carries arrival positions: round 4's form, still what unpacked entries take), and the path a full table takes (look up,
-    then answer by scatter all the same). 3 ranks and 1 rank, each byte-equal to the oracle."""
+    by scattering from its sorted order (the sort carries arrival positions: round 4's form, still what unpacked entries take), and the look-up's fall-backs: a look-up that
+    succeeds answered by scatter all the same (2), a table whose displacement limit is 1 so that it really FAILS (3: the recovery path of the default mechanism), a table that
+    does not fit the free memory (4). h10x_counters.shard_reply_path says which path answered (mode 2 used to be mode 1 in disguise). 3 ranks and 1 rank, each
+    byte-equal to the oracle."""
     recs = orc.gen_fqb(workdir.file("x.fqb"), 40000, 180, 300000, 0.003, 61, 4.0, 150, 6000)
     o = orc.Oracle(B=20)
     o.read_fqb(recs); o.depth_range(4, 30); o.cluster(1, 0, 3)
     o.write_hash(workdir.file("orc.hash"))
     exp = open(workdir.file("orc.hash"), "rb").read()
+    want = {0: 1, 1: 2, 2: 3, 3: 3, 4: 3}[mode]
     for nranks in (3, 1):
-        _run_sharded(recs, nranks, 20, 4, 30, 3, workdir.file("hip.hash"), opts={"shard_reply_sort": mode})
+        path = [None] * nranks
+        _run_sharded(recs, nranks, 20, 4, 30, 3, workdir.file("hip.hash"), opts={"shard_reply_sort": mode},
+                     after=lambda h, r: path.__setitem__(r, h.counters()["shard_reply_path"]))
         got = open(workdir.file("hip.hash"), "rb").read()
         assert got == exp, orc.describe_diff(got, exp)
+        assert path == [want] * nranks, path
+
+
+def test_hash_owner_shares_are_balanced(workdir):
+    """Hash owners hold equal SHARES of the entries, not equal value ranges: a canonical hash is min(hashF, hashR) (seqhash.c:67-68), density 2 (1 - x), so equal ranges gave owner 0
+    of 8 1 - (7/8)^2 = 23.4 %. Cut at the quantiles (shard.hip ownerCuts) the busiest owner of 8 receives at most 14 % of the index replies; the old cut (knob
+    shard_owner_cut = 1) shows the 23 %; both byte-equal to the oracle."""
+    recs = orc.gen_fqb(workdir.file("x.fqb"), 60000, 240, 400000, 0.003, 67, 4.0, 150, 6000)
+    o = orc.Oracle(B=21)
+    o.read_fqb(recs); o.depth_range(4, 30); o.cluster(1, 0, 3)
+    o.write_hash(workdir.file("orc.hash"))
+    exp = open(workdir.file("orc.hash"), "rb").read()
+    share = {}
+    for cut in (0, 1):
+        out = [None] * 8
+        _run_sharded(recs, 8, 21, 4, 30, 3, workdir.file("hip.hash"), opts={"shard_owner_cut": cut},
+                     after=lambda h, r: out.__setitem__(r, h.exchanges()["indices_back (all-to-all)"]["bytes_out"]))
+        assert open(workdir.file("hip.hash"), "rb").read() == exp
+        share[cut] = max(out) / sum(out)
+    assert share[0] <= 0.14, share
+    assert 0.21 <= share[1] <= 0.26, share
 
 
 def test_gather_then_continue_on_one_gpu(workdir):

@@ -40,7 +40,7 @@ def test_c_abi_exports_every_declared_symbol(native):
     for n in _declared("hash10x_amd/host/h10x_host.h"):
         assert hasattr(host, n), "libh10x_host.so does not export %s" % n
     import hash10x_amd
-    assert hip.h10x_abi_version() == hash10x_amd.ABI_VERSION == 2
+    assert hip.h10x_abi_version() == hash10x_amd.ABI_VERSION == 3
 
 
 def test_no_cpu_fallback(native):
