@@ -666,19 +666,30 @@ def rank_figures(h):
 def scaling_model(per_rank, single_ms):
     """A MODEL of the N-GPU step from figures measured on ONE GPU (ranks taking turns): max over ranks of their compute + per kind of exchange the largest per-peer
     share any rank sends, over one xGMI link at 80 % of its rate (the all-to-alls are grouped point-to-point sends: every link of a rank works at once, the busiest
-    pair bounds the call), + 30 us per call. No overlap of exchange and compute is assumed (there is none in the code). Not a measurement."""
+    pair bounds the call), + 30 us per call. An exchange the library queues on its exchange stream BESIDE a stage (h10x_exchange_beside: the in-range lists beside the
+    good lists, hashDepth[] beside the ClusterHash records) is charged only with what exceeds that stage's compute on the rank where it is shortest; every other
+    exchange in full. Not a measurement."""
     n = len(per_rank)
     comp = [r["compute_ms"] for r in per_rank]
     kinds = sorted({k for r in per_rank for k in r["exchanges"]})
     ex = {}
     xfer_ms = 0.0
+    cover = {}                                               # per stage: what is left of its (shortest) compute to hide exchanges behind
     for k in kinds:
         peer = max(r["exchanges"].get(k, {}).get("max_peer_out", 0) for r in per_rank)
         out = [r["exchanges"].get(k, {}).get("bytes_out", 0) for r in per_rank]
         calls = max(r["exchanges"].get(k, {}).get("calls", 0) for r in per_rank)
         ms = peer / (0.8 * XGMI_LINK_GBS * 1e9) * 1e3 + 0.03 * calls
-        xfer_ms += ms
+        beside = next((r["exchanges"][k].get("beside") for r in per_rank if k in r["exchanges"] and r["exchanges"][k].get("beside")), None)
+        exposed = ms
+        if beside:
+            if beside not in cover:
+                cover[beside] = min(r["stage_compute_ms"].get(beside, 0.0) for r in per_rank)
+            hidden = min(ms, cover[beside]); cover[beside] -= hidden; exposed = ms - hidden
+        xfer_ms += exposed
         ex[k] = {"calls_per_step": calls, "max_rank_bytes_out": max(out), "sum_bytes_out": sum(out), "busiest_peer_share_bytes": peer, "modelled_ms": round(ms, 3)}
+        if beside:
+            ex[k]["beside"] = beside; ex[k]["exposed_ms"] = round(exposed, 3)
     step = max(comp) + xfer_ms
     back = [r["exchanges"].get("indices_back (all-to-all)", {}).get("bytes_out", 0) for r in per_rank]      # what an owner answers = the entries it owns
     return {"ranks": n, "max_rank_compute_ms": round(max(comp), 3), "mean_rank_compute_ms": round(sum(comp) / n, 3), "compute_imbalance": round(max(comp) / (sum(comp) / n), 3) if sum(comp) else None,
@@ -686,7 +697,7 @@ def scaling_model(per_rank, single_ms):
             "modelled_speedup_vs_1_gpu": round(single_ms / step, 2) if step else None, "exchanges": ex,
             "busiest_owner_share": round(max(back) / sum(back), 4) if sum(back) else None,
             "model": "max rank compute (stage timers less the waits inside them, ranks taking turns on one GPU) + sum over exchanges of busiest-peer bytes / (0.8 x %.0f GB/s) + 30 us per call; "
-                     "no overlap assumed; a MODEL, not a measurement" % XGMI_LINK_GBS}
+                     "an exchange queued beside a stage counts with what exceeds that stage's shortest compute; a MODEL, not a measurement" % XGMI_LINK_GBS}
 
 
 def virtual_ranks_block(hash10x_amd, name, n, local_rank=0, steps=1):

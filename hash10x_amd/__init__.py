@@ -137,6 +137,7 @@ def load_native():
     hip.h10x_timing_get.argtypes = [vp, ci, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(cu64)]
     hip.h10x_timing_reset.argtypes = [vp]
     hip.h10x_exchange_name.restype = cs; hip.h10x_exchange_name.argtypes = [ci]
+    hip.h10x_exchange_beside.restype = ci; hip.h10x_exchange_beside.argtypes = [vp, ci]
     hip.h10x_timing_wait_get.argtypes = [vp, ci, ctypes.POINTER(ctypes.c_double)]
     hip.h10x_exchange_get.argtypes = [vp, ci, ctypes.POINTER(cu64), ctypes.POINTER(cu64), ctypes.POINTER(cu64), ctypes.POINTER(cu64), ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]
     hip.h10x_comm_local_serialize.argtypes = [vp, ci]
@@ -560,7 +561,9 @@ class Hash10x:
             v = [ctypes.c_uint64(0) for _ in range(4)]; ms, ms_in = ctypes.c_double(0), ctypes.c_double(0)
             self._hip.h10x_exchange_get(self._ctx(), i, ctypes.byref(v[0]), ctypes.byref(v[1]), ctypes.byref(v[2]), ctypes.byref(v[3]), ctypes.byref(ms), ctypes.byref(ms_in))
             if v[0].value:
-                out[self._hip.h10x_exchange_name(i).decode()] = {"calls": v[0].value, "bytes_out": v[1].value, "bytes_in": v[2].value, "max_peer_out": v[3].value, "ms": ms.value, "ms_in_stages": ms_in.value}
+                b = self._hip.h10x_exchange_beside(self._ctx(), i)
+                out[self._hip.h10x_exchange_name(i).decode()] = {"calls": v[0].value, "bytes_out": v[1].value, "bytes_in": v[2].value, "max_peer_out": v[3].value, "ms": ms.value, "ms_in_stages": ms_in.value,
+                                                                 "beside": self._hip.h10x_timing_name(self._ctx(), b).decode() if b >= 0 else None}
         return out
 
     def reset_timings(self):

@@ -13,16 +13,17 @@ struct RcclComm : Comm {
   ~RcclComm() override { if (nc) (void)ncclCommDestroy(nc); }
   int chk(Ctx *c, ncclResult_t r, const char *what) { return r == ncclSuccess ? 0 : c->fail("RCCL %s failed: %s", what, ncclGetErrorString(r)); }
   int alltoallv(Ctx *c, const void *dSend, const u64 *sendCnt, const u64 *sendOff, void *dRecv, const u64 *recvCnt, const u64 *recvOff,
-                size_t eb) override {
+                size_t eb, hipStream_t stArg) override {
+    hipStream_t const st = stArg ? stArg : c->stream;
     // self part by a device copy, peers by one grouped send/recv round (point-to-point over xGMI, all links at once)
     if (sendCnt[rank]) H10X_HIP(c, hipMemcpyAsync((char *)dRecv + recvOff[rank] * eb, (const char *)dSend + sendOff[rank] * eb, sendCnt[rank] * eb,
-                                                   hipMemcpyDeviceToDevice, c->stream));
+                                                   hipMemcpyDeviceToDevice, st));
     H10X_TRY(chk(c, ncclGroupStart(), "GroupStart"));
     ncclResult_t bad = ncclSuccess; const char *what = "";
     for (int p = 0; p < n && bad == ncclSuccess; ++p) {
       if (p == rank) continue;
-      if (sendCnt[p] && (bad = ncclSend((const char *)dSend + sendOff[p] * eb, sendCnt[p] * eb, ncclChar, p, nc, c->stream)) != ncclSuccess) { what = "Send"; break; }
-      if (recvCnt[p] && (bad = ncclRecv((char *)dRecv + recvOff[p] * eb, recvCnt[p] * eb, ncclChar, p, nc, c->stream)) != ncclSuccess) { what = "Recv"; break; }
+      if (sendCnt[p] && (bad = ncclSend((const char *)dSend + sendOff[p] * eb, sendCnt[p] * eb, ncclChar, p, nc, st)) != ncclSuccess) { what = "Send"; break; }
+      if (recvCnt[p] && (bad = ncclRecv((char *)dRecv + recvOff[p] * eb, recvCnt[p] * eb, ncclChar, p, nc, st)) != ncclSuccess) { what = "Recv"; break; }
     }
     const ncclResult_t end = ncclGroupEnd();                 // always closed, also after a failed call inside the group
     if (bad != ncclSuccess) return chk(c, bad, what);
@@ -75,8 +76,9 @@ struct LocalComm : Comm {
   void yield(Ctx *c) { if (g->serialize) { if (c) (void)hipStreamSynchronize(c->stream); g->tokRelease(rank); } }   // my kernels are done: somebody else's turn
   void resume() { if (g->serialize) g->tokAcquire(rank); }
   int alltoallv(Ctx *c, const void *dSend, const u64 *sendCnt, const u64 *sendOff, void *dRecv, const u64 *recvCnt, const u64 *recvOff,
-                size_t eb) override {
-    H10X_HIP(c, hipStreamSynchronize(c->stream));            // my send buffer is complete
+                size_t eb, hipStream_t stArg) override {
+    hipStream_t const st = stArg ? stArg : c->stream;       // (threads of one process rendezvous on the host: an exchange on the side stream is complete when this returns)
+    H10X_HIP(c, hipStreamSynchronize(st));                   // my send buffer is complete
     yield(c);
     struct Back { LocalComm *l; ~Back() { l->resume(); } } back{this};
     g->sendPtr[rank] = dSend; g->sendCnt[rank] = sendCnt; g->sendOff[rank] = sendOff;
@@ -85,10 +87,10 @@ struct LocalComm : Comm {
     for (int p = 0; p < n && !rc; ++p) {                     // pull my part from every rank (may live on another device)
       const u64 cnt = g->sendCnt[p][rank];
       if (cnt != recvCnt[p]) rc = c->fail("alltoallv: rank %d sends %llu elements to rank %d which expects %llu", p, (u64)cnt, rank, (u64)recvCnt[p]);
-      else if (cnt && hipMemcpyAsync((char *)dRecv + recvOff[p] * eb, (const char *)g->sendPtr[p] + g->sendOff[p][rank] * eb, cnt * eb, hipMemcpyDefault, c->stream) != hipSuccess)
+      else if (cnt && hipMemcpyAsync((char *)dRecv + recvOff[p] * eb, (const char *)g->sendPtr[p] + g->sendOff[p][rank] * eb, cnt * eb, hipMemcpyDefault, st) != hipSuccess)
         rc = c->fail("alltoallv: device copy from rank %d failed", p);
     }
-    if (!rc && hipStreamSynchronize(c->stream) != hipSuccess) rc = c->fail("alltoallv: stream synchronisation failed");
+    if (!rc && hipStreamSynchronize(st) != hipSuccess) rc = c->fail("alltoallv: stream synchronisation failed");
     // nobody reuses a send buffer before everyone has pulled — and everybody leaves with the same verdict (a rank that
     // returned early would leave the others waiting here for ever)
     if (g->wait(rc != 0) && !rc) rc = c->fail("alltoallv failed on another rank");
@@ -157,15 +159,16 @@ struct SockComm : Comm {
     }
     return 0;
   }
-  int alltoallv(Ctx *c, const void *dSend, const u64 *sendCnt, const u64 *sendOff, void *dRecv, const u64 *recvCnt, const u64 *recvOff, size_t eb) override {
+  int alltoallv(Ctx *c, const void *dSend, const u64 *sendCnt, const u64 *sendOff, void *dRecv, const u64 *recvCnt, const u64 *recvOff, size_t eb, hipStream_t stArg) override {
+    hipStream_t const st = stArg ? stArg : c->stream;
     std::vector<u64> sc((size_t)n), so((size_t)n), rc((size_t)n), ro((size_t)n); u64 ts = 0, tr = 0;
     for (int p = 0; p < n; ++p) { sc[p] = sendCnt[p] * eb; so[p] = ts; ts += sc[p]; rc[p] = recvCnt[p] * eb; ro[p] = tr; tr += rc[p]; }
     std::vector<char> hs(ts ? ts : 1), hr(tr ? tr : 1);
-    for (int p = 0; p < n; ++p) if (sc[p]) H10X_HIP(c, hipMemcpyAsync(hs.data() + so[p], (const char *)dSend + sendOff[p] * eb, sc[p], hipMemcpyDeviceToHost, c->stream));
-    H10X_HIP(c, hipStreamSynchronize(c->stream));
+    for (int p = 0; p < n; ++p) if (sc[p]) H10X_HIP(c, hipMemcpyAsync(hs.data() + so[p], (const char *)dSend + sendOff[p] * eb, sc[p], hipMemcpyDeviceToHost, st));
+    H10X_HIP(c, hipStreamSynchronize(st));
     H10X_TRY(exchange(c, hs.data(), sc.data(), so.data(), hr.data(), rc.data(), ro.data()));
-    for (int p = 0; p < n; ++p) if (rc[p]) H10X_HIP(c, hipMemcpyAsync((char *)dRecv + recvOff[p] * eb, hr.data() + ro[p], rc[p], hipMemcpyHostToDevice, c->stream));
-    H10X_HIP(c, hipStreamSynchronize(c->stream));
+    for (int p = 0; p < n; ++p) if (rc[p]) H10X_HIP(c, hipMemcpyAsync((char *)dRecv + recvOff[p] * eb, hr.data() + ro[p], rc[p], hipMemcpyHostToDevice, st));
+    H10X_HIP(c, hipStreamSynchronize(st));
     return 0;
   }
   int allgatherHost(Ctx *c, const void *send, void *recv, size_t bytes) override {

@@ -15,9 +15,11 @@ struct Comm {
   // recv[r*bytes .. ) = send of rank r
   virtual int allgatherHost(Ctx *c, const void *send, void *recv, size_t bytes) = 0;
   // for every peer p: send elements [sendOff[p], sendOff[p]+sendCnt[p]) of dSend to p; receive recvCnt[p] elements
-  // from p at recvOff[p] of dRecv. Counts/offsets in elements of elemBytes bytes. Completes on c->stream.
+  // from p at recvOff[p] of dRecv. Counts/offsets in elements of elemBytes bytes. Completes on `st` (null = c->stream): an exchange whose result is not needed
+  // until a later stage goes on the context's exchange stream (Ctx::xFork / xJoin) and runs beside the kernels of the main stream — every rank issues its
+  // collectives in the same order whatever the stream, and joins before the next one.
   virtual int alltoallv(Ctx *c, const void *dSend, const u64 *sendCnt, const u64 *sendOff, void *dRecv, const u64 *recvCnt,
-                        const u64 *recvOff, size_t elemBytes) = 0;
+                        const u64 *recvOff, size_t elemBytes, hipStream_t st = nullptr) = 0;
   virtual int barrier(Ctx *c) = 0;
   // max over ranks of a host double (timing plumbing)
   virtual int allreduceMaxHost(Ctx *c, double *v) = 0;

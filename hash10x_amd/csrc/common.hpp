@@ -128,7 +128,7 @@ static const char *const kXchgNames[X_COUNT] = {
   "host_counts (small host allgathers: sizes, counts)", "entries_to_hash_owners (all-to-all)", "first_seen_counts (allgather)", "indices_back (all-to-all)",
   "index_depth (allgather)", "list_heads (allgather: index + length of the in-range hashes)", "list_data (allgather: the in-range barcode lists)",
   "hash_tables (allgather: hashValue, for --writeHash / the crib)", "owner_lists_rebuild (after --clusterSplit)", "gather_to_rank0" };
-struct XchgStat { u64 calls = 0, bytesOut = 0, bytesIn = 0, maxPeerOut = 0; Timer t, tIn; };   // tIn: the calls made inside a stage timer's bracket (their time is part of that stage's figure)
+struct XchgStat { u64 calls = 0, bytesOut = 0, bytesIn = 0, maxPeerOut = 0; Timer t, tIn; int beside = -1; };   // beside: the stage timer whose kernels run while this exchange is on the exchange stream (-1: on the main stream, nothing beside it)   // tIn: the calls made inside a stage timer's bracket (their time is part of that stage's figure)
 
 // ---- local block number -> global block number ------------------------------------------------------
 // An unsharded context numbers its blocks as the reference does (one segment, identity). A shard owns a contiguous range
@@ -237,6 +237,7 @@ struct Ctx {
   int64_t optRowShift = -1;   // testing knob: force the list alignment of the sharded rows[] (-1 = as small as the offsets allow)
   int64_t optReplySort = 0;   // sharded index build, how an owner answers: 0 = by look-up in a table of its distinct hashes (packed entries), 1 = by scattering from the sorted order (the sort carries arrival positions; round 4's form),
                               // tests of the look-up's fall-back: 2 = look up, then answer by scatter all the same, 3 = a table whose displacement limit is 1 (it FAILS), 4 = as if the table did not fit the free memory
+  int64_t optOverlap = 1;     // sharded path: 1 = exchanges whose result a later stage needs run on the exchange stream beside the main stream's kernels (the in-range lists beside the good lists, hashDepth[] beside the ClusterHash records), 0 = every exchange on the main stream (round 5)
   int64_t optOwnerCut = 0;    // sharded index build, where the hash owners' value ranges are cut: 0 = at the quantiles of the canonical-hash density 2 (1 - x) (equal shares), 1 = equal value ranges (round 5: owner 0 of 8 holds 23.4 %)
   int64_t optDeltaLists = -1; // in-range barcode lists travel delta-coded between ranks: -1 = where bytes are dear (more than one rank on the host-staged TCP backend; not over xGMI: DESIGN 5), 0 never, 1 always (tests)
   int64_t optRowsFakeBase = 0; // testing knob: list offsets start at this many entries (multiple of 2^rowShift) in front of the real array: 64-bit offsets on small inputs
@@ -293,6 +294,28 @@ struct Ctx {
     for (int i = 0; i < n; ++i) if (hipStreamWaitEvent(aux[i], evFork, 0) != hipSuccess) return fail("hipStreamWaitEvent failed");
     return 0;
   }
+  // The exchange stream: a collective whose result a LATER stage needs (the in-range barcode lists: wanted by --cluster, not by the good lists; hashDepth[] of the other
+  // owners: wanted by --hashDepthRange, not by the ClusterHash records) is queued here and runs beside the main stream's kernels. xFork(): the exchange stream waits for
+  // what the main stream has queued so far (the send buffers); xJoin(): the main stream waits for the exchange, and the buffers parked in xHold — send buffers that must
+  // outlive the function that filled them — go back to the block cache (whose reuse order is the main stream's: not before this point).
+  hipStream_t xStream = nullptr; hipEvent_t evXFork = nullptr, evXDone = nullptr; bool xOpen = false;
+  DevBuf<u32> xHold[4];
+  int xFork() {
+    if (!xStream) {
+      if (hipStreamCreateWithFlags(&xStream, hipStreamNonBlocking) != hipSuccess) return fail("hipStreamCreate failed");
+      if (hipEventCreateWithFlags(&evXFork, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&evXDone, hipEventDisableTiming) != hipSuccess) return fail("hipEventCreate failed");
+    }
+    if (hipEventRecord(evXFork, stream) != hipSuccess || hipStreamWaitEvent(xStream, evXFork, 0) != hipSuccess) return fail("hipStreamWaitEvent failed");
+    xOpen = true;
+    return 0;
+  }
+  int xJoin() {
+    if (!xOpen) return 0;
+    xOpen = false;
+    if (hipEventRecord(evXDone, xStream) != hipSuccess || hipStreamWaitEvent(stream, evXDone, 0) != hipSuccess) return fail("hipStreamWaitEvent failed");
+    for (auto &b : xHold) b.release();
+    return 0;
+  }
   int joinStreams(int n) {                               // the main stream waits for the side streams
     for (int i = 0; i < n; ++i) {
       if (hipEventRecord(evJoin[i], aux[i]) != hipSuccess) return fail("hipEventRecord failed");
@@ -339,6 +362,14 @@ struct ForkGuard {
   ForkGuard(const ForkGuard &) = delete; ForkGuard &operator=(const ForkGuard &) = delete;
   ~ForkGuard() { if (!armed) return; for (int i = 0; i < 3; ++i) if (c->aux[i]) (void)hipStreamSynchronize(c->aux[i]); (void)hipStreamSynchronize(c->stream); }
   void done() { armed = false; }
+};
+
+// An exchange on the exchange stream whose function leaves early: wait for it before the buffers it uses go back to the block cache
+struct XGuard {
+  Ctx *c;
+  explicit XGuard(Ctx *c_) : c(c_) {}
+  XGuard(const XGuard &) = delete; XGuard &operator=(const XGuard &) = delete;
+  ~XGuard() { if (!c->xOpen) return; (void)hipStreamSynchronize(c->xStream); c->xOpen = false; for (auto &b : c->xHold) b.release(); }
 };
 
 #define H10X_HIP(ctx, call)                                                                      \

@@ -15,7 +15,7 @@ static int enter(Ctx &c) {
   DevCache::noteStream(c.device, c.stream);
   c.pendingReads.clear(); c.mailUsed = 0; c.mailDirect = false;                    // read-backs a failed call left behind point into its dead frame
   c.stageReset();                                                                   // (and so do the stage timers a failed call left open)
-  return 0;
+  return 0;                                                                         // (an exchange still on the exchange stream is joined by the command that needs its result: stageC_cluster, shard_*)
 }
 
 struct h10x_ctx { Ctx c; };
@@ -88,6 +88,9 @@ void h10x_destroy(h10x_ctx *h) {
   for (auto &t : h->c.timers) { if (t.a) (void)hipEventDestroy(t.a); if (t.b) (void)hipEventDestroy(t.b); }
   for (int i = 0; i < 3; ++i) { if (h->c.aux[i]) { (void)hipStreamSynchronize(h->c.aux[i]); (void)hipStreamDestroy(h->c.aux[i]); } if (h->c.evJoin[i]) (void)hipEventDestroy(h->c.evJoin[i]); }
   if (h->c.evFork) (void)hipEventDestroy(h->c.evFork);
+  if (h->c.xStream) { (void)hipStreamSynchronize(h->c.xStream); (void)hipStreamDestroy(h->c.xStream); h->c.xStream = nullptr; }
+  if (h->c.evXFork) (void)hipEventDestroy(h->c.evXFork);
+  if (h->c.evXDone) (void)hipEventDestroy(h->c.evXDone);
   for (auto &e : h->c.ingestEv) if (e) (void)hipEventDestroy(e);
   if (h->c.startFlags) (void)hipHostFree(h->c.startFlags);
   if (h->c.mail) (void)hipHostFree(h->c.mail);
@@ -535,6 +538,7 @@ int h10x_exchange_get(h10x_ctx *h, int i, uint64_t *calls, uint64_t *bytesOut, u
   if (ms) *ms = x.t.ms + x.tIn.ms;
   return 0;
 }
+int h10x_exchange_beside(h10x_ctx *h, int i) { return (!h || i < 0 || i >= X_COUNT) ? -1 : h->c.xs[i].beside; }
 int h10x_sort_fqb_device(h10x_ctx *h, const uint32_t *dIn, uint64_t n, uint32_t *dOut) {
   if (!h) return -1;
   Ctx &c = h->c; H10X_TRY(enter(c));
@@ -680,6 +684,7 @@ int h10x_set_option(h10x_ctx *h, const char *name, int64_t value) {
   if (!strcmp(name, "fault_inject")) { h->c.optFaultInject = value; return 0; }
   if (!strcmp(name, "shard_row_shift")) { if (value < -1 || value > 8) return h->c.fail("shard_row_shift must be -1..8"); h->c.optRowShift = value; return 0; }
   if (!strcmp(name, "shard_reply_sort")) { if (value < 0 || value > 4) return h->c.fail("shard_reply_sort must be 0..4"); h->c.optReplySort = value; return 0; }
+  if (!strcmp(name, "shard_overlap")) { h->c.optOverlap = value ? 1 : 0; return 0; }
   if (!strcmp(name, "shard_owner_cut")) { if (value < 0 || value > 1) return h->c.fail("shard_owner_cut must be 0 or 1"); h->c.optOwnerCut = value; return 0; }
   if (!strcmp(name, "shard_delta_lists")) { if (value < -1 || value > 1) return h->c.fail("shard_delta_lists must be -1, 0 or 1"); h->c.optDeltaLists = value; return 0; }
   if (!strcmp(name, "shard_rows_fake_base")) { if (value < 0) return h->c.fail("shard_rows_fake_base must be >= 0"); h->c.optRowsFakeBase = value; return 0; }

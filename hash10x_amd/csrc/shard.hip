@@ -197,16 +197,19 @@ __global__ void scatter_value_kernel(const u32 *__restrict__ idx, const u64 *__r
 }
 
 // every collective of this file goes through these two: byte and time accounting per kind of exchange (common.hpp XchgStat)
-static int xchg_a2a(Ctx *c, Comm *cm, XchgId id, const void *dSend, const u64 *sendCnt, const u64 *sendOff, void *dRecv, const u64 *recvCnt, const u64 *recvOff, size_t eb) {
+// beside >= 0: the exchange goes on the context's exchange stream (the caller has called xFork() and will call xJoin() before the next collective and before the result
+// is used) and runs beside the kernels of stage timer `beside` on the main stream
+static int xchg_a2a(Ctx *c, Comm *cm, XchgId id, const void *dSend, const u64 *sendCnt, const u64 *sendOff, void *dRecv, const u64 *recvCnt, const u64 *recvOff, size_t eb, int beside = -1) {
   XchgStat &x = c->xs[id]; ++x.calls;
   u64 peer = 0;
   for (int p = 0; p < cm->n; ++p) if (p != cm->rank) { x.bytesOut += sendCnt[p] * eb; x.bytesIn += recvCnt[p] * eb; if (sendCnt[p] * eb > peer) peer = sendCnt[p] * eb; }
   x.maxPeerOut += peer;
+  x.beside = beside;                                          // (the timers below stay on the MAIN stream: where the host blocks in the call — ranks as threads, TCP — they hold the wait, with RCCL they read ~0)
   Timer &t = c->stageOpen > 0 ? x.tIn : x.t;
   Timer *const ts = c->stageTop < T_COUNT ? &c->stageWait[c->stageTop] : nullptr;
   if (ts) c->tstart(*ts);
   c->tstart(t);
-  const int rc = cm->alltoallv(c, dSend, sendCnt, sendOff, dRecv, recvCnt, recvOff, eb);
+  const int rc = cm->alltoallv(c, dSend, sendCnt, sendOff, dRecv, recvCnt, recvOff, eb, beside >= 0 ? c->xStream : nullptr);
   c->tstop(t);
   if (ts) c->tstop(*ts);
   return rc;
@@ -434,16 +437,11 @@ int shard_readFqb(Ctx *c, Comm *cm, const u32 *dRec, u64 nRec) {
   H10X_TRY(xchg_a2a(c, cm, X_INDEX_BACK, reply.p, recvCnt.data(), recvOff.data(), rIdx.p, sendCnt.data(), sendOff.data(), 4));
   c->hashNumber = U + 1; c->depthBound = nB;
   c->tstop(T_RANK);
-  c->tstart(T_CLUSHASH);
-  { DevBuf<u64> key; H10X_HIP(c, key.alloc(H));
-    if (H) scatter_key_kernel<<<gridFor(H), 256, 0, st>>>(rIdx.p, perm.p, entRead.p, H, key.p);
-    H10X_TRY(stageB_finishClusHash(c, key)); }
-  c->tstop(T_CLUSHASH);
-
   // ---- 6. everyone gets hashDepth[] (the depth filter needs it in full). hashValue[] and the probe table hashIndex[] are
   //         only wanted by --writeHash / the crib: they are built when the shards are gathered (shard_materializeTables),
   //         not on every rank after every --readFQB (at N = 8: 24 M hash values allgathered and inserted into a 512 MB
-  //         table per rank, for nothing on the clustering path)
+  //         table per rank, for nothing on the clustering path).
+  //         Round 6: the two allgathers go on the exchange stream and run beside the ClusterHash records of step 7 (which need the replies only).
   c->tstart(T_PROBE);
   std::vector<u64> uo((size_t)N); { u64 u = Uo; H10X_TRY(xchg_hostGather(c, cm, &u, uo.data(), 8)); }
   std::vector<u64> sc((size_t)N, Uo), so((size_t)N, 0), rc((size_t)N), ro((size_t)N); u64 Utot = 0;
@@ -452,8 +450,20 @@ int shard_readFqb(Ctx *c, Comm *cm, const u32 *dRec, u64 nRec) {
   DevBuf<u32> dDepth, gIdx, gDepth;
   H10X_HIP(c, dDepth.alloc(Uo)); H10X_HIP(c, gIdx.alloc(U)); H10X_HIP(c, gDepth.alloc(U));
   if (Uo) depth_of_kernel<<<divUp(Uo, 256), 256, 0, st>>>(c->oSegStart.p, Uo, dDepth.p);
-  H10X_TRY(xchg_a2a(c, cm, X_INDEX_DEPTH, c->oIndex.p, sc.data(), so.data(), gIdx.p, rc.data(), ro.data(), 4));
-  H10X_TRY(xchg_a2a(c, cm, X_INDEX_DEPTH, dDepth.p, sc.data(), so.data(), gDepth.p, rc.data(), ro.data(), 4));
+  const int besideClus = c->optOverlap ? (int)T_CLUSHASH : -1;
+  XGuard xGuard(c);                                          // (an error return below must not park gIdx / gDepth / dDepth while the exchange stream still uses them)
+  if (besideClus >= 0) H10X_TRY(c->xFork());
+  H10X_TRY(xchg_a2a(c, cm, X_INDEX_DEPTH, c->oIndex.p, sc.data(), so.data(), gIdx.p, rc.data(), ro.data(), 4, besideClus));
+  H10X_TRY(xchg_a2a(c, cm, X_INDEX_DEPTH, dDepth.p, sc.data(), so.data(), gDepth.p, rc.data(), ro.data(), 4, besideClus));
+  c->tstop(T_PROBE);
+  // ---- 7. the ClusterHash records of my blocks from the replies
+  c->tstart(T_CLUSHASH);
+  { DevBuf<u64> key; H10X_HIP(c, key.alloc(H));
+    if (H) scatter_key_kernel<<<gridFor(H), 256, 0, st>>>(rIdx.p, perm.p, entRead.p, H, key.p);
+    H10X_TRY(stageB_finishClusHash(c, key)); }
+  c->tstop(T_CLUSHASH);
+  c->tstart(T_PROBE);
+  H10X_TRY(c->xJoin());
   H10X_HIP(c, c->hashDepth.alloc((size_t)U + 1));
   H10X_HIP(c, hipMemsetAsync(c->hashDepth.p, 0, 4, st));
   if (U) scatter_depth_kernel<<<gridFor(U), 256, 0, st>>>(gIdx.p, gDepth.p, U, c->hashDepth.p);
@@ -677,8 +687,13 @@ int shard_exchangeRows(Ctx *c) {
   H10X_HIP(c, hipMemsetAsync(aLen.p + nG, 0, 4, st));
   H10X_TRY(prim_exclusive_scan_u32_u64(c, pt, aLen.p, aOff.p, nG + 1));
   if (!delta) {
+    // Round 6: the lists themselves are wanted by --cluster only — the good lists need where a list STARTS (rowStart[], from the heads above), not what it holds — so they
+    // travel on the exchange stream beside good_block_kernel; stageC_depthRange joins behind its last launch. The send buffer outlives this function in Ctx::xHold.
+    const int beside = c->optOverlap ? (int)T_GOOD : -1;
     nR = 0; for (int r = 0; r < N; ++r) { sc[r] = mine[1]; ro[r] = nR; nR += rc[r]; }
-    H10X_TRY(xchg_a2a(c, cm, X_LIST_DATA, gRows.p, sc.data(), so.data(), c->rows.p, rc.data(), ro.data(), 4));
+    if (beside >= 0) H10X_TRY(c->xFork());
+    H10X_TRY(xchg_a2a(c, cm, X_LIST_DATA, gRows.p, sc.data(), so.data(), c->rows.p, rc.data(), ro.data(), 4, beside));
+    if (beside >= 0) c->xHold[0].swap(gRows);
   } else {
     // coded lengths, coded stream, the same allgather-shaped exchange, decode into the padded layout (see delta_len_kernel)
     DevBuf<u32> encLen, gEnc, enc, aEnc, encAll, aWords; DevBuf<u64> encOff, eOff;

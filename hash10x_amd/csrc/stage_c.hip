@@ -178,6 +178,7 @@ int stageC_depthRange(Ctx *c, int lo, int hi) {
   }
   // sharded: the barcode lists of the in-range hashes come from their owners first (they depend on the ranges alone), so that
   // the good lists below can point into them
+  XGuard xGuard(c);                                          // (the lists may still be arriving on the exchange stream when this function leaves early)
   if (c->sharded) { c->tstop(T_GOOD); H10X_TRY(shard_exchangeRows(c)); c->tstart(T_GOOD); }
   // goodHashesBuild (hash10x.c:738-766)
   DevBuf<u64> key, keyS; DevBuf<u32> key32, keyS32, off32, segEnd, wdepth, red;
@@ -241,6 +242,7 @@ int stageC_depthRange(Ctx *c, int lo, int hi) {
   if (!byBlocks && nBlocks) good_rows_kernel<<<hmin<u32>(nBlocks, 65535u * 4), 256, 0, st>>>(c->clusHash.p, c->blockOff.p, c->nGood.p, c->goodPos.p, nBlocks, c->hashDepth.p, c->rowStart.p,
                                                                                            (u32)c->rowShift, c->goodRow.p);
   H10X_HIP(c, hipGetLastError());                            // (no round trip here: --cluster, the next command, starts with one)
+  H10X_TRY(c->xJoin());                                      // sharded: the in-range lists have arrived before anything queued from here on runs (and before the next collective)
   c->haveGood = true;
   c->tstop(T_GOOD);
   return 0;

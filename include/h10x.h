@@ -317,6 +317,9 @@ int  h10x_timing_wait_get(h10x_ctx *ctx, int i, double *ms);
 int  h10x_exchange_count(void);
 const char *h10x_exchange_name(int i);
 int  h10x_exchange_get(h10x_ctx *ctx, int i, uint64_t *calls, uint64_t *bytesOut, uint64_t *bytesIn, uint64_t *maxPeerOut, double *ms, double *msInStages);
+/* the stage timer (index for h10x_timing_name) whose kernels ran on the main stream while exchange kind i was on the context's exchange stream, -1 if it ran on the main
+   stream with nothing beside it (option "shard_overlap" 0: always) */
+int  h10x_exchange_beside(h10x_ctx *ctx, int i);
 /* algorithmic work counters of the last commands: see DESIGN.md */
 typedef struct {
   uint64_t pairs;            /* read pairs hashed                                   */
@@ -352,6 +355,8 @@ int  h10x_get_counters(h10x_ctx *ctx, h10x_counters *out);
    "cluster_budget0" (placement and launch-class overrides of the tests), "cluster_stamps" (phase stamps into h10x_counters),
    "shard_reply_sort" (sharded index build: 0 default = a hash owner answers by look-up in a table of its distinct hashes, 1 = by scattering from its sorted order; tests of the
    fall-back, reported in h10x_counters.shard_reply_path: 2 = look up, then scatter all the same, 3 = a look-up table that fails, 4 = one that does not fit),
+   "shard_overlap" (1 default = the exchanges whose result a later stage needs — the in-range barcode lists, hashDepth[] of the other owners — run on an exchange stream beside
+   the main stream's kernels; 0 = every exchange on the main stream),
    "shard_owner_cut" (0 default = hash owners' value ranges cut at the quantiles of the canonical-hash density, equal shares; 1 = equal value ranges),
    "shard_row_shift", "shard_rows_fake_base" (sharded list offsets beyond 32 bits on small inputs), "shard_delta_lists" (-1 default:
    the in-range barcode lists travel delta-coded where bytes are dear — more than one rank on the host-staged TCP backend, not over xGMI; 0 never; 1 always). Unknown name: -1. */

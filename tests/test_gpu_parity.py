@@ -478,6 +478,27 @@ def test_hash_owner_shares_are_balanced(workdir):
     assert 0.21 <= share[1] <= 0.26, share
 
 
+@pytest.mark.parametrize("overlap", [1, 0], ids=["exchange_stream", "main_stream"])
+def test_sharded_exchanges_beside_compute(workdir, overlap):
+    """Round 6: the exchanges whose result a LATER stage needs run on the context's exchange stream beside the main stream's kernels — the in-range barcode lists beside the
+    good lists (wanted by --cluster), hashDepth[] of the other owners beside the ClusterHash records (wanted by --hashDepthRange); knob shard_overlap 0 = everything on the
+    main stream as in round 5. Both byte-equal to the oracle, on 3 ranks and on 1, and h10x_exchange_beside says which way the exchanges went."""
+    recs = orc.gen_fqb(workdir.file("x.fqb"), 40000, 180, 300000, 0.003, 61, 4.0, 150, 6000)
+    o = orc.Oracle(B=20)
+    o.read_fqb(recs); o.depth_range(4, 30); o.cluster(1, 0, 3)
+    o.write_hash(workdir.file("orc.hash"))
+    exp = open(workdir.file("orc.hash"), "rb").read()
+    for nranks in (3, 1):
+        beside = [None] * nranks
+        _run_sharded(recs, nranks, 20, 4, 30, 3, workdir.file("hip.hash"), opts={"shard_overlap": overlap},
+                     after=lambda h, r: beside.__setitem__(r, {k.split(" ")[0]: v["beside"] for k, v in h.exchanges().items()}))
+        got = open(workdir.file("hip.hash"), "rb").read()
+        assert got == exp, orc.describe_diff(got, exp)
+        for b in beside:
+            assert b["list_data"] == ("good_hashes" if overlap else None) and b["index_depth"] == ("clushash_build" if overlap else None), b
+            assert b["entries_to_hash_owners"] is None and b["indices_back"] is None
+
+
 def test_gather_then_continue_on_one_gpu(workdir):
     """h10x_shard_gather leaves rank 0 a complete single-GPU context: its barcode lists are rebuilt, so a new depth range and
     another clustering on rank 0 alone give what one GPU gives from the start (the lists used to be stale)."""
