@@ -58,6 +58,9 @@ WORKLOADS = {
     # the same proportions at 1/4: the virtual-rank model at a second size (how much of the modelled 8-rank step is fixed cost) — no digest, parity is pinned at 1/10 and at full size
     "genome3g-quarter-75M": dict(pairs=75000000, barcodes=400000, genome=750000000, err=0.0005, mol=10.0, snp=150, mol_len=50000.0,
                                  B=28, lo=6, hi=45, ct=5, seed=3, gen=2),
+    # ... and at 1/2: the largest set the model is run on (1/10 sets misled three times) — 18 GB of records, one unsharded context and then eight ranks' shards on ONE GPU
+    "genome3g-half-150M": dict(pairs=150000000, barcodes=800000, genome=1500000000, err=0.0005, mol=10.0, snp=150, mol_len=50000.0,
+                               B=29, lo=6, hi=45, ct=5, seed=3, gen=2),
     "config3-tenth-20M": dict(pairs=20000000, barcodes=100000, genome=50000000, err=0.001, mol=10.0, snp=150, mol_len=50000.0,
                               B=26, lo=30, hi=100, ct=5, seed=2),
 }

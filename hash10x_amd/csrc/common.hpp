@@ -404,6 +404,7 @@ int stageB_run(Ctx *c, DevBuf<u64> &entHash, DevBuf<u32> &entCode, DevBuf<u32> &
 void warm_prim(hipStream_t), warm_stageA(hipStream_t), warm_stageB(hipStream_t), warm_stageC(hipStream_t), warm_stageD(hipStream_t), warm_stageE(hipStream_t), warm_shard(hipStream_t);   // h10x_warm
 int stageB_buildCSR(Ctx *c);                   // rows/rowStart from clusHash + hashDepth (fillHashTable)
 int stageB_finishClusHash(Ctx *c, DevBuf<u64> &key);   // key[e] = index << 32 | read16 in block order -> clusHash sorted per block
+int stageB_finishClusHashFromReplies(Ctx *c, const u32 *replyIdx, const u32 *replyPos, const u32 *entRead);   // sharded: entry e's index is replyIdx[replyPos[e]]
 // workgroup-local sorts of a block's entries (clushash_block_kernel, good_block_kernel): three launch classes, side by side on
 // forked streams — 256 lanes x 12 items (blocks up to 3072 entries: 98 % of them at 250 read pairs per barcode), 512 x 12, 1024 x 8
 #ifndef H10X_BS_T0

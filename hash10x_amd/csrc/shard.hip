@@ -59,7 +59,8 @@ template <int PASS>
 __global__ __launch_bounds__(256)
 void owner_partition_kernel(const u64 *__restrict__ entHash, const u32 *__restrict__ entCode, const u64 *__restrict__ blockOff, u32 nBlocks,
                             const u64 *__restrict__ lowHash /* N+1 */, int N, u32 codeBase, u32 *__restrict__ cnt /* N x nBlocks: counts, then offsets */,
-                            u64 *__restrict__ sHash, u32 *__restrict__ sCode, u32 *__restrict__ perm, int cb /* > 0: key << cb | global block in sHash, no sCode */) {
+                            u64 *__restrict__ sHash, u32 *__restrict__ sCode, u32 *__restrict__ perm /* perm[pos] = e */, int cb /* > 0: key << cb | global block in sHash, no sCode */,
+                            u32 *__restrict__ posOf = nullptr /* instead of perm: posOf[e] = pos — a coalesced store, and what the ClusterHash records gather the replies by */) {
   __shared__ u64 low[PART_MAX_OWNERS + 1];
   __shared__ u32 fill[PART_MAX_OWNERS];
   for (int o = threadIdx.x; o <= N; o += blockDim.x) low[o] = lowHash[o];
@@ -73,7 +74,7 @@ void owner_partition_kernel(const u64 *__restrict__ entHash, const u32 *__restri
       int lo = 0, hi = N;                                    // largest o with low[o] <= h
       while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (low[mid] <= h) lo = mid; else hi = mid; }
       const u32 pos = atomicAdd(&fill[lo], 1u);
-      if (PASS) { if (cb) sHash[pos] = (h << cb) | (u64)(entCode[e] + codeBase); else { sHash[pos] = h; sCode[pos] = entCode[e] + codeBase; } perm[pos] = (u32)e; }
+      if (PASS) { if (cb) sHash[pos] = (h << cb) | (u64)(entCode[e] + codeBase); else { sHash[pos] = h; sCode[pos] = entCode[e] + codeBase; } if (posOf) posOf[e] = pos; else perm[pos] = (u32)e; }
     }
     if (!PASS) { __syncthreads(); for (int o = threadIdx.x; o < N; o += blockDim.x) cnt[(size_t)o * nBlocks + b] = fill[o]; }
   }
@@ -311,6 +312,7 @@ int shard_readFqb(Ctx *c, Comm *cm, const u32 *dRec, u64 nRec) {
   int cbG = 1; while (cbG < 32 && ((nB - 1) >> cbG)) ++cbG;
   const int pk = (!c->optNoPack && N <= PART_MAX_OWNERS && c->keyBits + cbG <= 63) ? cbG : 0;
   DevBuf<u64> sHash; DevBuf<u32> perm, sCodeG;
+  const bool byPos = N <= PART_MAX_OWNERS;                   // the partition records where every entry went (posOf[e]) instead of which entry went where (perm[pos])
   H10X_HIP(c, sHash.alloc(H)); H10X_HIP(c, perm.alloc(H)); if (!pk) H10X_HIP(c, sCodeG.alloc(H));
   std::vector<u64> lowHash((size_t)N + 1), bound((size_t)N + 1);
   // (the entries hold hash / w, Ctx::keyInv: the owner ranges are cut in that space)
@@ -325,7 +327,7 @@ int shard_readFqb(Ctx *c, Comm *cm, const u32 *dRec, u64 nRec) {
     const unsigned grid = hmin<u32>(nBl, 16384);
     if (H) owner_partition_kernel<0><<<grid, 256, 0, st>>>(entHash.p, entCode.p, c->blockOff.p, nBl, dLow.p, N, c->codeBase, cnt.p, nullptr, nullptr, nullptr, 0);
     H10X_TRY(prim_exclusive_scan_u32(c, pt, cnt.p, off.p, cells + 1));
-    if (H) owner_partition_kernel<1><<<grid, 256, 0, st>>>(entHash.p, entCode.p, c->blockOff.p, nBl, dLow.p, N, c->codeBase, off.p, sHash.p, sCodeG.p, perm.p, pk);
+    if (H) owner_partition_kernel<1><<<grid, 256, 0, st>>>(entHash.p, entCode.p, c->blockOff.p, nBl, dLow.p, N, c->codeBase, off.p, sHash.p, sCodeG.p, nullptr, pk, perm.p);
     partition_bounds_kernel<<<divUp((u64)N + 1, 256), 256, 0, st>>>(off.p, nBl, N, H, dBound.p);
     H10X_TRY(c->readback(bound.data(), dBound.p, ((size_t)N + 1) * 8));
     H10X_TRY(c->syncReadbacks());
@@ -458,7 +460,8 @@ int shard_readFqb(Ctx *c, Comm *cm, const u32 *dRec, u64 nRec) {
   c->tstop(T_PROBE);
   // ---- 7. the ClusterHash records of my blocks from the replies
   c->tstart(T_CLUSHASH);
-  { DevBuf<u64> key; H10X_HIP(c, key.alloc(H));
+  if (byPos) H10X_TRY(stageB_finishClusHashFromReplies(c, rIdx.p, perm.p, entRead.p));     // (perm holds posOf[] here)
+  else { DevBuf<u64> key; H10X_HIP(c, key.alloc(H));
     if (H) scatter_key_kernel<<<gridFor(H), 256, 0, st>>>(rIdx.p, perm.p, entRead.p, H, key.p);
     H10X_TRY(stageB_finishClusHash(c, key)); }
   c->tstop(T_CLUSHASH);
@@ -560,14 +563,20 @@ __global__ void good_ids_kernel(const u32 *__restrict__ isGood, const u32 *__res
   const u32 d = blockIdx.x * blockDim.x + threadIdx.x;
   if (d < U && isGood[d]) goodId[pos[d]] = d;
 }
-__global__ void good_pack_kernel(const u32 *__restrict__ oIndex, const u32 *__restrict__ segStart, const u32 *__restrict__ oRows, const u32 *__restrict__ goodId, u32 nGood,
-                                 const u64 *__restrict__ off, const u32 *__restrict__ padLen, bool copyRows,
-                                 u32 *__restrict__ gIdx, u32 *__restrict__ gLen, u32 *__restrict__ gRows) {
-  for (u32 g = blockIdx.x; g < nGood; g += gridDim.x) {
+// GW lanes per list (16: four lists to a wave where the lists are short — depth range 6 - 45 on the 3 Gb set: a 64-lane workgroup per list ran a third full, 0.94 ms per rank
+// of the 1/4 set at 8 ranks; 64 where they are long)
+template <int GW>
+__global__ __launch_bounds__(256)
+void good_pack_kernel(const u32 *__restrict__ oIndex, const u32 *__restrict__ segStart, const u32 *__restrict__ oRows, const u32 *__restrict__ goodId, u32 nGood,
+                      const u64 *__restrict__ off, const u32 *__restrict__ padLen, bool copyRows,
+                      u32 *__restrict__ gIdx, u32 *__restrict__ gLen, u32 *__restrict__ gRows) {
+  constexpr u32 GPB = 256 / GW;
+  const u32 jl = threadIdx.x & (GW - 1);
+  for (u32 g = blockIdx.x * GPB + threadIdx.x / GW; g < nGood; g += gridDim.x * GPB) {
     const u32 d = goodId[g];
     const u32 s = segStart[d], n = segStart[d + 1] - s; const u64 o = off[d];
-    if (threadIdx.x == 0) { gIdx[g] = oIndex[d]; gLen[g] = padLen[d]; }
-    if (copyRows) for (u32 j = threadIdx.x; j < n; j += blockDim.x) gRows[o + j] = oRows[s + j];
+    if (jl == 0) { gIdx[g] = oIndex[d]; gLen[g] = padLen[d]; }
+    if (copyRows) for (u32 j = jl; j < n; j += GW) gRows[o + j] = oRows[s + j];
   }
 }
 // ---- delta-coded lists. A list is ascending global block numbers; between ranks it travels as 16-bit units: the first number in
@@ -675,7 +684,10 @@ int shard_exchangeRows(Ctx *c) {
   DevBuf<u32> gIdx, gLen, gRows, goodId;
   H10X_HIP(c, gIdx.alloc(mine[0])); H10X_HIP(c, gLen.alloc(mine[0])); H10X_HIP(c, goodId.alloc(mine[0])); if (!delta) H10X_HIP(c, gRows.alloc(mine[1]));
   if (Uo) good_ids_kernel<<<divUp(Uo, 256), 256, 0, st>>>(isGood.p, pos.p, Uo, goodId.p);
-  if (nGoodU) good_pack_kernel<<<hmin<u32>(nGoodU, 65535u * 2), 64, 0, st>>>(c->oIndex.p, c->oSegStart.p, c->oRows.p, goodId.p, nGoodU, off.p, len.p, !delta, gIdx.p, gLen.p, gRows.p);
+  if (nGoodU) {
+    if (c->rangeHiMax && c->rangeHiMax <= 64) good_pack_kernel<16><<<hmin<u32>(divUp(nGoodU, 16), 65535u * 2), 256, 0, st>>>(c->oIndex.p, c->oSegStart.p, c->oRows.p, goodId.p, nGoodU, off.p, len.p, !delta, gIdx.p, gLen.p, gRows.p);
+    else good_pack_kernel<64><<<hmin<u32>(divUp(nGoodU, 4), 65535u * 2), 256, 0, st>>>(c->oIndex.p, c->oSegStart.p, c->oRows.p, goodId.p, nGoodU, off.p, len.p, !delta, gIdx.p, gLen.p, gRows.p);
+  }
   std::vector<u64> sc((size_t)N), so((size_t)N, 0), rc((size_t)N), ro((size_t)N); u64 nG = 0, nR = 0;
   for (int r = 0; r < N; ++r) { sc[r] = mine[0]; rc[r] = all[2 * r]; ro[r] = nG; nG += rc[r]; }
   DevBuf<u32> aIdx, aLen; H10X_HIP(c, aIdx.alloc(nG)); H10X_HIP(c, aLen.alloc(nG + 1));

@@ -321,7 +321,8 @@ void clushash_block_kernel(const u64 *__restrict__ entHash /* hash / w */, const
                            const u64 *__restrict__ blockOff, const u32 *__restrict__ list, const u32 *__restrict__ count /* this class's blocks */,
                            const u64 *__restrict__ table64, int B, u64 w, int qBits, int cb /* packed entries */, int sortBits,
                            h10x_clushash *__restrict__ out, int privT = 0 /* > 0: table64 is the private table of 2^privT slots (priv_find) */,
-                           const u32 *__restrict__ hashIndex = nullptr, const u64 *__restrict__ hashValue = nullptr) {
+                           const u32 *__restrict__ hashIndex = nullptr, const u64 *__restrict__ hashValue = nullptr,
+                           const u32 *__restrict__ replyIdx = nullptr, const u32 *__restrict__ replyPos = nullptr /* !LOOKUP, sharded: entry e's index is replyIdx[replyPos[e]], its read entRead[e] */) {
   using Sort = BlockIndexSort<THREADS, IPT>;
   __shared__ typename Sort::Storage storage;
   const u32 nList = *count;
@@ -365,6 +366,17 @@ void clushash_block_kernel(const u64 *__restrict__ entHash /* hash / w */, const
           }
         }
       }
+    } else if (replyPos) {
+      // sharded --readFQB (round 6): the owners' replies lie in the order the entries were SENT — per owner a slice in block order — and replyPos[e] says where entry e's
+      // is. A block's entries read eight slices at consecutive places each: a gather the caches serve, where scatter_key_kernel wrote every index 8 bytes wide to a
+      // random place first (1.7 ms per rank on the 1/4 3 Gb set at 8 ranks) and this kernel read the keys back. Loads without a branch around them, as above.
+      u32 pp[IPT];
+#pragma unroll
+      for (int j = 0; j < IPT; ++j) { const u32 e = (u32)j * THREADS + threadIdx.x; pp[j] = replyPos[o + (e < n ? e : n - 1)]; }
+#pragma unroll
+      for (int j = 0; j < IPT; ++j) { const u32 e = (u32)j * THREADS + threadIdx.x; v[j] = entRead[o + (e < n ? e : n - 1)] & 0xFFFFu; }
+#pragma unroll
+      for (int j = 0; j < IPT; ++j) { const u32 e = (u32)j * THREADS + threadIdx.x; const u32 kk = replyIdx[pp[j]]; k[j] = e < n ? kk : 0xFFFFFFFFu; }
     } else {
 #pragma unroll
       for (int j = 0; j < IPT; ++j) {
@@ -384,7 +396,7 @@ void clushash_block_kernel(const u64 *__restrict__ entHash /* hash / w */, const
 }
 
 // clusHash of every block by workgroup-local sorts; needs maxBlockHashes <= BLOCK_SORT_MAX. key = nullptr: look the entries up in table64
-static int clusHashByBlocks(Ctx *c, const u64 *entHash, const u32 *entRead, const u64 *key, const u64 *table64, int privT = 0) {
+static int clusHashByBlocks(Ctx *c, const u64 *entHash, const u32 *entRead, const u64 *key, const u64 *table64, int privT = 0, const u32 *replyIdx = nullptr, const u32 *replyPos = nullptr) {
   hipStream_t st = c->stream; const u32 nBlocks = c->nBlocks;
   H10X_HIP(c, c->clusHash.alloc(c->nEntries));
   if (!c->nEntries || nBlocks < 2) return 0;
@@ -395,13 +407,13 @@ static int clusHashByBlocks(Ctx *c, const u64 *entHash, const u32 *entRead, cons
   // workgroups per launch: the class's blocks are pulled from its list (count on the device: no round trip); enough workgroups to fill the chip
   const unsigned gridBig = hmin<u32>(nBlocks, (u32)c->numCU * 8), gridSmall = hmin<u32>(nBlocks, 65535u * 4);
 #define H10X_CH_LAUNCH(T, I, LOOK, CLS, STREAM) clushash_block_kernel<T, I, LOOK><<<(CLS == 0 ? gridSmall : gridBig), T, 0, STREAM>>>(entHash, entRead, key, c->blockOff.p, \
-    lists.p + (size_t)CLS * nBlocks, counts.p + CLS, table64, B, w, qBits, key ? 0 : c->entCodeBits, sortBits, c->clusHash.p, privT, c->hashIndex.p, c->hashValue.p)
+    lists.p + (size_t)CLS * nBlocks, counts.p + CLS, table64, B, w, qBits, (key || replyPos) ? 0 : c->entCodeBits, sortBits, c->clusHash.p, privT, c->hashIndex.p, c->hashValue.p, replyIdx, replyPos)
   const int side = c->maxBlockHashes > BLOCK_SORT_CAP1 ? 2 : (c->maxBlockHashes > BLOCK_SORT_CAP0 ? 1 : 0);
   ForkGuard forkGuard(c);
   if (side) H10X_TRY(c->forkStreams(side));                  // the few large blocks beside the many small ones
   // six entries per lane (512 / 1024 lanes for the 3072 / 6144-entry classes): at twelve the kernel needs 102 registers — four waves per SIMD —
   // and a block's latency chain (loads, look-up, three sort passes, store) has too few neighbours to hide behind
-  if (key) { H10X_CH_LAUNCH(H10X_BS_T0, H10X_BS_I0, false, 0, st); if (side >= 1) H10X_CH_LAUNCH(H10X_BS_T1, H10X_BS_I1, false, 1, c->aux[0]); if (side >= 2) H10X_CH_LAUNCH(1024, 8, false, 2, c->aux[1]); }
+  if (key || replyPos) { H10X_CH_LAUNCH(H10X_BS_T0, H10X_BS_I0, false, 0, st); if (side >= 1) H10X_CH_LAUNCH(H10X_BS_T1, H10X_BS_I1, false, 1, c->aux[0]); if (side >= 2) H10X_CH_LAUNCH(1024, 8, false, 2, c->aux[1]); }
   else { H10X_CH_LAUNCH(H10X_BS_T0, H10X_BS_I0, true, 0, st); if (side >= 1) H10X_CH_LAUNCH(H10X_BS_T1, H10X_BS_I1, true, 1, c->aux[0]); if (side >= 2) H10X_CH_LAUNCH(1024, 8, true, 2, c->aux[1]); }
 #undef H10X_CH_LAUNCH
   H10X_TRY(c->faultAt(2));
@@ -511,6 +523,19 @@ int stageB_buildProbeTable(Ctx *c) {
   probe_finish_kernel<<<(unsigned)hmin<u64>(divUp(tableSize, 256), 65535u * 2), 256, 0, st>>>(c->hashIndex.p, tableSize);
   c->tstop(T_PROBE);
   return 0;
+}
+
+// the same from the owners' replies of the sharded index build: entry e (block order) has index replyIdx[replyPos[e]] and read entRead[e]
+__global__ void reply_key_kernel(const u32 *__restrict__ replyIdx, const u32 *__restrict__ replyPos, const u32 *__restrict__ entRead, u64 n, u64 *__restrict__ key) {
+  u64 e = (u64)blockIdx.x * blockDim.x + threadIdx.x; const u64 stride = (u64)gridDim.x * blockDim.x;
+  for (; e < n; e += stride) key[e] = ((u64)replyIdx[replyPos[e]] << 32) | (u64)(entRead[e] & 0xFFFFu);
+}
+int stageB_finishClusHashFromReplies(Ctx *c, const u32 *replyIdx, const u32 *replyPos, const u32 *entRead) {
+  if (c->maxBlockHashes <= BLOCK_SORT_MAX) return clusHashByBlocks(c, nullptr, entRead, nullptr, nullptr, 0, replyIdx, replyPos);
+  const u64 H = c->nEntries;                                 // blocks too large for a workgroup-local sort: the keys as an array, then the device-wide segmented sort
+  DevBuf<u64> key; H10X_HIP(c, key.alloc(H));
+  if (H) reply_key_kernel<<<(unsigned)hmin<u64>(divUp(H, 256), 65535u * 2), 256, 0, c->stream>>>(replyIdx, replyPos, entRead, H, key.p);
+  return stageB_finishClusHash(c, key);
 }
 
 // key[e] = hash index << 32 | read (U16), entries in block order: sort every block by index, emit ClusterHash
