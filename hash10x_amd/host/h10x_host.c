@@ -208,57 +208,107 @@ int h10x_session_readFQB_dev(h10x_session *s, const uint32_t *devRec, uint64_t n
 /* records [first, first + n) of a file through the library's streaming ingest (h10x_ingest_fqb / h10x_shard_ingest_fqb), 64 MiB at a
    time: the file never sits in host memory, and the closing call is the --readFQB itself (collective when sharded). A rank that fails
    here while sharded still makes the closing call's counterpart impossible for the others, so the verdict is agreed on first. */
-/* bytes [off, off + len) of the file into dst, on a few threads (a single pread copies out of the page cache at ~6 GB/s: the file read, not the
-   PCIe transfer, is what a --readFQB of a cached file waits for) */
-typedef struct { int fd; char *dst; uint64_t off, len; int ok; } ReadJob;
-static void *read_job(void *a) {
-  ReadJob *j = (ReadJob *)a; uint64_t got = 0;
-  while (got < j->len) { const ssize_t r = pread(j->fd, j->dst + got, j->len - got, (off_t)(j->off + got)); if (r <= 0) break; got += (uint64_t)r; }
-  j->ok = got == j->len; return 0;
+/* ---- --readFQB's fread loop (hash10x.c:202-209) as a pipeline of page-locked slabs, round 6. What scratch/r6_io_rate.c measured on a GPU box's memory-backed storage
+   (profiles/r6d_io_rate.log): one pread copies out of the page cache at 9.5 GB/s, sixteen at 136 GB/s — reads scale, and PCIe takes ~55 GB/s — so the file is read by a
+   pool of READERS persistent threads, PIECE bytes at a time, into NSLAB slabs of SLAB bytes; the calling thread alone talks to the library (the C ABI is single-threaded):
+   it queues a slab's upload (h10x_ingest_fqb_async, in file order) as soon as all its pieces are in, and hands a slab back to the readers when its upload has landed.
+   Round 5 read 16 MiB slabs on 4 threads created and joined per slab, one slab at a time: 5.2 GB/s, 4.6 s of the 9.5 s configs[2] needs end to end. */
+enum { IN_PIECE = 4 << 20, IN_SLAB = ((64 << 20) / 120 / 30) * 120 * 30, IN_NSLAB = 6, IN_MAXREADERS = 32 };   /* whole records per slab */
+typedef struct {
+  int fd; uint64_t base, bytes;                       /* the byte range of the file to read */
+  uint64_t nSlabs, piecesPerSlab;
+  int S;                                              /* slabs in use: slab k lives in slot k % S */
+  char *slab[IN_NSLAB];
+  pthread_mutex_t mu; pthread_cond_t cv;
+  uint64_t nextPiece;                                 /* next piece (global number: slab * piecesPerSlab + piece) a reader takes */
+  uint64_t freeBelow;                                 /* slabs below this number may be written to (their slot's previous upload has landed) */
+  uint32_t done[IN_NSLAB];                            /* pieces of the slab now in slot k that are in */
+  int failed, stop;
+} InPipe;
+static uint64_t inpipe_slab_bytes(const InPipe *q, uint64_t k) { const uint64_t at = k * IN_SLAB; return q->bytes - at < IN_SLAB ? q->bytes - at : IN_SLAB; }
+static void *inpipe_reader(void *a) {
+  InPipe *q = (InPipe *)a;
+  for (;;) {
+    pthread_mutex_lock(&q->mu);
+    const uint64_t p = q->nextPiece; const uint64_t k = p / q->piecesPerSlab;
+    if (q->stop || q->failed || k >= q->nSlabs) { pthread_mutex_unlock(&q->mu); return 0; }
+    while (k >= q->freeBelow && !q->stop && !q->failed) pthread_cond_wait(&q->cv, &q->mu);
+    if (q->stop || q->failed) { pthread_mutex_unlock(&q->mu); return 0; }
+    if (q->nextPiece != p) { pthread_mutex_unlock(&q->mu); continue; }           /* somebody else took it while this thread waited */
+    q->nextPiece = p + 1;
+    pthread_mutex_unlock(&q->mu);
+    const uint64_t slabBytes = inpipe_slab_bytes(q, k), off = (p % q->piecesPerSlab) * (uint64_t)IN_PIECE;
+    int ok = 1;
+    if (off < slabBytes) {
+      const uint64_t len = slabBytes - off < IN_PIECE ? slabBytes - off : IN_PIECE; uint64_t got = 0;
+      char *dst = q->slab[k % (uint64_t)q->S] + off;
+      while (got < len) { const ssize_t r = pread(q->fd, dst + got, len - got, (off_t)(q->base + k * IN_SLAB + off + got)); if (r <= 0) break; got += (uint64_t)r; }
+      ok = got == len;
+    }
+    pthread_mutex_lock(&q->mu);
+    if (!ok) q->failed = 1;
+    ++q->done[k % (uint64_t)q->S];
+    pthread_cond_broadcast(&q->cv);
+    pthread_mutex_unlock(&q->mu);
+  }
 }
-static int read_parallel(int fd, char *dst, uint64_t off, uint64_t len) {
-  enum { T = 4 };
-  ReadJob job[T]; pthread_t th[T]; int started[T] = {0};
-  const uint64_t per = len < (4u << 20) ? len : (((len + T - 1) / T) + 4095) & ~(uint64_t)4095;
-  int nj = 0;
-  for (uint64_t at = 0; at < len; at += per, ++nj) { job[nj].fd = fd; job[nj].dst = dst + at; job[nj].off = off + at; job[nj].len = len - at < per ? len - at : per; job[nj].ok = 0; }
-  for (int i = 1; i < nj; ++i) started[i] = pthread_create(&th[i], 0, read_job, &job[i]) == 0;
-  read_job(&job[0]);
-  int ok = job[0].ok;
-  for (int i = 1; i < nj; ++i) { if (started[i]) pthread_join(th[i], 0); else read_job(&job[i]); ok = ok && job[i].ok; }
-  return ok ? 0 : -1;
-}
-/* records [first, first + n) of the file into the context's image: the reference's fread loop (hash10x.c:202-209) as a pipeline — three page-locked
-   slabs; while one is on its way to the device (h10x_ingest_fqb_async) the next is read from the file. Without page-locked memory: one slab, one
-   copy at a time, as before. */
 static void *warm_job(void *a) { (void)h10x_warm(*(int *)a); return 0; }           /* a failure here shows up in the first command proper */
 static int stream_records(h10x_session *s, const char *path, uint64_t first, uint64_t n, int sharded) {
-  enum { SLAB = ((16 << 20) / 120) * 120, NSLAB = 3 };                                /* whole records per read */
   int rc = 0;
   struct timespec t0, t1, t2, t3; clock_gettime(CLOCK_MONOTONIC, &t0);
   static int warmed[64];                                                              /* the device code loads while the file is read (once per process and device; ranks may be threads) */
   pthread_t warmTh; int warmDev = s->device;
   const int warming = warmDev >= 0 && warmDev < 64 && !getenv("H10X_NOWARM") && !__sync_lock_test_and_set(&warmed[warmDev], 1) && pthread_create(&warmTh, 0, warm_job, &warmDev) == 0;
-  const int fd = open(path, O_RDONLY);
-  char *slab[NSLAB] = {0, 0, 0}; int pinned = 1;
-  for (int k = 0; k < NSLAB && pinned; ++k) if (!(slab[k] = (char *)h10x_pinned_alloc(SLAB))) pinned = 0;
-  if (!pinned) { for (int k = 0; k < NSLAB; ++k) { h10x_pinned_free(slab[k]); slab[k] = 0; } slab[0] = (char *)malloc(SLAB); }
-  if (fd < 0) rc = fail(s, "failed to open fqb file %s", path);                       /* hash10x.c:1201 */
-  else if (!slab[0]) rc = fail(s, "out of memory for a %d MiB read buffer", SLAB >> 20);
+  const uint64_t bytes = n * 120;
+  InPipe q; memset(&q, 0, sizeof q);
+  q.fd = open(path, O_RDONLY); q.base = first * 120; q.bytes = bytes;
+  q.nSlabs = (bytes + IN_SLAB - 1) / IN_SLAB; q.piecesPerSlab = (IN_SLAB + IN_PIECE - 1) / IN_PIECE;
+  const int nSlabBuf = q.nSlabs < IN_NSLAB ? (int)(q.nSlabs ? q.nSlabs : 1) : IN_NSLAB;
+  int pinned = 1;
+  for (int k = 0; k < nSlabBuf && pinned; ++k) if (!(q.slab[k] = (char *)h10x_pinned_alloc(bytes < IN_SLAB ? (bytes ? bytes : 1) : IN_SLAB))) pinned = 0;
+  if (!pinned) { for (int k = 0; k < IN_NSLAB; ++k) { h10x_pinned_free(q.slab[k]); q.slab[k] = 0; } q.slab[0] = (char *)malloc(bytes < IN_SLAB ? (bytes ? bytes : 1) : IN_SLAB); }
+  q.S = pinned ? nSlabBuf : 1;                                                        /* without page-locked memory: one slab, one synchronous copy at a time, as before */
+  if (q.fd < 0) rc = fail(s, "failed to open fqb file %s", path);                     /* hash10x.c:1201 */
+  else if (!q.slab[0]) rc = fail(s, "out of memory for a %d MiB read buffer", IN_SLAB >> 20);
   else if (h10x_ingest_reserve(s->ctx, n)) rc = fail_ctx(s);
-  const uint64_t bytes = n * 120; uint64_t done = 0;
   clock_gettime(CLOCK_MONOTONIC, &t1);
-  for (uint64_t k = 0; !rc && done < bytes; ++k) {
-    const uint64_t want = bytes - done < SLAB ? bytes - done : SLAB;
-    const int slot = pinned ? (int)(k % NSLAB) : 0;
-    if (pinned && k >= NSLAB && h10x_ingest_wait(s->ctx, slot)) { rc = fail_ctx(s); break; }   /* the slab's earlier upload has landed */
-    if (read_parallel(fd, slab[slot], first * 120 + done, want)) { rc = fail(s, "file read problem"); break; }   /* hash10x.c:209 */
-    if (pinned ? h10x_ingest_fqb_async(s->ctx, (const uint32_t *)slab[slot], want / 120, slot)
-               : (sharded ? h10x_shard_ingest_fqb(s->ctx, (const uint32_t *)slab[0], want / 120, 0) : h10x_ingest_fqb(s->ctx, (const uint32_t *)slab[0], want / 120, 0))) { rc = fail_ctx(s); break; }
-    done += want;
+  pthread_t th[IN_MAXREADERS]; int nTh = 0;
+  if (!rc && q.nSlabs) {
+    pthread_mutex_init(&q.mu, 0); pthread_cond_init(&q.cv, 0);
+    q.freeBelow = (uint64_t)q.S;                                                      /* = slabs whose upload has landed + S */
+    long cpus = sysconf(_SC_NPROCESSORS_ONLN); if (cpus < 1) cpus = 1;
+    const char *e = getenv("H10X_READERS"); int want = e ? atoi(e) : 16;
+    if (want < 1) want = 1;
+    if (want > IN_MAXREADERS) want = IN_MAXREADERS;
+    if (want > cpus) want = (int)cpus;
+    if ((uint64_t)want > q.nSlabs * q.piecesPerSlab) want = (int)(q.nSlabs * q.piecesPerSlab);
+    for (int i = 0; i < want; ++i) if (pthread_create(&th[nTh], 0, inpipe_reader, &q) == 0) ++nTh;
+    if (!nTh) rc = fail(s, "could not start a reader thread");
+    for (uint64_t k = 0; !rc && k < q.nSlabs; ++k) {
+      const int slot = (int)(k % (uint64_t)q.S); const uint64_t want120 = inpipe_slab_bytes(&q, k) / 120;
+      pthread_mutex_lock(&q.mu);
+      while (q.done[slot] < q.piecesPerSlab && !q.failed) pthread_cond_wait(&q.cv, &q.mu);
+      const int bad = q.failed; q.done[slot] = 0;
+      pthread_mutex_unlock(&q.mu);
+      if (bad) { rc = fail(s, "file read problem"); break; }                          /* hash10x.c:209 */
+      if (pinned ? h10x_ingest_fqb_async(s->ctx, (const uint32_t *)q.slab[slot], want120, slot)
+                 : (sharded ? h10x_shard_ingest_fqb(s->ctx, (const uint32_t *)q.slab[0], want120, 0) : h10x_ingest_fqb(s->ctx, (const uint32_t *)q.slab[0], want120, 0))) { rc = fail_ctx(s); break; }
+      /* a slab goes back to the readers when its upload has landed. Uploads are queued in order: with several slots the calling thread waits for the PREVIOUS slab's
+         (this one is on its way while the next is read); with one slot for this one's */
+      uint64_t landed;
+      if (q.S > 1) { landed = k; if (k >= 1 && h10x_ingest_wait(s->ctx, (int)((k - 1) % (uint64_t)q.S))) { rc = fail_ctx(s); break; } }
+      else { landed = k + 1; if (pinned && h10x_ingest_wait(s->ctx, slot)) { rc = fail_ctx(s); break; } }
+      pthread_mutex_lock(&q.mu);
+      q.freeBelow = landed + (uint64_t)q.S;
+      pthread_cond_broadcast(&q.cv);
+      pthread_mutex_unlock(&q.mu);
+    }
+    pthread_mutex_lock(&q.mu); q.stop = 1; pthread_cond_broadcast(&q.cv); pthread_mutex_unlock(&q.mu);
+    for (int i = 0; i < nTh; ++i) pthread_join(th[i], 0);
+    pthread_mutex_destroy(&q.mu); pthread_cond_destroy(&q.cv);
   }
-  if (fd >= 0) close(fd);
-  if (pinned) { for (int k = 0; k < NSLAB; ++k) { h10x_ingest_wait(s->ctx, k); h10x_pinned_free(slab[k]); } } else free(slab[0]);
+  if (q.fd >= 0) close(q.fd);
+  if (pinned) { for (int k = 0; k < IN_NSLAB; ++k) { if (q.slab[k]) h10x_ingest_wait(s->ctx, k); h10x_pinned_free(q.slab[k]); } } else free(q.slab[0]);
   if (warming) pthread_join(warmTh, 0);
   if (sharded) { int allOk = 0; if (h10x_shard_agree(s->ctx, !rc, &allOk)) return fail_ctx(s); if (!allOk && !rc) rc = fail(s, "another rank failed to read its part of %s", path); }
   if (rc) { h10x_ingest_reserve(s->ctx, 0); return rc; }
@@ -266,9 +316,9 @@ static int stream_records(h10x_session *s, const char *path, uint64_t first, uin
   if (sharded ? h10x_shard_ingest_fqb(s->ctx, 0, 0, 1) : h10x_ingest_fqb(s->ctx, 0, 0, 1)) return fail_ctx(s);
   clock_gettime(CLOCK_MONOTONIC, &t3);
   if (getenv("H10X_INGEST_TIMING"))                                                    /* where a --readFQB spends its wall time */
-    fprintf(stderr, "  ingest of %.2f GB: buffers + image %.3f s, read + upload %.3f s (%.1f GB/s), hashing + index %.3f s\n", (double)bytes / 1e9,
+    fprintf(stderr, "  ingest of %.2f GB: buffers + image %.3f s, read + upload %.3f s (%.1f GB/s, %d readers), hashing + index %.3f s\n", (double)bytes / 1e9,
             (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec), (double)(t2.tv_sec - t1.tv_sec) + 1e-9 * (double)(t2.tv_nsec - t1.tv_nsec),
-            (double)bytes / 1e9 / ((double)(t2.tv_sec - t1.tv_sec) + 1e-9 * (double)(t2.tv_nsec - t1.tv_nsec) + 1e-9), (double)(t3.tv_sec - t2.tv_sec) + 1e-9 * (double)(t3.tv_nsec - t2.tv_nsec));
+            (double)bytes / 1e9 / ((double)(t2.tv_sec - t1.tv_sec) + 1e-9 * (double)(t2.tv_nsec - t1.tv_nsec) + 1e-9), nTh, (double)(t3.tv_sec - t2.tv_sec) + 1e-9 * (double)(t3.tv_nsec - t2.tv_nsec));
   return 0;
 }
 static int file_records(h10x_session *s, const char *path, uint64_t *n, int *cutByN) {
@@ -346,22 +396,18 @@ static void *write_job(void *a) {
   while (done < j->len) { const ssize_t w = pwrite(j->fd, j->src + done, j->len - done > (1u << 30) ? (1u << 30) : j->len - done, (off_t)(j->at + done)); if (w <= 0) break; done += (uint64_t)w; }
   j->ok = done == j->len; return 0;
 }
-/* n bytes to the file at `at`, on a few threads when there are many (the page cache of a GPU box takes ~10 GB/s from one thread as from thirty-two —
-   scratch/pwrite_rate.py — so the threads only cover for a slow one; what matters is that the next slice comes off the device meanwhile: Writer below) */
+/* n bytes to the file at `at`. ONE pwrite stream per file: writers of one file take the inode's lock in turn, and on a GPU box's memory-backed storage one thread
+   writes a new file at 9.0 GB/s, two at 8.9, four at 4.1, eight at 4.4 (scratch/r6_io_rate.c, profiles/r6d_io_rate.log; a mapping of the file filled by memcpy: 2 - 4.6) —
+   round 5 split every slice over four threads and had two slices in the air: 3.7 GB/s. What matters is that the one stream never waits for the device: Writer below. */
+static pthread_mutex_t fileWriteMu = PTHREAD_MUTEX_INITIALIZER;                      /* (ranks of one process write the same file: one at a time) */
 static int put(int fd, const void *p, uint64_t n, uint64_t at) {
-  enum { T = 4 };
-  WriteJob job[T]; pthread_t th[T]; int started[T] = {0};
-  const uint64_t per = n < (4u << 20) ? (n ? n : 1) : (((n + T - 1) / T) + 4095) & ~(uint64_t)4095;
-  int nj = 0;
-  for (uint64_t o = 0; o < n; o += per, ++nj) { job[nj].fd = fd; job[nj].src = (const char *)p + o; job[nj].at = at + o; job[nj].len = n - o < per ? n - o : per; job[nj].ok = 0; }
-  for (int i = 1; i < nj; ++i) started[i] = pthread_create(&th[i], 0, write_job, &job[i]) == 0;
-  int ok = 1;
-  if (nj) { write_job(&job[0]); ok = job[0].ok; }
-  for (int i = 1; i < nj; ++i) { if (started[i]) pthread_join(th[i], 0); else write_job(&job[i]); ok = ok && job[i].ok; }
-  return ok ? 0 : -1;
+  WriteJob job = {fd, (const char *)p, at, n, 0};
+  if (n >= (1u << 20)) { pthread_mutex_lock(&fileWriteMu); write_job(&job); pthread_mutex_unlock(&fileWriteMu); }
+  else write_job(&job);
+  return job.ok ? 0 : -1;
 }
-/* --writeHash as a pipeline: two host buffers; while one is being written to the file (put, on a thread of its own) the next slice comes off the
-   device into the other. */
+/* --writeHash as a pipeline: two page-locked host buffers of 128 MiB; while one is being written to the file (put, on a thread of its own) the next slice comes off
+   the device into the other (~50 GB/s against the file's 9): the write stream is busy all the time. */
 typedef struct { int fd; void *buf; uint64_t n, at; int rc, busy; pthread_t th; double profWait, profExport; /* H10X_HOSTPROF: where --writeHash spends its time (per call: ranks of one process write side by side) */ } Writer;
 static void *writer_job(void *a) { Writer *w = (Writer *)a; w->rc = put(w->fd, w->buf, w->n, w->at); return 0; }
 static int writer_wait(Writer *w) { if (w->busy) { pthread_join(w->th, 0); w->busy = 0; } const int rc = w->rc; w->rc = 0; return rc; }
@@ -396,7 +442,7 @@ int h10x_session_writeHash(h10x_session *s, const char *path) {
   const uint64_t oIndex = 16, oNumber = oIndex + 4 * T, oValue = oNumber + 4, oDepthHdr = oValue + 8 * (uint64_t)z.hashNumber, oDepth = oDepthHdr + 32,
                  oBlocksHdr = oDepth + 4 * depthDim, oBlocks = oBlocksHdr + 32, oClus = oBlocks + 32 * blocksDim, total = oClus + 8 * z.nEntriesGlobal;
   const double tp0 = hostprof() ? now_ms() : 0;
-  int fd = -1, rc = 0, turn = 0; enum { BUF = 32 << 20 }; int bufPinned = 1;
+  int fd = -1, rc = 0, turn = 0; enum { BUF = 128 << 20 }; int bufPinned = 1;
   Writer w[2]; memset(w, 0, sizeof w);
   w[0].buf = h10x_pinned_alloc(BUF); w[1].buf = h10x_pinned_alloc(BUF);             /* page-locked: the slices come off the device at DMA speed */
   if (!w[0].buf || !w[1].buf) { bufPinned = 0; h10x_pinned_free(w[0].buf); h10x_pinned_free(w[1].buf); w[0].buf = malloc(BUF); w[1].buf = malloc(BUF); }
