@@ -292,7 +292,7 @@ def mosh_int_ops(kmers, ms_per_step):
                                "change, from a 16-entry LDS table; two real multiplies per lane and read pair) - same values mod 2^64, so this is the rate "
                                "an implementation that multiplies would need",
             "int_peak_derivation": "64 lanes x 1024 SIMDs x 2.4 GHz / (4.9 + 2 x 4.2) SIMD cycles per u64 multiply (v_mad_u64_u32 + 2 v_mul_lo_u32, rates measured by scratch/valu_rate64.hip); "
-                                   "the kernel issues ~35 vector + 23 scalar instructions per 64 k-mer slots all told (profiles/r3c_pmc_sq.json; DESIGN 3, K1); its vector units are busy 61 % of the time by the 4-cycle accounting of SQ_ACTIVE_INST_VALU"}
+                                   "the kernel issues ~35 vector + 23 scalar instructions per 64 k-mer slots all told (profiles/r3d_pmc_sq.json; DESIGN 3, K1); its vector units are busy 61 % of the time by the 4-cycle accounting of SQ_ACTIVE_INST_VALU"}
 
 
 def cpu_model():
