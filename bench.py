@@ -517,7 +517,7 @@ def cli_end_to_end(recs, B, lo, hi, ct, expect_sha256=None, expect_size=None):
                 "per_command_wall_seconds": walls, "io_commands_share": (io / wall) if wall else None,
                 "io_commands_note": "--readFQB (file read beside the uploads, hashing and index build) + --writeHash (device -> host beside the file writes) as a share of the process's wall time",
                 "hash_sha256": digest, "hash_identical_to_reference": (digest == expect_sha256 and info["size"] == expect_size) if expect_sha256 else None,
-                "stderr_tail": g.stderr.decode(errors="replace")[-600:] if (os.environ.get("H10X_INGEST_TIMING") or os.environ.get("H10X_HOSTPROF")) else None,
+                "host_timing_lines": [ln.strip() for ln in g.stderr.decode(errors="replace").splitlines() if ln.strip().startswith(("ingest of", "hostprof:"))][-6:] or None,   # (H10X_INGEST_TIMING / H10X_HOSTPROF in the environment)
                 "write_input_seconds": round(write_in_s, 1), "digest_seconds": round(digest_s, 1)}
     finally:
         shutil.rmtree(d, ignore_errors=True)

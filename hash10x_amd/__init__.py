@@ -29,7 +29,7 @@ class Hash10xError(RuntimeError):
 class _Counters(ctypes.Structure):
     _fields_ = [(n, ctypes.c_uint64) for n in (
         "pairs", "kmers", "entries", "distinct", "clustered_codes", "sum_good", "sum_good_depth",
-        "sum_hash_clustered", "fallback_blocks")] + [("cluster_class_counts", ctypes.c_uint64 * 4), ("cluster_first_mode", ctypes.c_uint64), ("cluster_overflow_blocks", ctypes.c_uint64), ("cluster_main", ctypes.c_uint64 * 4), ("cluster_phase_ticks", ctypes.c_uint64 * 8), ("list_words", ctypes.c_uint64 * 2), ("shard_reply_path", ctypes.c_uint64)]
+        "sum_hash_clustered", "fallback_blocks")] + [("cluster_class_counts", ctypes.c_uint64 * 4), ("cluster_first_mode", ctypes.c_uint64), ("cluster_overflow_blocks", ctypes.c_uint64), ("cluster_main", ctypes.c_uint64 * 4), ("cluster_phase_ticks", ctypes.c_uint64 * 8), ("list_words", ctypes.c_uint64 * 2), ("index_table_form", ctypes.c_uint64), ("shard_reply_path", ctypes.c_uint64)]
 
 
 class _Sizes(ctypes.Structure):

@@ -223,6 +223,7 @@ struct Ctx {
   int64_t optClusterThreads0 = 0, optClusterBudget0 = 0;   // tuning knobs: lanes and LDS bytes of the first cluster class
   int64_t optBigRanks = 0;    // tuning knob: rank count above which a barcode goes to the front of the main work queue (0 = 1.5 x the mean)
   int64_t optPrivTable = 0;   // entry look-ups of the index build: 0 = the table of this library's own where key + index do not fit the 64-bit reference-shaped one, 1 = always (tests), 2 = never, 3 = always and too small (tests: the fall-back)
+  int64_t optProbedTable = 0; // index build, the wide table's "probed" entry format (index | hash >> B | probe number: stage_b.hip probe_insertP_kernel): 0 = where the classic entry (index | hash / w) does not fit 64 bits (-B 29 / 30 at k = 21), 1 = always (tests), 2 = never (round 5: two tables), 3 = always with ONE bit of probe number (tests: the table fails and the two tables are built)
   int64_t optNoPack = 0;      // index build with separate key / block arrays even where the packed form fits (A/B, tests)
   int64_t optNarrowFirst = 0; // first[] of the cluster kernel at 2 bytes per entry in every block (default: 4 where the block's working set leaves room)
   int64_t optTrEstDiv = 0;    // tuning knob: translated placement, classification: a block's barcodes estimated as entries / this (0 = 6)

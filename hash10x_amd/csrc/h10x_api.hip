@@ -677,6 +677,7 @@ int h10x_set_option(h10x_ctx *h, const char *name, int64_t value) {
   if (!strcmp(name, "cluster_tr_class_t")) { h->c.optTrClassT = value; return 0; }
   if (!strcmp(name, "cluster_tr_est_div")) { h->c.optTrEstDiv = value; return 0; }
   if (!strcmp(name, "index_no_pack")) { h->c.optNoPack = value; return 0; }
+  if (!strcmp(name, "index_probed_table")) { if (value < 0 || value > 3) return h->c.fail("index_probed_table must be 0..3"); h->c.optProbedTable = value; return 0; }
   if (!strcmp(name, "index_priv_table")) { if (value < 0 || value > 3) return h->c.fail("index_priv_table must be 0..3"); h->c.optPrivTable = value; return 0; }
   if (!strcmp(name, "cluster_stamps")) { h->c.optStamps = value; return 0; }
   if (!strcmp(name, "chunk_size")) { if (value < 0) return h->c.fail("chunk_size must be >= 0"); h->c.optChunk = value; return 0; }

@@ -117,6 +117,30 @@ __global__ void probe_insert64_kernel(const u64 *__restrict__ hashValue, u32 has
     }
   }
 }
+// Round 6: where key + index do not fit 64 bits (k = 21, w = 31: B = 29, 30) the wide table still works if an entry holds, instead of the key, what the SLOT does not
+// already say: entry = index << SH | (hash >> B) << PB | probe number. The probe sequence of the reference (start hash & mask, stride ((hash >> B) & mask) | 1) makes slot,
+// hash >> B and the probe number together the hash: an evicted entry knows its stride and its next probe number without its low bits, a look-up compares
+// (hash >> B, probe number) at every step — one random 8-byte read per step in the reference's OWN geometry, and hashIndex[] is the index column of the same table
+// (probe_finish64_kernel). Before, B = 29 / 30 built two tables: hashIndex[] by 4-byte minimum-and-evict with hashValue[] re-read on every eviction (6 / 15 ms on
+// configs[2] / the 3 Gb set) and the look-up table of the library's own (priv_insert_kernel: 7 / 16 ms). PB = 66 - 2k bits of probe number (24 at k = 21); a probe
+// sequence longer than 2^PB - 1 raises *fail and the caller builds the two tables as before.
+__global__ void probe_insertP_kernel(const u64 *__restrict__ hashValue, u32 hashNumber, int B, int SH, int PB, u64 *__restrict__ table, u32 *__restrict__ fail) {
+  const u32 first = blockIdx.x * blockDim.x + threadIdx.x + 1;
+  const u64 mask = ((u64)1 << B) - 1, pmask = ((u64)1 << PB) - 1, umask = ((u64)1 << (SH - PB)) - 1;
+  for (u32 start = first; start < hashNumber; start += gridDim.x * blockDim.x) {
+    const u64 h = hashValue[start];
+    u64 cur = ((u64)start << SH) | ((h >> B) << PB);         // probe number 0
+    u64 slot = h & mask, step = ((h >> B) & mask) | 1;
+    for (;;) {
+      const u64 old = atomicMin((unsigned long long *)&table[slot], (unsigned long long)cur);
+      if (old == SLOT_EMPTY64) break;                        // took a free slot
+      if (old > cur) { cur = old; step = (((cur >> PB) & umask) & mask) | 1; }   // evicted a later index: it continues from here, with ITS stride and probe number
+      if ((cur & pmask) == pmask) { *fail = 1; break; }
+      ++cur;                                                 // next probe
+      slot = (slot + step) & mask;
+    }
+  }
+}
 __global__ void probe_finish64_kernel(const u64 *__restrict__ table64, u64 n, int qBits, u32 *__restrict__ table) {
   u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
   const u64 stride = (u64)gridDim.x * blockDim.x;
@@ -322,7 +346,8 @@ void clushash_block_kernel(const u64 *__restrict__ entHash /* hash / w */, const
                            const u64 *__restrict__ table64, int B, u64 w, int qBits, int cb /* packed entries */, int sortBits,
                            h10x_clushash *__restrict__ out, int privT = 0 /* > 0: table64 is the private table of 2^privT slots (priv_find) */,
                            const u32 *__restrict__ hashIndex = nullptr, const u64 *__restrict__ hashValue = nullptr,
-                           const u32 *__restrict__ replyIdx = nullptr, const u32 *__restrict__ replyPos = nullptr /* !LOOKUP, sharded: entry e's index is replyIdx[replyPos[e]], its read entRead[e] */) {
+                           const u32 *__restrict__ replyIdx = nullptr, const u32 *__restrict__ replyPos = nullptr /* !LOOKUP, sharded: entry e's index is replyIdx[replyPos[e]], its read entRead[e] */,
+                           int probeBits = 0 /* > 0: table64 holds index << qBits | (hash >> B) << probeBits | probe number (probe_insertP_kernel) */) {
   using Sort = BlockIndexSort<THREADS, IPT>;
   __shared__ typename Sort::Storage storage;
   const u32 nList = *count;
@@ -359,7 +384,8 @@ void clushash_block_kernel(const u64 *__restrict__ entHash /* hash / w */, const
             else {
               const u64 h = q[j] * w; u64 slot = h & mask; const u64 step = ((h >> B) & mask) | 1;
               u64 tt = t[g];
-              while (tt != SLOT_EMPTY64 && (tt & qmask) != q[j]) { slot = (slot + step) & mask; tt = table64[slot]; }
+              if (probeBits) { u64 want = (h >> B) << probeBits; while (tt != SLOT_EMPTY64 && (tt & qmask) != want) { slot = (slot + step) & mask; ++want; tt = table64[slot]; } }   // (uniform)
+              else while (tt != SLOT_EMPTY64 && (tt & qmask) != q[j]) { slot = (slot + step) & mask; tt = table64[slot]; }
               kk = tt == SLOT_EMPTY64 ? 0u : (u32)(tt >> qBits);
             }
             k[j] = e < n ? kk : 0xFFFFFFFFu;
@@ -396,18 +422,19 @@ void clushash_block_kernel(const u64 *__restrict__ entHash /* hash / w */, const
 }
 
 // clusHash of every block by workgroup-local sorts; needs maxBlockHashes <= BLOCK_SORT_MAX. key = nullptr: look the entries up in table64
-static int clusHashByBlocks(Ctx *c, const u64 *entHash, const u32 *entRead, const u64 *key, const u64 *table64, int privT = 0, const u32 *replyIdx = nullptr, const u32 *replyPos = nullptr) {
+static int clusHashByBlocks(Ctx *c, const u64 *entHash, const u32 *entRead, const u64 *key, const u64 *table64, int privT = 0, const u32 *replyIdx = nullptr, const u32 *replyPos = nullptr,
+                            int probeSH = 0, int probeBits = 0 /* table64 in the probed format: index << probeSH | (hash >> B) << probeBits | probe number */) {
   hipStream_t st = c->stream; const u32 nBlocks = c->nBlocks;
   H10X_HIP(c, c->clusHash.alloc(c->nEntries));
   if (!c->nEntries || nBlocks < 2) return 0;
   int sortBits = bitsFor(c->hashNumber) + 1 > 32 ? 32 : bitsFor(c->hashNumber) + 1;
-  const int B = c->prm.B; const u64 w = (u64)c->prm.w; const int qBits = c->keyBits;
+  const int B = c->prm.B; const u64 w = (u64)c->prm.w; const int qBits = probeBits ? probeSH : c->keyBits;
   DevBuf<u32> lists, counts;
   H10X_TRY(stageB_blockClassLists(c, lists, counts));
   // workgroups per launch: the class's blocks are pulled from its list (count on the device: no round trip); enough workgroups to fill the chip
   const unsigned gridBig = hmin<u32>(nBlocks, (u32)c->numCU * 8), gridSmall = hmin<u32>(nBlocks, 65535u * 4);
 #define H10X_CH_LAUNCH(T, I, LOOK, CLS, STREAM) clushash_block_kernel<T, I, LOOK><<<(CLS == 0 ? gridSmall : gridBig), T, 0, STREAM>>>(entHash, entRead, key, c->blockOff.p, \
-    lists.p + (size_t)CLS * nBlocks, counts.p + CLS, table64, B, w, qBits, (key || replyPos) ? 0 : c->entCodeBits, sortBits, c->clusHash.p, privT, c->hashIndex.p, c->hashValue.p, replyIdx, replyPos)
+    lists.p + (size_t)CLS * nBlocks, counts.p + CLS, table64, B, w, qBits, (key || replyPos) ? 0 : c->entCodeBits, sortBits, c->clusHash.p, privT, c->hashIndex.p, c->hashValue.p, replyIdx, replyPos, probeBits)
   const int side = c->maxBlockHashes > BLOCK_SORT_CAP1 ? 2 : (c->maxBlockHashes > BLOCK_SORT_CAP0 ? 1 : 0);
   ForkGuard forkGuard(c);
   if (side) H10X_TRY(c->forkStreams(side));                  // the few large blocks beside the many small ones
@@ -477,21 +504,45 @@ int stageB_run(Ctx *c, DevBuf<u64> &entHash, DevBuf<u32> &entCode, DevBuf<u32> &
   const bool forcePriv = (c->optPrivTable == 1 || c->optPrivTable == 3) && c->keyBits <= 40;
   const bool wideTable = !forcePriv && c->keyBits + (B - 2) <= 64 && c->keyBits < 64;   // index < 2^(B-2) (hash10x.c:149)
   DevBuf<u64> table64;
-  if (wideTable) {
+  // the probed format (probe_insertP_kernel) where the classic wide entry does not fit: index bits B - 2, hash >> B in 2k - B bits, the rest — 66 - 2k — for the probe number
+  const int hashBits = 2 * c->prm.k, UB = hashBits > B ? hashBits - B : 0, PBroom = 64 - (B - 2) - UB;
+  int PB = 0, SH = 0; bool probed = false;
+  if (!forcePriv && c->optProbedTable != 2 && (!wideTable || c->optProbedTable == 1 || c->optProbedTable == 3) && PBroom >= 12 && c->keyBits < 64) {
+    PB = PBroom > 24 ? 24 : PBroom; if (c->optProbedTable == 3) PB = 1;          // (knob 3, tests: one bit of probe number — the first second collision fails the table)
+    SH = UB + PB;
+    c->tstart(T_PROBE);
+    DevBuf<u32> failFlag; u32 failed = 0;
+    H10X_HIP(c, table64.alloc(tableSize)); H10X_HIP(c, c->hashIndex.alloc(tableSize)); H10X_HIP(c, failFlag.alloc(1));
+    H10X_HIP(c, hipMemsetAsync(table64.p, 0xFF, tableSize * 8, st)); H10X_HIP(c, hipMemsetAsync(failFlag.p, 0, 4, st));
+    if (U) probe_insertP_kernel<<<hmin<u32>(divUp(U, 256), 16384), 256, 0, st>>>(c->hashValue.p, U + 1, B, SH, PB, table64.p, failFlag.p);
+    H10X_TRY(c->readback(&failed, failFlag.p, 4));
+    H10X_TRY(c->syncReadbacks());
+    probed = !failed;
+    if (probed) probe_finish64_kernel<<<(unsigned)hmin<u64>(divUp(tableSize, 256), 65535u * 2), 256, 0, st>>>(table64.p, tableSize, SH, c->hashIndex.p);
+    else { table64.release(); c->hashIndex.release(); }
+    c->tstop(T_PROBE);
+    c->ctr.index_table_form = probed ? 2 : 3;
+  }
+  if (probed) {}
+  else if (wideTable) {
+    c->ctr.index_table_form = 1;
     c->tstart(T_PROBE);
     H10X_HIP(c, table64.alloc(tableSize)); H10X_HIP(c, c->hashIndex.alloc(tableSize));
     H10X_HIP(c, hipMemsetAsync(table64.p, 0xFF, tableSize * 8, st));
     if (U) probe_insert64_kernel<<<hmin<u32>(divUp(U, 256), 16384), 256, 0, st>>>(c->hashValue.p, U + 1, B, (u64)c->prm.w, c->keyBits, table64.p);
     probe_finish64_kernel<<<(unsigned)hmin<u64>(divUp(tableSize, 256), 65535u * 2), 256, 0, st>>>(table64.p, tableSize, c->keyBits, c->hashIndex.p);
     c->tstop(T_PROBE);
-  } else H10X_TRY(stageB_buildProbeTable(c));
+  } else { if (c->ctr.index_table_form != 3) c->ctr.index_table_form = 0; H10X_TRY(stageB_buildProbeTable(c)); }
 
   // ---- clusHash: look every entry up, order each block by index (hash10x.c:177-183)
   c->tstart(T_CLUSHASH);
-  if (H && wideTable && c->maxBlockHashes <= BLOCK_SORT_MAX) {
+  if (H && probed && c->maxBlockHashes <= BLOCK_SORT_MAX) {
+    H10X_TRY(clusHashByBlocks(c, entHash.p, entRead.p, nullptr, table64.p, 0, nullptr, nullptr, SH, PB));
+    table64.release();
+  } else if (H && !probed && wideTable && c->maxBlockHashes <= BLOCK_SORT_MAX) {
     H10X_TRY(clusHashByBlocks(c, entHash.p, entRead.p, nullptr, table64.p));
     table64.release();
-  } else if (H && !wideTable && c->maxBlockHashes <= BLOCK_SORT_MAX && c->keyBits <= 40 && c->optPrivTable != 2) {
+  } else if (H && !probed && !wideTable && c->maxBlockHashes <= BLOCK_SORT_MAX && c->keyBits <= 40 && c->optPrivTable != 2) {
     // the look-up table of this library's own (priv_insert_kernel): 2^T slots >= 2 (U + 1), T >= keyBits - 24 so that q >> T fits the entry's 24 bits
     int T = 16; while (((u64)1 << T) < 2 * ((u64)U + 1) && T < 32) ++T;
     if (c->optPrivTable == 3) { T = 4; while (((u64)1 << T) < ((u64)U + 1) / 2 && T < 32) ++T; }   // (test knob: half the hashes find no slot and are looked up the old way)
@@ -503,7 +554,7 @@ int stageB_run(Ctx *c, DevBuf<u64> &entHash, DevBuf<u32> &entCode, DevBuf<u32> &
     H10X_TRY(clusHashByBlocks(c, entHash.p, entRead.p, nullptr, priv.p, T));
   } else if (H) {
     DevBuf<u64> key; H10X_HIP(c, key.alloc(H));
-    if (wideTable) lookup_pack64_kernel<<<gH, 256, 0, st>>>(entHash.p, entRead.p, H, table64.p, B, (u64)c->prm.w, c->keyBits, cb, key.p);
+    if (wideTable && !probed) lookup_pack64_kernel<<<gH, 256, 0, st>>>(entHash.p, entRead.p, H, table64.p, B, (u64)c->prm.w, c->keyBits, cb, key.p);
     else lookup_pack_kernel<<<gH, 256, 0, st>>>(entHash.p, entRead.p, H, c->hashIndex.p, c->hashValue.p, B, (u64)c->prm.w, cb, key.p);
     table64.release();
     H10X_TRY(stageB_finishClusHash(c, key));

@@ -16,7 +16,7 @@
 #define ARRAY_MAGIC 8918274                            /* array.h:56 */
 typedef struct { int32_t magic, pad0; uint64_t base; int32_t dim, size, max, pad1; } array_hdr;   /* array.h:41-50 */
 
-enum { N_KNOBS = 20 };
+enum { N_KNOBS = 21 };
 struct h10x_session {
   int k, w, r, B, N, chunk, ct, device;                /* params (hash10x.c:25-33) */
   int timing;                                          /* measurement hook: enable hipEvent timers on every new context */
@@ -30,7 +30,7 @@ struct h10x_session {
   char err[1024];
 };
 static const char *const knobName[N_KNOBS] = {"cluster_stamps", "cluster_lds_budget", "cluster_first_global", "cluster_first_cap",
-                                              "cluster_big_ranks", "cluster_threads0", "cluster_budget0", "shard_row_shift", "shard_rows_fake_base", "stage_a_max_slots", "cluster_narrow_first", "index_no_pack", "shard_delta_lists", "index_priv_table", "cluster_tr_packed", "cluster_tr_est_div", "cluster_tr_class_t", "shard_reply_sort", "shard_owner_cut", "shard_overlap"};
+                                              "cluster_big_ranks", "cluster_threads0", "cluster_budget0", "shard_row_shift", "shard_rows_fake_base", "stage_a_max_slots", "cluster_narrow_first", "index_no_pack", "shard_delta_lists", "index_priv_table", "cluster_tr_packed", "cluster_tr_est_div", "cluster_tr_class_t", "shard_reply_sort", "shard_owner_cut", "shard_overlap", "index_probed_table"};
 
 static int fail(h10x_session *s, const char *fmt, ...) {
   va_list ap; va_start(ap, fmt); vsnprintf(s->err, sizeof s->err, fmt, ap); va_end(ap);

@@ -339,13 +339,18 @@ typedef struct {
                                       [0] init (+ bitmap), [1] list loop, [2] barrier, [3] replay, [4] quotient, [5] output */
   uint64_t list_words[2];          /* sharded --hashDepthRange: 32-bit words of in-range barcode lists this rank received, [0] as plain
                                       numbers, [1] as they travelled (delta-coded: option "shard_delta_lists"); 0 0 if sent plain */
+  uint64_t index_table_form;       /* single-GPU index build, the look-up table behind the ClusterHash records: 0 = hashIndex[] + hashValue[] (or the library's private table: option
+                                      "index_priv_table"), 1 = the wide table, entry = index | hash / w, 2 = the wide table in the probed format (index | hash >> B | probe number:
+                                      -B 29 / 30 at k = 21), 3 = the probed table failed and the round-5 pair was built (option "index_probed_table") */
   uint64_t shard_reply_path;       /* sharded --readFQB, how this hash owner answered its entries: 0 nothing to answer, 1 by look-up, 2 by scatter, 3 by scatter after a look-up
                                       that failed or did not fit (option "shard_reply_sort") */
 } h10x_counters;
 int  h10x_get_counters(h10x_ctx *ctx, h10x_counters *out);
 /* test / tuning knobs (none changes a result): "stage_a_max_slots" caps the LDS hash-set slots per barcode in stage A (0 =
    default) so that the global-memory fallback can be exercised on small inputs; "chunk_size" (above); "index_no_pack" 1 = index
-   build with separate key / block arrays even where the packed one-word entries fit; "index_priv_table" 1 = the entry look-ups of the
+   build with separate key / block arrays even where the packed one-word entries fit; "index_probed_table" 0 default = the wide look-up table takes the probed entry format
+   (index | hash >> B | probe number, in the reference's own geometry: hashIndex[] is its index column) where index | hash / w does not fit 64 bits, 1 = always, 2 = never (two
+   tables, as round 5 built them), 3 = always and with one bit of probe number (exercises the fall-back; h10x_counters.index_table_form says what was built); "index_priv_table" 1 = the entry look-ups of the
    index build through the library's own one-read table also where the reference-shaped 64-bit table fits (default 0: only where it
    does not, i.e. -B 29 / 30 at k = 21), 2 = never, 3 = always and undersized (exercises its fall-back); "cluster_narrow_first" 1 = first[] of the
    cluster kernel at 2 bytes per entry in every block, w >= 2 = 4 bytes down to w list-loop waves (default 0: 4 bytes where that

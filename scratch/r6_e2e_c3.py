@@ -9,4 +9,4 @@ t = time.perf_counter(); recs, _f, _t = bench.generate_v2(wl, g["seed"]); print(
 os.environ["H10X_INGEST_TIMING"] = "1"; os.environ["H10X_HOSTPROF"] = "1"
 for run in range(int(sys.argv[1]) if len(sys.argv) > 1 else 2):
     e = bench.cli_end_to_end(recs, man["B"], 30, 100, 5, expect_sha256=man["sha256"] if run == 0 else None, expect_size=man["size"])
-    print(json.dumps({k: e.get(k) for k in ("wall_seconds", "per_command_wall_seconds", "hash_identical_to_reference", "io_commands_share", "storage", "stderr_tail")}), flush=True)
+    print(json.dumps({k: e.get(k) for k in ("wall_seconds", "per_command_wall_seconds", "hash_identical_to_reference", "io_commands_share", "storage", "host_timing_lines")}), flush=True)

@@ -28,25 +28,32 @@ static void *job(void *p) {
 int main(int argc, char **argv) {
   const char *dir = argc > 1 ? argv[1] : "/dev/shm"; const uint64_t n = (uint64_t)((argc > 2 ? atof(argv[2]) : 2.0) * (1 << 30));
   const uint64_t piece = 8u << 20; char path[512]; snprintf(path, sizeof path, "%s/r6_io_rate.bin", dir);
-  static const char *const name[4] = {"pwrite, new file", "memcpy into a mapping of a new file", "pread", "memcpy out of a mapping"};
-  for (int mode = 0; mode < 4; ++mode)
+  static const char *const name[6] = {"pwrite, new file", "memcpy into a mapping of a new file", "pread", "memcpy out of a mapping", "pwrite, file fallocate()d first", "memcpy into a mapping, fallocate()d first"};
+  const int order[6] = {0, 1, 4, 5, 2, 3};
+  for (int oi = 0; oi < 6; ++oi) { const int mode = order[oi];
     for (int T = 1; T <= 32; T *= 2) {
-      if (mode < 2) unlink(path);
-      const int fd = open(path, mode < 2 ? O_RDWR | O_CREAT : O_RDONLY, 0666); if (fd < 0) { perror(path); return 1; }
-      if (mode < 2 && ftruncate(fd, (off_t)n)) { perror("ftruncate"); return 1; }
+      const int wr = mode < 2 || mode >= 4, mapped = mode == 1 || mode == 3 || mode == 5;
+      if (wr) unlink(path);
+      const int fd = open(path, wr ? O_RDWR | O_CREAT : O_RDONLY, 0666); if (fd < 0) { perror(path); return 1; }
+      if (wr && ftruncate(fd, (off_t)n)) { perror("ftruncate"); return 1; }
+      double tf = 0;
+      if (mode >= 4) { const double a = now(); if (fallocate(fd, 0, 0, (off_t)n)) { perror("fallocate"); return 1; } tf = now() - a; }
       char *map = 0;
-      if (mode == 1 || mode == 3) { map = mmap(0, n, mode == 1 ? PROT_READ | PROT_WRITE : PROT_READ, MAP_SHARED, fd, 0); if (map == MAP_FAILED) { perror("mmap"); return 1; } }
+      if (mapped) { map = mmap(0, n, wr ? PROT_READ | PROT_WRITE : PROT_READ, MAP_SHARED, fd, 0); if (map == MAP_FAILED) { perror("mmap"); return 1; } }
       Job jb[32]; pthread_t th[32];
-      for (int i = 0; i < T; ++i) { jb[i] = (Job){fd, mode, map, 0, n / T * i, i + 1 == T ? n : n / T * (i + 1), piece}; if (posix_memalign((void **)&jb[i].buf, 4096, piece)) return 1; memset(jb[i].buf, 0x5A + i, piece); }
+      for (int i = 0; i < T; ++i) { jb[i] = (Job){fd, mode == 4 ? 0 : (mode == 5 ? 1 : mode), map, 0, n / T * i, i + 1 == T ? n : n / T * (i + 1), piece}; if (posix_memalign((void **)&jb[i].buf, 4096, piece)) return 1; memset(jb[i].buf, 0x5A + i, piece); }
       const double t0 = now();
       for (int i = 0; i < T; ++i) pthread_create(&th[i], 0, job, &jb[i]);
       for (int i = 0; i < T; ++i) pthread_join(th[i], 0);
       const double dt = now() - t0;
-      printf("%-38s %2d threads: %.3f s = %5.1f GB/s\n", name[mode], T, dt, n / dt / 1e9); fflush(stdout);
+      printf("%-42s %2d threads: %.3f s = %5.1f GB/s", name[mode], T, dt, n / dt / 1e9);
+      if (mode >= 4) printf("   (+ fallocate %.3f s: %.1f GB/s all told)", tf, n / (dt + tf) / 1e9);
+      printf("\n"); fflush(stdout);
       if (map) munmap(map, n);
       close(fd);
       for (int i = 0; i < T; ++i) free(jb[i].buf);
     }
+  }
   unlink(path);
   return 0;
 }
