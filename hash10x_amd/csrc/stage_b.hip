@@ -525,7 +525,7 @@ int stageB_run(Ctx *c, DevBuf<u64> &entHash, DevBuf<u32> &entCode, DevBuf<u32> &
   }
   if (probed) {}
   else if (wideTable) {
-    c->ctr.index_table_form = 1;
+    if (c->ctr.index_table_form != 3) c->ctr.index_table_form = 1;   // (3: the probed table failed just above — what is built instead does not change the report)
     c->tstart(T_PROBE);
     H10X_HIP(c, table64.alloc(tableSize)); H10X_HIP(c, c->hashIndex.alloc(tableSize));
     H10X_HIP(c, hipMemsetAsync(table64.p, 0xFF, tableSize * 8, st));

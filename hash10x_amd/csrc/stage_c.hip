@@ -1875,9 +1875,11 @@ __device__ __forceinline__ void cluster_one_block_tp(const ClusterArgs &a, u32 c
     const u32 nTodo = sh[2];
     u64 *const res = a.res + o;
     if (a.phase && tid == 0) { atomicAdd((u64 *)&a.phase[6], (u64)nTodo); atomicAdd((u64 *)&a.phase[7], (u64)n); }   // diagnostic: ranks settled behind the loop / ranks
+    u16 *const todoBest = todo + nTodo;                      // msBest of the open ranks, kept here for the recount below (read from the result word once, not twice; 4 nTodo bytes < the five histogram regions of >= n bytes)
     for (u32 k = tid; k < nTodo; k += CL_THREADS) {
       const u32 i = todo[k];
       u32 r = (u32)(__hip_atomic_load(&res[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 0xFFFFu);   // msBest: from the rank's result word (read past this CU's L1)
+      todoBest[k] = (u16)r;
       for (u32 hop = 0; hop < n && r < n; ++hop) {
         const u32 rr = *(volatile u16 *)&root[r];
         if (rr != NONE16) { r = rr; break; }
@@ -1886,17 +1888,31 @@ __device__ __forceinline__ void cluster_one_block_tp(const ClusterArgs &a, u32 c
       root[i] = (u16)r;                                      // (a walker passing through i meanwhile reads NONE16 or r: the same answer either way)
     }
     SYNC();
+    // the open ranks' lists once more, TIF of them in flight per wave. Round 6: every load of a round is issued without a branch around it — written as
+    // `lane < length ? load : none` each of the 2 x TIF handle loads was a branch, a load and a wait of its own BEHIND the descriptor load its condition came from
+    // (twelve memory latencies in a row for four ranks; the phase was 14-16 % of a block's time for 4-9 % of its ranks: HISTORY 9) — a rank past the end of the
+    // list re-reads rank 0's places (valid memory: the slot's queue area lies behind the handles), lanes past a list's end are masked AFTER the loads.
     constexpr int TIF = ROWS_IN_FLIGHT;
     for (u32 k0 = uwave * TIF; k0 < nTodo; k0 += CL_WAVES * TIF) {
-      u32 ii[TIF], hA[TIF], hB[TIF], dl[TIF], qv[TIF];
+      u32 ii[TIF], hA[TIF], hB[TIF], dl[TIF], qv[TIF], bst[TIF]; u64 g[TIF];
 #pragma unroll
       for (int t = 0; t < TIF; ++t) {
-        const bool on = k0 + t < nTodo;
-        ii[t] = (u32)__builtin_amdgcn_readfirstlane((int)(on ? (u32)todo[k0 + t] : 0u));
-        qv[t] = on ? (u32)root[ii[t]] : NONE16;
-        dl[t] = on ? (u32)__builtin_amdgcn_readfirstlane((int)(u32)(gr[ii[t]] >> 32)) : 0u;
+        const u32 kk = k0 + (u32)t < nTodo ? k0 + (u32)t : nTodo - 1;      // (past the end: the last open rank again, its result dropped below)
+        ii[t] = (u32)__builtin_amdgcn_readfirstlane((int)(u32)todo[kk]);
+        bst[t] = (u32)todoBest[kk];
+        qv[t] = (u32)root[ii[t]];
+      }
+#pragma unroll
+      for (int t = 0; t < TIF; ++t) g[t] = gr[ii[t]];
+#pragma unroll
+      for (int t = 0; t < TIF; ++t) {
         const u16 *const hrow = hs + tpPos(tp, ii[t], hst), *const hrow64 = hs + tpPos64(tp, ii[t], hst);   // (class T keeps entries 64 .. in the unit's third chunk)
-        hA[t] = laneU < dl[t] ? (u32)hrow[laneU] : S; hB[t] = WAVE + laneU < dl[t] ? (u32)hrow64[laneU] : S;   // (only the list's own entries: the neighbours in the chunk are other lists')
+        hA[t] = (u32)hrow[laneU]; hB[t] = (u32)hrow64[laneU];
+      }
+#pragma unroll
+      for (int t = 0; t < TIF; ++t) {
+        dl[t] = k0 + (u32)t < nTodo ? (u32)__builtin_amdgcn_readfirstlane((int)(u32)(g[t] >> 32)) : 0u;
+        hA[t] = laneU < dl[t] ? hA[t] : S; hB[t] = WAVE + laneU < dl[t] ? hB[t] : S;   // (only the list's own entries: the neighbours in the chunk are other lists')
       }
 #pragma unroll
       for (int t = 0; t < TIF; ++t) {
@@ -1906,7 +1922,7 @@ __device__ __forceinline__ void cluster_one_block_tp(const ClusterArgs &a, u32 c
         u32 q = (u32)__popcll(__ballot(f == qv[t])), tt = (u32)__popcll(__ballot(f < i));
         if (dl[t] > WAVE) { f = ft.peek(hB[t]); q += (u32)__popcll(__ballot(f == qv[t])); tt += (u32)__popcll(__ballot(f < i)); }
         if (dl[t] > 2 * WAVE) { const u16 *const hrow = hs + tpPos(tp, i, hst); for (u32 b0 = 2 * WAVE; b0 < dl[t]; b0 += WAVE) { f = b0 + laneU < dl[t] ? ft.peek(hrow[b0 + laneU]) : (u32)NONE16; q += (u32)__popcll(__ballot(f == qv[t])); tt += (u32)__popcll(__ballot(f < i)); } }
-        if (lane == 0) res[i] = RES_PACK(__hip_atomic_load(&res[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 0xFFFFu, q, tt);
+        if (lane == 0) res[i] = RES_PACK(bst[t], q, tt);
       }
     }
   }

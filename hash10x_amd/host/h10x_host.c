@@ -209,7 +209,7 @@ int h10x_session_readFQB_dev(h10x_session *s, const uint32_t *devRec, uint64_t n
    time: the file never sits in host memory, and the closing call is the --readFQB itself (collective when sharded). A rank that fails
    here while sharded still makes the closing call's counterpart impossible for the others, so the verdict is agreed on first. */
 /* ---- --readFQB's fread loop (hash10x.c:202-209) as a pipeline of page-locked slabs, round 6. What scratch/r6_io_rate.c measured on a GPU box's memory-backed storage
-   (profiles/r6d_io_rate.log): one pread copies out of the page cache at 9.5 GB/s, sixteen at 136 GB/s — reads scale, and PCIe takes ~55 GB/s — so the file is read by a
+   (profiles/r6g_io_rate.log): one pread copies out of the page cache at 9.5 GB/s, sixteen at 136 GB/s — reads scale, and PCIe takes ~55 GB/s — so the file is read by a
    pool of READERS persistent threads, PIECE bytes at a time, into NSLAB slabs of SLAB bytes; the calling thread alone talks to the library (the C ABI is single-threaded):
    it queues a slab's upload (h10x_ingest_fqb_async, in file order) as soon as all its pieces are in, and hands a slab back to the readers when its upload has landed.
    Round 5 read 16 MiB slabs on 4 threads created and joined per slab, one slab at a time: 5.2 GB/s, 4.6 s of the 9.5 s configs[2] needs end to end. */
@@ -397,7 +397,7 @@ static void *write_job(void *a) {
   j->ok = done == j->len; return 0;
 }
 /* n bytes to the file at `at`. ONE pwrite stream per file: writers of one file take the inode's lock in turn, and on a GPU box's memory-backed storage one thread
-   writes a new file at 9.0 GB/s, two at 8.9, four at 4.1, eight at 4.4 (scratch/r6_io_rate.c, profiles/r6d_io_rate.log; a mapping of the file filled by memcpy: 2 - 4.6) —
+   writes a new file at 9.0 GB/s, two at 8.9, four at 4.1, eight at 4.4 (scratch/r6_io_rate.c, profiles/r6g_io_rate.log; a mapping of the file filled by memcpy: 2 - 4.6) —
    round 5 split every slice over four threads and had two slices in the air: 3.7 GB/s. What matters is that the one stream never waits for the device: Writer below. */
 static pthread_mutex_t fileWriteMu = PTHREAD_MUTEX_INITIALIZER;                      /* (ranks of one process write the same file: one at a time) */
 static int put(int fd, const void *p, uint64_t n, uint64_t at) {
