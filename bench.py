@@ -708,6 +708,7 @@ def virtual_ranks_block(hash10x_amd, name, n, local_rank=0, steps=1):
     """`n` ranks as threads on ONE GPU (in-process communicator, ranks taking turns: h10x_comm_local_serialize), each with its shard of the generator-v2 workload `name`:
     per rank the compute of a step and every exchange's bytes; the same set on one unsharded context for the single-GPU step; scaling_model() on top."""
     import threading
+    t_block = time.perf_counter()
     wl = dict(WORKLOADS[name])
     # one GPU, unsharded: the step the speed-up is quoted against
     recs, _f, total = generate_v2(wl, wl["seed"])
@@ -767,6 +768,7 @@ def virtual_ranks_block(hash10x_amd, name, n, local_rank=0, steps=1):
         c.destroy()
     out = scaling_model(res, sum(single) / len(single))
     out["workload"] = name
+    out["seconds"] = round(time.perf_counter() - t_block, 1)   # what the block cost the bench run (generation of the set and of the eight shards included)
     out["single_gpu_stage_ms"] = single_stage
     out["max_rank_stage_compute_ms"] = {k: max(r["stage_compute_ms"].get(k, 0.0) for r in res) for k in STAGE_TIMERS if any(k in r["stage_compute_ms"] for r in res)}
     out["per_rank"] = [{"read_pairs": r["read_pairs"], "compute_ms": round(r["compute_ms"], 3), "stage_compute_ms": r["stage_compute_ms"],

@@ -1424,7 +1424,11 @@ __device__ __forceinline__ void cluster_one_block_tp(const ClusterArgs &a, u32 c
 
   // ---- the table of pass A is cleared, and meanwhile the classes are counted: ranks ascend in list length, so `lists of at most L entries` is a rank
   u32 *const tab = (u32 *)region;
-  for (u32 i = tid; i <= S; i += CL_THREADS) tab[i] = 0xFFFFFFFFu;   // (+ the word of handle `none`)
+  {                                                          // (16 bytes per store: S is a multiple of 4, the region 16-byte aligned; + the word of handle `none`)
+    const uint4 ones = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
+    for (u32 i = tid; i < S / 4; i += CL_THREADS) ((uint4 *)tab)[i] = ones;
+    if (tid == 0) tab[S] = 0xFFFFFFFFu;
+  }
   if (tid < 8) sh[tid] = 0;                                  // [0] entries left for the second table, [1] barcodes in the first, [2] a table overflowed, [3..7] class counts (96, 16, 32, 64, 128)
   SYNC();
   {
@@ -1663,7 +1667,7 @@ __device__ __forceinline__ void cluster_one_block_tp(const ClusterArgs &a, u32 c
     for (u32 base = 0; base < count; base += 4 * CL_THREADS) {
       u32 v[4];
 #pragma unroll
-      for (int k = 0; k < 4; ++k) { const u32 idx = base + (u32)k * CL_THREADS + tid; v[k] = idx < count ? src[idx] : 0u; }
+      for (int k = 0; k < 4; ++k) { const u32 idx = base + (u32)k * CL_THREADS + tid; v[k] = src[idx < count ? idx : count - 1]; }   // (reads without a branch around them)
       SYNC();
 #pragma unroll
       for (int k = 0; k < 4; ++k) { const u32 idx = base + (u32)k * CL_THREADS + tid; if (idx < count) dst[idx] = (u16)(v[k] >> 16); }

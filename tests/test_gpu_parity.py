@@ -240,7 +240,7 @@ def test_alternative_layouts_give_the_same_bytes(workdir, opts):
     assert hf.blocks["nSubCluster"].sum() > 0
 
 
-@pytest.mark.parametrize("knob,form,B,k", [(1, 2, 20, 21), (3, 3, 20, 21), (2, 1, 20, 21), (1, 2, 22, 25), (1, 2, 19, 17)],
+@pytest.mark.parametrize("knob,form,B,k", [(1, 2, 20, 21), (3, 3, 20, 21), (2, 1, 20, 21), (1, 2, 22, 25), (1, 2, 20, 17)],
                          ids=["probed", "probed_table_fails", "never_probed", "probed_k25", "probed_k17"])
 def test_index_table_in_the_probed_format(workdir, knob, form, B, k):
     """Round 6: where index | hash / w does not fit a 64-bit entry (-B 29 / 30 at k = 21) the index build's wide table holds index | hash >> B | probe number in the
