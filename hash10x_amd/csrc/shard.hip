@@ -192,6 +192,18 @@ __global__ void scatter_depth_kernel(const u32 *__restrict__ idx, const u32 *__r
   u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; const u64 stride = (u64)gridDim.x * blockDim.x;
   for (; i < n; i += stride) hashDepth[idx[i]] = depth[i];
 }
+// hashDepth[] from the owners' (index, depth) runs when every run is SORTED BY INDEX (round 6): lane t takes element t / N of run t % N, so the N runs are walked in step —
+// each covers the whole index range evenly (an owner's hashes get indices all over it), the places written at one moment lie within a narrow moving window, and the
+// 4-byte writes of a table that no longer fits the Infinity Cache (0.9 GB at 226 M hashes: 23-28 G random writes/s, scratch/r5_scatter_rate.hip) combine in the L2
+// instead of each going out as a partial sector. One element after the other of the concatenated runs (scatter_depth_kernel) is a random scatter: 1.05 ms per rank on
+// the 1/4 3 Gb set, 2.1 ms on the 1/2 set, every rank scattering ALL U depths.
+__global__ void scatter_depth_runs_kernel(const u32 *__restrict__ idx, const u32 *__restrict__ depth, const u64 *__restrict__ runStart /* N + 1 */, int N, u64 maxRun, u32 *__restrict__ hashDepth) {
+  u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x; const u64 stride = (u64)gridDim.x * blockDim.x, total = maxRun * (u64)N;
+  for (; t < total; t += stride) {
+    const u32 r = (u32)(t % (u64)N); const u64 p = t / (u64)N, a = runStart[r];
+    if (a + p < runStart[r + 1]) hashDepth[idx[a + p]] = depth[a + p];
+  }
+}
 __global__ void scatter_value_kernel(const u32 *__restrict__ idx, const u64 *__restrict__ hash /* hash / w */, u64 n, u64 w, u64 *__restrict__ hashValue) {
   u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; const u64 stride = (u64)gridDim.x * blockDim.x;
   for (; i < n; i += stride) hashValue[idx[i]] = hash[i] * w;
@@ -449,14 +461,20 @@ int shard_readFqb(Ctx *c, Comm *cm, const u32 *dRec, u64 nRec) {
   std::vector<u64> sc((size_t)N, Uo), so((size_t)N, 0), rc((size_t)N), ro((size_t)N); u64 Utot = 0;
   for (int r = 0; r < N; ++r) { rc[r] = uo[r]; ro[r] = Utot; Utot += uo[r]; }
   if (Utot != U) return c->fail("sharded index: %llu distinct hashes gathered, %u numbered", (u64)Utot, U);
-  DevBuf<u32> dDepth, gIdx, gDepth;
+  DevBuf<u32> dDepth, gIdx, gDepth, sIdx, sDepth;
   H10X_HIP(c, dDepth.alloc(Uo)); H10X_HIP(c, gIdx.alloc(U)); H10X_HIP(c, gDepth.alloc(U));
   if (Uo) depth_of_kernel<<<divUp(Uo, 256), 256, 0, st>>>(c->oSegStart.p, Uo, dDepth.p);
+  // my (index, depth) pairs travel sorted by index: every rank then fills hashDepth[] from N runs walked in step (scatter_depth_runs_kernel) instead of by a random scatter
+  const bool runsByIndex = c->optOverlap != 0 && N > 1;      // (one rank: its own run IS the whole table in hash order — nothing to walk in step; knob 0 = round 5's form throughout)
+  if (runsByIndex) {
+    H10X_HIP(c, sIdx.alloc(Uo)); H10X_HIP(c, sDepth.alloc(Uo));
+    H10X_TRY(prim_sort_pairs_u32_u32(c, pt, c->oIndex.p, sIdx.p, dDepth.p, sDepth.p, Uo, 0, bitsForS((u64)U + 1)));
+  }
   const int besideClus = c->optOverlap ? (int)T_CLUSHASH : -1;
   XGuard xGuard(c);                                          // (an error return below must not park gIdx / gDepth / dDepth while the exchange stream still uses them)
   if (besideClus >= 0) H10X_TRY(c->xFork());
-  H10X_TRY(xchg_a2a(c, cm, X_INDEX_DEPTH, c->oIndex.p, sc.data(), so.data(), gIdx.p, rc.data(), ro.data(), 4, besideClus));
-  H10X_TRY(xchg_a2a(c, cm, X_INDEX_DEPTH, dDepth.p, sc.data(), so.data(), gDepth.p, rc.data(), ro.data(), 4, besideClus));
+  H10X_TRY(xchg_a2a(c, cm, X_INDEX_DEPTH, runsByIndex ? sIdx.p : c->oIndex.p, sc.data(), so.data(), gIdx.p, rc.data(), ro.data(), 4, besideClus));
+  H10X_TRY(xchg_a2a(c, cm, X_INDEX_DEPTH, runsByIndex ? sDepth.p : dDepth.p, sc.data(), so.data(), gDepth.p, rc.data(), ro.data(), 4, besideClus));
   c->tstop(T_PROBE);
   // ---- 7. the ClusterHash records of my blocks from the replies
   c->tstart(T_CLUSHASH);
@@ -469,7 +487,14 @@ int shard_readFqb(Ctx *c, Comm *cm, const u32 *dRec, u64 nRec) {
   H10X_TRY(c->xJoin());
   H10X_HIP(c, c->hashDepth.alloc((size_t)U + 1));
   H10X_HIP(c, hipMemsetAsync(c->hashDepth.p, 0, 4, st));
-  if (U) scatter_depth_kernel<<<gridFor(U), 256, 0, st>>>(gIdx.p, gDepth.p, U, c->hashDepth.p);
+  if (U && runsByIndex) {
+    DevBuf<u64> dRun; H10X_HIP(c, dRun.alloc((size_t)N + 1));
+    std::vector<u64> run((size_t)N + 1); u64 maxRun = 0;   // (lives to the end of the function, past the stream synchronisation below)
+    for (int r = 0; r < N; ++r) { run[r] = ro[r]; maxRun = hmax(maxRun, rc[r]); }
+    run[N] = Utot;
+    H10X_HIP(c, hipMemcpyAsync(dRun.p, run.data(), ((size_t)N + 1) * 8, hipMemcpyHostToDevice, st));
+    scatter_depth_runs_kernel<<<gridFor(maxRun * (u64)N), 256, 0, st>>>(gIdx.p, gDepth.p, dRun.p, N, maxRun, c->hashDepth.p);
+  } else if (U) scatter_depth_kernel<<<gridFor(U), 256, 0, st>>>(gIdx.p, gDepth.p, U, c->hashDepth.p);
   c->oHash.swap(dHash);                                      // this owner's distinct hashes, for shard_materializeTables
   c->hashValue.release(); c->hashIndex.release(); c->tablesPending = true;
   c->tstop(T_PROBE);

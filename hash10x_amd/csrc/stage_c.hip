@@ -1673,7 +1673,24 @@ __device__ __forceinline__ void cluster_one_block_tp(const ClusterArgs &a, u32 c
       for (int k = 0; k < 4; ++k) { const u32 idx = base + (u32)k * CL_THREADS + tid; if (idx < count) dst[idx] = (u16)(v[k] >> 16); }
     }
   };
-  compactRanks(tab, (u16 *)region, S + 1);
+  {
+    // the first table, four entries per lane and step (round 6): 16-byte reads, 8-byte writes, rounds of 3 x 1024 x 4 entries with ONE barrier each — two rounds for the
+    // largest table — where a word at a time took a barrier per 4096 entries and five times the LDS instructions; the phase is workgroup-synchronous (nobody to hide its
+    // latencies behind but the CU's other workgroup): this and the 16-byte clears took the 3 Gb set's cluster time from 285 to ... ms. Round r writes bytes
+    // [r * 24 K, (r + 1) * 24 K), which lie inside what rounds <= r have read (every round's reads are behind a barrier before the next round writes).
+    const u32 noneWord = tab[S];                             // (the word of handle `none`, index S: read before anything is overwritten — S >= 64, so it is not in round 0's writes... kept by every lane, written by one)
+    const uint4 *const src4 = (const uint4 *)tab; uint2 *const dst2 = (uint2 *)region; const u32 count4 = S / 4;
+    for (u32 base = 0; base < count4; base += 3 * CL_THREADS) {
+      uint4 v[3];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) { const u32 idx = base + (u32)k * CL_THREADS + tid; v[k] = src4[idx < count4 ? idx : count4 - 1]; }
+      SYNC();
+#pragma unroll
+      for (int k = 0; k < 3; ++k) { const u32 idx = base + (u32)k * CL_THREADS + tid; if (idx < count4) dst2[idx] = make_uint2((v[k].x >> 16) | (v[k].y & 0xFFFF0000u), (v[k].z >> 16) | (v[k].w & 0xFFFF0000u)); }
+    }
+    SYNC();
+    if (tid == 0) ((u16 *)region)[S] = (u16)(noneWord >> 16);
+  }
   ft.base = region; ft.sh = 1; firstBytes = pad16(2 * ((size_t)S + 8));
   if (spill) {
     u32 *const tab2 = (u32 *)(region + firstBytes);
@@ -1699,7 +1716,11 @@ __device__ __forceinline__ void cluster_one_block_tp(const ClusterArgs &a, u32 c
   u32 *const hist = (u32 *)(region + firstBytes + pad16((size_t)n * 2));
   const u32 histWords = histBytes / 4;
   SYNC();
-  for (u32 i = tid; i < nW * histWords; i += CL_THREADS) hist[i] = 0;
+  {                                                          // (16 bytes per store; the region starts 16-byte aligned)
+    const u32 words = nW * histWords;
+    for (u32 i = tid; i < words / 4; i += CL_THREADS) ((uint4 *)hist)[i] = make_uint4(0, 0, 0, 0);
+    if (tid < (words & 3u)) hist[(words & ~3u) + tid] = 0;
+  }
   for (u32 i = tid; i < n; i += CL_THREADS) root[i] = i ? NONE16 : (u16)0;      // rank 0 is never processed (hash10x.c:789): inactive, its own root
   SYNC();
   STAMP(3);
