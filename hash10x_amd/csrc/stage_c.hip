@@ -709,6 +709,13 @@ __device__ __forceinline__ u32 descFix(u32 v, u32 i0, u32 nLists, u32 n) {
 // work counters of a workgroup: the list entries gathered are summed per lane (32 bits: a wave's share of a launch) and posted when the kernel ends; what thread 0
 // alone counts — good hashes, nHash, barcodes, the lengths of the rank-0 lists — lives in LDS (the four 64-bit registers per lane these took were a tenth of the
 // 64 a wave has where two 1024-lane workgroups share a CU)
+// `bytes` (a multiple of 16, the region 16-byte aligned: every part of the working set is padded so) set to the word `v`, 16 bytes per store. The init phases of a block
+// are workgroup-synchronous — every wave does the same thing between two barriers, nobody but the CU's other workgroup hides their latencies — and were written a word
+// per store: 20 store instructions per lane for the 79 KB table of the packed form, 4 per lane now (round 6: with the rank compaction 285 -> 275 ms on the 3 Gb set).
+template <int CL_THREADS> __device__ __forceinline__ void fill16(void *p, size_t bytes, u32 v) {
+  const uint4 v4 = make_uint4(v, v, v, v);
+  for (u32 i = threadIdx.x; i < (u32)(bytes / 16); i += CL_THREADS) ((uint4 *)p)[i] = v4;
+}
 struct WorkAcc { u32 depth; unsigned long long *s; };
 template <bool IN_LDS, int FIRST_MODE /* 0 dense in LDS, 1 ranked in LDS, 2 dense on an HBM slot, 3 hashed in LDS */, int CL_THREADS, int KLASS>
 __device__ __forceinline__ void cluster_one_block(const ClusterArgs &a, u32 code, unsigned char *region, u16 *firstGlobal, u32 *sh /* small shared ints */, WorkAcc &acc) {   // code: local block number
@@ -754,14 +761,14 @@ __device__ __forceinline__ void cluster_one_block(const ClusterArgs &a, u32 code
 
   if (a.phase && threadIdx.x == 0) acc.s[4] = wall_clock64();
   // ---- init: clear the tables; nothing is fetched per rank any more
-  if (FIRST_LDS && !RANKED) {
-    if (wideFirst) for (u32 i = tid; i < a.nBlocksFirst; i += CL_THREADS) ((u32 *)w.first)[i] = NONE16;
-    else for (u32 i = tid; i < (a.nBlocksFirst + 1) / 2; i += CL_THREADS) ((u32 *)w.first)[i] = 0xFFFFFFFFu;
+  if (FIRST_LDS && !RANKED) {                              // (16 bytes per store: fill16; the parts of the working set are padded to 16 bytes, the histograms have 16 bytes of slack behind them: workBytes)
+    if (wideFirst) fill16<CL_THREADS>(w.first, pad16((size_t)a.nBlocksFirst * 4), (u32)NONE16);
+    else fill16<CL_THREADS>(w.first, pad16((size_t)a.nBlocksFirst * 2), 0xFFFFFFFFu);
   }
-  if (RANKED) for (u32 i = tid; i < bmWords; i += CL_THREADS) w.bm[i] = 0;
-  if (!RANKED) for (u32 i = tid; i < nW * w.histWords; i += CL_THREADS) w.hist[i] = 0;
-  for (u32 i = tid; i < n; i += CL_THREADS) w.root[i] = i ? NONE16 : (u16)0;   // rank 0 is never processed (hash10x.c:789): inactive, its own root
-  if (tid == 0) res[0] = RES_PACK(NONE16, 0, 0);
+  if (RANKED) fill16<CL_THREADS>(w.bm, pad16((size_t)bmWords * 4), 0u);
+  if (!RANKED) fill16<CL_THREADS>(w.hist, pad16((size_t)nW * w.histWords * 4), 0u);
+  fill16<CL_THREADS>(w.root, pad16((size_t)n * 2), 0xFFFFFFFFu);     // NONE16 everywhere ...
+  if (tid == 0) { w.root[0] = 0; res[0] = RES_PACK(NONE16, 0, 0); }  // ... but rank 0, which is never processed (hash10x.c:789): inactive, its own root (lane 0 wrote its word just above)
   SYNC();
   if constexpr (RANKED) {
     // ---- (0) which barcodes occur in this block's lists: presence bitmap, per-word popcount prefix, and a first[] sized by
@@ -1721,7 +1728,8 @@ __device__ __forceinline__ void cluster_one_block_tp(const ClusterArgs &a, u32 c
     for (u32 i = tid; i < words / 4; i += CL_THREADS) ((uint4 *)hist)[i] = make_uint4(0, 0, 0, 0);
     if (tid < (words & 3u)) hist[(words & ~3u) + tid] = 0;
   }
-  for (u32 i = tid; i < n; i += CL_THREADS) root[i] = i ? NONE16 : (u16)0;      // rank 0 is never processed (hash10x.c:789): inactive, its own root
+  fill16<CL_THREADS>(root, pad16((size_t)n * 2), 0xFFFFFFFFu);
+  if (tid == 0) root[0] = 0;                                 // rank 0 is never processed (hash10x.c:789): inactive, its own root
   SYNC();
   STAMP(3);
 

@@ -272,7 +272,7 @@ static int stream_records(h10x_session *s, const char *path, uint64_t first, uin
   else if (!q.slab[0]) rc = fail(s, "out of memory for a %d MiB read buffer", IN_SLAB >> 20);
   else if (h10x_ingest_reserve(s->ctx, n)) rc = fail_ctx(s);
   clock_gettime(CLOCK_MONOTONIC, &t1);
-  pthread_t th[IN_MAXREADERS]; int nTh = 0;
+  pthread_t th[IN_MAXREADERS]; int nTh = 0; double waitRead = 0, waitUpload = 0;   /* ms the calling thread waited for the readers / for uploads to land */
   if (!rc && q.nSlabs) {
     pthread_mutex_init(&q.mu, 0); pthread_cond_init(&q.cv, 0);
     q.freeBelow = (uint64_t)q.S;                                                      /* = slabs whose upload has landed + S */
@@ -286,18 +286,21 @@ static int stream_records(h10x_session *s, const char *path, uint64_t first, uin
     if (!nTh) rc = fail(s, "could not start a reader thread");
     for (uint64_t k = 0; !rc && k < q.nSlabs; ++k) {
       const int slot = (int)(k % (uint64_t)q.S); const uint64_t want120 = inpipe_slab_bytes(&q, k) / 120;
+      const double tw0 = now_ms();
       pthread_mutex_lock(&q.mu);
       while (q.done[slot] < q.piecesPerSlab && !q.failed) pthread_cond_wait(&q.cv, &q.mu);
       const int bad = q.failed; q.done[slot] = 0;
       pthread_mutex_unlock(&q.mu);
+      waitRead += now_ms() - tw0;
       if (bad) { rc = fail(s, "file read problem"); break; }                          /* hash10x.c:209 */
       if (pinned ? h10x_ingest_fqb_async(s->ctx, (const uint32_t *)q.slab[slot], want120, slot)
                  : (sharded ? h10x_shard_ingest_fqb(s->ctx, (const uint32_t *)q.slab[0], want120, 0) : h10x_ingest_fqb(s->ctx, (const uint32_t *)q.slab[0], want120, 0))) { rc = fail_ctx(s); break; }
       /* a slab goes back to the readers when its upload has landed. Uploads are queued in order: with several slots the calling thread waits for the PREVIOUS slab's
          (this one is on its way while the next is read); with one slot for this one's */
-      uint64_t landed;
+      uint64_t landed; const double tw1 = now_ms();
       if (q.S > 1) { landed = k; if (k >= 1 && h10x_ingest_wait(s->ctx, (int)((k - 1) % (uint64_t)q.S))) { rc = fail_ctx(s); break; } }
       else { landed = k + 1; if (pinned && h10x_ingest_wait(s->ctx, slot)) { rc = fail_ctx(s); break; } }
+      waitUpload += now_ms() - tw1;
       pthread_mutex_lock(&q.mu);
       q.freeBelow = landed + (uint64_t)q.S;
       pthread_cond_broadcast(&q.cv);
@@ -316,9 +319,9 @@ static int stream_records(h10x_session *s, const char *path, uint64_t first, uin
   if (sharded ? h10x_shard_ingest_fqb(s->ctx, 0, 0, 1) : h10x_ingest_fqb(s->ctx, 0, 0, 1)) return fail_ctx(s);
   clock_gettime(CLOCK_MONOTONIC, &t3);
   if (getenv("H10X_INGEST_TIMING"))                                                    /* where a --readFQB spends its wall time */
-    fprintf(stderr, "  ingest of %.2f GB: buffers + image %.3f s, read + upload %.3f s (%.1f GB/s, %d readers), hashing + index %.3f s\n", (double)bytes / 1e9,
+    fprintf(stderr, "  ingest of %.2f GB: buffers + image %.3f s, read + upload %.3f s (%.1f GB/s, %d readers; the calling thread waited %.3f s for readers, %.3f s for uploads), hashing + index %.3f s\n", (double)bytes / 1e9,
             (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec), (double)(t2.tv_sec - t1.tv_sec) + 1e-9 * (double)(t2.tv_nsec - t1.tv_nsec),
-            (double)bytes / 1e9 / ((double)(t2.tv_sec - t1.tv_sec) + 1e-9 * (double)(t2.tv_nsec - t1.tv_nsec) + 1e-9), nTh, (double)(t3.tv_sec - t2.tv_sec) + 1e-9 * (double)(t3.tv_nsec - t2.tv_nsec));
+            (double)bytes / 1e9 / ((double)(t2.tv_sec - t1.tv_sec) + 1e-9 * (double)(t2.tv_nsec - t1.tv_nsec) + 1e-9), nTh, waitRead * 1e-3, waitUpload * 1e-3, (double)(t3.tv_sec - t2.tv_sec) + 1e-9 * (double)(t3.tv_nsec - t2.tv_nsec));
   return 0;
 }
 static int file_records(h10x_session *s, const char *path, uint64_t *n, int *cutByN) {
