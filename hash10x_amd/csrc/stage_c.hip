@@ -1451,9 +1451,9 @@ __device__ __forceinline__ void cluster_one_block_tp(const ClusterArgs &a, u32 c
   STAMP(0);
   // ---- how the lists are packed: four / two to a wave instruction where the histogram regions of that many segments fit beside first[] and root[]
   // (pass B: first[] at 2 bytes per slot, root[] 2 bytes per rank, one region per segment and wave). Decided here, before pass A: the handles are laid out by it.
+  TpShape tp;
   u32 histBytes;                                             // per wave in pass B
   {
-    TpShape tp;
     const u32 c16 = sh[4], c32 = sh[5];
     tp.m64 = sh[6]; tp.m128 = sh[7]; tp.m96 = a.tpClassT ? sh[3] : tp.m64;
     if (tp.m96 < tp.m64) tp.m96 = tp.m64;                    // (cannot happen: counts of <= 64 and <= 96)
@@ -1480,15 +1480,7 @@ __device__ __forceinline__ void cluster_one_block_tp(const ClusterArgs &a, u32 c
     tp.posT = tp.posF + 64u * (tp.m64 - tp.m32);
     tp.posD = tp.posT + 192u * ((tp.m96 - tp.m64 + 1u) / 2u);
     tp.posX = tp.posD + 128u * (tp.m128 - tp.m96);
-    if (lane == 0) { sh[16] = tp.m16; sh[17] = tp.m32; sh[18] = tp.m64; sh[19] = tp.m96; sh[20] = tp.m128; sh[21] = tp.posH; sh[22] = tp.posF; sh[23] = tp.posT; sh[24] = tp.posD; sh[25] = tp.posX; }
   }
-  // The ten values of the shape live in LDS from here on (round 6): as kernel-long scalars they were ten of the 78 scalar registers the kernel has at
-  // 8 waves per SIMD — it spills 120-140, and every reload is a v_readlane, a VECTOR instruction, in the pass loops. Every wave computes the same ten values and
-  // stores them before it reads any (same addresses, same data: no barrier needed); a class loop fetches its three when it starts.
-  typedef __attribute__((address_space(3))) u32 lds_u32_t;
-  auto TPV = [&](int i) { return (u32)__builtin_amdgcn_readfirstlane((int)*(volatile lds_u32_t *)(lds_u32_t *)&sh[16 + i]); };
-  auto tpLoad = [&]() { TpShape t; t.m16 = TPV(0); t.m32 = TPV(1); t.m64 = TPV(2); t.m96 = TPV(3); t.m128 = TPV(4); t.posH = TPV(5); t.posF = TPV(6); t.posT = TPV(7); t.posD = TPV(8); t.posX = TPV(9); return t; };
-  enum { TP_M16 = 0, TP_M32, TP_M64, TP_M96, TP_M128, TP_POSH, TP_POSF, TP_POST, TP_POSD, TP_POSX };
   // entries whose search goes beyond the home bucket are parked — barcode | rank << 22 | position of the handle << 38 — in a queue of the wave's own
   // behind the handles on the HBM slot, and searched for with search() 64 lanes at a time when the pass is over (or the queue full). What search()
   // cannot settle — a barcode that is new when the table is closed — stays in the queue, for the second table.
@@ -1644,16 +1636,15 @@ __device__ __forceinline__ void cluster_one_block_tp(const ClusterArgs &a, u32 c
         roundEnd(false);
       }
     };
-    classA(std::integral_constant<u32, 16>{}, std::integral_constant<u32, 1>{}, 0u, TPV(TP_M16), 0u);
-    classA(std::integral_constant<u32, 32>{}, std::integral_constant<u32, 1>{}, TPV(TP_M16), TPV(TP_M32), TPV(TP_POSH));
-    classA(std::integral_constant<u32, 64>{}, std::integral_constant<u32, 1>{}, TPV(TP_M32), TPV(TP_M64), TPV(TP_POSF));
-    classAT(TPV(TP_M64), TPV(TP_M96), TPV(TP_POST));
-    classA(std::integral_constant<u32, 64>{}, std::integral_constant<u32, 2>{}, TPV(TP_M96), TPV(TP_M128), TPV(TP_POSD));
-    const u32 m128A = TPV(TP_M128);
-    for (u32 i = m128A + uwave; i < n; i += CL_WAVES) {       // class X (depth ranges beyond 128): list after list, chunk after chunk
+    classA(std::integral_constant<u32, 16>{}, std::integral_constant<u32, 1>{}, 0u, tp.m16, 0u);
+    classA(std::integral_constant<u32, 32>{}, std::integral_constant<u32, 1>{}, tp.m16, tp.m32, tp.posH);
+    classA(std::integral_constant<u32, 64>{}, std::integral_constant<u32, 1>{}, tp.m32, tp.m64, tp.posF);
+    classAT(tp.m64, tp.m96, tp.posT);
+    classA(std::integral_constant<u32, 64>{}, std::integral_constant<u32, 2>{}, tp.m96, tp.m128, tp.posD);
+    for (u32 i = tp.m128 + uwave; i < n; i += CL_WAVES) {     // class X (depth ranges beyond 128): list after list, chunk after chunk
       if (i == 0) continue;
       const u64 g2 = gr[i]; const u32 d = (u32)__builtin_amdgcn_readfirstlane((int)(u32)(g2 >> 32)); const u32 *row = ROWP((u32)__builtin_amdgcn_readfirstlane((int)(u32)g2));
-      const u32 pos = TPV(TP_POSX) + hst * (i - m128A);
+      const u32 pos = tp.posX + hst * (i - tp.m128);
       for (u32 lj = 0; lj < d; lj += WAVE) {
         const u32 cj = row[lj + laneU];
         place(cj, i, lj + laneU < d && cj != code, pos + lj);
@@ -1875,16 +1866,15 @@ __device__ __forceinline__ void cluster_one_block_tp(const ClusterArgs &a, u32 c
         }
       }
     };
-    classB(std::integral_constant<u32, 16>{}, std::integral_constant<u32, 1>{}, 0u, TPV(TP_M16), 0u);
-    classB(std::integral_constant<u32, 32>{}, std::integral_constant<u32, 1>{}, TPV(TP_M16), TPV(TP_M32), TPV(TP_POSH));
-    classB(std::integral_constant<u32, 64>{}, std::integral_constant<u32, 1>{}, TPV(TP_M32), TPV(TP_M64), TPV(TP_POSF));
-    classBT(TPV(TP_M64), TPV(TP_M96), TPV(TP_POST));
-    classB(std::integral_constant<u32, 64>{}, std::integral_constant<u32, 2>{}, TPV(TP_M96), TPV(TP_M128), TPV(TP_POSD));
-    const u32 m128B = TPV(TP_M128);
-    for (u32 i = m128B + uwave; i < n; i += nW) {            // class X
+    classB(std::integral_constant<u32, 16>{}, std::integral_constant<u32, 1>{}, 0u, tp.m16, 0u);
+    classB(std::integral_constant<u32, 32>{}, std::integral_constant<u32, 1>{}, tp.m16, tp.m32, tp.posH);
+    classB(std::integral_constant<u32, 64>{}, std::integral_constant<u32, 1>{}, tp.m32, tp.m64, tp.posF);
+    classBT(tp.m64, tp.m96, tp.posT);
+    classB(std::integral_constant<u32, 64>{}, std::integral_constant<u32, 2>{}, tp.m96, tp.m128, tp.posD);
+    for (u32 i = tp.m128 + uwave; i < n; i += nW) {          // class X
       if (i == 0) continue;
       const u32 d = (u32)__builtin_amdgcn_readfirstlane((int)(u32)(gr[i] >> 32));
-      const u16 *const hrow = hs + TPV(TP_POSX) + (size_t)hst * (i - m128B);
+      const u16 *const hrow = hs + tp.posX + (size_t)hst * (i - tp.m128);
       u32 best, bcnt, tot, rb, q;
       if (d < RCHUNK * WAVE) row_mode_hist<IN_LDS, RCHUNK>(hrow, (u32)hrow[laneU], (u32)hrow[WAVE + laneU], d, code, i, ft, myHist, root, thr, best, bcnt, tot, rb, q);
       else {
@@ -1936,7 +1926,6 @@ __device__ __forceinline__ void cluster_one_block_tp(const ClusterArgs &a, u32 c
     // (twelve memory latencies in a row for four ranks; the phase was 14-16 % of a block's time for 4-9 % of its ranks: HISTORY 9) — a rank past the end of the
     // list re-reads rank 0's places (valid memory: the slot's queue area lies behind the handles), lanes past a list's end are masked AFTER the loads.
     constexpr int TIF = ROWS_IN_FLIGHT;
-    const TpShape tp = tpLoad();                             // (the shape, back from LDS for this phase)
     for (u32 k0 = uwave * TIF; k0 < nTodo; k0 += CL_WAVES * TIF) {
       u32 ii[TIF], hA[TIF], hB[TIF], dl[TIF], qv[TIF], bst[TIF]; u64 g[TIF];
 #pragma unroll
