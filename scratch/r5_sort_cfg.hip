@@ -31,5 +31,9 @@ int main(int argc, char **argv) {
   run<CFG(1024, 8, 8, match)>("1024x8 r8 match", in, out, n);
   run<CFG(1024, 10, 8, match)>("1024x10 r8 match", in, out, n);
   run<CFG(768, 10, 8, match)>("768x10 r8 match", in, out, n);
+  // round 6: 38 key bits are five passes of 8 bits — four of 10?
+  run<CFG(1024, 8, 10, match)>("1024x8 r10 match (4 passes)", in, out, n);
+  run<CFG(512, 12, 10, match)>("512x12 r10 match (4 passes)", in, out, n);
+  run<CFG(1024, 6, 10, match)>("1024x6 r10 match (4 passes)", in, out, n);
   return 0;
 }
