@@ -12,6 +12,7 @@
 #include <unistd.h>
 #include <sys/types.h>
 #include <sys/stat.h>
+#include <sys/mman.h>
 
 #define ARRAY_MAGIC 8918274                            /* array.h:56 */
 typedef struct { int32_t magic, pad0; uint64_t base; int32_t dim, size, max, pad1; } array_hdr;   /* array.h:41-50 */
@@ -216,6 +217,7 @@ int h10x_session_readFQB_dev(h10x_session *s, const uint32_t *devRec, uint64_t n
 enum { IN_PIECE = 4 << 20, IN_SLAB = ((64 << 20) / 120 / 30) * 120 * 30, IN_NSLAB = 6, IN_MAXREADERS = 32 };   /* whole records per slab */
 typedef struct {
   int fd; uint64_t base, bytes;                       /* the byte range of the file to read */
+  const char *map;                                    /* the whole file mapped (MAP_SHARED), or 0: pread */
   uint64_t nSlabs, piecesPerSlab;
   int S;                                              /* slabs in use: slab k lives in slot k % S */
   char *slab[IN_NSLAB];
@@ -242,6 +244,7 @@ static void *inpipe_reader(void *a) {
     if (off < slabBytes) {
       const uint64_t len = slabBytes - off < IN_PIECE ? slabBytes - off : IN_PIECE; uint64_t got = 0;
       char *dst = q->slab[k % (uint64_t)q->S] + off;
+      if (q->map) { memcpy(dst, q->map + q->base + k * IN_SLAB + off, len); got = len; }
       while (got < len) { const ssize_t r = pread(q->fd, dst + got, len - got, (off_t)(q->base + k * IN_SLAB + off + got)); if (r <= 0) break; got += (uint64_t)r; }
       ok = got == len;
     }
@@ -262,6 +265,17 @@ static int stream_records(h10x_session *s, const char *path, uint64_t first, uin
   const uint64_t bytes = n * 120;
   InPipe q; memset(&q, 0, sizeof q);
   q.fd = open(path, O_RDONLY); q.base = first * 120; q.bytes = bytes;
+  /* The readers copy out of a MAP_SHARED mapping of the file rather than pread it: the FIRST read of a file fresh in memory-backed storage goes through the page cache's LRU
+     lists under a lock when it is a read() — 16 threads: 15.3 GB/s the first time, 150-250 the second (scratch/r6_read_existing.c, profiles/r6n_read_existing.log,
+     r6o_read_mmap.log) — and at 146 GB/s through a mapping. pread where the file cannot be mapped (a pipe, a special file), or H10X_NO_MMAP is set. */
+  size_t mapLen = 0;
+  if (q.fd >= 0 && bytes && !getenv("H10X_NO_MMAP")) {
+    struct stat sb;
+    if (fstat(q.fd, &sb) == 0 && S_ISREG(sb.st_mode) && (uint64_t)sb.st_size >= q.base + bytes) {
+      void *m = mmap(0, (size_t)(q.base + bytes), PROT_READ, MAP_SHARED, q.fd, 0);
+      if (m != MAP_FAILED) { q.map = (const char *)m; mapLen = (size_t)(q.base + bytes); }
+    }
+  }
   q.nSlabs = (bytes + IN_SLAB - 1) / IN_SLAB; q.piecesPerSlab = (IN_SLAB + IN_PIECE - 1) / IN_PIECE;
   const int nSlabBuf = q.nSlabs < IN_NSLAB ? (int)(q.nSlabs ? q.nSlabs : 1) : IN_NSLAB;
   int pinned = 1;
@@ -310,6 +324,7 @@ static int stream_records(h10x_session *s, const char *path, uint64_t first, uin
     for (int i = 0; i < nTh; ++i) pthread_join(th[i], 0);
     pthread_mutex_destroy(&q.mu); pthread_cond_destroy(&q.cv);
   }
+  if (q.map) munmap((void *)q.map, mapLen);
   if (q.fd >= 0) close(q.fd);
   if (pinned) { for (int k = 0; k < IN_NSLAB; ++k) { if (q.slab[k]) h10x_ingest_wait(s->ctx, k); h10x_pinned_free(q.slab[k]); } } else free(q.slab[0]);
   if (warming) pthread_join(warmTh, 0);
@@ -319,9 +334,9 @@ static int stream_records(h10x_session *s, const char *path, uint64_t first, uin
   if (sharded ? h10x_shard_ingest_fqb(s->ctx, 0, 0, 1) : h10x_ingest_fqb(s->ctx, 0, 0, 1)) return fail_ctx(s);
   clock_gettime(CLOCK_MONOTONIC, &t3);
   if (getenv("H10X_INGEST_TIMING"))                                                    /* where a --readFQB spends its wall time */
-    fprintf(stderr, "  ingest of %.2f GB: buffers + image %.3f s, read + upload %.3f s (%.1f GB/s, %d readers; the calling thread waited %.3f s for readers, %.3f s for uploads), hashing + index %.3f s\n", (double)bytes / 1e9,
+    fprintf(stderr, "  ingest of %.2f GB: buffers + image %.3f s, read + upload %.3f s (%.1f GB/s, %d readers%s; the calling thread waited %.3f s for readers, %.3f s for uploads), hashing + index %.3f s\n", (double)bytes / 1e9,
             (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec), (double)(t2.tv_sec - t1.tv_sec) + 1e-9 * (double)(t2.tv_nsec - t1.tv_nsec),
-            (double)bytes / 1e9 / ((double)(t2.tv_sec - t1.tv_sec) + 1e-9 * (double)(t2.tv_nsec - t1.tv_nsec) + 1e-9), nTh, waitRead * 1e-3, waitUpload * 1e-3, (double)(t3.tv_sec - t2.tv_sec) + 1e-9 * (double)(t3.tv_nsec - t2.tv_nsec));
+            (double)bytes / 1e9 / ((double)(t2.tv_sec - t1.tv_sec) + 1e-9 * (double)(t2.tv_nsec - t1.tv_nsec) + 1e-9), nTh, mapLen ? " on a mapping" : ", pread", waitRead * 1e-3, waitUpload * 1e-3, (double)(t3.tv_sec - t2.tv_sec) + 1e-9 * (double)(t3.tv_nsec - t2.tv_nsec));
   return 0;
 }
 static int file_records(h10x_session *s, const char *path, uint64_t *n, int *cutByN) {
