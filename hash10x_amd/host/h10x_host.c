@@ -218,6 +218,7 @@ enum { IN_PIECE = 4 << 20, IN_SLAB = ((64 << 20) / 120 / 30) * 120 * 30, IN_NSLA
 typedef struct {
   int fd; uint64_t base, bytes;                       /* the byte range of the file to read */
   const char *map;                                    /* the whole file mapped (MAP_SHARED), or 0: pread */
+  int populate;                                       /* madvise(MADV_POPULATE_READ) a piece before it is copied */
   uint64_t nSlabs, piecesPerSlab;
   int S;                                              /* slabs in use: slab k lives in slot k % S */
   char *slab[IN_NSLAB];
@@ -244,7 +245,16 @@ static void *inpipe_reader(void *a) {
     if (off < slabBytes) {
       const uint64_t len = slabBytes - off < IN_PIECE ? slabBytes - off : IN_PIECE; uint64_t got = 0;
       char *dst = q->slab[k % (uint64_t)q->S] + off;
-      if (q->map) { memcpy(dst, q->map + q->base + k * IN_SLAB + off, len); got = len; }
+      if (q->map) {
+        const char *src = q->map + q->base + k * IN_SLAB + off;
+#ifdef MADV_POPULATE_READ
+        if (q->populate) {                              /* the piece's pages into this process's page tables in ONE call: a fault per 16 pages (2 M faults/s over the pool) otherwise — see stream_records */
+          const uintptr_t a = (uintptr_t)src & ~(uintptr_t)4095, e = ((uintptr_t)src + len + 4095) & ~(uintptr_t)4095;
+          (void)madvise((void *)a, (size_t)(e - a), MADV_POPULATE_READ);
+        }
+#endif
+        memcpy(dst, src, len); got = len;
+      }
       while (got < len) { const ssize_t r = pread(q->fd, dst + got, len - got, (off_t)(q->base + k * IN_SLAB + off + got)); if (r <= 0) break; got += (uint64_t)r; }
       ok = got == len;
     }
@@ -273,7 +283,7 @@ static int stream_records(h10x_session *s, const char *path, uint64_t first, uin
     struct stat sb;
     if (fstat(q.fd, &sb) == 0 && S_ISREG(sb.st_mode) && (uint64_t)sb.st_size >= q.base + bytes) {
       void *m = mmap(0, (size_t)(q.base + bytes), PROT_READ, MAP_SHARED, q.fd, 0);
-      if (m != MAP_FAILED) { q.map = (const char *)m; mapLen = (size_t)(q.base + bytes); }
+      if (m != MAP_FAILED) { q.map = (const char *)m; mapLen = (size_t)(q.base + bytes); q.populate = !getenv("H10X_NO_POPULATE"); }
     }
   }
   q.nSlabs = (bytes + IN_SLAB - 1) / IN_SLAB; q.piecesPerSlab = (IN_SLAB + IN_PIECE - 1) / IN_PIECE;
@@ -286,7 +296,7 @@ static int stream_records(h10x_session *s, const char *path, uint64_t first, uin
   else if (!q.slab[0]) rc = fail(s, "out of memory for a %d MiB read buffer", IN_SLAB >> 20);
   else if (h10x_ingest_reserve(s->ctx, n)) rc = fail_ctx(s);
   clock_gettime(CLOCK_MONOTONIC, &t1);
-  pthread_t th[IN_MAXREADERS]; int nTh = 0; double waitRead = 0, waitUpload = 0;   /* ms the calling thread waited for the readers / for uploads to land */
+  pthread_t th[IN_MAXREADERS]; int nTh = 0; double waitRead = 0, waitUpload = 0, inCalls = 0;   /* ms the calling thread waited for the readers / for uploads to land / spent queueing uploads */
   if (!rc && q.nSlabs) {
     pthread_mutex_init(&q.mu, 0); pthread_cond_init(&q.cv, 0);
     q.freeBelow = (uint64_t)q.S;                                                      /* = slabs whose upload has landed + S */
@@ -307,11 +317,12 @@ static int stream_records(h10x_session *s, const char *path, uint64_t first, uin
       pthread_mutex_unlock(&q.mu);
       waitRead += now_ms() - tw0;
       if (bad) { rc = fail(s, "file read problem"); break; }                          /* hash10x.c:209 */
+      const double tc0 = now_ms();
       if (pinned ? h10x_ingest_fqb_async(s->ctx, (const uint32_t *)q.slab[slot], want120, slot)
                  : (sharded ? h10x_shard_ingest_fqb(s->ctx, (const uint32_t *)q.slab[0], want120, 0) : h10x_ingest_fqb(s->ctx, (const uint32_t *)q.slab[0], want120, 0))) { rc = fail_ctx(s); break; }
       /* a slab goes back to the readers when its upload has landed. Uploads are queued in order: with several slots the calling thread waits for the PREVIOUS slab's
          (this one is on its way while the next is read); with one slot for this one's */
-      uint64_t landed; const double tw1 = now_ms();
+      uint64_t landed; const double tw1 = now_ms(); inCalls += tw1 - tc0;
       if (q.S > 1) { landed = k; if (k >= 1 && h10x_ingest_wait(s->ctx, (int)((k - 1) % (uint64_t)q.S))) { rc = fail_ctx(s); break; } }
       else { landed = k + 1; if (pinned && h10x_ingest_wait(s->ctx, slot)) { rc = fail_ctx(s); break; } }
       waitUpload += now_ms() - tw1;
@@ -334,9 +345,9 @@ static int stream_records(h10x_session *s, const char *path, uint64_t first, uin
   if (sharded ? h10x_shard_ingest_fqb(s->ctx, 0, 0, 1) : h10x_ingest_fqb(s->ctx, 0, 0, 1)) return fail_ctx(s);
   clock_gettime(CLOCK_MONOTONIC, &t3);
   if (getenv("H10X_INGEST_TIMING"))                                                    /* where a --readFQB spends its wall time */
-    fprintf(stderr, "  ingest of %.2f GB: buffers + image %.3f s, read + upload %.3f s (%.1f GB/s, %d readers%s; the calling thread waited %.3f s for readers, %.3f s for uploads), hashing + index %.3f s\n", (double)bytes / 1e9,
+    fprintf(stderr, "  ingest of %.2f GB: buffers + image %.3f s, read + upload %.3f s (%.1f GB/s, %d readers%s; the calling thread waited %.3f s for readers, %.3f s for uploads, queued uploads for %.3f s), hashing + index %.3f s\n", (double)bytes / 1e9,
             (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec), (double)(t2.tv_sec - t1.tv_sec) + 1e-9 * (double)(t2.tv_nsec - t1.tv_nsec),
-            (double)bytes / 1e9 / ((double)(t2.tv_sec - t1.tv_sec) + 1e-9 * (double)(t2.tv_nsec - t1.tv_nsec) + 1e-9), nTh, mapLen ? " on a mapping" : ", pread", waitRead * 1e-3, waitUpload * 1e-3, (double)(t3.tv_sec - t2.tv_sec) + 1e-9 * (double)(t3.tv_nsec - t2.tv_nsec));
+            (double)bytes / 1e9 / ((double)(t2.tv_sec - t1.tv_sec) + 1e-9 * (double)(t2.tv_nsec - t1.tv_nsec) + 1e-9), nTh, mapLen ? " on a mapping" : ", pread", waitRead * 1e-3, waitUpload * 1e-3, inCalls * 1e-3, (double)(t3.tv_sec - t2.tv_sec) + 1e-9 * (double)(t3.tv_nsec - t2.tv_nsec));
   return 0;
 }
 static int file_records(h10x_session *s, const char *path, uint64_t *n, int *cutByN) {

@@ -47,6 +47,26 @@ int main(int argc, char **argv) {
     const double dt = now() - t0; stop = true; u.join(); close(fd);
     printf("16 readers into page-locked slabs: %5.1f GB/s  WHILE  uploads of other slabs: %5.1f GB/s   (%.3f s)\n", (double)FILEB / dt / 1e9, up * (double)SLAB / dt / 1e9, dt);
   }
+  {                                                          // the ingest's own pattern: a FRESH 24 GB device image filled slab by slab, an event per slab, the previous slab's event waited for
+    const size_t IMG = (size_t)24 << 30; char *img; CK(hipMalloc((void **)&img, IMG));
+    hipEvent_t ev[NS]; for (size_t k = 0; k < NS; ++k) CK(hipEventCreateWithFlags(&ev[k], hipEventDisableTiming));
+    for (int pattern = 0; pattern < 3; ++pattern) {
+      const double t0 = now(); double tCall = 0, tWait = 0;
+      const size_t n = IMG / SLAB;
+      for (size_t k = 0; k < n; ++k) {
+        const double a = now();
+        CK(hipMemcpyAsync(img + k * SLAB, slab[k % NS], SLAB, hipMemcpyHostToDevice, st));
+        if (pattern >= 1) CK(hipEventRecord(ev[k % NS], st));
+        const double b = now(); tCall += b - a;
+        if (pattern == 2 && k >= 1) CK(hipEventSynchronize(ev[(k - 1) % NS]));
+        tWait += now() - b;
+      }
+      CK(hipStreamSynchronize(st));
+      const double dt = now() - t0;
+      printf("24 GB image, %-58s %.3f s = %5.1f GB/s (in the calls %.3f s, in the waits %.3f s)\n", pattern == 0 ? "back-to-back async copies, one sync at the end:" : pattern == 1 ? "+ an event recorded behind every copy:" : "+ the previous copy's event waited for (the ingest's loop):", dt, (double)IMG / dt / 1e9, tCall, tWait); fflush(stdout);
+    }
+    CK(hipFree(img));
+  }
   unlink(path);
   return 0;
 }
