@@ -218,7 +218,6 @@ enum { IN_PIECE = 4 << 20, IN_SLAB = ((64 << 20) / 120 / 30) * 120 * 30, IN_NSLA
 typedef struct {
   int fd; uint64_t base, bytes;                       /* the byte range of the file to read */
   const char *map;                                    /* the whole file mapped (MAP_SHARED), or 0: pread */
-  int populate;                                       /* madvise(MADV_POPULATE_READ) a piece before it is copied */
   uint64_t nSlabs, piecesPerSlab;
   int S;                                              /* slabs in use: slab k lives in slot k % S */
   char *slab[IN_NSLAB];
@@ -247,13 +246,12 @@ static void *inpipe_reader(void *a) {
       char *dst = q->slab[k % (uint64_t)q->S] + off;
       if (q->map) {
         const char *src = q->map + q->base + k * IN_SLAB + off;
-#ifdef MADV_POPULATE_READ
-        if (q->populate) {                              /* the piece's pages into this process's page tables in ONE call: a fault per 16 pages (2 M faults/s over the pool) otherwise — see stream_records */
-          const uintptr_t a = (uintptr_t)src & ~(uintptr_t)4095, e = ((uintptr_t)src + len + 4095) & ~(uintptr_t)4095;
-          (void)madvise((void *)a, (size_t)(e - a), MADV_POPULATE_READ);
-        }
-#endif
         memcpy(dst, src, len); got = len;
+        /* the piece's pages out of this process's page tables again, here, by the thread that brought them in: unmapping the whole 24 GB mapping at the end took
+           0.8 s of the calling thread's time (6 M page-table entries, one thread); MADV_DONTNEED on a shared mapping drops the entries, not the file's pages, under the
+           shared side of the address-space lock — sixteen threads do it side by side (whole pages inside the piece only: a neighbour may still want the edges) */
+        const uintptr_t a = ((uintptr_t)src + 4095) & ~(uintptr_t)4095, e = ((uintptr_t)src + len) & ~(uintptr_t)4095;
+        if (e > a) (void)madvise((void *)a, (size_t)(e - a), MADV_DONTNEED);
       }
       while (got < len) { const ssize_t r = pread(q->fd, dst + got, len - got, (off_t)(q->base + k * IN_SLAB + off + got)); if (r <= 0) break; got += (uint64_t)r; }
       ok = got == len;
@@ -277,13 +275,13 @@ static int stream_records(h10x_session *s, const char *path, uint64_t first, uin
   q.fd = open(path, O_RDONLY); q.base = first * 120; q.bytes = bytes;
   /* The readers copy out of a MAP_SHARED mapping of the file rather than pread it: the FIRST read of a file fresh in memory-backed storage goes through the page cache's LRU
      lists under a lock when it is a read() — 16 threads: 15.3 GB/s the first time, 150-250 the second (scratch/r6_read_existing.c, profiles/r6n_read_existing.log,
-     r6o_read_mmap.log) — and at 146 GB/s through a mapping. pread where the file cannot be mapped (a pipe, a special file), or H10X_NO_MMAP is set. */
+     r6o_read_mmap.log) — and at 146 GB/s through a mapping (MADV_POPULATE_READ first: as slow as the read()). pread where the file cannot be mapped (a pipe, a special file), or H10X_NO_MMAP is set. */
   size_t mapLen = 0;
   if (q.fd >= 0 && bytes && !getenv("H10X_NO_MMAP")) {
     struct stat sb;
     if (fstat(q.fd, &sb) == 0 && S_ISREG(sb.st_mode) && (uint64_t)sb.st_size >= q.base + bytes) {
       void *m = mmap(0, (size_t)(q.base + bytes), PROT_READ, MAP_SHARED, q.fd, 0);
-      if (m != MAP_FAILED) { q.map = (const char *)m; mapLen = (size_t)(q.base + bytes); q.populate = !getenv("H10X_NO_POPULATE"); }
+      if (m != MAP_FAILED) { q.map = (const char *)m; mapLen = (size_t)(q.base + bytes); }
     }
   }
   q.nSlabs = (bytes + IN_SLAB - 1) / IN_SLAB; q.piecesPerSlab = (IN_SLAB + IN_PIECE - 1) / IN_PIECE;
