@@ -247,11 +247,6 @@ static void *inpipe_reader(void *a) {
       if (q->map) {
         const char *src = q->map + q->base + k * IN_SLAB + off;
         memcpy(dst, src, len); got = len;
-        /* the piece's pages out of this process's page tables again, here, by the thread that brought them in: unmapping the whole 24 GB mapping at the end took
-           0.8 s of the calling thread's time (6 M page-table entries, one thread); MADV_DONTNEED on a shared mapping drops the entries, not the file's pages, under the
-           shared side of the address-space lock — sixteen threads do it side by side (whole pages inside the piece only: a neighbour may still want the edges) */
-        const uintptr_t a = ((uintptr_t)src + 4095) & ~(uintptr_t)4095, e = ((uintptr_t)src + len) & ~(uintptr_t)4095;
-        if (e > a) (void)madvise((void *)a, (size_t)(e - a), MADV_DONTNEED);
       }
       while (got < len) { const ssize_t r = pread(q->fd, dst + got, len - got, (off_t)(q->base + k * IN_SLAB + off + got)); if (r <= 0) break; got += (uint64_t)r; }
       ok = got == len;
@@ -263,6 +258,8 @@ static void *inpipe_reader(void *a) {
     pthread_mutex_unlock(&q->mu);
   }
 }
+typedef struct { void *p; size_t n; } UnmapJob;
+static void *unmap_job(void *a) { UnmapJob *u = (UnmapJob *)a; munmap(u->p, u->n); free(u); return 0; }
 static void *warm_job(void *a) { (void)h10x_warm(*(int *)a); return 0; }           /* a failure here shows up in the first command proper */
 static int stream_records(h10x_session *s, const char *path, uint64_t first, uint64_t n, int sharded) {
   int rc = 0;
@@ -333,7 +330,14 @@ static int stream_records(h10x_session *s, const char *path, uint64_t first, uin
     for (int i = 0; i < nTh; ++i) pthread_join(th[i], 0);
     pthread_mutex_destroy(&q.mu); pthread_cond_destroy(&q.cv);
   }
-  if (q.map) munmap((void *)q.map, mapLen);
+  /* the mapping goes away on a thread of its own, beside the hashing and the commands that follow: unmapping 24 GB is 6 M page-table entries, 0.8 s of one thread
+     (dropping them piece by piece from the reader threads — MADV_DONTNEED — made the readers as slow as read(): the per-page cost is the kernel's either way) */
+  if (q.map) {
+    UnmapJob *u = (UnmapJob *)malloc(sizeof *u); pthread_t ut;
+    if (u) { u->p = (void *)q.map; u->n = mapLen; }
+    if (!u || pthread_create(&ut, 0, unmap_job, u) != 0) { munmap((void *)q.map, mapLen); free(u); }
+    else pthread_detach(ut);
+  }
   if (q.fd >= 0) close(q.fd);
   if (pinned) { for (int k = 0; k < IN_NSLAB; ++k) { if (q.slab[k]) h10x_ingest_wait(s->ctx, k); h10x_pinned_free(q.slab[k]); } } else free(q.slab[0]);
   if (warming) pthread_join(warmTh, 0);
