@@ -260,13 +260,26 @@ static void *inpipe_reader(void *a) {
 }
 typedef struct { void *p; size_t n; } UnmapJob;
 static void *unmap_job(void *a) { UnmapJob *u = (UnmapJob *)a; munmap(u->p, u->n); free(u); return 0; }
+/* The device code loads on a thread of its own (h10x_warm: HIP loads a translation unit's code object on first use, ~1.2 s for the library's 50 MB — with the file read
+   at PCIe speed that, not the read, is what a --readFQB of a cached file waits for). Started as early as the device is known — the CLI calls h10x_host_warm_start at
+   process start when a reading command is on its line —, once per process and device (ranks may be threads); joined where the first kernels are about to run. */
+static int warmDevs[64]; static pthread_t warmThreads[64]; static volatile int warmState[64];   /* 0 not started, 1 running, 2 joined */
 static void *warm_job(void *a) { (void)h10x_warm(*(int *)a); return 0; }           /* a failure here shows up in the first command proper */
+void h10x_host_warm_start(int device) {
+  if (device < 0 || device >= 64 || getenv("H10X_NOWARM")) return;
+  if (__sync_lock_test_and_set(&warmState[device], 1)) return;
+  warmDevs[device] = device;
+  if (pthread_create(&warmThreads[device], 0, warm_job, &warmDevs[device]) != 0) warmState[device] = 2;
+}
+static void warm_join(int device) {
+  if (device < 0 || device >= 64) return;
+  if (__sync_bool_compare_and_swap(&warmState[device], 1, 3)) { pthread_join(warmThreads[device], 0); warmState[device] = 2; }
+  else while (warmState[device] == 3) usleep(200);                                  /* another rank's thread is joining it */
+}
 static int stream_records(h10x_session *s, const char *path, uint64_t first, uint64_t n, int sharded) {
   int rc = 0;
   struct timespec t0, t1, t2, t3; clock_gettime(CLOCK_MONOTONIC, &t0);
-  static int warmed[64];                                                              /* the device code loads while the file is read (once per process and device; ranks may be threads) */
-  pthread_t warmTh; int warmDev = s->device;
-  const int warming = warmDev >= 0 && warmDev < 64 && !getenv("H10X_NOWARM") && !__sync_lock_test_and_set(&warmed[warmDev], 1) && pthread_create(&warmTh, 0, warm_job, &warmDev) == 0;
+  h10x_host_warm_start(s->device);                                                   /* (no-op if the CLI started it at process start) */
   const uint64_t bytes = n * 120;
   InPipe q; memset(&q, 0, sizeof q);
   q.fd = open(path, O_RDONLY); q.base = first * 120; q.bytes = bytes;
@@ -340,7 +353,7 @@ static int stream_records(h10x_session *s, const char *path, uint64_t first, uin
   }
   if (q.fd >= 0) close(q.fd);
   if (pinned) { for (int k = 0; k < IN_NSLAB; ++k) { if (q.slab[k]) h10x_ingest_wait(s->ctx, k); h10x_pinned_free(q.slab[k]); } } else free(q.slab[0]);
-  if (warming) pthread_join(warmTh, 0);
+  warm_join(s->device);
   if (sharded) { int allOk = 0; if (h10x_shard_agree(s->ctx, !rc, &allOk)) return fail_ctx(s); if (!allOk && !rc) rc = fail(s, "another rank failed to read its part of %s", path); }
   if (rc) { h10x_ingest_reserve(s->ctx, 0); return rc; }
   clock_gettime(CLOCK_MONOTONIC, &t2);

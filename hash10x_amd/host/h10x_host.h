@@ -87,6 +87,8 @@ int  h10x_host_partition(const uint32_t *records, uint64_t nRecords, int nParts,
 /* the same cuts for the first nRecords records of a file, reading only the barcode words around each cut */
 int  h10x_host_partition_file(const char *path, uint64_t nRecords, int nParts, uint64_t *cut, char *err, int errlen);
 
+/* starts loading the library's device code for `device` on a thread of its own (once per process and device; --readFQB joins it before its first kernels) */
+void h10x_host_warm_start(int device);
 #ifdef __cplusplus
 }
 #endif
