@@ -267,7 +267,7 @@ static int warmDevs[64]; static pthread_t warmThreads[64]; static volatile int w
 static void *warm_job(void *a) { (void)h10x_warm(*(int *)a); return 0; }           /* a failure here shows up in the first command proper */
 void h10x_host_warm_start(int device) {
   if (device < 0 || device >= 64 || getenv("H10X_NOWARM")) return;
-  if (__sync_lock_test_and_set(&warmState[device], 1)) return;
+  if (!__sync_bool_compare_and_swap(&warmState[device], 0, 1)) return;              /* (started before — running or long joined: a swap that stored 1 over "joined" sent a second --readFQB of the process into joining a dead thread) */
   warmDevs[device] = device;
   if (pthread_create(&warmThreads[device], 0, warm_job, &warmDevs[device]) != 0) warmState[device] = 2;
 }
