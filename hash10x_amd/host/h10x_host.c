@@ -353,16 +353,16 @@ static int stream_records(h10x_session *s, const char *path, uint64_t first, uin
   }
   if (q.fd >= 0) close(q.fd);
   if (pinned) { for (int k = 0; k < IN_NSLAB; ++k) { if (q.slab[k]) h10x_ingest_wait(s->ctx, k); h10x_pinned_free(q.slab[k]); } } else free(q.slab[0]);
-  warm_join(s->device);
+  const double tj0 = now_ms(); warm_join(s->device); const double waitWarm = now_ms() - tj0;
   if (sharded) { int allOk = 0; if (h10x_shard_agree(s->ctx, !rc, &allOk)) return fail_ctx(s); if (!allOk && !rc) rc = fail(s, "another rank failed to read its part of %s", path); }
   if (rc) { h10x_ingest_reserve(s->ctx, 0); return rc; }
   clock_gettime(CLOCK_MONOTONIC, &t2);
   if (sharded ? h10x_shard_ingest_fqb(s->ctx, 0, 0, 1) : h10x_ingest_fqb(s->ctx, 0, 0, 1)) return fail_ctx(s);
   clock_gettime(CLOCK_MONOTONIC, &t3);
   if (getenv("H10X_INGEST_TIMING"))                                                    /* where a --readFQB spends its wall time */
-    fprintf(stderr, "  ingest of %.2f GB: buffers + image %.3f s, read + upload %.3f s (%.1f GB/s, %d readers%s; the calling thread waited %.3f s for readers, %.3f s for uploads, queued uploads for %.3f s), hashing + index %.3f s\n", (double)bytes / 1e9,
+    fprintf(stderr, "  ingest of %.2f GB: buffers + image %.3f s, read + upload %.3f s (%.1f GB/s, %d readers%s; the calling thread waited %.3f s for readers, %.3f s for uploads, queued uploads for %.3f s, waited %.3f s for the device code to load), hashing + index %.3f s\n", (double)bytes / 1e9,
             (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec), (double)(t2.tv_sec - t1.tv_sec) + 1e-9 * (double)(t2.tv_nsec - t1.tv_nsec),
-            (double)bytes / 1e9 / ((double)(t2.tv_sec - t1.tv_sec) + 1e-9 * (double)(t2.tv_nsec - t1.tv_nsec) + 1e-9), nTh, mapLen ? " on a mapping" : ", pread", waitRead * 1e-3, waitUpload * 1e-3, inCalls * 1e-3, (double)(t3.tv_sec - t2.tv_sec) + 1e-9 * (double)(t3.tv_nsec - t2.tv_nsec));
+            (double)bytes / 1e9 / ((double)(t2.tv_sec - t1.tv_sec) + 1e-9 * (double)(t2.tv_nsec - t1.tv_nsec) + 1e-9), nTh, mapLen ? " on a mapping" : ", pread", waitRead * 1e-3, waitUpload * 1e-3, inCalls * 1e-3, waitWarm * 1e-3, (double)(t3.tv_sec - t2.tv_sec) + 1e-9 * (double)(t3.tv_nsec - t2.tv_nsec));
   return 0;
 }
 static int file_records(h10x_session *s, const char *path, uint64_t *n, int *cutByN) {
