@@ -389,7 +389,7 @@ def cpu_baseline(wl, recs, workdir, gpu_hash_path):
             cli_same = open(os.path.join(workdir, "cli.hash"), "rb").read() == gpu_canon
             os.remove(os.path.join(workdir, "cli.hash"))
             e2e = {"command": "hash10x-amd -B %d --readFQB bench.fqb --hashDepthRange %d %d --cluster 1 0 --writeHash cli.hash" % (wl["B"], wl["lo"], wl["hi"]),
-                   "wall_seconds": best, "read_pairs_per_s": pairs / best, "includes": "process start, HIP context, file read (page cache, 4 reader threads) beside H2D from three 16 MiB page-locked slabs, all kernels, D2H + file write of the .hash",
+                   "wall_seconds": best, "read_pairs_per_s": pairs / best, "includes": "process start, HIP context, file read (page cache: 16 reader threads on a mapping) beside H2D from six 64 MiB page-locked slabs, all kernels, D2H + file write of the .hash",
                    "per_command_wall_seconds": walls, "reference_two_processes_wall_seconds": w_read + w_clu, "speedup_vs_reference_1thread": (w_read + w_clu) / best,
                    "reference_omp_wall_seconds": (o_read + o_clu) if omp else None, "hash_identical_to_library_path": cli_same}
         one["end_to_end"] = e2e
@@ -429,8 +429,14 @@ def full_config3_block(hash10x_amd, local_rank, steps=3):
     up_s = time.perf_counter() - t0
     pairs = recs.size // 30
     e2e = None
-    try:
+    try:                                                     # twice: the first run of the program on a box also pages in the libraries and the device code (6.3-7.9 s); the second is what a user sees from then on
+        first = cli_end_to_end(recs, case["B"], 30, 100, 5, expect_sha256=case["sha256"], expect_size=case["size"])
         e2e = cli_end_to_end(recs, case["B"], 30, 100, 5, expect_sha256=case["sha256"], expect_size=case["size"])
+        if isinstance(first, dict) and isinstance(e2e, dict) and "wall_seconds" in first and "wall_seconds" in e2e:
+            e2e["first_run_wall_seconds"] = first["wall_seconds"]
+            e2e["hash_identical_to_reference"] = bool(first.get("hash_identical_to_reference")) and bool(e2e.get("hash_identical_to_reference"))
+            if first["wall_seconds"] < e2e["wall_seconds"]:
+                first["first_run_wall_seconds"] = first["wall_seconds"]; first["hash_identical_to_reference"] = e2e["hash_identical_to_reference"]; e2e = first
     except Exception as e:
         e2e = {"error": str(e)[:300]}
     del recs
