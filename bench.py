@@ -914,7 +914,7 @@ def headline(out, detail_file="bench_detail.json"):
     if isinstance(fc, dict):
         e = fc.get("end_to_end") if isinstance(fc.get("end_to_end"), dict) else {}
         s["full_config3"] = ({"ms_per_step": fc.get("ms_per_step"), "read_pairs_per_s": fc.get("read_pairs_per_s"), "sizes_match_reference": fc.get("sizes_match_reference"),
-                              "end_to_end": {"wall_seconds": e.get("wall_seconds"), "per_command_wall_seconds": e.get("per_command_wall_seconds"),
+                              "end_to_end": {"wall_seconds": e.get("wall_seconds"), "first_run_wall_seconds": e.get("first_run_wall_seconds"), "per_command_wall_seconds": e.get("per_command_wall_seconds"),
                                              "hash_identical_to_reference": e.get("hash_identical_to_reference"), "error": (e.get("error") or e.get("skipped"))}}
                              if "ms_per_step" in fc else {"skipped": str(fc.get("skipped") or fc.get("error"))[:160]})
     g3 = out.get("genome3g")
