@@ -261,8 +261,9 @@ static void *inpipe_reader(void *a) {
 typedef struct { void *p; size_t n; } UnmapJob;
 static void *unmap_job(void *a) { UnmapJob *u = (UnmapJob *)a; munmap(u->p, u->n); free(u); return 0; }
 /* The device code loads on a thread of its own (h10x_warm: HIP loads a translation unit's code object on first use, ~1.2 s for the library's 50 MB — with the file read
-   at PCIe speed that, not the read, is what a --readFQB of a cached file waits for). Started as early as the device is known — the CLI calls h10x_host_warm_start at process start when a reading command is on its line —, once per process and
-   device (ranks may be threads); joined where the first kernels are about to run. */
+   at PCIe speed that, not the read, is what a --readFQB of a cached file waits for). Started when --readFQB has validated its parameters and has its context, once per process and device (ranks may be threads); joined where the first kernels are about
+   to run. (Not at process start: a die() — exit(-1), hash10x.c's way — while that thread is inside the runtime's initialisation ends in the allocator's abort
+   instead of exit code 255: test_cli_matches_reference_commands_and_reports, round 6; and it bought nothing measurable.) */
 static int warmDevs[64]; static pthread_t warmThreads[64]; static volatile int warmState[64];   /* 0 not started, 1 running, 2 joined */
 static void *warm_job(void *a) { (void)h10x_warm(*(int *)a); return 0; }           /* a failure here shows up in the first command proper */
 void h10x_host_warm_start(int device) {

@@ -277,12 +277,6 @@ int main(int argc, char **argv) {
   timeUpdate(stdout, 0);
   if (!(team.s[0] = h10x_session_new())) die("out of memory");
   if (!argc) usage();
-  {                                                          /* a line that reads records: the device code starts loading now, beside the context's creation and the file read
-                                                                (device 0 unless --device / --gpus say otherwise: those lines start it when --readFQB comes) */
-    int reads = 0, plain = 1;
-    for (int i = 0; i < argc; ++i) { if (!strcmp(argv[i], "--readFQB")) reads = 1; if (!strcmp(argv[i], "--device") || !strcmp(argv[i], "--gpus")) plain = 0; }
-    if (reads && plain) h10x_host_warm_start(0);
-  }
 
   while (argc) {
     if (**argv != '-') die("option/command %s does not start with '-': run without arguments for usage", *argv);
