@@ -48,8 +48,8 @@ h10x_session *h10x_session_new(void) {
   if (!s) return 0;
   s->k = 21; s->w = 31; s->r = 17; s->B = 28; s->N = 0; s->chunk = 100000; s->ct = 5; s->device = 0;
   for (int i = 0; i < N_KNOBS; ++i)                    /* by name: the table above may be reordered */
-    if (!strcmp(knobName[i], "shard_delta_lists") || !strcmp(knobName[i], "shard_row_shift") || !strcmp(knobName[i], "cluster_tr_packed") || !strcmp(knobName[i], "cluster_tr_class_t")) s->knob[i] = -1;
-    else if (!strcmp(knobName[i], "shard_overlap")) s->knob[i] = 1;   /* delta-coded list exchange when there is more than one rank; list alignment as small as the offsets allow */
+    if (!strcmp(knobName[i], "shard_delta_lists") || !strcmp(knobName[i], "shard_row_shift") || !strcmp(knobName[i], "cluster_tr_packed") || !strcmp(knobName[i], "cluster_tr_class_t")) s->knob[i] = -1;   /* delta-coded list exchange when there is more than one rank; list alignment as small as the offsets allow */
+    else if (!strcmp(knobName[i], "shard_overlap")) s->knob[i] = 1;   /* exchanges beside compute */
   s->blocksDim = 1200;                                 /* arrayCreate(1200, ClusterBlock), hash10x.c:1151 */
   return s;
 }
@@ -210,8 +210,8 @@ int h10x_session_readFQB_dev(h10x_session *s, const uint32_t *devRec, uint64_t n
    time: the file never sits in host memory, and the closing call is the --readFQB itself (collective when sharded). A rank that fails
    here while sharded still makes the closing call's counterpart impossible for the others, so the verdict is agreed on first. */
 /* ---- --readFQB's fread loop (hash10x.c:202-209) as a pipeline of page-locked slabs, round 6. What scratch/r6_io_rate.c measured on a GPU box's memory-backed storage
-   (profiles/r6g_io_rate.log): one pread copies out of the page cache at 9.5 GB/s, sixteen at 136 GB/s — reads scale, and PCIe takes ~55 GB/s — so the file is read by a
-   pool of READERS persistent threads, PIECE bytes at a time, into NSLAB slabs of SLAB bytes; the calling thread alone talks to the library (the C ABI is single-threaded):
+   (profiles/r6g_io_rate.log): one thread copies out of the page cache at 9.5 GB/s, sixteen at 136 GB/s — reads scale, and PCIe takes ~55 GB/s — so the file is read by a
+   pool of READERS persistent threads, PIECE bytes at a time (out of a mapping of the file: see stream_records), into NSLAB slabs of SLAB bytes; the calling thread alone talks to the library (the C ABI is single-threaded):
    it queues a slab's upload (h10x_ingest_fqb_async, in file order) as soon as all its pieces are in, and hands a slab back to the readers when its upload has landed.
    Round 5 read 16 MiB slabs on 4 threads created and joined per slab, one slab at a time: 5.2 GB/s, 4.6 s of the 9.5 s configs[2] needs end to end. */
 enum { IN_PIECE = 4 << 20, IN_SLAB = ((64 << 20) / 120 / 30) * 120 * 30, IN_NSLAB = 6, IN_MAXREADERS = 32 };   /* whole records per slab */
@@ -280,13 +280,14 @@ static void warm_join(int device) {
 static int stream_records(h10x_session *s, const char *path, uint64_t first, uint64_t n, int sharded) {
   int rc = 0;
   struct timespec t0, t1, t2, t3; clock_gettime(CLOCK_MONOTONIC, &t0);
-  h10x_host_warm_start(s->device);                                                   /* (no-op if the CLI started it at process start) */
+  h10x_host_warm_start(s->device);                                                   /* (once per process and device) */
   const uint64_t bytes = n * 120;
   InPipe q; memset(&q, 0, sizeof q);
   q.fd = open(path, O_RDONLY); q.base = first * 120; q.bytes = bytes;
   /* The readers copy out of a MAP_SHARED mapping of the file rather than pread it: the FIRST read of a file fresh in memory-backed storage goes through the page cache's LRU
      lists under a lock when it is a read() — 16 threads: 15.3 GB/s the first time, 150-250 the second (scratch/r6_read_existing.c, profiles/r6n_read_existing.log,
-     r6o_read_mmap.log) — and at 146 GB/s through a mapping (MADV_POPULATE_READ first: as slow as the read()). pread where the file cannot be mapped (a pipe, a special file), or H10X_NO_MMAP is set. */
+     r6o_read_mmap.log) — and at 146 GB/s through a mapping (MADV_POPULATE_READ first: as slow as the read()). pread where the file cannot be mapped (a pipe, a special file), or H10X_NO_MMAP is set.
+     (A file that shrinks under the mapping ends in SIGBUS where read() would have come back short: the reference's fread loop dies on a short file either way.) */
   size_t mapLen = 0;
   if (q.fd >= 0 && bytes && !getenv("H10X_NO_MMAP")) {
     struct stat sb;
