@@ -522,6 +522,21 @@ def test_sharded_exchanges_beside_compute(workdir, overlap):
             assert b["entries_to_hash_owners"] is None and b["indices_back"] is None
 
 
+def test_sharded_blocks_too_large_for_a_workgroup_sort(workdir):
+    """Sharded --readFQB where a block holds more entries than a workgroup sorts in LDS (BLOCK_SORT_MAX = 8192): the ClusterHash records then take the device-wide path, fed by
+    reply_key_kernel (the owners' replies gathered into keys) instead of the block kernel's own gather. 12 barcodes of 5000 read pairs on 3 ranks and on 1, byte-equal to the oracle."""
+    recs = orc.gen_fqb(workdir.file("x.fqb"), 60000, 12, 400000, 0.003, 71, 4.0, 150, 6000)
+    o = orc.Oracle(B=21)
+    o.read_fqb(recs); o.depth_range(2, 12); o.cluster(1, 0, 3)
+    o.write_hash(workdir.file("orc.hash"))
+    exp = open(workdir.file("orc.hash"), "rb").read()
+    assert orc.HashFile(exp).blocks["nHash"].max() > 8192
+    for nranks in (3, 1):
+        _run_sharded(recs, nranks, 21, 2, 12, 3, workdir.file("hip.hash"))
+        got = open(workdir.file("hip.hash"), "rb").read()
+        assert got == exp, orc.describe_diff(got, exp)
+
+
 def test_gather_then_continue_on_one_gpu(workdir):
     """h10x_shard_gather leaves rank 0 a complete single-GPU context: its barcode lists are rebuilt, so a new depth range and
     another clustering on rank 0 alone give what one GPU gives from the start (the lists used to be stale)."""
