@@ -524,15 +524,15 @@ def test_sharded_exchanges_beside_compute(workdir, overlap):
 
 def test_sharded_blocks_too_large_for_a_workgroup_sort(workdir):
     """Sharded --readFQB where a block holds more entries than a workgroup sorts in LDS (BLOCK_SORT_MAX = 8192): the ClusterHash records then take the device-wide path, fed by
-    reply_key_kernel (the owners' replies gathered into keys) instead of the block kernel's own gather. 12 barcodes of 5000 read pairs on 3 ranks and on 1, byte-equal to the oracle."""
-    recs = orc.gen_fqb(workdir.file("x.fqb"), 60000, 12, 400000, 0.003, 71, 4.0, 150, 6000)
+    reply_key_kernel (the owners' replies gathered into keys) instead of the block kernel's own gather. 8 barcodes of 10 000 read pairs over 40 molecules each, on 3 ranks and on 1, byte-equal to the oracle."""
+    recs = orc.gen_fqb(workdir.file("x.fqb"), 80000, 8, 2000000, 0.003, 71, 40.0, 150, 10000)
     o = orc.Oracle(B=21)
-    o.read_fqb(recs); o.depth_range(2, 12); o.cluster(1, 0, 3)
+    o.read_fqb(recs); o.depth_range(2, 9); o.cluster(1, 0, 1)
     o.write_hash(workdir.file("orc.hash"))
     exp = open(workdir.file("orc.hash"), "rb").read()
-    assert orc.HashFile(exp).blocks["nHash"].max() > 8192
+    assert orc.HashFile(exp).blocks["nHash"].max() > 8192 and orc.HashFile(exp).blocks["nSubCluster"].sum() > 0
     for nranks in (3, 1):
-        _run_sharded(recs, nranks, 21, 2, 12, 3, workdir.file("hip.hash"))
+        _run_sharded(recs, nranks, 21, 2, 9, 1, workdir.file("hip.hash"))
         got = open(workdir.file("hip.hash"), "rb").read()
         assert got == exp, orc.describe_diff(got, exp)
 
