@@ -67,6 +67,14 @@ int main(int argc, char **argv) {
     }
     CK(hipFree(img));
   }
+  for (int pinnedSrc = 0; pinnedSrc < 2; ++pinnedSrc) {      // --writeHash's write stream: one pwrite stream into a NEW file, 64 MiB pieces, from ordinary / page-locked memory
+    char p2[600]; snprintf(p2, sizeof p2, "%s/r6_h2d_w.bin", dir); unlink(p2);
+    const int fd = open(p2, O_RDWR | O_CREAT | O_TRUNC, 0666); const size_t total = (size_t)8 << 30; if (ftruncate(fd, (off_t)total)) return 1;
+    const double t0 = now();
+    for (size_t at = 0; at < total; at += SLAB) if (pwrite(fd, (pinnedSrc ? slab : plain)[(at / SLAB) % 2], SLAB, (off_t)at) != (ssize_t)SLAB) { perror("pwrite"); return 1; }
+    const double dt = now() - t0; close(fd); unlink(p2);
+    printf("pwrite of a new 8 GB file, one stream, from %-28s %.3f s = %5.1f GB/s\n", pinnedSrc ? "page-locked memory:" : "ordinary memory:", dt, (double)total / dt / 1e9); fflush(stdout);
+  }
   unlink(path);
   return 0;
 }
