@@ -2432,7 +2432,10 @@ static int cluster_local_range(Ctx *c, int codeMin, int codeMax, int threshold, 
     // CUs when that ends first), and behind the main launch, on its stream, the whole-CU class is launched a SECOND time on the same work queue
     // (secondWind): workgroups for every CU, which find the queue empty — or the CUs the main launch has just left free. (Before this the main launch
     // was held to the CUs the split gave it once the whole-CU class had more than half of them: 890 ms instead of 570 on a set classified that way.)
-    const u32 cu2 = hmin<u32>((u32)c->numCU > 16 ? (u32)c->numCU - 8 : (u32)c->numCU - 1, hmax<u32>(1u, (u32)(share2 * c->numCU + 0.5) + 4u));
+    // (round 6: never fewer than an eighth of the CUs, 32 of 256, while the class has the blocks: where it is a side show — 2 169 blocks of the 3 Gb set, ~130 of a rank's
+    // eighth of it — five CUs made it a 2 ms tail whenever the two launches do not run side by side, e.g. when their streams share a hardware queue (seen with eight ranks'
+    // forty streams in one process: the rank's --cluster 19.5 instead of 17.4 ms); with 32 CUs it is done in 0.3 ms, and the main launch's workgroups take the CUs over)
+    const u32 cu2 = hmin<u32>((u32)c->numCU > 16 ? (u32)c->numCU - 8 : (u32)c->numCU - 1, hmax<u32>(hmax<u32>(1u, (u32)c->numCU / 8u), (u32)(share2 * c->numCU + 0.5) + 4u));
     gridOf[2] = hmin<u32>(hc[2], cu2);
     gridOf[0] = hmin<u32>(gridOf[0], 2 * (u32)c->numCU);
     secondWind = hc[2] > gridOf[2] ? hmin<u32>(hc[2] - gridOf[2], (u32)c->numCU) : 0u;
