@@ -214,9 +214,10 @@ int h10x_session_readFQB_dev(h10x_session *s, const uint32_t *devRec, uint64_t n
    pool of READERS persistent threads, PIECE bytes at a time (out of a mapping of the file: see stream_records), into NSLAB slabs of SLAB bytes; the calling thread alone talks to the library (the C ABI is single-threaded):
    it queues a slab's upload (h10x_ingest_fqb_async, in file order) as soon as all its pieces are in, and hands a slab back to the readers when its upload has landed.
    Round 5 read 16 MiB slabs on 4 threads created and joined per slab, one slab at a time: 5.2 GB/s, 4.6 s of the 9.5 s configs[2] needs end to end. */
-enum { IN_PIECE = 4 << 20, IN_SLAB = ((64 << 20) / 120 / 30) * 120 * 30, IN_NSLAB = 6, IN_MAXREADERS = 32 };   /* whole records per slab */
+enum { IN_PIECE = 4 << 20, IN_SLAB_DEFAULT = ((64 << 20) / 120 / 30) * 120 * 30, IN_NSLAB = 6, IN_MAXREADERS = 32 };   /* whole records per slab; H10X_SLAB_MIB (tests): slabs of that many MiB, so that small files cycle through the slots */
 typedef struct {
   int fd; uint64_t base, bytes;                       /* the byte range of the file to read */
+  uint64_t slabBytes;                                 /* bytes per slab: a whole number of 120-byte records */
   const char *map;                                    /* the whole file mapped (MAP_SHARED), or 0: pread */
   uint64_t nSlabs, piecesPerSlab;
   int S;                                              /* slabs in use: slab k lives in slot k % S */
@@ -227,7 +228,7 @@ typedef struct {
   uint32_t done[IN_NSLAB];                            /* pieces of the slab now in slot k that are in */
   int failed, stop;
 } InPipe;
-static uint64_t inpipe_slab_bytes(const InPipe *q, uint64_t k) { const uint64_t at = k * IN_SLAB; return q->bytes - at < IN_SLAB ? q->bytes - at : IN_SLAB; }
+static uint64_t inpipe_slab_bytes(const InPipe *q, uint64_t k) { const uint64_t at = k * q->slabBytes; return q->bytes - at < q->slabBytes ? q->bytes - at : q->slabBytes; }
 static void *inpipe_reader(void *a) {
   InPipe *q = (InPipe *)a;
   for (;;) {
@@ -245,10 +246,10 @@ static void *inpipe_reader(void *a) {
       const uint64_t len = slabBytes - off < IN_PIECE ? slabBytes - off : IN_PIECE; uint64_t got = 0;
       char *dst = q->slab[k % (uint64_t)q->S] + off;
       if (q->map) {
-        const char *src = q->map + q->base + k * IN_SLAB + off;
+        const char *src = q->map + q->base + k * q->slabBytes + off;
         memcpy(dst, src, len); got = len;
       }
-      while (got < len) { const ssize_t r = pread(q->fd, dst + got, len - got, (off_t)(q->base + k * IN_SLAB + off + got)); if (r <= 0) break; got += (uint64_t)r; }
+      while (got < len) { const ssize_t r = pread(q->fd, dst + got, len - got, (off_t)(q->base + k * q->slabBytes + off + got)); if (r <= 0) break; got += (uint64_t)r; }
       ok = got == len;
     }
     pthread_mutex_lock(&q->mu);
@@ -296,14 +297,16 @@ static int stream_records(h10x_session *s, const char *path, uint64_t first, uin
       if (m != MAP_FAILED) { q.map = (const char *)m; mapLen = (size_t)(q.base + bytes); }
     }
   }
-  q.nSlabs = (bytes + IN_SLAB - 1) / IN_SLAB; q.piecesPerSlab = (IN_SLAB + IN_PIECE - 1) / IN_PIECE;
+  { const char *e = getenv("H10X_SLAB_MIB"); const long mib = e ? atol(e) : 0; q.slabBytes = mib >= 1 && mib <= 1024 ? ((uint64_t)mib << 20) / 3600 * 3600 : (uint64_t)IN_SLAB_DEFAULT; }
+  const uint64_t SLABB = q.slabBytes;
+  q.nSlabs = (bytes + SLABB - 1) / SLABB; q.piecesPerSlab = (SLABB + IN_PIECE - 1) / IN_PIECE;
   const int nSlabBuf = q.nSlabs < IN_NSLAB ? (int)(q.nSlabs ? q.nSlabs : 1) : IN_NSLAB;
   int pinned = 1;
-  for (int k = 0; k < nSlabBuf && pinned; ++k) if (!(q.slab[k] = (char *)h10x_pinned_alloc(bytes < IN_SLAB ? (bytes ? bytes : 1) : IN_SLAB))) pinned = 0;
-  if (!pinned) { for (int k = 0; k < IN_NSLAB; ++k) { h10x_pinned_free(q.slab[k]); q.slab[k] = 0; } q.slab[0] = (char *)malloc(bytes < IN_SLAB ? (bytes ? bytes : 1) : IN_SLAB); }
+  for (int k = 0; k < nSlabBuf && pinned; ++k) if (!(q.slab[k] = (char *)h10x_pinned_alloc(bytes < SLABB ? (bytes ? bytes : 1) : SLABB))) pinned = 0;
+  if (!pinned) { for (int k = 0; k < IN_NSLAB; ++k) { h10x_pinned_free(q.slab[k]); q.slab[k] = 0; } q.slab[0] = (char *)malloc(bytes < SLABB ? (bytes ? bytes : 1) : SLABB); }
   q.S = pinned ? nSlabBuf : 1;                                                        /* without page-locked memory: one slab, one synchronous copy at a time, as before */
   if (q.fd < 0) rc = fail(s, "failed to open fqb file %s", path);                     /* hash10x.c:1201 */
-  else if (!q.slab[0]) rc = fail(s, "out of memory for a %d MiB read buffer", IN_SLAB >> 20);
+  else if (!q.slab[0]) rc = fail(s, "out of memory for a %d MiB read buffer", (int)(SLABB >> 20));
   else if (h10x_ingest_reserve(s->ctx, n)) rc = fail_ctx(s);
   clock_gettime(CLOCK_MONOTONIC, &t1);
   pthread_t th[IN_MAXREADERS]; int nTh = 0; double waitRead = 0, waitUpload = 0, inCalls = 0;   /* ms the calling thread waited for the readers / for uploads to land / spent queueing uploads */

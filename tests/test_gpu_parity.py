@@ -1221,10 +1221,10 @@ def test_bench_strong_scaling_on_one_fixed_set(workdir, world):
 
 
 def test_cli_streams_files_larger_than_one_slab(workdir):
-    """bin/hash10x-amd reads the .fqb in 16 MiB page-locked slabs through h10x_ingest_fqb_async (three in flight: the file read beside the
-    uploads): a file of several slabs (72 MB; a slab is a whole
-    number of 120-byte records, which a round-3 build got wrong — bench.py's end-to-end check caught it) gives the bytes of the library
-    path on the same records, on one GPU and on 2 shards (every shard's range larger or smaller than a slab)."""
+    """bin/hash10x-amd reads the .fqb on a pool of reader threads into six page-locked slabs (64 MiB each; here, through H10X_SLAB_MIB, 4 and 9 MiB so that a 72 MB file cycles
+    through the slots three times and slabs hold one and several 4 MiB pieces), out of a mapping of the file or by pread (H10X_NO_MMAP), with 16 readers or 3, uploads queued
+    in file order beside the reads (h10x_ingest_fqb_async): the bytes of the library path on the same records every time, on one GPU and on 2 shards (every shard's range
+    larger or smaller than a slab). A slab is a whole number of 120-byte records, which a round-3 build got wrong — bench.py's end-to-end check caught it."""
     import subprocess
     import hash10x_amd
     recs = orc.gen_fqb(workdir.file("x.fqb"), 600000, 2400, 3000000, 0.003, 77, 8.0, 150, 30000)
@@ -1232,12 +1232,12 @@ def test_cli_streams_files_larger_than_one_slab(workdir):
     h = hash10x_amd.Hash10x(B=22); h.read_fqb(recs.reshape(-1)); h.depth_range(10, 60); h.cluster(1, 0, 4); h.write_hash(workdir.file("lib.hash")); h.close()
     exp = open(workdir.file("lib.hash"), "rb").read()
     exe = os.path.join(orc.REPO, "bin", "hash10x-amd")
-    for gpus in (1, 2):
+    for gpus, extra in ((1, {}), (2, {}), (1, {"H10X_SLAB_MIB": "4"}), (2, {"H10X_SLAB_MIB": "9", "H10X_READERS": "3"}), (1, {"H10X_SLAB_MIB": "4", "H10X_NO_MMAP": "1"})):
         g = subprocess.run([exe] + (["--gpus", str(gpus)] if gpus > 1 else []) + ["-B", "22", "-ct", "4", "--readFQB", "x.fqb", "--hashDepthRange", "10", "60", "--cluster", "1", "0",
-                           "--writeHash", "cli.hash"], cwd=workdir.path, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+                           "--writeHash", "cli.hash"], cwd=workdir.path, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300, env=dict(os.environ, **extra))
         assert g.returncode == 0, g.stderr.decode()
         got = open(workdir.file("cli.hash"), "rb").read()
-        assert got == exp, "--gpus %d: %s" % (gpus, orc.describe_diff(got, exp))
+        assert got == exp, "--gpus %d %r: %s" % (gpus, extra, orc.describe_diff(got, exp))
 
 
 def test_streaming_ingest_at_the_c_abi(workdir):
